@@ -1,0 +1,432 @@
+"""Generate tests/golden/*.npz by running the REAL reference (phlippe/CategoricalNF) on seeded inputs.
+
+Runs only in the build container, where the reference is mounted read-only at /root/reference:
+
+    PYTHONPATH=/root/reference MPLBACKEND=Agg PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py
+
+The reference's own modules are imported and called (nothing of their source is copied); the
+coupling subnets are replaced by a stub that returns a pre-drawn ``nn_out`` so that the layer
+arithmetic is captured in isolation.  Each .npz holds, per case, the inputs, the parameters and the
+reference outputs plus a JSON ``meta`` entry describing the cases.  The fixtures are data only.
+"""
+import io
+import json
+import os
+import sys
+import contextlib
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+REF = os.environ.get("CNF_REFERENCE", "/root/reference")
+sys.path.insert(0, REF)
+os.environ.setdefault("MPLBACKEND", "Agg")
+
+with contextlib.redirect_stdout(io.StringIO()):
+    from layers.flows.coupling_layer import CouplingLayer
+    from layers.flows.mixture_cdf_layer import MixtureCDFCoupling
+    from layers.flows.autoregressive_coupling import AutoregressiveMixtureCDFCoupling
+    from layers.flows.activation_normalization import ActNormFlow, ExtActNormFlow
+    from layers.flows.permutation_layers import InvertibleConv
+    from layers.flows.distributions import LogisticDistribution
+    from layers.flows.sigmoid_layer import SigmoidFlow
+    from layers.flows.flow_model import FlowModel
+    from layers.categorical_encoding.linear_encoding import LinearCategoricalEncoding
+    from layers.categorical_encoding.variational_dequantization import VariationalDequantization
+    from general.mutils import create_channel_mask
+
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+
+
+class Inject(nn.Module):
+    """Stand-in coupling subnet: ignores its input and returns a fixed tensor."""
+
+    def __init__(self):
+        super().__init__()
+        self.value = None
+
+    def forward(self, x=None, **kwargs):
+        return self.value
+
+
+def npy(t):
+    return t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+
+
+def save(name, cases):
+    flat, meta = {}, []
+    for i, c in enumerate(cases):
+        m = dict(c.get("meta", {}))
+        m["keys"] = []
+        for k, v in c.items():
+            if k == "meta":
+                continue
+            flat["c%d_%s" % (i, k)] = npy(v)
+            m["keys"].append(k)
+        meta.append(m)
+    flat["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **flat)
+    print("%-28s %3d cases  %7.1f kB" % (name, len(cases), os.path.getsize(path) / 1e3))
+
+
+def lengths(B, N, g):
+    ln = torch.randint(max(1, N // 2), N + 1, (B,), generator=g)
+    ln[0] = N
+    return ln
+
+
+# ------------------------------------------------------------------------------------------
+def gen_affine():
+    cases = []
+    g = torch.Generator().manual_seed(42)
+    cfgs = [(4, 5, 2, "channel", 0), (3, 7, 4, "channel", 0), (5, 8, 6, "channel", 0),
+            (6, 16, 3, "channel", 0), (4, 5, 1, "chess", 0), (4, 6, 1, "chess", 1),
+            (64, 1, 4, "channel", 0), (2, 64, 6, "channel", 0), (3, 9, 5, "channel", 0)]
+    for (B, N, D, kind, flip) in cfgs:
+        if kind == "channel":
+            mask = CouplingLayer.create_channel_mask(D)
+        else:
+            mask = CouplingLayer.create_chess_mask()
+            if flip:
+                mask = 1 - mask
+        with contextlib.redirect_stdout(io.StringIO()):
+            layer = CouplingLayer(c_in=D, mask=mask, model_func=lambda c_out: Inject())
+        sf = 0.6 * torch.randn(D, generator=g)
+        layer.scaling_factor.data = sf.clone()
+        z = torch.randn(B, N, D, generator=g)
+        nn_out = 1.5 * torch.randn(B, N, 2 * D, generator=g)
+        layer.nn.value = nn_out
+        ldj_in = torch.randn(B, generator=g)
+        zf, lf = layer(z, ldj=ldj_in.clone(), reverse=False)
+        zr, lr = layer(zf, ldj=None, reverse=True)
+        s, t = CouplingLayer.get_coup_params(nn_out, layer._prepare_mask(mask, z), scaling_factor=sf)
+        s_raw, t_raw = CouplingLayer.get_coup_params(nn_out, layer._prepare_mask(mask, z), scaling_factor=None)
+        cases.append(dict(meta=dict(B=B, N=N, D=D, mask_kind=kind, flip=flip),
+                          z=z, nn_out=nn_out, scaling_factor=sf, mask=mask, ldj_in=ldj_in,
+                          z_fwd=zf, ldj_fwd=lf, z_rev=zr, ldj_rev=lr, s=s, t=t, s_nofac=s_raw, t_nofac=t_raw))
+    save("affine_coupling", cases)
+
+
+def gen_mixture():
+    cases = []
+    g = torch.Generator().manual_seed(43)
+    cfgs = [
+        # B, N, D, K, mask, reg_max, reg_factor, training, padded, tail_scale
+        (4, 6, 2, 4, "channel", -1, 1, True, False, 1.0),
+        (3, 16, 4, 8, "channel", -1, 1, False, False, 1.0),
+        (3, 9, 6, 16, "channel", 3.5, 2, True, True, 1.0),
+        (3, 9, 6, 16, "channel", 3.5, 2, False, True, 1.0),
+        (2, 11, 3, 51, "none", -1, 1, True, False, 1.0),
+        (4, 7, 1, 8, "chess", -1, 1, True, True, 1.0),
+        (4, 8, 4, 8, "channel", 3.5, 2, True, False, 8.0),
+        (4, 8, 4, 8, "channel", -1, 1, False, False, 8.0),
+        (2, 5, 2, 8, "channel", 3.5, 1, True, True, 3.0),
+        (5, 10, 3, 4, "channel", -1, 1, True, True, 1.0),
+    ]
+    for (B, N, D, K, kind, reg_max, reg_factor, training, padded, tail) in cfgs:
+        P = 2 + 3 * K
+        z = tail * torch.randn(B, N, D, generator=g)
+        nn_out = 0.8 * torch.randn(B, N, D * P, generator=g)
+        sf = 0.4 * torch.randn(D, generator=g)
+        msf = 0.4 * torch.randn(D, K, generator=g)
+        ln = lengths(B, N, g) if padded else None
+        pad = create_channel_mask(ln, max_len=N) if padded else None
+        meta = dict(B=B, N=N, D=D, K=K, mask_kind=kind, reg_max=reg_max, reg_factor=reg_factor,
+                    training=training, padded=padded, tail=tail)
+        if kind == "none":
+            with contextlib.redirect_stdout(io.StringIO()):
+                layer = AutoregressiveMixtureCDFCoupling(c_in=D, model_func=lambda c_out: Inject(), num_mixtures=K)
+            layer.scaling_factor.data, layer.mixture_scaling_factor.data = sf.clone(), msf.clone()
+            layer.nn.value = nn_out
+            layer.train(training)
+            zf, lf = layer(z, reverse=False)
+            t, log_s, log_pi, mu, ls = MixtureCDFCoupling.get_mixt_params(nn_out, None, K, sf, msf)
+            zr64, lr64 = MixtureCDFCoupling.run_with_params(zf.double(), t, log_s, log_pi, mu, ls, reverse=True)
+            cases.append(dict(meta=meta, z=z, nn_out=nn_out, scaling_factor=sf, mixture_scaling_factor=msf,
+                              z_fwd=zf, ldj_fwd=lf, z_rev=zr64.float(), ldj_rev=lr64.float(),
+                              p_t=t, p_log_s=log_s, p_log_pi=log_pi, p_mixt_t=mu, p_mixt_log_s=ls))
+            continue
+        mask = CouplingLayer.create_channel_mask(D) if kind == "channel" else CouplingLayer.create_chess_mask()
+        with contextlib.redirect_stdout(io.StringIO()):
+            layer = MixtureCDFCoupling(c_in=D, mask=mask, model_func=lambda c_out: Inject(), num_mixtures=K,
+                                       regularizer_max=reg_max, regularizer_factor=reg_factor)
+        layer.scaling_factor.data, layer.mixture_scaling_factor.data = sf.clone(), msf.clone()
+        layer.nn.value = nn_out
+        layer.train(training)
+        kw = dict(channel_padding_mask=pad) if padded else {}
+        zf, lf, det = layer(z, reverse=False, **kw)
+        zr, lr, _ = layer(zf, reverse=True, **kw)
+        t, log_s, log_pi, mu, ls = MixtureCDFCoupling.get_mixt_params(nn_out, layer._prepare_mask(mask, z), K, sf, msf)
+        c = dict(meta=meta, z=z, nn_out=nn_out, scaling_factor=sf, mixture_scaling_factor=msf, mask=mask,
+                 z_fwd=zf, ldj_fwd=lf, z_rev=zr, ldj_rev=lr, reg_ldj=det["regularizer_ldj"],
+                 p_t=t, p_log_s=log_s, p_log_pi=log_pi, p_mixt_t=mu, p_mixt_log_s=ls)
+        if padded:
+            c["length"] = ln
+            c["pad"] = pad
+        cases.append(c)
+    # the reference's own __main__ demo (mixture_cdf_layer.py:279-302): linear subnet, seed 42
+    torch.manual_seed(42)
+    c_in, K, hidden = 4, 10, 128
+    with contextlib.redirect_stdout(io.StringIO()):
+        layer = MixtureCDFCoupling(c_in=c_in, mask=CouplingLayer.create_channel_mask(c_in),
+                                   model_func=lambda c_out: nn.Sequential(nn.Linear(c_in, hidden), nn.ReLU(),
+                                                                          nn.Linear(hidden, c_out)),
+                                   block_type="Linear net", num_mixtures=K)
+    x = torch.randn(size=(8, 16, c_in))
+    zf, lf, _ = layer(z=x, reverse=False)
+    zr, lr, _ = layer(z=zf, reverse=True)
+    mask = layer.mask
+    nn_f = layer.nn(x * mask)
+    nn_r = layer.nn(zf * mask)
+    cases.append(dict(meta=dict(B=8, N=16, D=c_in, K=K, mask_kind="channel", reg_max=-1, reg_factor=1, training=True,
+                                padded=False, tail=1.0, demo=True,
+                                demo_max_recon_err=float((x - zr).abs().max()),
+                                demo_max_ldj_err=float((lf + lr).abs().max())),
+                      z=x, nn_out=nn_f, nn_out_rev=nn_r, scaling_factor=layer.scaling_factor.data,
+                      mixture_scaling_factor=layer.mixture_scaling_factor.data, mask=mask,
+                      z_fwd=zf, ldj_fwd=lf, z_rev=zr, ldj_rev=lr))
+    save("mixture_coupling", cases)
+
+
+def gen_actnorm():
+    cases = []
+    g = torch.Generator().manual_seed(44)
+    for (B, N, D, mode) in [(4, 6, 3, "length"), (4, 6, 3, "none"), (5, 9, 6, "mask"), (3, 16, 4, "length_mask"),
+                            (8, 1, 2, "none"), (2, 7, 1, "length_mask")]:
+        layer = ActNormFlow(D)
+        layer.bias.data = torch.randn(1, 1, D, generator=g)
+        layer.scales.data = 0.5 * torch.randn(1, 1, D, generator=g)
+        z = torch.randn(B, N, D, generator=g)
+        ln = lengths(B, N, g)
+        pad = create_channel_mask(ln, max_len=N)
+        kw = {}
+        if "length" in mode:
+            kw["length"] = ln
+        if "mask" in mode:
+            kw["channel_padding_mask"] = pad
+        ldj_in = torch.randn(B, generator=g)
+        zf, lf = layer(z, ldj=ldj_in.clone(), reverse=False, **kw)
+        zr, lr = layer(zf, ldj=None, reverse=True, **kw)
+        # data-dependent init on a fresh layer
+        init = ActNormFlow(D)
+        with contextlib.redirect_stdout(io.StringIO()):
+            init.data_init_forward(z, channel_padding_mask=(pad.expand(-1, -1, D) if "mask" in mode else None))
+        cases.append(dict(meta=dict(B=B, N=N, D=D, mode=mode), z=z, bias=layer.bias.data, scales=layer.scales.data,
+                          length=ln, pad=pad, ldj_in=ldj_in, z_fwd=zf, ldj_fwd=lf, z_rev=zr, ldj_rev=lr,
+                          init_bias=init.bias.data, init_scales=init.scales.data))
+    save("actnorm", cases)
+
+    cases = []
+    for (B, N, D, padded) in [(6, 1, 3, False), (4, 5, 4, True), (3, 8, 6, False), (16, 1, 2, False)]:
+        net = Inject()
+        layer = ExtActNormFlow(D, net=net)
+        z = torch.randn(B, N, D, generator=g)
+        nn_out = torch.randn(B, N, 2 * D, generator=g)
+        net.value = nn_out
+        ln = lengths(B, N, g)
+        pad = create_channel_mask(ln, max_len=N)
+        kw = dict(channel_padding_mask=pad) if padded else {}
+        ldj_in = torch.randn(B, generator=g)
+        zf, lf = layer(z, ldj_in.clone(), ext_input=z, reverse=False, **kw)
+        zr, lr = layer(zf, None, ext_input=z, reverse=True, **kw)
+        cases.append(dict(meta=dict(B=B, N=N, D=D, padded=padded), z=z, nn_out=nn_out, pad=pad, ldj_in=ldj_in,
+                          z_fwd=zf, ldj_fwd=lf, z_rev=zr, ldj_rev=lr))
+    save("ext_actnorm", cases)
+
+
+def gen_invconv():
+    cases = []
+    g = torch.Generator().manual_seed(45)
+    np.random.seed(45)
+    # NB dense D=2 is unusable in the reference itself (fp64 rotation init -> dtype error in matmul)
+    for (B, N, D, lu, mode) in [(4, 6, 2, True, "none"), (4, 6, 3, False, "none"), (3, 7, 3, True, "length"),
+                                (3, 5, 4, True, "length_mask"), (2, 9, 6, True, "none"), (2, 9, 6, False, "length_mask"),
+                                (5, 4, 8, True, "length"), (7, 1, 4, True, "none")]:
+        layer = InvertibleConv(D, LU_decomposed=lu)
+        z = torch.randn(B, N, D, generator=g)
+        ln = lengths(B, N, g)
+        pad = create_channel_mask(ln, max_len=N)
+        kw = {}
+        if "length" in mode:
+            kw["length"] = ln
+        if "mask" in mode:
+            kw["channel_padding_mask"] = pad
+        ldj_in = torch.randn(B, generator=g)
+        layer.train()
+        zf, lf = layer(z, ldj=ldj_in.clone(), reverse=False, **kw)
+        zr, lr = layer(zf, ldj=None, reverse=True, **kw)
+        w_train, sldj_train = layer._get_weight("cpu")
+        layer.eval()
+        zf_e, lf_e = layer(z, ldj=ldj_in.clone(), reverse=False, **kw)
+        zr_e, lr_e = layer(zf_e, ldj=None, reverse=True, **kw)
+        c = dict(meta=dict(B=B, N=N, D=D, lu=lu, mode=mode), z=z, length=ln, pad=pad, ldj_in=ldj_in,
+                 weight=w_train, sldj=sldj_train, inv_weight=layer.eval_dict["cpu"]["inv_weight"],
+                 z_fwd=zf, ldj_fwd=lf, z_rev=zr, ldj_rev=lr, z_fwd_eval=zf_e, ldj_fwd_eval=lf_e,
+                 z_rev_eval=zr_e, ldj_rev_eval=lr_e)
+        for k, v in layer.state_dict().items():
+            c["sd_" + k] = v
+        cases.append(c)
+    save("invconv", cases)
+
+
+def gen_prior():
+    cases = []
+    prior = LogisticDistribution(mu=0.0, sigma=1.0)
+    g = torch.Generator().manual_seed(46)
+    x = torch.cat([3 * torch.randn(200, generator=g), torch.tensor([0.0, 25.0, -25.0, 60.0, -60.0, 1e-8])])
+    cases.append(dict(meta=dict(kind="log_prob", sigma=prior.sigma, log_sigma=float(prior.log_sigma)),
+                      x=x, log_prob=prior.log_prob(x)))
+    for seed, shape in [(7, (6, 1, 3)), (8, (5, 1, 1)), (9, (4, 1, 6))]:
+        torch.manual_seed(seed)
+        u = torch.rand(shape)                      # == Uniform(0,1).sample(shape) on the CPU generator
+        torch.manual_seed(seed)
+        s = prior.sample(shape=shape)
+        cases.append(dict(meta=dict(kind="sample", seed=seed, shape=list(shape)), u=u, sample=s,
+                          log_prob=prior.log_prob(s)))
+    # NLL assembly as in experiments/set_modeling/task.py:96-118
+    B, N, D = 6, 8, 4
+    z = 1.5 * torch.randn(B, N, D, generator=g)
+    ldj = torch.randn(B, generator=g)
+    ln = lengths(B, N, g)
+    pad = create_channel_mask(ln, max_len=N)
+    neglog = -(prior.log_prob(z) * pad).sum(dim=[1, 2])
+    nll = (-ldj) / ln.float() + neglog / ln.float()
+    cases.append(dict(meta=dict(kind="nll", B=B, N=N, D=D), z=z, ldj=ldj, length=ln, pad=pad,
+                      neglog=neglog, nll=nll, nll_mean=nll.mean(), bpd=np.log2(np.exp(1)) * nll.mean()))
+    save("prior", cases)
+
+
+def gen_encoder():
+    cases = []
+    for i, (B, N, D, C, beta, prior, padded, training) in enumerate([
+            (3, 6, 3, 4, 1.0, False, False, True), (4, 5, 2, 1, 1.0, False, False, False),
+            (4, 5, 2, 2, 1.0, False, True, False), (3, 7, 4, 3, 2.0, True, True, True),
+            (2, 9, 6, 9, 1.0, True, False, False), (4, 16, 4, 16, 1.0, False, False, False),
+            (2, 11, 3, 51, 1.0, True, True, False), (5, 3, 1, 5, 1.0, False, False, False)]):
+        torch.manual_seed(100 + i)
+        np.random.seed(100 + i)
+        cp = torch.randn(C) if prior else None
+        with contextlib.redirect_stdout(io.StringIO()):
+            enc = LinearCategoricalEncoding(num_dimensions=D, flow_config={"num_flows": 0}, vocab_size=C,
+                                            category_prior=cp)
+        # give the scale half of the predictor non-trivial values (it is zero at init, help_layers.py:62-66)
+        lin = enc.flow_layers[0].pred_net.layer
+        lin.weight.data[D:, :] = 0.2 * torch.randn(D, lin.weight.shape[1])
+        lin.bias.data = 0.1 * torch.randn(2 * D)
+        enc.train(training)
+        cat = torch.randint(0, C, (B, N))
+        ln = lengths(B, N, torch.Generator().manual_seed(i))
+        pad = create_channel_mask(ln, max_len=N)
+        kw = dict(channel_padding_mask=pad) if padded else {}
+        torch.manual_seed(500 + i)
+        u = torch.rand(B * N, 1, D)
+        torch.manual_seed(500 + i)
+        z, ldj, det = enc(cat, reverse=False, beta=beta, **kw)
+        dec, _, _ = enc(z, reverse=True)
+        z_probe = z + 0.7 * torch.randn(z.shape)
+        dec_probe, _, _ = enc(z_probe, reverse=True)
+        table = enc.flow_layers[0].pred_net(enc.embed_layer.weight)     # [C, 2D]
+        c = dict(meta=dict(B=B, N=N, D=D, C=C, beta=beta, prior=prior, padded=padded, training=training),
+                 categ=cat, u=u, table=table, category_prior=enc.category_prior, pad=pad, z=z, ldj=ldj,
+                 decoded=dec, z_probe=z_probe, decoded_probe=dec_probe)
+        for k, v in det.items():
+            c["detail_" + k] = v
+        for k, v in enc.state_dict().items():
+            c["sd_" + k] = v
+        cases.append(c)
+    save("encoder", cases)
+
+
+def gen_sigmoid_dequant():
+    cases = []
+    g = torch.Generator().manual_seed(48)
+    for rev_layer in (False, True):
+        layer = SigmoidFlow(reverse=rev_layer)
+        z = 2 * torch.randn(4, 6, 1, generator=g)
+        u = torch.rand(4, 6, 1, generator=g)
+        a, la = layer(z if not rev_layer else u, reverse=False)
+        b, lb = layer(u if not rev_layer else z, reverse=True)
+        cases.append(dict(meta=dict(reverse_layer=rev_layer), z=z, u=u, out_fwd=a, ldj_fwd=la, out_rev=b, ldj_rev=lb))
+    save("sigmoid", cases)
+
+    # variational dequantisation round trip (variational_dequantization.py:101-144 demo shape)
+    torch.manual_seed(42)
+    B, N, C, hidden, emb = 3, 6, 4, 16, 8
+
+    class Net(nn.Module):
+        def __init__(self, c_out):
+            super().__init__()
+            self.inp = nn.Linear(1, hidden)
+            self.main = nn.Sequential(nn.Linear(hidden + emb, hidden), nn.ReLU(), nn.Linear(hidden, c_out))
+
+        def forward(self, x, ext_input, **kw):
+            return self.main(torch.cat([self.inp(x), ext_input], dim=-1))
+
+    with contextlib.redirect_stdout(io.StringIO()):
+        vd = VariationalDequantization(vocab_size=C, flow_config={"num_flows": 2, "model_func": lambda c_out: Net(c_out),
+                                                                  "block_type": "Linear"},
+                                       default_embed_layer_dims=emb)
+    for p in vd.parameters():
+        p.data = p.data + 0.05 * torch.randn(p.shape)
+    cat = torch.randint(high=C, size=(B, N))
+    torch.manual_seed(77)
+    u = torch.rand(B, N)
+    torch.manual_seed(77)
+    z, ldj = vd(cat, reverse=False)
+    rec, _ = vd(z, reverse=True)
+    c = dict(meta=dict(B=B, N=N, C=C, hidden=hidden, emb=emb, num_flows=2), categ=cat, u=u, z=z, ldj=ldj, decoded=rec)
+    for k, v in vd.state_dict().items():
+        c["sd_" + k] = v
+    save("dequant", [c])
+
+
+def gen_flow_stack():
+    """configs[0]-style plumbing: encoder + 4 x (ActNorm, InvConv, affine Coupling) through FlowModel,
+    C in {2,16}, D=2, batch 256, |S|=16.  Subnet = small MLP (weights stored)."""
+    cases = []
+    for C in (2, 16):
+        torch.manual_seed(11 + C)
+        np.random.seed(11 + C)
+        B, N, D, hidden = 256, 16, 2, 32
+        mk = lambda c_out: nn.Sequential(nn.Linear(D, hidden), nn.GELU(), nn.Linear(hidden, c_out))
+        with contextlib.redirect_stdout(io.StringIO()):
+            layers = [LinearCategoricalEncoding(num_dimensions=D, flow_config={"num_flows": 0}, vocab_size=C)]
+            for _ in range(4):
+                layers += [ActNormFlow(D), InvertibleConv(D),
+                           CouplingLayer(D, CouplingLayer.create_channel_mask(D), mk)]
+            model = FlowModel(layers)
+        for p in model.parameters():
+            p.data = p.data + 0.05 * torch.randn(p.shape)
+        model.eval()
+        cat = torch.randint(0, C, (B, N))
+        ln = torch.full((B,), N, dtype=torch.long)
+        torch.manual_seed(900 + C)
+        u = torch.rand(B * N, 1, D)
+        torch.manual_seed(900 + C)
+        with torch.no_grad():
+            z, ldj = model(cat, reverse=False, length=ln)
+            prior = LogisticDistribution()
+            neglog = -prior.log_prob(z).sum(dim=[1, 2])
+            nll = (-ldj + neglog) / ln.float()
+            dec, _ = model(z, reverse=True, length=ln)
+        c = dict(meta=dict(B=B, N=N, D=D, C=C, hidden=hidden, flows=4), categ=cat, u=u, z=z, ldj=ldj, nll=nll,
+                 decoded=dec, bpd=np.log2(np.exp(1)) * nll.mean())
+        for k, v in model.state_dict().items():
+            c["sd_" + k] = v
+        cases.append(c)
+    save("flow_stack", cases)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(1)
+    gen_affine()
+    gen_mixture()
+    gen_actnorm()
+    gen_invconv()
+    gen_prior()
+    gen_encoder()
+    gen_sigmoid_dequant()
+    gen_flow_stack()
