@@ -1,0 +1,244 @@
+#!/usr/bin/env python
+"""Benchmark of the coupling hot path: forward + log-det, then inverse + log-det, of the affine
+coupling over one synthetic [B, N, D] batch per step (BASELINE.json metric "coupling fwd+inv+logdet
+elems/s"; workload = the north-star shape B=16384, N=64, d_latent=6).
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One step on every rank (weak scaling: each rank owns its own B samples, no data-path collective):
+    1. cnf_affine_coupling   forward  z -> z', ldj            (16 B/elem)
+    2. cnf_prior_nll         z', ldj -> per-sample NLL, (sum, count)   (4 B/elem)
+    3. cnf_affine_coupling   inverse  z' -> z, -ldj           (16 B/elem)
+    4. N > 1: ONE all-reduce of the two fp64 scalars (sum NLL, count) over RCCL.
+`value` = B*N*D elements pushed through forward+inverse(+log-det) per second, summed over ranks, with
+all inputs resident in HBM.  Prints ONE JSON line on rank 0.
+
+The CPU baseline (`cpu_baseline`, kind "port") times the oracle's torch-CPU restatement of the same
+step on the host cores; it is a reported baseline, never the target.  `roofline` prices the
+dominant kernel (affine forward) by its algorithmic bytes against the 8 TB/s HBM3E peak.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=200)
+    p.add_argument("--warmup", type=int, default=20)
+    p.add_argument("--batch", type=int, default=16384)
+    p.add_argument("--seq", type=int, default=64)
+    p.add_argument("--dim", type=int, default=6)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-mixture", action="store_true", help="skip the secondary mixture-CDF measurement")
+    p.add_argument("--tile-chunks", type=int, default=0)
+    p.add_argument("--unroll", type=int, default=0)
+    p.add_argument("--rotate", type=int, default=4, help="buffer sets rotated through (defeats the 256 MB Infinity Cache)")
+    return p.parse_args()
+
+
+def cpu_baseline(B, N, D, budget_s=15.0):
+    """Oracle (torch CPU ops, all host threads) on the same step at the same shape."""
+    from oracle import cnf_oracle as O
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    g = torch.Generator().manual_seed(0)
+    z = torch.randn(B, N, D, generator=g)
+    nn_out = 0.5 * torch.randn(B, N, 2 * D, generator=g)
+    sf, mask = torch.zeros(D), O.channel_mask(D)
+    ln = torch.full((B,), N)
+
+    def step():
+        zf, lf = O.affine_coupling(z, nn_out, mask, sf, reverse=False)
+        O.nll_per_sample(zf, lf, ln)
+        O.affine_coupling(zf, nn_out, mask, sf, reverse=True)
+
+    for _ in range(2):
+        step()
+    times = []
+    t_start = time.perf_counter()
+    while len(times) < 10 or (time.perf_counter() - t_start < budget_s and len(times) < 40):
+        t0 = time.perf_counter()
+        step()
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    return {"value": B * N * D / med, "unit": "elems/s", "cores": threads, "kind": "port",
+            "sample": "%d steps of the same step (affine fwd + NLL + inv) at B=%d,N=%d,D=%d on torch CPU ops; median %.1f ms/step"
+                      % (len(times), B, N, D, med * 1e3)}
+
+
+def mixture_measure(ops, dev, steps=20, warmup=3):
+    """Secondary measurement, BASELINE configs[1]: mixture-CDF coupling fwd + inv, B=16384, N=16, D=4, K=8."""
+    from oracle.cnf_oracle import channel_mask
+    B, N, D, K = 16384, 16, 4, 8
+    g = torch.Generator(device=dev).manual_seed(1)
+    z = torch.randn(B, N, D, generator=g, device=dev)
+    nn_out = 0.5 * torch.randn(B, N, D * (2 + 3 * K), generator=g, device=dev)
+    mask = channel_mask(D).to(dev)
+    zf, zr = torch.empty_like(z), torch.empty_like(z)
+    lf, lr = torch.empty(B, device=dev), torch.empty(B, device=dev)
+    fwd = ops.mixture_coupling_launch(z, nn_out, mask, K, zf, lf)
+    inv = ops.mixture_coupling_launch(zf, nn_out, mask, K, zr, lr, reverse=True)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    tf = ti = 0.0
+    for i in range(warmup + steps):
+        ev[0].record()
+        fwd()
+        ev[1].record()
+        inv()
+        ev[2].record()
+        torch.cuda.synchronize(dev)
+        if i >= warmup:
+            tf += ev[0].elapsed_time(ev[1])
+            ti += ev[1].elapsed_time(ev[2])
+    assert (zr - z).abs().max().item() < 2e-4, "mixture inverse did not recover z"
+    tf, ti = tf / steps, ti / steps
+    elems = B * N * D
+    bytes_alg = elems * (16 + 12 * K)
+    return {"workload": "mixture_cdf_coupling B=16384 N=16 D=4 K=8 (configs[1])", "dtype": "f64",
+            "fwd_ms": tf, "inv_ms": ti, "fwd_elems_per_s": elems / (tf * 1e-3), "inv_elems_per_s": elems / (ti * 1e-3),
+            "fwd_inv_elems_per_s": elems / ((tf + ti) * 1e-3),
+            "fwd_algorithmic_GBps": bytes_alg / (tf * 1e-3) / 1e9, "fwd_hbm_frac": bytes_alg / (tf * 1e-3) / 1e9 / HBM_PEAK_GBS}
+
+
+def main():
+    args = parse()
+    from categoricalnf_amd import _lib, ops
+    from categoricalnf_amd.distributed import init_process_group
+    from oracle.cnf_oracle import channel_mask        # mask constructor only (test helper, not compute)
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no CUDA(HIP) device visible")
+    rank, local_rank, world = init_process_group("nccl")
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+    lib = _lib.load()
+    if args.tile_chunks:
+        lib.cnf_set_tile_chunks(args.tile_chunks)
+    if args.unroll:
+        lib.cnf_set_unroll(args.unroll)
+
+    B, N, D = args.batch, args.seq, args.dim
+    elems = B * N * D
+    g = torch.Generator(device=dev).manual_seed(rank)
+    R = max(1, args.rotate)
+    zs = [torch.randn(B, N, D, generator=g, device=dev) for _ in range(R)]
+    nns = [0.5 * torch.randn(B, N, 2 * D, generator=g, device=dev) for _ in range(R)]
+    sf = torch.zeros(D, device=dev)
+    mask = channel_mask(D).to(dev)
+    length = torch.full((B,), float(N), device=dev)
+    sums = torch.zeros(2, dtype=torch.float64, device=dev)
+    ev_a = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev_b = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+
+    # outputs and pre-bound launches per buffer set (host cost per launch ~2 us)
+    zfs = [torch.empty_like(zs[0]) for _ in range(R)]
+    zrs = [torch.empty_like(zs[0]) for _ in range(R)]
+    lfs = [torch.empty(B, device=dev) for _ in range(R)]
+    lrs = [torch.empty(B, device=dev) for _ in range(R)]
+    neglog, nll = torch.empty(B, device=dev), torch.empty(B, device=dev)
+    fwd = [ops.affine_coupling_launch(zs[r], nns[r], sf, mask, zfs[r], lfs[r], reverse=False) for r in range(R)]
+    nlls = [ops.prior_nll_launch(zfs[r], lfs[r], length, neglog, nll, sums) for r in range(R)]
+    inv = [ops.affine_coupling_launch(zfs[r], nns[r], sf, mask, zrs[r], lrs[r], reverse=True) for r in range(R)]
+
+    def step(i, timed=-1):
+        r = i % R
+        if timed >= 0:
+            ev_a[timed].record()
+        fwd[r]()
+        if timed >= 0:
+            ev_b[timed].record()
+        sums.zero_()
+        nlls[r]()
+        inv[r]()
+        if world > 1:
+            dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+        return zrs[r], lrs[r]
+
+    for i in range(args.warmup):
+        step(i)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        zr, lr = step(i, timed=i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ops.check_flags(dev, "bench")
+    r_last = (args.steps - 1) % R
+    err = (zrs[r_last] - zs[r_last]).abs().max().item()
+    assert err < 1e-4, "inverse(forward(z)) != z (max err %g)" % err
+    assert torch.equal(lfs[r_last], -lrs[r_last]), "ldj_fwd + ldj_inv != 0"
+    mean_nll = float(sums[0].item() / max(sums[1].item(), 1.0))
+
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev_a, ev_b)]))
+    alg_bytes = 16.0 * elems + 4.0 * B            # z 4 + (s,t) 8 + z' 4 per elem, + ldj per sample
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("affine_coupling_fwd_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    if rank == 0:
+        out = {
+            "metric": "coupling fwd+inv+logdet elems/s",
+            "value": elems * world * args.steps / elapsed,
+            "unit": "elems/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "affine coupling fwd+logdet, NLL, inverse+logdet on z~N(0,1) [B=%d,N=%d,D=%d] per GPU, "
+                                   "nn_out~0.5N(0,1), channel mask 0.5, scaling_factor=0" % (B, N, D),
+                       "batch_per_gpu": B, "seq": N, "d_latent": D, "elems_per_step_per_gpu": elems,
+                       "buffer_sets_rotated": R, "parallelism": "dp%d (batch shards, 1 all-reduce of 2 fp64)" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "affine_coupling_kernel<VEC=4,fwd>", "kernel_ms": kern_ms,
+                         "algorithmic_bytes_per_launch": alg_bytes},
+            "mean_nll": mean_nll,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(B, N, D)
+        if world == 1 and not args.no_mixture:
+            out["extra"] = {"mixture": mixture_measure(ops, dev)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

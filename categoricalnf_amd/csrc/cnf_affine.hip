@@ -1,0 +1,526 @@
+// Row-streaming fp32 kernels: affine coupling (fwd / inv + log-det), its static-API split forms,
+// ExtActNorm, the sigmoid/logit flow and the prior-log-prob + NLL assembly.
+//
+// All are HBM-bound (16 B/elem for the coupling: z 4 + interleaved (s,t) 8 + z' 4).  One wave owns
+// a tile of whole rows (= samples), walks it in 16-byte chunks with fully coalesced loads, and
+// reduces the per-row log-det through its private LDS strip — no atomics, deterministic sums.
+#include "cnf_common.h"
+
+#include <algorithm>
+
+namespace cnf {
+
+// per (mask-row, channel) constants staged in LDS: keep = 1-mask, keepf = keep*e^sf, fc = max(e^sf,1)
+struct alignas(16) ChanTab {
+    float keep, keepf, fc, pad_;
+};
+constexpr int kMaxTab = 256;
+
+struct AffineArgs {
+    const float* z;
+    const float* nn;
+    const float* sf;
+    const float* mask;
+    const float* ldj_in;
+    float* z_out;
+    float* ldj_out;
+    int* flags;
+    int N, D, L, mr, mc, reverse;
+    FastDiv div_d;
+};
+
+template <int VEC>
+struct VecIO;
+template <>
+struct VecIO<4> {
+    static __device__ __forceinline__ void load_z(const float* p, float* v) {
+        const float4 a = *reinterpret_cast<const float4*>(p);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+    }
+    static __device__ __forceinline__ void load_st(const float* p, float* s, float* t) {
+        const float4 a = *reinterpret_cast<const float4*>(p);
+        const float4 b = *reinterpret_cast<const float4*>(p + 4);
+        s[0] = a.x; t[0] = a.y; s[1] = a.z; t[1] = a.w;
+        s[2] = b.x; t[2] = b.y; s[3] = b.z; t[3] = b.w;
+    }
+    static __device__ __forceinline__ void store(float* p, const float* v) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+};
+template <>
+struct VecIO<2> {
+    static __device__ __forceinline__ void load_z(const float* p, float* v) {
+        const float2 a = *reinterpret_cast<const float2*>(p);
+        v[0] = a.x; v[1] = a.y;
+    }
+    static __device__ __forceinline__ void load_st(const float* p, float* s, float* t) {
+        const float4 a = *reinterpret_cast<const float4*>(p);
+        s[0] = a.x; t[0] = a.y; s[1] = a.z; t[1] = a.w;
+    }
+    static __device__ __forceinline__ void store(float* p, const float* v) {
+        *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]);
+    }
+};
+template <>
+struct VecIO<1> {
+    static __device__ __forceinline__ void load_z(const float* p, float* v) { v[0] = *p; }
+    static __device__ __forceinline__ void load_st(const float* p, float* s, float* t) {
+        const float2 a = *reinterpret_cast<const float2*>(p);
+        s[0] = a.x; t[0] = a.y;
+    }
+    static __device__ __forceinline__ void store(float* p, const float* v) { *p = v[0]; }
+};
+
+// coupling_layer.py:53-60 + :88-98 fused.  HAS_SF: tanh bound with the learned scaling factor.
+template <int VEC>
+struct AffineChunk {
+    float zv[VEC], sr[VEC], tr[VEC];
+};
+
+template <int VEC, int U, bool HAS_SF, bool REVERSE>
+__global__ __launch_bounds__(kBlock) void affine_coupling_kernel(AffineArgs a, RowTiling tl) {
+    __shared__ float part[kWavesPerBlock][kMaxTileChunks];
+    __shared__ ChanTab tab[kMaxTab];
+    const int ntab = a.mr * a.D;
+    for (int i = threadIdx.x; i < ntab; i += kBlock) {
+        const int r = i / a.D, d = i - r * a.D;
+        const float m = a.mask ? a.mask[r * a.mc + (a.mc == 1 ? 0 : d)] : 0.f;
+        const float f = HAS_SF ? expf(a.sf[d]) : 1.f;
+        ChanTab t;
+        t.keep = 1.f - m;
+        t.keepf = (1.f - m) * f;
+        t.fc = fmaxf(f, 1.f);
+        t.pad_ = 0.f;
+        tab[i] = t;
+    }
+    __syncthreads();
+
+    bool bad = false;
+    auto load = [&](int row, int e0) {
+        const size_t off = (size_t)row * a.L + e0;
+        AffineChunk<VEC> c;
+        VecIO<VEC>::load_z(a.z + off, c.zv);
+        VecIO<VEC>::load_st(a.nn + 2 * off, c.sr, c.tr);
+        return c;
+    };
+    auto proc = [&](const AffineChunk<VEC>& c, int row, int e0) -> float {
+        const size_t off = (size_t)row * a.L + e0;
+        float out[VEC];
+        int n = (int)fdiv((uint32_t)e0, a.div_d);
+        int d = e0 - n * a.D;
+        int nm = a.mr == 1 ? 0 : n % a.mr;
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const ChanTab tb = tab[nm * a.D + d];
+            const float s = HAS_SF ? tanhf(c.sr[j] / tb.fc) * tb.keepf : c.sr[j] * tb.keep;
+            const float t = c.tr[j] * tb.keep;
+            out[j] = REVERSE ? c.zv[j] * expf(-1.f * s) - t : (c.zv[j] + t) * expf(s);
+            bad |= isnan(out[j]);
+            acc += s;
+            if (++d == a.D) {
+                d = 0;
+                if (++nm == a.mr) nm = 0;
+            }
+        }
+        VecIO<VEC>::store(a.z_out + off, out);
+        return acc;
+    };
+    auto finish = [&](int row, float sum) {
+        const float base = a.ldj_in ? a.ldj_in[row] : 0.f;
+        const float v = REVERSE ? base - sum : base + sum;
+        a.ldj_out[row] = v;
+        if (isnan(v)) raise_flag(a.flags, CNF_FLAG_NAN_LDJ);
+    };
+    walk_row_tile_split<U, float, AffineChunk<VEC>>(tl, part[threadIdx.x >> 6], load, proc, finish);
+    if (bad) raise_flag(a.flags, CNF_FLAG_NAN_Z);
+}
+
+template <int VEC, int U>
+static void launch_affine_u(const AffineArgs& a, const RowTiling& tl, bool has_sf, bool reverse,
+                            hipStream_t st) {
+    const dim3 grid = tiling_grid(tl), block(kBlock);
+    if (has_sf) {
+        if (reverse) hipLaunchKernelGGL((affine_coupling_kernel<VEC, U, true, true>), grid, block, 0, st, a, tl);
+        else hipLaunchKernelGGL((affine_coupling_kernel<VEC, U, true, false>), grid, block, 0, st, a, tl);
+    } else {
+        if (reverse) hipLaunchKernelGGL((affine_coupling_kernel<VEC, U, false, true>), grid, block, 0, st, a, tl);
+        else hipLaunchKernelGGL((affine_coupling_kernel<VEC, U, false, false>), grid, block, 0, st, a, tl);
+    }
+}
+
+template <int VEC>
+static void launch_affine(const AffineArgs& a, const RowTiling& tl, bool has_sf, bool reverse,
+                          hipStream_t st) {
+    // chunks per lane in one tile decide how many loads are worth issuing back to back
+    const int per_lane = (int)std::min<long>(((long)tl.rw * tl.cpr + kWave - 1) / kWave, unroll_target());
+    switch (per_lane) {
+        case 1: launch_affine_u<VEC, 1>(a, tl, has_sf, reverse, st); break;
+        case 2: launch_affine_u<VEC, 2>(a, tl, has_sf, reverse, st); break;
+        case 3: launch_affine_u<VEC, 3>(a, tl, has_sf, reverse, st); break;
+        default: launch_affine_u<VEC, 4>(a, tl, has_sf, reverse, st); break;
+    }
+}
+
+// ---- static-API split forms (coupling_layer.py:76-86 and :88-98) ---------------------------------
+__global__ __launch_bounds__(kBlock) void affine_params_kernel(const float* nn, const float* sf,
+                                                               const float* mask, int mr, int mc,
+                                                               float* s_out, float* t_out, long total,
+                                                               int N, int D) {
+    for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long)gridDim.x * kBlock) {
+        const int d = (int)(i % D);
+        const int n = (int)((i / D) % N);
+        const float keep = 1.f - mask_at(mask, mr, mc, n, d);
+        const float2 p = *reinterpret_cast<const float2*>(nn + 2 * i);
+        float s = p.x;
+        if (sf) {
+            const float f = expf(sf[d]);
+            s = tanhf(s / fmaxf(f, 1.f)) * f;
+        }
+        s_out[i] = s * keep;
+        t_out[i] = p.y * keep;
+    }
+}
+
+struct TransformArgs {
+    const float* z;
+    const float* s;
+    const float* t;
+    const float* ldj_in;
+    float* z_out;
+    float* ldj_out;
+    int* flags;
+    int L, reverse;
+};
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void affine_transform_kernel(TransformArgs a, RowTiling tl) {
+    __shared__ float part[kWavesPerBlock][kMaxTileChunks];
+    bool bad = false;
+    auto chunk = [&](int row, int e0) -> float {
+        const size_t off = (size_t)row * a.L + e0;
+        float zv[VEC], sv[VEC], tv[VEC], out[VEC];
+        VecIO<VEC>::load_z(a.z + off, zv);
+        VecIO<VEC>::load_z(a.s + off, sv);
+        VecIO<VEC>::load_z(a.t + off, tv);
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            out[j] = a.reverse ? zv[j] * expf(-1.f * sv[j]) - tv[j] : (zv[j] + tv[j]) * expf(sv[j]);
+            bad |= isnan(out[j]);
+            acc += sv[j];
+        }
+        VecIO<VEC>::store(a.z_out + off, out);
+        return acc;
+    };
+    auto finish = [&](int row, float sum) {
+        const float base = a.ldj_in ? a.ldj_in[row] : 0.f;
+        a.ldj_out[row] = a.reverse ? base - sum : base + sum;
+    };
+    walk_row_tile<float>(tl, part[threadIdx.x >> 6], chunk, finish);
+    if (bad) raise_flag(a.flags, CNF_FLAG_NAN_Z);
+}
+
+// ---- ExtActNorm (activation_normalization.py:116-144) ------------------------------------------
+struct ExtArgs {
+    const float* z;
+    const float* nn;    // [B,N,2D] = [bias | scales_raw] per token
+    const float* pad;   // [B,N] or null
+    const float* ldj_in;
+    float* z_out;
+    float* ldj_out;
+    int* flags;
+    int N, D, L, reverse;
+    FastDiv div_d;
+};
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void ext_actnorm_kernel(ExtArgs a, RowTiling tl) {
+    __shared__ float part[kWavesPerBlock][kMaxTileChunks];
+    bool bad = false;
+    auto chunk = [&](int row, int e0) -> float {
+        const size_t off = (size_t)row * a.L + e0;
+        float zv[VEC], out[VEC];
+        VecIO<VEC>::load_z(a.z + off, zv);
+        int n = (int)fdiv((uint32_t)e0, a.div_d);
+        int d = e0 - n * a.D;
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const size_t tok = (size_t)row * a.N + n;
+            const float bias = a.nn[tok * 2 * a.D + d];
+            const float sc = tanhf(a.nn[tok * 2 * a.D + a.D + d]);
+            out[j] = a.reverse ? zv[j] * expf(-sc) - bias : (zv[j] + bias) * expf(sc);
+            bad |= isnan(out[j]);
+            acc += a.pad ? sc * a.pad[tok] : sc;
+            if (++d == a.D) {
+                d = 0;
+                ++n;
+            }
+        }
+        VecIO<VEC>::store(a.z_out + off, out);
+        return acc;
+    };
+    auto finish = [&](int row, float sum) {
+        const float base = a.ldj_in ? a.ldj_in[row] : 0.f;
+        const float v = a.reverse ? base - sum : base + sum;
+        a.ldj_out[row] = v;
+        if (isnan(v)) raise_flag(a.flags, CNF_FLAG_NAN_LDJ);
+    };
+    walk_row_tile<float>(tl, part[threadIdx.x >> 6], chunk, finish);
+    if (bad) raise_flag(a.flags, CNF_FLAG_NAN_Z);
+}
+
+// ---- sigmoid / logit flow (sigmoid_layer.py:24-47) ---------------------------------------------
+__device__ __forceinline__ float softplus_t20(float x) {   // F.softplus, beta 1, threshold 20
+    return x > 20.f ? x : log1pf(expf(x));
+}
+struct SigArgs {
+    const float* z;
+    const float* ldj_in;
+    float* z_out;
+    float* ldj_out;
+    int* flags;
+    int L, reverse;
+    float alpha, log1ma;
+};
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void sigmoid_flow_kernel(SigArgs a, RowTiling tl) {
+    __shared__ float part[kWavesPerBlock][kMaxTileChunks];
+    bool bad = false;
+    auto chunk = [&](int row, int e0) -> float {
+        const size_t off = (size_t)row * a.L + e0;
+        float zv[VEC], out[VEC];
+        VecIO<VEC>::load_z(a.z + off, zv);
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            if (!a.reverse) {
+                acc += -zv[j] - 2.f * softplus_t20(-zv[j]);
+                out[j] = 1.f / (1.f + expf(-zv[j]));
+            } else {
+                const float u = zv[j] * (1.f - a.alpha) + a.alpha * 0.5f;
+                const float lu = logf(u), l1u = logf(1.f - u);
+                acc += (-lu - l1u + a.log1ma);
+                out[j] = lu - l1u;
+            }
+            bad |= isnan(out[j]);
+        }
+        VecIO<VEC>::store(a.z_out + off, out);
+        return acc;
+    };
+    auto finish = [&](int row, float sum) {
+        a.ldj_out[row] = (a.ldj_in ? a.ldj_in[row] : 0.f) + sum;
+    };
+    walk_row_tile<float>(tl, part[threadIdx.x >> 6], chunk, finish);
+    if (bad) raise_flag(a.flags, CNF_FLAG_NAN_Z);
+}
+
+// ---- logistic prior log-prob + NLL (distributions.py:129-136,154-163; set_modeling/task.py:96-118)
+__device__ __forceinline__ float logistic_logp(float x, float mu, float sigma, float log_sigma) {
+    const float v = (x - mu) / sigma;
+    return -(softplus_t20(v) + softplus_t20(-v) + log_sigma);
+}
+struct NllArgs {
+    const float* z;
+    const float* pad;
+    const float* ldj;
+    const float* length;
+    float* neglog_out;
+    float* nll_out;
+    double* sums;
+    int N, D, L;
+    float sigma, log_sigma;
+    FastDiv div_d;
+};
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void prior_nll_kernel(NllArgs a, RowTiling tl) {
+    __shared__ float part[kWavesPerBlock][kMaxTileChunks];
+    auto chunk = [&](int row, int e0) -> float {
+        const size_t off = (size_t)row * a.L + e0;
+        float zv[VEC];
+        VecIO<VEC>::load_z(a.z + off, zv);
+        int n = (int)fdiv((uint32_t)e0, a.div_d);
+        int d = e0 - n * a.D;
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const float lp = logistic_logp(zv[j], 0.f, a.sigma, a.log_sigma);
+            acc += a.pad ? lp * a.pad[(size_t)row * a.N + n] : lp;
+            if (++d == a.D) {
+                d = 0;
+                ++n;
+            }
+        }
+        return acc;
+    };
+    double local = 0.0;
+    int local_n = 0;
+    auto finish = [&](int row, float sum) {
+        const float neglog = -sum;
+        const float len = a.length ? a.length[row] : (float)a.N;
+        const float ldj = a.ldj ? a.ldj[row] : 0.f;
+        const float nll = (-ldj) / len + neglog / len;
+        if (a.neglog_out) a.neglog_out[row] = neglog;
+        if (a.nll_out) a.nll_out[row] = nll;
+        local += (double)nll;
+        local_n += 1;
+    };
+    walk_row_tile<float>(tl, part[threadIdx.x >> 6], chunk, finish);
+    if (a.sums) {
+        local = wave_sum(local);
+        const int cnt = wave_sum(local_n);
+        if ((threadIdx.x & 63) == 0 && cnt > 0) {
+            atomicAdd(&a.sums[0], local);
+            atomicAdd(&a.sums[1], (double)cnt);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void logistic_log_prob_kernel(const float* x, float* out, long n,
+                                                                   float mu, float sigma,
+                                                                   float log_sigma, int* flags) {
+    bool bad = false;
+    for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long)gridDim.x * kBlock) {
+        const float lp = logistic_logp(x[i], mu, sigma, log_sigma);
+        bad |= isnan(lp);
+        out[i] = lp;
+    }
+    if (bad) raise_flag(flags, CNF_FLAG_NAN_Z);
+}
+
+// distributions.py:139-145,117-127 — logit evaluated in fp64 like the reference
+__global__ __launch_bounds__(kBlock) void logistic_from_uniform_kernel(const float* u, float* x, long n,
+                                                                       float mu, float sigma,
+                                                                       float eps) {
+    for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long)gridDim.x * kBlock) {
+        const float uf = (u[i] * (1.f - eps)) + eps / 2.f;
+        const double ud = (double)uf;
+        const float v = (float)(-log(1.0 / ud - 1.0));
+        x[i] = v * sigma + mu;
+    }
+}
+
+static inline int stream_grid(long n) {
+    const long blocks = (n + kBlock - 1) / kBlock;
+    return (int)std::min<long>(std::max<long>(blocks, 1), 256 * 8);
+}
+
+}  // namespace cnf
+
+using namespace cnf;
+
+#define DISPATCH_VEC(tl, CALL)            \
+    switch ((tl).vec) {                   \
+        case 4: { constexpr int V = 4; CALL; } break; \
+        case 2: { constexpr int V = 2; CALL; } break; \
+        default: { constexpr int V = 1; CALL; } break; \
+    }
+
+extern "C" {
+
+int cnf_affine_coupling(const float* z, const float* nn_out, const float* scaling_factor,
+                        const float* mask, int mask_rows, int mask_cols,
+                        const float* ldj_in, float* z_out, float* ldj_out,
+                        int B, int N, int D, int reverse, int* flags, cnf_stream_t stream) {
+    CNF_REQUIRE(z && nn_out && z_out && ldj_out, "cnf_affine_coupling: null tensor");
+    CNF_REQUIRE(B >= 0 && N > 0 && D > 0, "cnf_affine_coupling: bad shape B=%d N=%d D=%d", B, N, D);
+    if (B == 0) return CNF_OK;
+    if (!mask) { mask_rows = 1; mask_cols = D; }
+    CNF_REQUIRE(mask_rows >= 1 && (mask_cols == D || mask_cols == 1),
+                "cnf_affine_coupling: mask must be [rows,%d] or [rows,1], got [%d,%d]", D, mask_rows, mask_cols);
+    CNF_REQUIRE((long)N * D < 65536, "cnf_affine_coupling: N*D=%ld exceeds 65535", (long)N * D);
+    if (mask_rows > N) mask_rows = N;   // coupling_layer.py:72-73 truncation
+    if (mask_rows * D > kMaxTab) { set_error("cnf_affine_coupling: mask period %d x D %d too large", mask_rows, D); return CNF_ERR_UNSUPPORTED; }
+    AffineArgs a;
+    a.z = z; a.nn = nn_out; a.sf = scaling_factor; a.mask = mask; a.ldj_in = ldj_in;
+    a.z_out = z_out; a.ldj_out = ldj_out; a.flags = flags;
+    a.N = N; a.D = D; a.L = N * D; a.mr = mask_rows; a.mc = mask_cols; a.reverse = reverse;
+    a.div_d = make_fastdiv((uint32_t)D);
+    const RowTiling tl = make_row_tiling(B, a.L);
+    DISPATCH_VEC(tl, launch_affine<V>(a, tl, scaling_factor != nullptr, reverse != 0, (hipStream_t)stream));
+    return launch_status("cnf_affine_coupling");
+}
+
+int cnf_affine_params(const float* nn_out, const float* scaling_factor,
+                      const float* mask, int mask_rows, int mask_cols,
+                      float* s_out, float* t_out, int B, int N, int D, cnf_stream_t stream) {
+    CNF_REQUIRE(nn_out && s_out && t_out, "cnf_affine_params: null tensor");
+    CNF_REQUIRE(B >= 0 && N > 0 && D > 0, "cnf_affine_params: bad shape");
+    if (B == 0) return CNF_OK;
+    if (mask && mask_rows > N) mask_rows = N;
+    const long total = (long)B * N * D;
+    hipLaunchKernelGGL(affine_params_kernel, dim3(stream_grid(total)), dim3(kBlock), 0, (hipStream_t)stream,
+                       nn_out, scaling_factor, mask, mask_rows, mask_cols, s_out, t_out, total, N, D);
+    return launch_status("cnf_affine_params");
+}
+
+int cnf_affine_transform(const float* z, const float* s, const float* t,
+                         const float* ldj_in, float* z_out, float* ldj_out,
+                         int B, int N, int D, int reverse, int* flags, cnf_stream_t stream) {
+    CNF_REQUIRE(z && s && t && z_out && ldj_out, "cnf_affine_transform: null tensor");
+    CNF_REQUIRE(B >= 0 && N > 0 && D > 0, "cnf_affine_transform: bad shape");
+    if (B == 0) return CNF_OK;
+    TransformArgs a{z, s, t, ldj_in, z_out, ldj_out, flags, N * D, reverse};
+    const RowTiling tl = make_row_tiling(B, a.L);
+    DISPATCH_VEC(tl, hipLaunchKernelGGL((affine_transform_kernel<V>), tiling_grid(tl), dim3(kBlock), 0,
+                                        (hipStream_t)stream, a, tl));
+    return launch_status("cnf_affine_transform");
+}
+
+int cnf_ext_actnorm(const float* z, const float* nn_out, const float* pad,
+                    const float* ldj_in, float* z_out, float* ldj_out,
+                    int B, int N, int D, int reverse, int* flags, cnf_stream_t stream) {
+    CNF_REQUIRE(z && nn_out && z_out && ldj_out, "cnf_ext_actnorm: null tensor");
+    CNF_REQUIRE(B >= 0 && N > 0 && D > 0 && (long)N * D < 65536, "cnf_ext_actnorm: bad shape");
+    if (B == 0) return CNF_OK;
+    ExtArgs a{z, nn_out, pad, ldj_in, z_out, ldj_out, flags, N, D, N * D, reverse, make_fastdiv((uint32_t)D)};
+    const RowTiling tl = make_row_tiling(B, a.L);
+    DISPATCH_VEC(tl, hipLaunchKernelGGL((ext_actnorm_kernel<V>), tiling_grid(tl), dim3(kBlock), 0,
+                                        (hipStream_t)stream, a, tl));
+    return launch_status("cnf_ext_actnorm");
+}
+
+int cnf_sigmoid_flow(const float* z, const float* ldj_in, float* z_out, float* ldj_out,
+                     int B, int L, int reverse, float alpha, int* flags, cnf_stream_t stream) {
+    CNF_REQUIRE(z && z_out && ldj_out, "cnf_sigmoid_flow: null tensor");
+    CNF_REQUIRE(B >= 0 && L > 0, "cnf_sigmoid_flow: bad shape");
+    if (B == 0) return CNF_OK;
+    SigArgs a{z, ldj_in, z_out, ldj_out, flags, L, reverse, alpha, (float)log(1.0 - (double)alpha)};
+    const RowTiling tl = make_row_tiling(B, L);
+    DISPATCH_VEC(tl, hipLaunchKernelGGL((sigmoid_flow_kernel<V>), tiling_grid(tl), dim3(kBlock), 0,
+                                        (hipStream_t)stream, a, tl));
+    return launch_status("cnf_sigmoid_flow");
+}
+
+int cnf_logistic_log_prob(const float* x, float* logp, int64_t n, float mu, float sigma,
+                          float log_sigma, int* flags, cnf_stream_t stream) {
+    CNF_REQUIRE(x && logp && n >= 0, "cnf_logistic_log_prob: bad argument");
+    if (n == 0) return CNF_OK;
+    hipLaunchKernelGGL(logistic_log_prob_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, (hipStream_t)stream,
+                       x, logp, (long)n, mu, sigma, log_sigma, flags);
+    return launch_status("cnf_logistic_log_prob");
+}
+
+int cnf_logistic_from_uniform(const float* u, float* x, int64_t n, float mu, float sigma, float eps,
+                              cnf_stream_t stream) {
+    CNF_REQUIRE(u && x && n >= 0, "cnf_logistic_from_uniform: bad argument");
+    if (n == 0) return CNF_OK;
+    hipLaunchKernelGGL(logistic_from_uniform_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, (hipStream_t)stream,
+                       u, x, (long)n, mu, sigma, eps);
+    return launch_status("cnf_logistic_from_uniform");
+}
+
+int cnf_prior_nll(const float* z, const float* pad, const float* ldj, const float* length,
+                  float* neglog_out, float* nll_out, double* sums,
+                  int B, int N, int D, float sigma, float log_sigma, cnf_stream_t stream) {
+    CNF_REQUIRE(z, "cnf_prior_nll: null tensor");
+    CNF_REQUIRE(B >= 0 && N > 0 && D > 0 && (long)N * D < 65536, "cnf_prior_nll: bad shape");
+    if (B == 0) return CNF_OK;
+    NllArgs a{z, pad, ldj, length, neglog_out, nll_out, sums, N, D, N * D, sigma, log_sigma,
+              make_fastdiv((uint32_t)D)};
+    const RowTiling tl = make_row_tiling(B, a.L);
+    DISPATCH_VEC(tl, hipLaunchKernelGGL((prior_nll_kernel<V>), tiling_grid(tl), dim3(kBlock), 0,
+                                        (hipStream_t)stream, a, tl));
+    return launch_status("cnf_prior_nll");
+}
+
+}  // extern "C"

@@ -1,0 +1,159 @@
+// Shared host/device helpers for the gfx950 kernels of libcnf_hip.so.
+// CDNA4 only: wave = 64 lanes, no CUDA compatibility paths.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/cnf_hip.h"
+
+namespace cnf {
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;              // 4 waves per workgroup
+constexpr int kWavesPerBlock = kBlock / kWave;
+constexpr int kMaxTileChunks = 512;      // LDS partials one wave may own (floats)
+
+// ---- host-side status ------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+int launch_status(const char* what);     // CNF_OK or CNF_ERR_LAUNCH (+ message)
+int tile_chunks_target();
+int unroll_target();
+
+#define CNF_REQUIRE(cond, ...)                \
+    do {                                      \
+        if (!(cond)) {                        \
+            cnf::set_error(__VA_ARGS__);      \
+            return CNF_ERR_ARG;               \
+        }                                     \
+    } while (0)
+
+// Exact floor(n / d) for n, d < 65536 with one v_mul_hi_u32.
+struct FastDiv {
+    uint32_t magic;
+    uint32_t d;
+};
+inline FastDiv make_fastdiv(uint32_t d) {
+    FastDiv f;
+    f.d = d;
+    f.magic = d <= 1 ? 0u : (uint32_t)((0x100000000ull + d - 1) / d);
+    return f;
+}
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv f) {
+    return f.d <= 1 ? n : __umulhi(n, f.magic);
+}
+
+// How the rows (= samples, L contiguous elements each) of a [B, L] tensor are dealt to waves:
+// one wave owns `rw` consecutive rows per tile and walks them in chunks of VEC elements.
+struct RowTiling {
+    int B;          // rows
+    int L;          // elements per row
+    int vec;        // 4, 2 or 1 — largest of those dividing L, so a chunk never straddles rows
+    int cpr;        // chunks per row = L / vec
+    int rw;         // rows per wave-tile
+    int p2;         // power of two >= rw, capped at 64 (row slots reduced per pass)
+    long ntiles;
+    FastDiv div_cpr;
+};
+RowTiling make_row_tiling(int B, int L, int force_vec = 0);
+inline dim3 tiling_grid(const RowTiling& t) {
+    return dim3((unsigned)((t.ntiles + kWavesPerBlock - 1) / kWavesPerBlock));
+}
+
+// ---- device helpers ---------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
+    return v;
+}
+// sum inside aligned groups of g lanes (g a power of two <= 64); every lane gets its group's sum
+template <typename T>
+__device__ __forceinline__ T group_sum(T v, int g) {
+    for (int m = g >> 1; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
+    return v;
+}
+// make this wave's LDS writes visible to its own later reads (lanes exchange data through LDS)
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ void raise_flag(int* flags, int bit) {
+    if (flags) atomicOr(flags, bit);
+}
+
+// Walk one wave-tile.  For each chunk of VEC elements starting at element e0 of `row`:
+//   load_fn(row, e0) -> Data        issues the global loads (U chunks are issued back to back so
+//                                   that U x 48 B per lane are in flight before the first use);
+//   proc_fn(data, row, e0) -> T     computes, stores and returns the chunk's log-det contribution;
+//   finish_fn(row, sum)             stores the row's sum.
+// `part` is this wave's private LDS scratch (kMaxTileChunks values of T).
+template <int U, typename T, typename Data, typename LoadFn, typename ProcFn, typename FinishFn>
+__device__ __forceinline__ void walk_row_tile_split(const RowTiling& tl, T* part, LoadFn&& load_fn,
+                                                    ProcFn&& proc_fn, FinishFn&& finish_fn) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long tile = (long)blockIdx.x * kWavesPerBlock + wave;
+    if (tile >= tl.ntiles) return;
+    const int row0 = (int)(tile * tl.rw);
+    const int nrows = min(tl.rw, tl.B - row0);
+    const int nch = nrows * tl.cpr;
+    T acc1 = 0;
+    for (int c0 = lane; c0 < nch; c0 += kWave * U) {
+        Data dat[U];
+        int rr[U], ee[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = c0 + kWave * u;
+            const int r = tl.rw == 1 ? 0 : (int)fdiv((uint32_t)c, tl.div_cpr);
+            rr[u] = row0 + r;
+            ee[u] = (c - r * tl.cpr) * tl.vec;
+            if (c < nch) dat[u] = load_fn(rr[u], ee[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = c0 + kWave * u;
+            if (c < nch) {
+                const T v = proc_fn(dat[u], rr[u], ee[u]);
+                if (tl.rw == 1) acc1 += v;
+                else part[c] = v;
+            }
+        }
+    }
+    if (tl.rw == 1) {
+        acc1 = wave_sum(acc1);
+        if (lane == 0) finish_fn(row0, acc1);
+        return;
+    }
+    wave_lds_sync();
+    const int g = kWave / tl.p2;          // lanes cooperating on one row
+    const int sub = lane & (g - 1);
+    for (int r0 = 0; r0 < nrows; r0 += tl.p2) {
+        const int r = r0 + lane / g;
+        T acc = 0;
+        if (r < nrows)
+            for (int i = sub; i < tl.cpr; i += g) acc += part[r * tl.cpr + i];
+        acc = group_sum(acc, g);
+        if (sub == 0 && r < nrows) finish_fn(row0 + r, acc);
+    }
+}
+
+// Single-functor form: chunk_fn(row, e0) loads, computes, stores and returns the contribution.
+template <typename T, typename ChunkFn, typename FinishFn>
+__device__ __forceinline__ void walk_row_tile(const RowTiling& tl, T* part, ChunkFn&& chunk_fn,
+                                              FinishFn&& finish_fn) {
+    struct Nothing {};
+    walk_row_tile_split<1, T, Nothing>(
+        tl, part, [](int, int) { return Nothing{}; },
+        [&](const Nothing&, int row, int e0) { return chunk_fn(row, e0); }, finish_fn);
+}
+
+// expanded coupling mask value (coupling_layer.py:67-74): rows tile along N, cols broadcast over D
+__device__ __forceinline__ float mask_at(const float* mask, int mr, int mc, int n, int d) {
+    if (!mask) return 0.f;
+    const int r = mr == 1 ? 0 : n % mr;
+    return mask[r * mc + (mc == 1 ? 0 : d)];
+}
+
+}  // namespace cnf

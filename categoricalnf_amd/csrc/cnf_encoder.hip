@@ -1,0 +1,218 @@
+// Mixture-model categorical encoder (LinearCategoricalEncoding with num_flows == 0):
+// forward = class-conditional affine push of logistic noise + the per-category log-prob over ALL
+// classes (posterior) ; reverse = argmax decode.  linear_encoding.py:59-133,153-196.
+//
+// One lane per token.  The per-class flow (one ExtActNorm whose predictor input is the class
+// embedding) collapses to a table [C, 2D]; its derived constants live in LDS:
+//   bias[c][d], ts = tanh(scale_raw), e^{ts}, e^{-ts}, sum_d ts.
+// The reference materialises [T*C, 1, D] tensors and runs an embedding + Linear for every class
+// (:155-160); here the C x D loop runs in registers and the log-sum-exp is streamed.
+#include "cnf_common.h"
+
+#include <algorithm>
+
+namespace cnf {
+
+struct EncArgs {
+    const int64_t* categ;
+    const float* eps;
+    const float* z_in;       // decode
+    const float* table;      // [C, 2D]
+    const float* prior;      // [C]
+    const float* pad;        // [B*N] or null
+    const float* ldj_in;
+    float* z_out;
+    float* ldj_out;
+    float* cpl;              // class_prob_log [B*N] or null
+    int64_t* categ_out;
+    int* flags;
+    int B, N, D, C;
+    float beta, sigma, log_sigma;
+};
+
+__device__ __forceinline__ float softplus_t20(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+// LogisticDistribution.log_prob (distributions.py:129-136,154-163), mu = 0
+__device__ __forceinline__ float logistic_logp0(float x, float sigma, float log_sigma) {
+    const float v = x / sigma;
+    return -(softplus_t20(v) + softplus_t20(-v) + log_sigma);
+}
+
+// LDS layout per class: [bias D | ts D | e^ts D | e^-ts D | sum_ts], stride 4D+1 (odd -> no bank conflicts)
+__device__ __forceinline__ void build_class_table(const EncArgs& a, float* tab) {
+    const int stride = 4 * a.D + 1;
+    for (int i = threadIdx.x; i < a.C * a.D; i += blockDim.x) {
+        const int c = i / a.D, d = i - c * a.D;
+        const float ts = tanhf(a.table[(size_t)c * 2 * a.D + a.D + d]);
+        float* t = tab + c * stride;
+        t[d] = a.table[(size_t)c * 2 * a.D + d];
+        t[a.D + d] = ts;
+        t[2 * a.D + d] = expf(ts);
+        t[3 * a.D + d] = expf(-ts);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < a.C; c += blockDim.x) {
+        float* t = tab + c * stride;
+        float s = 0.f;
+        for (int d = 0; d < a.D; ++d) s += t[a.D + d];
+        t[4 * a.D] = s;
+    }
+    __syncthreads();
+}
+
+// score of class j at point z (reverse flow log-prob + ldj + prior), linear_encoding.py:159-164
+template <int DT>
+__device__ __forceinline__ float class_score(const float* t, const float* z, int D, float prior_j,
+                                             float sigma, float log_sigma) {
+    float lp = 0.f;
+    const int DD = DT > 0 ? DT : D;
+#pragma unroll
+    for (int d = 0; d < DD; ++d) {
+        const float zb = z[d] * t[3 * D + d] - t[d];
+        lp += logistic_logp0(zb, sigma, log_sigma);
+    }
+    return (lp + (-t[4 * D])) + prior_j;
+}
+
+constexpr int kEncMaxD = 16;
+
+template <int DT>
+__global__ __launch_bounds__(kBlock) void encoder_forward_kernel(EncArgs a, RowTiling tl) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* part_all = reinterpret_cast<float*>(smem);
+    float* tab = part_all + kWavesPerBlock * kMaxTileChunks;
+    build_class_table(a, tab);
+    const int D = DT > 0 ? DT : a.D;
+    const int stride = 4 * D + 1;
+    bool bad = false;
+
+    auto chunk = [&](int row, int n) -> float {
+        const size_t tok = (size_t)row * a.N + n;
+        const int c = (int)a.categ[tok];
+        const float* tc = tab + c * stride;
+        float z[DT > 0 ? DT : kEncMaxD];
+        float init_lp = 0.f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const float e = a.eps[tok * D + d];
+            init_lp += logistic_logp0(e, a.sigma, a.log_sigma);
+            z[d] = (e + tc[d]) * tc[2 * D + d];
+        }
+        const float ldj_f = tc[4 * D];
+        const float log_point = (init_lp - ldj_f) + a.prior[c];
+        // streamed log-sum-exp over the classes; the true class uses the forward value (:167-168)
+        float m = -INFINITY, s = 0.f;
+        for (int j = 0; j < a.C; ++j) {
+            const float v = j == c ? log_point
+                                   : class_score<DT>(tab + j * stride, z, D, a.prior[j], a.sigma, a.log_sigma);
+            if (v > m) {
+                s = s * expf(m - v) + 1.f;
+                m = v;
+            } else {
+                s += expf(v - m);
+            }
+        }
+        const float cpl = log_point - (m + logf(s));
+        const float pv = a.pad ? a.pad[tok] : 1.f;
+        if (a.cpl) a.cpl[tok] = cpl;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const float o = z[d] * pv;
+            bad |= isnan(o);
+            a.z_out[tok * D + d] = o;
+        }
+        return (a.beta * cpl - (init_lp - ldj_f)) * pv;
+    };
+    auto finish = [&](int row, float sum) {
+        const float v = (a.ldj_in ? a.ldj_in[row] : 0.f) + sum;
+        a.ldj_out[row] = v;
+        if (isnan(v)) raise_flag(a.flags, CNF_FLAG_NAN_LDJ);
+    };
+    walk_row_tile<float>(tl, part_all + (threadIdx.x >> 6) * kMaxTileChunks, chunk, finish);
+    if (bad) raise_flag(a.flags, CNF_FLAG_NAN_Z);
+}
+
+template <int DT>
+__global__ __launch_bounds__(kBlock) void encoder_decode_kernel(EncArgs a, long ntok) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* tab = reinterpret_cast<float*>(smem);
+    build_class_table(a, tab);
+    const int D = DT > 0 ? DT : a.D;
+    const int stride = 4 * D + 1;
+    for (long tok = (long)blockIdx.x * kBlock + threadIdx.x; tok < ntok; tok += (long)gridDim.x * kBlock) {
+        float z[DT > 0 ? DT : kEncMaxD];
+#pragma unroll
+        for (int d = 0; d < D; ++d) z[d] = a.z_in[tok * D + d];
+        float best = -INFINITY;
+        int arg = 0;
+        for (int j = 0; j < a.C; ++j) {
+            const float v = class_score<DT>(tab + j * stride, z, D, a.prior[j], a.sigma, a.log_sigma);
+            if (j == 0 || v > best) {   // first maximum wins, like torch.argmax
+                best = v;
+                arg = j;
+            }
+        }
+        a.categ_out[tok] = (int64_t)arg;
+    }
+}
+
+}  // namespace cnf
+
+using namespace cnf;
+
+static size_t table_bytes(int C, int D) { return (size_t)C * (4 * D + 1) * sizeof(float); }
+
+#define DISPATCH_D(D, CALL)                               \
+    switch (D) {                                          \
+        case 1: { constexpr int DT = 1; CALL; } break;    \
+        case 2: { constexpr int DT = 2; CALL; } break;    \
+        case 3: { constexpr int DT = 3; CALL; } break;    \
+        case 4: { constexpr int DT = 4; CALL; } break;    \
+        case 6: { constexpr int DT = 6; CALL; } break;    \
+        case 8: { constexpr int DT = 8; CALL; } break;    \
+        default: { constexpr int DT = 0; CALL; } break;   \
+    }
+
+extern "C" {
+
+int cnf_encoder_forward(const int64_t* categ, const float* eps, const float* table,
+                        const float* category_prior, const float* pad, float beta,
+                        const float* ldj_in, float* z_out, float* ldj_out, float* class_prob_log,
+                        int B, int N, int D, int C, float sigma, float log_sigma,
+                        int* flags, cnf_stream_t stream) {
+    CNF_REQUIRE(categ && eps && table && category_prior && z_out && ldj_out, "cnf_encoder_forward: null tensor");
+    CNF_REQUIRE(B >= 0 && N > 0 && D > 0 && C > 0, "cnf_encoder_forward: bad shape");
+    if (B == 0) return CNF_OK;
+    CNF_REQUIRE(D <= kEncMaxD, "cnf_encoder_forward: D=%d exceeds %d", D, kEncMaxD);
+    CNF_REQUIRE(N < 65536, "cnf_encoder_forward: N=%d exceeds 65535", N);
+    const size_t smem = (size_t)kWavesPerBlock * kMaxTileChunks * sizeof(float) + table_bytes(C, D);
+    if (smem > 64 * 1024) { set_error("cnf_encoder_forward: class table for C=%d D=%d exceeds LDS", C, D); return CNF_ERR_UNSUPPORTED; }
+    EncArgs a = {};
+    a.categ = categ; a.eps = eps; a.table = table; a.prior = category_prior; a.pad = pad;
+    a.ldj_in = ldj_in; a.z_out = z_out; a.ldj_out = ldj_out; a.cpl = class_prob_log; a.flags = flags;
+    a.B = B; a.N = N; a.D = D; a.C = C; a.beta = beta; a.sigma = sigma; a.log_sigma = log_sigma;
+    const RowTiling tl = make_row_tiling(B, N, /*force_vec=*/1);
+    DISPATCH_D(D, hipLaunchKernelGGL((encoder_forward_kernel<DT>), tiling_grid(tl), dim3(kBlock), smem,
+                                     (hipStream_t)stream, a, tl));
+    return launch_status("cnf_encoder_forward");
+}
+
+int cnf_encoder_decode(const float* z, const float* table, const float* category_prior,
+                       int64_t* categ_out, int B, int N, int D, int C, float sigma, float log_sigma,
+                       cnf_stream_t stream) {
+    CNF_REQUIRE(z && table && category_prior && categ_out, "cnf_encoder_decode: null tensor");
+    CNF_REQUIRE(B >= 0 && N > 0 && D > 0 && C > 0, "cnf_encoder_decode: bad shape");
+    if (B == 0) return CNF_OK;
+    CNF_REQUIRE(D <= kEncMaxD, "cnf_encoder_decode: D=%d exceeds %d", D, kEncMaxD);
+    const size_t smem = table_bytes(C, D);
+    if (smem > 64 * 1024) { set_error("cnf_encoder_decode: class table for C=%d D=%d exceeds LDS", C, D); return CNF_ERR_UNSUPPORTED; }
+    EncArgs a = {};
+    a.z_in = z; a.table = table; a.prior = category_prior; a.categ_out = categ_out;
+    a.B = B; a.N = N; a.D = D; a.C = C; a.sigma = sigma; a.log_sigma = log_sigma;
+    const long ntok = (long)B * N;
+    const int grid = (int)std::min<long>((ntok + kBlock - 1) / kBlock, 256 * 8);
+    DISPATCH_D(D, hipLaunchKernelGGL((encoder_decode_kernel<DT>), dim3(grid), dim3(kBlock), smem,
+                                     (hipStream_t)stream, a, ntok));
+    return launch_status("cnf_encoder_decode");
+}
+
+}  // extern "C"

@@ -1,0 +1,76 @@
+// Host-side plumbing of libcnf_hip.so: status strings, launch checks, row tiling.
+#include "cnf_common.h"
+
+#include <algorithm>
+#include <string.h>
+
+namespace cnf {
+
+static thread_local char g_err[512] = "";
+static int g_tile_chunks = 256;
+static int g_unroll = 4;
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int launch_status(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return CNF_OK;
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return CNF_ERR_LAUNCH;
+}
+
+int tile_chunks_target() { return g_tile_chunks; }
+int unroll_target() { return g_unroll; }
+
+RowTiling make_row_tiling(int B, int L, int force_vec) {
+    RowTiling t;
+    t.B = B;
+    t.L = L;
+    t.vec = force_vec ? force_vec : (L % 4 == 0 ? 4 : (L % 2 == 0 ? 2 : 1));
+    t.cpr = L / t.vec;
+    const int target = std::min(g_tile_chunks, kMaxTileChunks);
+    int best = 1;
+    if (t.cpr < target) {
+        // rows per wave: keep the 64 lanes busy (chunks close to a multiple of 64), prefer more rows
+        double best_eff = -1.0;
+        const int rmax = std::max(1, std::min(target / t.cpr, std::max(1, B)));
+        for (int r = 1; r <= rmax; ++r) {
+            const int ch = r * t.cpr;
+            const double eff = (double)ch / (double)(((ch + kWave - 1) / kWave) * kWave);
+            if (eff >= best_eff - 1e-9) {
+                best_eff = std::max(eff, best_eff);
+                best = r;
+            }
+        }
+    }
+    t.rw = best;
+    int p2 = 1;
+    while (p2 < t.rw && p2 < kWave) p2 <<= 1;
+    t.p2 = p2;
+    t.ntiles = ((long)B + t.rw - 1) / t.rw;
+    t.div_cpr = make_fastdiv((uint32_t)t.cpr);
+    return t;
+}
+
+}  // namespace cnf
+
+extern "C" {
+
+int cnf_abi_version(void) { return 1; }
+
+const char* cnf_last_error(void) { return cnf::g_err; }
+
+void cnf_set_tile_chunks(int chunks) {
+    if (chunks >= 64 && chunks <= cnf::kMaxTileChunks) cnf::g_tile_chunks = chunks;
+}
+
+void cnf_set_unroll(int u) {
+    if (u == 1 || u == 2 || u == 3 || u == 4) cnf::g_unroll = u;
+}
+
+}  // extern "C"

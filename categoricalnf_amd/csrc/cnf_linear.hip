@@ -1,0 +1,280 @@
+// ActNorm (per-channel affine) and the invertible 1x1 convolution: 8 B/elem streaming kernels whose
+// log-det is analytic (no reduction over elements), plus the data-dependent-init statistics.
+#include "cnf_common.h"
+
+#include <algorithm>
+
+namespace cnf {
+
+constexpr int kMaxD = 64;   // channels staged in LDS
+
+struct ActNormArgs {
+    const float* z;
+    const float* bias;
+    const float* scales;
+    const float* pad;
+    const float* length;
+    const float* ldj_in;
+    float* z_out;
+    float* ldj_out;
+    int* flags;
+    int B, N, D, reverse;
+    long total;         // B*N*D
+};
+
+// activation_normalization.py:24-48.  Flat float4 streaming; channel = element index mod D.
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void actnorm_kernel(ActNormArgs a) {
+    __shared__ float sb[kMaxD], se[kMaxD];
+    __shared__ float ssum;
+    for (int d = threadIdx.x; d < a.D; d += kBlock) {
+        sb[d] = a.bias[d];
+        se[d] = a.reverse ? expf(-a.scales[d]) : expf(a.scales[d]);
+    }
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int d = 0; d < a.D; ++d) s += a.scales[d];   // scales.sum(dim=[1,2])
+        ssum = a.reverse ? -s : s;
+    }
+    __syncthreads();
+
+    bool bad = false;
+    const long nvec = a.total / VEC;
+    for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < nvec; i += (long)gridDim.x * kBlock) {
+        const long e0 = i * VEC;
+        float v[VEC];
+        if (VEC == 4) {
+            const float4 q = *reinterpret_cast<const float4*>(a.z + e0);
+            v[0] = q.x; v[1] = q.y; v[VEC > 2 ? 2 : 0] = q.z; v[VEC > 3 ? 3 : 0] = q.w;
+        } else {
+            for (int j = 0; j < VEC; ++j) v[j] = a.z[e0 + j];
+        }
+        long tok = e0 / a.D;
+        int d = (int)(e0 - tok * a.D);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            float o = a.reverse ? v[j] * se[d] - sb[d] : (v[j] + sb[d]) * se[d];
+            if (a.pad) o = o * a.pad[tok];
+            bad |= isnan(o);
+            v[j] = o;
+            if (++d == a.D) {
+                d = 0;
+                ++tok;
+            }
+        }
+        if (VEC == 4) {
+            *reinterpret_cast<float4*>(a.z_out + e0) = make_float4(v[0], v[1], v[VEC > 2 ? 2 : 0], v[VEC > 3 ? 3 : 0]);
+        } else {
+            for (int j = 0; j < VEC; ++j) a.z_out[e0 + j] = v[j];
+        }
+    }
+    if (bad) raise_flag(a.flags, CNF_FLAG_NAN_Z);
+
+    // analytic log-det: one thread per sample
+    for (long b = (long)blockIdx.x * kBlock + threadIdx.x; b < a.B; b += (long)gridDim.x * kBlock) {
+        float len;
+        if (a.length) {
+            len = a.length[b];
+        } else if (a.pad) {
+            len = 0.f;
+            for (int n = 0; n < a.N; ++n) len += a.pad[b * a.N + n];
+        } else {
+            len = (float)a.N;
+        }
+        const float v = (a.ldj_in ? a.ldj_in[b] : 0.f) + ssum * len;
+        a.ldj_out[b] = v;
+        if (isnan(v)) raise_flag(a.flags, CNF_FLAG_NAN_LDJ);
+    }
+}
+
+// activation_normalization.py:55-67 statistics (fp64 accumulation, one atomic per wave and channel)
+__global__ __launch_bounds__(kBlock) void actnorm_stats_kernel(const float* z, const float* pad,
+                                                               const double* mean, double* out,
+                                                               long ntok, int D, int pass) {
+    // each thread owns channel d = threadIdx.x % D of tokens strided by the block; D <= kMaxD
+    const int lanes_per_tok = D;
+    const int toks_per_block = kBlock / lanes_per_tok;
+    const int slot = threadIdx.x / lanes_per_tok, d = threadIdx.x % lanes_per_tok;
+    double acc = 0.0, cnt = 0.0;
+    if (slot < toks_per_block) {
+        const double m = pass == 1 ? mean[d] : 0.0;
+        for (long t = (long)blockIdx.x * toks_per_block + slot; t < ntok; t += (long)gridDim.x * toks_per_block) {
+            const double w = pad ? (double)pad[t] : 1.0;
+            const double x = (double)z[t * D + d];
+            acc += pass == 0 ? x * w : (x - m) * (x - m) * w;
+            cnt += w;
+        }
+    }
+    __shared__ double sacc[kBlock], scnt[kBlock];
+    sacc[threadIdx.x] = acc;
+    scnt[threadIdx.x] = cnt;
+    __syncthreads();
+    if (threadIdx.x < D) {
+        double s = 0.0, c = 0.0;
+        for (int k = 0; k < toks_per_block; ++k) {
+            s += sacc[k * D + threadIdx.x];
+            c += scnt[k * D + threadIdx.x];
+        }
+        atomicAdd(&out[threadIdx.x], s);
+        if (pass == 0 && threadIdx.x == 0) atomicAdd(&out[D], c);
+    }
+}
+
+struct ConvArgs {
+    const float* x;
+    const float* w;      // [D,D] row-major, z' = x @ W
+    const float* sldj;   // device scalar
+    const float* pad;
+    const float* length;
+    const float* ldj_in;
+    float* z_out;
+    float* ldj_out;
+    int* flags;
+    int B, N, D, reverse;
+    long ntok;
+};
+
+// permutation_layers.py:106-136.  One lane per token, the D-vector in registers, W broadcast
+// through scalar loads (uniform addresses).  The dot product runs i = 0..D-1 in order.
+template <int D>
+__global__ __launch_bounds__(kBlock) void invconv_kernel(ConvArgs a) {
+    bool bad = false;
+    for (long t = (long)blockIdx.x * kBlock + threadIdx.x; t < a.ntok; t += (long)gridDim.x * kBlock) {
+        float xv[D], ov[D];
+        const float* src = a.x + t * D;
+        if (D % 4 == 0) {
+#pragma unroll
+            for (int i = 0; i < D; i += 4) {
+                const float4 q = *reinterpret_cast<const float4*>(src + i);
+                xv[i] = q.x; xv[i + 1] = q.y; xv[i + 2] = q.z; xv[i + 3] = q.w;
+            }
+        } else if (D % 2 == 0) {
+#pragma unroll
+            for (int i = 0; i < D; i += 2) {
+                const float2 q = *reinterpret_cast<const float2*>(src + i);
+                xv[i] = q.x; xv[i + 1] = q.y;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < D; ++i) xv[i] = src[i];
+        }
+        const float p = a.pad ? a.pad[t] : 1.f;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < D; ++i) acc = fmaf(xv[i], a.w[i * D + j], acc);
+            if (a.pad) acc = acc * p;
+            bad |= isnan(acc);
+            ov[j] = acc;
+        }
+        float* dst = a.z_out + t * D;
+        if (D % 4 == 0) {
+#pragma unroll
+            for (int i = 0; i < D; i += 4) *reinterpret_cast<float4*>(dst + i) = make_float4(ov[i], ov[i + 1], ov[i + 2], ov[i + 3]);
+        } else if (D % 2 == 0) {
+#pragma unroll
+            for (int i = 0; i < D; i += 2) *reinterpret_cast<float2*>(dst + i) = make_float2(ov[i], ov[i + 1]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < D; ++i) dst[i] = ov[i];
+        }
+    }
+    if (bad) raise_flag(a.flags, CNF_FLAG_NAN_Z);
+    const float sl = a.sldj[0];
+    for (long b = (long)blockIdx.x * kBlock + threadIdx.x; b < a.B; b += (long)gridDim.x * kBlock) {
+        const float s = sl * (a.length ? a.length[b] : (float)a.N);
+        const float base = a.ldj_in ? a.ldj_in[b] : 0.f;
+        const float v = a.reverse ? base - s : base + s;
+        a.ldj_out[b] = v;
+        if (isnan(v)) raise_flag(a.flags, CNF_FLAG_NAN_LDJ);
+    }
+}
+
+// any D: one lane per output element
+__global__ __launch_bounds__(kBlock) void invconv_generic_kernel(ConvArgs a) {
+    const int D = a.D;
+    bool bad = false;
+    const long total = a.ntok * D;
+    for (long e = (long)blockIdx.x * kBlock + threadIdx.x; e < total; e += (long)gridDim.x * kBlock) {
+        const long t = e / D;
+        const int j = (int)(e - t * D);
+        float acc = 0.f;
+        for (int i = 0; i < D; ++i) acc = fmaf(a.x[t * D + i], a.w[i * D + j], acc);
+        if (a.pad) acc = acc * a.pad[t];
+        bad |= isnan(acc);
+        a.z_out[e] = acc;
+    }
+    if (bad) raise_flag(a.flags, CNF_FLAG_NAN_Z);
+    const float sl = a.sldj[0];
+    for (long b = (long)blockIdx.x * kBlock + threadIdx.x; b < a.B; b += (long)gridDim.x * kBlock) {
+        const float s = sl * (a.length ? a.length[b] : (float)a.N);
+        const float base = a.ldj_in ? a.ldj_in[b] : 0.f;
+        a.ldj_out[b] = a.reverse ? base - s : base + s;
+    }
+}
+
+static inline int stream_grid(long n) {
+    const long blocks = (n + kBlock - 1) / kBlock;
+    return (int)std::min<long>(std::max<long>(blocks, 1), 256 * 8);
+}
+
+}  // namespace cnf
+
+using namespace cnf;
+
+extern "C" {
+
+int cnf_actnorm(const float* z, const float* bias, const float* scales,
+                const float* pad, const float* length,
+                const float* ldj_in, float* z_out, float* ldj_out,
+                int B, int N, int D, int reverse, int* flags, cnf_stream_t stream) {
+    CNF_REQUIRE(z && bias && scales && z_out && ldj_out, "cnf_actnorm: null tensor");
+    CNF_REQUIRE(B >= 0 && N > 0 && D > 0 && D <= kMaxD, "cnf_actnorm: bad shape B=%d N=%d D=%d (D<=%d)", B, N, D, kMaxD);
+    if (B == 0) return CNF_OK;
+    ActNormArgs a{z, bias, scales, pad, length, ldj_in, z_out, ldj_out, flags, B, N, D, reverse, (long)B * N * D};
+    const long work = std::max<long>(a.total / 4, B);
+    if (a.total % 4 == 0)
+        hipLaunchKernelGGL((actnorm_kernel<4>), dim3(stream_grid(work)), dim3(kBlock), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL((actnorm_kernel<1>), dim3(stream_grid(a.total)), dim3(kBlock), 0, (hipStream_t)stream, a);
+    return launch_status("cnf_actnorm");
+}
+
+int cnf_actnorm_stats(const float* z, const float* pad, const double* mean, double* out,
+                      int B, int N, int D, int pass, cnf_stream_t stream) {
+    CNF_REQUIRE(z && out && (pass == 0 || mean), "cnf_actnorm_stats: null tensor");
+    CNF_REQUIRE(B > 0 && N > 0 && D > 0 && D <= kMaxD, "cnf_actnorm_stats: bad shape");
+    const long ntok = (long)B * N;
+    const int tpb = kBlock / D;
+    const int grid = (int)std::min<long>((ntok + tpb - 1) / tpb, 1024);
+    hipLaunchKernelGGL(actnorm_stats_kernel, dim3(std::max(grid, 1)), dim3(kBlock), 0, (hipStream_t)stream,
+                       z, pad, mean, out, ntok, D, pass);
+    return launch_status("cnf_actnorm_stats");
+}
+
+int cnf_invconv(const float* x, const float* weight, const float* sldj,
+                const float* pad, const float* length,
+                const float* ldj_in, float* z_out, float* ldj_out,
+                int B, int N, int D, int reverse, int* flags, cnf_stream_t stream) {
+    CNF_REQUIRE(x && weight && sldj && z_out && ldj_out, "cnf_invconv: null tensor");
+    CNF_REQUIRE(B >= 0 && N > 0 && D > 0, "cnf_invconv: bad shape");
+    if (B == 0) return CNF_OK;
+    ConvArgs a{x, weight, sldj, pad, length, ldj_in, z_out, ldj_out, flags, B, N, D, reverse, (long)B * N};
+    const dim3 grid(stream_grid(std::max<long>(a.ntok, B))), block(kBlock);
+    hipStream_t st = (hipStream_t)stream;
+    switch (D) {
+        case 1: hipLaunchKernelGGL((invconv_kernel<1>), grid, block, 0, st, a); break;
+        case 2: hipLaunchKernelGGL((invconv_kernel<2>), grid, block, 0, st, a); break;
+        case 3: hipLaunchKernelGGL((invconv_kernel<3>), grid, block, 0, st, a); break;
+        case 4: hipLaunchKernelGGL((invconv_kernel<4>), grid, block, 0, st, a); break;
+        case 5: hipLaunchKernelGGL((invconv_kernel<5>), grid, block, 0, st, a); break;
+        case 6: hipLaunchKernelGGL((invconv_kernel<6>), grid, block, 0, st, a); break;
+        case 8: hipLaunchKernelGGL((invconv_kernel<8>), grid, block, 0, st, a); break;
+        default:
+            hipLaunchKernelGGL(invconv_generic_kernel, dim3(stream_grid(a.ntok * D)), block, 0, st, a);
+    }
+    return launch_status("cnf_invconv");
+}
+
+}  // extern "C"

@@ -1,0 +1,504 @@
+// Logistic-mixture CDF coupling (Flow++ style) — forward, bisection inverse, log-det — in fp64,
+// following mixture_cdf_layer.py:95-180, 197-276 of the reference.
+//
+// Work item = one TRANSFORMED element (b, n, d): masked channels are never evaluated (the
+// reference evaluates them on all-zero parameters and then overwrites the result, :137-138), they
+// are copied through.  One wave owns whole samples; the per-sample log-det is summed in fp64
+// through the wave's private LDS strip, in a fixed order.
+//
+// Arithmetic: the reference works in log space and exponentiates immediately
+// (`mixture_log_cdf(...).exp()`, :105).  Here the mixture CDF and PDF are accumulated directly,
+//     u   = sum_k w_k sigma(z_k) / sum_k w_k,        w_k = exp(log_pi_k - max log_pi)
+//     pdf = sum_k w_k e^{-ls_k} sigma(z_k)(1 - sigma(z_k)) / sum_k w_k,
+// which is the same quantity to fp64 rounding (3 exp + 1 divide per mixture instead of ~6
+// transcendentals); if the PDF sum underflows, the element falls back to the log-space form.
+#include "cnf_common.h"
+
+#include <algorithm>
+
+namespace cnf {
+
+constexpr int kMaxAct = 64;          // channels per token
+constexpr double kLn10 = 2.302585092994045684;
+
+struct MixArgs {
+    // fused (module) form: fp32 z / nn_out
+    const float* z;
+    const float* nn;
+    const float* sf;
+    const float* msf;
+    // split (static API) form: fp64 tensors
+    const double* z64;
+    const double* p_t;
+    const double* p_log_s;
+    const double* p_log_pi;
+    const double* p_mu;
+    const double* p_ls;
+    const float* mask;
+    const float* pad;
+    const float* ldj_in;
+    float* z_out;
+    float* ldj_out;
+    float* reg_out;
+    double* z_out64;
+    double* ldj_out64;
+    double* reg_elem64;
+    int* flags;
+    int B, N, D, K, P, L;
+    int mr, mc;
+    int DA;                 // transformed channels per token (channel mask) or D (per-item test)
+    unsigned long long act_bits;   // bit d set = channel d is transformed (a list cannot be indexed per lane)
+    int per_item_mask;      // 1: mask varies along N (chess) -> test every item
+    int reverse, pad_in_transform, pad_output, use_reg;
+    double reg_max, reg_factor;
+    FastDiv div_d, div_da;
+};
+
+__device__ __forceinline__ double safe_log(double x) { return log(fmax(x, 1e-22)); }
+
+// F.softplus (beta 1, threshold 20) and F.logsigmoid in fp64, as torch evaluates them
+__device__ __forceinline__ double softplus64(double x) { return x > 20.0 ? x : log1p(exp(x)); }
+
+// Per-element parameter access.  FUSED: read the fp32 subnet row and apply the tanh bounds in fp32
+// exactly like get_mixt_params (:156-162) before widening; SPLIT: read the fp64 tensors.
+template <bool SPLIT>
+struct ParamRow {
+    // plain values only: holding a reference to the kernel-argument block would force a stack copy
+    const float* row;     // fused: start of this channel's P-block of nn_out
+    const float* sf_d;    // fused: &scaling_factor[d] or null
+    const float* msf_d;   // fused: &mixture_scaling_factor[d*K] or null
+    const double* pt;     // split: &t[elem], &log_s[elem], &log_pi[elem*K] ...
+    const double* pls;
+    const double* ppi;
+    const double* pmu;
+    const double* pmls;
+    int K;
+    __device__ __forceinline__ ParamRow(const MixArgs& a, size_t elem, int d) {
+        K = a.K;
+        if (SPLIT) {
+            pt = a.p_t + elem; pls = a.p_log_s + elem;
+            ppi = a.p_log_pi + elem * K; pmu = a.p_mu + elem * K; pmls = a.p_ls + elem * K;
+            row = nullptr; sf_d = nullptr; msf_d = nullptr;
+        } else {
+            row = a.nn + elem * a.P;
+            sf_d = a.sf ? a.sf + d : nullptr;
+            msf_d = a.msf ? a.msf + (size_t)d * K : nullptr;
+            pt = pls = ppi = pmu = pmls = nullptr;
+        }
+    }
+    __device__ __forceinline__ double t() const { return SPLIT ? pt[0] : (double)row[0]; }
+    __device__ __forceinline__ double log_s() const {
+        if (SPLIT) return pls[0];
+        float v = row[1];
+        if (sf_d) {
+            const float f = expf(sf_d[0]);
+            v = tanhf(v / fmaxf(f, 1.f)) * f;
+        }
+        return (double)v;
+    }
+    __device__ __forceinline__ double log_pi(int k) const { return SPLIT ? ppi[k] : (double)row[2 + k]; }
+    __device__ __forceinline__ double mu(int k) const { return SPLIT ? pmu[k] : (double)row[2 + K + k]; }
+    __device__ __forceinline__ double ls(int k) const {
+        if (SPLIT) return pmls[k];
+        float v = row[2 + 2 * K + k];
+        if (msf_d) {
+            const float f = expf(msf_d[k]);
+            v = tanhf(v / fmaxf(f, 1.f)) * f;
+        }
+        return (double)v;
+    }
+};
+
+// log-space mixture log-pdf (:217-223) — only used when the direct sum underflows
+template <bool SPLIT>
+__device__ __noinline__ double log_pdf_logspace(const ParamRow<SPLIT> p, int K, double x, double lse_pi) {
+    double m = -INFINITY;
+    for (int k = 0; k < K; ++k) {
+        const double ls = p.ls(k);
+        const double zk = (x - p.mu(k)) * exp(-ls);
+        m = fmax(m, p.log_pi(k) - lse_pi + zk - ls - 2.0 * softplus64(zk));
+    }
+    double s = 0.0;
+    for (int k = 0; k < K; ++k) {
+        const double ls = p.ls(k);
+        const double zk = (x - p.mu(k)) * exp(-ls);
+        s += exp(p.log_pi(k) - lse_pi + zk - ls - 2.0 * softplus64(zk) - m);
+    }
+    return m + log(s);
+}
+
+struct MixEval {
+    double u;        // mixture CDF at x
+    double log_pdf;  // mixture log-PDF at x
+};
+
+// one pass over the K mixtures at point x
+template <bool SPLIT>
+__device__ __forceinline__ MixEval eval_mixture(const ParamRow<SPLIT>& p, int K, double x) {
+    double mx = -INFINITY;
+    for (int k = 0; k < K; ++k) mx = fmax(mx, p.log_pi(k));
+    double se = 0.0, cdf = 0.0, pdf = 0.0;
+    for (int k = 0; k < K; ++k) {
+        const double w = exp(p.log_pi(k) - mx);
+        const double inv_s = exp(-p.ls(k));
+        const double zk = (x - p.mu(k)) * inv_s;
+        const double e = exp(-fabs(zk));
+        const double r = 1.0 / (1.0 + e);
+        const double sig = zk >= 0.0 ? r : e * r;
+        se += w;
+        cdf += w * sig;
+        pdf += w * inv_s * (e * r * r);
+    }
+    MixEval o;
+    o.u = cdf / se;
+    if (pdf > 1e-290) o.log_pdf = log(pdf) - log(se);
+    else o.log_pdf = log_pdf_logspace<SPLIT>(p, K, x, mx + log(se));
+    return o;
+}
+
+// SPLIT selects the parameter source and the I/O precision (fp64 tensors for the static API)
+template <bool SPLIT, bool REVERSE>
+__global__ __launch_bounds__(kBlock) void mixture_kernel(MixArgs a, RowTiling tl) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int W = blockDim.x >> 6;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double* part = reinterpret_cast<double*>(smem) + (size_t)wave * kMaxTileChunks;
+    double* cst = reinterpret_cast<double*>(smem) + (size_t)W * kMaxTileChunks;   // [3K][blockDim]
+    __shared__ int s_act[kMaxAct];   // kernel arguments cannot be indexed per lane
+    if (threadIdx.x < kMaxAct && ((a.act_bits >> threadIdx.x) & 1ull))
+        s_act[__popcll(a.act_bits & ((1ull << threadIdx.x) - 1ull))] = threadIdx.x;
+    __syncthreads();
+    const long tile = (long)blockIdx.x * W + wave;
+    if (tile >= tl.ntiles) return;
+    const int row0 = (int)(tile * tl.rw);
+    const int nrows = min(tl.rw, tl.B - row0);
+    bool bad = false, range = false;
+
+    // ---- phase 1: copy the elements that are not transformed (masked channel or padded token)
+    {
+        const long nel = (long)nrows * a.L;
+        const size_t base = (size_t)row0 * a.L;
+        for (long e = lane; e < nel; e += kWave) {
+            const int r = (int)(e / a.L);
+            const int er = (int)(e - (long)r * a.L);
+            const int n = (int)fdiv((uint32_t)er, a.div_d);
+            const int d = er - n * a.D;
+            const float m = mask_at(a.mask, a.mr, a.mc, n, d);
+            const float pv = a.pad ? a.pad[(size_t)(row0 + r) * a.N + n] : 1.f;
+            const float change = (1.f - m) * (a.pad_in_transform ? pv : 1.f);
+            if (change == 0.f) {
+                if (SPLIT) {
+                    a.z_out64[base + e] = a.z64[base + e];
+                    if (a.reg_elem64) a.reg_elem64[base + e] = 0.0;
+                } else {
+                    const float zv = a.z[base + e];
+                    a.z_out[base + e] = a.pad_output ? zv * pv : zv;
+                }
+            }
+        }
+    }
+
+    // ---- phase 2: transformed elements, one item per lane
+    const int ipr = tl.L;                 // items per row = N * DA
+    const int nitems = nrows * ipr;
+    double acc1 = 0.0;
+    for (int c = lane; c < nitems; c += kWave) {
+        const int r = tl.rw == 1 ? 0 : (int)fdiv((uint32_t)c, tl.div_cpr);
+        const int it = c - r * ipr;
+        const int n = (int)fdiv((uint32_t)it, a.div_da);
+        const int d = s_act[it - n * a.DA];
+        const int row = row0 + r;
+        double contrib = 0.0;
+        bool active = true;
+        if (a.per_item_mask) active = mask_at(a.mask, a.mr, a.mc, n, d) == 0.f;
+        const float pv = a.pad ? a.pad[(size_t)row * a.N + n] : 1.f;
+        if (a.pad_in_transform && pv == 0.f) active = false;
+        if (active) {
+            const size_t elem = ((size_t)row * a.N + n) * a.D + d;
+            const ParamRow<SPLIT> p(a, elem, d);
+            const double x = SPLIT ? a.z64[elem] : (double)a.z[elem];
+            const double t = p.t(), log_s = p.log_s();
+            double out, reg = 0.0;
+            if (!REVERSE) {
+                const MixEval ev = eval_mixture<SPLIT>(p, a.K, x);
+                const double u = ev.u;
+                if (a.use_reg) {
+                    const double r1 = safe_log(u) / kLn10, r2 = safe_log(1.0 - u) / kLn10;
+                    reg = (fmin(r1, -a.reg_max) + a.reg_max) + (fmin(r2, -a.reg_max) + a.reg_max);
+                }
+                const double y = -safe_log(1.0 / u - 1.0);
+                const double mixt_ldj = -safe_log(u) - safe_log(1.0 - u);
+                out = (y + t) * exp(log_s);
+                contrib = log_s + mixt_ldj + ev.log_pdf + reg * a.reg_factor;
+            } else {
+                const double v = x * exp(-log_s) - t;
+                double u = 1.0 / (1.0 + exp(-v));
+                const double mixt_ldj = softplus64(v) + softplus64(-v);
+                u = fmin(fmax(u, 1e-5), 1.0 - 1e-5);
+                if (!(u > 0.0 && u < 1.0)) range = true;
+                // per-mixture constants of this element, strided by thread: [3k + c][tid]
+                double* my = cst + threadIdx.x;
+                const int S = blockDim.x;
+                double mx = -INFINITY;
+                for (int k = 0; k < a.K; ++k) mx = fmax(mx, p.log_pi(k));
+                double se = 0.0, spread = 0.0;
+                for (int k = 0; k < a.K; ++k) {
+                    const double w = exp(p.log_pi(k) - mx);
+                    const double ls = p.ls(k);
+                    se += w;
+                    spread += exp(ls);
+                    my[(3 * k + 0) * S] = w;
+                    my[(3 * k + 1) * S] = exp(-ls);
+                    my[(3 * k + 2) * S] = p.mu(k);
+                }
+                double lb = INFINITY, ub = -INFINITY;
+                for (int k = 0; k < a.K; ++k) {
+                    const double mu = my[(3 * k + 2) * S];
+                    lb = fmin(lb, mu - 20.0 * spread);
+                    ub = fmax(ub, mu + 20.0 * spread);
+                }
+                const double target = u * se;          // compare un-normalised sums
+                double xb = 0.0;
+                for (int iter = 0; iter < 100; ++iter) {
+                    double cdf = 0.0;
+                    for (int k = 0; k < a.K; ++k) {
+                        const double zk = (xb - my[(3 * k + 2) * S]) * my[(3 * k + 1) * S];
+                        const double e = exp(-fabs(zk));
+                        const double rr = 1.0 / (1.0 + e);
+                        cdf += my[(3 * k + 0) * S] * (zk >= 0.0 ? rr : e * rr);
+                    }
+                    double nx;
+                    if (cdf > target) {
+                        nx = (xb + lb) / 2.0;
+                        ub = xb;
+                    } else {
+                        nx = (xb + ub) / 2.0;
+                        lb = xb;
+                    }
+                    const double diff = fabs(nx - xb);
+                    xb = nx;
+                    if (!(diff > 1e-10)) break;
+                }
+                out = xb;
+                const MixEval ev = eval_mixture<SPLIT>(p, a.K, xb);
+                contrib = log_s + mixt_ldj + ev.log_pdf;
+            }
+            if (SPLIT) {
+                a.z_out64[elem] = out;
+                if (a.reg_elem64) a.reg_elem64[elem] = reg;
+                bad |= isnan(out);
+            } else {
+                float of = (float)out;
+                if (a.pad_output) of = of * pv;
+                a.z_out[elem] = of;
+                bad |= isnan(of);
+                if (a.use_reg && a.reg_out && reg != 0.0) atomicAdd(&a.reg_out[row], (float)reg);
+            }
+        }
+        if (tl.rw == 1) acc1 += contrib;
+        else part[c] = contrib;
+    }
+
+    // ---- per-sample log-det
+    auto finish = [&](int row, double sum) {
+        const double s = REVERSE ? -sum : sum;
+        if (SPLIT) {
+            a.ldj_out64[row] = s;
+            if (isnan(s)) raise_flag(a.flags, CNF_FLAG_NAN_LDJ);
+        } else {
+            const float v = (a.ldj_in ? a.ldj_in[row] : 0.f) + (float)s;
+            a.ldj_out[row] = v;
+            if (isnan(v)) raise_flag(a.flags, CNF_FLAG_NAN_LDJ);
+        }
+    };
+    if (tl.rw == 1) {
+        acc1 = wave_sum(acc1);
+        if (lane == 0) finish(row0, acc1);
+    } else {
+        wave_lds_sync();
+        const int g = kWave / tl.p2;
+        const int sub = lane & (g - 1);
+        for (int r0 = 0; r0 < nrows; r0 += tl.p2) {
+            const int r = r0 + lane / g;
+            double acc = 0.0;
+            if (r < nrows)
+                for (int i = sub; i < ipr; i += g) acc += part[r * ipr + i];
+            acc = group_sum(acc, g);
+            if (sub == 0 && r < nrows) finish(row0 + r, acc);
+        }
+    }
+    if (bad) raise_flag(a.flags, CNF_FLAG_NAN_Z);
+    if (range) raise_flag(a.flags, CNF_FLAG_RANGE);
+}
+
+// get_mixt_params (:145-180): split + fp32 tanh bound + mask, widened to fp64
+__global__ __launch_bounds__(kBlock) void mixture_params_kernel(const float* nn, const float* sf,
+                                                                const float* msf, const float* mask,
+                                                                int mr, int mc, double* t, double* log_s,
+                                                                double* log_pi, double* mu, double* ls,
+                                                                long nelem, int N, int D, int K) {
+    const int P = 2 + 3 * K;
+    const long total = nelem * P;
+    for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long)gridDim.x * kBlock) {
+        const long elem = i / P;
+        const int j = (int)(i - elem * P);
+        const int d = (int)(elem % D);
+        const int n = (int)((elem / D) % N);
+        const float keep = 1.f - mask_at(mask, mr, mc, n, d);
+        float v = nn[i];
+        if (j == 0) {
+            t[elem] = (double)(mask ? v * keep : v);
+        } else if (j == 1) {
+            if (sf) {
+                const float f = expf(sf[d]);
+                v = tanhf(v / fmaxf(f, 1.f)) * f;
+            }
+            log_s[elem] = (double)(mask ? v * keep : v);
+        } else if (j < 2 + K) {
+            log_pi[elem * K + (j - 2)] = (double)(mask ? v * keep : v);
+        } else if (j < 2 + 2 * K) {
+            mu[elem * K + (j - 2 - K)] = (double)(mask ? v * keep : v);
+        } else {
+            const int k = j - 2 - 2 * K;
+            if (msf) {
+                const float f = expf(msf[d * K + k]);
+                v = tanhf(v / fmaxf(f, 1.f)) * f;
+            }
+            ls[elem * K + k] = (double)(mask ? v * keep : v);
+        }
+    }
+}
+
+// Which channels are transformed.  The caller knows the (tiny, constant) coupling mask on the host
+// and passes the list of transformed channels; without it every item tests the mask itself.
+static void fill_act(MixArgs& a, const int* act_host, int n_act) {
+    a.per_item_mask = 0;
+    a.act_bits = 0;
+    if (a.mask && act_host && a.mr == 1 && a.mc == a.D && n_act >= 0 && n_act <= a.D) {
+        a.DA = n_act;
+        for (int i = 0; i < n_act; ++i) a.act_bits |= 1ull << act_host[i];
+    } else {
+        a.DA = a.D;
+        a.act_bits = a.D >= 64 ? ~0ull : ((1ull << a.D) - 1ull);
+        a.per_item_mask = a.mask ? 1 : 0;
+    }
+    if (a.DA == 0) {   // nothing is transformed: keep one (inactive) item per token
+        a.DA = 1;
+        a.act_bits = 1ull;
+        a.per_item_mask = 1;
+    }
+}
+
+}  // namespace cnf
+
+using namespace cnf;
+
+extern "C" {
+
+static int launch_mixture(MixArgs& a, bool split, const int* act_host, int n_act, hipStream_t st,
+                          const char* who) {
+    CNF_REQUIRE(a.B >= 0 && a.N > 0 && a.D > 0 && a.K > 0, "%s: bad shape B=%d N=%d D=%d K=%d", who, a.B, a.N, a.D, a.K);
+    if (a.B == 0) return CNF_OK;
+    CNF_REQUIRE(a.D <= kMaxAct, "%s: D=%d exceeds %d", who, a.D, kMaxAct);
+    CNF_REQUIRE((long)a.N * a.D < 65536, "%s: N*D=%ld exceeds 65535", who, (long)a.N * a.D);
+    if (!a.mask) { a.mr = 1; a.mc = a.D; }
+    CNF_REQUIRE(a.mr >= 1 && (a.mc == a.D || a.mc == 1), "%s: mask must be [rows,%d] or [rows,1]", who, a.D);
+    if (a.mr > a.N) a.mr = a.N;
+    a.P = 2 + 3 * a.K;
+    a.L = a.N * a.D;
+    a.div_d = make_fastdiv((uint32_t)a.D);
+    fill_act(a, act_host, n_act);
+    a.div_da = make_fastdiv((uint32_t)a.DA);
+    const RowTiling tl = make_row_tiling(a.B, a.N * a.DA, /*force_vec=*/1);
+    // block size: the inverse keeps 3K fp64 constants per thread in LDS (<= 64 KiB per block)
+    int threads = kBlock;
+    size_t cst_bytes = 0;
+    if (a.reverse) {
+        const size_t per_thread = (size_t)3 * a.K * sizeof(double);
+        while (threads > kWave &&
+               per_thread * threads + (size_t)(threads / kWave) * kMaxTileChunks * sizeof(double) > 65536)
+            threads >>= 1;
+        cst_bytes = per_thread * threads;
+        if (cst_bytes + (size_t)(threads / kWave) * kMaxTileChunks * sizeof(double) > 65536) {
+            set_error("%s: inverse with K=%d mixtures needs more than 64 KiB of LDS", who, a.K);
+            return CNF_ERR_UNSUPPORTED;
+        }
+    }
+    const int W = threads / kWave;
+    const size_t smem = (size_t)W * kMaxTileChunks * sizeof(double) + cst_bytes;
+    const dim3 grid((unsigned)((tl.ntiles + W - 1) / W)), block(threads);
+    if (split) {
+        if (a.reverse) hipLaunchKernelGGL((mixture_kernel<true, true>), grid, block, smem, st, a, tl);
+        else hipLaunchKernelGGL((mixture_kernel<true, false>), grid, block, smem, st, a, tl);
+    } else {
+        if (a.reverse) hipLaunchKernelGGL((mixture_kernel<false, true>), grid, block, smem, st, a, tl);
+        else hipLaunchKernelGGL((mixture_kernel<false, false>), grid, block, smem, st, a, tl);
+    }
+    return launch_status(who);
+}
+
+int cnf_mixture_coupling(const float* z, const float* nn_out,
+                         const float* scaling_factor, const float* mixture_scaling_factor,
+                         const float* mask, int mask_rows, int mask_cols,
+                         const int* act_host, int n_act,
+                         const float* pad, int pad_in_transform, int pad_output,
+                         const float* ldj_in, float* z_out, float* ldj_out, float* reg_out,
+                         int B, int N, int D, int K, int reverse,
+                         double reg_max, double reg_factor, int is_training,
+                         int* flags, cnf_stream_t stream) {
+    CNF_REQUIRE(z && nn_out && z_out && ldj_out, "cnf_mixture_coupling: null tensor");
+    MixArgs a = {};
+    a.z = z; a.nn = nn_out; a.sf = scaling_factor; a.msf = mixture_scaling_factor;
+    a.mask = mask; a.pad = pad; a.ldj_in = ldj_in; a.z_out = z_out; a.ldj_out = ldj_out;
+    a.reg_out = reg_out; a.flags = flags;
+    a.B = B; a.N = N; a.D = D; a.K = K; a.mr = mask_rows; a.mc = mask_cols;
+    a.reverse = reverse != 0;
+    a.pad_in_transform = pad ? pad_in_transform : 0;
+    a.pad_output = pad ? pad_output : 0;
+    a.use_reg = (!reverse && reg_max > 0 && is_training) ? 1 : 0;
+    a.reg_max = reg_max; a.reg_factor = reg_factor;
+    return launch_mixture(a, false, act_host, n_act, (hipStream_t)stream, "cnf_mixture_coupling");
+}
+
+int cnf_mixture_transform(const double* z, const double* t, const double* log_s,
+                          const double* log_pi, const double* mixt_t, const double* mixt_log_s,
+                          const float* mask, int mask_rows, int mask_cols,
+                          const int* act_host, int n_act, const float* pad,
+                          double* z_out, double* ldj_out, double* reg_ldj,
+                          int B, int N, int D, int K, int reverse,
+                          double reg_max, double reg_factor, int is_training,
+                          int* flags, cnf_stream_t stream) {
+    CNF_REQUIRE(z && t && log_s && log_pi && mixt_t && mixt_log_s && z_out && ldj_out,
+                "cnf_mixture_transform: null tensor");
+    MixArgs a = {};
+    a.z64 = z; a.p_t = t; a.p_log_s = log_s; a.p_log_pi = log_pi; a.p_mu = mixt_t; a.p_ls = mixt_log_s;
+    a.mask = mask; a.pad = pad; a.z_out64 = z_out; a.ldj_out64 = ldj_out; a.reg_elem64 = reg_ldj;
+    a.flags = flags;
+    a.B = B; a.N = N; a.D = D; a.K = K; a.mr = mask_rows; a.mc = mask_cols;
+    a.reverse = reverse != 0;
+    a.pad_in_transform = pad ? 1 : 0;
+    a.pad_output = 0;
+    a.use_reg = (!reverse && reg_max > 0 && is_training) ? 1 : 0;
+    a.reg_max = reg_max; a.reg_factor = reg_factor;
+    return launch_mixture(a, true, act_host, n_act, (hipStream_t)stream, "cnf_mixture_transform");
+}
+
+int cnf_mixture_params(const float* nn_out, const float* scaling_factor,
+                       const float* mixture_scaling_factor,
+                       const float* mask, int mask_rows, int mask_cols,
+                       double* t, double* log_s, double* log_pi, double* mixt_t, double* mixt_log_s,
+                       int B, int N, int D, int K, cnf_stream_t stream) {
+    CNF_REQUIRE(nn_out && t && log_s && log_pi && mixt_t && mixt_log_s, "cnf_mixture_params: null tensor");
+    CNF_REQUIRE(B >= 0 && N > 0 && D > 0 && K > 0, "cnf_mixture_params: bad shape");
+    if (B == 0) return CNF_OK;
+    if (mask && mask_rows > N) mask_rows = N;
+    const long nelem = (long)B * N * D;
+    const long total = nelem * (2 + 3 * K);
+    const int grid = (int)std::min<long>((total + kBlock - 1) / kBlock, 256 * 16);
+    hipLaunchKernelGGL(mixture_params_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream,
+                       nn_out, scaling_factor, mixture_scaling_factor, mask, mask_rows, mask_cols,
+                       t, log_s, log_pi, mixt_t, mixt_log_s, nelem, N, D, K);
+    return launch_status("cnf_mixture_params");
+}
+
+}  // extern "C"

@@ -1,0 +1,56 @@
+"""One process per GPU, batch sharded on dim 0, ONE collective on the data path.
+
+The hot path is independent per sample, so ranks never exchange latents; the only
+exchange is the all-reduce (sum) of two fp64 scalars (sum of per-sample NLL, sample count) from
+which every rank gets the mean NLL / bits-per-dim — the MI355X-native replacement of the
+reference's `nn.DataParallel` gather (general/train.py:36-44).  Backend "nccl" is RCCL over xGMI on
+ROCm; "gloo" is used by the CPU tests."""
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    """(rank, local_rank, world_size) from the torchrun environment (1 process => (0, 0, 1))."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init_process_group(backend=None):
+    """Initialise torch.distributed from the environment if WORLD_SIZE > 1; returns (rank, local_rank, world)."""
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def shard_bounds(total_rows, rank, world):
+    """Contiguous, near-even split of `total_rows` samples: rows [lo, hi) belong to `rank`."""
+    base, rem = divmod(total_rows, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def allreduce_nll(sums):
+    """sums: fp64 tensor [2] = (sum of per-sample NLL, sample count) of this rank, on the device the
+    backend expects.  Returns (mean NLL, bits/dim) over ALL ranks (general/task.py:139-149)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+    total, count = float(sums[0].item()), float(sums[1].item())
+    mean = total / max(1e-5, count)
+    return mean, float(np.log2(np.exp(1)) * mean)
+
+
+def allreduce_actnorm_stats(acc):
+    """fp64 [D+1] (per-channel sums + count) partials of the ActNorm data-dependent init (§8e)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+    return acc

@@ -1,0 +1,58 @@
+"""Small host-side helpers the layer modules need (the reference keeps them in general/mutils.py)."""
+import numpy as np
+import torch
+
+
+def get_param_val(param_dict, key, default_val=None, allow_default=True, error_location="", warning_if_default=True):
+    """general/mutils.py:206-214 — dict lookup with default (+ the reference's warning line)."""
+    if key in param_dict:
+        return param_dict[key]
+    if not allow_default:
+        assert False, "[!] ERROR (%s): could not find key \"%s\" in the dictionary although it is required." % (
+            error_location, str(key))
+    if warning_if_default:
+        print("[#] WARNING: Using default value %s for key %s" % (str(default_val), str(key)))
+    return default_val
+
+
+def one_hot(x, num_classes, dtype=torch.float32):
+    """general/mutils.py:259-270."""
+    if isinstance(x, np.ndarray):
+        out = np.zeros(x.shape + (num_classes,), dtype=np.float32)
+        out[np.arange(x.shape[0]), x] = 1.0
+        return out
+    assert torch.max(x) < num_classes, "[!] ERROR: One-hot input has larger entries (%s) than classes (%i)" % (
+        str(torch.max(x)), num_classes)
+    out = x.new_zeros(x.shape + (num_classes,), dtype=dtype)
+    out.scatter_(-1, x.unsqueeze(dim=-1), 1)
+    return out
+
+
+def _create_length_mask(length, max_len=None, dtype=torch.float32):
+    """general/mutils.py:273-277."""
+    if max_len is None:
+        max_len = length.max()
+    return (torch.arange(max_len, device=length.device).view(1, max_len) < length.unsqueeze(dim=-1)).to(dtype=dtype)
+
+
+def create_transformer_mask(length, max_len=None, dtype=torch.float32):
+    """general/mutils.py:279-283 — True where a position is padding."""
+    return ~_create_length_mask(length=length, max_len=max_len, dtype=torch.bool)
+
+
+def create_channel_mask(length, max_len=None, dtype=torch.float32):
+    """general/mutils.py:285-288 — [B,N,1] fp32."""
+    return _create_length_mask(length=length, max_len=max_len, dtype=dtype).unsqueeze(dim=-1)
+
+
+def grad_needed(*tensors):
+    return torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors)
+
+
+def forbid_grad(what, *tensors):
+    """Backward kernels are the next scope row; refuse instead of silently
+    falling back to eager PyTorch."""
+    if grad_needed(*tensors):
+        raise NotImplementedError(
+            "%s: this build ships the forward / inverse / log-det HIP kernels only; gradients through them are "
+            "not implemented yet. Wrap the call in torch.no_grad()." % what)

@@ -1,0 +1,40 @@
+"""Mixture-CDF transform of ALL channels with parameters from an autoregressive subnet.
+
+Interface of layers/flows/autoregressive_coupling.py:9-47 (forward only; reverse raises, as there)."""
+import torch
+import torch.nn as nn
+
+from ... import ops
+from ...host_utils import forbid_grad
+from .flow_layer import FlowLayer
+
+
+class AutoregressiveMixtureCDFCoupling(FlowLayer):
+
+    def __init__(self, c_in, model_func, block_type=None, num_mixtures=10):
+        super().__init__()
+        self.c_in = c_in
+        self.num_mixtures = num_mixtures
+        self.block_type = block_type
+        self.scaling_factor = nn.Parameter(torch.zeros(self.c_in))
+        self.mixture_scaling_factor = nn.Parameter(torch.zeros(self.c_in, self.num_mixtures))
+        self.nn = model_func(c_out=c_in * (2 + 3 * self.num_mixtures))
+
+    def forward(self, z, ldj=None, reverse=False, **kwargs):
+        if reverse:
+            raise NotImplementedError
+        nn_out = self.nn(x=z, **kwargs)
+        forbid_grad("AutoregressiveMixtureCDFCoupling", z, nn_out, self.scaling_factor, self.mixture_scaling_factor)
+        # no mask and no padding inside the transform; the output is multiplied by the padding mask
+        # afterwards (autoregressive_coupling.py:38-45)
+        z_out, ldj_out, _ = ops.mixture_coupling(
+            z, nn_out, None, self.num_mixtures, self.scaling_factor, self.mixture_scaling_factor, reverse=False,
+            channel_padding_mask=kwargs.get("channel_padding_mask", None), pad_in_transform=False, pad_output=True,
+            ldj=ldj, want_reg=False)
+        return z_out, ldj_out
+
+    def info(self):
+        s = "Autoregressive Mixture CDF Coupling Layer - Input size %i" % (self.c_in)
+        if self.block_type is not None:
+            s += ", block type %s" % (self.block_type)
+        return s

@@ -1,0 +1,126 @@
+"""Ordered container of flow layers with the running log-det sum.
+
+Interface of layers/flows/flow_model.py (FlowModel.forward :25-53, run_data_init_layer :104-131).
+Differences that are deliberate: the per-layer `torch.isnan(z).sum() == 0` host sync (:42) is replaced
+by device-side flag bits that the kernels raise and that are checked ONCE at the end of the pass
+(same AssertionError), unless CNF_STRICT_ASSERTS=1 asks for the per-layer check."""
+import torch
+import torch.nn as nn
+
+from ... import ops
+
+
+class FlowModel(nn.Module):
+
+    def __init__(self, layers=None, name="Flow model"):
+        super().__init__()
+        self.flow_layers = nn.ModuleList()
+        self.name = name
+        if layers is not None:
+            self.add_layers(layers)
+
+    def add_layers(self, layers):
+        for layer in layers:
+            self.flow_layers.append(layer)
+        self.print_overview()
+
+    def forward(self, z, ldj=None, reverse=False, get_ldj_per_layer=False, **kwargs):
+        if ldj is None:
+            ldj = z.new_zeros(z.size(0), dtype=torch.float32)
+        order = list(enumerate(self.flow_layers))
+        if reverse:
+            order.reverse()
+        per_layer = []
+        for index, layer in order:
+            res = layer(z, reverse=reverse, get_ldj_per_layer=get_ldj_per_layer, **kwargs)
+            if len(res) == 2:
+                z, layer_ldj = res
+                detail = layer_ldj
+            elif len(res) == 3:
+                z, layer_ldj, detail = res
+            else:
+                print("[!] ERROR: Got more return values than expected: %i" % (len(res)))
+            if ops._STRICT and z.is_cuda:
+                ops.check_flags(z.device, "Layer (%i):\n%s" % (index + 1, layer.info()))
+            ldj = ldj + layer_ldj
+            if isinstance(detail, list):
+                per_layer += detail
+            else:
+                per_layer.append(detail)
+        if z.is_cuda:
+            ops.check_flags(z.device, "Flow: %s" % self.name)
+        if get_ldj_per_layer:
+            return z, ldj, per_layer
+        return z, ldj
+
+    def reverse(self, z):
+        return self.forward(z, reverse)
+
+    def test_reversibility(self, z, **kwargs):
+        """flow_model.py:60-78 — per-layer fwd∘inv check, exact-zero criterion like the reference."""
+        failed = False
+        for index, layer in enumerate(self.flow_layers):
+            z_layer, ldj_layer = layer(z, reverse=False, **kwargs)[:2]
+            z_rec, ldj_rec = layer(z_layer, reverse=True, **kwargs)[:2]
+            if (z_layer - z_rec).abs().sum() != 0 or (ldj_layer + ldj_rec).abs().sum() != 0:
+                print("-" * 100)
+                print("[!] WARNING: Reversibility check failed for layer index %i" % index)
+                print(layer.info())
+                print("-" * 100)
+                failed = True
+        print("+" * 100)
+        print("Reversibility test %s (tested %i layers)" % ("failed" if failed else "succeeded", len(self.flow_layers)))
+        print("+" * 100)
+
+    def get_inner_activations(self, z, reverse=False, return_names=False, **kwargs):
+        outs, names = [z.detach()], []
+        for layer in (self.flow_layers if not reverse else reversed(self.flow_layers)):
+            z = layer(z, reverse=reverse, **kwargs)[0]
+            outs.append(z.detach())
+            names.append(layer.__class__.__name__)
+        return (outs, names) if return_names else outs
+
+    def initialize_data_dependent(self, batch_list):
+        """batch_list: [(z, kwargs), ...] (flow_model.py:96-101)."""
+        with torch.no_grad():
+            for index, layer in enumerate(self.flow_layers):
+                print("Processing layer %i..." % (index + 1), end="\r")
+                batch_list = FlowModel.run_data_init_layer(batch_list, layer)
+
+    @staticmethod
+    def run_data_init_layer(batch_list, layer):
+        """Initialise `layer` on the concatenation of all batches, then push every batch through it."""
+        multi = isinstance(batch_list[0][0], (tuple, list))
+        if layer.need_data_init():
+            stacked = {}
+            for key in batch_list[0][1].keys():
+                vals = [b[1][key] for b in batch_list]
+                stacked[key] = torch.cat(vals, dim=0) if isinstance(vals[0], torch.Tensor) else vals[0]
+            if not multi:
+                layer.data_init_forward(torch.cat([z for z, _ in batch_list], dim=0), **stacked)
+            else:
+                joined = [torch.cat([z[i] for z, _ in batch_list], dim=0) for i in range(len(batch_list[0][0]))]
+                layer.data_init_forward(*joined, **stacked)
+        outs = []
+        for z, kwargs in batch_list:
+            if multi:
+                res = layer(*z, reverse=False, **kwargs)
+                outs.append([e.detach() for e in res[:-1] if isinstance(e, torch.Tensor)])
+                if len(res) == 4 and isinstance(res[-1], dict):
+                    kwargs.update(res[-1])
+                    outs[-1] = outs[-1][:-1]
+            else:
+                outs.append(layer(z, reverse=False, **kwargs)[0].detach())
+        return [(outs[i], batch_list[i][1]) for i in range(len(batch_list))]
+
+    def need_data_init(self):
+        return any(flow.need_data_init() for flow in self.flow_layers)
+
+    def print_overview(self):
+        lines = ["(%2i) %s" % (i + 1, layer.info()) for i, layer in enumerate(self.flow_layers)]
+        width = max([20] + [len(s) for s in "\n".join(lines).split("\n")])
+        print("=" * width)
+        print("%s with %i flows" % (self.name, len(self.flow_layers)))
+        print("-" * width)
+        print("\n".join(lines))
+        print("=" * width)

@@ -1,0 +1,27 @@
+"""Sigmoid / logit flow with log-det (layers/flows/sigmoid_layer.py:12-51) on cnf_sigmoid_flow."""
+import torch
+
+from ... import ops
+from ...host_utils import forbid_grad
+from .flow_layer import FlowLayer
+
+
+class SigmoidFlow(FlowLayer):
+    """reverse=True at construction turns the layer into a logit flow."""
+
+    def __init__(self, reverse=False):
+        super().__init__()
+        self.reverse_layer = reverse
+
+    def forward(self, z, ldj=None, reverse=False, sum_ldj=True, **kwargs):
+        forbid_grad("SigmoidFlow", z, ldj)
+        direction = (self.reverse_layer != reverse)       # XOR of the two flags (:29)
+        if sum_ldj:
+            return ops.sigmoid_flow(z, reverse=direction, ldj=ldj)
+        # per-element log-det requested: rows of one element each
+        flat = z.reshape(-1, 1)
+        out, el = ops.sigmoid_flow(flat, reverse=direction, ldj=None)
+        return out.view_as(z), el.view_as(z)
+
+    def info(self):
+        return "Sigmoid Flow"

@@ -1,0 +1,200 @@
+/*
+ * cnf_hip.h — C ABI of libcnf_hip.so, the MI355X (gfx950) implementation of CategoricalNF's
+ * coupling-layer hot path (forward / inverse / log-det-Jacobian).
+ *
+ * The reference (phlippe/CategoricalNF) is pure eager PyTorch and has no FFI of its own
+ * (SURVEY.md §8b); each entry point below replaces one eager op chain and cites it as
+ * <file>:<lines> relative to the reference root.  A maintainer binds these from Python with
+ * ctypes; categoricalnf_amd/_lib.py is that binding.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless stated otherwise; tensors are dense, row-major,
+ *     fp32 latents `[B, N, D]`, int64 categories `[B, N]`, fp32 0/1 padding masks `[B, N]`
+ *     (the reference's `[B,N,1]` channel_padding_mask, same memory);
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls are asynchronous;
+ *   - return value: CNF_OK or a CNF_ERR_* code (cnf_last_error() gives a message; host side only);
+ *   - `flags` (nullable) points to one int32 in device memory into which kernels OR the CNF_FLAG_*
+ *     bits; the Python layer turns them into the reference's AssertionError / RuntimeError once
+ *     per forward instead of one host sync per layer (flow_model.py:42);
+ *   - `ldj_in` (nullable, may alias `ldj_out`) is the running log-det `[B]`; kernels write
+ *     `ldj_out[b] = (ldj_in ? ldj_in[b] : 0) + layer_ldj[b]` — the reference's `ldj = ldj + layer_ldj`
+ *     (flow_model.py:44) folded into the kernel epilogue;
+ *   - masks: `mask` is the small coupling mask buffer `[mask_rows, mask_cols]` (1 = channel is
+ *     fed to the subnet and left unchanged); `mask_rows` is 1 (channel mask, `mask_cols == D`) or
+ *     a period along N (chess mask `[2,1]`), expanded exactly like
+ *     coupling_layer.py:67-74 (`_prepare_mask`); NULL = no mask (everything transformed).
+ */
+#ifndef CNF_HIP_H
+#define CNF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CNF_OK 0
+#define CNF_ERR_ARG 1          /* bad size / NULL pointer / unsupported combination */
+#define CNF_ERR_LAUNCH 2       /* hipGetLastError() != hipSuccess after the launch */
+#define CNF_ERR_UNSUPPORTED 3  /* shape outside what the kernels are built for */
+
+#define CNF_FLAG_NAN_Z 1       /* a latent output is NaN          (flow_model.py:42) */
+#define CNF_FLAG_NAN_LDJ 2     /* a log-det output is NaN         (activation_normalization.py:46) */
+#define CNF_FLAG_RANGE 4       /* inverse-CDF input outside (0,1) (mixture_cdf_layer.py:238-239) */
+
+typedef void* cnf_stream_t;
+
+int cnf_abi_version(void);
+const char* cnf_last_error(void);
+
+/* Tuning knob for the row-streaming kernels: float4 chunks one wave owns per tile (default 256). */
+void cnf_set_tile_chunks(int chunks);
+/* Chunks per lane whose loads are issued back to back in the affine coupling kernel (1..4, default 4). */
+void cnf_set_unroll(int u);
+
+/* ---- affine coupling -------------------------------------------------------------------- */
+
+/* coupling_layer.py:42-65 (CouplingLayer.forward after the subnet), :76-98.
+ * nn_out [B,N,2D] holds interleaved (s_raw, t) per channel.  scaling_factor [D] or NULL
+ * (NULL = no tanh bound, get_coup_params(scaling_factor=None)).
+ * fwd: z' = (z + t) e^s, ldj += sum s ; rev: z' = z e^-s - t, ldj -= sum s. */
+int cnf_affine_coupling(const float* z, const float* nn_out, const float* scaling_factor,
+                        const float* mask, int mask_rows, int mask_cols,
+                        const float* ldj_in, float* z_out, float* ldj_out,
+                        int B, int N, int D, int reverse, int* flags, cnf_stream_t stream);
+
+/* CouplingLayer.get_coup_params (coupling_layer.py:76-86): materialise s, t [B,N,D]. */
+int cnf_affine_params(const float* nn_out, const float* scaling_factor,
+                      const float* mask, int mask_rows, int mask_cols,
+                      float* s_out, float* t_out, int B, int N, int D, cnf_stream_t stream);
+
+/* CouplingLayer.run_with_params (coupling_layer.py:88-98) on materialised s, t. */
+int cnf_affine_transform(const float* z, const float* s, const float* t,
+                         const float* ldj_in, float* z_out, float* ldj_out,
+                         int B, int N, int D, int reverse, int* flags, cnf_stream_t stream);
+
+/* ---- activation normalisation ------------------------------------------------------------- */
+
+/* ActNormFlow.forward (activation_normalization.py:24-48).  bias, scales [D].
+ * ldj += (+-sum_d scales) * len_b with len_b = length[b] (fp32) if given, else sum_n pad[b,n] if
+ * pad given, else N.  z' *= pad if given. */
+int cnf_actnorm(const float* z, const float* bias, const float* scales,
+                const float* pad, const float* length,
+                const float* ldj_in, float* z_out, float* ldj_out,
+                int B, int N, int D, int reverse, int* flags, cnf_stream_t stream);
+
+/* ExtActNormFlow.forward (activation_normalization.py:116-144) with the predictor output given:
+ * nn_out [B,N,2D] = [bias(D) | scales_raw(D)] per token; scales = tanh(scales_raw);
+ * ldj += +-sum_{n,d} scales * pad.  z' is NOT multiplied by pad (as in the reference). */
+int cnf_ext_actnorm(const float* z, const float* nn_out, const float* pad,
+                    const float* ldj_in, float* z_out, float* ldj_out,
+                    int B, int N, int D, int reverse, int* flags, cnf_stream_t stream);
+
+/* ActNormFlow.data_init_forward (activation_normalization.py:55-67): per-channel weighted
+ * sum / sum of squared deviations.  pass 0: out[0..D) = sum_x, out[D] = count (fp64);
+ * pass 1 (given mean[D] fp64): out[0..D) = sum (x-mean)^2.  `out` must be zeroed by the caller. */
+int cnf_actnorm_stats(const float* z, const float* pad, const double* mean, double* out,
+                      int B, int N, int D, int pass, cnf_stream_t stream);
+
+/* ---- invertible 1x1 convolution ------------------------------------------------------------ */
+
+/* InvertibleConv.forward (permutation_layers.py:106-136): z' = x @ W (right multiply, W [D,D]
+ * row-major), z' *= pad, ldj +-= sldj * len_b (len_b = length[b] or N).  For reverse the caller
+ * passes W^-1 (computed in fp64 like the reference, :77,:85) and reverse=1 flips the sign.
+ * `sldj` points to ONE fp32 in device memory. */
+int cnf_invconv(const float* x, const float* weight, const float* sldj,
+                const float* pad, const float* length,
+                const float* ldj_in, float* z_out, float* ldj_out,
+                int B, int N, int D, int reverse, int* flags, cnf_stream_t stream);
+
+/* ---- logistic-mixture CDF coupling ----------------------------------------------------------- */
+
+/* MixtureCDFCoupling.forward after the subnet (mixture_cdf_layer.py:45-92) = get_mixt_params
+ * (:145-180) + run_with_params (:95-142) + mixture_inv_cdf (:235-264), fp64 inside.
+ * nn_out [B,N,D*(2+3K)] channel-major blocks [t, log_s, log_pi[K], mixt_t[K], mixt_log_s[K]].
+ * scaling_factor [D] / mixture_scaling_factor [D,K] nullable.  pad [B,N] nullable.
+ * reg_out [B] (nullable) receives sum_{n,d} reg_ldj (detail "regularizer_ldj", :79-80).
+ * act_host (HOST pointer, nullable): for a channel mask (mask_rows == 1) the n_act channel indices
+ * with mask == 0, so that only transformed channels get a lane; NULL = every lane tests the mask.
+ * pad_output: multiply z' by pad (MixtureCDFCoupling :76; the autoregressive variant passes
+ * mask=NULL and transforms padded tokens too, autoregressive_coupling.py:38-45 -> pad_in_transform=0). */
+int cnf_mixture_coupling(const float* z, const float* nn_out,
+                         const float* scaling_factor, const float* mixture_scaling_factor,
+                         const float* mask, int mask_rows, int mask_cols,
+                         const int* act_host, int n_act,
+                         const float* pad, int pad_in_transform, int pad_output,
+                         const float* ldj_in, float* z_out, float* ldj_out, float* reg_out,
+                         int B, int N, int D, int K, int reverse,
+                         double reg_max, double reg_factor, int is_training,
+                         int* flags, cnf_stream_t stream);
+
+/* MixtureCDFCoupling.get_mixt_params (mixture_cdf_layer.py:145-180): split + bound + mask in
+ * fp32, results cast to fp64: t, log_s [B,N,D]; log_pi, mixt_t, mixt_log_s [B,N,D,K]. */
+int cnf_mixture_params(const float* nn_out, const float* scaling_factor,
+                       const float* mixture_scaling_factor,
+                       const float* mask, int mask_rows, int mask_cols,
+                       double* t, double* log_s, double* log_pi, double* mixt_t, double* mixt_log_s,
+                       int B, int N, int D, int K, cnf_stream_t stream);
+
+/* MixtureCDFCoupling.run_with_params (mixture_cdf_layer.py:95-142) on fp64 split parameters.
+ * mask_full / pad: fp64-free fp32 [B,N,D]-broadcast description as above.  Outputs fp64:
+ * z_out [B,N,D], ldj_out [B] (NOT accumulated: the reference overwrites), reg_ldj [B,N,D] nullable. */
+int cnf_mixture_transform(const double* z, const double* t, const double* log_s,
+                          const double* log_pi, const double* mixt_t, const double* mixt_log_s,
+                          const float* mask, int mask_rows, int mask_cols,
+                          const int* act_host, int n_act, const float* pad,
+                          double* z_out, double* ldj_out, double* reg_ldj,
+                          int B, int N, int D, int K, int reverse,
+                          double reg_max, double reg_factor, int is_training,
+                          int* flags, cnf_stream_t stream);
+
+/* ---- logistic prior and NLL ------------------------------------------------------------------ */
+
+/* LogisticDistribution.log_prob (distributions.py:129-136,154-163), element-wise. */
+int cnf_logistic_log_prob(const float* x, float* logp, int64_t n, float mu, float sigma,
+                          float log_sigma, int* flags, cnf_stream_t stream);
+
+/* LogisticDistribution.sample given the uniform draw (distributions.py:139-145,117-127):
+ * u' = u(1-eps)+eps/2, x = logit(u') in fp64 -> fp32, x*sigma+mu. */
+int cnf_logistic_from_uniform(const float* u, float* x, int64_t n, float mu, float sigma, float eps,
+                              cnf_stream_t stream);
+
+/* NLL assembly (experiments/set_modeling/task.py:96-118, general/task.py:148-149):
+ * neglog[b] = -sum_{n,d} logp(z)*pad ; nll[b] = (-ldj[b] + neglog[b]) / length[b].
+ * sums (nullable, 2 fp64, caller-zeroed) += {sum_b nll[b], B} — the pair that is all-reduced
+ * over ranks. */
+int cnf_prior_nll(const float* z, const float* pad, const float* ldj, const float* length,
+                  float* neglog_out, float* nll_out, double* sums,
+                  int B, int N, int D, float sigma, float log_sigma, cnf_stream_t stream);
+
+/* ---- mixture-model categorical encoder --------------------------------------------------------- */
+
+/* LinearCategoricalEncoding.forward, num_flows == 0 (linear_encoding.py:59-106,120-133,153-174).
+ * categ int64 [B,N]; eps fp32 [B*N,D] logistic noise (cnf_logistic_from_uniform);
+ * table fp32 [C,2D] = pred_net(embed_layer.weight) rows [bias | scales_raw];
+ * category_prior [C] (log-softmax'ed buffer); pad [B,N] nullable.
+ * Outputs: z [B,N,D], ldj_out [B] (+= ldj_in), class_prob_log [B*N] (nullable). */
+int cnf_encoder_forward(const int64_t* categ, const float* eps, const float* table,
+                        const float* category_prior, const float* pad, float beta,
+                        const float* ldj_in, float* z_out, float* ldj_out, float* class_prob_log,
+                        int B, int N, int D, int C, float sigma, float log_sigma,
+                        int* flags, cnf_stream_t stream);
+
+/* LinearCategoricalEncoding reverse / _posterior_sample (linear_encoding.py:108-118,184-196):
+ * argmax_c of (reverse-flow log-prob + category prior) -> int64 [B,N]; first max wins. */
+int cnf_encoder_decode(const float* z, const float* table, const float* category_prior,
+                       int64_t* categ_out, int B, int N, int D, int C, float sigma, float log_sigma,
+                       cnf_stream_t stream);
+
+/* ---- sigmoid / logit flow ------------------------------------------------------------------- */
+
+/* SigmoidFlow.forward (sigmoid_layer.py:24-47) after the XOR of the two reverse flags:
+ * reverse=0: ldj += sum(-z - 2 softplus(-z)), z' = sigmoid(z);
+ * reverse=1: z = z(1-a)+a/2, ldj += sum(-log z - log(1-z) + log(1-a)), z' = log z - log(1-z). */
+int cnf_sigmoid_flow(const float* z, const float* ldj_in, float* z_out, float* ldj_out,
+                     int B, int L, int reverse, float alpha, int* flags, cnf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CNF_HIP_H */

@@ -412,7 +412,8 @@ def gen_flow_stack():
             neglog = -prior.log_prob(z).sum(dim=[1, 2])
             nll = (-ldj + neglog) / ln.float()
             dec, _ = model(z, reverse=True, length=ln)
-        c = dict(meta=dict(B=B, N=N, D=D, C=C, hidden=hidden, flows=4), categ=cat, u=u, z=z, ldj=ldj, nll=nll,
+        c = dict(meta=dict(B=B, N=N, D=D, C=C, hidden=hidden, flows=4, infos=[l.info() for l in model.flow_layers]),
+                 categ=cat, u=u, z=z, ldj=ldj, nll=nll,
                  decoded=dec, bpd=np.log2(np.exp(1)) * nll.mean())
         for k, v in model.state_dict().items():
             c["sd_" + k] = v

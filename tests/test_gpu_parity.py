@@ -1,0 +1,435 @@
+"""GPU parity tests: the HIP path (through the C ABI, via categoricalnf_amd.ops / the layer modules)
+against (a) the golden vectors captured from the real reference and (b) the CPU oracle on seeded
+inputs, plus size-independent properties at the full benchmark shape.
+
+Tolerances: fp32 kernels 2e-5 abs/rel per element (1 ulp-level libm differences between ocml and
+the reference's SLEEF/MKL), per-sample log-det / log-likelihood 1e-4 relative (BASELINE.json
+north_star), integer category indices bit-exact."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from oracle import cnf_oracle as O
+from tests.golden_util import load_cases
+
+pytestmark = pytest.mark.gpu
+
+ELEM = dict(rtol=2e-5, atol=2e-5)
+LDJ = dict(rtol=1e-4, atol=1e-4)
+
+
+def ops():
+    from categoricalnf_amd import ops as _ops
+    return _ops
+
+
+def g(t):
+    return t.cuda() if isinstance(t, torch.Tensor) else t
+
+
+def close(a, b, **kw):
+    torch.testing.assert_close(a.detach().cpu(), b.detach().cpu(), **kw)
+
+
+def test_library_loaded_is_hip():
+    from categoricalnf_amd import _lib
+    lib = _lib.load()
+    assert lib.cnf_abi_version() == 1
+    assert torch.cuda.is_available()
+    assert "libcnf_hip.so" in open("/proc/self/maps").read()
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("c", load_cases("affine_coupling"))
+def test_affine_golden(c):
+    zf, lf = ops().affine_coupling(g(c.z), g(c.nn_out), g(c.scaling_factor), g(c.mask), reverse=False, ldj=g(c.ldj_in))
+    close(zf, c.z_fwd, **ELEM); close(lf, c.ldj_fwd, **LDJ)
+    zr, lr = ops().affine_coupling(g(c.z_fwd), g(c.nn_out), g(c.scaling_factor), g(c.mask), reverse=True)
+    close(zr, c.z_rev, **ELEM); close(lr, c.ldj_rev, **LDJ)
+    s, t = ops().affine_params(g(c.nn_out), g(c.mask), g(c.scaling_factor))
+    close(s, c.s, **ELEM); close(t, c.t, **ELEM)
+    s, t = ops().affine_params(g(c.nn_out), g(c.mask), None)
+    close(s, c.s_nofac, **ELEM); close(t, c.t_nofac, **ELEM)
+    z2, l2 = ops().affine_transform(g(c.z), g(c.s), g(c.t), reverse=False)
+    close(z2, c.z_fwd, **ELEM); close(l2, c.ldj_fwd - c.ldj_in, **LDJ)
+
+
+@pytest.mark.parametrize("B,N,D,chess", [(37, 64, 6, False), (130, 16, 4, False), (9, 703, 2, False), (50, 21, 2, False),
+                                         (33, 7, 3, False), (1000, 1, 4, False), (17, 9, 1, True), (5, 288, 3, False),
+                                         (3, 2000, 6, False), (64, 38, 6, False)])
+def test_affine_vs_oracle(B, N, D, chess):
+    gen = torch.Generator().manual_seed(B * 1000 + N * 10 + D)
+    z = torch.randn(B, N, D, generator=gen)
+    nn_out = 0.7 * torch.randn(B, N, 2 * D, generator=gen)
+    sf = 0.3 * torch.randn(D, generator=gen)
+    mask = O.chess_mask() if chess else O.channel_mask(D)
+    ldj0 = torch.randn(B, generator=gen)
+    for use_sf in (True, False):
+        zf_o, lf_o = O.affine_coupling(z, nn_out, mask, sf if use_sf else None, reverse=False, ldj=ldj0)
+        zf, lf = ops().affine_coupling(g(z), g(nn_out), g(sf) if use_sf else None, g(mask), reverse=False, ldj=g(ldj0))
+        close(zf, zf_o, **ELEM); close(lf, lf_o, **LDJ)
+        zr_o, lr_o = O.affine_coupling(zf_o, nn_out, mask, sf if use_sf else None, reverse=True)
+        zr, lr = ops().affine_coupling(g(zf_o), g(nn_out), g(sf) if use_sf else None, g(mask), reverse=True)
+        close(zr, zr_o, **ELEM); close(lr, lr_o, **LDJ)
+
+
+def test_affine_tiling_knobs_do_not_change_results():
+    from categoricalnf_amd import _lib
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(5)
+    z, nn_out = torch.randn(301, 64, 6, generator=gen), 0.5 * torch.randn(301, 64, 12, generator=gen)
+    sf, mask = torch.zeros(6), O.channel_mask(6)
+    ref = None
+    try:
+        for chunks in (64, 128, 192, 256, 512):
+            for unroll in (1, 2, 3, 4):
+                lib.cnf_set_tile_chunks(chunks); lib.cnf_set_unroll(unroll)
+                out = ops().affine_coupling(g(z), g(nn_out), g(sf), g(mask))
+                if ref is None:
+                    ref = out
+                    zo, lo = O.affine_coupling(z, nn_out, mask, sf)
+                    close(out[0], zo, **ELEM); close(out[1], lo, **LDJ)
+                assert torch.equal(out[0], ref[0])            # element math independent of the tiling
+                close(out[1], ref[1], rtol=1e-6, atol=1e-5)    # sums may associate differently
+    finally:
+        lib.cnf_set_tile_chunks(256); lib.cnf_set_unroll(4)
+
+
+def test_affine_full_size_properties():
+    """B=16384, N=64, D=6 (the north-star shape): inverse∘forward round trip and ldj antisymmetry."""
+    B, N, D = 16384, 64, 6
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    z = torch.randn(B, N, D, generator=gen, device="cuda")
+    nn_out = 0.5 * torch.randn(B, N, 2 * D, generator=gen, device="cuda")
+    sf = torch.zeros(D, device="cuda")
+    mask = g(O.channel_mask(D))
+    zf, lf = ops().affine_coupling(z, nn_out, sf, mask, reverse=False)
+    zr, lr = ops().affine_coupling(zf, nn_out, sf, mask, reverse=True)
+    assert torch.equal(lf, -lr)                                   # same sums, opposite sign: exact
+    assert (zr - z).abs().max().item() <= 4e-6 * max(1.0, z.abs().max().item())
+    assert torch.equal(zf[..., :3], z[..., :3])                   # masked channels untouched bit-for-bit
+    # a slice against the oracle + linearity of the log-det in the batch (checksum of checksums)
+    zo, lo = O.affine_coupling(z[:64].cpu(), nn_out[:64].cpu(), mask.cpu(), sf.cpu())
+    close(zf[:64], zo, **ELEM); close(lf[:64], lo, **LDJ)
+    _, l_half = ops().affine_coupling(z[:8192].contiguous(), nn_out[:8192].contiguous(), sf, mask)
+    assert torch.equal(l_half, lf[:8192])
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("c", load_cases("mixture_coupling"))
+def test_mixture_golden(c):
+    m = c.meta
+    mask, pad = c.get("mask"), c.get("pad")
+    ar = m["mask_kind"] == "none"
+    kw = dict(num_mixtures=m["K"], scaling_factor=g(c.scaling_factor), mixture_scaling_factor=g(c.mixture_scaling_factor),
+              channel_padding_mask=g(pad), reg_max=m["reg_max"], reg_factor=m["reg_factor"], is_training=m["training"])
+    zf, lf, reg = ops().mixture_coupling(g(c.z), g(c.nn_out), g(mask), reverse=False, **kw)
+    tail = m.get("tail", 1.0) > 1.0
+    etol = dict(rtol=1e-4, atol=1e-4) if tail else ELEM
+    close(zf, c.z_fwd, **etol); close(lf, c.ldj_fwd, **LDJ)
+    if "reg_ldj" in c:
+        close(reg, c.reg_ldj, **LDJ)
+    if m["K"] <= 42:         # the inverse keeps 3K fp64 constants per lane in LDS; the reference has no AR inverse
+        zr, lr, _ = ops().mixture_coupling(g(c.z_fwd), g(c.get("nn_out_rev", c.nn_out)), g(mask), reverse=True, **kw)
+        close(zr, c.z_rev, rtol=1e-4, atol=1e-4); close(lr, c.ldj_rev, **LDJ)
+    if "p_t" in c:
+        p = ops().mixture_params(g(c.nn_out), g(mask), m["K"], g(c.scaling_factor), g(c.mixture_scaling_factor))
+        for got, key in zip(p, ["p_t", "p_log_s", "p_log_pi", "p_mixt_t", "p_mixt_log_s"]):
+            assert got.dtype == torch.float64
+            close(got, c[key], rtol=2e-6, atol=2e-6)
+        # static run_with_params on the reference's own fp64 parameters
+        mk = O.expand_mask(mask, c.z) if mask is not None else None
+        z64, l64, reg_el = ops().mixture_transform(g(c.z.double()), *[g(c[k]) for k in ["p_t", "p_log_s", "p_log_pi", "p_mixt_t", "p_mixt_log_s"]],
+                                                   reverse=False, reg_max=m["reg_max"], reg_factor=m["reg_factor"], mask=g(mk),
+                                                   channel_padding_mask=g(pad) if mask is not None else None, is_training=m["training"])
+        zo, lo, ro = O.mixture_transform(c.z.double(), c.p_t, c.p_log_s, c.p_log_pi, c.p_mixt_t, c.p_mixt_log_s, reverse=False,
+                                         reg_max=m["reg_max"], reg_factor=m["reg_factor"], mask=mk,
+                                         channel_padding_mask=pad if mask is not None else None, is_training=m["training"])
+        close(z64, zo, rtol=1e-9, atol=1e-9); close(l64, lo, rtol=1e-9, atol=1e-9); close(reg_el, ro, rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("B,N,D,K,kind", [(40, 16, 4, 8, "channel"), (7, 50, 6, 16, "channel"), (3, 288, 3, 51, "none"),
+                                          (9, 38, 6, 16, "channel"), (4, 703, 2, 8, "channel"), (11, 13, 1, 8, "chess"),
+                                          (70, 5, 3, 4, "channel"), (300, 1, 2, 8, "channel")])
+def test_mixture_vs_oracle(B, N, D, K, kind):
+    gen = torch.Generator().manual_seed(B + 7 * N + 31 * D + K)
+    z = 1.5 * torch.randn(B, N, D, generator=gen)
+    nn_out = 0.6 * torch.randn(B, N, D * (2 + 3 * K), generator=gen)
+    sf, msf = 0.2 * torch.randn(D, generator=gen), 0.2 * torch.randn(D, K, generator=gen)
+    mask = None if kind == "none" else (O.chess_mask() if kind == "chess" else O.channel_mask(D))
+    ln = torch.randint(max(1, N // 2), N + 1, (B,), generator=gen)
+    pad = O.length_mask(ln, N) if kind != "none" else None
+    kw = dict(num_mixtures=K, reg_max=3.5, reg_factor=2.0, is_training=True)
+    zo, lo, ro = O.mixture_coupling(z, nn_out, mask, scaling_factor=sf, mixture_scaling_factor=msf, channel_padding_mask=pad, **kw)
+    zf, lf, rf = ops().mixture_coupling(g(z), g(nn_out), g(mask), scaling_factor=g(sf), mixture_scaling_factor=g(msf),
+                                        channel_padding_mask=g(pad), **kw)
+    close(zf, zo, **ELEM); close(lf, lo, **LDJ); close(rf, ro, **LDJ)
+    if K <= 42:
+        zo2, lo2, _ = O.mixture_coupling(zo, nn_out, mask, scaling_factor=sf, mixture_scaling_factor=msf,
+                                         channel_padding_mask=pad, reverse=True, **kw)
+        zr, lr, _ = ops().mixture_coupling(g(zo), g(nn_out), g(mask), scaling_factor=g(sf), mixture_scaling_factor=g(msf),
+                                           channel_padding_mask=g(pad), reverse=True, **kw)
+        close(zr, zo2, rtol=1e-4, atol=1e-4); close(lr, lo2, **LDJ)
+        # round trip on the transformed, un-padded entries
+        keep = (pad if pad is not None else torch.ones(B, N, 1)).expand(-1, -1, D) > 0
+        assert ((zr.cpu() - z)[keep]).abs().max() < 5e-4
+
+
+def test_mixture_underflow_fallback_matches_logspace():
+    """Force the direct PDF sum to underflow (|z| ~ 900 scales from every mean): the element must take
+    the log-space branch and still agree with the oracle (rule: rare data-dependent branch gets its own test)."""
+    B, N, D, K = 2, 4, 2, 4
+    gen = torch.Generator().manual_seed(3)
+    z = torch.randn(B, N, D, generator=gen)
+    z[0, 0, 1] = 900.0
+    z[1, 2, 1] = -850.0
+    nn_out = 0.1 * torch.randn(B, N, D * (2 + 3 * K), generator=gen)
+    mask = O.channel_mask(D)
+    zo, lo, _ = O.mixture_coupling(z, nn_out, mask, K, None, None)
+    zf, lf, _ = ops().mixture_coupling(g(z), g(nn_out), g(mask), K)
+    assert torch.isfinite(lf).all()
+    close(lf, lo, **LDJ)
+    fin = torch.isfinite(zo)
+    close(zf.cpu()[fin], zo[fin], **ELEM)
+
+
+def test_mixture_full_size_properties():
+    """configs[1] shape: B=16384, N=16, D=4, K=8 — forward then inverse recovers z; ldj antisymmetric."""
+    B, N, D, K = 16384, 16, 4, 8
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    z = torch.randn(B, N, D, generator=gen, device="cuda")
+    nn_out = 0.5 * torch.randn(B, N, D * (2 + 3 * K), generator=gen, device="cuda")
+    mask = g(O.channel_mask(D))
+    zf, lf, _ = ops().mixture_coupling(z, nn_out, mask, K)
+    zr, lr, _ = ops().mixture_coupling(zf, nn_out, mask, K, reverse=True)
+    assert (zr - z).abs().max().item() < 2e-4
+    assert ((lf + lr).abs() / lf.abs().clamp(min=1.0)).max().item() < 1e-4
+    assert torch.equal(zf[..., :2], z[..., :2])
+    zo, lo, _ = O.mixture_coupling(z[:32].cpu(), nn_out[:32].cpu(), mask.cpu(), K, None, None)
+    close(zf[:32], zo, **ELEM); close(lf[:32], lo, **LDJ)
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("c", load_cases("actnorm"))
+def test_actnorm_golden(c):
+    mode = c.meta["mode"]
+    kw = {}
+    if "length" in mode:
+        kw["length"] = g(c.length)
+    if "mask" in mode:
+        kw["channel_padding_mask"] = g(c.pad)
+    ldj = g(c.ldj_in.clone())
+    zf, lf = ops().actnorm(g(c.z), g(c.bias), g(c.scales), reverse=False, ldj=ldj, **kw)
+    assert lf.data_ptr() == ldj.data_ptr()           # in-place `ldj +=` like the reference
+    close(zf, c.z_fwd, **ELEM); close(lf, c.ldj_fwd, **LDJ)
+    zr, lr = ops().actnorm(g(c.z_fwd), g(c.bias), g(c.scales), reverse=True, **kw)
+    close(zr, c.z_rev, **ELEM); close(lr, c.ldj_rev, **LDJ)
+    b, s = ops().actnorm_data_init(g(c.z), g(c.pad) if "mask" in mode else None)
+    close(b, c.init_bias, rtol=1e-5, atol=1e-5); close(s, c.init_scales, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("c", load_cases("ext_actnorm"))
+def test_ext_actnorm_golden(c):
+    pad = g(c.pad) if c.meta["padded"] else None
+    zf, lf = ops().ext_actnorm(g(c.z), g(c.nn_out), reverse=False, channel_padding_mask=pad, ldj=g(c.ldj_in.clone()))
+    close(zf, c.z_fwd, **ELEM); close(lf, c.ldj_fwd, **LDJ)
+    zr, lr = ops().ext_actnorm(g(c.z_fwd), g(c.nn_out), reverse=True, channel_padding_mask=pad)
+    close(zr, c.z_rev, **ELEM); close(lr, c.ldj_rev, **LDJ)
+
+
+@pytest.mark.parametrize("c", load_cases("invconv"))
+def test_invconv_golden(c):
+    from categoricalnf_amd.layers.flows.permutation_layers import InvertibleConv
+    mode = c.meta["mode"]
+    kw = {}
+    if "length" in mode:
+        kw["length"] = g(c.length)
+    if "mask" in mode:
+        kw["channel_padding_mask"] = g(c.pad)
+    D = c.meta["D"]
+    layer = InvertibleConv(D, LU_decomposed=c.meta["lu"])
+    layer.load_state_dict({k[3:]: v for k, v in c.items() if k.startswith("sd_")})     # reference checkpoint keys
+    layer.cuda()
+    with torch.no_grad():
+        for train in (True, False):
+            layer.train(train)
+            zf, lf = layer(g(c.z), ldj=g(c.ldj_in.clone()), reverse=False, **kw)
+            close(zf, c.z_fwd, **ELEM); close(lf, c.ldj_fwd, **LDJ)
+            zr, lr = layer(g(c.z_fwd), reverse=True, **kw)
+            close(zr, c.z_rev, **ELEM); close(lr, c.ldj_rev, **LDJ)
+        assert str(torch.device("cuda:0")) in layer.eval_dict or "cuda:0" in layer.eval_dict
+
+
+@pytest.mark.parametrize("D", [1, 2, 3, 4, 5, 6, 7, 8, 10])
+def test_actnorm_invconv_vs_oracle(D):
+    B, N = 257, 19
+    gen = torch.Generator().manual_seed(D)
+    z = torch.randn(B, N, D, generator=gen)
+    w = torch.linalg.qr(torch.randn(D, D, generator=gen))[0] + 0.1 * torch.randn(D, D, generator=gen)
+    sldj = torch.slogdet(w)[1]
+    ln = torch.randint(N // 2, N + 1, (B,), generator=gen)
+    pad = O.length_mask(ln, N)
+    zo, lo = O.invconv(z, w, sldj, length=ln, channel_padding_mask=pad)
+    zf, lf = ops().invconv(g(z), g(w), g(sldj), length=g(ln), channel_padding_mask=g(pad))
+    close(zf, zo, **ELEM); close(lf, lo, **LDJ)
+    bias, sc = torch.randn(1, 1, D, generator=gen), 0.3 * torch.randn(1, 1, D, generator=gen)
+    zo, lo = O.actnorm(z, bias, sc, channel_padding_mask=pad)           # length from the mask row-sum
+    zf, lf = ops().actnorm(g(z), g(bias), g(sc), channel_padding_mask=g(pad))
+    close(zf, zo, **ELEM); close(lf, lo, **LDJ)
+
+
+# ------------------------------------------------------------------------------------------------
+def test_prior_golden():
+    for c in load_cases("prior"):
+        k = c.meta["kind"]
+        if k == "log_prob":
+            close(ops().logistic_log_prob(g(c.x)), c.log_prob, rtol=2e-6, atol=2e-6)
+        elif k == "sample":
+            s = ops().logistic_from_uniform(g(c.u))
+            close(s, c.sample, rtol=2e-6, atol=2e-6)
+        else:
+            sums = torch.zeros(2, dtype=torch.float64, device="cuda")
+            neglog, nll = ops().prior_nll(g(c.z), g(c.ldj), g(c.length), g(c.pad), sums=sums)
+            close(neglog, c.neglog, **LDJ); close(nll, c.nll, **LDJ)
+            assert abs(sums[0].item() / sums[1].item() - float(c.nll_mean)) < 1e-5
+            assert sums[1].item() == c.z.size(0)
+
+
+@pytest.mark.parametrize("c", load_cases("encoder"))
+def test_encoder_golden(c):
+    m = c.meta
+    eps = ops().logistic_from_uniform(g(c.u))
+    pad = g(c.pad) if m["padded"] else None
+    z, ldj, cpl = ops().encoder_forward(g(c.categ), eps, g(c.table), g(c.category_prior), beta=m["beta"],
+                                        channel_padding_mask=pad, want_class_prob=True)
+    close(z, c.z, **ELEM); close(ldj, c.ldj, **LDJ)
+    dec = ops().encoder_decode(g(c.z), g(c.table), g(c.category_prior))
+    assert torch.equal(dec.cpu(), c.decoded)                       # integer indices: bit-exact
+    dec = ops().encoder_decode(g(c.z_probe), g(c.table), g(c.category_prior))
+    assert torch.equal(dec.cpu(), c.decoded_probe)
+
+
+@pytest.mark.parametrize("c", load_cases("encoder"))
+def test_encoder_module_golden(c):
+    """The drop-in module with the reference's state_dict and the reference's noise draw."""
+    from categoricalnf_amd.layers.categorical_encoding.linear_encoding import LinearCategoricalEncoding
+    m = c.meta
+    enc = LinearCategoricalEncoding(num_dimensions=m["D"], flow_config={"num_flows": 0}, vocab_size=m["C"])
+    enc.load_state_dict({k[3:]: v for k, v in c.items() if k.startswith("sd_")})
+    enc.cuda().train(m["training"])
+    kw = dict(channel_padding_mask=g(c.pad)) if m["padded"] else {}
+    with torch.no_grad():
+        z, ldj, det = enc(g(c.categ), reverse=False, beta=m["beta"], noise=g(c.u), **kw)
+        dec, ldj_r, _ = enc(g(c.z), reverse=True)
+    close(z, c.z, **ELEM); close(ldj, c.ldj, **LDJ)
+    assert torch.equal(dec.cpu(), c.decoded) and float(ldj_r.abs().sum()) == 0.0
+    if m["training"]:
+        assert set(det) == {"avg_token_prob", "avg_token_bpd", "z_min", "z_max", "z_std"}
+        close(det["avg_token_prob"], c.detail_avg_token_prob, rtol=1e-4, atol=1e-5)
+        close(det["z_std"], c.detail_z_std, rtol=1e-4, atol=1e-5)
+    else:
+        assert det == {}
+
+
+def test_encoder_cpu_generator_matches_reference_seed():
+    """CNF_NOISE=cpu mode: torch.manual_seed reproduces the reference's own noise (linear_encoding.py:76)."""
+    from categoricalnf_amd.layers.categorical_encoding.linear_encoding import LinearCategoricalEncoding
+    c = load_cases("encoder")[0]
+    m = c.meta
+    enc = LinearCategoricalEncoding(num_dimensions=m["D"], flow_config={"num_flows": 0}, vocab_size=m["C"])
+    enc.load_state_dict({k[3:]: v for k, v in c.items() if k.startswith("sd_")})
+    enc.cuda().train(m["training"])
+    enc.noise_generator = "cpu"
+    torch.manual_seed(500 + 0)
+    with torch.no_grad():
+        z, ldj, _ = enc(g(c.categ), reverse=False, beta=m["beta"])
+    close(z, c.z, **ELEM); close(ldj, c.ldj, **LDJ)
+
+
+def test_sigmoid_and_dequant_golden():
+    for c in load_cases("sigmoid"):
+        if not c.meta["reverse_layer"]:
+            a, la = ops().sigmoid_flow(g(c.z), reverse=False)
+            b, lb = ops().sigmoid_flow(g(c.u), reverse=True)
+        else:
+            a, la = ops().sigmoid_flow(g(c.u), reverse=True)
+            b, lb = ops().sigmoid_flow(g(c.z), reverse=False)
+        close(a, c.out_fwd, **ELEM); close(la, c.ldj_fwd, **LDJ); close(b, c.out_rev, **ELEM); close(lb, c.ldj_rev, **LDJ)
+
+    from categoricalnf_amd.layers.categorical_encoding.variational_dequantization import VariationalDequantization
+    c = load_cases("dequant")[0]
+    m = c.meta
+    hidden, emb = m["hidden"], m["emb"]
+
+    class Net(nn.Module):
+        def __init__(self, c_out):
+            super().__init__()
+            self.inp = nn.Linear(1, hidden)
+            self.main = nn.Sequential(nn.Linear(hidden + emb, hidden), nn.ReLU(), nn.Linear(hidden, c_out))
+
+        def forward(self, x, ext_input, **kw):
+            return self.main(torch.cat([self.inp(x), ext_input], dim=-1))
+
+    vd = VariationalDequantization(vocab_size=m["C"], flow_config={"num_flows": m["num_flows"], "model_func": lambda c_out: Net(c_out),
+                                                                    "block_type": "Linear"}, default_embed_layer_dims=emb)
+    vd.load_state_dict({k[3:]: v for k, v in c.items() if k.startswith("sd_")})
+    vd.cuda()
+    with torch.no_grad():
+        z, ldj = vd(g(c.categ), reverse=False, noise=g(c.u))
+        rec, _ = vd(z, reverse=True)
+    close(z, c.z, rtol=1e-4, atol=1e-4); close(ldj, c.ldj, rtol=1e-4, atol=2e-4)
+    assert torch.equal(rec.cpu(), c.categ)                          # inverse∘forward bit-exact on integer indices
+    assert torch.equal(rec.cpu(), c.decoded)
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("c", load_cases("flow_stack"))
+def test_flow_stack_config0(c):
+    """BASELINE configs[0]: |S|=16, d_latent=2, 4 affine couplings, batch 256 — whole-model per-sample
+    log-likelihood (<= 1e-4 relative), bits/dim (+-0.01) and decoded indices vs the reference."""
+    from categoricalnf_amd.layers.flows.flow_model import FlowModel
+    from categoricalnf_amd.layers.flows.activation_normalization import ActNormFlow
+    from categoricalnf_amd.layers.flows.permutation_layers import InvertibleConv
+    from categoricalnf_amd.layers.flows.coupling_layer import CouplingLayer
+    from categoricalnf_amd.layers.flows.distributions import LogisticDistribution
+    from categoricalnf_amd.layers.categorical_encoding.linear_encoding import LinearCategoricalEncoding
+    m = c.meta
+    D, hidden = m["D"], m["hidden"]
+    mk = lambda c_out: nn.Sequential(nn.Linear(D, hidden), nn.GELU(), nn.Linear(hidden, c_out))
+    layers = [LinearCategoricalEncoding(num_dimensions=D, flow_config={"num_flows": 0}, vocab_size=m["C"])]
+    for _ in range(m["flows"]):
+        layers += [ActNormFlow(D), InvertibleConv(D), CouplingLayer(D, CouplingLayer.create_channel_mask(D), mk)]
+    model = FlowModel(layers)
+    model.load_state_dict({k[3:]: v for k, v in c.items() if k.startswith("sd_")})
+    model.cuda().eval()
+    ln = torch.full((m["B"],), m["N"], dtype=torch.long, device="cuda")
+    with torch.no_grad():
+        z, ldj = model(g(c.categ), reverse=False, length=ln, noise=g(c.u))
+        neglog, nll = ops().prior_nll(z, ldj, ln)
+        dec, _ = model(g(c.z), reverse=True, length=ln)
+    close(z, c.z, rtol=1e-4, atol=1e-4)
+    close(ldj, c.ldj, **LDJ)
+    close(nll, c.nll, **LDJ)
+    bpd = float(np.log2(np.exp(1)) * nll.mean().item())
+    assert abs(bpd - float(c.bpd)) < 0.01
+    assert torch.equal(dec.cpu(), c.decoded)
+
+
+def test_nan_raises_reference_assertion():
+    from categoricalnf_amd.layers.flows.flow_model import FlowModel
+    from categoricalnf_amd.layers.flows.activation_normalization import ActNormFlow
+    model = FlowModel([ActNormFlow(3, data_init=False)]).cuda()
+    z = torch.randn(4, 5, 3, device="cuda")
+    z[1, 2, 0] = float("nan")
+    with pytest.raises(AssertionError):
+        with torch.no_grad():
+            model(z)
+    with torch.no_grad():
+        model(torch.randn(4, 5, 3, device="cuda"))       # flag word was cleared
+
+
+def test_cpu_tensor_is_rejected():
+    from categoricalnf_amd import ops as o
+    with pytest.raises(o.HipOnlyError):
+        o.affine_coupling(torch.randn(2, 3, 2), torch.randn(2, 3, 4), None, None)

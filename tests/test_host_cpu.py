@@ -1,0 +1,178 @@
+"""CPU-side tests (no GPU): C-ABI surface, loader, host logic of the drop-in modules, and the
+world_size-2 gloo path of the sharded NLL reduction."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from tests.golden_util import load_cases
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    from categoricalnf_amd import build, _lib
+    build.build()
+    return _lib.load()
+
+
+def test_abi_exports_every_declared_symbol(built_lib):
+    from categoricalnf_amd import _lib
+    header = open(os.path.join(ROOT, "include", "cnf_hip.h")).read()
+    declared = set(re.findall(r"^(?:int|void|const char\*)\s+(cnf_\w+)\s*\(", header, flags=re.M))
+    assert declared, "no prototypes found in include/cnf_hip.h"
+    assert declared == set(_lib.exported_symbols())
+    nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], stdout=subprocess.PIPE, text=True).stdout
+    exported = set(re.findall(r" T (cnf_\w+)", nm))
+    assert declared <= exported, "missing from the .so: %s" % sorted(declared - exported)
+    assert built_lib.cnf_abi_version() == 1
+
+
+def test_abi_rejects_bad_arguments_without_touching_a_gpu(built_lib):
+    rc = built_lib.cnf_affine_coupling(None, None, None, None, 0, 0, None, None, None, 4, 4, 4, 0, None, None)
+    assert rc == 1 and b"null tensor" in built_lib.cnf_last_error()
+    rc = built_lib.cnf_mixture_coupling(None, None, None, None, None, 0, 0, None, 0, None, 0, 0, None, None, None, None,
+                                        1, 1, 1, 1, 0, -1.0, 1.0, 1, None, None)
+    assert rc == 1
+
+
+def test_single_hip_runtime_mapped(built_lib):
+    maps = open("/proc/self/maps").read()
+    assert len(set(re.findall(r"\S*libamdhip64\S*", maps))) == 1
+
+
+def test_no_cpu_fallback():
+    from categoricalnf_amd import ops
+    with pytest.raises(ops.HipOnlyError):
+        ops.affine_coupling(torch.randn(2, 3, 2), torch.randn(2, 3, 4), None, None)
+    with pytest.raises(ops.HipOnlyError):
+        ops.logistic_log_prob(torch.randn(5))
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "categoricalnf_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f
+                assert "cnf_oracle" not in src, f
+
+
+def test_masks_and_helpers_match_reference_semantics():
+    from categoricalnf_amd.layers.flows.coupling_layer import CouplingLayer
+    from categoricalnf_amd.host_utils import create_channel_mask, create_transformer_mask, get_param_val, one_hot
+    assert CouplingLayer.create_channel_mask(6).tolist() == [[1, 1, 1, 0, 0, 0]]
+    assert CouplingLayer.create_channel_mask(3).tolist() == [[1, 0, 0]]
+    assert CouplingLayer.create_channel_mask(3, mask_floor=False).tolist() == [[1, 1, 0]]
+    assert CouplingLayer.create_chess_mask().tolist() == [[1], [0]]
+    for c in load_cases("affine_coupling"):
+        kind = c.meta["mask_kind"]
+        m = CouplingLayer.create_channel_mask(c.meta["D"]) if kind == "channel" else CouplingLayer.create_chess_mask()
+        if c.meta["flip"]:
+            m = 1 - m
+        assert torch.equal(m, c.mask)
+    layer = CouplingLayer(1, CouplingLayer.create_chess_mask(), lambda c_out: nn.Identity())
+    assert layer._prepare_mask(layer.mask, torch.zeros(2, 5, 1)).flatten().tolist() == [1, 0, 1, 0, 1]
+    ln = torch.tensor([3, 1])
+    assert create_channel_mask(ln, 4).shape == (2, 4, 1) and create_channel_mask(ln, 4)[1, :, 0].tolist() == [1, 0, 0, 0]
+    assert create_transformer_mask(ln, 4)[0].tolist() == [False, False, False, True]
+    assert get_param_val({"a": 1}, "a") == 1 and get_param_val({}, "b", 7, warning_if_default=False) == 7
+    assert one_hot(torch.tensor([2, 0]), 3).tolist() == [[0, 0, 1], [1, 0, 0]]
+
+
+def test_state_dict_names_info_strings_and_factory():
+    """Checkpoint compatibility: parameter/buffer names and info() strings equal the reference's."""
+    from categoricalnf_amd.layers.flows.flow_model import FlowModel
+    from categoricalnf_amd.layers.flows.activation_normalization import ActNormFlow
+    from categoricalnf_amd.layers.flows.permutation_layers import InvertibleConv
+    from categoricalnf_amd.layers.flows.coupling_layer import CouplingLayer
+    from categoricalnf_amd.layers.flows.mixture_cdf_layer import MixtureCDFCoupling
+    from categoricalnf_amd.layers.flows.autoregressive_coupling import AutoregressiveMixtureCDFCoupling
+    from categoricalnf_amd.layers.categorical_encoding.mutils import create_encoding
+    c = load_cases("flow_stack")[1]
+    m = c.meta
+    D, hidden = m["D"], m["hidden"]
+    mk = lambda c_out: nn.Sequential(nn.Linear(D, hidden), nn.GELU(), nn.Linear(hidden, c_out))
+    params = {"use_dequantization": False, "use_variational": False, "num_dimensions": D, "flow_config": {"num_flows": 0}}
+    enc = create_encoding(params, dataset_class=None, vocab_size=m["C"])
+    assert "use_dequantization" not in params and "use_variational" not in params      # popped, like the reference
+    layers = [enc]
+    for _ in range(m["flows"]):
+        layers += [ActNormFlow(D), InvertibleConv(D), CouplingLayer(D, CouplingLayer.create_channel_mask(D), mk)]
+    model = FlowModel(layers)
+    ref_keys = sorted(k[3:] for k in c if k.startswith("sd_"))
+    assert sorted(model.state_dict().keys()) == ref_keys
+    model.load_state_dict({k[3:]: v for k, v in c.items() if k.startswith("sd_")})
+    assert [l.info() for l in model.flow_layers] == m["infos"]
+    assert model.need_data_init()
+    mix = MixtureCDFCoupling(c_in=4, mask=CouplingLayer.create_channel_mask(4), model_func=lambda c_out: nn.Linear(4, c_out),
+                             block_type="Transformer", num_mixtures=8)
+    assert set(dict(mix.named_parameters())) == {"scaling_factor", "mixture_scaling_factor", "nn.weight", "nn.bias"}
+    assert mix.nn.out_features == 4 * (2 + 3 * 8) and tuple(mix.mixture_scaling_factor.shape) == (4, 8)
+    assert mix.info() == "Mixture CDF Coupling Layer - Input size 4, block type Transformer, 8 mixtures, mask ratio 0.50, channel mask"
+    ar = AutoregressiveMixtureCDFCoupling(c_in=3, model_func=lambda c_out: nn.Linear(3, c_out), num_mixtures=51)
+    assert ar.nn.out_features == 3 * 155
+    with pytest.raises(NotImplementedError):
+        ar(torch.zeros(1, 2, 3), reverse=True)
+
+
+def test_install_aliases_reference_import_paths():
+    code = ("import categoricalnf_amd as c; c.install();"
+            "from layers.flows.coupling_layer import CouplingLayer;"
+            "from layers.categorical_encoding.mutils import create_encoding;"
+            "from layers.flows.mixture_cdf_layer import MixtureCDFCoupling;"
+            "print(CouplingLayer.__module__, create_encoding.__module__)")
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert out.returncode == 0, out.stderr
+    assert "categoricalnf_amd.layers.flows.coupling_layer" in out.stdout
+
+
+def test_row_tiling_covers_every_row_once():
+    """Host logic of the kernels' tiling mirrored in Python: every row is owned by exactly one tile."""
+    from categoricalnf_amd.distributed import shard_bounds
+    for total, world in [(16384, 8), (10, 3), (7, 8), (1, 2)]:
+        cover = []
+        for r in range(world):
+            lo, hi = shard_bounds(total, r, world)
+            cover += list(range(lo, hi))
+        assert cover == list(range(total))
+
+
+WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from categoricalnf_amd.distributed import init_process_group, shard_bounds, allreduce_nll
+from oracle import cnf_oracle as O          # test infrastructure: per-rank compute on CPU
+rank, _, world = init_process_group("gloo")
+g = torch.Generator().manual_seed(0)
+B, N, D = 64, 8, 4
+z, ldj = torch.randn(B, N, D, generator=g), torch.randn(B, generator=g)
+ln = torch.full((B,), N)
+lo, hi = shard_bounds(B, rank, world)
+nll = O.nll_per_sample(z[lo:hi], ldj[lo:hi], ln[lo:hi])
+sums = torch.tensor([float(nll.double().sum()), float(hi - lo)], dtype=torch.float64)
+mean, bpd = allreduce_nll(sums)
+full = O.nll_per_sample(z, ldj, ln).double().mean().item()
+assert abs(mean - full) < 1e-9, (mean, full)
+assert abs(bpd - O.bits_per_dim(full)) < 1e-9
+if rank == 0:
+    print("OK", world, mean)
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_gloo_nll_allreduce(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", "29631", str(script), ROOT]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=240, env=env)
+    assert out.returncode == 0, out.stdout[-2000:]
+    assert "OK 2" in out.stdout
