@@ -46,15 +46,28 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-mixture", action="store_true", help="skip the secondary mixture-CDF measurement")
     p.add_argument("--tile-chunks", type=int, default=0)
-    p.add_argument("--unroll", type=int, default=0)
+    p.add_argument("--unroll", type=int, default=-1)
+    p.add_argument("--math-mode", type=int, default=-1)
     p.add_argument("--rotate", type=int, default=4, help="buffer sets rotated through (defeats the 256 MB Infinity Cache)")
     return p.parse_args()
+
+
+def usable_cores():
+    """Host cores this process may really use: min(affinity, cgroup CPU quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
 
 
 def cpu_baseline(B, N, D, budget_s=15.0):
     """Oracle (torch CPU ops, all host threads) on the same step at the same shape."""
     from oracle import cnf_oracle as O
-    threads = os.cpu_count() or 1
+    threads = usable_cores()
     torch.set_num_threads(threads)
     g = torch.Generator().manual_seed(0)
     z = torch.randn(B, N, D, generator=g)
@@ -131,8 +144,10 @@ def main():
     lib = _lib.load()
     if args.tile_chunks:
         lib.cnf_set_tile_chunks(args.tile_chunks)
-    if args.unroll:
+    if args.unroll >= 0:
         lib.cnf_set_unroll(args.unroll)
+    if args.math_mode >= 0:
+        lib.cnf_set_math_mode(args.math_mode)
 
     B, N, D = args.batch, args.seq, args.dim
     elems = B * N * D
@@ -146,6 +161,7 @@ def main():
     sums = torch.zeros(2, dtype=torch.float64, device=dev)
     ev_a = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev_b = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev_c = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]   # empty pair: event overhead
 
     # outputs and pre-bound launches per buffer set (host cost per launch ~2 us)
     zfs = [torch.empty_like(zs[0]) for _ in range(R)]
@@ -164,7 +180,7 @@ def main():
         fwd[r]()
         if timed >= 0:
             ev_b[timed].record()
-        sums.zero_()
+            ev_c[timed].record()
         nlls[r]()
         inv[r]()
         if world > 1:
@@ -196,13 +212,32 @@ def main():
     assert torch.equal(lfs[r_last], -lrs[r_last]), "ldj_fwd + ldj_inv != 0"
     mean_nll = float(sums[0].item() / max(sums[1].item(), 1.0))
 
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev_a, ev_b)]))
+    # Duration of the dominant kernel (affine forward), with HIP events on the launch stream:
+    #  (1) every forward launch of the timed region is bracketed by an event pair (raw_ms; it carries the
+    #      record-to-record latency of two markers, ovh_ms is that latency for an empty pair);
+    #  (2) `kern_ms`, the figure the roofline uses, is the mean over 100 back-to-back forward launches on the
+    #      same rotating buffer sets, one event pair around the batch.  It contains the
+    #      inter-kernel boundary (~1 us), so it is slightly pessimistic against rocprofv3's kernel-only average.
+    raw_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev_a, ev_b)]))
+    ovh_ms = float(np.mean([b.elapsed_time(c) for b, c in zip(ev_b, ev_c)]))
+    reps, rounds = 100, []
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(reps):
+            fwd[i % R]()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        rounds.append(e0.elapsed_time(e1) / reps)
+    kern_ms = float(np.median(rounds))
     alg_bytes = 16.0 * elems + 4.0 * B            # z 4 + (s,t) 8 + z' 4 per elem, + ldj per sample
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
+            # HBM bytes per launch from the rocprofv3 --pmc passes (FETCH_SIZE x2 per the gfx950 correction,
+            # WRITE_SIZE x1, both calibrated on a known-size copy; tools/pmc_summarize.py)
             traffic = json.load(open(tpath)).get("affine_coupling_fwd_bytes_per_launch")
         except Exception:
             traffic = None
@@ -227,7 +262,7 @@ def main():
                        "buffer_sets_rotated": R, "parallelism": "dp%d (batch shards, 1 all-reduce of 2 fp64)" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "affine_coupling_kernel<VEC=4,fwd>", "kernel_ms": kern_ms,
+                         "kernel": "affine_coupling_kernel<VEC=4,fwd>", "kernel_ms": kern_ms, "in_step_event_pair_ms": raw_ms, "empty_event_pair_ms": ovh_ms,
                          "algorithmic_bytes_per_launch": alg_bytes},
             "mean_nll": mean_nll,
         }

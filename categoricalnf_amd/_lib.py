@@ -44,7 +44,8 @@ SIGNATURES = {
     "cnf_sigmoid_flow": [_p, _p, _p, _p, _i, _i, _i, _f, _p, _p],
 }
 _PLAIN = {"cnf_abi_version": ([], _i), "cnf_last_error": ([], ctypes.c_char_p),
-          "cnf_set_tile_chunks": ([_i], None), "cnf_set_unroll": ([_i], None)}
+          "cnf_set_tile_chunks": ([_i], None), "cnf_set_unroll": ([_i], None),
+          "cnf_set_math_mode": ([_i], None)}
 
 _lib = None
 

@@ -12,9 +12,19 @@ namespace cnf {
 
 // per (mask-row, channel) constants staged in LDS: keep = 1-mask, keepf = keep*e^sf, fc = max(e^sf,1)
 struct alignas(16) ChanTab {
-    float keep, keepf, fc, pad_;
+    float keep, keepf, fc, inv_fc;
 };
-constexpr int kMaxTab = 256;
+
+// FAST = hardware transcendental path: exp via v_exp_f32, tanh(x) = 1 - 2/(e^{2x}+1)
+template <bool FAST>
+__device__ __forceinline__ float exp_m(float x) { return FAST ? __expf(x) : expf(x); }
+template <bool FAST>
+__device__ __forceinline__ float tanh_m(float x) {
+    if (!FAST) return tanhf(x);
+    const float e = __expf(2.f * x);
+    return 1.f - __fdividef(2.f, e + 1.f);
+}
+constexpr int kMaxTab = 64;     // (mask period) x D entries, one private copy per wave
 
 struct AffineArgs {
     const float* z;
@@ -77,23 +87,37 @@ struct AffineChunk {
     float zv[VEC], sr[VEC], tr[VEC];
 };
 
-template <int VEC, int U, bool HAS_SF, bool REVERSE>
+template <int VEC, int U, bool HAS_SF, bool REVERSE, bool FAST>
 __global__ __launch_bounds__(kBlock) void affine_coupling_kernel(AffineArgs a, RowTiling tl) {
     __shared__ float part[kWavesPerBlock][kMaxTileChunks];
-    __shared__ ChanTab tab[kMaxTab];
+    __shared__ ChanTab tab_all[kWavesPerBlock][kMaxTab];
+    ChanTab* tab = tab_all[threadIdx.x >> 6];
+    // per-wave constant table: its two tiny loads are issued FIRST, the table itself is finished
+    // after the first chunk loads are in flight (vmcnt is in-order, so waiting for these does not
+    // wait for the chunk loads issued behind them) — see walk_row_tile_split.
     const int ntab = a.mr * a.D;
-    for (int i = threadIdx.x; i < ntab; i += kBlock) {
-        const int r = i / a.D, d = i - r * a.D;
-        const float m = a.mask ? a.mask[r * a.mc + (a.mc == 1 ? 0 : d)] : 0.f;
-        const float f = HAS_SF ? expf(a.sf[d]) : 1.f;
-        ChanTab t;
-        t.keep = 1.f - m;
-        t.keepf = (1.f - m) * f;
-        t.fc = fmaxf(f, 1.f);
-        t.pad_ = 0.f;
-        tab[i] = t;
+    const int ti = threadIdx.x & 63;
+    float m_raw = 0.f, sf_raw = 0.f;
+    if (ti < ntab) {
+        const int r = ti / a.D, d = ti - r * a.D;
+        if (a.mask) m_raw = a.mask[r * a.mc + (a.mc == 1 ? 0 : d)];
+        if (HAS_SF) sf_raw = a.sf[d];
     }
-    __syncthreads();
+    auto pre = [&]() {
+        // opaque to the optimiser until here: keeps the wait for these two values (and the exp)
+        // behind the chunk loads issued in between
+        asm volatile("" : "+v"(sf_raw), "+v"(m_raw) : : "memory");
+        if (ti < ntab) {
+            const float f = HAS_SF ? expf(sf_raw) : 1.f;
+            ChanTab t;
+            t.keep = 1.f - m_raw;
+            t.keepf = (1.f - m_raw) * f;
+            t.fc = fmaxf(f, 1.f);
+            t.inv_fc = 1.f / fmaxf(f, 1.f);
+            tab[ti] = t;
+        }
+        wave_lds_sync();
+    };
 
     bool bad = false;
     auto load = [&](int row, int e0) {
@@ -113,9 +137,9 @@ __global__ __launch_bounds__(kBlock) void affine_coupling_kernel(AffineArgs a, R
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             const ChanTab tb = tab[nm * a.D + d];
-            const float s = HAS_SF ? tanhf(c.sr[j] / tb.fc) * tb.keepf : c.sr[j] * tb.keep;
+            const float s = HAS_SF ? tanh_m<FAST>(FAST ? c.sr[j] * tb.inv_fc : c.sr[j] / tb.fc) * tb.keepf : c.sr[j] * tb.keep;
             const float t = c.tr[j] * tb.keep;
-            out[j] = REVERSE ? c.zv[j] * expf(-1.f * s) - t : (c.zv[j] + t) * expf(s);
+            out[j] = REVERSE ? c.zv[j] * exp_m<FAST>(-1.f * s) - t : (c.zv[j] + t) * exp_m<FAST>(s);
             bad |= isnan(out[j]);
             acc += s;
             if (++d == a.D) {
@@ -132,34 +156,43 @@ __global__ __launch_bounds__(kBlock) void affine_coupling_kernel(AffineArgs a, R
         a.ldj_out[row] = v;
         if (isnan(v)) raise_flag(a.flags, CNF_FLAG_NAN_LDJ);
     };
-    walk_row_tile_split<U, float, AffineChunk<VEC>>(tl, part[threadIdx.x >> 6], load, proc, finish);
+    walk_row_tile_split<(U == 0 ? 1 : U), float, AffineChunk<VEC>, U == 0>(tl, part[threadIdx.x >> 6], load, proc, finish, pre);
     if (bad) raise_flag(a.flags, CNF_FLAG_NAN_Z);
 }
 
-template <int VEC, int U>
+template <int VEC, int U, bool FAST>
 static void launch_affine_u(const AffineArgs& a, const RowTiling& tl, bool has_sf, bool reverse,
                             hipStream_t st) {
     const dim3 grid = tiling_grid(tl), block(kBlock);
     if (has_sf) {
-        if (reverse) hipLaunchKernelGGL((affine_coupling_kernel<VEC, U, true, true>), grid, block, 0, st, a, tl);
-        else hipLaunchKernelGGL((affine_coupling_kernel<VEC, U, true, false>), grid, block, 0, st, a, tl);
+        if (reverse) hipLaunchKernelGGL((affine_coupling_kernel<VEC, U, true, true, FAST>), grid, block, 0, st, a, tl);
+        else hipLaunchKernelGGL((affine_coupling_kernel<VEC, U, true, false, FAST>), grid, block, 0, st, a, tl);
     } else {
-        if (reverse) hipLaunchKernelGGL((affine_coupling_kernel<VEC, U, false, true>), grid, block, 0, st, a, tl);
-        else hipLaunchKernelGGL((affine_coupling_kernel<VEC, U, false, false>), grid, block, 0, st, a, tl);
+        if (reverse) hipLaunchKernelGGL((affine_coupling_kernel<VEC, U, false, true, FAST>), grid, block, 0, st, a, tl);
+        else hipLaunchKernelGGL((affine_coupling_kernel<VEC, U, false, false, FAST>), grid, block, 0, st, a, tl);
+    }
+}
+
+template <int VEC, bool FAST>
+static void launch_affine_m(const AffineArgs& a, const RowTiling& tl, bool has_sf, bool reverse,
+                            hipStream_t st) {
+    // chunks per lane in one tile bound how many loads are worth issuing back to back
+    const int want = unroll_target();
+    const int per_lane = (int)std::min<long>(((long)tl.rw * tl.cpr + kWave - 1) / kWave, std::max(want, 1));
+    if (want == 0) { launch_affine_u<VEC, 0, FAST>(a, tl, has_sf, reverse, st); return; }
+    switch (per_lane) {
+        case 1: launch_affine_u<VEC, 1, FAST>(a, tl, has_sf, reverse, st); break;
+        case 2: launch_affine_u<VEC, 2, FAST>(a, tl, has_sf, reverse, st); break;
+        case 3: launch_affine_u<VEC, 3, FAST>(a, tl, has_sf, reverse, st); break;
+        default: launch_affine_u<VEC, 4, FAST>(a, tl, has_sf, reverse, st); break;
     }
 }
 
 template <int VEC>
 static void launch_affine(const AffineArgs& a, const RowTiling& tl, bool has_sf, bool reverse,
                           hipStream_t st) {
-    // chunks per lane in one tile decide how many loads are worth issuing back to back
-    const int per_lane = (int)std::min<long>(((long)tl.rw * tl.cpr + kWave - 1) / kWave, unroll_target());
-    switch (per_lane) {
-        case 1: launch_affine_u<VEC, 1>(a, tl, has_sf, reverse, st); break;
-        case 2: launch_affine_u<VEC, 2>(a, tl, has_sf, reverse, st); break;
-        case 3: launch_affine_u<VEC, 3>(a, tl, has_sf, reverse, st); break;
-        default: launch_affine_u<VEC, 4>(a, tl, has_sf, reverse, st); break;
-    }
+    if (math_mode() == 1) launch_affine_m<VEC, true>(a, tl, has_sf, reverse, st);
+    else launch_affine_m<VEC, false>(a, tl, has_sf, reverse, st);
 }
 
 // ---- static-API split forms (coupling_layer.py:76-86 and :88-98) ---------------------------------
@@ -315,9 +348,11 @@ __global__ __launch_bounds__(kBlock) void sigmoid_flow_kernel(SigArgs a, RowTili
 }
 
 // ---- logistic prior log-prob + NLL (distributions.py:129-136,154-163; set_modeling/task.py:96-118)
+// softplus(v) + softplus(-v) = |v| + 2 log(1 + e^{-|v|}); one exp and one log instead of two each
+// (identical to F.softplus's thresholded form to fp32 rounding: for |v| > 20 the log term is < 5e-9)
 __device__ __forceinline__ float logistic_logp(float x, float mu, float sigma, float log_sigma) {
-    const float v = (x - mu) / sigma;
-    return -(softplus_t20(v) + softplus_t20(-v) + log_sigma);
+    const float v = fabsf((x - mu) / sigma);
+    return -((v + 2.f * __logf(1.f + __expf(-v))) + log_sigma);
 }
 struct NllArgs {
     const float* z;
@@ -352,8 +387,6 @@ __global__ __launch_bounds__(kBlock) void prior_nll_kernel(NllArgs a, RowTiling 
         }
         return acc;
     };
-    double local = 0.0;
-    int local_n = 0;
     auto finish = [&](int row, float sum) {
         const float neglog = -sum;
         const float len = a.length ? a.length[row] : (float)a.N;
@@ -361,17 +394,24 @@ __global__ __launch_bounds__(kBlock) void prior_nll_kernel(NllArgs a, RowTiling 
         const float nll = (-ldj) / len + neglog / len;
         if (a.neglog_out) a.neglog_out[row] = neglog;
         if (a.nll_out) a.nll_out[row] = nll;
-        local += (double)nll;
-        local_n += 1;
     };
     walk_row_tile<float>(tl, part[threadIdx.x >> 6], chunk, finish);
-    if (a.sums) {
-        local = wave_sum(local);
-        const int cnt = wave_sum(local_n);
-        if ((threadIdx.x & 63) == 0 && cnt > 0) {
-            atomicAdd(&a.sums[0], local);
-            atomicAdd(&a.sums[1], (double)cnt);
-        }
+}
+
+// sums = (sum_b nll[b], B): one workgroup, fixed order (deterministic), fp64 accumulation.
+// 16k waves adding into one address would serialise at ~12 ns per atomic (~200 us); this is ~3 us.
+__global__ __launch_bounds__(1024) void nll_sum_kernel(const float* nll, int B, double* sums) {
+    __shared__ double sh[16];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < B; i += 1024) acc += (double)nll[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < 16; ++w) t += sh[w];
+        sums[0] = t;
+        sums[1] = (double)B;
     }
 }
 
@@ -435,7 +475,7 @@ int cnf_affine_coupling(const float* z, const float* nn_out, const float* scalin
     a.z_out = z_out; a.ldj_out = ldj_out; a.flags = flags;
     a.N = N; a.D = D; a.L = N * D; a.mr = mask_rows; a.mc = mask_cols; a.reverse = reverse;
     a.div_d = make_fastdiv((uint32_t)D);
-    const RowTiling tl = make_row_tiling(B, a.L);
+    const RowTiling tl = make_row_tiling(B, a.L, 0, tile_chunks_target());
     DISPATCH_VEC(tl, launch_affine<V>(a, tl, scaling_factor != nullptr, reverse != 0, (hipStream_t)stream));
     return launch_status("cnf_affine_coupling");
 }
@@ -513,6 +553,7 @@ int cnf_prior_nll(const float* z, const float* pad, const float* ldj, const floa
                   float* neglog_out, float* nll_out, double* sums,
                   int B, int N, int D, float sigma, float log_sigma, cnf_stream_t stream) {
     CNF_REQUIRE(z, "cnf_prior_nll: null tensor");
+    CNF_REQUIRE(!sums || nll_out, "cnf_prior_nll: `sums` needs `nll_out` (the batch sum is taken over it)");
     CNF_REQUIRE(B >= 0 && N > 0 && D > 0 && (long)N * D < 65536, "cnf_prior_nll: bad shape");
     if (B == 0) return CNF_OK;
     NllArgs a{z, pad, ldj, length, neglog_out, nll_out, sums, N, D, N * D, sigma, log_sigma,
@@ -520,6 +561,7 @@ int cnf_prior_nll(const float* z, const float* pad, const float* ldj, const floa
     const RowTiling tl = make_row_tiling(B, a.L);
     DISPATCH_VEC(tl, hipLaunchKernelGGL((prior_nll_kernel<V>), tiling_grid(tl), dim3(kBlock), 0,
                                         (hipStream_t)stream, a, tl));
+    if (sums) hipLaunchKernelGGL(nll_sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, nll_out, B, sums);
     return launch_status("cnf_prior_nll");
 }
 

@@ -20,6 +20,7 @@ void set_error(const char* fmt, ...);
 int launch_status(const char* what);     // CNF_OK or CNF_ERR_LAUNCH (+ message)
 int tile_chunks_target();
 int unroll_target();
+int math_mode();
 
 #define CNF_REQUIRE(cond, ...)                \
     do {                                      \
@@ -56,7 +57,7 @@ struct RowTiling {
     long ntiles;
     FastDiv div_cpr;
 };
-RowTiling make_row_tiling(int B, int L, int force_vec = 0);
+RowTiling make_row_tiling(int B, int L, int force_vec = 0, int target_chunks = 256);
 inline dim3 tiling_grid(const RowTiling& t) {
     return dim3((unsigned)((t.ntiles + kWavesPerBlock - 1) / kWavesPerBlock));
 }
@@ -90,9 +91,17 @@ __device__ __forceinline__ void raise_flag(int* flags, int bit) {
 //   proc_fn(data, row, e0) -> T     computes, stores and returns the chunk's log-det contribution;
 //   finish_fn(row, sum)             stores the row's sum.
 // `part` is this wave's private LDS scratch (kMaxTileChunks values of T).
-template <int U, typename T, typename Data, typename LoadFn, typename ProcFn, typename FinishFn>
+struct NoPre {
+    __device__ __forceinline__ void operator()() const {}
+};
+
+// pre_fn() runs once per wave AFTER the first group of loads has been issued and before the first
+// proc_fn: per-wave setup (LDS tables) hides behind the HBM latency of those loads.
+template <int U, typename T, typename Data, bool PREFETCH = false, typename LoadFn, typename ProcFn, typename FinishFn,
+          typename PreFn = NoPre>
 __device__ __forceinline__ void walk_row_tile_split(const RowTiling& tl, T* part, LoadFn&& load_fn,
-                                                    ProcFn&& proc_fn, FinishFn&& finish_fn) {
+                                                    ProcFn&& proc_fn, FinishFn&& finish_fn,
+                                                    PreFn&& pre_fn = NoPre()) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long tile = (long)blockIdx.x * kWavesPerBlock + wave;
     if (tile >= tl.ntiles) return;
@@ -100,26 +109,54 @@ __device__ __forceinline__ void walk_row_tile_split(const RowTiling& tl, T* part
     const int nrows = min(tl.rw, tl.B - row0);
     const int nch = nrows * tl.cpr;
     T acc1 = 0;
-    for (int c0 = lane; c0 < nch; c0 += kWave * U) {
-        Data dat[U];
-        int rr[U], ee[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int c = c0 + kWave * u;
-            const int r = tl.rw == 1 ? 0 : (int)fdiv((uint32_t)c, tl.div_cpr);
-            rr[u] = row0 + r;
-            ee[u] = (c - r * tl.cpr) * tl.vec;
-            if (c < nch) dat[u] = load_fn(rr[u], ee[u]);
+    if (PREFETCH && U == 1) {
+        // software pipeline: the loads of chunk i+1 are in flight while chunk i is computed
+        int c = lane;
+        int r = tl.rw == 1 ? 0 : (int)fdiv((uint32_t)c, tl.div_cpr);
+        int row = row0 + r, e0 = (c - r * tl.cpr) * tl.vec;
+        Data cur;
+        if (c < nch) cur = load_fn(row, e0);
+        pre_fn();
+        while (c < nch) {
+            const int cn = c + kWave;
+            const int rn = tl.rw == 1 ? 0 : (int)fdiv((uint32_t)cn, tl.div_cpr);
+            const int rown = row0 + rn, en = (cn - rn * tl.cpr) * tl.vec;
+            Data nxt;
+            if (cn < nch) nxt = load_fn(rown, en);
+            const T v = proc_fn(cur, row, e0);
+            if (tl.rw == 1) acc1 += v;
+            else part[c] = v;
+            cur = nxt;
+            c = cn; row = rown; e0 = en;
         }
+    } else {
+        // one group = U chunks per lane: all loads first, then (first group only) pre_fn, then compute
+        auto group = [&](int c0, auto&& between) {
+            Data dat[U];
+            int rr[U], ee[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int c = c0 + kWave * u;
-            if (c < nch) {
-                const T v = proc_fn(dat[u], rr[u], ee[u]);
-                if (tl.rw == 1) acc1 += v;
-                else part[c] = v;
+            for (int u = 0; u < U; ++u) {
+                // lanes past the end of the tile re-load its last chunk (unconditional loads keep the
+                // data out of control-flow phis, so no wait is forced before `between`)
+                const int c = min(c0 + kWave * u, nch - 1);
+                const int r = tl.rw == 1 ? 0 : (int)fdiv((uint32_t)c, tl.div_cpr);
+                rr[u] = row0 + r;
+                ee[u] = (c - r * tl.cpr) * tl.vec;
+                dat[u] = load_fn(rr[u], ee[u]);
             }
-        }
+            between();
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int c = c0 + kWave * u;
+                if (c < nch) {
+                    const T v = proc_fn(dat[u], rr[u], ee[u]);
+                    if (tl.rw == 1) acc1 += v;
+                    else part[c] = v;
+                }
+            }
+        };
+        group(lane, pre_fn);
+        for (int c0 = lane + kWave * U; c0 < nch; c0 += kWave * U) group(c0, NoPre());
     }
     if (tl.rw == 1) {
         acc1 = wave_sum(acc1);
@@ -144,7 +181,7 @@ template <typename T, typename ChunkFn, typename FinishFn>
 __device__ __forceinline__ void walk_row_tile(const RowTiling& tl, T* part, ChunkFn&& chunk_fn,
                                               FinishFn&& finish_fn) {
     struct Nothing {};
-    walk_row_tile_split<1, T, Nothing>(
+    walk_row_tile_split<1, T, Nothing, false>(
         tl, part, [](int, int) { return Nothing{}; },
         [&](const Nothing&, int row, int e0) { return chunk_fn(row, e0); }, finish_fn);
 }

@@ -33,8 +33,8 @@ struct EncArgs {
 __device__ __forceinline__ float softplus_t20(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 // LogisticDistribution.log_prob (distributions.py:129-136,154-163), mu = 0
 __device__ __forceinline__ float logistic_logp0(float x, float sigma, float log_sigma) {
-    const float v = x / sigma;
-    return -(softplus_t20(v) + softplus_t20(-v) + log_sigma);
+    const float v = fabsf(x / sigma);        // softplus(v)+softplus(-v) = |v| + 2 log(1 + e^{-|v|})
+    return -((v + 2.f * __logf(1.f + __expf(-v))) + log_sigma);
 }
 
 // LDS layout per class: [bias D | ts D | e^ts D | e^-ts D | sum_ts], stride 4D+1 (odd -> no bank conflicts)

@@ -7,8 +7,10 @@
 namespace cnf {
 
 static thread_local char g_err[512] = "";
-static int g_tile_chunks = 256;
-static int g_unroll = 4;
+// defaults from the interleaved A/B sweep on MI355X (tools/sweep_affine.py, profiles/r01_sweep_affine.txt)
+static int g_tile_chunks = 128;
+static int g_unroll = 2;
+static int g_math = 1;
 
 void set_error(const char* fmt, ...) {
     va_list ap;
@@ -26,14 +28,15 @@ int launch_status(const char* what) {
 
 int tile_chunks_target() { return g_tile_chunks; }
 int unroll_target() { return g_unroll; }
+int math_mode() { return g_math; }
 
-RowTiling make_row_tiling(int B, int L, int force_vec) {
+RowTiling make_row_tiling(int B, int L, int force_vec, int target_chunks) {
     RowTiling t;
     t.B = B;
     t.L = L;
     t.vec = force_vec ? force_vec : (L % 4 == 0 ? 4 : (L % 2 == 0 ? 2 : 1));
     t.cpr = L / t.vec;
-    const int target = std::min(g_tile_chunks, kMaxTileChunks);
+    const int target = std::min(std::max(target_chunks, kWave), kMaxTileChunks);
     int best = 1;
     if (t.cpr < target) {
         // rows per wave: keep the 64 lanes busy (chunks close to a multiple of 64), prefer more rows
@@ -70,7 +73,11 @@ void cnf_set_tile_chunks(int chunks) {
 }
 
 void cnf_set_unroll(int u) {
-    if (u == 1 || u == 2 || u == 3 || u == 4) cnf::g_unroll = u;
+    if (u == 0 || u == 1 || u == 2 || u == 3 || u == 4) cnf::g_unroll = u;
+}
+
+void cnf_set_math_mode(int mode) {
+    if (mode == 0 || mode == 1) cnf::g_math = mode;
 }
 
 }  // extern "C"

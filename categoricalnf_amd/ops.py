@@ -398,7 +398,7 @@ def logistic_from_uniform(u, mu=0.0, sigma=LOGISTIC_SIGMA, eps=1e-4):
 
 def prior_nll(z, ldj, length=None, channel_padding_mask=None, sums=None,
               sigma=LOGISTIC_SIGMA, log_sigma=LOGISTIC_LOG_SIGMA):
-    """Returns (neglog [B], nll [B]); `sums` (fp64 [2], optional) += (sum nll, B)."""
+    """Returns (neglog [B], nll [B]); `sums` (fp64 [2], optional) is set to (sum nll, B) of this batch."""
     z = _f32(z, "z")
     dev = z.device
     B, N, D = z.shape

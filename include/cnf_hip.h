@@ -47,10 +47,15 @@ typedef void* cnf_stream_t;
 int cnf_abi_version(void);
 const char* cnf_last_error(void);
 
-/* Tuning knob for the row-streaming kernels: float4 chunks one wave owns per tile (default 256). */
+/* Tuning knob for the row-streaming kernels: float4 chunks one wave owns per tile (default 128). */
 void cnf_set_tile_chunks(int chunks);
-/* Chunks per lane whose loads are issued back to back in the affine coupling kernel (1..4, default 4). */
+/* Load scheduling of the affine coupling kernel: 0 = one chunk at a time, software-pipelined (the next
+ * chunk's loads are issued before the current one is computed); 1..4 = that many chunks per lane
+ * loaded back to back.  Default 2. */
 void cnf_set_unroll(int u);
+/* Affine coupling transcendental path: 1 (default) = hardware v_exp_f32-based exp / tanh
+ * (absolute error ~1e-7, well inside the 1e-4 parity bar); 0 = ocml expf / tanhf. */
+void cnf_set_math_mode(int mode);
 
 /* ---- affine coupling -------------------------------------------------------------------- */
 
@@ -161,8 +166,8 @@ int cnf_logistic_from_uniform(const float* u, float* x, int64_t n, float mu, flo
 
 /* NLL assembly (experiments/set_modeling/task.py:96-118, general/task.py:148-149):
  * neglog[b] = -sum_{n,d} logp(z)*pad ; nll[b] = (-ldj[b] + neglog[b]) / length[b].
- * sums (nullable, 2 fp64, caller-zeroed) += {sum_b nll[b], B} — the pair that is all-reduced
- * over ranks. */
+ * sums (nullable, 2 fp64; needs nll_out) = {sum_b nll[b], B} of THIS call (overwritten, fixed summation
+ * order) — the pair that is all-reduced over ranks. */
 int cnf_prior_nll(const float* z, const float* pad, const float* ldj, const float* length,
                   float* neglog_out, float* nll_out, double* sums,
                   int B, int N, int D, float sigma, float log_sigma, cnf_stream_t stream);

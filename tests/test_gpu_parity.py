@@ -82,8 +82,9 @@ def test_affine_tiling_knobs_do_not_change_results():
     sf, mask = torch.zeros(6), O.channel_mask(6)
     ref = None
     try:
+        lib.cnf_set_math_mode(0)
         for chunks in (64, 128, 192, 256, 512):
-            for unroll in (1, 2, 3, 4):
+            for unroll in (0, 1, 2, 3, 4):
                 lib.cnf_set_tile_chunks(chunks); lib.cnf_set_unroll(unroll)
                 out = ops().affine_coupling(g(z), g(nn_out), g(sf), g(mask))
                 if ref is None:
@@ -92,8 +93,12 @@ def test_affine_tiling_knobs_do_not_change_results():
                     close(out[0], zo, **ELEM); close(out[1], lo, **LDJ)
                 assert torch.equal(out[0], ref[0])            # element math independent of the tiling
                 close(out[1], ref[1], rtol=1e-6, atol=1e-5)    # sums may associate differently
+        # hardware-transcendental math mode: same results to ~1e-6
+        lib.cnf_set_math_mode(1)
+        fast = ops().affine_coupling(g(z), g(nn_out), g(sf), g(mask))
+        close(fast[0], ref[0], rtol=5e-6, atol=5e-6); close(fast[1], ref[1], rtol=1e-5, atol=1e-4)
     finally:
-        lib.cnf_set_tile_chunks(256); lib.cnf_set_unroll(4)
+        lib.cnf_set_tile_chunks(128); lib.cnf_set_unroll(2); lib.cnf_set_math_mode(1)
 
 
 def test_affine_full_size_properties():
