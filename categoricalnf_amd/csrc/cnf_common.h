@@ -21,6 +21,7 @@ int launch_status(const char* what);     // CNF_OK or CNF_ERR_LAUNCH (+ message)
 int tile_chunks_target();
 int unroll_target();
 int math_mode();
+int inverse_mode();
 
 #define CNF_REQUIRE(cond, ...)                \
     do {                                      \

@@ -11,6 +11,7 @@ static thread_local char g_err[512] = "";
 static int g_tile_chunks = 128;
 static int g_unroll = 2;
 static int g_math = 1;
+static int g_inverse = 1;
 
 void set_error(const char* fmt, ...) {
     va_list ap;
@@ -29,6 +30,7 @@ int launch_status(const char* what) {
 int tile_chunks_target() { return g_tile_chunks; }
 int unroll_target() { return g_unroll; }
 int math_mode() { return g_math; }
+int inverse_mode() { return g_inverse; }
 
 RowTiling make_row_tiling(int B, int L, int force_vec, int target_chunks) {
     RowTiling t;
@@ -78,6 +80,10 @@ void cnf_set_unroll(int u) {
 
 void cnf_set_math_mode(int mode) {
     if (mode == 0 || mode == 1) cnf::g_math = mode;
+}
+
+void cnf_set_inverse_mode(int mode) {
+    if (mode == 0 || mode == 1) cnf::g_inverse = mode;
 }
 
 }  // extern "C"

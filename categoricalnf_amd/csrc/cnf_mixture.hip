@@ -132,12 +132,42 @@ struct MixEval {
     double log_pdf;  // mixture log-PDF at x
 };
 
+// Parameters of one transformed element.  With K a template constant (KT > 0) they are loaded once,
+// in one batch of independent loads, and stay in registers; KT == 0 reads them lazily (any K).
+template <bool SPLIT, int KT>
+struct ElemParams {
+    static constexpr int KK = KT > 0 ? KT : 1;
+    ParamRow<SPLIT> row;
+    double t_, log_s_;
+    double lp[KK], mu_[KK], ls_[KK];
+    int K;
+    __device__ __forceinline__ ElemParams(const MixArgs& a, size_t elem, int d) : row(a, elem, d) {
+        K = KT > 0 ? KT : a.K;
+        t_ = row.t();
+        log_s_ = row.log_s();
+        if (KT > 0) {
+#pragma unroll
+            for (int k = 0; k < KK; ++k) {
+                lp[k] = row.log_pi(k);
+                mu_[k] = row.mu(k);
+                ls_[k] = row.ls(k);
+            }
+        }
+    }
+    __device__ __forceinline__ double log_pi(int k) const { return KT > 0 ? lp[k] : row.log_pi(k); }
+    __device__ __forceinline__ double mu(int k) const { return KT > 0 ? mu_[k] : row.mu(k); }
+    __device__ __forceinline__ double ls(int k) const { return KT > 0 ? ls_[k] : row.ls(k); }
+};
+
 // one pass over the K mixtures at point x
-template <bool SPLIT>
-__device__ __forceinline__ MixEval eval_mixture(const ParamRow<SPLIT>& p, int K, double x) {
+template <bool SPLIT, int KT>
+__device__ __forceinline__ MixEval eval_mixture(const ElemParams<SPLIT, KT>& p, double x) {
+    const int K = p.K;
     double mx = -INFINITY;
+#pragma unroll
     for (int k = 0; k < K; ++k) mx = fmax(mx, p.log_pi(k));
     double se = 0.0, cdf = 0.0, pdf = 0.0;
+#pragma unroll
     for (int k = 0; k < K; ++k) {
         const double w = exp(p.log_pi(k) - mx);
         const double inv_s = exp(-p.ls(k));
@@ -151,19 +181,20 @@ __device__ __forceinline__ MixEval eval_mixture(const ParamRow<SPLIT>& p, int K,
     }
     MixEval o;
     o.u = cdf / se;
-    if (pdf > 1e-290) o.log_pdf = log(pdf) - log(se);
-    else o.log_pdf = log_pdf_logspace<SPLIT>(p, K, x, mx + log(se));
+    if (pdf > 1e-290) o.log_pdf = log(pdf / se);
+    else o.log_pdf = log_pdf_logspace<SPLIT>(p.row, K, x, mx + log(se));
     return o;
 }
 
-// SPLIT selects the parameter source and the I/O precision (fp64 tensors for the static API)
-template <bool SPLIT, bool REVERSE>
+// SPLIT selects the parameter source and the I/O precision (fp64 tensors for the static API);
+// KT = compile-time number of mixtures (0 = run-time K); NEWTON = safeguarded Newton inverse.
+template <bool SPLIT, bool REVERSE, int KT, bool NEWTON>
 __global__ __launch_bounds__(kBlock) void mixture_kernel(MixArgs a, RowTiling tl) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int W = blockDim.x >> 6;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     double* part = reinterpret_cast<double*>(smem) + (size_t)wave * kMaxTileChunks;
-    double* cst = reinterpret_cast<double*>(smem) + (size_t)W * kMaxTileChunks;   // [3K][blockDim]
+    double* cst = reinterpret_cast<double*>(smem) + (size_t)W * kMaxTileChunks;   // [3K][blockDim], KT == 0 only
     __shared__ int s_act[kMaxAct];   // kernel arguments cannot be indexed per lane
     if (threadIdx.x < kMaxAct && ((a.act_bits >> threadIdx.x) & 1ull))
         s_act[__popcll(a.act_bits & ((1ull << threadIdx.x) - 1ull))] = threadIdx.x;
@@ -215,19 +246,23 @@ __global__ __launch_bounds__(kBlock) void mixture_kernel(MixArgs a, RowTiling tl
         if (a.pad_in_transform && pv == 0.f) active = false;
         if (active) {
             const size_t elem = ((size_t)row * a.N + n) * a.D + d;
-            const ParamRow<SPLIT> p(a, elem, d);
+            const ElemParams<SPLIT, KT> p(a, elem, d);
+            const int K = p.K;
             const double x = SPLIT ? a.z64[elem] : (double)a.z[elem];
-            const double t = p.t(), log_s = p.log_s();
+            const double t = p.t_, log_s = p.log_s_;
             double out, reg = 0.0;
             if (!REVERSE) {
-                const MixEval ev = eval_mixture<SPLIT>(p, a.K, x);
+                const MixEval ev = eval_mixture<SPLIT, KT>(p, x);
                 const double u = ev.u;
+                const double lu = safe_log(u), l1u = safe_log(1.0 - u);
                 if (a.use_reg) {
-                    const double r1 = safe_log(u) / kLn10, r2 = safe_log(1.0 - u) / kLn10;
+                    const double r1 = lu / kLn10, r2 = l1u / kLn10;
                     reg = (fmin(r1, -a.reg_max) + a.reg_max) + (fmin(r2, -a.reg_max) + a.reg_max);
                 }
-                const double y = -safe_log(1.0 / u - 1.0);
-                const double mixt_ldj = -safe_log(u) - safe_log(1.0 - u);
+                // y = -safe_log(1/u - 1) (:273) = log u - log(1-u); identical under the 1e-22 clamp except
+                // at u == 0 exactly, where the reference's form gives -inf
+                const double y = u > 0.0 ? lu - l1u : -safe_log(1.0 / u - 1.0);
+                const double mixt_ldj = -lu - l1u;
                 out = (y + t) * exp(log_s);
                 contrib = log_s + mixt_ldj + ev.log_pdf + reg * a.reg_factor;
             } else {
@@ -236,37 +271,68 @@ __global__ __launch_bounds__(kBlock) void mixture_kernel(MixArgs a, RowTiling tl
                 const double mixt_ldj = softplus64(v) + softplus64(-v);
                 u = fmin(fmax(u, 1e-5), 1.0 - 1e-5);
                 if (!(u > 0.0 && u < 1.0)) range = true;
-                // per-mixture constants of this element, strided by thread: [3k + c][tid]
+                // per-mixture constants: registers when K is a template constant, else LDS [3k + c][tid]
+                constexpr int KK = KT > 0 ? KT : 1;
+                double wr[KK], isr[KK], mur[KK];
                 double* my = cst + threadIdx.x;
                 const int S = blockDim.x;
                 double mx = -INFINITY;
-                for (int k = 0; k < a.K; ++k) mx = fmax(mx, p.log_pi(k));
-                double se = 0.0, spread = 0.0;
-                for (int k = 0; k < a.K; ++k) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) mx = fmax(mx, p.log_pi(k));
+                double se = 0.0, spread = 0.0, lb = INFINITY, ub = -INFINITY;
+                // NEWTON: every component's own u-quantile q_k = mu_k + s_k logit(u); the mixture quantile
+                // lies in [min q_k, max q_k] (all component CDFs are <= u at min q_k and >= u at max q_k)
+                const double logit_u = NEWTON ? log(u) - log(1.0 - u) : 0.0;
+                double qsum = 0.0;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
                     const double w = exp(p.log_pi(k) - mx);
                     const double ls = p.ls(k);
+                    const double sk = exp(ls);
+                    const double mk = p.mu(k);
                     se += w;
-                    spread += exp(ls);
-                    my[(3 * k + 0) * S] = w;
-                    my[(3 * k + 1) * S] = exp(-ls);
-                    my[(3 * k + 2) * S] = p.mu(k);
+                    spread += sk;
+                    if (NEWTON) {
+                        const double qk = mk + sk * logit_u;
+                        lb = fmin(lb, qk);
+                        ub = fmax(ub, qk);
+                        qsum += w * qk;
+                    }
+                    if (KT > 0) {
+                        wr[k] = w; isr[k] = exp(-ls); mur[k] = mk;
+                    } else {
+                        my[(3 * k + 0) * S] = w;
+                        my[(3 * k + 1) * S] = exp(-ls);
+                        my[(3 * k + 2) * S] = mk;
+                    }
                 }
-                double lb = INFINITY, ub = -INFINITY;
-                for (int k = 0; k < a.K; ++k) {
-                    const double mu = my[(3 * k + 2) * S];
-                    lb = fmin(lb, mu - 20.0 * spread);
-                    ub = fmax(ub, mu + 20.0 * spread);
+                if (!NEWTON) {
+                    // the reference's bracket (:252-254): mu_k -+ 20 * sum_k s_k, min / max over k
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        const double mu = KT > 0 ? mur[k] : my[(3 * k + 2) * S];
+                        lb = fmin(lb, mu - 20.0 * spread);
+                        ub = fmax(ub, mu + 20.0 * spread);
+                    }
                 }
                 const double target = u * se;          // compare un-normalised sums
-                double xb = 0.0;
+                // start: x = 0 like the reference (:251), or the weight-averaged component quantile
+                double xb = NEWTON ? fmin(fmax(qsum / se, lb), ub) : 0.0;
+                double dx_prev = ub - lb;              // previous step length (Newton acceptance test)
                 for (int iter = 0; iter < 100; ++iter) {
-                    double cdf = 0.0;
-                    for (int k = 0; k < a.K; ++k) {
-                        const double zk = (xb - my[(3 * k + 2) * S]) * my[(3 * k + 1) * S];
+                    double cdf = 0.0, dens = 0.0;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        const double wk = KT > 0 ? wr[k] : my[(3 * k + 0) * S];
+                        const double ik = KT > 0 ? isr[k] : my[(3 * k + 1) * S];
+                        const double mk = KT > 0 ? mur[k] : my[(3 * k + 2) * S];
+                        const double zk = (xb - mk) * ik;
                         const double e = exp(-fabs(zk));
                         const double rr = 1.0 / (1.0 + e);
-                        cdf += my[(3 * k + 0) * S] * (zk >= 0.0 ? rr : e * rr);
+                        cdf += wk * (zk >= 0.0 ? rr : e * rr);
+                        if (NEWTON) dens += wk * ik * (e * rr * rr);
                     }
+                    // the reference's bisection step and bracket update (:244-248)
                     double nx;
                     if (cdf > target) {
                         nx = (xb + lb) / 2.0;
@@ -275,12 +341,22 @@ __global__ __launch_bounds__(kBlock) void mixture_kernel(MixArgs a, RowTiling tl
                         nx = (xb + ub) / 2.0;
                         lb = xb;
                     }
+                    if (NEWTON) {
+                        // safeguarded Newton (rtsafe): take the Newton step from the same evaluation when it
+                        // stays inside the bracket and at least halves the previous step, else bisect
+                        const double f = cdf - target;
+                        if (dens > 0.0 && fabs(2.0 * f) <= fabs(dx_prev * dens)) {
+                            const double xn = xb - f / dens;
+                            if (xn >= lb && xn <= ub) nx = xn;   // inclusive: at f == 0 the step is 0 and xn sits on the bracket
+                        }
+                    }
                     const double diff = fabs(nx - xb);
+                    dx_prev = diff;
                     xb = nx;
                     if (!(diff > 1e-10)) break;
                 }
                 out = xb;
-                const MixEval ev = eval_mixture<SPLIT>(p, a.K, xb);
+                const MixEval ev = eval_mixture<SPLIT, KT>(p, xb);
                 contrib = log_s + mixt_ldj + ev.log_pdf;
             }
             if (SPLIT) {
@@ -410,10 +486,11 @@ static int launch_mixture(MixArgs& a, bool split, const int* act_host, int n_act
     fill_act(a, act_host, n_act);
     a.div_da = make_fastdiv((uint32_t)a.DA);
     const RowTiling tl = make_row_tiling(a.B, a.N * a.DA, /*force_vec=*/1);
-    // block size: the inverse keeps 3K fp64 constants per thread in LDS (<= 64 KiB per block)
+    // block size: with a run-time K the inverse keeps 3K fp64 constants per thread in LDS (<= 64 KiB/block)
+    const int kt = (a.K == 4 || a.K == 8 || a.K == 16) ? a.K : 0;
     int threads = kBlock;
     size_t cst_bytes = 0;
-    if (a.reverse) {
+    if (a.reverse && kt == 0) {
         const size_t per_thread = (size_t)3 * a.K * sizeof(double);
         while (threads > kWave &&
                per_thread * threads + (size_t)(threads / kWave) * kMaxTileChunks * sizeof(double) > 65536)
@@ -427,13 +504,25 @@ static int launch_mixture(MixArgs& a, bool split, const int* act_host, int n_act
     const int W = threads / kWave;
     const size_t smem = (size_t)W * kMaxTileChunks * sizeof(double) + cst_bytes;
     const dim3 grid((unsigned)((tl.ntiles + W - 1) / W)), block(threads);
-    if (split) {
-        if (a.reverse) hipLaunchKernelGGL((mixture_kernel<true, true>), grid, block, smem, st, a, tl);
-        else hipLaunchKernelGGL((mixture_kernel<true, false>), grid, block, smem, st, a, tl);
-    } else {
-        if (a.reverse) hipLaunchKernelGGL((mixture_kernel<false, true>), grid, block, smem, st, a, tl);
-        else hipLaunchKernelGGL((mixture_kernel<false, false>), grid, block, smem, st, a, tl);
+    const bool newton = inverse_mode() == 1;
+#define CNF_MIX_LAUNCH(SPLIT_, REV_, KT_, NEWT_) \
+    hipLaunchKernelGGL((mixture_kernel<SPLIT_, REV_, KT_, NEWT_>), grid, block, smem, st, a, tl)
+#define CNF_MIX_K(SPLIT_, REV_, NEWT_)                                   \
+    switch (kt) {                                                        \
+        case 4: CNF_MIX_LAUNCH(SPLIT_, REV_, 4, NEWT_); break;           \
+        case 8: CNF_MIX_LAUNCH(SPLIT_, REV_, 8, NEWT_); break;           \
+        case 16: CNF_MIX_LAUNCH(SPLIT_, REV_, 16, NEWT_); break;         \
+        default: CNF_MIX_LAUNCH(SPLIT_, REV_, 0, NEWT_); break;          \
     }
+    if (split) {
+        if (a.reverse) { if (newton) { CNF_MIX_K(true, true, true) } else { CNF_MIX_K(true, true, false) } }
+        else { CNF_MIX_K(true, false, false) }
+    } else {
+        if (a.reverse) { if (newton) { CNF_MIX_K(false, true, true) } else { CNF_MIX_K(false, true, false) } }
+        else { CNF_MIX_K(false, false, false) }
+    }
+#undef CNF_MIX_K
+#undef CNF_MIX_LAUNCH
     return launch_status(who);
 }
 

@@ -56,6 +56,11 @@ void cnf_set_unroll(int u);
 /* Affine coupling transcendental path: 1 (default) = hardware v_exp_f32-based exp / tanh
  * (absolute error ~1e-7, well inside the 1e-4 parity bar); 0 = ocml expf / tanhf. */
 void cnf_set_math_mode(int mode);
+/* Mixture-CDF inverse: 0 = the reference's bisection (mixture_cdf_layer.py:235-264, per-element stop at
+ * |dx| <= 1e-10); 1 (default) = safeguarded Newton (rtsafe) on the same equation, bracketed by the
+ * component quantiles mu_k + s_k logit(u) and started at their weighted mean, same stop: same root to
+ * ~1e-10, several times fewer CDF evaluations. */
+void cnf_set_inverse_mode(int mode);
 
 /* ---- affine coupling -------------------------------------------------------------------- */
 

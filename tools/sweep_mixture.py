@@ -1,0 +1,45 @@
+"""Interleaved timing of the mixture-CDF coupling kernels (fwd / inverse, both inverse modes) on the
+config-shaped workloads of SURVEY.md §8d.  GPU only."""
+import os, sys
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from categoricalnf_amd import _lib, ops
+dev = torch.device("cuda:0")
+lib = _lib.load()
+shapes = [("set_summation configs[1]", 16384, 16, 4, 8, "channel"), ("north-star S* mixture", 16384, 64, 6, 8, "channel"),
+          ("graph colouring large", 128, 50, 6, 16, "channel"), ("PTB AR (mask=None)", 128, 288, 3, 51, "none"),
+          ("zinc nodes", 512, 38, 6, 16, "channel"), ("zinc edges", 512, 703, 2, 8, "channel")]
+for name, B, N, D, K, kind in shapes:
+    g = torch.Generator(device=dev).manual_seed(1)
+    z = torch.randn(B, N, D, generator=g, device=dev)
+    nn_out = 0.5 * torch.randn(B, N, D * (2 + 3 * K), generator=g, device=dev)
+    mask = None if kind == "none" else torch.cat([torch.ones(1, D // 2), torch.zeros(1, D - D // 2)], 1).to(dev)
+    zf, zr = torch.empty_like(z), torch.empty_like(z)
+    lf, lr = torch.empty(B, device=dev), torch.empty(B, device=dev)
+    fwd = ops.mixture_coupling_launch(z, nn_out, mask, K, zf, lf)
+    inv = ops.mixture_coupling_launch(zf, nn_out, mask, K, zr, lr, reverse=True) if K <= 42 else None
+
+    def timeit(fn, reps=10):
+        fn(); torch.cuda.synchronize()
+        ts = []
+        for _ in range(5):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(reps):
+                fn()
+            b.record(); torch.cuda.synchronize()
+            ts.append(a.elapsed_time(b) / reps * 1e3)
+        return min(ts)
+    tf = timeit(fwd)
+    elems = B * N * D
+    line = "%-26s B=%5d N=%3d D=%d K=%2d | fwd %8.1f us (%6.2f Gelem/s, %5.0f GB/s alg)" % (
+        name, B, N, D, K, tf, elems / tf / 1e3, elems * (16 + 12 * K) / tf / 1e3)
+    if inv is not None:
+        for mode in (0, 1):
+            lib.cnf_set_inverse_mode(mode)
+            ti = timeit(inv, reps=5)
+            err = (zr - z).abs().max().item()
+            line += " | inv[%s] %8.1f us err %.1e" % ("bisect" if mode == 0 else "newton", ti, err)
+        lib.cnf_set_inverse_mode(1)
+    print(line, flush=True)
