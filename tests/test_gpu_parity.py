@@ -438,3 +438,56 @@ def test_cpu_tensor_is_rejected():
     from categoricalnf_amd import ops as o
     with pytest.raises(o.HipOnlyError):
         o.affine_coupling(torch.randn(2, 3, 2), torch.randn(2, 3, 4), None, None)
+
+
+# ------------------------------------------------------------------------------------------------
+def _set_model(meta):
+    from categoricalnf_amd.experiments.set_modeling import FlowSetModeling, SetShufflingDataset
+    params = {"set_size": meta["set_size"], "coupling_hidden_layers": meta["transformer_layers"],
+              "coupling_hidden_size": meta["hidden"], "coupling_num_flows": meta["flows"], "coupling_mask_ratio": 0.5,
+              "coupling_num_mixtures": meta["K"],
+              "categ_encoding": {"use_dequantization": False, "use_variational": False, "use_decoder": False,
+                                 "num_dimensions": meta["D"], "flow_config": {"num_flows": 0, "hidden_layers": 2, "hidden_size": 128},
+                                 "decoder_config": {"num_layers": 1, "hidden_size": 64}}}
+    return FlowSetModeling(params, SetShufflingDataset), SetShufflingDataset
+
+
+def test_set_shuffling_trained_model_bits_per_dim():
+    """A FlowSetModeling trained WITH THE REFERENCE (oracle/gen_set_shuffling_golden.py): same weights on
+    the HIP path must give the reference's per-sample log-likelihood (1e-4 relative), decoded indices
+    (bit-exact) and validation bits/dim (+-0.01) — BASELINE.json north_star."""
+    import json
+    import os
+    from tests.golden_util import GOLDEN_DIR
+    data = np.load(os.path.join(GOLDEN_DIR, "set_shuffling_model.npz"))
+    meta = json.loads(bytes(data["meta"]).decode())
+    model, dataset = _set_model(meta)
+    model.load_state_dict({k[3:]: torch.from_numpy(np.array(data[k])) for k in data.files if k.startswith("sd_")})
+    model.cuda().eval()
+    S = meta["set_size"]
+    x = torch.from_numpy(data["x256"]).cuda()
+    ln = torch.full((x.size(0),), S, dtype=torch.long, device="cuda")
+    with torch.no_grad():
+        z, ldj = model(x, reverse=False, length=ln, beta=1, noise=torch.from_numpy(data["u256"]).cuda())
+        _, nll = ops().prior_nll(z, ldj, ln)
+        dec, _ = model(torch.from_numpy(data["z256"]).cuda(), reverse=True, length=ln)
+    close(z, torch.from_numpy(data["z256"]), rtol=2e-4, atol=2e-4)
+    close(ldj, torch.from_numpy(data["ldj256"]), rtol=1e-4, atol=1e-3)
+    close(nll, torch.from_numpy(data["nll256"]), rtol=1e-4, atol=1e-4)
+    assert torch.equal(dec.cpu(), torch.from_numpy(data["dec256"]))
+    # full deterministic validation set (32768 permutations, seed 123), device-generated noise
+    val = torch.from_numpy(dataset(S, train=False, val=True).shuffle_set).long().cuda()
+    total = torch.zeros(2, dtype=torch.float64, device="cuda")
+    sums = torch.zeros(2, dtype=torch.float64, device="cuda")
+    torch.manual_seed(0)
+    with torch.no_grad():
+        for i in range(0, val.size(0), 4096):
+            xb = val[i:i + 4096]
+            lb = torch.full((xb.size(0),), S, dtype=torch.long, device="cuda")
+            zb, lj = model(xb, reverse=False, length=lb, beta=1)
+            ops().prior_nll(zb, lj, lb, sums=sums)
+            total += sums
+    from categoricalnf_amd.distributed import allreduce_nll
+    mean_nll, bpd = allreduce_nll(total)
+    assert abs(bpd - meta["val_bpd"]) < 0.01, (bpd, meta["val_bpd"])
+    assert bpd > dataset.optimum_bpd(S) - 1e-3

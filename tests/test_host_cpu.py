@@ -176,3 +176,52 @@ def test_two_rank_gloo_nll_allreduce(tmp_path):
     out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=240, env=env)
     assert out.returncode == 0, out.stdout[-2000:]
     assert "OK 2" in out.stdout
+
+
+def test_set_modeling_assembly_matches_reference_checkpoint_keys():
+    import json
+    data = np.load(os.path.join(ROOT, "tests", "golden", "set_shuffling_model.npz"))
+    meta = json.loads(bytes(data["meta"]).decode())
+    from categoricalnf_amd.experiments.set_modeling import FlowSetModeling, SetShufflingDataset
+    params = {"set_size": meta["set_size"], "coupling_hidden_layers": meta["transformer_layers"],
+              "coupling_hidden_size": meta["hidden"], "coupling_num_flows": meta["flows"], "coupling_mask_ratio": 0.5,
+              "coupling_num_mixtures": meta["K"],
+              "categ_encoding": {"use_dequantization": False, "use_variational": False, "use_decoder": False,
+                                 "num_dimensions": meta["D"], "flow_config": {"num_flows": 0}, "decoder_config": {}}}
+    model = FlowSetModeling(params, SetShufflingDataset)
+    sd = {k[3:]: torch.from_numpy(np.array(data[k])) for k in data.files if k.startswith("sd_")}
+    assert sorted(model.state_dict().keys()) == sorted(sd.keys())
+    model.load_state_dict(sd)
+    assert [l.info() for l in model.flow_layers] == meta["infos"]
+    val = SetShufflingDataset(meta["set_size"], train=False, val=True).shuffle_set
+    assert val.shape == (32768, 16) and (np.sort(val, axis=1) == np.arange(16)).all()
+    assert np.array_equal(val[:256], data["x256"])            # same deterministic validation set as the reference
+    assert abs(SetShufflingDataset.optimum_bpd(16) - meta["optimum_bpd"]) < 1e-12
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/experiments"), reason="reference checkout only exists in the build container")
+def test_reference_experiment_code_runs_on_the_dropin_layers():
+    """The reference's OWN experiments/set_modeling/flow_model.py, unmodified, assembled on these layers."""
+    code = r'''
+import sys, io, contextlib
+sys.path.insert(0, "%s"); sys.path.insert(0, "/root/reference")
+import categoricalnf_amd
+categoricalnf_amd.install()
+with contextlib.redirect_stdout(io.StringIO()):
+    from experiments.set_modeling.flow_model import FlowSetModeling
+    from experiments.set_modeling.datasets.set_shuffling import SetShufflingDataset
+    import layers.flows.mixture_cdf_layer as m
+    assert m.__name__.startswith("categoricalnf_amd"), m.__name__
+    p = {"set_size": 16, "coupling_hidden_layers": 1, "coupling_hidden_size": 32, "coupling_num_flows": 2,
+         "coupling_mask_ratio": 0.5, "coupling_num_mixtures": 8,
+         "categ_encoding": {"use_dequantization": False, "use_variational": False, "use_decoder": False, "num_dimensions": 4,
+                            "flow_config": {"num_flows": 0}, "decoder_config": {}}}
+    model = FlowSetModeling(p, SetShufflingDataset)
+kinds = [type(l).__module__ for l in model.flow_layers]
+assert all(k.startswith("categoricalnf_amd") for k in kinds), kinds
+print("OK", len(model.state_dict()))
+''' % ROOT
+    env = dict(os.environ, MPLBACKEND="Agg", PYTHONDONTWRITEBYTECODE="1")
+    out = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd="/tmp")
+    assert out.returncode == 0, out.stderr[-1500:]
+    assert "OK" in out.stdout
