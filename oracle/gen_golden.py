@@ -421,6 +421,122 @@ def gen_flow_stack():
     save("flow_stack", cases)
 
 
+def gen_linear_flow_encoder():
+    """Linear-flow encoding (num_flows > 0): ExtActNorm + InvertibleConv + affine coupling with a LinearNet
+    sub-network per flow, posterior over all classes by inverting every class flow (linear_encoding.py)."""
+    cases = []
+    for i, (B, N, D, C, flows, padded, training) in enumerate([(3, 5, 4, 5, 2, False, False), (2, 6, 2, 3, 1, True, True),
+                                                               (4, 4, 3, 7, 2, False, False)]):
+        torch.manual_seed(300 + i)
+        np.random.seed(300 + i)
+        with contextlib.redirect_stdout(io.StringIO()):
+            enc = LinearCategoricalEncoding(num_dimensions=D, flow_config={"num_flows": flows, "hidden_layers": 1, "hidden_size": 16},
+                                            vocab_size=C, default_embed_layer_dims=8)
+        for p in enc.parameters():
+            p.data = p.data + 0.05 * torch.randn(p.shape)
+        enc.train(training)
+        cat = torch.randint(0, C, (B, N))
+        ln = lengths(B, N, torch.Generator().manual_seed(i))
+        pad = create_channel_mask(ln, max_len=N)
+        kw = dict(channel_padding_mask=pad) if padded else {}
+        torch.manual_seed(700 + i)
+        u = torch.rand(B * N, 1, D)
+        torch.manual_seed(700 + i)
+        with torch.no_grad():
+            z, ldj, det = enc(cat, reverse=False, beta=1, **kw)
+            dec, _, _ = enc(z, reverse=True)
+        c = dict(meta=dict(B=B, N=N, D=D, C=C, flows=flows, padded=padded, training=training, embed=8, hidden=16,
+                           infos=enc.info()),
+                 categ=cat, u=u, pad=pad, z=z, ldj=ldj, decoded=dec)
+        for k, v in enc.state_dict().items():
+            c["sd_" + k] = v
+        cases.append(c)
+    save("encoder_linear_flows", cases)
+
+
+def gen_node_edge():
+    """NodeEdgeCoupling / NodeEdgeFlowWrapper (experiments/molecule_generation/graph_node_edge_coupling.py): the
+    second caller of the mixture statics, nodes [B,Nn,6] K=16 and edges [B,E,2] K=8, regulariser 3.5 x 2."""
+    with contextlib.redirect_stdout(io.StringIO()):
+        from experiments.molecule_generation.graph_node_edge_coupling import NodeEdgeCoupling, NodeEdgeFlowWrapper
+
+    class Stub(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.out = None
+
+        def forward(self, **kwargs):
+            return self.out
+
+    cases = []
+    g = torch.Generator().manual_seed(49)
+    for (B, Nn, training) in [(3, 7, True), (2, 9, False)]:
+        E = Nn * (Nn - 1) // 2
+        Dn, De, Kn, Ke = 6, 2, 16, 8
+        mn, me = CouplingLayer.create_channel_mask(Dn), CouplingLayer.create_channel_mask(De)
+        with contextlib.redirect_stdout(io.StringIO()):
+            layer = NodeEdgeCoupling(c_in_nodes=Dn, c_in_edges=De, mask_nodes=mn, mask_edges=me, num_mixtures_nodes=Kn,
+                                     num_mixtures_edges=Ke, model_func=lambda c_out_nodes, c_out_edges: Stub(),
+                                     regularizer_max=3.5, regularizer_factor=2)
+        layer.scaling_factor_nodes.data = 0.3 * torch.randn(Dn, generator=g)
+        layer.scaling_factor_edges.data = 0.3 * torch.randn(De, generator=g)
+        layer.mixture_scaling_factor_nodes.data = 0.3 * torch.randn(Dn, Kn, generator=g)
+        layer.mixture_scaling_factor_edges.data = 0.3 * torch.randn(De, Ke, generator=g)
+        layer.train(training)
+        zn, ze = torch.randn(B, Nn, Dn, generator=g), torch.randn(B, E, De, generator=g)
+        nn_n = 0.6 * torch.randn(B, Nn, Dn * (2 + 3 * Kn), generator=g)
+        nn_e = 0.6 * torch.randn(B, E, De * (2 + 3 * Ke), generator=g)
+        layer.nn.out = (nn_n, nn_e)
+        ln = lengths(B, Nn, g)
+        pad = create_channel_mask(ln, max_len=Nn)
+        valid = (torch.rand(B, E, generator=g) > 0.3).float()
+        kw = dict(length=ln, channel_padding_mask=pad, mask_valid=valid)
+        zn_f, ze_f, ldj_f, det = layer(zn, ze, reverse=False, **kw)
+        zn_r, ze_r, ldj_r, _ = layer(zn_f, ze_f, reverse=True, **kw)
+        wrap = NodeEdgeFlowWrapper(ActNormFlow(Dn, data_init=False), ActNormFlow(De, data_init=False))
+        wrap.node_flow.bias.data, wrap.node_flow.scales.data = torch.randn(1, 1, Dn, generator=g), 0.3 * torch.randn(1, 1, Dn, generator=g)
+        wrap.edge_flow.bias.data, wrap.edge_flow.scales.data = torch.randn(1, 1, De, generator=g), 0.3 * torch.randn(1, 1, De, generator=g)
+        ldj0 = torch.randn(B, generator=g)
+        wn, we, wl = wrap(zn, ze, ldj=ldj0.clone(), reverse=False, **kw)
+        c = dict(meta=dict(B=B, Nn=Nn, E=E, Dn=Dn, De=De, Kn=Kn, Ke=Ke, training=training, info=layer.info()),
+                 z_nodes=zn, z_edges=ze, nn_nodes=nn_n, nn_edges=nn_e, length=ln, pad=pad, mask_valid=valid,
+                 z_nodes_fwd=zn_f, z_edges_fwd=ze_f, ldj_fwd=ldj_f, z_nodes_rev=zn_r, z_edges_rev=ze_r, ldj_rev=ldj_r,
+                 reg_nodes=det["regularizer_nodes_ldj"], reg_edges=det["regularizer_edges_ldj"],
+                 wrap_ldj_in=ldj0, wrap_nodes=wn, wrap_edges=we, wrap_ldj=wl)
+        for k, v in layer.state_dict().items():
+            c["sd_" + k] = v
+        for k, v in wrap.state_dict().items():
+            c["wsd_" + k] = v
+        cases.append(c)
+    save("node_edge_coupling", cases)
+
+
+def gen_data_init():
+    """FlowModel.initialize_data_dependent (flow_model.py:96-131) through ActNorm -> InvConv -> ActNorm."""
+    torch.manual_seed(51)
+    np.random.seed(51)
+    D, N = 4, 6
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = FlowModel([ActNormFlow(D), InvertibleConv(D), ActNormFlow(D)])
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    batches = []
+    g = torch.Generator().manual_seed(52)
+    for b in range(3):
+        B = 5 + b
+        ln = lengths(B, N, g)
+        batches.append((2.0 * torch.randn(B, N, D, generator=g) + 0.5, {"length": ln, "channel_padding_mask": create_channel_mask(ln, max_len=N)}))
+    with contextlib.redirect_stdout(io.StringIO()):
+        model.initialize_data_dependent([(z.clone(), dict(kw)) for z, kw in batches])
+    c = dict(meta=dict(D=D, N=N, batches=[int(z.size(0)) for z, _ in batches]))
+    for i, (z, kw) in enumerate(batches):
+        c["z%d" % i], c["length%d" % i], c["pad%d" % i] = z, kw["length"], kw["channel_padding_mask"]
+    for k, v in sd0.items():
+        c["sd0_" + k] = v
+    for k, v in model.state_dict().items():
+        c["sd_" + k] = v
+    save("data_init", [c])
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
     gen_affine()
@@ -431,3 +547,6 @@ if __name__ == "__main__":
     gen_encoder()
     gen_sigmoid_dequant()
     gen_flow_stack()
+    gen_linear_flow_encoder()
+    gen_node_edge()
+    gen_data_init()

@@ -491,3 +491,108 @@ def test_set_shuffling_trained_model_bits_per_dim():
     mean_nll, bpd = allreduce_nll(total)
     assert abs(bpd - meta["val_bpd"]) < 0.01, (bpd, meta["val_bpd"])
     assert bpd > dataset.optimum_bpd(S) - 1e-3
+
+
+# ------------------------------------------------------------------------------------------------
+class _Stub(nn.Module):
+    """coupling sub-network stand-in that returns a fixed tensor (as in oracle/gen_golden.py)"""
+
+    def __init__(self):
+        super().__init__()
+        self.out = None
+
+    def forward(self, *args, **kwargs):
+        return self.out
+
+
+@pytest.mark.parametrize("c", load_cases("encoder_linear_flows"))
+def test_linear_flow_encoder_golden(c):
+    """num_flows > 0: the class flows are ExtActNorm + 1x1 conv + affine coupling kernels composed over [T*C,1,D]."""
+    from categoricalnf_amd.layers.categorical_encoding.linear_encoding import LinearCategoricalEncoding
+    m = c.meta
+    enc = LinearCategoricalEncoding(num_dimensions=m["D"], flow_config={"num_flows": m["flows"], "hidden_layers": 1, "hidden_size": m["hidden"]},
+                                    vocab_size=m["C"], default_embed_layer_dims=m["embed"])
+    enc.load_state_dict({k[3:]: v for k, v in c.items() if k.startswith("sd_")})
+    assert enc.info() == m["infos"]
+    enc.cuda().train(m["training"])
+    kw = dict(channel_padding_mask=g(c.pad)) if m["padded"] else {}
+    with torch.no_grad():
+        z, ldj, _ = enc(g(c.categ), reverse=False, beta=1, noise=g(c.u), **kw)
+        dec, _, _ = enc(g(c.z), reverse=True)
+    close(z, c.z, rtol=1e-4, atol=1e-4); close(ldj, c.ldj, rtol=1e-4, atol=2e-4)
+    assert torch.equal(dec.cpu(), c.decoded)
+
+
+@pytest.mark.parametrize("c", load_cases("node_edge_coupling"))
+def test_node_edge_coupling_golden(c):
+    from categoricalnf_amd.experiments.graph_node_edge_coupling import NodeEdgeCoupling, NodeEdgeFlowWrapper
+    from categoricalnf_amd.layers.flows.coupling_layer import CouplingLayer
+    from categoricalnf_amd.layers.flows.activation_normalization import ActNormFlow
+    m = c.meta
+    layer = NodeEdgeCoupling(c_in_nodes=m["Dn"], c_in_edges=m["De"], mask_nodes=CouplingLayer.create_channel_mask(m["Dn"]),
+                             mask_edges=CouplingLayer.create_channel_mask(m["De"]), num_mixtures_nodes=m["Kn"],
+                             num_mixtures_edges=m["Ke"], model_func=lambda c_out_nodes, c_out_edges: _Stub(),
+                             regularizer_max=3.5, regularizer_factor=2)
+    layer.load_state_dict({k[3:]: v for k, v in c.items() if k.startswith("sd_")})
+    assert layer.info() == m["info"]
+    layer.cuda().train(m["training"])
+    layer.nn.out = (g(c.nn_nodes), g(c.nn_edges))
+    kw = dict(length=g(c.length), channel_padding_mask=g(c.pad), mask_valid=g(c.mask_valid))
+    with torch.no_grad():
+        zn, ze, ldj, det = layer(g(c.z_nodes), g(c.z_edges), reverse=False, **kw)
+        zn_r, ze_r, ldj_r, det_r = layer(g(c.z_nodes_fwd), g(c.z_edges_fwd), reverse=True, **kw)
+    close(zn, c.z_nodes_fwd, **ELEM); close(ze, c.z_edges_fwd, **ELEM); close(ldj, c.ldj_fwd, **LDJ)
+    close(det["regularizer_nodes_ldj"], c.reg_nodes, **LDJ); close(det["regularizer_edges_ldj"], c.reg_edges, **LDJ)
+    close(zn_r, c.z_nodes_rev, rtol=1e-4, atol=1e-4); close(ze_r, c.z_edges_rev, rtol=1e-4, atol=1e-4)
+    close(ldj_r, c.ldj_rev, **LDJ)
+    assert "regularizer_nodes_ldj" not in det_r
+    # the reference's two-call static path (get_mixt_params + run_with_params) gives the same nodes result
+    from categoricalnf_amd.layers.flows.mixture_cdf_layer import MixtureCDFCoupling
+    mask_n = layer.mask_nodes[None, :1, :]
+    params = MixtureCDFCoupling.get_mixt_params(g(c.nn_nodes) * g(c.pad), mask_n, m["Kn"], layer.scaling_factor_nodes.data,
+                                                layer.mixture_scaling_factor_nodes.data)
+    z64, l64, reg64 = MixtureCDFCoupling.run_with_params(g(c.z_nodes).double(), *params, reverse=False, is_training=m["training"],
+                                                         reg_max=3.5, reg_factor=2, mask=mask_n, channel_padding_mask=g(c.pad),
+                                                         return_reg_ldj=True)
+    close((z64.float() * g(c.pad)), c.z_nodes_fwd, **ELEM)
+    wrap = NodeEdgeFlowWrapper(ActNormFlow(m["Dn"], data_init=False), ActNormFlow(m["De"], data_init=False))
+    wrap.load_state_dict({k[4:]: v for k, v in c.items() if k.startswith("wsd_")})
+    wrap.cuda()
+    with torch.no_grad():
+        wn, we, wl = wrap(g(c.z_nodes), g(c.z_edges), ldj=g(c.wrap_ldj_in.clone()), reverse=False, **kw)
+    close(wn, c.wrap_nodes, **ELEM); close(we, c.wrap_edges, **ELEM); close(wl, c.wrap_ldj, **LDJ)
+
+
+def test_data_dependent_init_driver_golden():
+    """FlowModel.initialize_data_dependent: ActNorm -> 1x1 conv -> ActNorm on three ragged batches."""
+    from categoricalnf_amd.layers.flows.flow_model import FlowModel
+    from categoricalnf_amd.layers.flows.activation_normalization import ActNormFlow
+    from categoricalnf_amd.layers.flows.permutation_layers import InvertibleConv
+    c = load_cases("data_init")[0]
+    D = c.meta["D"]
+    model = FlowModel([ActNormFlow(D), InvertibleConv(D), ActNormFlow(D)])
+    model.load_state_dict({k[4:]: v for k, v in c.items() if k.startswith("sd0_")})
+    model.cuda()
+    batches = [(g(c["z%d" % i]), {"length": g(c["length%d" % i]), "channel_padding_mask": g(c["pad%d" % i])})
+               for i in range(len(c.meta["batches"]))]
+    model.initialize_data_dependent(batches)
+    got = model.state_dict()
+    for k in ("flow_layers.0.bias", "flow_layers.0.scales", "flow_layers.2.bias", "flow_layers.2.scales"):
+        close(got[k], c["sd_" + k], rtol=1e-4, atol=1e-4)
+        assert tuple(got[k].shape) == (1, 1, D)
+
+
+def test_autoregressive_module_golden():
+    from categoricalnf_amd.layers.flows.autoregressive_coupling import AutoregressiveMixtureCDFCoupling
+    c = [x for x in load_cases("mixture_coupling") if x.meta["mask_kind"] == "none"][0]
+    m = c.meta
+    layer = AutoregressiveMixtureCDFCoupling(c_in=m["D"], model_func=lambda c_out: _Stub(), num_mixtures=m["K"])
+    layer.scaling_factor.data, layer.mixture_scaling_factor.data = c.scaling_factor.clone(), c.mixture_scaling_factor.clone()
+    layer.cuda()
+    layer.nn.out = g(c.nn_out)
+    ldj0 = torch.randn(m["B"], device="cuda")
+    with torch.no_grad():
+        z, ldj = layer(g(c.z), ldj=ldj0)
+    close(z, c.z_fwd, **ELEM); close(ldj - ldj0, c.ldj_fwd, **LDJ)
+    with pytest.raises(NotImplementedError):
+        layer(g(c.z), reverse=True)
