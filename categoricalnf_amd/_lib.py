@@ -42,10 +42,18 @@ SIGNATURES = {
     "cnf_encoder_forward": [_p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p, _p],
     "cnf_encoder_decode": [_p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
     "cnf_sigmoid_flow": [_p, _p, _p, _p, _i, _i, _i, _f, _p, _p],
+    "cnf_affine_coupling_bwd": [_p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "cnf_ext_actnorm_bwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "cnf_actnorm_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "cnf_invconv_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "cnf_logistic_log_prob_bwd": [_p, _p, _p, _i64, _f, _f, _p],
+    "cnf_prior_nll_bwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p],
+    "cnf_sigmoid_flow_bwd": [_p, _p, _p, _p, _i, _i, _i, _f, _p],
 }
 _PLAIN = {"cnf_abi_version": ([], _i), "cnf_last_error": ([], ctypes.c_char_p),
           "cnf_set_tile_chunks": ([_i], None), "cnf_set_unroll": ([_i], None),
-          "cnf_set_math_mode": ([_i], None), "cnf_set_inverse_mode": ([_i], None)}
+          "cnf_set_math_mode": ([_i], None), "cnf_set_inverse_mode": ([_i], None),
+          "cnf_bwd_workspace_floats": ([_i], _i64)}
 
 _lib = None
 

@@ -1,0 +1,210 @@
+"""Differentiable entry points: torch.autograd.Function wrappers whose forward AND backward are HIP kernels.
+
+The reference trains by differentiating its eager op chains; here each flow layer is one forward kernel and
+one backward kernel (csrc/cnf_backward.hip, csrc/cnf_mixture_bwd.hip).  Without grad mode (evaluation,
+sampling, benchmarks) the layer modules call `ops` directly; with it they go through these Functions."""
+import ctypes
+
+import torch
+
+from . import _lib, ops
+from .ops import _f32, _mask_desc, _opt_f32, _pad2d, _length, _ptr, _stream
+
+
+def _ws(param_count, device):
+    n = int(_lib.load().cnf_bwd_workspace_floats(int(param_count)))
+    return torch.empty(n, dtype=torch.float32, device=device)
+
+
+def _g(t, like=None):
+    """contiguous fp32 upstream gradient or None"""
+    if t is None:
+        return None
+    return t.contiguous() if not t.is_contiguous() else t
+
+
+class AffineCouplingFn(torch.autograd.Function):
+    """(z, nn_out, scaling_factor, ldj) -> (z', ldj + layer_ldj); mask / reverse are constants."""
+
+    @staticmethod
+    def forward(ctx, z, nn_out, scaling_factor, ldj, mask, reverse):
+        z_out, ldj_out = ops.affine_coupling(z, nn_out, scaling_factor, mask, reverse=reverse, ldj=ldj)
+        ctx.save_for_backward(z_out, nn_out, scaling_factor if scaling_factor is not None else z_out.new_empty(0), mask if mask is not None else z_out.new_empty(0))
+        ctx.has_sf, ctx.has_mask, ctx.has_ldj, ctx.reverse = scaling_factor is not None, mask is not None, ldj is not None, bool(reverse)
+        return z_out, ldj_out
+
+    @staticmethod
+    def backward(ctx, g_zout, g_ldj):
+        z_out, nn_out, sf, mask = ctx.saved_tensors
+        sf = sf if ctx.has_sf else None
+        mask = mask if ctx.has_mask else None
+        dev = z_out.device
+        B, N, D = z_out.shape
+        nn_c = _f32(nn_out, "nn_out")
+        sfc = _opt_f32(sf, "scaling_factor", dev)
+        m, mr, mc = _mask_desc(mask, D, dev)
+        g_z, g_nn = torch.empty_like(z_out), torch.empty_like(nn_c)
+        g_sf = torch.empty(D, dtype=torch.float32, device=dev) if sf is not None else None
+        ws = _ws(D, dev) if sf is not None else None
+        lib = _lib.load()
+        _lib.check(lib.cnf_affine_coupling_bwd(_ptr(z_out), _ptr(nn_c), _ptr(sfc), _ptr(m), mr, mc, _ptr(_g(g_zout)),
+                                               _ptr(_g(g_ldj)), _ptr(g_z), _ptr(g_nn), _ptr(g_sf), _ptr(ws), B, N, D,
+                                               int(ctx.reverse), _stream(dev)), "cnf_affine_coupling_bwd")
+        return g_z, g_nn.view_as(nn_out), (g_sf.view_as(sf) if sf is not None else None), (g_ldj if ctx.has_ldj else None), None, None
+
+
+class ExtActNormFn(torch.autograd.Function):
+    """(z, nn_out [B,N,2D], ldj) -> (z', ldj +- sum tanh(scales) pad)."""
+
+    @staticmethod
+    def forward(ctx, z, nn_out, ldj, pad, reverse):
+        z_out, ldj_out = ops.ext_actnorm(z, nn_out, reverse=reverse, channel_padding_mask=pad,
+                                         ldj=(ldj.clone() if ldj is not None else None))
+        ctx.save_for_backward(z_out, nn_out, pad if isinstance(pad, torch.Tensor) else z_out.new_empty(0))
+        ctx.has_pad, ctx.has_ldj, ctx.reverse = isinstance(pad, torch.Tensor), ldj is not None, bool(reverse)
+        return z_out, ldj_out
+
+    @staticmethod
+    def backward(ctx, g_zout, g_ldj):
+        z_out, nn_out, pad = ctx.saved_tensors
+        dev = z_out.device
+        B, N, D = z_out.shape
+        nn_c = _f32(nn_out, "nn_out")
+        p2 = _pad2d(pad, B, N, dev) if ctx.has_pad else None
+        g_z, g_nn = torch.empty_like(z_out), torch.empty_like(nn_c)
+        lib = _lib.load()
+        _lib.check(lib.cnf_ext_actnorm_bwd(_ptr(z_out), _ptr(nn_c), _ptr(p2), _ptr(_g(g_zout)), _ptr(_g(g_ldj)), _ptr(g_z),
+                                           _ptr(g_nn), B, N, D, int(ctx.reverse), _stream(dev)), "cnf_ext_actnorm_bwd")
+        return g_z, g_nn.view_as(nn_out), (g_ldj if ctx.has_ldj else None), None, None
+
+
+class ActNormFn(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, z, bias, scales, ldj, length, pad, reverse):
+        z_out, ldj_out = ops.actnorm(z, bias, scales, reverse=reverse, length=length, channel_padding_mask=pad,
+                                     ldj=(ldj.clone() if ldj is not None else None))
+        empty = z_out.new_empty(0)
+        ctx.save_for_backward(z_out, bias, scales, length if isinstance(length, torch.Tensor) else empty,
+                              pad if isinstance(pad, torch.Tensor) else empty)
+        ctx.has_len, ctx.has_pad, ctx.has_ldj, ctx.reverse = isinstance(length, torch.Tensor), isinstance(pad, torch.Tensor), ldj is not None, bool(reverse)
+        return z_out, ldj_out
+
+    @staticmethod
+    def backward(ctx, g_zout, g_ldj):
+        z_out, bias, scales, length, pad = ctx.saved_tensors
+        dev = z_out.device
+        B, N, D = z_out.shape
+        p2 = _pad2d(pad, B, N, dev) if ctx.has_pad else None
+        ln = _length(length, B, dev) if ctx.has_len else None
+        g_z = torch.empty_like(z_out)
+        g_b = torch.empty(D, dtype=torch.float32, device=dev)
+        g_s = torch.empty(D, dtype=torch.float32, device=dev)
+        ws = _ws(2 * D, dev)
+        lib = _lib.load()
+        _lib.check(lib.cnf_actnorm_bwd(_ptr(z_out), _ptr(_f32(bias.reshape(-1), "bias")), _ptr(_f32(scales.reshape(-1), "scales")),
+                                       _ptr(p2), _ptr(ln), _ptr(_g(g_zout)), _ptr(_g(g_ldj)), _ptr(g_z), _ptr(g_b), _ptr(g_s),
+                                       _ptr(ws), B, N, D, int(ctx.reverse), _stream(dev)), "cnf_actnorm_bwd")
+        return g_z, g_b.view_as(bias), g_s.view_as(scales), (g_ldj if ctx.has_ldj else None), None, None, None
+
+
+class InvConvFn(torch.autograd.Function):
+    """(x, weight [D,D], sldj scalar, ldj) -> (x @ weight * pad, ldj +- sldj * len)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, sldj, ldj, length, pad, reverse):
+        z, ldj_out = ops.invconv(x, weight, sldj, reverse=reverse, length=length, channel_padding_mask=pad, ldj=ldj)
+        empty = z.new_empty(0)
+        ctx.save_for_backward(x, weight, sldj, length if isinstance(length, torch.Tensor) else empty,
+                              pad if isinstance(pad, torch.Tensor) else empty)
+        ctx.has_len, ctx.has_pad, ctx.has_ldj, ctx.reverse = isinstance(length, torch.Tensor), isinstance(pad, torch.Tensor), ldj is not None, bool(reverse)
+        return z, ldj_out
+
+    @staticmethod
+    def backward(ctx, g_zout, g_ldj):
+        x, weight, sldj, length, pad = ctx.saved_tensors
+        dev = x.device
+        B, N, D = x.shape
+        xc, wc = _f32(x, "x"), _f32(weight, "weight")
+        p2 = _pad2d(pad, B, N, dev) if ctx.has_pad else None
+        ln = _length(length, B, dev) if ctx.has_len else None
+        g_x = torch.empty_like(xc)
+        g_w = torch.empty(D, D, dtype=torch.float32, device=dev)
+        g_s = torch.empty(1, dtype=torch.float32, device=dev)
+        ws = _ws(D * D + 1, dev)
+        lib = _lib.load()
+        _lib.check(lib.cnf_invconv_bwd(_ptr(xc), _ptr(wc), _ptr(p2), _ptr(ln), _ptr(_g(g_zout)), _ptr(_g(g_ldj)), _ptr(g_x),
+                                       _ptr(g_w), _ptr(g_s), _ptr(ws), B, N, D, int(ctx.reverse), _stream(dev)), "cnf_invconv_bwd")
+        return g_x, g_w, g_s.view_as(sldj), (g_ldj if ctx.has_ldj else None), None, None, None
+
+
+class LogisticLogProbFn(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, x, mu, sigma, log_sigma):
+        ctx.save_for_backward(x)
+        ctx.mu, ctx.sigma = float(mu), float(sigma)
+        return ops.logistic_log_prob(x, mu=mu, sigma=sigma, log_sigma=log_sigma)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        xc = _f32(x, "x")
+        g_x = torch.empty_like(xc)
+        lib = _lib.load()
+        _lib.check(lib.cnf_logistic_log_prob_bwd(_ptr(xc), _ptr(_g(g)), _ptr(g_x), xc.numel(), ctx.mu, ctx.sigma,
+                                                 _stream(xc.device)), "cnf_logistic_log_prob_bwd")
+        return g_x.view_as(x), None, None, None
+
+
+class PriorNllFn(torch.autograd.Function):
+    """(z, ldj) -> per-sample NLL [B] (length / padding are constants)."""
+
+    @staticmethod
+    def forward(ctx, z, ldj, length, pad):
+        _, nll = ops.prior_nll(z, ldj, length=length, channel_padding_mask=pad)
+        empty = z.new_empty(0)
+        ctx.save_for_backward(z, length if isinstance(length, torch.Tensor) else empty, pad if isinstance(pad, torch.Tensor) else empty)
+        ctx.has_len, ctx.has_pad = isinstance(length, torch.Tensor), isinstance(pad, torch.Tensor)
+        return nll
+
+    @staticmethod
+    def backward(ctx, g_nll):
+        z, length, pad = ctx.saved_tensors
+        dev = z.device
+        B, N, D = z.shape
+        zc = _f32(z, "z")
+        p2 = _pad2d(pad, B, N, dev) if ctx.has_pad else None
+        ln = _length(length, B, dev) if ctx.has_len else None
+        g_z = torch.empty_like(zc)
+        g_ldj = torch.empty(B, dtype=torch.float32, device=dev)
+        lib = _lib.load()
+        _lib.check(lib.cnf_prior_nll_bwd(_ptr(zc), _ptr(p2), _ptr(ln), _ptr(_g(g_nll)), _ptr(g_z), _ptr(g_ldj), B, N, D,
+                                         float(ops.LOGISTIC_SIGMA), _stream(dev)), "cnf_prior_nll_bwd")
+        return g_z, g_ldj, None, None
+
+
+class SigmoidFlowFn(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, z, ldj, reverse, alpha):
+        z_out, ldj_out = ops.sigmoid_flow(z, reverse=reverse, ldj=ldj, alpha=alpha)
+        ctx.save_for_backward(z)
+        ctx.reverse, ctx.alpha, ctx.has_ldj = bool(reverse), float(alpha), ldj is not None
+        return z_out, ldj_out
+
+    @staticmethod
+    def backward(ctx, g_zout, g_ldj):
+        (z,) = ctx.saved_tensors
+        zc = _f32(z, "z")
+        B = zc.shape[0]
+        L = zc.numel() // B
+        g_z = torch.empty_like(zc)
+        lib = _lib.load()
+        _lib.check(lib.cnf_sigmoid_flow_bwd(_ptr(zc), _ptr(_g(g_zout)), _ptr(_g(g_ldj)), _ptr(g_z), B, L, int(ctx.reverse),
+                                            ctx.alpha, _stream(zc.device)), "cnf_sigmoid_flow_bwd")
+        return g_z, (g_ldj if ctx.has_ldj else None), None, None
+
+
+def needs_grad(*tensors):
+    return torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors)

@@ -6,8 +6,8 @@ Both add into the caller's `ldj` IN PLACE like the reference (:37,:40,:133,:139)
 import torch
 import torch.nn as nn
 
+from ... import functional as Fn
 from ... import ops
-from ...host_utils import forbid_grad
 from .flow_layer import FlowLayer
 
 
@@ -21,7 +21,9 @@ class ActNormFlow(FlowLayer):
         self.scales = nn.Parameter(torch.zeros(1, 1, self.c_in))
 
     def forward(self, z, ldj=None, reverse=False, length=None, channel_padding_mask=None, **kwargs):
-        forbid_grad("ActNormFlow", z, self.bias, self.scales, ldj)
+        if Fn.needs_grad(z, self.bias, self.scales, ldj):
+            # out of place on `ldj` under autograd (nobody relies on the alias while training)
+            return Fn.ActNormFn.apply(z, self.bias, self.scales, ldj, length, channel_padding_mask, reverse)
         return ops.actnorm(z, self.bias, self.scales, reverse=reverse, length=length,
                            channel_padding_mask=channel_padding_mask, ldj=ldj)
 
@@ -73,8 +75,10 @@ class ExtActNormFlow(FlowLayer):
             nn_out = z.new_zeros(z.size(0), z.size(1), 2 * z.size(2))
         else:
             nn_out = self._run_nn(ext_input)
-        forbid_grad("ExtActNormFlow", z, nn_out, ldj)
-        z_out, ldj_out = ops.ext_actnorm(z, nn_out, reverse=reverse, channel_padding_mask=channel_padding_mask, ldj=ldj)
+        if Fn.needs_grad(z, nn_out, ldj):
+            z_out, ldj_out = Fn.ExtActNormFn.apply(z, nn_out, ldj, channel_padding_mask, reverse)
+        else:
+            z_out, ldj_out = ops.ext_actnorm(z, nn_out, reverse=reverse, channel_padding_mask=channel_padding_mask, ldj=ldj)
         if layer_share_dict is not None and not reverse:
             bias, scales = nn_out.chunk(2, dim=2)
             scales = torch.tanh(scales)

@@ -8,6 +8,7 @@ import math
 import torch
 import torch.nn as nn
 
+from ... import functional as Fn
 from ... import ops
 from ...host_utils import forbid_grad
 from ..networks.help_layers import run_sequential_with_mask
@@ -47,9 +48,9 @@ class CouplingLayer(FlowLayer):
     def forward(self, z, ldj=None, reverse=False, channel_padding_mask=None, **kwargs):
         # NB: like the reference, padding is ignored by the affine coupling
         nn_out = self.run_network(x=z * self._prepare_mask(self.mask, z), **kwargs)
-        forbid_grad("CouplingLayer", z, nn_out, self.scaling_factor)
-        z_out, ldj_out = ops.affine_coupling(z, nn_out, self.scaling_factor, self.mask, reverse=reverse, ldj=ldj)
-        return z_out, ldj_out
+        if Fn.needs_grad(z, nn_out, self.scaling_factor, ldj):
+            return Fn.AffineCouplingFn.apply(z, nn_out, self.scaling_factor, ldj, self.mask, reverse)
+        return ops.affine_coupling(z, nn_out, self.scaling_factor, self.mask, reverse=reverse, ldj=ldj)
 
     @staticmethod
     def get_coup_params(nn_out, mask, scaling_factor=None):

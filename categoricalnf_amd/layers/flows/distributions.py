@@ -9,6 +9,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from ... import functional as Fn
 from ... import ops
 from ...host_utils import get_param_val
 
@@ -113,6 +114,8 @@ class LogisticDistribution(PriorDistribution):
         return x, -self.log_prob(x)
 
     def log_prob(self, x):
+        if Fn.needs_grad(x):
+            return Fn.LogisticLogProbFn.apply(x, self.mu, self.sigma, float(self.log_sigma))
         return ops.logistic_log_prob(x, mu=self.mu, sigma=self.sigma, log_sigma=float(self.log_sigma))
 
     def info(self):

@@ -11,8 +11,8 @@ import scipy.linalg
 import torch
 import torch.nn as nn
 
+from ... import functional as Fn
 from ... import ops
-from ...host_utils import forbid_grad
 from .flow_layer import FlowLayer
 
 
@@ -86,9 +86,11 @@ class InvertibleConv(FlowLayer):
     def forward(self, x, ldj=None, reverse=False, length=None, channel_padding_mask=None,
                 layer_share_dict=None, **kwargs):
         weight, sldj = self._get_weight(device_name=str(x.device), inverse=reverse)
-        forbid_grad("InvertibleConv", x, weight, sldj, ldj)
-        z, ldj_out = ops.invconv(x, weight, sldj, reverse=reverse, length=length,
-                                 channel_padding_mask=channel_padding_mask, ldj=ldj)
+        if Fn.needs_grad(x, weight, sldj, ldj):
+            z, ldj_out = Fn.InvConvFn.apply(x, weight, sldj, ldj, length, channel_padding_mask, reverse)
+        else:
+            z, ldj_out = ops.invconv(x, weight, sldj, reverse=reverse, length=length,
+                                     channel_padding_mask=channel_padding_mask, ldj=ldj)
         if layer_share_dict is not None:
             layer_share_dict["t"] = layer_share_dict["t"] * 0.0
             layer_share_dict["log_s"] = layer_share_dict["log_s"] * 0.0

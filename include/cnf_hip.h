@@ -204,6 +204,50 @@ int cnf_encoder_decode(const float* z, const float* table, const float* category
 int cnf_sigmoid_flow(const float* z, const float* ldj_in, float* z_out, float* ldj_out,
                      int B, int L, int reverse, float alpha, int* flags, cnf_stream_t stream);
 
+/* ---- backward (vector-Jacobian products) ------------------------------------------------------------
+ * The reference differentiates its eager op chains with autograd (general/train.py:144-155); these entry
+ * points return the same gradients.  g_zout [B,N,D] / g_ldj [B] are the upstream gradients of a layer's two
+ * outputs (either may be NULL = zero).  Parameter gradients are batch reductions: the caller passes
+ * `workspace` with cnf_bwd_workspace_floats(P) floats (P = number of parameter entries of that call); the
+ * sum is formed in fp64 in a fixed order (deterministic). */
+int64_t cnf_bwd_workspace_floats(int param_count);
+
+/* d(CouplingLayer.forward) (coupling_layer.py:53-63,88-98).  z_out = the forward OUTPUT of the same
+ * direction.  g_scaling_factor [D] only when scaling_factor != NULL (P = D). */
+int cnf_affine_coupling_bwd(const float* z_out, const float* nn_out, const float* scaling_factor,
+                            const float* mask, int mask_rows, int mask_cols,
+                            const float* g_zout, const float* g_ldj,
+                            float* g_z, float* g_nn, float* g_scaling_factor, float* workspace,
+                            int B, int N, int D, int reverse, cnf_stream_t stream);
+
+/* d(ExtActNormFlow.forward) w.r.t. z and the predictor output nn_out [B,N,2D] (activation_normalization.py:127-139). */
+int cnf_ext_actnorm_bwd(const float* z_out, const float* nn_out, const float* pad,
+                        const float* g_zout, const float* g_ldj, float* g_z, float* g_nn,
+                        int B, int N, int D, int reverse, cnf_stream_t stream);
+
+/* d(ActNormFlow.forward) (activation_normalization.py:35-43): g_z, g_bias [D], g_scales [D]; P = 2D. */
+int cnf_actnorm_bwd(const float* z_out, const float* bias, const float* scales,
+                    const float* pad, const float* length, const float* g_zout, const float* g_ldj,
+                    float* g_z, float* g_bias, float* g_scales, float* workspace,
+                    int B, int N, int D, int reverse, cnf_stream_t stream);
+
+/* d(InvertibleConv.forward) (permutation_layers.py:112-121): g_x, g_weight [D,D] (of the matrix that was
+ * applied), g_sldj [1]; P = D*D + 1. */
+int cnf_invconv_bwd(const float* x, const float* weight, const float* pad, const float* length,
+                    const float* g_zout, const float* g_ldj,
+                    float* g_x, float* g_weight, float* g_sldj, float* workspace,
+                    int B, int N, int D, int reverse, cnf_stream_t stream);
+
+/* d(LogisticDistribution.log_prob) and d(NLL assembly) w.r.t. z (and ldj). */
+int cnf_logistic_log_prob_bwd(const float* x, const float* g_logp, float* g_x, int64_t n, float mu, float sigma,
+                              cnf_stream_t stream);
+int cnf_prior_nll_bwd(const float* z, const float* pad, const float* length, const float* g_nll,
+                      float* g_z, float* g_ldj, int B, int N, int D, float sigma, cnf_stream_t stream);
+
+/* d(SigmoidFlow.forward) w.r.t. its input (sigmoid_layer.py:31-37). */
+int cnf_sigmoid_flow_bwd(const float* z_in, const float* g_zout, const float* g_ldj, float* g_z,
+                         int B, int L, int reverse, float alpha, cnf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

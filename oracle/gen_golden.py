@@ -537,6 +537,173 @@ def gen_data_init():
     save("data_init", [c])
 
 
+def gen_grads():
+    """Gradients of every differentiable hot-path layer, taken with the reference's autograd:
+    loss = sum(z_out * wz) + sum(ldj * wl) with fixed random weights."""
+    g = torch.Generator().manual_seed(60)
+    cases = []
+
+    def leaf(t):
+        return t.clone().requires_grad_(True)
+
+    # affine coupling, both directions, channel and chess masks
+    for (B, N, D, kind, reverse) in [(4, 6, 4, "channel", False), (3, 5, 6, "channel", True), (4, 7, 1, "chess", False),
+                                     (5, 3, 3, "channel", True), (2, 64, 6, "channel", False)]:
+        mask = CouplingLayer.create_channel_mask(D) if kind == "channel" else CouplingLayer.create_chess_mask()
+        with contextlib.redirect_stdout(io.StringIO()):
+            layer = CouplingLayer(c_in=D, mask=mask, model_func=lambda c_out: Inject())
+        layer.scaling_factor.data = torch.cat([torch.zeros(1), 0.5 * torch.randn(D - 1, generator=g)]) if D > 1 else torch.zeros(1)
+        z, nn_out, ldj = leaf(torch.randn(B, N, D, generator=g)), leaf(1.2 * torch.randn(B, N, 2 * D, generator=g)), leaf(torch.randn(B, generator=g))
+        layer.nn.value = nn_out
+        wz, wl = torch.randn(B, N, D, generator=g), torch.randn(B, generator=g)
+        zo, lo = layer(z, ldj=ldj, reverse=reverse)
+        ((zo * wz).sum() + (lo * wl).sum()).backward()
+        cases.append(dict(meta=dict(layer="affine", B=B, N=N, D=D, mask_kind=kind, reverse=reverse), z=z.detach(), nn_out=nn_out.detach(),
+                          ldj=ldj.detach(), mask=mask, scaling_factor=layer.scaling_factor.data, wz=wz, wl=wl,
+                          g_z=z.grad, g_nn=nn_out.grad, g_ldj=ldj.grad, g_sf=layer.scaling_factor.grad))
+
+    # ActNorm
+    for (B, N, D, mode, reverse) in [(4, 6, 3, "length_mask", False), (3, 5, 4, "none", True), (5, 4, 6, "mask", False), (3, 7, 2, "length", True)]:
+        layer = ActNormFlow(D)
+        layer.bias.data, layer.scales.data = torch.randn(1, 1, D, generator=g), 0.4 * torch.randn(1, 1, D, generator=g)
+        z, ldj = leaf(torch.randn(B, N, D, generator=g)), leaf(torch.randn(B, generator=g))
+        ln = lengths(B, N, g)
+        pad = create_channel_mask(ln, max_len=N)
+        kw = {}
+        if "length" in mode:
+            kw["length"] = ln
+        if "mask" in mode:
+            kw["channel_padding_mask"] = pad
+        wz, wl = torch.randn(B, N, D, generator=g), torch.randn(B, generator=g)
+        zo, lo = layer(z, ldj=ldj * 1.0, reverse=reverse, **kw)
+        ((zo * wz).sum() + (lo * wl).sum()).backward()
+        cases.append(dict(meta=dict(layer="actnorm", B=B, N=N, D=D, mode=mode, reverse=reverse), z=z.detach(), ldj=ldj.detach(),
+                          bias=layer.bias.data, scales=layer.scales.data, length=ln, pad=pad, wz=wz, wl=wl,
+                          g_z=z.grad, g_ldj=ldj.grad, g_bias=layer.bias.grad, g_scales=layer.scales.grad))
+
+    # ExtActNorm
+    for (B, N, D, padded, reverse) in [(6, 1, 3, False, False), (4, 5, 4, True, False), (5, 1, 2, False, True)]:
+        net = Inject()
+        layer = ExtActNormFlow(D, net=net)
+        z, nn_out, ldj = leaf(torch.randn(B, N, D, generator=g)), leaf(torch.randn(B, N, 2 * D, generator=g)), leaf(torch.randn(B, generator=g))
+        net.value = nn_out
+        ln = lengths(B, N, g)
+        pad = create_channel_mask(ln, max_len=N)
+        wz, wl = torch.randn(B, N, D, generator=g), torch.randn(B, generator=g)
+        zo, lo = layer(z, ldj * 1.0, ext_input=z, reverse=reverse, **(dict(channel_padding_mask=pad) if padded else {}))
+        ((zo * wz).sum() + (lo * wl).sum()).backward()
+        cases.append(dict(meta=dict(layer="ext_actnorm", B=B, N=N, D=D, padded=padded, reverse=reverse), z=z.detach(), nn_out=nn_out.detach(),
+                          ldj=ldj.detach(), pad=pad, wz=wz, wl=wl, g_z=z.grad, g_nn=nn_out.grad, g_ldj=ldj.grad))
+
+    # invertible 1x1 convolution (LU parameters and dense weight)
+    np.random.seed(61)
+    for (B, N, D, lu, mode, reverse) in [(4, 6, 4, True, "length_mask", False), (3, 5, 3, False, "none", False), (4, 3, 6, True, "length", True),
+                                         (3, 4, 2, True, "none", False)]:
+        layer = InvertibleConv(D, LU_decomposed=lu)
+        layer.train()
+        x, ldj = leaf(torch.randn(B, N, D, generator=g)), leaf(torch.randn(B, generator=g))
+        ln = lengths(B, N, g)
+        pad = create_channel_mask(ln, max_len=N)
+        kw = {}
+        if "length" in mode:
+            kw["length"] = ln
+        if "mask" in mode:
+            kw["channel_padding_mask"] = pad
+        wz, wl = torch.randn(B, N, D, generator=g), torch.randn(B, generator=g)
+        zo, lo = layer(x, ldj=ldj, reverse=reverse, **kw)
+        ((zo * wz).sum() + (lo * wl).sum()).backward()
+        c = dict(meta=dict(layer="invconv", B=B, N=N, D=D, lu=lu, mode=mode, reverse=reverse), x=x.detach(), ldj=ldj.detach(),
+                 length=ln, pad=pad, wz=wz, wl=wl, g_x=x.grad, g_ldj=ldj.grad)
+        for k, v in layer.state_dict().items():
+            c["sd_" + k] = v
+        for k, v in layer.named_parameters():
+            c["gp_" + k] = v.grad
+        cases.append(c)
+
+    # logistic prior log-prob, NLL assembly, sigmoid flows
+    prior = LogisticDistribution()
+    x = leaf(2 * torch.randn(5, 6, 3, generator=g))
+    w = torch.randn(5, 6, 3, generator=g)
+    (prior.log_prob(x) * w).sum().backward()
+    cases.append(dict(meta=dict(layer="log_prob"), x=x.detach(), w=w, g_x=x.grad))
+    B, N, D = 5, 6, 4
+    z, ldj = leaf(1.5 * torch.randn(B, N, D, generator=g)), leaf(torch.randn(B, generator=g))
+    ln = lengths(B, N, g)
+    pad = create_channel_mask(ln, max_len=N)
+    wl = torch.randn(B, generator=g)
+    nll = (-ldj) / ln.float() + (-(prior.log_prob(z) * pad).sum(dim=[1, 2])) / ln.float()
+    (nll * wl).sum().backward()
+    cases.append(dict(meta=dict(layer="nll", B=B, N=N, D=D), z=z.detach(), ldj=ldj.detach(), length=ln, pad=pad, wl=wl,
+                      g_z=z.grad, g_ldj=ldj.grad))
+    for reverse in (False, True):
+        layer = SigmoidFlow()
+        zi = leaf(2 * torch.randn(4, 6, 1, generator=g)) if not reverse else leaf(torch.rand(4, 6, 1, generator=g))
+        ldj = leaf(torch.randn(4, generator=g))
+        wz, wl = torch.randn(4, 6, 1, generator=g), torch.randn(4, generator=g)
+        zo, lo = layer(zi, ldj=ldj, reverse=reverse)
+        ((zo * wz).sum() + (lo * wl).sum()).backward()
+        cases.append(dict(meta=dict(layer="sigmoid", reverse=reverse), z=zi.detach(), ldj=ldj.detach(), wz=wz, wl=wl, g_z=zi.grad, g_ldj=ldj.grad))
+
+    # mixture-CDF coupling forward (the inverse is never differentiated by the reference)
+    for (B, N, D, K, kind, reg_max, training, padded) in [(3, 6, 4, 8, "channel", -1, True, False), (3, 5, 6, 16, "channel", 3.5, True, True),
+                                                          (2, 7, 3, 4, "none", -1, True, False), (4, 6, 1, 8, "chess", -1, True, True),
+                                                          (2, 4, 2, 10, "channel", -1, False, False)]:
+        P = 2 + 3 * K
+        z, nn_out = leaf(1.5 * torch.randn(B, N, D, generator=g)), leaf(0.8 * torch.randn(B, N, D * P, generator=g))
+        sf, msf = 0.4 * torch.randn(D, generator=g), 0.4 * torch.randn(D, K, generator=g)
+        sf[0] = 0.0
+        ln = lengths(B, N, g)
+        pad = create_channel_mask(ln, max_len=N)
+        wz, wl = torch.randn(B, N, D, generator=g), torch.randn(B, generator=g)
+        if kind == "none":
+            with contextlib.redirect_stdout(io.StringIO()):
+                layer = AutoregressiveMixtureCDFCoupling(c_in=D, model_func=lambda c_out: Inject(), num_mixtures=K)
+            mask = None
+        else:
+            mask = CouplingLayer.create_channel_mask(D) if kind == "channel" else CouplingLayer.create_chess_mask()
+            with contextlib.redirect_stdout(io.StringIO()):
+                layer = MixtureCDFCoupling(c_in=D, mask=mask, model_func=lambda c_out: Inject(), num_mixtures=K,
+                                           regularizer_max=reg_max, regularizer_factor=2)
+        layer.scaling_factor.data, layer.mixture_scaling_factor.data = sf.clone(), msf.clone()
+        layer.nn.value = nn_out
+        layer.train(training)
+        res = layer(z, reverse=False, **(dict(channel_padding_mask=pad) if padded else {}))
+        zo, lo = res[0], res[1]
+        ((zo * wz).sum() + (lo * wl).sum()).backward()
+        c = dict(meta=dict(layer="mixture", B=B, N=N, D=D, K=K, mask_kind=kind, reg_max=reg_max, reg_factor=2, training=training, padded=padded),
+                 z=z.detach(), nn_out=nn_out.detach(), scaling_factor=sf, mixture_scaling_factor=msf, pad=pad, wz=wz, wl=wl,
+                 g_z=z.grad, g_nn=nn_out.grad, g_sf=layer.scaling_factor.grad, g_msf=layer.mixture_scaling_factor.grad)
+        if mask is not None:
+            c["mask"] = mask
+        cases.append(c)
+
+    # mixture-model encoder: gradients reach the embedding and the predictor through the class table
+    for i, (B, N, D, C, beta, padded) in enumerate([(3, 6, 3, 4, 1.0, False), (4, 5, 4, 9, 1.5, True)]):
+        torch.manual_seed(800 + i)
+        with contextlib.redirect_stdout(io.StringIO()):
+            enc = LinearCategoricalEncoding(num_dimensions=D, flow_config={"num_flows": 0}, vocab_size=C, default_embed_layer_dims=8)
+        lin = enc.flow_layers[0].pred_net.layer
+        lin.weight.data[D:, :] = 0.2 * torch.randn(D, lin.weight.shape[1])
+        lin.bias.data = 0.1 * torch.randn(2 * D)
+        enc.eval()
+        cat = torch.randint(0, C, (B, N))
+        ln = lengths(B, N, torch.Generator().manual_seed(i))
+        pad = create_channel_mask(ln, max_len=N)
+        torch.manual_seed(900 + i)
+        u = torch.rand(B * N, 1, D)
+        torch.manual_seed(900 + i)
+        zo, lo, _ = enc(cat, reverse=False, beta=beta, **(dict(channel_padding_mask=pad) if padded else {}))
+        wz, wl = torch.randn(B, N, D), torch.randn(B)
+        ((zo * wz).sum() + (lo * wl).sum()).backward()
+        c = dict(meta=dict(layer="encoder", B=B, N=N, D=D, C=C, beta=beta, padded=padded), categ=cat, u=u, pad=pad, wz=wz, wl=wl)
+        for k, v in enc.state_dict().items():
+            c["sd_" + k] = v
+        for k, v in enc.named_parameters():
+            c["gp_" + k] = v.grad
+        cases.append(c)
+    save("grads", cases)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
     gen_affine()
@@ -550,3 +717,4 @@ if __name__ == "__main__":
     gen_linear_flow_encoder()
     gen_node_edge()
     gen_data_init()
+    gen_grads()

@@ -25,7 +25,7 @@ def built_lib():
 def test_abi_exports_every_declared_symbol(built_lib):
     from categoricalnf_amd import _lib
     header = open(os.path.join(ROOT, "include", "cnf_hip.h")).read()
-    declared = set(re.findall(r"^(?:int|void|const char\*)\s+(cnf_\w+)\s*\(", header, flags=re.M))
+    declared = set(re.findall(r"^(?:int64_t|int|void|const char\*)\s+(cnf_\w+)\s*\(", header, flags=re.M))
     assert declared, "no prototypes found in include/cnf_hip.h"
     assert declared == set(_lib.exported_symbols())
     nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], stdout=subprocess.PIPE, text=True).stdout
