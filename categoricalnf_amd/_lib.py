@@ -49,6 +49,9 @@ SIGNATURES = {
     "cnf_logistic_log_prob_bwd": [_p, _p, _p, _i64, _f, _f, _p],
     "cnf_prior_nll_bwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p],
     "cnf_sigmoid_flow_bwd": [_p, _p, _p, _p, _i, _i, _i, _f, _p],
+    "cnf_mixture_coupling_bwd": [_p, _p, _p, _p, _p, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p,
+                                 _i, _i, _i, _i, _d, _d, _i, _p],
+    "cnf_encoder_forward_bwd": [_p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
 }
 _PLAIN = {"cnf_abi_version": ([], _i), "cnf_last_error": ([], ctypes.c_char_p),
           "cnf_set_tile_chunks": ([_i], None), "cnf_set_unroll": ([_i], None),

@@ -1,0 +1,214 @@
+// Backward of the logistic-mixture CDF coupling FORWARD transform (mixture_cdf_layer.py:95-123,145-180),
+// fp64 like the forward kernel.  The reference never differentiates the inverse (its encoders use affine
+// couplings for that reason, linear_encoding.py:233), so only the forward direction has a backward.
+//
+// Per transformed element (x, parameters t, log_s, log_pi[K], mu[K], ls[K]):
+//   u = sum_k pi_k sigma_k,  pdf = sum_k pi_k p_k,  p_k = sigma_k (1 - sigma_k) e^{-ls_k},  z_k = (x - mu_k) e^{-ls_k}
+//   y = log u - log(1-u),  z' = (y + t) e^{log_s},  ldj = log_s - log u - log(1-u) + log pdf (+ reg)
+// Upstream: g_zout (d loss / d z'), g_ldj (per sample).  Outputs: g_z, g_nn (raw subnet output, through
+// the fp32 tanh bounds and the channel mask), g_scaling_factor [D], g_mixture_scaling_factor [D,K].
+#include "cnf_common.h"
+
+#include <algorithm>
+
+namespace cnf {
+
+constexpr int kMixBwdMaxP = 1024;
+constexpr int kMixBwdGrid = 1024;
+constexpr double kLn10b = 2.302585092994045684;
+
+struct MixBwdArgs {
+    const float* z;
+    const float* nn;
+    const float* sf;
+    const float* msf;
+    const float* mask;
+    const float* pad;
+    const float* g_zout;
+    const float* g_ldj;
+    float* g_z;
+    float* g_nn;            // pre-zeroed by the caller side (hipMemsetAsync below)
+    float* partials;        // [gridDim.x, D + D*K]
+    long total;             // B*N*D
+    int N, D, K, P, L, mr, mc;
+    int pad_in_transform, pad_output, use_reg;
+    double reg_max, reg_factor;
+};
+
+__device__ __forceinline__ float bound_f(float raw, const float* fac_ptr) {      // tanh bound in fp32 (:156-162)
+    if (!fac_ptr) return raw;
+    const float f = expf(fac_ptr[0]);
+    return tanhf(raw / fmaxf(f, 1.f)) * f;
+}
+// d bound / d raw and d bound / d factor-parameter (f = e^sf; clamp(min=1) passes the gradient for f >= 1)
+__device__ __forceinline__ void bound_grads(float raw, const float* fac_ptr, double& d_raw, double& d_sf) {
+    if (!fac_ptr) { d_raw = 1.0; d_sf = 0.0; return; }
+    const float f = expf(fac_ptr[0]);
+    const float fc = fmaxf(f, 1.f);
+    const float u = raw / fc;
+    const float th = tanhf(u);
+    const float sech2 = 1.f - th * th;
+    d_raw = (double)(f * sech2 / fc);
+    d_sf = (double)((f >= 1.f) ? f * (th - u * sech2) : f * th);
+}
+
+__global__ __launch_bounds__(kBlock) void mixture_fwd_bwd_kernel(MixBwdArgs a) {
+    __shared__ float acc[kMixBwdMaxP];
+    const int PP = a.D + a.D * a.K;
+    for (int i = threadIdx.x; i < PP; i += kBlock) acc[i] = 0.f;
+    __syncthreads();
+    const int K = a.K;
+    for (long e = (long)blockIdx.x * kBlock + threadIdx.x; e < a.total; e += (long)gridDim.x * kBlock) {
+        const long b = e / a.L;
+        const int er = (int)(e - b * a.L);
+        const int n = er / a.D, d = er - n * a.D;
+        const long tok = e / a.D;
+        const float m = mask_at(a.mask, a.mr, a.mc, n, d);
+        const float pv = a.pad ? a.pad[tok] : 1.f;
+        const float change = (1.f - m) * (a.pad_in_transform ? pv : 1.f);
+        const float outscale = a.pad_output ? pv : 1.f;
+        const double gzo = (double)((a.g_zout ? a.g_zout[e] : 0.f) * outscale);
+        if (change == 0.f) {                    // copied through: z' = z * outscale, no parameter dependence
+            a.g_z[e] = (float)gzo;
+            continue;
+        }
+        const double gl = a.g_ldj ? (double)a.g_ldj[b] : 0.0;
+        const float* row = a.nn + (size_t)e * a.P;
+        float* grow = a.g_nn + (size_t)e * a.P;
+        const float* sf_d = a.sf ? a.sf + d : nullptr;
+        const double x = (double)a.z[e];
+        const double t = (double)row[0];
+        const double log_s = (double)bound_f(row[1], sf_d);
+        // pass 1: softmax normaliser and the mixture sums
+        double mx = -INFINITY;
+        for (int k = 0; k < K; ++k) mx = fmax(mx, (double)row[2 + k]);
+        double se = 0.0, cdf = 0.0, pdf = 0.0, dpdf = 0.0;
+        for (int k = 0; k < K; ++k) {
+            const double w = exp((double)row[2 + k] - mx);
+            const double ls = (double)bound_f(row[2 + 2 * K + k], a.msf ? a.msf + (size_t)d * K + k : nullptr);
+            const double inv_s = exp(-ls);
+            const double zk = (x - (double)row[2 + K + k]) * inv_s;
+            const double ee = exp(-fabs(zk));
+            const double r = 1.0 / (1.0 + ee);
+            const double sig = zk >= 0.0 ? r : ee * r;
+            const double pk = ee * r * r * inv_s;                // sigma (1 - sigma) / s
+            se += w;
+            cdf += w * sig;
+            pdf += w * pk;
+            dpdf += w * pk * (1.0 - 2.0 * sig) * inv_s;           // d p_k / d x
+        }
+        const double u = cdf / se;
+        const double pdf_n = pdf / se;
+        const double a_s = exp(log_s);
+        const double uc = fmax(u, 1e-22), u1c = fmax(1.0 - u, 1e-22);
+        const double lu = log(uc), l1u = log(u1c);
+        const double dlu = u > 1e-22 ? 1.0 / u : 0.0;               // d safe_log(u) / du
+        const double dl1u = (1.0 - u) > 1e-22 ? -1.0 / (1.0 - u) : 0.0;   // d safe_log(1-u) / du
+        const double zt = ((lu - l1u) + t) * a_s;
+        double g_u = gzo * a_s * (dlu - dl1u) + gl * (-dlu - dl1u);
+        if (a.use_reg) {
+            const double r1 = lu / kLn10b, r2 = l1u / kLn10b;
+            double dreg = 0.0;
+            if (r1 <= -a.reg_max) dreg += dlu / kLn10b;
+            if (r2 <= -a.reg_max) dreg += dl1u / kLn10b;
+            g_u += gl * a.reg_factor * dreg;
+        }
+        const double inv_pdf = pdf_n > 1e-290 ? 1.0 / pdf_n : 0.0;
+        a.g_z[e] = (float)(g_u * pdf_n + gl * (dpdf / se) * inv_pdf);
+        // t and log_s
+        grow[0] = (float)(gzo * a_s);
+        {
+            const double g_logs = gzo * zt + gl;
+            double d_raw, d_sf;
+            bound_grads(row[1], sf_d, d_raw, d_sf);
+            grow[1] = (float)(g_logs * d_raw);
+            if (sf_d) atomicAdd(&acc[d], (float)(g_logs * d_sf));
+        }
+        // pass 2: per-mixture parameter gradients
+        for (int k = 0; k < K; ++k) {
+            const double pi = exp((double)row[2 + k] - mx) / se;
+            const float* msf_k = a.msf ? a.msf + (size_t)d * K + k : nullptr;
+            const double ls = (double)bound_f(row[2 + 2 * K + k], msf_k);
+            const double inv_s = exp(-ls);
+            const double zk = (x - (double)row[2 + K + k]) * inv_s;
+            const double ee = exp(-fabs(zk));
+            const double r = 1.0 / (1.0 + ee);
+            const double sig = zk >= 0.0 ? r : ee * r;
+            const double s1s = ee * r * r;                         // sigma (1 - sigma)
+            const double pk = s1s * inv_s;
+            const double resp = pi * pk * inv_pdf;                 // pi_k p_k / pdf
+            // logits
+            grow[2 + k] = (float)(g_u * pi * (sig - u) + gl * (resp - pi));
+            // mean
+            grow[2 + K + k] = (float)(g_u * (-pi * pk) + gl * (-resp * (1.0 - 2.0 * sig) * inv_s));
+            // log-scale (through its tanh bound)
+            const double g_ls = g_u * (-pi * zk * s1s) + gl * (resp * (-1.0 - zk * (1.0 - 2.0 * sig)));
+            double d_raw, d_sf;
+            bound_grads(row[2 + 2 * K + k], msf_k, d_raw, d_sf);
+            grow[2 + 2 * K + k] = (float)(g_ls * d_raw);
+            if (msf_k) atomicAdd(&acc[a.D + d * K + k], (float)(g_ls * d_sf));
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < PP; i += kBlock) a.partials[(size_t)blockIdx.x * PP + i] = acc[i];
+}
+
+__global__ __launch_bounds__(kBlock) void mix_reduce_partials_kernel(const float* partials, int nrows, int P, float* out) {
+    const int p = blockIdx.x;
+    double accd = 0.0;
+    for (int r = threadIdx.x; r < nrows; r += kBlock) accd += (double)partials[(size_t)r * P + p];
+    __shared__ double sh[kWavesPerBlock];
+    accd = wave_sum(accd);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = accd;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < kWavesPerBlock; ++w) t += sh[w];
+        out[p] = (float)t;
+    }
+}
+
+}  // namespace cnf
+
+using namespace cnf;
+
+extern "C" {
+
+int cnf_mixture_coupling_bwd(const float* z, const float* nn_out,
+                             const float* scaling_factor, const float* mixture_scaling_factor,
+                             const float* mask, int mask_rows, int mask_cols,
+                             const float* pad, int pad_in_transform, int pad_output,
+                             const float* g_zout, const float* g_ldj,
+                             float* g_z, float* g_nn, float* g_scaling_factor, float* g_mixture_scaling_factor,
+                             float* workspace,
+                             int B, int N, int D, int K, double reg_max, double reg_factor, int is_training,
+                             cnf_stream_t stream) {
+    CNF_REQUIRE(z && nn_out && g_z && g_nn && workspace, "cnf_mixture_coupling_bwd: null tensor");
+    CNF_REQUIRE(B > 0 && N > 0 && D > 0 && K > 0, "cnf_mixture_coupling_bwd: bad shape");
+    CNF_REQUIRE(D + D * K <= kMixBwdMaxP, "cnf_mixture_coupling_bwd: D*(K+1)=%d exceeds %d", D + D * K, kMixBwdMaxP);
+    CNF_REQUIRE(!scaling_factor || g_scaling_factor, "cnf_mixture_coupling_bwd: g_scaling_factor missing");
+    CNF_REQUIRE(!mixture_scaling_factor || g_mixture_scaling_factor, "cnf_mixture_coupling_bwd: g_mixture_scaling_factor missing");
+    if (!mask) { mask_rows = 1; mask_cols = D; }
+    if (mask_rows > N) mask_rows = N;
+    hipStream_t st = (hipStream_t)stream;
+    MixBwdArgs a = {};
+    a.z = z; a.nn = nn_out; a.sf = scaling_factor; a.msf = mixture_scaling_factor; a.mask = mask; a.pad = pad;
+    a.g_zout = g_zout; a.g_ldj = g_ldj; a.g_z = g_z; a.g_nn = g_nn; a.partials = workspace;
+    a.total = (long)B * N * D; a.N = N; a.D = D; a.K = K; a.P = 2 + 3 * K; a.L = N * D; a.mr = mask_rows; a.mc = mask_cols;
+    a.pad_in_transform = pad ? pad_in_transform : 0;
+    a.pad_output = pad ? pad_output : 0;
+    a.use_reg = (reg_max > 0 && is_training) ? 1 : 0;
+    a.reg_max = reg_max; a.reg_factor = reg_factor;
+    // parameters of untransformed elements get no gradient
+    hipMemsetAsync(g_nn, 0, sizeof(float) * (size_t)a.total * a.P, st);
+    const int grid = (int)std::min<long>(std::max<long>((a.total + kBlock - 1) / kBlock, 1), kMixBwdGrid);
+    hipLaunchKernelGGL(mixture_fwd_bwd_kernel, dim3(grid), dim3(kBlock), 0, st, a);
+    const int PP = D + D * K;
+    float* red = workspace + (size_t)kMixBwdGrid * PP;
+    hipLaunchKernelGGL(mix_reduce_partials_kernel, dim3(PP), dim3(kBlock), 0, st, workspace, grid, PP, red);
+    if (scaling_factor) hipMemcpyAsync(g_scaling_factor, red, sizeof(float) * D, hipMemcpyDeviceToDevice, st);
+    if (mixture_scaling_factor) hipMemcpyAsync(g_mixture_scaling_factor, red + D, sizeof(float) * D * K, hipMemcpyDeviceToDevice, st);
+    return launch_status("cnf_mixture_coupling_bwd");
+}
+
+}  // extern "C"

@@ -9,8 +9,8 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from .. import functional as Fn
 from .. import ops
-from ..host_utils import forbid_grad
 from ..layers.flows.flow_layer import FlowLayer
 
 
@@ -41,16 +41,21 @@ class NodeEdgeCoupling(FlowLayer):
         nn_nodes, nn_edges = self.nn(z_nodes=mask_nodes * z_nodes, z_edges=mask_edges * z_edges, length=length,
                                      channel_padding_mask=channel_padding_mask, x_indices=x_indices,
                                      mask_valid=mask_valid, binary_adjacency=binary_adjacency)
-        forbid_grad("NodeEdgeCoupling", z_nodes, z_edges, nn_nodes, nn_edges)
-        common = dict(reverse=reverse, reg_max=self.regularizer_max, reg_factor=self.regularizer_factor,
-                      is_training=self.training)
         # padded nodes / invalid edges are never transformed, so the reference's `nn_out * mask` (:65,:78) is moot
-        zn, ldj_n, reg_n = ops.mixture_coupling(z_nodes, nn_nodes, mask_nodes, self.num_mixtures_nodes,
-                                                self.scaling_factor_nodes, self.mixture_scaling_factor_nodes,
-                                                channel_padding_mask=channel_padding_mask, **common)
-        ze, ldj_e, reg_e = ops.mixture_coupling(z_edges, nn_edges, mask_edges, self.num_mixtures_edges,
-                                                self.scaling_factor_edges, self.mixture_scaling_factor_edges,
-                                                channel_padding_mask=mask_valid.unsqueeze(dim=-1), **common)
+        def run(z, nn_out, mask, K, sf, msf, pad):
+            if Fn.needs_grad(z, nn_out, sf, msf):
+                if reverse:
+                    raise NotImplementedError("the mixture-CDF inverse is not differentiable; use torch.no_grad()")
+                return Fn.MixtureCouplingFn.apply(z, nn_out, sf, msf, None, mask, pad, K, self.regularizer_max,
+                                                  self.regularizer_factor, self.training, True, True)
+            return ops.mixture_coupling(z, nn_out, mask, K, sf, msf, reverse=reverse, channel_padding_mask=pad,
+                                        reg_max=self.regularizer_max, reg_factor=self.regularizer_factor,
+                                        is_training=self.training)
+
+        zn, ldj_n, reg_n = run(z_nodes, nn_nodes, mask_nodes, self.num_mixtures_nodes, self.scaling_factor_nodes,
+                               self.mixture_scaling_factor_nodes, channel_padding_mask)
+        ze, ldj_e, reg_e = run(z_edges, nn_edges, mask_edges, self.num_mixtures_edges, self.scaling_factor_edges,
+                               self.mixture_scaling_factor_edges, mask_valid.unsqueeze(dim=-1))
         ldj = ldj + ldj_n + ldj_e
         detail = {"ldj": ldj}
         if not reverse:

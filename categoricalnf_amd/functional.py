@@ -206,5 +206,78 @@ class SigmoidFlowFn(torch.autograd.Function):
         return g_z, (g_ldj if ctx.has_ldj else None), None, None
 
 
+class MixtureCouplingFn(torch.autograd.Function):
+    """(z, nn_out, scaling_factor, mixture_scaling_factor, ldj) -> (z', ldj + layer_ldj, reg_sum); forward direction only."""
+
+    @staticmethod
+    def forward(ctx, z, nn_out, sf, msf, ldj, mask, pad, K, reg_max, reg_factor, is_training, pad_in_transform, pad_output):
+        z_out, ldj_out, reg = ops.mixture_coupling(z, nn_out, mask, K, sf, msf, reverse=False, channel_padding_mask=pad,
+                                                   reg_max=reg_max, reg_factor=reg_factor, is_training=is_training,
+                                                   pad_in_transform=pad_in_transform, pad_output=pad_output, ldj=ldj)
+        empty = z_out.new_empty(0)
+        ctx.save_for_backward(z, nn_out, sf if sf is not None else empty, msf if msf is not None else empty,
+                              mask if mask is not None else empty, pad if isinstance(pad, torch.Tensor) else empty)
+        ctx.flags = (sf is not None, msf is not None, mask is not None, isinstance(pad, torch.Tensor), ldj is not None)
+        ctx.cfg = (int(K), float(reg_max), float(reg_factor), bool(is_training), bool(pad_in_transform), bool(pad_output))
+        ctx.mark_non_differentiable(reg)
+        return z_out, ldj_out, reg
+
+    @staticmethod
+    def backward(ctx, g_zout, g_ldj, _g_reg):
+        z, nn_out, sf, msf, mask, pad = ctx.saved_tensors
+        has_sf, has_msf, has_mask, has_pad, has_ldj = ctx.flags
+        K, reg_max, reg_factor, is_training, pit, pout = ctx.cfg
+        dev = z.device
+        B, N, D = z.shape
+        zc, nn_c = _f32(z, "z"), _f32(nn_out, "nn_out")
+        sfc = _opt_f32(sf, "scaling_factor", dev) if has_sf else None
+        msfc = _opt_f32(msf, "mixture_scaling_factor", dev) if has_msf else None
+        m, mr, mc = _mask_desc(mask if has_mask else None, D, dev)
+        p2 = _pad2d(pad, B, N, dev) if has_pad else None
+        g_z, g_nn = torch.empty_like(zc), torch.empty_like(nn_c)
+        g_sf = torch.empty(D, dtype=torch.float32, device=dev) if has_sf else None
+        g_msf = torch.empty(D, K, dtype=torch.float32, device=dev) if has_msf else None
+        ws = _ws(D + D * K, dev)
+        lib = _lib.load()
+        _lib.check(lib.cnf_mixture_coupling_bwd(_ptr(zc), _ptr(nn_c), _ptr(sfc), _ptr(msfc), _ptr(m), mr, mc, _ptr(p2), int(pit), int(pout),
+                                                _ptr(_g(g_zout)), _ptr(_g(g_ldj)), _ptr(g_z), _ptr(g_nn), _ptr(g_sf), _ptr(g_msf), _ptr(ws),
+                                                B, N, D, K, reg_max, reg_factor, int(is_training), _stream(dev)),
+                   "cnf_mixture_coupling_bwd")
+        return (g_z, g_nn.view_as(nn_out), (g_sf.view_as(sf) if has_sf else None), (g_msf.view_as(msf) if has_msf else None),
+                (g_ldj if has_ldj else None), None, None, None, None, None, None, None, None)
+
+
+class EncoderForwardFn(torch.autograd.Function):
+    """class table [C,2D] -> (z, ldj, class_prob_log); categories, noise, prior and padding are constants."""
+
+    @staticmethod
+    def forward(ctx, table, categ, eps, prior, pad, beta, want_class_prob):
+        z, ldj, cpl = ops.encoder_forward(categ, eps, table, prior, beta=beta, channel_padding_mask=pad,
+                                          want_class_prob=want_class_prob)
+        ctx.save_for_backward(table, categ, eps, prior, pad if isinstance(pad, torch.Tensor) else z.new_empty(0))
+        ctx.has_pad, ctx.beta = isinstance(pad, torch.Tensor), float(beta)
+        if cpl is None:
+            cpl = z.new_empty(0)
+        ctx.mark_non_differentiable(cpl)
+        return z, ldj, cpl
+
+    @staticmethod
+    def backward(ctx, g_zout, g_ldj, _g_cpl):
+        table, categ, eps, prior, pad = ctx.saved_tensors
+        dev = table.device
+        B, N = categ.shape
+        C, D = table.shape[0], table.shape[1] // 2
+        tc, ec, pc = _f32(table, "table"), _f32(eps, "eps"), _f32(prior, "category_prior")
+        p2 = _pad2d(pad, B, N, dev) if ctx.has_pad else None
+        g_table = torch.empty_like(tc)
+        ws = _ws(C * 2 * D, dev)
+        lib = _lib.load()
+        _lib.check(lib.cnf_encoder_forward_bwd(_ptr(categ.contiguous()), _ptr(ec), _ptr(tc), _ptr(pc), _ptr(p2), ctx.beta,
+                                               _ptr(_g(g_zout)), _ptr(_g(g_ldj)), _ptr(g_table), _ptr(ws), B, N, D, C,
+                                               float(ops.LOGISTIC_SIGMA), float(ops.LOGISTIC_LOG_SIGMA), _stream(dev)),
+                   "cnf_encoder_forward_bwd")
+        return g_table, None, None, None, None, None, None
+
+
 def needs_grad(*tensors):
     return torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors)

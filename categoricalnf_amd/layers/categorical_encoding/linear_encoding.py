@@ -15,8 +15,9 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ... import functional as Fn
 from ... import ops
-from ...host_utils import forbid_grad, get_param_val, one_hot
+from ...host_utils import get_param_val, one_hot
 from ..flows.activation_normalization import ExtActNormFlow
 from ..flows.coupling_layer import CouplingLayer
 from ..flows.distributions import LogisticDistribution
@@ -76,11 +77,14 @@ class LinearCategoricalEncoding(FlowLayer):
         if not reverse:
             if self._is_mixture_model():
                 table = self.class_table()
-                forbid_grad("LinearCategoricalEncoding", table)
                 eps = self._noise(batch_size * seq_length, z.device, noise)
-                z_out, ldj_loc, cpl = ops.encoder_forward(z, eps, table, self.category_prior, beta=float(beta),
-                                                          channel_padding_mask=channel_padding_mask,
-                                                          want_class_prob=self.training)
+                if Fn.needs_grad(table):
+                    z_out, ldj_loc, cpl = Fn.EncoderForwardFn.apply(table, z, eps, self.category_prior, channel_padding_mask,
+                                                                    float(beta), self.training)
+                else:
+                    z_out, ldj_loc, cpl = ops.encoder_forward(z, eps, table, self.category_prior, beta=float(beta),
+                                                              channel_padding_mask=channel_padding_mask,
+                                                              want_class_prob=self.training)
                 if self.training:
                     detailed_ldj = self._train_stats(z_out, cpl, channel_padding_mask)
             else:

@@ -4,8 +4,8 @@ Interface of layers/flows/autoregressive_coupling.py:9-47 (forward only; reverse
 import torch
 import torch.nn as nn
 
+from ... import functional as Fn
 from ... import ops
-from ...host_utils import forbid_grad
 from .flow_layer import FlowLayer
 
 
@@ -24,7 +24,11 @@ class AutoregressiveMixtureCDFCoupling(FlowLayer):
         if reverse:
             raise NotImplementedError
         nn_out = self.nn(x=z, **kwargs)
-        forbid_grad("AutoregressiveMixtureCDFCoupling", z, nn_out, self.scaling_factor, self.mixture_scaling_factor)
+        if Fn.needs_grad(z, nn_out, self.scaling_factor, self.mixture_scaling_factor, ldj):
+            z_out, ldj_out, _ = Fn.MixtureCouplingFn.apply(
+                z, nn_out, self.scaling_factor, self.mixture_scaling_factor, ldj, None, kwargs.get("channel_padding_mask", None),
+                self.num_mixtures, -1, 1, self.training, False, True)
+            return z_out, ldj_out
         # no mask and no padding inside the transform; the output is multiplied by the padding mask
         # afterwards (autoregressive_coupling.py:38-45)
         z_out, ldj_out, _ = ops.mixture_coupling(

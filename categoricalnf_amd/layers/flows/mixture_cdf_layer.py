@@ -6,6 +6,7 @@ Interface of layers/flows/mixture_cdf_layer.py: constructor (:13-42), forward (:
 import torch
 import torch.nn as nn
 
+from ... import functional as Fn
 from ... import ops
 from ...host_utils import forbid_grad
 from .coupling_layer import CouplingLayer
@@ -24,8 +25,15 @@ class MixtureCDFCoupling(CouplingLayer):
 
     def forward(self, z, ldj=None, reverse=False, channel_padding_mask=None, **kwargs):
         nn_out = self.run_network(x=z * self._prepare_mask(self.mask, z), **kwargs)
-        forbid_grad("MixtureCDFCoupling", z, nn_out, self.scaling_factor, self.mixture_scaling_factor)
         # the incoming ldj is ignored on purpose: the reference overwrites it (:63) and the caller sums
+        if Fn.needs_grad(z, nn_out, self.scaling_factor, self.mixture_scaling_factor):
+            if reverse:
+                raise NotImplementedError("the mixture-CDF inverse is not differentiable (the reference never differentiates "
+                                          "its bisection either); run it under torch.no_grad()")
+            z_out, layer_ldj, reg = Fn.MixtureCouplingFn.apply(
+                z, nn_out, self.scaling_factor, self.mixture_scaling_factor, None, self.mask, channel_padding_mask,
+                self.num_mixtures, self.regularizer_max, self.regularizer_factor, self.training, True, True)
+            return z_out, layer_ldj, {"ldj": layer_ldj, "regularizer_ldj": reg}
         z_out, layer_ldj, reg = ops.mixture_coupling(
             z, nn_out, self.mask, self.num_mixtures, self.scaling_factor, self.mixture_scaling_factor,
             reverse=reverse, channel_padding_mask=channel_padding_mask, reg_max=self.regularizer_max,

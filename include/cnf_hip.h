@@ -244,6 +244,27 @@ int cnf_logistic_log_prob_bwd(const float* x, const float* g_logp, float* g_x, i
 int cnf_prior_nll_bwd(const float* z, const float* pad, const float* length, const float* g_nll,
                       float* g_z, float* g_ldj, int B, int N, int D, float sigma, cnf_stream_t stream);
 
+/* d(MixtureCDFCoupling.forward, reverse=False) (mixture_cdf_layer.py:45-123,145-180): g_z, g_nn (same layout as
+ * nn_out; zero for untransformed elements), g_scaling_factor [D], g_mixture_scaling_factor [D,K] (each only if the
+ * parameter is given); workspace = cnf_bwd_workspace_floats(D + D*K).  The inverse has no backward (the reference
+ * never differentiates it). */
+int cnf_mixture_coupling_bwd(const float* z, const float* nn_out,
+                             const float* scaling_factor, const float* mixture_scaling_factor,
+                             const float* mask, int mask_rows, int mask_cols,
+                             const float* pad, int pad_in_transform, int pad_output,
+                             const float* g_zout, const float* g_ldj,
+                             float* g_z, float* g_nn, float* g_scaling_factor, float* g_mixture_scaling_factor,
+                             float* workspace,
+                             int B, int N, int D, int K, double reg_max, double reg_factor, int is_training,
+                             cnf_stream_t stream);
+
+/* d(LinearCategoricalEncoding.forward, num_flows == 0) w.r.t. the class table [C,2D] (linear_encoding.py:59-106,
+ * 153-174): g_table [C,2D]; workspace = cnf_bwd_workspace_floats(C*2D).  eps / categories / prior are constants. */
+int cnf_encoder_forward_bwd(const int64_t* categ, const float* eps, const float* table,
+                            const float* category_prior, const float* pad, float beta,
+                            const float* g_zout, const float* g_ldj, float* g_table, float* workspace,
+                            int B, int N, int D, int C, float sigma, float log_sigma, cnf_stream_t stream);
+
 /* d(SigmoidFlow.forward) w.r.t. its input (sigmoid_layer.py:31-37). */
 int cnf_sigmoid_flow_bwd(const float* z_in, const float* g_zout, const float* g_ldj, float* g_z,
                          int B, int L, int reverse, float alpha, cnf_stream_t stream);
