@@ -52,6 +52,11 @@ SIGNATURES = {
     "cnf_mixture_coupling_bwd": [_p, _p, _p, _p, _p, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p,
                                  _i, _i, _i, _i, _d, _d, _i, _p],
     "cnf_encoder_forward_bwd": [_p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
+    "cnf_affine_params_bwd": [_p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _i, _i, _i, _p],
+    "cnf_affine_transform_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "cnf_mixture_transform_bwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p,
+                                  _i, _i, _i, _i, _d, _d, _i, _p],
+    "cnf_mixture_params_bwd": [_p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
 }
 _PLAIN = {"cnf_abi_version": ([], _i), "cnf_last_error": ([], ctypes.c_char_p),
           "cnf_set_tile_chunks": ([_i], None), "cnf_set_unroll": ([_i], None),

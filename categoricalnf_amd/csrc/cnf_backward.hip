@@ -307,6 +307,54 @@ __global__ __launch_bounds__(kBlock) void sigmoid_flow_bwd_kernel(const float* z
     }
 }
 
+// ---- static-API split forms of the affine coupling (coupling_layer.py:76-98) ---------------------------------
+__global__ __launch_bounds__(kBlock) void affine_params_bwd_kernel(const float* nn, const float* sf, const float* mask,
+                                                                   int mr, int mc, const float* g_s, const float* g_t,
+                                                                   float* g_nn, float* partials, long total, int N, int D) {
+    __shared__ float gsf[kBwdMaxP];
+    for (int i = threadIdx.x; i < D; i += kBlock) gsf[i] = 0.f;
+    __syncthreads();
+    for (long e = (long)blockIdx.x * kBlock + threadIdx.x; e < total; e += (long)gridDim.x * kBlock) {
+        const int d = (int)(e % D);
+        const int n = (int)((e / D) % N);
+        const float keep = 1.f - mask_at(mask, mr, mc, n, d);
+        const float gs = (g_s ? g_s[e] : 0.f) * keep;
+        const float gt = (g_t ? g_t[e] : 0.f) * keep;
+        float g_sr = gs;
+        if (sf) {
+            const float f = expf(sf[d]);
+            const float fc = fmaxf(f, 1.f);
+            const float u = nn[2 * e] / fc;
+            const float th = tanhf(u);
+            const float sech2 = 1.f - th * th;
+            g_sr = gs * f * sech2 / fc;
+            if (gs != 0.f) atomicAdd(&gsf[d], gs * ((f >= 1.f) ? f * (th - u * sech2) : f * th));
+        }
+        *reinterpret_cast<float2*>(g_nn + 2 * e) = make_float2(g_sr, gt);
+    }
+    if (sf) flush_partials(gsf, D, partials);
+}
+
+__global__ __launch_bounds__(kBlock) void affine_transform_bwd_kernel(const float* z_out, const float* s, const float* t,
+                                                                      const float* g_zout, const float* g_ldj,
+                                                                      float* g_z, float* g_s, float* g_t, long total,
+                                                                      int L, int reverse) {
+    for (long e = (long)blockIdx.x * kBlock + threadIdx.x; e < total; e += (long)gridDim.x * kBlock) {
+        const float gzo = g_zout ? g_zout[e] : 0.f;
+        const float gl = g_ldj ? g_ldj[e / L] : 0.f;
+        if (!reverse) {
+            const float gz = gzo * expf(s[e]);
+            g_z[e] = gz;
+            g_t[e] = gz;
+            g_s[e] = gzo * z_out[e] + gl;
+        } else {
+            g_z[e] = gzo * expf(-s[e]);
+            g_t[e] = -gzo;
+            g_s[e] = -gzo * (z_out[e] + t[e]) - gl;
+        }
+    }
+}
+
 static inline int bwd_grid(long n) {
     return (int)std::min<long>(std::max<long>((n + kBlock - 1) / kBlock, 1), kBwdGrid);
 }
@@ -343,6 +391,31 @@ int cnf_affine_coupling_bwd(const float* z_out, const float* nn_out, const float
     hipLaunchKernelGGL(affine_bwd_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a);
     if (scaling_factor) reduce_partials(workspace, grid, D, g_scaling_factor, (hipStream_t)stream);
     return launch_status("cnf_affine_coupling_bwd");
+}
+
+int cnf_affine_params_bwd(const float* nn_out, const float* scaling_factor, const float* mask, int mask_rows, int mask_cols,
+                          const float* g_s, const float* g_t, float* g_nn, float* g_scaling_factor, float* workspace,
+                          int B, int N, int D, cnf_stream_t stream) {
+    CNF_REQUIRE(nn_out && g_nn, "cnf_affine_params_bwd: null tensor");
+    CNF_REQUIRE(B > 0 && N > 0 && D > 0 && D <= kBwdMaxP, "cnf_affine_params_bwd: bad shape");
+    CNF_REQUIRE(!scaling_factor || (g_scaling_factor && workspace), "cnf_affine_params_bwd: scaling_factor needs g_scaling_factor and workspace");
+    if (mask && mask_rows > N) mask_rows = N;
+    const long total = (long)B * N * D;
+    const int grid = bwd_grid(total);
+    hipLaunchKernelGGL(affine_params_bwd_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, nn_out, scaling_factor, mask,
+                       mask_rows, mask_cols, g_s, g_t, g_nn, workspace, total, N, D);
+    if (scaling_factor) reduce_partials(workspace, grid, D, g_scaling_factor, (hipStream_t)stream);
+    return launch_status("cnf_affine_params_bwd");
+}
+
+int cnf_affine_transform_bwd(const float* z_out, const float* s, const float* t, const float* g_zout, const float* g_ldj,
+                             float* g_z, float* g_s, float* g_t, int B, int N, int D, int reverse, cnf_stream_t stream) {
+    CNF_REQUIRE(z_out && s && t && g_z && g_s && g_t, "cnf_affine_transform_bwd: null tensor");
+    CNF_REQUIRE(B > 0 && N > 0 && D > 0, "cnf_affine_transform_bwd: bad shape");
+    const long total = (long)B * N * D;
+    hipLaunchKernelGGL(affine_transform_bwd_kernel, dim3(bwd_grid(total)), dim3(kBlock), 0, (hipStream_t)stream, z_out, s, t,
+                       g_zout, g_ldj, g_z, g_s, g_t, total, N * D, reverse);
+    return launch_status("cnf_affine_transform_bwd");
 }
 
 int cnf_ext_actnorm_bwd(const float* z_out, const float* nn_out, const float* pad,

@@ -279,5 +279,136 @@ class EncoderForwardFn(torch.autograd.Function):
         return g_table, None, None, None, None, None, None
 
 
+class AffineParamsFn(torch.autograd.Function):
+    """CouplingLayer.get_coup_params: (nn_out, scaling_factor) -> (s, t)."""
+
+    @staticmethod
+    def forward(ctx, nn_out, sf, mask):
+        s, t = ops.affine_params(nn_out, mask, sf)
+        empty = s.new_empty(0)
+        ctx.save_for_backward(nn_out, sf if sf is not None else empty, mask if mask is not None else empty)
+        ctx.flags = (sf is not None, mask is not None)
+        return s, t
+
+    @staticmethod
+    def backward(ctx, g_s, g_t):
+        nn_out, sf, mask = ctx.saved_tensors
+        has_sf, has_mask = ctx.flags
+        dev = nn_out.device
+        nn_c = _f32(nn_out, "nn_out")
+        B, N = nn_c.shape[0], nn_c.shape[1]
+        D = nn_c.shape[-1] // 2
+        sfc = _opt_f32(sf, "scaling_factor", dev) if has_sf else None
+        m, mr, mc = _mask_desc(mask if has_mask else None, D, dev)
+        g_nn = torch.empty_like(nn_c)
+        g_sf = torch.empty(D, dtype=torch.float32, device=dev) if has_sf else None
+        ws = _ws(D, dev) if has_sf else None
+        lib = _lib.load()
+        _lib.check(lib.cnf_affine_params_bwd(_ptr(nn_c), _ptr(sfc), _ptr(m), mr, mc, _ptr(_g(g_s)), _ptr(_g(g_t)), _ptr(g_nn),
+                                             _ptr(g_sf), _ptr(ws), B, N, D, _stream(dev)), "cnf_affine_params_bwd")
+        return g_nn.view_as(nn_out), (g_sf.view_as(sf) if has_sf else None), None
+
+
+class AffineTransformFn(torch.autograd.Function):
+    """CouplingLayer.run_with_params: (z, s, t) -> (z', ldj)."""
+
+    @staticmethod
+    def forward(ctx, z, s, t, reverse):
+        z_out, ldj = ops.affine_transform(z, s, t, reverse=reverse)
+        ctx.save_for_backward(z_out, s.expand_as(z).contiguous(), t.expand_as(z).contiguous())
+        ctx.reverse, ctx.shapes = bool(reverse), (s.shape, t.shape)
+        return z_out, ldj
+
+    @staticmethod
+    def backward(ctx, g_zout, g_ldj):
+        z_out, s, t = ctx.saved_tensors
+        dev = z_out.device
+        B, N, D = z_out.shape
+        g_z, g_s, g_t = torch.empty_like(z_out), torch.empty_like(z_out), torch.empty_like(z_out)
+        lib = _lib.load()
+        _lib.check(lib.cnf_affine_transform_bwd(_ptr(z_out), _ptr(s), _ptr(t), _ptr(_g(g_zout)), _ptr(_g(g_ldj)), _ptr(g_z),
+                                                _ptr(g_s), _ptr(g_t), B, N, D, int(ctx.reverse), _stream(dev)),
+                   "cnf_affine_transform_bwd")
+        return g_z, g_s.sum_to_size(ctx.shapes[0]), g_t.sum_to_size(ctx.shapes[1]), None
+
+
+class MixtureParamsFn(torch.autograd.Function):
+    """MixtureCDFCoupling.get_mixt_params: (nn_out, scaling_factor, mixture_scaling_factor) -> five fp64 tensors."""
+
+    @staticmethod
+    def forward(ctx, nn_out, sf, msf, mask, K):
+        out = ops.mixture_params(nn_out, mask, K, sf, msf)
+        empty = nn_out.new_empty(0)
+        ctx.save_for_backward(nn_out, sf if sf is not None else empty, msf if msf is not None else empty,
+                              mask if mask is not None else empty)
+        ctx.flags, ctx.K = (sf is not None, msf is not None, mask is not None), int(K)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_t, g_log_s, g_log_pi, g_mu, g_ls):
+        nn_out, sf, msf, mask = ctx.saved_tensors
+        has_sf, has_msf, has_mask = ctx.flags
+        K = ctx.K
+        dev = nn_out.device
+        nn_c = _f32(nn_out, "nn_out")
+        P = 2 + 3 * K
+        D = nn_c.shape[-1] // P
+        B = nn_c.shape[0]
+        N = nn_c.numel() // (B * D * P)
+        sfc = _opt_f32(sf, "scaling_factor", dev) if has_sf else None
+        msfc = _opt_f32(msf, "mixture_scaling_factor", dev) if has_msf else None
+        m, mr, mc = _mask_desc(mask if has_mask else None, D, dev)
+        g_nn = torch.empty_like(nn_c)
+        g_sf = torch.empty(D, dtype=torch.float32, device=dev) if has_sf else None
+        g_msf = torch.empty(D, K, dtype=torch.float32, device=dev) if has_msf else None
+        ws = _ws(D + D * K, dev)
+        dd = lambda t: None if t is None else (t.double().contiguous())
+        gs = [dd(x) for x in (g_t, g_log_s, g_log_pi, g_mu, g_ls)]
+        lib = _lib.load()
+        _lib.check(lib.cnf_mixture_params_bwd(_ptr(nn_c), _ptr(sfc), _ptr(msfc), _ptr(m), mr, mc, *[_ptr(x) for x in gs], _ptr(g_nn),
+                                              _ptr(g_sf), _ptr(g_msf), _ptr(ws), B, N, D, K, _stream(dev)), "cnf_mixture_params_bwd")
+        return g_nn.view_as(nn_out), (g_sf.view_as(sf) if has_sf else None), (g_msf.view_as(msf) if has_msf else None), None, None
+
+
+class MixtureTransformFn(torch.autograd.Function):
+    """MixtureCDFCoupling.run_with_params (forward direction) on fp64 split parameters."""
+
+    @staticmethod
+    def forward(ctx, z, t, log_s, log_pi, mu, ls, mask, pad, reg_max, reg_factor, is_training):
+        z_out, ldj, reg = ops.mixture_transform(z, t, log_s, log_pi, mu, ls, reverse=False, reg_max=reg_max, reg_factor=reg_factor,
+                                                mask=mask, channel_padding_mask=pad, is_training=is_training)
+        empty = z_out.new_empty(0)
+        ctx.save_for_backward(z, t, log_s, log_pi, mu, ls, mask if mask is not None else empty,
+                              pad if isinstance(pad, torch.Tensor) else empty)
+        ctx.flags = (mask is not None, isinstance(pad, torch.Tensor))
+        ctx.cfg = (float(reg_max), float(reg_factor), bool(is_training))
+        ctx.mark_non_differentiable(reg)
+        return z_out, ldj, reg
+
+    @staticmethod
+    def backward(ctx, g_zout, g_ldj, _g_reg):
+        z, t, log_s, log_pi, mu, ls, mask, pad = ctx.saved_tensors
+        has_mask, has_pad = ctx.flags
+        reg_max, reg_factor, is_training = ctx.cfg
+        z64 = ops._f64(z, "orig_z")
+        dev = z64.device
+        B, N, D = z64.shape
+        K = log_pi.shape[-1]
+        kshape = tuple(z64.shape) + (K,)
+        t64, s64 = ops._f64(t, "t", z64.shape), ops._f64(log_s, "log_s", z64.shape)
+        pi64, mu64, ls64 = ops._f64(log_pi, "log_pi", kshape), ops._f64(mu, "mixt_t", kshape), ops._f64(ls, "mixt_log_s", kshape)
+        m, mr, mc = _mask_desc(mask if has_mask else None, D, dev)
+        p2 = _pad2d(pad, B, N, dev) if has_pad else None
+        g_z, g_t, g_s = torch.empty_like(z64), torch.empty_like(z64), torch.empty_like(z64)
+        g_pi, g_mu, g_ls = torch.empty_like(pi64), torch.empty_like(pi64), torch.empty_like(pi64)
+        dd = lambda x: None if x is None else x.double().contiguous()
+        lib = _lib.load()
+        _lib.check(lib.cnf_mixture_transform_bwd(_ptr(z64), _ptr(t64), _ptr(s64), _ptr(pi64), _ptr(mu64), _ptr(ls64), _ptr(m), mr, mc, _ptr(p2),
+                                                 _ptr(dd(g_zout)), _ptr(dd(g_ldj)), _ptr(g_z), _ptr(g_t), _ptr(g_s), _ptr(g_pi), _ptr(g_mu), _ptr(g_ls),
+                                                 B, N, D, K, reg_max, reg_factor, int(is_training), _stream(dev)), "cnf_mixture_transform_bwd")
+        return (g_z.to(z.dtype), g_t.sum_to_size(t.shape), g_s.sum_to_size(log_s.shape), g_pi.sum_to_size(log_pi.shape),
+                g_mu.sum_to_size(mu.shape), g_ls.sum_to_size(ls.shape), None, None, None, None, None)
+
+
 def needs_grad(*tensors):
     return torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors)

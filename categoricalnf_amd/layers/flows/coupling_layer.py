@@ -10,7 +10,6 @@ import torch.nn as nn
 
 from ... import functional as Fn
 from ... import ops
-from ...host_utils import forbid_grad
 from ..networks.help_layers import run_sequential_with_mask
 from .flow_layer import FlowLayer
 
@@ -55,13 +54,15 @@ class CouplingLayer(FlowLayer):
     @staticmethod
     def get_coup_params(nn_out, mask, scaling_factor=None):
         """coupling_layer.py:76-86 — materialised (s, t)."""
-        forbid_grad("CouplingLayer.get_coup_params", nn_out, scaling_factor)
+        if Fn.needs_grad(nn_out, scaling_factor):
+            return Fn.AffineParamsFn.apply(nn_out, scaling_factor, mask)
         return ops.affine_params(nn_out, mask, scaling_factor)
 
     @staticmethod
     def run_with_params(orig_z, s, t, reverse=False):
         """coupling_layer.py:88-98."""
-        forbid_grad("CouplingLayer.run_with_params", orig_z, s, t)
+        if Fn.needs_grad(orig_z, s, t):
+            return Fn.AffineTransformFn.apply(orig_z, s, t, reverse)
         return ops.affine_transform(orig_z, s, t, reverse=reverse)
 
     @staticmethod

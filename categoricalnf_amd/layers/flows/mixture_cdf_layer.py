@@ -8,7 +8,6 @@ import torch.nn as nn
 
 from ... import functional as Fn
 from ... import ops
-from ...host_utils import forbid_grad
 from .coupling_layer import CouplingLayer
 
 
@@ -46,14 +45,20 @@ class MixtureCDFCoupling(CouplingLayer):
     @staticmethod
     def get_mixt_params(nn_out, mask, num_mixtures, scaling_factor=None, mixture_scaling_factor=None):
         """Five fp64 tensors (t, log_s, log_pi, mixt_t, mixt_log_s), tanh-bounded and masked."""
-        forbid_grad("MixtureCDFCoupling.get_mixt_params", nn_out, scaling_factor, mixture_scaling_factor)
+        if Fn.needs_grad(nn_out, scaling_factor, mixture_scaling_factor):
+            return Fn.MixtureParamsFn.apply(nn_out, scaling_factor, mixture_scaling_factor, mask, num_mixtures)
         return ops.mixture_params(nn_out, mask, num_mixtures, scaling_factor, mixture_scaling_factor)
 
     @staticmethod
     def run_with_params(orig_z, t, log_s, log_pi, mixt_t, mixt_log_s, reverse=False,
                         reg_max=-1, reg_factor=1, mask=None, channel_padding_mask=None,
                         is_training=True, return_reg_ldj=False):
-        forbid_grad("MixtureCDFCoupling.run_with_params", orig_z, t, log_s, log_pi, mixt_t, mixt_log_s)
+        if Fn.needs_grad(orig_z, t, log_s, log_pi, mixt_t, mixt_log_s):
+            if reverse:
+                raise NotImplementedError("the mixture-CDF inverse is not differentiable; run it under torch.no_grad()")
+            z_out, ldj, reg = Fn.MixtureTransformFn.apply(orig_z, t, log_s, log_pi, mixt_t, mixt_log_s, mask, channel_padding_mask,
+                                                          reg_max, reg_factor, is_training)
+            return (z_out, ldj, reg) if return_reg_ldj else (z_out, ldj)
         z_out, ldj, reg = ops.mixture_transform(orig_z, t, log_s, log_pi, mixt_t, mixt_log_s, reverse=reverse,
                                                 reg_max=reg_max, reg_factor=reg_factor, mask=mask,
                                                 channel_padding_mask=channel_padding_mask, is_training=is_training)

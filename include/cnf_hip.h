@@ -220,6 +220,14 @@ int cnf_affine_coupling_bwd(const float* z_out, const float* nn_out, const float
                             float* g_z, float* g_nn, float* g_scaling_factor, float* workspace,
                             int B, int N, int D, int reverse, cnf_stream_t stream);
 
+/* d(CouplingLayer.get_coup_params) / d(CouplingLayer.run_with_params), the static split forms
+ * (coupling_layer.py:76-86 / :88-98).  P = D for cnf_affine_params_bwd. */
+int cnf_affine_params_bwd(const float* nn_out, const float* scaling_factor, const float* mask, int mask_rows, int mask_cols,
+                          const float* g_s, const float* g_t, float* g_nn, float* g_scaling_factor, float* workspace,
+                          int B, int N, int D, cnf_stream_t stream);
+int cnf_affine_transform_bwd(const float* z_out, const float* s, const float* t, const float* g_zout, const float* g_ldj,
+                             float* g_z, float* g_s, float* g_t, int B, int N, int D, int reverse, cnf_stream_t stream);
+
 /* d(ExtActNormFlow.forward) w.r.t. z and the predictor output nn_out [B,N,2D] (activation_normalization.py:127-139). */
 int cnf_ext_actnorm_bwd(const float* z_out, const float* nn_out, const float* pad,
                         const float* g_zout, const float* g_ldj, float* g_z, float* g_nn,
@@ -257,6 +265,26 @@ int cnf_mixture_coupling_bwd(const float* z, const float* nn_out,
                              float* workspace,
                              int B, int N, int D, int K, double reg_max, double reg_factor, int is_training,
                              cnf_stream_t stream);
+
+/* d(MixtureCDFCoupling.run_with_params, reverse=False) on fp64 split parameters (static API, :95-123):
+ * fp64 gradients for z and the five parameter tensors (zero where nothing is transformed). */
+int cnf_mixture_transform_bwd(const double* z, const double* t, const double* log_s, const double* log_pi,
+                              const double* mixt_t, const double* mixt_log_s,
+                              const float* mask, int mask_rows, int mask_cols, const float* pad,
+                              const double* g_zout, const double* g_ldj,
+                              double* g_z, double* g_t, double* g_log_s, double* g_log_pi, double* g_mixt_t,
+                              double* g_mixt_log_s,
+                              int B, int N, int D, int K, double reg_max, double reg_factor, int is_training,
+                              cnf_stream_t stream);
+
+/* d(MixtureCDFCoupling.get_mixt_params) (:145-180): five fp64 upstream gradients (nullable) -> g_nn fp32,
+ * g_scaling_factor [D], g_mixture_scaling_factor [D,K]; workspace = cnf_bwd_workspace_floats(D + D*K). */
+int cnf_mixture_params_bwd(const float* nn_out, const float* scaling_factor, const float* mixture_scaling_factor,
+                           const float* mask, int mask_rows, int mask_cols,
+                           const double* g_t, const double* g_log_s, const double* g_log_pi, const double* g_mixt_t,
+                           const double* g_mixt_log_s,
+                           float* g_nn, float* g_scaling_factor, float* g_mixture_scaling_factor, float* workspace,
+                           int B, int N, int D, int K, cnf_stream_t stream);
 
 /* d(LinearCategoricalEncoding.forward, num_flows == 0) w.r.t. the class table [C,2D] (linear_encoding.py:59-106,
  * 153-174): g_table [C,2D]; workspace = cnf_bwd_workspace_floats(C*2D).  eps / categories / prior are constants. */

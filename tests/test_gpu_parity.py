@@ -760,3 +760,35 @@ def test_training_steps_reduce_nll_on_set_shuffling():
     assert all(np.isfinite(losses))
     assert np.mean(losses[-10:]) < np.mean(losses[:10]) - 0.1, (losses[:3], losses[-3:])
     assert all(p.grad is not None for p in model.parameters() if p.requires_grad)
+
+
+@pytest.mark.parametrize("c", [x for x in _grad_cases("mixture") if x.meta["mask_kind"] != "none"])
+def test_mixture_static_api_backward(c):
+    """The reference's own call pattern (get_mixt_params + run_with_params, as NodeEdgeCoupling uses it) is
+    differentiable end to end and gives the reference's gradients."""
+    from categoricalnf_amd.layers.flows.mixture_cdf_layer import MixtureCDFCoupling
+    m = c.meta
+    z, nn_out = _leaf(c.z), _leaf(c.nn_out)
+    sf, msf = _leaf(c.scaling_factor), _leaf(c.mixture_scaling_factor)
+    mask = O.expand_mask(c.mask, c.z).cuda()
+    pad = g(c.pad) if m["padded"] else None
+    p = MixtureCDFCoupling.get_mixt_params(nn_out, mask, m["K"], sf, msf)
+    z64, l64, _ = MixtureCDFCoupling.run_with_params(z.double(), *p, reverse=False, reg_max=m["reg_max"], reg_factor=m["reg_factor"],
+                                                     mask=mask, channel_padding_mask=pad if pad is not None else torch.ones_like(z),
+                                                     is_training=m["training"], return_reg_ldj=True)
+    zo = z64.float() * (pad if pad is not None else 1.0)
+    ((zo * g(c.wz)).sum() + (l64.float() * g(c.wl)).sum()).backward()
+    close(z.grad, c.g_z, rtol=5e-4, atol=5e-4); close(nn_out.grad, c.g_nn, rtol=5e-4, atol=5e-4)
+    close(sf.grad, c.g_sf, rtol=1e-3, atol=1e-3); close(msf.grad, c.g_msf, rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("c", _grad_cases("affine"))
+def test_affine_static_api_backward(c):
+    from categoricalnf_amd.layers.flows.coupling_layer import CouplingLayer
+    m = c.meta
+    z, nn_out, sf = _leaf(c.z), _leaf(c.nn_out), _leaf(c.scaling_factor)
+    mask = O.expand_mask(c.mask, c.z).cuda()
+    s, t = CouplingLayer.get_coup_params(nn_out, mask, scaling_factor=sf)
+    zo, lo = CouplingLayer.run_with_params(z, s, t, reverse=m["reverse"])
+    ((zo * g(c.wz)).sum() + ((g(c.ldj) + lo) * g(c.wl)).sum()).backward()
+    close(z.grad, c.g_z, **GRAD); close(nn_out.grad, c.g_nn, **GRAD); close(sf.grad, c.g_sf, rtol=5e-4, atol=5e-4)
