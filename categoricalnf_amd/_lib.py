@@ -31,6 +31,7 @@ SIGNATURES = {
     "cnf_ext_actnorm": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p],
     "cnf_actnorm_stats": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
     "cnf_invconv": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p],
+    "cnf_actnorm_invconv": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p],
     "cnf_mixture_coupling": [_p, _p, _p, _p, _p, _i, _i, _p, _i, _p, _i, _i, _p, _p, _p, _p,
                              _i, _i, _i, _i, _i, _d, _d, _i, _p, _p],
     "cnf_mixture_params": [_p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],

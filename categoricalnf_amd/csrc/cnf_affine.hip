@@ -367,18 +367,24 @@ struct NllArgs {
     FastDiv div_d;
 };
 template <int VEC>
+struct ZChunk {
+    float v[VEC];
+};
+template <int VEC>
 __global__ __launch_bounds__(kBlock) void prior_nll_kernel(NllArgs a, RowTiling tl) {
     __shared__ float part[kWavesPerBlock][kMaxTileChunks];
-    auto chunk = [&](int row, int e0) -> float {
-        const size_t off = (size_t)row * a.L + e0;
-        float zv[VEC];
-        VecIO<VEC>::load_z(a.z + off, zv);
+    auto load = [&](int row, int e0) {
+        ZChunk<VEC> c;
+        VecIO<VEC>::load_z(a.z + (size_t)row * a.L + e0, c.v);
+        return c;
+    };
+    auto proc = [&](const ZChunk<VEC>& c, int row, int e0) -> float {
         int n = (int)fdiv((uint32_t)e0, a.div_d);
         int d = e0 - n * a.D;
         float acc = 0.f;
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-            const float lp = logistic_logp(zv[j], 0.f, a.sigma, a.log_sigma);
+            const float lp = logistic_logp(c.v[j], 0.f, a.sigma, a.log_sigma);
             acc += a.pad ? lp * a.pad[(size_t)row * a.N + n] : lp;
             if (++d == a.D) {
                 d = 0;
@@ -395,7 +401,8 @@ __global__ __launch_bounds__(kBlock) void prior_nll_kernel(NllArgs a, RowTiling 
         if (a.neglog_out) a.neglog_out[row] = neglog;
         if (a.nll_out) a.nll_out[row] = nll;
     };
-    walk_row_tile<float>(tl, part[threadIdx.x >> 6], chunk, finish);
+    // read-only stream: all (up to 4) chunks of a lane are loaded back to back
+    walk_row_tile_split<4, float, ZChunk<VEC>>(tl, part[threadIdx.x >> 6], load, proc, finish);
 }
 
 // sums = (sum_b nll[b], B): one workgroup, fixed order (deterministic), fp64 accumulation.

@@ -30,31 +30,44 @@ struct EncArgs {
     float beta, sigma, log_sigma;
 };
 
-__device__ __forceinline__ float softplus_t20(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+
+// logistic log-density pieces in base-2 units so that the hardware exp2 / log2 are used directly:
+//   softplus(v) + softplus(-v) = |v| + 2 ln(1 + e^{-|v|}) = ln2 * (vs + 2 log2(1 + 2^{-vs})),  vs = |v| log2(e)
+__device__ __forceinline__ float sp_pair2(float vs_abs) {
+    return vs_abs + 2.f * __builtin_amdgcn_logf(1.f + __builtin_amdgcn_exp2f(-vs_abs));
+}
 // LogisticDistribution.log_prob (distributions.py:129-136,154-163), mu = 0
 __device__ __forceinline__ float logistic_logp0(float x, float sigma, float log_sigma) {
-    const float v = fabsf(x / sigma);        // softplus(v)+softplus(-v) = |v| + 2 log(1 + e^{-|v|})
-    return -((v + 2.f * __logf(1.f + __expf(-v))) + log_sigma);
+    return -(kLn2 * sp_pair2(fabsf(x / sigma) * kLog2e) + log_sigma);
 }
 
-// LDS layout per class: [bias D | ts D | e^ts D | e^-ts D | sum_ts], stride 4D+1 (odd -> no bank conflicts)
+// LDS layout per class (stride 6D+1, odd -> no bank conflicts):
+//   [bias D | ts D | e^ts D | e^-ts D | (A, C) pairs 2D | sum_ts],  A = e^-ts log2e / sigma,  C = bias log2e / sigma
+// so that |z_back / sigma| log2e = |z A - C| is one FMA per (class, channel).
 __device__ __forceinline__ void build_class_table(const EncArgs& a, float* tab) {
-    const int stride = 4 * a.D + 1;
+    const int stride = 6 * a.D + 1;
+    const float k = kLog2e / a.sigma;
     for (int i = threadIdx.x; i < a.C * a.D; i += blockDim.x) {
         const int c = i / a.D, d = i - c * a.D;
         const float ts = tanhf(a.table[(size_t)c * 2 * a.D + a.D + d]);
+        const float bias = a.table[(size_t)c * 2 * a.D + d];
+        const float ems = expf(-ts);
         float* t = tab + c * stride;
-        t[d] = a.table[(size_t)c * 2 * a.D + d];
+        t[d] = bias;
         t[a.D + d] = ts;
         t[2 * a.D + d] = expf(ts);
-        t[3 * a.D + d] = expf(-ts);
+        t[3 * a.D + d] = ems;
+        t[4 * a.D + 2 * d] = ems * k;
+        t[4 * a.D + 2 * d + 1] = bias * k;
     }
     __syncthreads();
     for (int c = threadIdx.x; c < a.C; c += blockDim.x) {
         float* t = tab + c * stride;
         float s = 0.f;
         for (int d = 0; d < a.D; ++d) s += t[a.D + d];
-        t[4 * a.D] = s;
+        t[6 * a.D] = s;
     }
     __syncthreads();
 }
@@ -63,14 +76,12 @@ __device__ __forceinline__ void build_class_table(const EncArgs& a, float* tab) 
 template <int DT>
 __device__ __forceinline__ float class_score(const float* t, const float* z, int D, float prior_j,
                                              float sigma, float log_sigma) {
-    float lp = 0.f;
+    float acc = 0.f;
     const int DD = DT > 0 ? DT : D;
 #pragma unroll
-    for (int d = 0; d < DD; ++d) {
-        const float zb = z[d] * t[3 * D + d] - t[d];
-        lp += logistic_logp0(zb, sigma, log_sigma);
-    }
-    return (lp + (-t[4 * D])) + prior_j;
+    for (int d = 0; d < DD; ++d) acc += sp_pair2(fabsf(fmaf(z[d], t[4 * D + 2 * d], -t[4 * D + 2 * d + 1])));
+    const float lp = -(kLn2 * acc + (float)DD * log_sigma);
+    return (lp + (-t[6 * D])) + prior_j;
 }
 
 constexpr int kEncMaxD = 16;
@@ -82,7 +93,7 @@ __global__ __launch_bounds__(kBlock) void encoder_forward_kernel(EncArgs a, RowT
     float* tab = part_all + kWavesPerBlock * kMaxTileChunks;
     build_class_table(a, tab);
     const int D = DT > 0 ? DT : a.D;
-    const int stride = 4 * D + 1;
+    const int stride = 6 * D + 1;
     bool bad = false;
 
     auto chunk = [&](int row, int n) -> float {
@@ -97,7 +108,7 @@ __global__ __launch_bounds__(kBlock) void encoder_forward_kernel(EncArgs a, RowT
             init_lp += logistic_logp0(e, a.sigma, a.log_sigma);
             z[d] = (e + tc[d]) * tc[2 * D + d];
         }
-        const float ldj_f = tc[4 * D];
+        const float ldj_f = tc[6 * D];
         const float log_point = (init_lp - ldj_f) + a.prior[c];
         // streamed log-sum-exp over the classes; the true class uses the forward value (:167-168)
         float m = -INFINITY, s = 0.f;
@@ -105,13 +116,13 @@ __global__ __launch_bounds__(kBlock) void encoder_forward_kernel(EncArgs a, RowT
             const float v = j == c ? log_point
                                    : class_score<DT>(tab + j * stride, z, D, a.prior[j], a.sigma, a.log_sigma);
             if (v > m) {
-                s = s * expf(m - v) + 1.f;
+                s = s * __expf(m - v) + 1.f;
                 m = v;
             } else {
-                s += expf(v - m);
+                s += __expf(v - m);
             }
         }
-        const float cpl = log_point - (m + logf(s));
+        const float cpl = log_point - (m + __logf(s));
         const float pv = a.pad ? a.pad[tok] : 1.f;
         if (a.cpl) a.cpl[tok] = cpl;
 #pragma unroll
@@ -137,7 +148,7 @@ __global__ __launch_bounds__(kBlock) void encoder_decode_kernel(EncArgs a, long 
     float* tab = reinterpret_cast<float*>(smem);
     build_class_table(a, tab);
     const int D = DT > 0 ? DT : a.D;
-    const int stride = 4 * D + 1;
+    const int stride = 6 * D + 1;
     for (long tok = (long)blockIdx.x * kBlock + threadIdx.x; tok < ntok; tok += (long)gridDim.x * kBlock) {
         float z[DT > 0 ? DT : kEncMaxD];
 #pragma unroll
@@ -159,7 +170,7 @@ __global__ __launch_bounds__(kBlock) void encoder_decode_kernel(EncArgs a, long 
 
 using namespace cnf;
 
-static size_t table_bytes(int C, int D) { return (size_t)C * (4 * D + 1) * sizeof(float); }
+static size_t table_bytes(int C, int D) { return (size_t)C * (6 * D + 1) * sizeof(float); }
 
 #define DISPATCH_D(D, CALL)                               \
     switch (D) {                                          \

@@ -191,6 +191,106 @@ __global__ __launch_bounds__(kBlock) void invconv_kernel(ConvArgs a) {
     }
 }
 
+// ActNorm followed by the 1x1 convolution (the first two layers of every flow step of the reference's models),
+// one pass instead of two: forward  z' = (((z + b) e^{sc}) pad) @ W pad ; reverse  z' = (((z @ W^-1) pad) e^{-sc} - b) pad.
+// The arithmetic is the two kernels' arithmetic in the same order, so results are identical to running them
+// back to back; only the intermediate [B,N,D] round trip through HBM (8 B/elem) disappears.
+struct ActConvArgs {
+    const float* z;
+    const float* bias;
+    const float* scales;
+    const float* w;
+    const float* sldj;
+    const float* pad;
+    const float* length;
+    const float* ldj_in;
+    float* z_out;
+    float* ldj_out;
+    int* flags;
+    int B, N, D, reverse;
+    long ntok;
+};
+template <int D>
+__global__ __launch_bounds__(kBlock) void actnorm_invconv_kernel(ActConvArgs a) {
+    bool bad = false;
+    for (long t = (long)blockIdx.x * kBlock + threadIdx.x; t < a.ntok; t += (long)gridDim.x * kBlock) {
+        float xv[D], ov[D];
+        const float* src = a.z + t * D;
+        if (D % 4 == 0) {
+#pragma unroll
+            for (int i = 0; i < D; i += 4) {
+                const float4 q = *reinterpret_cast<const float4*>(src + i);
+                xv[i] = q.x; xv[i + 1] = q.y; xv[i + 2] = q.z; xv[i + 3] = q.w;
+            }
+        } else if (D % 2 == 0) {
+#pragma unroll
+            for (int i = 0; i < D; i += 2) {
+                const float2 q = *reinterpret_cast<const float2*>(src + i);
+                xv[i] = q.x; xv[i + 1] = q.y;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < D; ++i) xv[i] = src[i];
+        }
+        const float p = a.pad ? a.pad[t] : 1.f;
+        if (!a.reverse) {
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                float y = (xv[i] + a.bias[i]) * expf(a.scales[i]);
+                if (a.pad) y = y * p;
+                xv[i] = y;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < D; ++i) acc = fmaf(xv[i], a.w[i * D + j], acc);
+            if (a.pad) acc = acc * p;
+            if (a.reverse) {
+                acc = acc * expf(-a.scales[j]) - a.bias[j];
+                if (a.pad) acc = acc * p;
+            }
+            bad |= isnan(acc);
+            ov[j] = acc;
+        }
+        float* dst = a.z_out + t * D;
+        if (D % 4 == 0) {
+#pragma unroll
+            for (int i = 0; i < D; i += 4) *reinterpret_cast<float4*>(dst + i) = make_float4(ov[i], ov[i + 1], ov[i + 2], ov[i + 3]);
+        } else if (D % 2 == 0) {
+#pragma unroll
+            for (int i = 0; i < D; i += 2) *reinterpret_cast<float2*>(dst + i) = make_float2(ov[i], ov[i + 1]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < D; ++i) dst[i] = ov[i];
+        }
+    }
+    if (bad) raise_flag(a.flags, CNF_FLAG_NAN_Z);
+    // log-det of both layers: ActNorm uses length | sum(pad) | N, the convolution length | N
+    float ssum = 0.f;
+#pragma unroll
+    for (int i = 0; i < D; ++i) ssum += a.scales[i];
+    const float sl = a.sldj[0];
+    for (long b = (long)blockIdx.x * kBlock + threadIdx.x; b < a.B; b += (long)gridDim.x * kBlock) {
+        float len_a, len_c;
+        if (a.length) {
+            len_a = len_c = a.length[b];
+        } else {
+            len_c = (float)a.N;
+            if (a.pad) {
+                len_a = 0.f;
+                for (int n = 0; n < a.N; ++n) len_a += a.pad[b * a.N + n];
+            } else len_a = (float)a.N;
+        }
+        const float base = a.ldj_in ? a.ldj_in[b] : 0.f;
+        // same association as the two layers run in sequence
+        const float v = a.reverse ? (base - sl * len_c) + (-ssum) * len_a : (base + ssum * len_a) + sl * len_c;
+        a.ldj_out[b] = v;
+        if (isnan(v)) raise_flag(a.flags, CNF_FLAG_NAN_LDJ);
+    }
+}
+
 // any D: one lane per output element
 __global__ __launch_bounds__(kBlock) void invconv_generic_kernel(ConvArgs a) {
     const int D = a.D;
@@ -214,9 +314,11 @@ __global__ __launch_bounds__(kBlock) void invconv_generic_kernel(ConvArgs a) {
     }
 }
 
+// one vector per lane (no grid-stride loop): every load of the launch can be in flight at once, which is
+// what keeps HBM busy for these single-pass 8 B/elem kernels (measured against a 2048-workgroup cap)
 static inline int stream_grid(long n) {
     const long blocks = (n + kBlock - 1) / kBlock;
-    return (int)std::min<long>(std::max<long>(blocks, 1), 256 * 8);
+    return (int)std::min<long>(std::max<long>(blocks, 1), 1 << 22);
 }
 
 }  // namespace cnf
@@ -275,6 +377,31 @@ int cnf_invconv(const float* x, const float* weight, const float* sldj,
             hipLaunchKernelGGL(invconv_generic_kernel, dim3(stream_grid(a.ntok * D)), block, 0, st, a);
     }
     return launch_status("cnf_invconv");
+}
+
+int cnf_actnorm_invconv(const float* z, const float* bias, const float* scales, const float* weight,
+                        const float* sldj, const float* pad, const float* length,
+                        const float* ldj_in, float* z_out, float* ldj_out,
+                        int B, int N, int D, int reverse, int* flags, cnf_stream_t stream) {
+    CNF_REQUIRE(z && bias && scales && weight && sldj && z_out && ldj_out, "cnf_actnorm_invconv: null tensor");
+    CNF_REQUIRE(B >= 0 && N > 0 && D > 0, "cnf_actnorm_invconv: bad shape");
+    if (B == 0) return CNF_OK;
+    ActConvArgs a{z, bias, scales, weight, sldj, pad, length, ldj_in, z_out, ldj_out, flags, B, N, D, reverse, (long)B * N};
+    const dim3 grid(stream_grid(std::max<long>(a.ntok, B))), block(kBlock);
+    hipStream_t st = (hipStream_t)stream;
+    switch (D) {
+        case 1: hipLaunchKernelGGL((actnorm_invconv_kernel<1>), grid, block, 0, st, a); break;
+        case 2: hipLaunchKernelGGL((actnorm_invconv_kernel<2>), grid, block, 0, st, a); break;
+        case 3: hipLaunchKernelGGL((actnorm_invconv_kernel<3>), grid, block, 0, st, a); break;
+        case 4: hipLaunchKernelGGL((actnorm_invconv_kernel<4>), grid, block, 0, st, a); break;
+        case 5: hipLaunchKernelGGL((actnorm_invconv_kernel<5>), grid, block, 0, st, a); break;
+        case 6: hipLaunchKernelGGL((actnorm_invconv_kernel<6>), grid, block, 0, st, a); break;
+        case 8: hipLaunchKernelGGL((actnorm_invconv_kernel<8>), grid, block, 0, st, a); break;
+        default:
+            set_error("cnf_actnorm_invconv: fused kernel is built for D in {1,2,3,4,5,6,8}; run the two layers separately for D=%d", D);
+            return CNF_ERR_UNSUPPORTED;
+    }
+    return launch_status("cnf_actnorm_invconv");
 }
 
 }  // extern "C"

@@ -8,6 +8,8 @@ import torch
 import torch.nn as nn
 
 from ... import ops
+from .activation_normalization import ActNormFlow
+from .permutation_layers import InvertibleConv
 
 
 class FlowModel(nn.Module):
@@ -31,7 +33,21 @@ class FlowModel(nn.Module):
         if reverse:
             order.reverse()
         per_layer = []
-        for index, layer in order:
+        fuse = self._fusable(z, get_ldj_per_layer)
+        skip = -1
+        for pos, (index, layer) in enumerate(order):
+            if index == skip:
+                continue
+            if fuse and pos + 1 < len(order):
+                pair = (layer, order[pos + 1][1]) if not reverse else (order[pos + 1][1], layer)
+                if type(pair[0]) is ActNormFlow and type(pair[1]) is InvertibleConv and pair[0].c_in in ops.FUSED_ACTCONV_DIMS:
+                    # ActNorm -> 1x1 conv (or the pair backwards) in one kernel; same arithmetic as the two layers
+                    weight, sldj = pair[1]._get_weight(device_name=str(z.device), inverse=reverse)
+                    z, ldj = ops.actnorm_invconv(z, pair[0].bias, pair[0].scales, weight, sldj, reverse=reverse,
+                                                 length=kwargs.get("length", None),
+                                                 channel_padding_mask=kwargs.get("channel_padding_mask", None), ldj=ldj)
+                    skip = order[pos + 1][0]
+                    continue
             res = layer(z, reverse=reverse, get_ldj_per_layer=get_ldj_per_layer, **kwargs)
             if len(res) == 2:
                 z, layer_ldj = res
@@ -52,6 +68,11 @@ class FlowModel(nn.Module):
         if get_ldj_per_layer:
             return z, ldj, per_layer
         return z, ldj
+
+    def _fusable(self, z, get_ldj_per_layer):
+        """Layer fusion only where it is unobservable: no autograd, no per-layer log-det report, CUDA tensors."""
+        return (not get_ldj_per_layer and not torch.is_grad_enabled() and isinstance(z, torch.Tensor) and z.is_cuda
+                and z.dtype == torch.float32 and ops.FUSE_LAYERS)
 
     def reverse(self, z):
         return self.forward(z, reverse)

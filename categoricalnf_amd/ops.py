@@ -15,6 +15,7 @@ LOGISTIC_SIGMA = 1.0 / 1.81                       # reference: layers/flows/dist
 LOGISTIC_LOG_SIGMA = float(np.log(LOGISTIC_SIGMA))
 
 _STRICT = os.environ.get("CNF_STRICT_ASSERTS", "0") == "1"
+FUSE_LAYERS = os.environ.get("CNF_FUSE_LAYERS", "1") == "1"      # FlowModel: ActNorm + InvertibleConv in one kernel
 _flags = {}
 
 
@@ -265,6 +266,28 @@ def invconv(x, weight, sldj, reverse=False, length=None, channel_padding_mask=No
                                _ptr(ldj_out), B, N, D, int(bool(reverse)), _ptr(flag_word(dev)), _stream(dev)),
                "cnf_invconv")
     _after(dev, "InvertibleConv")
+    return z_out, ldj_out
+
+
+FUSED_ACTCONV_DIMS = (1, 2, 3, 4, 5, 6, 8)
+
+
+def actnorm_invconv(z, bias, scales, weight, sldj, reverse=False, length=None, channel_padding_mask=None, ldj=None):
+    """ActNorm then 1x1 convolution (reverse: the pair backwards) in one pass; `weight` already inverted for reverse."""
+    z = _f32(z, "z")
+    dev = z.device
+    B, N, D = z.shape
+    b, s = _f32(bias.reshape(-1), "bias"), _f32(scales.reshape(-1), "scales")
+    w, sl = _f32(weight, "weight"), _f32(sldj.reshape(1), "sldj")
+    pad = _pad2d(channel_padding_mask, B, N, dev)
+    ln = _length(length, B, dev) if isinstance(length, torch.Tensor) else None
+    ldj_in, ldj_out = _ldj_io(ldj, B, dev, inplace=False)
+    z_out = torch.empty_like(z)
+    lib = _lib.load()
+    _lib.check(lib.cnf_actnorm_invconv(_ptr(z), _ptr(b), _ptr(s), _ptr(w), _ptr(sl), _ptr(pad), _ptr(ln), _ptr(ldj_in),
+                                       _ptr(z_out), _ptr(ldj_out), B, N, D, int(bool(reverse)), _ptr(flag_word(dev)),
+                                       _stream(dev)), "cnf_actnorm_invconv")
+    _after(dev, "ActNorm + InvertibleConv")
     return z_out, ldj_out
 
 

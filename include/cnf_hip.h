@@ -117,6 +117,16 @@ int cnf_invconv(const float* x, const float* weight, const float* sldj,
                 const float* ldj_in, float* z_out, float* ldj_out,
                 int B, int N, int D, int reverse, int* flags, cnf_stream_t stream);
 
+/* ActNormFlow followed by InvertibleConv in ONE pass (the first two layers of every flow step in
+ * experiments/set_modeling/flow_model.py:55-57, graph_node_flow.py, graphCNF.py): same arithmetic, same order,
+ * identical results to cnf_actnorm + cnf_invconv, without the intermediate [B,N,D] round trip.  reverse = 1 runs
+ * the pair backwards (convolution with the given inverse weight first, then the inverse ActNorm).
+ * D in {1,2,3,4,5,6,8}; otherwise CNF_ERR_UNSUPPORTED (run the two kernels). */
+int cnf_actnorm_invconv(const float* z, const float* bias, const float* scales, const float* weight,
+                        const float* sldj, const float* pad, const float* length,
+                        const float* ldj_in, float* z_out, float* ldj_out,
+                        int B, int N, int D, int reverse, int* flags, cnf_stream_t stream);
+
 /* ---- logistic-mixture CDF coupling ----------------------------------------------------------- */
 
 /* MixtureCDFCoupling.forward after the subnet (mixture_cdf_layer.py:45-92) = get_mixt_params
