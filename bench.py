@@ -11,7 +11,9 @@ One step on every rank (weak scaling: each rank owns its own B samples, no data-
     1. cnf_affine_coupling   forward  z -> z', ldj            (16 B/elem)
     2. cnf_prior_nll         z', ldj -> per-sample NLL, (sum, count)   (4 B/elem)
     3. cnf_affine_coupling   inverse  z' -> z, -ldj           (16 B/elem)
-    4. N > 1: ONE all-reduce of the two fp64 scalars (sum NLL, count) over RCCL.
+    4. the per-batch (sum NLL, count) pair is added to a running device total; after the last step ONE all-reduce
+       of that pair over RCCL gives every rank the mean NLL / bits-per-dim of the whole job (the reference's eval
+       loop also averages once after its batch loop, general/task.py:118-139).
 `value` = B*N*D elements pushed through forward+inverse(+log-det) per second, summed over ranks, with
 all inputs resident in HBM.  Prints ONE JSON line on rank 0.
 
@@ -48,6 +50,9 @@ def parse():
     p.add_argument("--tile-chunks", type=int, default=0)
     p.add_argument("--unroll", type=int, default=-1)
     p.add_argument("--math-mode", type=int, default=-1)
+    p.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
+    p.add_argument("--share-device", action="store_true",
+                   help="TEST ONLY: all ranks use cuda:0 (exercise the multi-rank path on a 1-GPU box, with --backend gloo)")
     p.add_argument("--rotate", type=int, default=4, help="buffer sets rotated through (defeats the 256 MB Infinity Cache)")
     return p.parse_args()
 
@@ -136,10 +141,10 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no CUDA(HIP) device visible")
-    rank, local_rank, world = init_process_group("nccl")
+    rank, local_rank, world = init_process_group(args.backend if not args.share_device else "gloo")
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", local_rank if (world > 1 and not args.share_device) else 0)
     torch.cuda.set_device(dev)
     lib = _lib.load()
     if args.tile_chunks:
@@ -159,6 +164,7 @@ def main():
     mask = channel_mask(D).to(dev)
     length = torch.full((B,), float(N), device=dev)
     sums = torch.zeros(2, dtype=torch.float64, device=dev)
+    total = torch.zeros(2, dtype=torch.float64, device=dev)
     ev_a = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev_b = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev_c = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]   # empty pair: event overhead
@@ -182,9 +188,8 @@ def main():
             ev_b[timed].record()
             ev_c[timed].record()
         nlls[r]()
+        total.add_(sums)
         inv[r]()
-        if world > 1:
-            dist.all_reduce(sums, op=dist.ReduceOp.SUM)
         return zrs[r], lrs[r]
 
     for i in range(args.warmup):
@@ -196,9 +201,12 @@ def main():
         torch.cuda.synchronize(dev)
 
     barrier()
+    total.zero_()
     t0 = time.perf_counter()
     for i in range(args.steps):
         zr, lr = step(i, timed=i)
+    if world > 1:
+        dist.all_reduce(total, op=dist.ReduceOp.SUM)        # the single collective of the job
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -210,7 +218,7 @@ def main():
     err = (zrs[r_last] - zs[r_last]).abs().max().item()
     assert err < 1e-4, "inverse(forward(z)) != z (max err %g)" % err
     assert torch.equal(lfs[r_last], -lrs[r_last]), "ldj_fwd + ldj_inv != 0"
-    mean_nll = float(sums[0].item() / max(sums[1].item(), 1.0))
+    mean_nll = float(total[0].item() / max(total[1].item(), 1.0))
 
     # Duration of the dominant kernel (affine forward), with HIP events on the launch stream:
     #  (1) every forward launch of the timed region is bracketed by an event pair (raw_ms; it carries the
@@ -259,7 +267,7 @@ def main():
             "config": {"workload": "affine coupling fwd+logdet, NLL, inverse+logdet on z~N(0,1) [B=%d,N=%d,D=%d] per GPU, "
                                    "nn_out~0.5N(0,1), channel mask 0.5, scaling_factor=0" % (B, N, D),
                        "batch_per_gpu": B, "seq": N, "d_latent": D, "elems_per_step_per_gpu": elems,
-                       "buffer_sets_rotated": R, "parallelism": "dp%d (batch shards, 1 all-reduce of 2 fp64)" % world},
+                       "buffer_sets_rotated": R, "parallelism": "dp%d (batch shards, one all-reduce of 2 fp64 per job)" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "affine_coupling_kernel<VEC=4,fwd>", "kernel_ms": kern_ms, "in_step_event_pair_ms": raw_ms, "empty_event_pair_ms": ovh_ms,
