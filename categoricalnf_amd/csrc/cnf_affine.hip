@@ -410,7 +410,13 @@ __global__ __launch_bounds__(kBlock) void prior_nll_kernel(NllArgs a, RowTiling 
 __global__ __launch_bounds__(1024) void nll_sum_kernel(const float* nll, int B, double* sums) {
     __shared__ double sh[16];
     double acc = 0.0;
-    for (int i = threadIdx.x; i < B; i += 1024) acc += (double)nll[i];
+    // four independent loads in flight per lane (the values were just written: L2 hits, latency-bound otherwise)
+    int i = threadIdx.x;
+    for (; i + 3 * 1024 < B; i += 4 * 1024) {
+        const float a0 = nll[i], a1 = nll[i + 1024], a2 = nll[i + 2048], a3 = nll[i + 3072];
+        acc += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+    }
+    for (; i < B; i += 1024) acc += (double)nll[i];
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
     __syncthreads();

@@ -51,7 +51,11 @@ def _opt_f32(t, name, device):
 
 
 def _ptr(t):
-    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    # an empty tensor has a null data pointer; hand the kernels a harmless non-null address instead
+    # (every entry point returns before touching memory when B == 0)
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr() if t.numel() > 0 else 8)
 
 
 def _stream(device):

@@ -848,3 +848,26 @@ def test_flow_model_layer_fusion_is_unobservable():
         o.FUSE_LAYERS = True
     assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][1], outs[False][1])
     assert torch.equal(outs[True][2], outs[False][2])
+
+
+def test_empty_and_single_element_batches():
+    """Edge shapes: B = 0 (nothing launched), B = 1, N = 1, D = 1."""
+    z0 = torch.zeros(0, 5, 4, device="cuda")
+    zf, lf = ops().affine_coupling(z0, torch.zeros(0, 5, 8, device="cuda"), torch.zeros(4, device="cuda"), g(O.channel_mask(4)))
+    assert zf.shape == (0, 5, 4) and lf.shape == (0,)
+    zf, lf, _ = ops().mixture_coupling(z0, torch.zeros(0, 5, 4 * 26, device="cuda"), g(O.channel_mask(4)), 8)
+    assert zf.shape == (0, 5, 4)
+    za, la = ops().actnorm(z0, torch.zeros(1, 1, 4, device="cuda"), torch.zeros(1, 1, 4, device="cuda"))
+    assert za.shape == (0, 5, 4) and la.shape == (0,)
+    gen = torch.Generator().manual_seed(9)
+    for (B, N, D) in [(1, 1, 1), (1, 7, 1), (1, 1, 6), (2, 1, 3)]:
+        z, nn_out = torch.randn(B, N, D, generator=gen), torch.randn(B, N, 2 * D, generator=gen)
+        mask = O.channel_mask(D) if D > 1 else O.chess_mask()
+        zo, lo = O.affine_coupling(z, nn_out, mask, None)
+        zf, lf = ops().affine_coupling(g(z), g(nn_out), None, g(mask))
+        close(zf, zo, **ELEM); close(lf, lo, **LDJ)
+        K = 4
+        nn_m = 0.5 * torch.randn(B, N, D * (2 + 3 * K), generator=gen)
+        zo, lo, _ = O.mixture_coupling(z, nn_m, mask, K, None, None)
+        zf, lf, _ = ops().mixture_coupling(g(z), g(nn_m), g(mask), K)
+        close(zf, zo, **ELEM); close(lf, lo, **LDJ)
