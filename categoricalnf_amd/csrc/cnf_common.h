@@ -55,11 +55,13 @@ struct RowTiling {
     int cpr;        // chunks per row = L / vec
     int rw;         // rows per wave-tile
     int p2;         // power of two >= rw, capped at 64 (row slots reduced per pass)
+    int bpr;        // 1: small batch of long rows -> the four waves of a workgroup share ONE row (4x the waves)
     long ntiles;
     FastDiv div_cpr;
 };
 RowTiling make_row_tiling(int B, int L, int force_vec = 0, int target_chunks = 256);
 inline dim3 tiling_grid(const RowTiling& t) {
+    if (t.bpr) return dim3((unsigned)t.B);
     return dim3((unsigned)((t.ntiles + kWavesPerBlock - 1) / kWavesPerBlock));
 }
 
@@ -104,6 +106,36 @@ __device__ __forceinline__ void walk_row_tile_split(const RowTiling& tl, T* part
                                                     ProcFn&& proc_fn, FinishFn&& finish_fn,
                                                     PreFn&& pre_fn = NoPre()) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (tl.bpr) {
+        // block-per-row mode (training-sized batches: B ~ 10^2 rows of 10^3 elements would otherwise
+        // occupy B waves only): the workgroup's waves interleave over the chunks of one row and combine
+        // their partial sums through LDS in wave order
+        __shared__ T bpr_sh[kWavesPerBlock];
+        const int row = blockIdx.x;
+        T acc = 0;
+        bool first = true;
+        for (int c0 = threadIdx.x; c0 < tl.cpr || first; c0 += kBlock * U) {
+            Data dat[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) dat[u] = load_fn(row, min(c0 + kBlock * u, tl.cpr - 1) * tl.vec);
+            if (first) {
+                pre_fn();
+                first = false;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (c0 + kBlock * u < tl.cpr) acc += proc_fn(dat[u], row, (c0 + kBlock * u) * tl.vec);
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) bpr_sh[wave] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            T t = 0;
+            for (int w = 0; w < kWavesPerBlock; ++w) t += bpr_sh[w];
+            finish_fn(row, t);
+        }
+        return;
+    }
     const long tile = (long)blockIdx.x * kWavesPerBlock + wave;
     if (tile >= tl.ntiles) return;
     const int row0 = (int)(tile * tl.rw);

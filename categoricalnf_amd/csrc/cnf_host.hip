@@ -57,6 +57,13 @@ RowTiling make_row_tiling(int B, int L, int force_vec, int target_chunks) {
     int p2 = 1;
     while (p2 < t.rw && p2 < kWave) p2 <<= 1;
     t.p2 = p2;
+    // few, longish rows (training-sized batches): one workgroup (4 waves) per row instead of one wave per
+    // one-or-more rows, so that B rows still put 4B waves on the chip
+    t.bpr = (B < 2048 && t.cpr >= kWave) ? 1 : 0;
+    if (t.bpr) {
+        t.rw = 1;
+        t.p2 = 1;
+    }
     t.ntiles = ((long)B + t.rw - 1) / t.rw;
     t.div_cpr = make_fastdiv((uint32_t)t.cpr);
     return t;

@@ -163,21 +163,55 @@ struct ElemParams {
 template <bool SPLIT, int KT>
 __device__ __forceinline__ MixEval eval_mixture(const ElemParams<SPLIT, KT>& p, double x) {
     const int K = p.K;
-    double mx = -INFINITY;
+    double mx = -INFINITY, se = 0.0, cdf = 0.0, pdf = 0.0;
+    if (KT > 0) {
 #pragma unroll
-    for (int k = 0; k < K; ++k) mx = fmax(mx, p.log_pi(k));
-    double se = 0.0, cdf = 0.0, pdf = 0.0;
+        for (int k = 0; k < K; ++k) mx = fmax(mx, p.log_pi(k));
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const double w = exp(p.log_pi(k) - mx);
-        const double inv_s = exp(-p.ls(k));
-        const double zk = (x - p.mu(k)) * inv_s;
-        const double e = exp(-fabs(zk));
-        const double r = 1.0 / (1.0 + e);
-        const double sig = zk >= 0.0 ? r : e * r;
-        se += w;
-        cdf += w * sig;
-        pdf += w * inv_s * (e * r * r);
+        for (int k = 0; k < K; ++k) {
+            const double w = exp(p.log_pi(k) - mx);
+            const double inv_s = exp(-p.ls(k));
+            const double zk = (x - p.mu(k)) * inv_s;
+            const double e = exp(-fabs(zk));
+            const double r = 1.0 / (1.0 + e);
+            const double sig = zk >= 0.0 ? r : e * r;
+            se += w;
+            cdf += w * sig;
+            pdf += w * inv_s * (e * r * r);
+        }
+    } else {
+        // run-time K: parameters come straight from memory; fetch them eight mixtures at a time so that 24
+        // independent loads are in flight instead of one dependent load per use (444 us -> at K = 51)
+        constexpr int CH = 8;
+        for (int k0 = 0; k0 < K; k0 += CH) {
+            double lpv[CH];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) lpv[j] = p.log_pi(min(k0 + j, K - 1));
+#pragma unroll
+            for (int j = 0; j < CH; ++j) mx = fmax(mx, lpv[j]);
+        }
+        for (int k0 = 0; k0 < K; k0 += CH) {
+            double lpv[CH], muv[CH], lsv[CH];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const int k = min(k0 + j, K - 1);
+                lpv[j] = p.log_pi(k);
+                muv[j] = p.mu(k);
+                lsv[j] = p.ls(k);
+            }
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const double w = (k0 + j < K) ? exp(lpv[j] - mx) : 0.0;
+                const double inv_s = exp(-lsv[j]);
+                const double zk = (x - muv[j]) * inv_s;
+                const double e = exp(-fabs(zk));
+                const double r = 1.0 / (1.0 + e);
+                const double sig = zk >= 0.0 ? r : e * r;
+                se += w;
+                cdf += w * sig;
+                pdf += w * inv_s * (e * r * r);
+            }
+        }
     }
     MixEval o;
     o.u = cdf / se;
@@ -199,7 +233,10 @@ __global__ __launch_bounds__(kBlock) void mixture_kernel(MixArgs a, RowTiling tl
     if (threadIdx.x < kMaxAct && ((a.act_bits >> threadIdx.x) & 1ull))
         s_act[__popcll(a.act_bits & ((1ull << threadIdx.x) - 1ull))] = threadIdx.x;
     __syncthreads();
-    const long tile = (long)blockIdx.x * W + wave;
+    // block-per-row mode (few long rows): all waves of the workgroup share row blockIdx.x
+    const int nlanes = tl.bpr ? (int)blockDim.x : kWave;       // lanes striding over one tile
+    const int lane_t = tl.bpr ? (int)threadIdx.x : lane;
+    const long tile = tl.bpr ? (long)blockIdx.x : (long)blockIdx.x * W + wave;
     if (tile >= tl.ntiles) return;
     const int row0 = (int)(tile * tl.rw);
     const int nrows = min(tl.rw, tl.B - row0);
@@ -209,7 +246,7 @@ __global__ __launch_bounds__(kBlock) void mixture_kernel(MixArgs a, RowTiling tl
     {
         const long nel = (long)nrows * a.L;
         const size_t base = (size_t)row0 * a.L;
-        for (long e = lane; e < nel; e += kWave) {
+        for (long e = lane_t; e < nel; e += nlanes) {
             const int r = (int)(e / a.L);
             const int er = (int)(e - (long)r * a.L);
             const int n = (int)fdiv((uint32_t)er, a.div_d);
@@ -233,7 +270,7 @@ __global__ __launch_bounds__(kBlock) void mixture_kernel(MixArgs a, RowTiling tl
     const int ipr = tl.L;                 // items per row = N * DA
     const int nitems = nrows * ipr;
     double acc1 = 0.0;
-    for (int c = lane; c < nitems; c += kWave) {
+    for (int c = lane_t; c < nitems; c += nlanes) {
         const int r = tl.rw == 1 ? 0 : (int)fdiv((uint32_t)c, tl.div_cpr);
         const int it = c - r * ipr;
         const int n = (int)fdiv((uint32_t)it, a.div_da);
@@ -387,7 +424,16 @@ __global__ __launch_bounds__(kBlock) void mixture_kernel(MixArgs a, RowTiling tl
             if (isnan(v)) raise_flag(a.flags, CNF_FLAG_NAN_LDJ);
         }
     };
-    if (tl.rw == 1) {
+    if (tl.bpr) {
+        acc1 = wave_sum(acc1);
+        if (lane == 0) part[0] = acc1;                 // this wave's strip, slot 0
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+            for (int w = 0; w < W; ++w) t += reinterpret_cast<double*>(smem)[(size_t)w * kMaxTileChunks];
+            finish(row0, t);
+        }
+    } else if (tl.rw == 1) {
         acc1 = wave_sum(acc1);
         if (lane == 0) finish(row0, acc1);
     } else {
@@ -503,7 +549,7 @@ static int launch_mixture(MixArgs& a, bool split, const int* act_host, int n_act
     }
     const int W = threads / kWave;
     const size_t smem = (size_t)W * kMaxTileChunks * sizeof(double) + cst_bytes;
-    const dim3 grid((unsigned)((tl.ntiles + W - 1) / W)), block(threads);
+    const dim3 grid(tl.bpr ? (unsigned)tl.ntiles : (unsigned)((tl.ntiles + W - 1) / W)), block(threads);
     const bool newton = inverse_mode() == 1;
 #define CNF_MIX_LAUNCH(SPLIT_, REV_, KT_, NEWT_) \
     hipLaunchKernelGGL((mixture_kernel<SPLIT_, REV_, KT_, NEWT_>), grid, block, smem, st, a, tl)
