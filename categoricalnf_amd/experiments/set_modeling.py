@@ -73,8 +73,10 @@ class FlowSetModeling(FlowModel):
 
     def forward(self, z, ldj=None, reverse=False, length=None, **kwargs):
         if length is not None:
-            kwargs["src_key_padding_mask"] = create_transformer_mask(length)
-            kwargs["channel_padding_mask"] = create_channel_mask(length)
+            # max_len = the padded set size: same masks as the reference's `length.max()` for any batch it can
+            # process, without the host sync (keeps the pass capturable in a HIP graph)
+            kwargs["src_key_padding_mask"] = create_transformer_mask(length, max_len=z.size(1))
+            kwargs["channel_padding_mask"] = create_channel_mask(length, max_len=z.size(1))
         return super().forward(z, ldj=ldj, reverse=reverse, length=length, **kwargs)
 
     def initialize_data_dependent(self, batch_list):

@@ -15,6 +15,7 @@ LOGISTIC_SIGMA = 1.0 / 1.81                       # reference: layers/flows/dist
 LOGISTIC_LOG_SIGMA = float(np.log(LOGISTIC_SIGMA))
 
 _STRICT = os.environ.get("CNF_STRICT_ASSERTS", "0") == "1"
+CAPTURING = False            # set by graphs.GraphedFlow while a pass is recorded into a HIP graph (no host syncs)
 FUSE_LAYERS = os.environ.get("CNF_FUSE_LAYERS", "1") == "1"      # FlowModel: ActNorm + InvertibleConv in one kernel
 _flags = {}
 
@@ -77,6 +78,8 @@ def check_flags(device=None, where=""):
 
     NaN in z / ldj -> AssertionError (flow_model.py:42, activation_normalization.py:45-46);
     inverse-CDF input outside (0,1) -> RuntimeError (mixture_cdf_layer.py:238-239)."""
+    if CAPTURING:
+        return
     for key, w in list(_flags.items()):
         if device is not None and (device.type, device.index if device.index is not None
                                    else torch.cuda.current_device()) != key:
