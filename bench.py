@@ -104,7 +104,8 @@ def cpu_baseline(B, N, D, budget_s=15.0):
 
 def mixture_measure(ops, dev, steps=20, warmup=3):
     """Secondary measurement, BASELINE configs[1]: mixture-CDF coupling fwd + inv, B=16384, N=16, D=4, K=8."""
-    from oracle.cnf_oracle import channel_mask
+    from categoricalnf_amd.layers.flows.coupling_layer import CouplingLayer
+    channel_mask = CouplingLayer.create_channel_mask
     B, N, D, K = 16384, 16, 4, 8
     g = torch.Generator(device=dev).manual_seed(1)
     z = torch.randn(B, N, D, generator=g, device=dev)
@@ -140,7 +141,8 @@ def main():
     args = parse()
     from categoricalnf_amd import _lib, ops
     from categoricalnf_amd.distributed import init_process_group
-    from oracle.cnf_oracle import channel_mask        # mask constructor only (test helper, not compute)
+    from categoricalnf_amd.layers.flows.coupling_layer import CouplingLayer
+    channel_mask = CouplingLayer.create_channel_mask
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no CUDA(HIP) device visible")
