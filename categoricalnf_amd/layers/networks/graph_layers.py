@@ -1,0 +1,143 @@
+"""Node-based graph sub-networks used as coupling networks in the graph-colouring flow: relational graph
+convolution / relational graph attention layers and the RGCN stack.
+
+Same constructor arguments, parameter names and mathematics as the reference's
+layers/networks/graph_layers.py (RelationGraphConv :15-50, RelationGraphAttention :53-154,
+RGCNNet :157-232, GNNSkipConnection :702-735), so its checkpoints load.  These are dense GEMM /
+attention sub-networks and stay PyTorch-ROCm (hipBLASLt / MFMA).  The attention is written MI355X-first as
+dense masked attention — `[B,H,N,N] @ [B,H,N,C]` batched GEMMs per edge type — instead of the reference's
+gather into a padded neighbour list (index_select / masked_select with a host sync on `max_neighbours`);
+the result is the same softmax over each node's neighbours."""
+import torch
+import torch.nn as nn
+
+from ...host_utils import one_hot
+
+
+class RelationGraphConv(nn.Module):
+    """h_i = W_s x_i + (1/|N_i|) sum_{j in N_i} W_{r(i,j)} x_j on layer-normed features."""
+
+    def __init__(self, c_in, c_out, num_edges, **kwargs):
+        super().__init__()
+        self.c_in, self.c_out, self.num_edges = c_in, c_out, num_edges
+        self.norm_layer = nn.LayerNorm(self.c_in)
+        self.linear_hs = nn.Linear(self.c_in, self.c_out)
+        self.linear_hr = nn.Linear(self.c_in, self.c_out * self.num_edges)
+
+    def forward(self, x, adjacency, num_neighbours=None):
+        B, N = x.size(0), x.size(1)
+        if num_neighbours is None:
+            num_neighbours = adjacency.sum(dim=[1, 3])
+        x = self.norm_layer(x)
+        hr_all = self.linear_hr(x).view(B, N, self.num_edges, self.c_out)
+        # sum over source nodes and edge types, exactly the reference's (hr_all * adjacency).sum(dim=[1,3])
+        hr = torch.einsum("bjec,bjie->bic", hr_all, adjacency)
+        return self.linear_hs(x) + hr / num_neighbours.unsqueeze(dim=-1).clamp(min=1e-5)
+
+
+class RelationGraphAttention(nn.Module):
+    """Multi-head graph attention with one value / key projection per edge type (+ self connection)."""
+
+    def __init__(self, c_in, c_out, num_edges, num_heads=4, **kwargs):
+        super().__init__()
+        self.c_in, self.c_out, self.num_edges, self.num_heads = c_in, c_out, num_edges, num_heads
+        self.c_out_per_head = self.c_out * 2 // self.num_heads
+        self.norm_layer = nn.LayerNorm(self.c_in)
+        self.linear_hs = nn.Linear(self.c_in, self.c_out_per_head * self.num_heads)
+        self.linear_hr = nn.Linear(self.c_in, self.c_out_per_head * self.num_heads * (self.num_edges + 1))
+        self.attn_weight = nn.Parameter(torch.zeros(self.num_heads, 2, self.c_out_per_head), requires_grad=True)
+        nn.init.xavier_uniform_(self.attn_weight.data, gain=1.414)
+        self.output_projection = nn.Sequential(nn.GELU(), nn.Linear(self.c_out_per_head * self.num_heads, self.c_out))
+        self.leaky_relu = nn.LeakyReLU(0.2)
+
+    def forward(self, x, adjacency, **kwargs):
+        B, N = x.size(0), x.size(1)
+        H, C, E1 = self.num_heads, self.c_out_per_head, self.num_edges + 1
+        x = self.norm_layer(x)
+        hs = self.linear_hs(x).reshape(B, N, H, C)
+        hr_all = self.linear_hr(x).reshape(B, N, E1, H, C)
+        hs_attn = (hs * self.attn_weight[:, 0].view(1, 1, H, C)).sum(dim=-1)                 # [B,N,H]   (query side)
+        hr_attn = (hr_all * self.attn_weight[:, 1].view(1, 1, 1, H, C)).sum(dim=-1)          # [B,N,E1,H] (key side)
+        with torch.no_grad():
+            eye = torch.eye(N, device=x.device, dtype=adjacency.dtype).view(1, N, N, 1).expand(B, -1, -1, -1)
+            adj = torch.cat([adjacency, eye], dim=-1)                                         # self connection = last type
+            connected = adj.sum(dim=-1) > 0                                                   # [B,N,N]
+        # key logit of neighbour j as seen from i: the projection of the edge type that links them
+        key = torch.einsum("bije,bjeh->bijh", adj, hr_attn)
+        logits = self.leaky_relu(hs_attn.unsqueeze(dim=2) + key)
+        logits = logits.masked_fill(~connected.unsqueeze(dim=-1), -9e15)
+        probs = torch.softmax(logits, dim=2)                                                  # over neighbours j
+        # values: sum_e (probs * adj_e) @ hr_all[:, :, e]  — one batched GEMM per edge type
+        out = x.new_zeros(B, H, N, C)
+        for e in range(E1):
+            out = out + torch.matmul((probs * adj[..., e:e + 1]).permute(0, 3, 1, 2), hr_all[:, :, e].permute(0, 2, 1, 3))
+        out = out.permute(0, 2, 1, 3).reshape(B, N, H * C)
+        return self.output_projection(out)
+
+
+class GNNSkipConnection(nn.Module):
+    """0: residual, 1: gated residual, 2: highway combination of the block input and the block output."""
+
+    def __init__(self, hidden_size, config=0, input_size=-1, dp_rate=0.0):
+        super().__init__()
+        self.hidden_size = hidden_size
+        self.input_size = input_size if input_size > 0 else hidden_size
+        self.config = config
+        self.dp_rate = dp_rate
+        assert config in (0, 1, 2), "[!] ERROR: Unknown skip connection config \"%s\"" % str(config)
+        self.skip_layer = nn.Linear(self.input_size, self.hidden_size * (1 if config == 0 else 2))
+        if self.dp_rate > 0.0:
+            self.skip_layer = nn.Sequential(nn.Dropout(self.dp_rate), self.skip_layer)
+
+    def forward(self, orig, feat):
+        if self.config == 0:
+            return orig + self.skip_layer(feat)
+        val, gate_logits = self.skip_layer(feat).chunk(2, dim=-1)
+        gate = torch.sigmoid(gate_logits)
+        return orig + val * gate if self.config == 1 else orig * (1 - gate) + val * gate
+
+
+class RGCNNet(nn.Module):
+    """Input MLP (+ embedding of the clamped neighbour count), `num_layers` x [graph layer, GELU, dropout, skip], output MLP."""
+
+    def __init__(self, c_in, c_out, num_edges, num_layers, hidden_size, dp_rate=0.0, max_neighbours=4,
+                 skip_config=2, rgc_layer_fun=RelationGraphConv, **kwargs):
+        super().__init__()
+        self.c_in, self.c_out, self.num_edges, self.num_layers = c_in, c_out, num_edges, num_layers
+        self.hidden_size, self.dp_rate, self.max_neighbours = hidden_size, dp_rate, max_neighbours
+        if self.max_neighbours > 0:
+            neighbour_embed_size = int(hidden_size // 4)
+            self.neighbour_embed = nn.Linear(max_neighbours + 1, neighbour_embed_size)
+        else:
+            neighbour_embed_size = 0
+        self.act_fn = nn.GELU()
+        self.dropout = nn.Dropout(dp_rate)
+        self.layers = nn.ModuleList([
+            nn.ModuleList([rgc_layer_fun(c_in=hidden_size, c_out=hidden_size, num_edges=num_edges), self.act_fn, self.dropout,
+                           GNNSkipConnection(hidden_size=hidden_size, config=skip_config)])
+            for _ in range(num_layers)])
+        self.input_layer = nn.Sequential(nn.Linear(c_in, hidden_size), self.act_fn,
+                                         nn.Linear(hidden_size, hidden_size - neighbour_embed_size))
+        self.output_layer = nn.Sequential(nn.LayerNorm(hidden_size), nn.Linear(hidden_size, hidden_size), self.act_fn,
+                                          nn.Linear(hidden_size, c_out))
+
+    def forward(self, x, adjacency, channel_padding_mask=None, embed_ext_input=None, **kwargs):
+        adj_one_hot = one_hot(adjacency, num_classes=self.num_edges + 1)[..., 1:]       # type 0 = no edge
+        num_neighbours = adj_one_hot.sum(dim=[1, 3])
+        x = self.input_layer(x)
+        if self.max_neighbours > 0:
+            num_neighbours = num_neighbours.clamp(max=self.max_neighbours)
+            x = torch.cat([x, self.neighbour_embed(one_hot(num_neighbours.long(), num_classes=self.max_neighbours + 1))], dim=-1)
+        for block in self.layers:
+            block_in = x
+            for layer in block:
+                if isinstance(layer, (RelationGraphConv, RelationGraphAttention)):
+                    x = layer(x, adjacency=adj_one_hot, num_neighbours=num_neighbours)
+                elif isinstance(layer, GNNSkipConnection):
+                    x = layer(orig=block_in, feat=x)
+                else:
+                    x = layer(x)
+        x = self.output_layer(x)
+        if channel_padding_mask is not None:       # the adjacency is already zero for padded nodes
+            x = x * channel_padding_mask
+        return x

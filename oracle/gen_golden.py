@@ -704,6 +704,60 @@ def gen_grads():
     save("grads", cases)
 
 
+def gen_graph_node_flow():
+    """configs[2]: node-based GraphCNF for graph colouring (experiments/graph_coloring/graph_node_flow.py) with the
+    RGCN-attention sub-network, 3 colours, synthetic sparse graphs of 6..10 nodes, reg_max 3.5 x 2, eval mode."""
+    with contextlib.redirect_stdout(io.StringIO()):
+        from experiments.graph_coloring.graph_node_flow import GraphNodeFlow
+
+    class Colours:
+        @staticmethod
+        def num_node_types():
+            return 3
+
+    torch.manual_seed(70)
+    np.random.seed(70)
+    params = {"coupling_num_flows": 2, "coupling_hidden_size": 32, "coupling_hidden_layers": 2, "coupling_num_mixtures": 8,
+              "coupling_mask_ratio": 0.5, "coupling_dropout": 0.0,
+              "categ_encoding": {"use_dequantization": False, "use_variational": False, "use_decoder": False, "num_dimensions": 2,
+                                 "flow_config": {"num_flows": 0, "hidden_layers": 2, "hidden_size": 128},
+                                 "decoder_config": {"num_layers": 1, "hidden_size": 64}}}
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = GraphNodeFlow(params, Colours)
+    for p in model.parameters():
+        p.data = p.data + 0.05 * torch.randn(p.shape)
+    model.eval()
+    B, N = 8, 10
+    g = torch.Generator().manual_seed(71)
+    ln = torch.randint(6, N + 1, (B,), generator=g)
+    ln[0] = N
+    adj = (torch.rand(B, N, N, generator=g) < 0.3).long()
+    adj = torch.triu(adj, 1)
+    adj = adj + adj.transpose(1, 2)
+    valid = (torch.arange(N).view(1, N) < ln.view(B, 1))
+    adj = adj * (valid.unsqueeze(1) & valid.unsqueeze(2)).long()
+    cat = torch.randint(0, 3, (B, N), generator=g) * valid.long()
+    torch.manual_seed(72)
+    u = torch.rand(B * N, 1, 2)
+    torch.manual_seed(72)
+    with torch.no_grad():
+        z, ldj = model(cat, adjacency=adj, reverse=False, length=ln)
+        dec, _ = model(z, adjacency=adj, reverse=True, length=ln)
+        with contextlib.redirect_stdout(io.StringIO()):
+            rev_ok = bool(model.test_reversibility(cat, adj, ln))
+            perm_ok = bool(model.test_permutation(cat, adj, ln))
+        # the RGCN-attention sub-network of the first coupling in isolation (a plain PyTorch module on both sides)
+        pad = create_channel_mask(ln, max_len=N)
+        sub_in = torch.randn(B, N, 2, generator=g) * pad
+        sub_out = model.flow_layers[3].nn(sub_in, adjacency=adj, channel_padding_mask=pad)
+    c = dict(meta=dict(B=B, N=N, D=2, K=8, hidden=32, layers=2, flows=2, rev_ok=rev_ok, perm_ok=perm_ok,
+                       infos=[l.info() for l in model.flow_layers]),
+             categ=cat, adjacency=adj, length=ln, u=u, z=z, ldj=ldj, decoded=dec, sub_in=sub_in, sub_out=sub_out)
+    for k, v in model.state_dict().items():
+        c["sd_" + k] = v
+    save("graph_node_flow", [c])
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
     gen_affine()
@@ -718,3 +772,4 @@ if __name__ == "__main__":
     gen_node_edge()
     gen_data_init()
     gen_grads()
+    gen_graph_node_flow()
