@@ -8,7 +8,7 @@ import ctypes
 import torch
 
 from . import _lib, ops
-from .ops import _f32, _mask_desc, _opt_f32, _pad2d, _length, _ptr, _stream
+from .ops import _f32, _launch, _mask_desc, _opt_f32, _pad2d, _length, _ptr, _stream
 
 
 def _ws(param_count, device):
@@ -46,10 +46,9 @@ class AffineCouplingFn(torch.autograd.Function):
         g_z, g_nn = torch.empty_like(z_out), torch.empty_like(nn_c)
         g_sf = torch.empty(D, dtype=torch.float32, device=dev) if sf is not None else None
         ws = _ws(D, dev) if sf is not None else None
-        lib = _lib.load()
-        _lib.check(lib.cnf_affine_coupling_bwd(_ptr(z_out), _ptr(nn_c), _ptr(sfc), _ptr(m), mr, mc, _ptr(_g(g_zout)),
+        _launch(dev, "cnf_affine_coupling_bwd", _ptr(z_out), _ptr(nn_c), _ptr(sfc), _ptr(m), mr, mc, _ptr(_g(g_zout)),
                                                _ptr(_g(g_ldj)), _ptr(g_z), _ptr(g_nn), _ptr(g_sf), _ptr(ws), B, N, D,
-                                               int(ctx.reverse), _stream(dev)), "cnf_affine_coupling_bwd")
+                                               int(ctx.reverse), _stream(dev))
         return g_z, g_nn.view_as(nn_out), (g_sf.view_as(sf) if sf is not None else None), (g_ldj if ctx.has_ldj else None), None, None
 
 
@@ -72,9 +71,8 @@ class ExtActNormFn(torch.autograd.Function):
         nn_c = _f32(nn_out, "nn_out")
         p2 = _pad2d(pad, B, N, dev) if ctx.has_pad else None
         g_z, g_nn = torch.empty_like(z_out), torch.empty_like(nn_c)
-        lib = _lib.load()
-        _lib.check(lib.cnf_ext_actnorm_bwd(_ptr(z_out), _ptr(nn_c), _ptr(p2), _ptr(_g(g_zout)), _ptr(_g(g_ldj)), _ptr(g_z),
-                                           _ptr(g_nn), B, N, D, int(ctx.reverse), _stream(dev)), "cnf_ext_actnorm_bwd")
+        _launch(dev, "cnf_ext_actnorm_bwd", _ptr(z_out), _ptr(nn_c), _ptr(p2), _ptr(_g(g_zout)), _ptr(_g(g_ldj)), _ptr(g_z),
+                                           _ptr(g_nn), B, N, D, int(ctx.reverse), _stream(dev))
         return g_z, g_nn.view_as(nn_out), (g_ldj if ctx.has_ldj else None), None, None
 
 
@@ -101,10 +99,9 @@ class ActNormFn(torch.autograd.Function):
         g_b = torch.empty(D, dtype=torch.float32, device=dev)
         g_s = torch.empty(D, dtype=torch.float32, device=dev)
         ws = _ws(2 * D, dev)
-        lib = _lib.load()
-        _lib.check(lib.cnf_actnorm_bwd(_ptr(z_out), _ptr(_f32(bias.reshape(-1), "bias")), _ptr(_f32(scales.reshape(-1), "scales")),
+        _launch(dev, "cnf_actnorm_bwd", _ptr(z_out), _ptr(_f32(bias.reshape(-1), "bias")), _ptr(_f32(scales.reshape(-1), "scales")),
                                        _ptr(p2), _ptr(ln), _ptr(_g(g_zout)), _ptr(_g(g_ldj)), _ptr(g_z), _ptr(g_b), _ptr(g_s),
-                                       _ptr(ws), B, N, D, int(ctx.reverse), _stream(dev)), "cnf_actnorm_bwd")
+                                       _ptr(ws), B, N, D, int(ctx.reverse), _stream(dev))
         return g_z, g_b.view_as(bias), g_s.view_as(scales), (g_ldj if ctx.has_ldj else None), None, None, None
 
 
@@ -132,9 +129,8 @@ class InvConvFn(torch.autograd.Function):
         g_w = torch.empty(D, D, dtype=torch.float32, device=dev)
         g_s = torch.empty(1, dtype=torch.float32, device=dev)
         ws = _ws(D * D + 1, dev)
-        lib = _lib.load()
-        _lib.check(lib.cnf_invconv_bwd(_ptr(xc), _ptr(wc), _ptr(p2), _ptr(ln), _ptr(_g(g_zout)), _ptr(_g(g_ldj)), _ptr(g_x),
-                                       _ptr(g_w), _ptr(g_s), _ptr(ws), B, N, D, int(ctx.reverse), _stream(dev)), "cnf_invconv_bwd")
+        _launch(dev, "cnf_invconv_bwd", _ptr(xc), _ptr(wc), _ptr(p2), _ptr(ln), _ptr(_g(g_zout)), _ptr(_g(g_ldj)), _ptr(g_x),
+                                       _ptr(g_w), _ptr(g_s), _ptr(ws), B, N, D, int(ctx.reverse), _stream(dev))
         return g_x, g_w, g_s.view_as(sldj), (g_ldj if ctx.has_ldj else None), None, None, None
 
 
@@ -151,9 +147,8 @@ class LogisticLogProbFn(torch.autograd.Function):
         (x,) = ctx.saved_tensors
         xc = _f32(x, "x")
         g_x = torch.empty_like(xc)
-        lib = _lib.load()
-        _lib.check(lib.cnf_logistic_log_prob_bwd(_ptr(xc), _ptr(_g(g)), _ptr(g_x), xc.numel(), ctx.mu, ctx.sigma,
-                                                 _stream(xc.device)), "cnf_logistic_log_prob_bwd")
+        _launch(xc.device, "cnf_logistic_log_prob_bwd", _ptr(xc), _ptr(_g(g)), _ptr(g_x), xc.numel(), ctx.mu, ctx.sigma,
+                                                 _stream(xc.device))
         return g_x.view_as(x), None, None, None
 
 
@@ -178,9 +173,8 @@ class PriorNllFn(torch.autograd.Function):
         ln = _length(length, B, dev) if ctx.has_len else None
         g_z = torch.empty_like(zc)
         g_ldj = torch.empty(B, dtype=torch.float32, device=dev)
-        lib = _lib.load()
-        _lib.check(lib.cnf_prior_nll_bwd(_ptr(zc), _ptr(p2), _ptr(ln), _ptr(_g(g_nll)), _ptr(g_z), _ptr(g_ldj), B, N, D,
-                                         float(ops.LOGISTIC_SIGMA), _stream(dev)), "cnf_prior_nll_bwd")
+        _launch(dev, "cnf_prior_nll_bwd", _ptr(zc), _ptr(p2), _ptr(ln), _ptr(_g(g_nll)), _ptr(g_z), _ptr(g_ldj), B, N, D,
+                                         float(ops.LOGISTIC_SIGMA), _stream(dev))
         return g_z, g_ldj, None, None
 
 
@@ -200,9 +194,8 @@ class SigmoidFlowFn(torch.autograd.Function):
         B = zc.shape[0]
         L = zc.numel() // B
         g_z = torch.empty_like(zc)
-        lib = _lib.load()
-        _lib.check(lib.cnf_sigmoid_flow_bwd(_ptr(zc), _ptr(_g(g_zout)), _ptr(_g(g_ldj)), _ptr(g_z), B, L, int(ctx.reverse),
-                                            ctx.alpha, _stream(zc.device)), "cnf_sigmoid_flow_bwd")
+        _launch(zc.device, "cnf_sigmoid_flow_bwd", _ptr(zc), _ptr(_g(g_zout)), _ptr(_g(g_ldj)), _ptr(g_z), B, L, int(ctx.reverse),
+                                            ctx.alpha, _stream(zc.device))
         return g_z, (g_ldj if ctx.has_ldj else None), None, None
 
 
@@ -238,11 +231,9 @@ class MixtureCouplingFn(torch.autograd.Function):
         g_sf = torch.empty(D, dtype=torch.float32, device=dev) if has_sf else None
         g_msf = torch.empty(D, K, dtype=torch.float32, device=dev) if has_msf else None
         ws = _ws(D + D * K, dev)
-        lib = _lib.load()
-        _lib.check(lib.cnf_mixture_coupling_bwd(_ptr(zc), _ptr(nn_c), _ptr(sfc), _ptr(msfc), _ptr(m), mr, mc, _ptr(p2), int(pit), int(pout),
+        _launch(dev, "cnf_mixture_coupling_bwd", _ptr(zc), _ptr(nn_c), _ptr(sfc), _ptr(msfc), _ptr(m), mr, mc, _ptr(p2), int(pit), int(pout),
                                                 _ptr(_g(g_zout)), _ptr(_g(g_ldj)), _ptr(g_z), _ptr(g_nn), _ptr(g_sf), _ptr(g_msf), _ptr(ws),
-                                                B, N, D, K, reg_max, reg_factor, int(is_training), _stream(dev)),
-                   "cnf_mixture_coupling_bwd")
+                                                B, N, D, K, reg_max, reg_factor, int(is_training), _stream(dev))
         return (g_z, g_nn.view_as(nn_out), (g_sf.view_as(sf) if has_sf else None), (g_msf.view_as(msf) if has_msf else None),
                 (g_ldj if has_ldj else None), None, None, None, None, None, None, None, None)
 
@@ -271,11 +262,9 @@ class EncoderForwardFn(torch.autograd.Function):
         p2 = _pad2d(pad, B, N, dev) if ctx.has_pad else None
         g_table = torch.empty_like(tc)
         ws = _ws(C * 2 * D, dev)
-        lib = _lib.load()
-        _lib.check(lib.cnf_encoder_forward_bwd(_ptr(categ.contiguous()), _ptr(ec), _ptr(tc), _ptr(pc), _ptr(p2), ctx.beta,
+        _launch(dev, "cnf_encoder_forward_bwd", _ptr(categ.contiguous()), _ptr(ec), _ptr(tc), _ptr(pc), _ptr(p2), ctx.beta,
                                                _ptr(_g(g_zout)), _ptr(_g(g_ldj)), _ptr(g_table), _ptr(ws), B, N, D, C,
-                                               float(ops.LOGISTIC_SIGMA), float(ops.LOGISTIC_LOG_SIGMA), _stream(dev)),
-                   "cnf_encoder_forward_bwd")
+                                               float(ops.LOGISTIC_SIGMA), float(ops.LOGISTIC_LOG_SIGMA), _stream(dev))
         return g_table, None, None, None, None, None, None
 
 
@@ -303,9 +292,8 @@ class AffineParamsFn(torch.autograd.Function):
         g_nn = torch.empty_like(nn_c)
         g_sf = torch.empty(D, dtype=torch.float32, device=dev) if has_sf else None
         ws = _ws(D, dev) if has_sf else None
-        lib = _lib.load()
-        _lib.check(lib.cnf_affine_params_bwd(_ptr(nn_c), _ptr(sfc), _ptr(m), mr, mc, _ptr(_g(g_s)), _ptr(_g(g_t)), _ptr(g_nn),
-                                             _ptr(g_sf), _ptr(ws), B, N, D, _stream(dev)), "cnf_affine_params_bwd")
+        _launch(dev, "cnf_affine_params_bwd", _ptr(nn_c), _ptr(sfc), _ptr(m), mr, mc, _ptr(_g(g_s)), _ptr(_g(g_t)), _ptr(g_nn),
+                                             _ptr(g_sf), _ptr(ws), B, N, D, _stream(dev))
         return g_nn.view_as(nn_out), (g_sf.view_as(sf) if has_sf else None), None
 
 
@@ -325,10 +313,8 @@ class AffineTransformFn(torch.autograd.Function):
         dev = z_out.device
         B, N, D = z_out.shape
         g_z, g_s, g_t = torch.empty_like(z_out), torch.empty_like(z_out), torch.empty_like(z_out)
-        lib = _lib.load()
-        _lib.check(lib.cnf_affine_transform_bwd(_ptr(z_out), _ptr(s), _ptr(t), _ptr(_g(g_zout)), _ptr(_g(g_ldj)), _ptr(g_z),
-                                                _ptr(g_s), _ptr(g_t), B, N, D, int(ctx.reverse), _stream(dev)),
-                   "cnf_affine_transform_bwd")
+        _launch(dev, "cnf_affine_transform_bwd", _ptr(z_out), _ptr(s), _ptr(t), _ptr(_g(g_zout)), _ptr(_g(g_ldj)), _ptr(g_z),
+                                                _ptr(g_s), _ptr(g_t), B, N, D, int(ctx.reverse), _stream(dev))
         return g_z, g_s.sum_to_size(ctx.shapes[0]), g_t.sum_to_size(ctx.shapes[1]), None
 
 
@@ -364,9 +350,8 @@ class MixtureParamsFn(torch.autograd.Function):
         ws = _ws(D + D * K, dev)
         dd = lambda t: None if t is None else (t.double().contiguous())
         gs = [dd(x) for x in (g_t, g_log_s, g_log_pi, g_mu, g_ls)]
-        lib = _lib.load()
-        _lib.check(lib.cnf_mixture_params_bwd(_ptr(nn_c), _ptr(sfc), _ptr(msfc), _ptr(m), mr, mc, *[_ptr(x) for x in gs], _ptr(g_nn),
-                                              _ptr(g_sf), _ptr(g_msf), _ptr(ws), B, N, D, K, _stream(dev)), "cnf_mixture_params_bwd")
+        _launch(dev, "cnf_mixture_params_bwd", _ptr(nn_c), _ptr(sfc), _ptr(msfc), _ptr(m), mr, mc, *[_ptr(x) for x in gs], _ptr(g_nn),
+                                              _ptr(g_sf), _ptr(g_msf), _ptr(ws), B, N, D, K, _stream(dev))
         return g_nn.view_as(nn_out), (g_sf.view_as(sf) if has_sf else None), (g_msf.view_as(msf) if has_msf else None), None, None
 
 
@@ -402,10 +387,9 @@ class MixtureTransformFn(torch.autograd.Function):
         g_z, g_t, g_s = torch.empty_like(z64), torch.empty_like(z64), torch.empty_like(z64)
         g_pi, g_mu, g_ls = torch.empty_like(pi64), torch.empty_like(pi64), torch.empty_like(pi64)
         dd = lambda x: None if x is None else x.double().contiguous()
-        lib = _lib.load()
-        _lib.check(lib.cnf_mixture_transform_bwd(_ptr(z64), _ptr(t64), _ptr(s64), _ptr(pi64), _ptr(mu64), _ptr(ls64), _ptr(m), mr, mc, _ptr(p2),
+        _launch(dev, "cnf_mixture_transform_bwd", _ptr(z64), _ptr(t64), _ptr(s64), _ptr(pi64), _ptr(mu64), _ptr(ls64), _ptr(m), mr, mc, _ptr(p2),
                                                  _ptr(dd(g_zout)), _ptr(dd(g_ldj)), _ptr(g_z), _ptr(g_t), _ptr(g_s), _ptr(g_pi), _ptr(g_mu), _ptr(g_ls),
-                                                 B, N, D, K, reg_max, reg_factor, int(is_training), _stream(dev)), "cnf_mixture_transform_bwd")
+                                                 B, N, D, K, reg_max, reg_factor, int(is_training), _stream(dev))
         return (g_z.to(z.dtype), g_t.sum_to_size(t.shape), g_s.sum_to_size(log_s.shape), g_pi.sum_to_size(log_pi.shape),
                 g_mu.sum_to_size(mu.shape), g_ls.sum_to_size(ls.shape), None, None, None, None, None)
 

@@ -63,6 +63,19 @@ def _stream(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+def _launch(dev, name, *args):
+    """Call one C-ABI entry point with `dev` as the current HIP device (a stream can only be launched into
+    from its own device; multi-GPU-per-process callers such as nn.DataParallel threads rely on this)."""
+    fn = getattr(_lib.load(), name)
+    if dev.index is not None and dev.index != torch.cuda.current_device():
+        with torch.cuda.device(dev):
+            status = fn(*args)
+    else:
+        status = fn(*args)
+    if status != _lib.CNF_OK:
+        _lib.check(status, name)
+
+
 def flag_word(device):
     """The per-device int32 word the kernels OR their CNF_FLAG_* bits into."""
     key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
@@ -162,10 +175,9 @@ def affine_coupling(z, nn_out, scaling_factor, mask, reverse=False, ldj=None):
     m, mr, mc = _mask_desc(mask, D, dev)
     ldj_in, ldj_out = _ldj_io(ldj, B, dev, inplace=False)
     z_out = torch.empty_like(z)
-    lib = _lib.load()
-    _lib.check(lib.cnf_affine_coupling(_ptr(z), _ptr(nn_out), _ptr(sf), _ptr(m), mr, mc, _ptr(ldj_in),
+    _launch(dev, "cnf_affine_coupling", _ptr(z), _ptr(nn_out), _ptr(sf), _ptr(m), mr, mc, _ptr(ldj_in),
                                        _ptr(z_out), _ptr(ldj_out), B, N, D, int(bool(reverse)),
-                                       _ptr(flag_word(dev)), _stream(dev)), "cnf_affine_coupling")
+                                       _ptr(flag_word(dev)), _stream(dev))
     _after(dev, "affine coupling")
     return z_out, ldj_out
 
@@ -179,9 +191,8 @@ def affine_params(nn_out, mask, scaling_factor=None):
     m, mr, mc = _mask_desc(mask, D, dev)
     s = torch.empty(B, N, D, dtype=torch.float32, device=dev)
     t = torch.empty_like(s)
-    lib = _lib.load()
-    _lib.check(lib.cnf_affine_params(_ptr(nn_out), _ptr(sf), _ptr(m), mr, mc, _ptr(s), _ptr(t), B, N, D,
-                                     _stream(dev)), "cnf_affine_params")
+    _launch(dev, "cnf_affine_params", _ptr(nn_out), _ptr(sf), _ptr(m), mr, mc, _ptr(s), _ptr(t), B, N, D,
+                                     _stream(dev))
     return s, t
 
 
@@ -193,10 +204,8 @@ def affine_transform(z, s, t, reverse=False):
         s, t = s.expand_as(z).contiguous(), t.expand_as(z).contiguous()
     z_out = torch.empty_like(z)
     ldj = torch.empty(B, dtype=torch.float32, device=dev)
-    lib = _lib.load()
-    _lib.check(lib.cnf_affine_transform(_ptr(z), _ptr(s), _ptr(t), None, _ptr(z_out), _ptr(ldj), B, N, D,
-                                        int(bool(reverse)), _ptr(flag_word(dev)), _stream(dev)),
-               "cnf_affine_transform")
+    _launch(dev, "cnf_affine_transform", _ptr(z), _ptr(s), _ptr(t), None, _ptr(z_out), _ptr(ldj), B, N, D,
+                                        int(bool(reverse)), _ptr(flag_word(dev)), _stream(dev))
     return z_out, ldj
 
 
@@ -211,10 +220,8 @@ def actnorm(z, bias, scales, reverse=False, length=None, channel_padding_mask=No
     ln = _length(length, B, dev)
     ldj_in, ldj_out = _ldj_io(ldj, B, dev, inplace=True)
     z_out = torch.empty_like(z)
-    lib = _lib.load()
-    _lib.check(lib.cnf_actnorm(_ptr(z), _ptr(b), _ptr(s), _ptr(pad), _ptr(ln), _ptr(ldj_in), _ptr(z_out),
-                               _ptr(ldj_out), B, N, D, int(bool(reverse)), _ptr(flag_word(dev)), _stream(dev)),
-               "cnf_actnorm")
+    _launch(dev, "cnf_actnorm", _ptr(z), _ptr(b), _ptr(s), _ptr(pad), _ptr(ln), _ptr(ldj_in), _ptr(z_out),
+                               _ptr(ldj_out), B, N, D, int(bool(reverse)), _ptr(flag_word(dev)), _stream(dev))
     _after(dev, "ActNorm")
     return z_out, ldj_out
 
@@ -225,14 +232,12 @@ def actnorm_data_init(x, channel_padding_mask=None):
     dev = x.device
     B, N, D = x.shape
     pad = _pad2d(channel_padding_mask, B, N, dev)
-    lib = _lib.load()
     acc = torch.zeros(D + 1, dtype=torch.float64, device=dev)
-    _lib.check(lib.cnf_actnorm_stats(_ptr(x), _ptr(pad), None, _ptr(acc), B, N, D, 0, _stream(dev)),
-               "cnf_actnorm_stats")
+    _launch(dev, "cnf_actnorm_stats", _ptr(x), _ptr(pad), None, _ptr(acc), B, N, D, 0, _stream(dev))
     mean = acc[:D] / acc[D]
     acc2 = torch.zeros(D + 1, dtype=torch.float64, device=dev)
-    _lib.check(lib.cnf_actnorm_stats(_ptr(x), _ptr(pad), _ptr(mean.contiguous()), _ptr(acc2), B, N, D, 1,
-                                     _stream(dev)), "cnf_actnorm_stats")
+    _launch(dev, "cnf_actnorm_stats", _ptr(x), _ptr(pad), _ptr(mean.contiguous()), _ptr(acc2), B, N, D, 1,
+                                     _stream(dev))
     var = acc2[:D] / acc[D]
     bias = (-mean).float().view(1, 1, D)
     scales = (-0.5 * var.log()).float().view(1, 1, D)
@@ -249,10 +254,8 @@ def ext_actnorm(z, nn_out, reverse=False, channel_padding_mask=None, ldj=None):
     pad = _pad2d(channel_padding_mask, B, N, dev) if isinstance(channel_padding_mask, torch.Tensor) else None
     ldj_in, ldj_out = _ldj_io(ldj, B, dev, inplace=True)
     z_out = torch.empty_like(z)
-    lib = _lib.load()
-    _lib.check(lib.cnf_ext_actnorm(_ptr(z), _ptr(nn_out), _ptr(pad), _ptr(ldj_in), _ptr(z_out), _ptr(ldj_out),
-                                   B, N, D, int(bool(reverse)), _ptr(flag_word(dev)), _stream(dev)),
-               "cnf_ext_actnorm")
+    _launch(dev, "cnf_ext_actnorm", _ptr(z), _ptr(nn_out), _ptr(pad), _ptr(ldj_in), _ptr(z_out), _ptr(ldj_out),
+                                   B, N, D, int(bool(reverse)), _ptr(flag_word(dev)), _stream(dev))
     _after(dev, "ExtActNorm")
     return z_out, ldj_out
 
@@ -268,10 +271,8 @@ def invconv(x, weight, sldj, reverse=False, length=None, channel_padding_mask=No
     ln = _length(length, B, dev) if isinstance(length, torch.Tensor) else None
     ldj_in, ldj_out = _ldj_io(ldj, B, dev, inplace=False)
     z_out = torch.empty_like(x)
-    lib = _lib.load()
-    _lib.check(lib.cnf_invconv(_ptr(x), _ptr(w), _ptr(sl), _ptr(pad), _ptr(ln), _ptr(ldj_in), _ptr(z_out),
-                               _ptr(ldj_out), B, N, D, int(bool(reverse)), _ptr(flag_word(dev)), _stream(dev)),
-               "cnf_invconv")
+    _launch(dev, "cnf_invconv", _ptr(x), _ptr(w), _ptr(sl), _ptr(pad), _ptr(ln), _ptr(ldj_in), _ptr(z_out),
+                               _ptr(ldj_out), B, N, D, int(bool(reverse)), _ptr(flag_word(dev)), _stream(dev))
     _after(dev, "InvertibleConv")
     return z_out, ldj_out
 
@@ -290,10 +291,9 @@ def actnorm_invconv(z, bias, scales, weight, sldj, reverse=False, length=None, c
     ln = _length(length, B, dev) if isinstance(length, torch.Tensor) else None
     ldj_in, ldj_out = _ldj_io(ldj, B, dev, inplace=False)
     z_out = torch.empty_like(z)
-    lib = _lib.load()
-    _lib.check(lib.cnf_actnorm_invconv(_ptr(z), _ptr(b), _ptr(s), _ptr(w), _ptr(sl), _ptr(pad), _ptr(ln), _ptr(ldj_in),
+    _launch(dev, "cnf_actnorm_invconv", _ptr(z), _ptr(b), _ptr(s), _ptr(w), _ptr(sl), _ptr(pad), _ptr(ln), _ptr(ldj_in),
                                        _ptr(z_out), _ptr(ldj_out), B, N, D, int(bool(reverse)), _ptr(flag_word(dev)),
-                                       _stream(dev)), "cnf_actnorm_invconv")
+                                       _stream(dev))
     _after(dev, "ActNorm + InvertibleConv")
     return z_out, ldj_out
 
@@ -337,13 +337,11 @@ def mixture_coupling(z, nn_out, mask, num_mixtures, scaling_factor=None, mixture
     z_out = torch.empty_like(z)
     use_reg = (not reverse) and reg_max > 0 and is_training
     reg = torch.zeros(B, dtype=torch.float32, device=dev) if want_reg else None
-    lib = _lib.load()
-    _lib.check(lib.cnf_mixture_coupling(_ptr(z), _ptr(nn_out), _ptr(sf), _ptr(msf), _ptr(m), mr, mc,
+    _launch(dev, "cnf_mixture_coupling", _ptr(z), _ptr(nn_out), _ptr(sf), _ptr(msf), _ptr(m), mr, mc,
                                         act, n_act, _ptr(pad), int(bool(pad_in_transform)), int(bool(pad_output)),
                                         _ptr(ldj_in), _ptr(z_out), _ptr(ldj_out), _ptr(reg if use_reg else None),
                                         B, N, D, K, int(bool(reverse)), float(reg_max), float(reg_factor),
-                                        int(bool(is_training)), _ptr(flag_word(dev)), _stream(dev)),
-               "cnf_mixture_coupling")
+                                        int(bool(is_training)), _ptr(flag_word(dev)), _stream(dev))
     _after(dev, "mixture-CDF coupling")
     return z_out, ldj_out, reg
 
@@ -363,10 +361,8 @@ def mixture_params(nn_out, mask, num_mixtures, scaling_factor=None, mixture_scal
     mk = lambda *s: torch.empty(*s, dtype=torch.float64, device=dev)
     t, log_s = mk(*lead, D), mk(*lead, D)
     log_pi, mu, ls = mk(*lead, D, K), mk(*lead, D, K), mk(*lead, D, K)
-    lib = _lib.load()
-    _lib.check(lib.cnf_mixture_params(_ptr(nn_out), _ptr(sf), _ptr(msf), _ptr(m), mr, mc, _ptr(t), _ptr(log_s),
-                                      _ptr(log_pi), _ptr(mu), _ptr(ls), B, N, D, K, _stream(dev)),
-               "cnf_mixture_params")
+    _launch(dev, "cnf_mixture_params", _ptr(nn_out), _ptr(sf), _ptr(msf), _ptr(m), mr, mc, _ptr(t), _ptr(log_s),
+                                      _ptr(log_pi), _ptr(mu), _ptr(ls), B, N, D, K, _stream(dev))
     return t, log_s, log_pi, mu, ls
 
 
@@ -395,12 +391,10 @@ def mixture_transform(orig_z, t, log_s, log_pi, mixt_t, mixt_log_s, reverse=Fals
     z_out = torch.empty_like(z)
     ldj = torch.empty(B, dtype=torch.float64, device=dev)
     reg = torch.empty_like(z)
-    lib = _lib.load()
-    _lib.check(lib.cnf_mixture_transform(_ptr(z), _ptr(t), _ptr(log_s), _ptr(log_pi), _ptr(mixt_t), _ptr(mixt_log_s),
+    _launch(dev, "cnf_mixture_transform", _ptr(z), _ptr(t), _ptr(log_s), _ptr(log_pi), _ptr(mixt_t), _ptr(mixt_log_s),
                                          _ptr(m), mr, mc, act, n_act, _ptr(pad), _ptr(z_out), _ptr(ldj), _ptr(reg),
                                          B, N, D, K, int(bool(reverse)), float(reg_max), float(reg_factor),
-                                         int(bool(is_training)), _ptr(flag_word(dev)), _stream(dev)),
-               "cnf_mixture_transform")
+                                         int(bool(is_training)), _ptr(flag_word(dev)), _stream(dev))
     _after(dev, "mixture-CDF transform")
     return z_out, ldj, reg
 
@@ -410,9 +404,8 @@ def logistic_log_prob(x, mu=0.0, sigma=LOGISTIC_SIGMA, log_sigma=LOGISTIC_LOG_SI
     x = _f32(x, "x")
     dev = x.device
     out = torch.empty_like(x)
-    lib = _lib.load()
-    _lib.check(lib.cnf_logistic_log_prob(_ptr(x), _ptr(out), x.numel(), float(mu), float(sigma), float(log_sigma),
-                                         _ptr(flag_word(dev)), _stream(dev)), "cnf_logistic_log_prob")
+    _launch(dev, "cnf_logistic_log_prob", _ptr(x), _ptr(out), x.numel(), float(mu), float(sigma), float(log_sigma),
+                                         _ptr(flag_word(dev)), _stream(dev))
     _after(dev, "log-prob of distribution")
     return out
 
@@ -420,9 +413,8 @@ def logistic_log_prob(x, mu=0.0, sigma=LOGISTIC_SIGMA, log_sigma=LOGISTIC_LOG_SI
 def logistic_from_uniform(u, mu=0.0, sigma=LOGISTIC_SIGMA, eps=1e-4):
     u = _f32(u, "u")
     out = torch.empty_like(u)
-    lib = _lib.load()
-    _lib.check(lib.cnf_logistic_from_uniform(_ptr(u), _ptr(out), u.numel(), float(mu), float(sigma), float(eps),
-                                             _stream(u.device)), "cnf_logistic_from_uniform")
+    _launch(u.device, "cnf_logistic_from_uniform", _ptr(u), _ptr(out), u.numel(), float(mu), float(sigma), float(eps),
+                                             _stream(u.device))
     return out
 
 
@@ -437,9 +429,8 @@ def prior_nll(z, ldj, length=None, channel_padding_mask=None, sums=None,
     ldj = _opt_f32(ldj, "ldj", dev)
     neglog = torch.empty(B, dtype=torch.float32, device=dev)
     nll = torch.empty(B, dtype=torch.float32, device=dev)
-    lib = _lib.load()
-    _lib.check(lib.cnf_prior_nll(_ptr(z), _ptr(pad), _ptr(ldj), _ptr(ln), _ptr(neglog), _ptr(nll), _ptr(sums),
-                                 B, N, D, float(sigma), float(log_sigma), _stream(dev)), "cnf_prior_nll")
+    _launch(dev, "cnf_prior_nll", _ptr(z), _ptr(pad), _ptr(ldj), _ptr(ln), _ptr(neglog), _ptr(nll), _ptr(sums),
+                                 B, N, D, float(sigma), float(log_sigma), _stream(dev))
     return neglog, nll
 
 
@@ -460,10 +451,9 @@ def encoder_forward(categ, eps, table, category_prior, beta=1.0, channel_padding
     ldj_in, ldj_out = _ldj_io(ldj, B, dev, inplace=False)
     z = torch.empty(B, N, D, dtype=torch.float32, device=dev)
     cpl = torch.empty(B * N, dtype=torch.float32, device=dev) if want_class_prob else None
-    lib = _lib.load()
-    _lib.check(lib.cnf_encoder_forward(_ptr(categ), _ptr(eps), _ptr(table), _ptr(prior), _ptr(pad), float(beta),
+    _launch(dev, "cnf_encoder_forward", _ptr(categ), _ptr(eps), _ptr(table), _ptr(prior), _ptr(pad), float(beta),
                                        _ptr(ldj_in), _ptr(z), _ptr(ldj_out), _ptr(cpl), B, N, D, C, float(sigma),
-                                       float(log_sigma), _ptr(flag_word(dev)), _stream(dev)), "cnf_encoder_forward")
+                                       float(log_sigma), _ptr(flag_word(dev)), _stream(dev))
     _after(dev, "categorical encoder")
     return z, ldj_out, cpl
 
@@ -476,9 +466,8 @@ def encoder_decode(z, table, category_prior, sigma=LOGISTIC_SIGMA, log_sigma=LOG
     C = table.shape[0]
     prior = _f32(category_prior, "category_prior")
     out = torch.empty(B, N, dtype=torch.int64, device=dev)
-    lib = _lib.load()
-    _lib.check(lib.cnf_encoder_decode(_ptr(z), _ptr(table), _ptr(prior), _ptr(out), B, N, D, C, float(sigma),
-                                      float(log_sigma), _stream(dev)), "cnf_encoder_decode")
+    _launch(dev, "cnf_encoder_decode", _ptr(z), _ptr(table), _ptr(prior), _ptr(out), B, N, D, C, float(sigma),
+                                      float(log_sigma), _stream(dev))
     return out
 
 
@@ -489,9 +478,8 @@ def sigmoid_flow(z, reverse=False, ldj=None, alpha=1e-5):
     L = z.numel() // B
     ldj_in, ldj_out = _ldj_io(ldj, B, dev, inplace=False)
     z_out = torch.empty_like(z)
-    lib = _lib.load()
-    _lib.check(lib.cnf_sigmoid_flow(_ptr(z), _ptr(ldj_in), _ptr(z_out), _ptr(ldj_out), B, L, int(bool(reverse)),
-                                    float(alpha), _ptr(flag_word(dev)), _stream(dev)), "cnf_sigmoid_flow")
+    _launch(dev, "cnf_sigmoid_flow", _ptr(z), _ptr(ldj_in), _ptr(z_out), _ptr(ldj_out), B, L, int(bool(reverse)),
+                                    float(alpha), _ptr(flag_word(dev)), _stream(dev))
     _after(dev, "SigmoidFlow")
     return z_out, ldj_out
 
