@@ -140,6 +140,8 @@ def mixture_measure(ops, dev, steps=20, warmup=3):
 def main():
     args = parse()
     from categoricalnf_amd import _lib, ops
+    if os.environ.get("CNF_LIB_OVERRIDE"):          # A/B of alternative builds of the same ABI (tools only)
+        _lib.LIB_PATH = os.environ["CNF_LIB_OVERRIDE"]
     from categoricalnf_amd.distributed import init_process_group
     from categoricalnf_amd.layers.flows.coupling_layer import CouplingLayer
     channel_mask = CouplingLayer.create_channel_mask
