@@ -39,6 +39,8 @@ SIGNATURES = {
                               _i, _i, _i, _i, _i, _d, _d, _i, _p, _p],
     "cnf_logistic_log_prob": [_p, _p, _i64, _f, _f, _f, _p, _p],
     "cnf_logistic_from_uniform": [_p, _p, _i64, _f, _f, _f, _p],
+    "cnf_affine_coupling_nll": [_p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _p, _p],
+    "cnf_nll_sum": [_p, _i, _p, _p],
     "cnf_prior_nll": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _p],
     "cnf_encoder_forward": [_p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p, _p],
     "cnf_encoder_decode": [_p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],

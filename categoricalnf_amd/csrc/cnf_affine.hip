@@ -7,24 +7,59 @@
 #include "cnf_common.h"
 
 #include <algorithm>
+#include <type_traits>
 
 namespace cnf {
 
 // per (mask-row, channel) constants staged in LDS: keep = 1-mask, keepf = keep*e^sf, fc = max(e^sf,1)
+// exact math: x2 = fc;  fast math: x2 = -2 keepf, x3 = 2 log2(e) / fc, so that
+// tanh(s / fc) * keepf = keepf - 2 keepf / (2^{s x3} + 1) is mul, exp2, add, rcp, fma
 struct alignas(16) ChanTab {
-    float keep, keepf, fc, inv_fc;
+    float keep, keepf, x2, x3;
 };
 
 // FAST = hardware transcendental path: exp via v_exp_f32, tanh(x) = 1 - 2/(e^{2x}+1)
 template <bool FAST>
-__device__ __forceinline__ float exp_m(float x) { return FAST ? __expf(x) : expf(x); }
+__device__ __forceinline__ float exp_m(float x) { return FAST ? __builtin_amdgcn_exp2f(x * 1.4426950408889634f) : expf(x); }
 template <bool FAST>
 __device__ __forceinline__ float tanh_m(float x) {
     if (!FAST) return tanhf(x);
-    const float e = __expf(2.f * x);
-    return 1.f - __fdividef(2.f, e + 1.f);
+    // v_exp_f32 + v_rcp_f32 (1 ulp each); HIP's __fdividef is a full IEEE division (~10 instructions)
+    const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+    return 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
 }
 constexpr int kMaxTab = 64;     // (mask period) x D entries, one private copy per wave
+
+// logistic prior log-prob (distributions.py:129-136,154-163):
+// softplus(v) + softplus(-v) = |v| + 2 log(1 + e^{-|v|}); one exp and one log instead of two each
+// (identical to F.softplus's thresholded form to fp32 rounding: for |v| > 20 the log term is < 5e-9)
+__device__ __forceinline__ float logistic_logp(float x, float mu, float sigma, float log_sigma) {
+    const float v = fabsf((x - mu) / sigma);
+    return -((v + 2.f * __logf(1.f + __expf(-v))) + log_sigma);
+}
+// the same for mu = 0 with the constants folded on the host: a = 1/sigma, a2 = log2(e)/sigma; the hardware
+// exp2 / log2 are used directly (no range-scaling code, no fp32 division): 8 VALU instructions per element
+struct PriorConst {
+    float inv_sigma, inv_sigma_log2e, log_sigma;
+};
+inline PriorConst make_prior_const(float sigma, float log_sigma) {
+    PriorConst c;
+    c.inv_sigma = (float)(1.0 / (double)sigma);
+    c.inv_sigma_log2e = (float)(1.4426950408889634 / (double)sigma);
+    c.log_sigma = log_sigma;
+    return c;
+}
+// -(softplus pair) without the constant: lp + log_sigma, as two fused multiply-adds
+__device__ __forceinline__ float prior_logp_nc(float x, const PriorConst& c) {
+    const float ax = fabsf(x);
+    const float l2 = __builtin_amdgcn_logf(1.f + __builtin_amdgcn_exp2f(-ax * c.inv_sigma_log2e));
+    return fmaf(l2, -1.3862943611198906f, -ax * c.inv_sigma);
+}
+__device__ __forceinline__ float prior_logp(float x, const PriorConst& c) {
+    const float ax = fabsf(x);
+    const float l2 = __builtin_amdgcn_logf(1.f + __builtin_amdgcn_exp2f(-ax * c.inv_sigma_log2e));
+    return -((ax * c.inv_sigma + 1.3862943611198906f * l2) + c.log_sigma);
+}
 
 struct AffineArgs {
     const float* z;
@@ -36,7 +71,15 @@ struct AffineArgs {
     float* ldj_out;
     int* flags;
     int N, D, L, mr, mc, reverse;
-    FastDiv div_d;
+    int P;                 // mask period x D: length of the per-channel constant table
+    FastDiv div_d, div_p;
+    // NLL epilogue (forward only; affine_coupling_kernel<..., NLL = true>): the prior term of z_out is
+    // accumulated while z_out is still in registers, so the NLL assembly never re-reads it
+    const float* pad;
+    const float* length;
+    float* neglog_out;
+    float* nll_out;
+    PriorConst prior;
 };
 
 template <int VEC>
@@ -108,19 +151,27 @@ struct AffineChunk {
     float zv[VEC], sr[VEC], tr[VEC];
 };
 
-template <int VEC, int U, bool HAS_SF, bool REVERSE, bool FAST>
+// NLLM: 0 = coupling only, 1 = + NLL epilogue, 2 = + NLL epilogue with a padding mask on the prior term
+template <int VEC, int U, bool HAS_SF, bool REVERSE, bool FAST, int NLLM = 0>
 __global__ __launch_bounds__(kBlock) void affine_coupling_kernel(AffineArgs a, RowTiling tl) {
-    __shared__ float part[kWavesPerBlock][kMaxTileChunks];
+    constexpr bool NLL = NLLM != 0;
+    using Acc = typename std::conditional<NLL, Sum2, float>::type;
+    // per-wave strip of row partials, sized by the host to the tile (rw * cpr entries; unused when rw == 1)
+    extern __shared__ __attribute__((aligned(16))) char part_raw[];
+    Acc* part = reinterpret_cast<Acc*>(part_raw) + (size_t)(threadIdx.x >> 6) * (tl.rw * tl.cpr);
     __shared__ ChanTab tab_all[kWavesPerBlock][kMaxTab];
     ChanTab* tab = tab_all[threadIdx.x >> 6];
     // per-wave constant table: its two tiny loads are issued FIRST, the table itself is finished
     // after the first chunk loads are in flight (vmcnt is in-order, so waiting for these does not
     // wait for the chunk loads issued behind them) — see walk_row_tile_split.
-    const int ntab = a.mr * a.D;
+    // The table holds the period P = (mask rows) x D once plus its first VEC - 1 entries again, so that the
+    // VEC consecutive elements of a chunk read entries i0 .. i0 + VEC - 1 with no wrap-around logic.
+    const int ntab = a.P + VEC - 1;
     const int ti = threadIdx.x & 63;
     float m_raw = 0.f, sf_raw = 0.f;
     if (ti < ntab) {
-        const int r = ti / a.D, d = ti - r * a.D;
+        const int tp = ti % a.P;
+        const int r = tp / a.D, d = tp - r * a.D;
         if (a.mask) m_raw = a.mask[r * a.mc + (a.mc == 1 ? 0 : d)];
         if (HAS_SF) sf_raw = a.sf[d];
     }
@@ -130,11 +181,12 @@ __global__ __launch_bounds__(kBlock) void affine_coupling_kernel(AffineArgs a, R
         asm volatile("" : "+v"(sf_raw), "+v"(m_raw) : : "memory");
         if (ti < ntab) {
             const float f = HAS_SF ? expf(sf_raw) : 1.f;
+            const float fc = fmaxf(f, 1.f);
             ChanTab t;
             t.keep = 1.f - m_raw;
             t.keepf = (1.f - m_raw) * f;
-            t.fc = fmaxf(f, 1.f);
-            t.inv_fc = 1.f / fmaxf(f, 1.f);
+            t.x2 = FAST ? -2.f * t.keepf : fc;
+            t.x3 = 2.8853900817779268f / fc;
             tab[ti] = t;
         }
         wave_lds_sync();
@@ -148,36 +200,57 @@ __global__ __launch_bounds__(kBlock) void affine_coupling_kernel(AffineArgs a, R
         VecIO<VEC>::load_st(a.nn + 2 * off, c.sr, c.tr);
         return c;
     };
-    auto proc = [&](const AffineChunk<VEC>& c, int row, int e0) -> float {
+    auto proc = [&](const AffineChunk<VEC>& c, int row, int e0) -> Acc {
         const size_t off = (size_t)row * a.L + e0;
         float out[VEC];
-        int n = (int)fdiv((uint32_t)e0, a.div_d);
-        int d = e0 - n * a.D;
-        int nm = a.mr == 1 ? 0 : n % a.mr;
-        float acc = 0.f;
+        const ChanTab* tb0 = tab + (e0 - (int)fdiv((uint32_t)e0, a.div_p) * a.P);   // e0 mod P
+        float acc = 0.f, lp_acc = 0.f;
+        const float* padrow = NLLM == 2 ? a.pad + (size_t)row * a.N : nullptr;
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-            const ChanTab tb = tab[nm * a.D + d];
-            const float s = HAS_SF ? tanh_m<FAST>(FAST ? c.sr[j] * tb.inv_fc : c.sr[j] / tb.fc) * tb.keepf : c.sr[j] * tb.keep;
+            const ChanTab tb = tb0[j];
+            float s;
+            if (!HAS_SF) s = c.sr[j] * tb.keep;
+            else if (FAST) s = fmaf(__builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(c.sr[j] * tb.x3) + 1.f), tb.x2, tb.keepf);
+            else s = tanhf(c.sr[j] / tb.x2) * tb.keepf;
             const float t = c.tr[j] * tb.keep;
             out[j] = REVERSE ? c.zv[j] * exp_m<FAST>(-1.f * s) - t : (c.zv[j] + t) * exp_m<FAST>(s);
             bad |= isnan(out[j]);
             acc += s;
-            if (++d == a.D) {
-                d = 0;
-                if (++nm == a.mr) nm = 0;
+            if (NLL) {
+                if (NLLM == 2) lp_acc += prior_logp(out[j], a.prior) * padrow[fdiv((uint32_t)(e0 + j), a.div_d)];
+                else lp_acc += prior_logp_nc(out[j], a.prior);
             }
         }
         VecIO<VEC>::store(a.z_out + off, out);
-        return acc;
+        if constexpr (NLL) {
+            // un-padded rows: the constant log(sigma) of every element is added once per chunk
+            if (NLLM == 1) lp_acc -= (float)VEC * a.prior.log_sigma;
+            return Sum2(acc, lp_acc);
+        } else {
+            return acc;
+        }
     };
-    auto finish = [&](int row, float sum) {
+    auto ldj_of = [&](int row, float sum) {
         const float base = a.ldj_in ? a.ldj_in[row] : 0.f;
         const float v = REVERSE ? base - sum : base + sum;
         a.ldj_out[row] = v;
         if (isnan(v)) raise_flag(a.flags, CNF_FLAG_NAN_LDJ);
+        return v;
     };
-    walk_row_tile_split<(U == 0 ? 1 : U), float, AffineChunk<VEC>, U == 0>(tl, part[threadIdx.x >> 6], load, proc, finish, pre);
+    auto finish = [&](int row, const Acc& sum) {
+        if constexpr (NLL) {
+            // task.py:96-118: nll = (-ldj + neglog) / length
+            const float ldj = ldj_of(row, sum.a);
+            const float neglog = -sum.b;
+            const float len = a.length ? a.length[row] : (float)a.N;
+            if (a.neglog_out) a.neglog_out[row] = neglog;
+            a.nll_out[row] = (-ldj) / len + neglog / len;
+        } else {
+            ldj_of(row, sum);
+        }
+    };
+    walk_row_tile_split<(U == 0 ? 1 : U), Acc, AffineChunk<VEC>, U == 0>(tl, part, load, proc, finish, pre);
     if (bad) raise_flag(a.flags, CNF_FLAG_NAN_Z);
 }
 
@@ -185,12 +258,26 @@ template <int VEC, int U, bool FAST>
 static void launch_affine_u(const AffineArgs& a, const RowTiling& tl, bool has_sf, bool reverse,
                             hipStream_t st) {
     const dim3 grid = tiling_grid(tl), block(kBlock);
+    const size_t strip = (tl.bpr || tl.rw == 1) ? 0 : (size_t)tl.rw * tl.cpr;      // partials per wave
+    if (a.nll_out) {   // forward + NLL epilogue
+        const size_t lds = kWavesPerBlock * strip * sizeof(Sum2);
+        constexpr int UN = (U == 1) ? 1 : 2;      // the epilogue variants are built for 1 and 2 chunks in flight only
+        if (a.pad) {
+            if (has_sf) hipLaunchKernelGGL((affine_coupling_kernel<VEC, UN, true, false, FAST, 2>), grid, block, lds, st, a, tl);
+            else hipLaunchKernelGGL((affine_coupling_kernel<VEC, UN, false, false, FAST, 2>), grid, block, lds, st, a, tl);
+        } else {
+            if (has_sf) hipLaunchKernelGGL((affine_coupling_kernel<VEC, UN, true, false, FAST, 1>), grid, block, lds, st, a, tl);
+            else hipLaunchKernelGGL((affine_coupling_kernel<VEC, UN, false, false, FAST, 1>), grid, block, lds, st, a, tl);
+        }
+        return;
+    }
+    const size_t lds = kWavesPerBlock * strip * sizeof(float);
     if (has_sf) {
-        if (reverse) hipLaunchKernelGGL((affine_coupling_kernel<VEC, U, true, true, FAST>), grid, block, 0, st, a, tl);
-        else hipLaunchKernelGGL((affine_coupling_kernel<VEC, U, true, false, FAST>), grid, block, 0, st, a, tl);
+        if (reverse) hipLaunchKernelGGL((affine_coupling_kernel<VEC, U, true, true, FAST>), grid, block, lds, st, a, tl);
+        else hipLaunchKernelGGL((affine_coupling_kernel<VEC, U, true, false, FAST>), grid, block, lds, st, a, tl);
     } else {
-        if (reverse) hipLaunchKernelGGL((affine_coupling_kernel<VEC, U, false, true, FAST>), grid, block, 0, st, a, tl);
-        else hipLaunchKernelGGL((affine_coupling_kernel<VEC, U, false, false, FAST>), grid, block, 0, st, a, tl);
+        if (reverse) hipLaunchKernelGGL((affine_coupling_kernel<VEC, U, false, true, FAST>), grid, block, lds, st, a, tl);
+        else hipLaunchKernelGGL((affine_coupling_kernel<VEC, U, false, false, FAST>), grid, block, lds, st, a, tl);
     }
 }
 
@@ -369,12 +456,6 @@ __global__ __launch_bounds__(kBlock) void sigmoid_flow_kernel(SigArgs a, RowTili
 }
 
 // ---- logistic prior log-prob + NLL (distributions.py:129-136,154-163; set_modeling/task.py:96-118)
-// softplus(v) + softplus(-v) = |v| + 2 log(1 + e^{-|v|}); one exp and one log instead of two each
-// (identical to F.softplus's thresholded form to fp32 rounding: for |v| > 20 the log term is < 5e-9)
-__device__ __forceinline__ float logistic_logp(float x, float mu, float sigma, float log_sigma) {
-    const float v = fabsf((x - mu) / sigma);
-    return -((v + 2.f * __logf(1.f + __expf(-v))) + log_sigma);
-}
 struct NllArgs {
     const float* z;
     const float* pad;
@@ -384,7 +465,7 @@ struct NllArgs {
     float* nll_out;
     double* sums;
     int N, D, L;
-    float sigma, log_sigma;
+    PriorConst prior;
     FastDiv div_d;
 };
 template <int VEC>
@@ -405,7 +486,7 @@ __global__ __launch_bounds__(kBlock) void prior_nll_kernel(NllArgs a, RowTiling 
         float acc = 0.f;
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-            const float lp = logistic_logp(c.v[j], 0.f, a.sigma, a.log_sigma);
+            const float lp = prior_logp(c.v[j], a.prior);
             acc += a.pad ? lp * a.pad[(size_t)row * a.N + n] : lp;
             if (++d == a.D) {
                 d = 0;
@@ -431,13 +512,23 @@ __global__ __launch_bounds__(kBlock) void prior_nll_kernel(NllArgs a, RowTiling 
 __global__ __launch_bounds__(1024) void nll_sum_kernel(const float* nll, int B, double* sums) {
     __shared__ double sh[16];
     double acc = 0.0;
-    // four independent loads in flight per lane (the values were just written: L2 hits, latency-bound otherwise)
-    int i = threadIdx.x;
-    for (; i + 3 * 1024 < B; i += 4 * 1024) {
-        const float a0 = nll[i], a1 = nll[i + 1024], a2 = nll[i + 2048], a3 = nll[i + 3072];
-        acc += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+    // latency-bound (the values were just written: L2 hits): every lane issues all its loads before the first
+    // use — four 16-byte loads per pass when the pointer allows, i.e. one round trip for B = 16384
+    int done = 0;
+    if ((reinterpret_cast<uintptr_t>(nll) & 15) == 0) {
+        const float4* p = reinterpret_cast<const float4*>(nll);
+        const int n4 = B >> 2;
+        for (int i = threadIdx.x; i < n4; i += 4 * 1024) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = p[min(i + u * 1024, n4 - 1)];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i + u * 1024 < n4) acc += ((double)v[u].x + (double)v[u].y) + ((double)v[u].z + (double)v[u].w);
+        }
+        done = n4 << 2;
     }
-    for (; i < B; i += 1024) acc += (double)nll[i];
+    for (int i = done + threadIdx.x; i < B; i += 1024) acc += (double)nll[i];
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
     __syncthreads();
@@ -491,27 +582,56 @@ using namespace cnf;
 
 extern "C" {
 
-int cnf_affine_coupling(const float* z, const float* nn_out, const float* scaling_factor,
-                        const float* mask, int mask_rows, int mask_cols,
-                        const float* ldj_in, float* z_out, float* ldj_out,
-                        int B, int N, int D, int reverse, int* flags, cnf_stream_t stream) {
-    CNF_REQUIRE(z && nn_out && z_out && ldj_out, "cnf_affine_coupling: null tensor");
-    CNF_REQUIRE(B >= 0 && N > 0 && D > 0, "cnf_affine_coupling: bad shape B=%d N=%d D=%d", B, N, D);
+static int affine_coupling_impl(const char* who, const float* z, const float* nn_out, const float* scaling_factor,
+                                const float* mask, int mask_rows, int mask_cols,
+                                const float* ldj_in, float* z_out, float* ldj_out,
+                                int B, int N, int D, int reverse,
+                                const float* pad, const float* length, float* neglog_out, float* nll_out,
+                                double* sums, float sigma, float log_sigma, int* flags, cnf_stream_t stream) {
+    CNF_REQUIRE(z && nn_out && z_out && ldj_out, "%s: null tensor", who);
+    CNF_REQUIRE(B >= 0 && N > 0 && D > 0, "%s: bad shape B=%d N=%d D=%d", who, B, N, D);
     if (B == 0) return CNF_OK;
     if (!mask) { mask_rows = 1; mask_cols = D; }
     CNF_REQUIRE(mask_rows >= 1 && (mask_cols == D || mask_cols == 1),
-                "cnf_affine_coupling: mask must be [rows,%d] or [rows,1], got [%d,%d]", D, mask_rows, mask_cols);
-    CNF_REQUIRE((long)N * D < 65536, "cnf_affine_coupling: N*D=%ld exceeds 65535", (long)N * D);
+                "%s: mask must be [rows,%d] or [rows,1], got [%d,%d]", who, D, mask_rows, mask_cols);
+    CNF_REQUIRE((long)N * D < 65536, "%s: N*D=%ld exceeds 65535", who, (long)N * D);
     if (mask_rows > N) mask_rows = N;   // coupling_layer.py:72-73 truncation
-    if (mask_rows * D > kMaxTab) { set_error("cnf_affine_coupling: mask period %d x D %d too large", mask_rows, D); return CNF_ERR_UNSUPPORTED; }
+    if (mask_rows * D + 3 > kMaxTab) { set_error("%s: mask period %d x D %d too large", who, mask_rows, D); return CNF_ERR_UNSUPPORTED; }
     AffineArgs a;
     a.z = z; a.nn = nn_out; a.sf = scaling_factor; a.mask = mask; a.ldj_in = ldj_in;
     a.z_out = z_out; a.ldj_out = ldj_out; a.flags = flags;
     a.N = N; a.D = D; a.L = N * D; a.mr = mask_rows; a.mc = mask_cols; a.reverse = reverse;
     a.div_d = make_fastdiv((uint32_t)D);
+    a.P = mask_rows * D;
+    a.div_p = make_fastdiv((uint32_t)a.P);
+    a.pad = pad; a.length = length; a.neglog_out = neglog_out; a.nll_out = nll_out;
+    a.prior = make_prior_const(sigma, log_sigma);
     const RowTiling tl = make_row_tiling(B, a.L, 0, tile_chunks_target());
     DISPATCH_VEC(tl, launch_affine<V>(a, tl, scaling_factor != nullptr, reverse != 0, (hipStream_t)stream));
-    return launch_status("cnf_affine_coupling");
+    if (sums) hipLaunchKernelGGL(nll_sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, nll_out, B, sums);
+    return launch_status(who);
+}
+
+int cnf_affine_coupling(const float* z, const float* nn_out, const float* scaling_factor,
+                        const float* mask, int mask_rows, int mask_cols,
+                        const float* ldj_in, float* z_out, float* ldj_out,
+                        int B, int N, int D, int reverse, int* flags, cnf_stream_t stream) {
+    return affine_coupling_impl("cnf_affine_coupling", z, nn_out, scaling_factor, mask, mask_rows, mask_cols,
+                                ldj_in, z_out, ldj_out, B, N, D, reverse, nullptr, nullptr, nullptr, nullptr,
+                                nullptr, 1.f, 0.f, flags, stream);
+}
+
+int cnf_affine_coupling_nll(const float* z, const float* nn_out, const float* scaling_factor,
+                            const float* mask, int mask_rows, int mask_cols,
+                            const float* ldj_in, float* z_out, float* ldj_out,
+                            const float* pad, const float* length,
+                            float* neglog_out, float* nll_out, double* sums,
+                            int B, int N, int D, float sigma, float log_sigma,
+                            int* flags, cnf_stream_t stream) {
+    CNF_REQUIRE(nll_out, "cnf_affine_coupling_nll: nll_out is required");
+    return affine_coupling_impl("cnf_affine_coupling_nll", z, nn_out, scaling_factor, mask, mask_rows, mask_cols,
+                                ldj_in, z_out, ldj_out, B, N, D, 0, pad, length, neglog_out, nll_out, sums,
+                                sigma, log_sigma, flags, stream);
 }
 
 int cnf_affine_params(const float* nn_out, const float* scaling_factor,
@@ -583,6 +703,12 @@ int cnf_logistic_from_uniform(const float* u, float* x, int64_t n, float mu, flo
     return launch_status("cnf_logistic_from_uniform");
 }
 
+int cnf_nll_sum(const float* nll, int B, double* sums, cnf_stream_t stream) {
+    CNF_REQUIRE(nll && sums && B >= 0, "cnf_nll_sum: bad argument");
+    hipLaunchKernelGGL(nll_sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, nll, B, sums);
+    return launch_status("cnf_nll_sum");
+}
+
 int cnf_prior_nll(const float* z, const float* pad, const float* ldj, const float* length,
                   float* neglog_out, float* nll_out, double* sums,
                   int B, int N, int D, float sigma, float log_sigma, cnf_stream_t stream) {
@@ -590,7 +716,7 @@ int cnf_prior_nll(const float* z, const float* pad, const float* ldj, const floa
     CNF_REQUIRE(!sums || nll_out, "cnf_prior_nll: `sums` needs `nll_out` (the batch sum is taken over it)");
     CNF_REQUIRE(B >= 0 && N > 0 && D > 0 && (long)N * D < 65536, "cnf_prior_nll: bad shape");
     if (B == 0) return CNF_OK;
-    NllArgs a{z, pad, ldj, length, neglog_out, nll_out, sums, N, D, N * D, sigma, log_sigma,
+    NllArgs a{z, pad, ldj, length, neglog_out, nll_out, sums, N, D, N * D, make_prior_const(sigma, log_sigma),
               make_fastdiv((uint32_t)D)};
     const RowTiling tl = make_row_tiling(B, a.L);
     DISPATCH_VEC(tl, hipLaunchKernelGGL((prior_nll_kernel<V>), tiling_grid(tl), dim3(kBlock), 0,

@@ -78,6 +78,20 @@ __device__ __forceinline__ T group_sum(T v, int g) {
     for (int m = g >> 1; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
     return v;
 }
+// two sums carried through one row walk (log-det and prior log-prob of the fused coupling + NLL kernel)
+struct Sum2 {
+    float a, b;
+    __device__ __forceinline__ Sum2() {}
+    __device__ __forceinline__ Sum2(int) : a(0.f), b(0.f) {}
+    __device__ __forceinline__ Sum2(float x, float y) : a(x), b(y) {}
+    __device__ __forceinline__ Sum2& operator+=(const Sum2& o) {
+        a += o.a;
+        b += o.b;
+        return *this;
+    }
+};
+__device__ __forceinline__ Sum2 wave_sum(Sum2 v) { return Sum2(wave_sum(v.a), wave_sum(v.b)); }
+__device__ __forceinline__ Sum2 group_sum(Sum2 v, int g) { return Sum2(group_sum(v.a, g), group_sum(v.b, g)); }
 // make this wave's LDS writes visible to its own later reads (lanes exchange data through LDS)
 __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -49,6 +49,7 @@ struct MixArgs {
     int DA;                 // transformed channels per token (channel mask) or D (per-item test)
     unsigned long long act_bits;   // bit d set = channel d is transformed (a list cannot be indexed per lane)
     int per_item_mask;      // 1: mask varies along N (chess) -> test every item
+    int cst_lds;            // inverse with run-time K: 1 = per-mixture constants cached in LDS
     int reverse, pad_in_transform, pad_output, use_reg;
     double reg_max, reg_factor;
     FastDiv div_d, div_da;
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(kBlock) void mixture_kernel(MixArgs a, RowTiling tl
                     }
                     if (KT > 0) {
                         wr[k] = w; isr[k] = exp(-ls); mur[k] = mk;
-                    } else {
+                    } else if (a.cst_lds) {
                         my[(3 * k + 0) * S] = w;
                         my[(3 * k + 1) * S] = exp(-ls);
                         my[(3 * k + 2) * S] = mk;
@@ -347,7 +348,7 @@ __global__ __launch_bounds__(kBlock) void mixture_kernel(MixArgs a, RowTiling tl
                     // the reference's bracket (:252-254): mu_k -+ 20 * sum_k s_k, min / max over k
 #pragma unroll
                     for (int k = 0; k < K; ++k) {
-                        const double mu = KT > 0 ? mur[k] : my[(3 * k + 2) * S];
+                        const double mu = KT > 0 ? mur[k] : p.mu(k);
                         lb = fmin(lb, mu - 20.0 * spread);
                         ub = fmax(ub, mu + 20.0 * spread);
                     }
@@ -360,9 +361,16 @@ __global__ __launch_bounds__(kBlock) void mixture_kernel(MixArgs a, RowTiling tl
                     double cdf = 0.0, dens = 0.0;
 #pragma unroll
                     for (int k = 0; k < K; ++k) {
-                        const double wk = KT > 0 ? wr[k] : my[(3 * k + 0) * S];
-                        const double ik = KT > 0 ? isr[k] : my[(3 * k + 1) * S];
-                        const double mk = KT > 0 ? mur[k] : my[(3 * k + 2) * S];
+                        double wk, ik, mk;
+                        if (KT > 0) {
+                            wk = wr[k]; ik = isr[k]; mk = mur[k];
+                        } else if (a.cst_lds) {
+                            wk = my[(3 * k + 0) * S]; ik = my[(3 * k + 1) * S]; mk = my[(3 * k + 2) * S];
+                        } else {
+                            // K too large for the LDS table: rebuild the constants from the (cache-resident)
+                            // parameter row in every iteration, same expressions as the table holds
+                            wk = exp(p.log_pi(k) - mx); ik = exp(-p.ls(k)); mk = p.mu(k);
+                        }
                         const double zk = (xb - mk) * ik;
                         const double e = exp(-fabs(zk));
                         const double rr = 1.0 / (1.0 + e);
@@ -542,9 +550,12 @@ static int launch_mixture(MixArgs& a, bool split, const int* act_host, int n_act
                per_thread * threads + (size_t)(threads / kWave) * kMaxTileChunks * sizeof(double) > 65536)
             threads >>= 1;
         cst_bytes = per_thread * threads;
+        a.cst_lds = 1;
         if (cst_bytes + (size_t)(threads / kWave) * kMaxTileChunks * sizeof(double) > 65536) {
-            set_error("%s: inverse with K=%d mixtures needs more than 64 KiB of LDS", who, a.K);
-            return CNF_ERR_UNSUPPORTED;
+            // K > 42: no LDS table, the kernel recomputes the per-mixture constants in its iterations
+            a.cst_lds = 0;
+            cst_bytes = 0;
+            threads = kBlock;
         }
     }
     const int W = threads / kWave;

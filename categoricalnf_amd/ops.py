@@ -182,6 +182,32 @@ def affine_coupling(z, nn_out, scaling_factor, mask, reverse=False, ldj=None):
     return z_out, ldj_out
 
 
+def affine_coupling_nll(z, nn_out, scaling_factor, mask, ldj=None, length=None, channel_padding_mask=None, sums=None,
+                        sigma=LOGISTIC_SIGMA, log_sigma=LOGISTIC_LOG_SIGMA):
+    """Last coupling layer + NLL assembly in one kernel: == affine_coupling(reverse=False) then prior_nll on its
+    outputs.  Returns (z_out, ldj_out, neglog [B], nll [B])."""
+    z = _f32(z, "z")
+    dev = z.device
+    B, N, D = z.shape
+    nn_out = _f32(nn_out, "nn_out")
+    if nn_out.numel() != z.numel() * 2:
+        raise ValueError("nn_out must be [B,N,2D]; got %s for z %s" % (tuple(nn_out.shape), tuple(z.shape)))
+    sf = _opt_f32(scaling_factor, "scaling_factor", dev)
+    m, mr, mc = _mask_desc(mask, D, dev)
+    ldj_in, ldj_out = _ldj_io(ldj, B, dev, inplace=False)
+    pad = _pad2d(channel_padding_mask, B, N, dev)
+    ln = _length(length, B, dev)
+    z_out = torch.empty_like(z)
+    neglog = torch.empty(B, dtype=torch.float32, device=dev)
+    nll = torch.empty(B, dtype=torch.float32, device=dev)
+    _launch(dev, "cnf_affine_coupling_nll", _ptr(z), _ptr(nn_out), _ptr(sf), _ptr(m), mr, mc, _ptr(ldj_in),
+                                           _ptr(z_out), _ptr(ldj_out), _ptr(pad), _ptr(ln), _ptr(neglog), _ptr(nll),
+                                           _ptr(sums), B, N, D, float(sigma), float(log_sigma),
+                                           _ptr(flag_word(dev)), _stream(dev))
+    _after(dev, "affine coupling + NLL")
+    return z_out, ldj_out, neglog, nll
+
+
 def affine_params(nn_out, mask, scaling_factor=None):
     nn_out = _f32(nn_out, "nn_out")
     dev = nn_out.device
@@ -513,6 +539,38 @@ def affine_coupling_launch(z, nn_out, scaling_factor, mask, z_out, ldj_out, reve
     args = [_ptr(z), _ptr(nn_out), _ptr(sf), _ptr(m), mr, mc, _ptr(ldj), _ptr(z_out), _ptr(ldj_out), B, N, D,
             int(bool(reverse)), _ptr(flag_word(dev)), None]
     return Launch("cnf_affine_coupling", lib.cnf_affine_coupling, args, dev, (z, nn_out, sf, m, ldj, z_out, ldj_out))
+
+
+def affine_coupling_nll_launch(z, nn_out, scaling_factor, mask, z_out, ldj_out, length, neglog, nll, sums, ldj=None,
+                               channel_padding_mask=None, sigma=LOGISTIC_SIGMA, log_sigma=LOGISTIC_LOG_SIGMA):
+    z, nn_out = _f32(z, "z"), _f32(nn_out, "nn_out")
+    dev = z.device
+    B, N, D = z.shape
+    sf = _opt_f32(scaling_factor, "scaling_factor", dev)
+    m, mr, mc = _mask_desc(mask, D, dev)
+    pad = _pad2d(channel_padding_mask, B, N, dev)
+    ln = _length(length, B, dev)
+    lib = _lib.load()
+    args = [_ptr(z), _ptr(nn_out), _ptr(sf), _ptr(m), mr, mc, _ptr(ldj), _ptr(z_out), _ptr(ldj_out), _ptr(pad), _ptr(ln),
+            _ptr(neglog), _ptr(nll), _ptr(sums), B, N, D, float(sigma), float(log_sigma), _ptr(flag_word(dev)), None]
+    return Launch("cnf_affine_coupling_nll", lib.cnf_affine_coupling_nll, args, dev,
+                  (z, nn_out, sf, m, ldj, z_out, ldj_out, pad, ln, neglog, nll, sums))
+
+
+def nll_sum_launch(nll, sums):
+    dev = nll.device
+    lib = _lib.load()
+    return Launch("cnf_nll_sum", lib.cnf_nll_sum, [_ptr(nll), int(nll.numel()), _ptr(sums), None], dev, (nll, sums))
+
+
+def nll_sum(nll, sums=None):
+    """(sum_b nll[b], B) in fp64, fixed summation order."""
+    nll = _f32(nll, "nll")
+    dev = nll.device
+    if sums is None:
+        sums = torch.empty(2, dtype=torch.float64, device=dev)
+    _launch(dev, "cnf_nll_sum", _ptr(nll), int(nll.numel()), _ptr(sums), _stream(dev))
+    return sums
 
 
 def prior_nll_launch(z, ldj, length, neglog, nll, sums, channel_padding_mask=None,

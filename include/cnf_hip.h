@@ -187,6 +187,23 @@ int cnf_prior_nll(const float* z, const float* pad, const float* ldj, const floa
                   float* neglog_out, float* nll_out, double* sums,
                   int B, int N, int D, float sigma, float log_sigma, cnf_stream_t stream);
 
+/* sums[0..1] = {sum_b nll[b] (fp64, fixed order), B}: the batch reduction of cnf_prior_nll on its own
+ * (general/task.py:148-149 mean over the batch, as the pair that is all-reduced over ranks). */
+int cnf_nll_sum(const float* nll, int B, double* sums, cnf_stream_t stream);
+
+/* Last coupling layer of a flow + NLL assembly in one pass: cnf_affine_coupling(reverse = 0) followed by
+ * cnf_prior_nll on its z_out / ldj_out (coupling_layer.py:42-65 then set_modeling/task.py:96-118), with the
+ * prior term accumulated while z_out is still in registers (saves the 4 B/elem re-read of z_out and one launch).
+ * Outputs z_out, ldj_out as cnf_affine_coupling; neglog_out (nullable), nll_out (required), sums (nullable)
+ * as cnf_prior_nll. */
+int cnf_affine_coupling_nll(const float* z, const float* nn_out, const float* scaling_factor,
+                            const float* mask, int mask_rows, int mask_cols,
+                            const float* ldj_in, float* z_out, float* ldj_out,
+                            const float* pad, const float* length,
+                            float* neglog_out, float* nll_out, double* sums,
+                            int B, int N, int D, float sigma, float log_sigma,
+                            int* flags, cnf_stream_t stream);
+
 /* ---- mixture-model categorical encoder --------------------------------------------------------- */
 
 /* LinearCategoricalEncoding.forward, num_flows == 0 (linear_encoding.py:59-106,120-133,153-174).

@@ -135,7 +135,7 @@ def test_mixture_golden(c):
     close(zf, c.z_fwd, **etol); close(lf, c.ldj_fwd, **LDJ)
     if "reg_ldj" in c:
         close(reg, c.reg_ldj, **LDJ)
-    if m["K"] <= 42:         # the inverse keeps 3K fp64 constants per lane in LDS; the reference has no AR inverse
+    if "z_rev" in c:
         zr, lr, _ = ops().mixture_coupling(g(c.z_fwd), g(c.get("nn_out_rev", c.nn_out)), g(mask), reverse=True, **kw)
         close(zr, c.z_rev, rtol=1e-4, atol=1e-4); close(lr, c.ldj_rev, **LDJ)
     if "p_t" in c:
@@ -170,15 +170,15 @@ def test_mixture_vs_oracle(B, N, D, K, kind):
     zf, lf, rf = ops().mixture_coupling(g(z), g(nn_out), g(mask), scaling_factor=g(sf), mixture_scaling_factor=g(msf),
                                         channel_padding_mask=g(pad), **kw)
     close(zf, zo, **ELEM); close(lf, lo, **LDJ); close(rf, ro, **LDJ)
-    if K <= 42:
-        zo2, lo2, _ = O.mixture_coupling(zo, nn_out, mask, scaling_factor=sf, mixture_scaling_factor=msf,
-                                         channel_padding_mask=pad, reverse=True, **kw)
-        zr, lr, _ = ops().mixture_coupling(g(zo), g(nn_out), g(mask), scaling_factor=g(sf), mixture_scaling_factor=g(msf),
-                                           channel_padding_mask=g(pad), reverse=True, **kw)
-        close(zr, zo2, rtol=1e-4, atol=1e-4); close(lr, lo2, **LDJ)
-        # round trip on the transformed, un-padded entries
-        keep = (pad if pad is not None else torch.ones(B, N, 1)).expand(-1, -1, D) > 0
-        assert ((zr.cpu() - z)[keep]).abs().max() < 5e-4
+    # inverse (K = 51 exceeds the LDS constant table: exercises the recompute path)
+    zo2, lo2, _ = O.mixture_coupling(zo, nn_out, mask, scaling_factor=sf, mixture_scaling_factor=msf,
+                                     channel_padding_mask=pad, reverse=True, **kw)
+    zr, lr, _ = ops().mixture_coupling(g(zo), g(nn_out), g(mask), scaling_factor=g(sf), mixture_scaling_factor=g(msf),
+                                       channel_padding_mask=g(pad), reverse=True, **kw)
+    close(zr, zo2, rtol=1e-4, atol=1e-4); close(lr, lo2, **LDJ)
+    # round trip on the transformed, un-padded entries
+    keep = (pad if pad is not None else torch.ones(B, N, 1)).expand(-1, -1, D) > 0
+    assert ((zr.cpu() - z)[keep]).abs().max() < 5e-4
 
 
 def test_mixture_underflow_fallback_matches_logspace():
@@ -299,6 +299,37 @@ def test_prior_golden():
             close(neglog, c.neglog, **LDJ); close(nll, c.nll, **LDJ)
             assert abs(sums[0].item() / sums[1].item() - float(c.nll_mean)) < 1e-5
             assert sums[1].item() == c.z.size(0)
+
+
+@pytest.mark.parametrize("B,N,D,kind,has_sf", [(33, 64, 6, "channel", True), (5, 13, 1, "chess", True), (300, 7, 3, "channel", False),
+                                                (16, 16, 4, "channel", True), (2, 703, 2, "channel", True), (1000, 1, 2, "channel", True),
+                                                (4096, 64, 6, "channel", True)])
+def test_affine_coupling_nll_fused_vs_oracle_and_split(B, N, D, kind, has_sf):
+    """cnf_affine_coupling_nll == the oracle's coupling followed by its NLL assembly, and == the two separate
+    kernels (z / ldj bit for bit: same arithmetic; NLL to summation-order rounding)."""
+    gen = torch.Generator().manual_seed(B * 31 + N * 7 + D)
+    z = torch.randn(B, N, D, generator=gen)
+    nn_out = 0.7 * torch.randn(B, N, 2 * D, generator=gen)
+    sf = 0.3 * torch.randn(D, generator=gen) if has_sf else None
+    mask = O.chess_mask() if kind == "chess" else O.channel_mask(D)
+    ldj0 = torch.randn(B, generator=gen)
+    ln = torch.randint(max(1, N // 2), N + 1, (B,), generator=gen)
+    pad = O.length_mask(ln, N)
+    zo, lo = O.affine_coupling(z, nn_out, mask, scaling_factor=sf, ldj=ldj0.clone())
+    nll_o = O.nll_per_sample(zo, lo, ln.float(), pad)
+    sums = torch.zeros(2, dtype=torch.float64, device="cuda")
+    zf, lf, neglog, nll = ops().affine_coupling_nll(g(z), g(nn_out), g(sf), g(mask), ldj=g(ldj0), length=g(ln),
+                                                    channel_padding_mask=g(pad), sums=sums)
+    close(zf, zo, **ELEM); close(lf, lo, **LDJ); close(nll, nll_o, **LDJ)
+    z2, l2 = ops().affine_coupling(g(z), g(nn_out), g(sf), g(mask), ldj=g(ldj0))
+    neglog2, nll2 = ops().prior_nll(z2, l2, g(ln), g(pad))
+    assert torch.equal(zf, z2) and torch.equal(lf, l2)
+    close(neglog, neglog2.cpu(), rtol=2e-6, atol=1e-4); close(nll, nll2.cpu(), rtol=2e-6, atol=2e-5)
+    assert sums[1].item() == B and abs(sums[0].item() - nll.double().sum().item()) < 1e-6 * max(1.0, abs(sums[0].item()))
+    # without padding / length (defaults: every token counts, length = N)
+    zf, lf, neglog, nll = ops().affine_coupling_nll(g(z), g(nn_out), g(sf), g(mask))
+    zo, lo = O.affine_coupling(z, nn_out, mask, scaling_factor=sf)
+    close(nll, O.nll_per_sample(zo, lo, torch.full((B,), float(N)), None), **LDJ)
 
 
 @pytest.mark.parametrize("c", load_cases("encoder"))

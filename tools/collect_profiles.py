@@ -1,0 +1,24 @@
+"""Copy the summaries tools/refresh_profiles.sh left under gpurun_out/ into profiles/ (tracked).
+Usage: python tools/collect_profiles.py [round_tag]   (default r01)"""
+import csv, os, shutil, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+
+line = [l for l in open(os.path.join(G, "bench.log")) if l.startswith("{")][-1]
+open(os.path.join(P, tag + "_bench.json"), "w").write(line)
+
+rows = list(csv.reader(open(os.path.join(G, "prof_r01", "bench_kernel_stats.csv"))))
+with open(os.path.join(P, tag + "_bench_kernel_stats.csv"), "w", newline="") as fh:
+    csv.writer(fh).writerows([rows[0]] + [[r[0][:120]] + r[1:] for r in rows[1:]])
+for r in rows[1:8]:
+    print(r[0][:80], r[1], r[3])
+
+shutil.copy(os.path.join(G, "traffic.json"), os.path.join(P, "traffic.json"))
+shutil.copy(os.path.join(G, "traffic.txt"), os.path.join(P, tag + "_pmc_traffic.txt"))
+for src, dst in (("sweep_affine.log", "_sweep_affine.txt"), ("sweep_mixture.log", "_sweep_mixture.txt"),
+                 ("bench_kernels.log", "_bench_kernels.txt"), ("flow_graph.txt", "_flow_graph.txt")):
+    if os.path.exists(os.path.join(G, src)):
+        shutil.copy(os.path.join(G, src), os.path.join(P, tag + dst))
+print(line[:400])

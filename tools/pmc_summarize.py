@@ -24,7 +24,10 @@ def pick(vals, key):
 fetch = collect(sys.argv[1], "FETCH_SIZE")
 write = collect(sys.argv[2], "WRITE_SIZE")
 COPY_BYTES = 16384 * 64 * 6 * 4 * 4.0         # bytes read (= bytes written) per calibration copy launch
-names = {"affine_coupling_fwd": "affine_coupling_kernel<4, 2, true, false", "affine_coupling_inv": "affine_coupling_kernel<4, 2, true, true",
+# template arguments: <VEC, U, HAS_SF, REVERSE, FAST, NLL>; "affine_coupling_fwd" is the kernel bench.py's roofline names
+names = {"affine_coupling_fwd": "affine_coupling_kernel<4, 2, true, false, true, 1>",
+         "affine_coupling_fwd_plain": "affine_coupling_kernel<4, 2, true, false, true, 0>",
+         "affine_coupling_inv": "affine_coupling_kernel<4, 2, true, true, true, 0>",
          "mixture_fwd": "mixture_kernel<false, false", "copy": "__amd_rocclr_copyBuffer"}
 med = lambda x: sorted(x)[len(x) // 2] if x else None
 big = lambda x: [v for v in x if v > 0.5 * max(x)] if x else x      # the calibration copies, not the tiny H2D/D2H ones
@@ -40,7 +43,7 @@ out = {"calibration": {"copy_bytes_each_way": COPY_BYTES, "fetch_factor": cf, "w
                        "note": "factor = known bytes / (counter KB * 1024) on the 100.66 MB d2d copy (__amd_rocclr_copyBuffer) of the "
                                "same pass; MI355X_MICROARCH.md: FETCH_SIZE reports 1/2 of a wide coalesced read on gfx950"},
        "raw_median_per_launch": raw}
-for tag in ("affine_coupling_fwd", "affine_coupling_inv", "mixture_fwd"):
+for tag in ("affine_coupling_fwd", "affine_coupling_fwd_plain", "affine_coupling_inv", "mixture_fwd"):
     f, w = raw[tag]["FETCH_SIZE_KB"], raw[tag]["WRITE_SIZE_KB"]
     if f is not None and w is not None and cf and cw:
         out[tag + "_read_bytes_per_launch"] = f * 1024.0 * cf

@@ -14,10 +14,16 @@ sf = torch.zeros(D, device=dev)
 mask = torch.tensor([[1., 1., 1., 0., 0., 0.]], device=dev)
 zo = [torch.empty_like(zs[0]) for _ in range(R)]
 lo = [torch.empty(B, device=dev) for _ in range(R)]
-fwd = [ops.affine_coupling_launch(zs[r], nns[r], sf, mask, zo[r], lo[r]) for r in range(R)]
+ln = torch.full((B,), float(N), device=dev)
+neglog, nll = torch.empty(B, device=dev), torch.empty(B, device=dev)
+# the bench's dominant kernel: forward coupling with the NLL epilogue
+fwd = [ops.affine_coupling_nll_launch(zs[r], nns[r], sf, mask, zo[r], lo[r], ln, neglog, nll, None) for r in range(R)]
+plain = [ops.affine_coupling_launch(zs[r], nns[r], sf, mask, zo[r], lo[r]) for r in range(R)]
 inv = [ops.affine_coupling_launch(zs[r], nns[r], sf, mask, zo[r], lo[r], reverse=True) for r in range(R)]
 for i in range(REP):
     fwd[i % R]()
+for i in range(REP):
+    plain[i % R]()
 for i in range(REP):
     inv[i % R]()
 # calibration copy: 25,165,824 floats = 100.66 MB read + 100.66 MB written per launch

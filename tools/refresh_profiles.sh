@@ -1,0 +1,28 @@
+#!/bin/bash
+# Re-measure everything profiles/ holds, on the GPU box.  Run from the repo root:
+#   gpurun --timeout 1500 -- 'bash tools/refresh_profiles.sh'
+# then, back in the build container:  python tools/collect_profiles.py
+# The --pmc passes are separate rocprofv3 runs with --kernel-trace only (never combined with sys/hip traces).
+set -u
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out
+mkdir -p "$OUT"
+cd /tmp; export TMPDIR=/tmp; cd "$ROOT"
+
+timeout 300 python bench.py > "$OUT/bench.log" 2>&1; tail -1 "$OUT/bench.log"
+
+rm -rf "$OUT/prof_r01" "$OUT/pmc_fetch" "$OUT/pmc_write"
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_r01" -o bench -- \
+    python bench.py --no-cpu-baseline > "$OUT/bench_prof.log" 2>&1
+tail -1 "$OUT/bench_prof.log" | cut -c1-300
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o pmc -- \
+    python tools/pmc_workload.py > "$OUT/pmc_fetch.log" 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o pmc -- \
+    python tools/pmc_workload.py > "$OUT/pmc_write.log" 2>&1
+python tools/pmc_summarize.py "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/traffic.json" "$OUT/traffic.txt" | tail -8
+rm -f "$OUT"/pmc_fetch/*kernel_trace.csv "$OUT"/pmc_write/*kernel_trace.csv "$OUT"/prof_r01/*kernel_trace.csv
+
+timeout 300 python tools/sweep_affine.py > "$OUT/sweep_affine.log" 2>&1; tail -4 "$OUT/sweep_affine.log"
+timeout 300 python tools/sweep_mixture.py > "$OUT/sweep_mixture.log" 2>&1; tail -4 "$OUT/sweep_mixture.log"
+timeout 300 python tools/bench_kernels.py > "$OUT/bench_kernels.log" 2>&1; tail -30 "$OUT/bench_kernels.log"
+timeout 300 python tools/bench_flow_graph.py > "$OUT/flow_graph.txt" 2>&1; tail -6 "$OUT/flow_graph.txt"
