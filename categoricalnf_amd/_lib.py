@@ -63,7 +63,7 @@ SIGNATURES = {
 }
 _PLAIN = {"cnf_abi_version": ([], _i), "cnf_last_error": ([], ctypes.c_char_p),
           "cnf_set_tile_chunks": ([_i], None), "cnf_set_unroll": ([_i], None),
-          "cnf_set_math_mode": ([_i], None), "cnf_set_inverse_mode": ([_i], None),
+          "cnf_set_math_mode": ([_i], None), "cnf_set_inverse_mode": ([_i], None), "cnf_set_mixture_tile": ([_i], None),
           "cnf_bwd_workspace_floats": ([_i], _i64)}
 
 _lib = None

@@ -22,6 +22,7 @@ int tile_chunks_target();
 int unroll_target();
 int math_mode();
 int inverse_mode();
+int mixture_tile_items();
 
 #define CNF_REQUIRE(cond, ...)                \
     do {                                      \

@@ -12,6 +12,7 @@ static int g_tile_chunks = 128;
 static int g_unroll = 2;
 static int g_math = 1;
 static int g_inverse = 1;
+static int g_mix_tile = 128;
 
 void set_error(const char* fmt, ...) {
     va_list ap;
@@ -31,6 +32,7 @@ int tile_chunks_target() { return g_tile_chunks; }
 int unroll_target() { return g_unroll; }
 int math_mode() { return g_math; }
 int inverse_mode() { return g_inverse; }
+int mixture_tile_items() { return g_mix_tile; }
 
 RowTiling make_row_tiling(int B, int L, int force_vec, int target_chunks) {
     RowTiling t;
@@ -87,6 +89,10 @@ void cnf_set_unroll(int u) {
 
 void cnf_set_math_mode(int mode) {
     if (mode == 0 || mode == 1) cnf::g_math = mode;
+}
+
+void cnf_set_mixture_tile(int items) {
+    if (items >= 64 && items <= cnf::kMaxTileChunks) cnf::g_mix_tile = items;
 }
 
 void cnf_set_inverse_mode(int mode) {

@@ -53,6 +53,7 @@ struct MixArgs {
     int reverse, pad_in_transform, pad_output, use_reg;
     double reg_max, reg_factor;
     FastDiv div_d, div_da;
+    FastDiv div_upi;        // fp32 forward kernel: staging units per item
 };
 
 __device__ __forceinline__ double safe_log(double x) { return log(fmax(x, 1e-22)); }
@@ -221,6 +222,26 @@ __device__ __forceinline__ MixEval eval_mixture(const ElemParams<SPLIT, KT>& p, 
     return o;
 }
 
+// Forward of one transformed element in fp64 (run_with_params :100-123): out = (logit(u) + t) e^{log_s},
+// contrib = its log-det term, reg = its regularisation term.
+template <bool SPLIT, int KT>
+__device__ __forceinline__ void forward_elem_f64(const MixArgs& a, const ElemParams<SPLIT, KT>& p, double x,
+                                                 double& out, double& contrib, double& reg) {
+    const MixEval ev = eval_mixture<SPLIT, KT>(p, x);
+    const double u = ev.u;
+    const double lu = safe_log(u), l1u = safe_log(1.0 - u);
+    reg = 0.0;
+    if (a.use_reg) {
+        const double r1 = lu / kLn10, r2 = l1u / kLn10;
+        reg = (fmin(r1, -a.reg_max) + a.reg_max) + (fmin(r2, -a.reg_max) + a.reg_max);
+    }
+    // y = -safe_log(1/u - 1) (:273) = log u - log(1-u) wherever safe_log(u) is not clamped; below u = 1e-22
+    // the reference's form keeps falling (down to -inf at u == 0) while lu stays at log(1e-22)
+    const double y = u >= 1e-22 ? lu - l1u : -safe_log(1.0 / u - 1.0);
+    const double mixt_ldj = -lu - l1u;
+    out = (y + p.t_) * exp(p.log_s_);
+    contrib = p.log_s_ + mixt_ldj + ev.log_pdf + reg * a.reg_factor;
+}
 // SPLIT selects the parameter source and the I/O precision (fp64 tensors for the static API);
 // KT = compile-time number of mixtures (0 = run-time K); NEWTON = safeguarded Newton inverse.
 template <bool SPLIT, bool REVERSE, int KT, bool NEWTON>
@@ -290,19 +311,7 @@ __global__ __launch_bounds__(kBlock) void mixture_kernel(MixArgs a, RowTiling tl
             const double t = p.t_, log_s = p.log_s_;
             double out, reg = 0.0;
             if (!REVERSE) {
-                const MixEval ev = eval_mixture<SPLIT, KT>(p, x);
-                const double u = ev.u;
-                const double lu = safe_log(u), l1u = safe_log(1.0 - u);
-                if (a.use_reg) {
-                    const double r1 = lu / kLn10, r2 = l1u / kLn10;
-                    reg = (fmin(r1, -a.reg_max) + a.reg_max) + (fmin(r2, -a.reg_max) + a.reg_max);
-                }
-                // y = -safe_log(1/u - 1) (:273) = log u - log(1-u); identical under the 1e-22 clamp except
-                // at u == 0 exactly, where the reference's form gives -inf
-                const double y = u > 0.0 ? lu - l1u : -safe_log(1.0 / u - 1.0);
-                const double mixt_ldj = -lu - l1u;
-                out = (y + t) * exp(log_s);
-                contrib = log_s + mixt_ldj + ev.log_pdf + reg * a.reg_factor;
+                forward_elem_f64<SPLIT, KT>(a, p, x, out, contrib, reg);
             } else {
                 const double v = x * exp(-log_s) - t;
                 double u = 1.0 / (1.0 + exp(-v));
@@ -461,6 +470,300 @@ __global__ __launch_bounds__(kBlock) void mixture_kernel(MixArgs a, RowTiling tl
     if (range) raise_flag(a.flags, CNF_FLAG_RANGE);
 }
 
+
+// ---- fast forward (math mode 1): fp32 arithmetic on LDS-staged parameter rows -------------------------------
+//
+// The fp64 kernel above is bound by software fp64 exp/log (2 waves/SIMD at 200+ VGPRs) and by its parameter
+// fetch: every lane walks its own 4(2+3K)-byte row with scalar loads, so one wave-level load touches 64 cache
+// lines.  This kernel
+//   * stages the rows of the 64 items a wave works on through its private LDS strip with coalesced loads (the
+//     rows of neighbouring items are contiguous or a fixed stride apart; every 128-byte line is fetched once),
+//     then each lane reads its row back at an odd stride (conflict-free);
+//   * evaluates the mixture in fp32 with the hardware exp2 / log2 / rcp, carrying BOTH tails as sums of
+//     positive terms,  u = sum w sigma(z_k) / sum w  and  1 - u = sum w sigma(-z_k) / sum w,  so that log u and
+//     log(1 - u) keep fp32 RELATIVE accuracy (the reference needs fp64 only because it forms 1 - u by
+//     subtraction);
+//   * hands elements with u or 1 - u below 1e-9 (|logit| > 20.7), or an underflowing PDF sum, to the fp64
+//     element routine, which reproduces the reference's clamps (safe_log 1e-22) and rounding there.
+// Differences to the fp64 kernel on the fast branch: <= 3e-6 absolute in z_out / per-element log-det
+// (tests/test_gpu_parity.py::test_mixture_fast_vs_exact).  The per-sample log-det is still summed in fp64.
+constexpr float kLog2eF = 1.4426950408889634f;
+constexpr float kLn2F = 0.6931471805599453f;
+
+struct BoundTab {       // tanh bound of one raw parameter: v -> f tanh(v / max(f,1)) = f - 2f / (2^{v x3} + 1)
+    float x3, m2f, f;
+};
+__device__ __forceinline__ BoundTab make_bound(float raw_sf) {
+    const float f = expf(raw_sf);
+    BoundTab b;
+    b.x3 = 2.8853900817779268f / fmaxf(f, 1.f);
+    b.m2f = -2.f * f;
+    b.f = f;
+    return b;
+}
+__device__ __forceinline__ float apply_bound(float v, const BoundTab& b) {
+    return fmaf(__builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(v * b.x3) + 1.f), b.m2f, b.f);
+}
+
+template <int KT>
+__global__ __launch_bounds__(kBlock) void mixture_fwd_f32_kernel(MixArgs a, RowTiling tl, int PS, int strip) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int W = blockDim.x >> 6;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int K = KT > 0 ? KT : a.K;
+    // LDS: [W][strip] fp64 row partials | [W][64 * PS] staged rows | [D] + [D*K] bound tables
+    double* part = reinterpret_cast<double*>(smem) + (size_t)wave * strip;
+    float* stage_all = reinterpret_cast<float*>(reinterpret_cast<double*>(smem) + (size_t)W * strip);
+    float* stage = stage_all + (size_t)wave * kWave * PS;
+    BoundTab* sf_tab = reinterpret_cast<BoundTab*>(stage_all + (size_t)W * kWave * PS);
+    BoundTab* msf_tab = sf_tab + a.D;
+    __shared__ int s_act[kMaxAct];
+    if (threadIdx.x < kMaxAct && ((a.act_bits >> threadIdx.x) & 1ull))
+        s_act[__popcll(a.act_bits & ((1ull << threadIdx.x) - 1ull))] = threadIdx.x;
+    for (int i = threadIdx.x; i < a.D; i += blockDim.x)
+        if (a.sf) sf_tab[i] = make_bound(a.sf[i]);
+    for (int i = threadIdx.x; i < a.D * K; i += blockDim.x)
+        if (a.msf) msf_tab[i] = make_bound(a.msf[i]);
+    __syncthreads();
+    const int nlanes = tl.bpr ? (int)blockDim.x : kWave;
+    const int lane_t = tl.bpr ? (int)threadIdx.x : lane;
+    const long tile = tl.bpr ? (long)blockIdx.x : (long)blockIdx.x * W + wave;
+    // a wave without a tile still has to reach no later barrier: none follow
+    if (tile >= tl.ntiles) return;
+    const int row0 = (int)(tile * tl.rw);
+    const int nrows = min(tl.rw, tl.B - row0);
+    bool bad = false;
+
+    // ---- phase 1: copy the elements that are not transformed (masked channel or padded token)
+    {
+        const long nel = (long)nrows * a.L;
+        const size_t base = (size_t)row0 * a.L;
+        for (long e = lane_t; e < nel; e += nlanes) {
+            const int r = (int)(e / a.L);
+            const int er = (int)(e - (long)r * a.L);
+            const int n = (int)fdiv((uint32_t)er, a.div_d);
+            const int d = er - n * a.D;
+            const float m = mask_at(a.mask, a.mr, a.mc, n, d);
+            const float pv = a.pad ? a.pad[(size_t)(row0 + r) * a.N + n] : 1.f;
+            const float change = (1.f - m) * (a.pad_in_transform ? pv : 1.f);
+            if (change == 0.f) {
+                const float zv = a.z[base + e];
+                a.z_out[base + e] = a.pad_output ? zv * pv : zv;
+            }
+        }
+    }
+
+    // ---- phase 2: transformed elements, 64 consecutive items per wave pass
+    const int ipr = tl.L;
+    const int nitems = nrows * ipr;
+    const int P = a.P;
+    const bool vec2 = (P & 1) == 0;                 // rows are 8-byte aligned -> stage in 8-byte units
+    const int upi = vec2 ? P >> 1 : P;              // units per item
+    const FastDiv div_upi = a.div_upi;
+    double acc1 = 0.0;
+    for (int c0 = tl.bpr ? wave * kWave : 0; c0 < nitems; c0 += nlanes) {     // wave-uniform
+        const int c = c0 + lane;
+        const bool valid = c < nitems;
+        const int cc = valid ? c : nitems - 1;
+        const int r = tl.rw == 1 ? 0 : (int)fdiv((uint32_t)cc, tl.div_cpr);
+        const int it = cc - r * ipr;
+        const int n = (int)fdiv((uint32_t)it, a.div_da);
+        const int d = s_act[it - n * a.DA];
+        const int row = row0 + r;
+        bool active = valid;
+        if (a.per_item_mask) active = active && mask_at(a.mask, a.mr, a.mc, n, d) == 0.f;
+        const float pv = a.pad ? a.pad[(size_t)row * a.N + n] : 1.f;
+        if (a.pad_in_transform && pv == 0.f) active = false;
+        const size_t elem = ((size_t)row * a.N + n) * a.D + d;
+        const float x = active ? a.z[elem] : 0.f;
+        // -- stage the 64 rows: unit q of the pass belongs to item q / upi; its row start comes from that lane
+        const unsigned long long rowbase = active ? (unsigned long long)(elem * (size_t)P) : ~0ull;
+        const unsigned lo = (unsigned)rowbase, hi = (unsigned)(rowbase >> 32);
+        const int total = kWave * upi;
+        for (int q0 = 0; q0 < total; q0 += kWave * 8) {
+            float2 v[8];
+            int itemv[8], offv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int q = min(q0 + u * kWave + lane, total - 1);
+                const int item = (int)fdiv((uint32_t)q, div_upi);
+                const int off = q - item * upi;
+                const unsigned blo = __shfl(lo, item, kWave), bhi = __shfl(hi, item, kWave);
+                const unsigned long long b = ((unsigned long long)bhi << 32) | blo;
+                itemv[u] = b == ~0ull ? -1 : item;
+                offv[u] = off;
+                v[u] = make_float2(0.f, 0.f);
+                if (b != ~0ull) {
+                    if (vec2) v[u] = *reinterpret_cast<const float2*>(a.nn + b + 2 * off);
+                    else v[u].x = a.nn[b + off];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (q0 + u * kWave + lane < total && itemv[u] >= 0) {
+                    float* dst = stage + itemv[u] * PS + (vec2 ? 2 * offv[u] : offv[u]);
+                    dst[0] = v[u].x;
+                    if (vec2) dst[1] = v[u].y;
+                }
+            }
+        }
+        wave_lds_sync();
+        double contrib = 0.0;
+        if (active) {
+            const float* my = stage + lane * PS;
+            const float t = my[0];
+            float log_s = my[1];
+            if (a.sf) log_s = apply_bound(log_s, sf_tab[d]);
+            constexpr int KK = KT > 0 ? KT : 1;
+            float lp[KK], mu[KK], lsr[KK];
+            float mx = -INFINITY;
+            if (KT > 0) {
+#pragma unroll
+                for (int k = 0; k < KK; ++k) {
+                    lp[k] = my[2 + k];
+                    mu[k] = my[2 + KK + k];
+                    lsr[k] = my[2 + 2 * KK + k];
+                }
+#pragma unroll
+                for (int k = 0; k < KK; ++k) mx = fmaxf(mx, lp[k]);
+            } else {
+                for (int k = 0; k < K; ++k) mx = fmaxf(mx, my[2 + k]);
+            }
+            const BoundTab* mt = msf_tab + d * K;
+            float se = 0.f, cdf = 0.f, ccdf = 0.f, pdf = 0.f;
+            auto one = [&](float lpk, float muk, float lsk, int k) {
+                const float ls = a.msf ? apply_bound(lsk, mt[k]) : lsk;
+                const float inv_s = __builtin_amdgcn_exp2f(-ls * kLog2eF);
+                const float w = __builtin_amdgcn_exp2f((lpk - mx) * kLog2eF);
+                const float zk = (x - muk) * inv_s;
+                const float e = __builtin_amdgcn_exp2f(-fabsf(zk) * kLog2eF);
+                const float rr = __builtin_amdgcn_rcpf(1.f + e);
+                const float er = e * rr;
+                const bool pos = zk >= 0.f;
+                se += w;
+                cdf = fmaf(w, pos ? rr : er, cdf);
+                ccdf = fmaf(w, pos ? er : rr, ccdf);
+                pdf = fmaf(w * inv_s, er * rr, pdf);
+            };
+            if (KT > 0) {
+#pragma unroll
+                for (int k = 0; k < KK; ++k) one(lp[k], mu[k], lsr[k], k);
+            } else {
+                for (int k = 0; k < K; ++k) one(my[2 + k], my[2 + K + k], my[2 + 2 * K + k], k);
+            }
+            float of;
+            double reg = 0.0;
+            const float inv_se = __builtin_amdgcn_rcpf(se);
+            const float u = cdf * inv_se, uc = ccdf * inv_se;
+            if (u > 1e-9f && uc > 1e-9f && pdf > 1e-30f) {
+                const float l2se = __builtin_amdgcn_logf(se);
+                const float lu = (__builtin_amdgcn_logf(cdf) - l2se) * kLn2F;
+                const float l1u = (__builtin_amdgcn_logf(ccdf) - l2se) * kLn2F;
+                const float lpdf = (__builtin_amdgcn_logf(pdf) - l2se) * kLn2F;
+                float regf = 0.f;
+                if (a.use_reg) {
+                    const float rmax = (float)a.reg_max;
+                    const float r1 = lu * 0.43429448190325176f, r2 = l1u * 0.43429448190325176f;
+                    regf = (fminf(r1, -rmax) + rmax) + (fminf(r2, -rmax) + rmax);
+                }
+                of = ((lu - l1u) + t) * __builtin_amdgcn_exp2f(log_s * kLog2eF);
+                contrib = (double)(log_s + (-lu - l1u) + lpdf + regf * (float)a.reg_factor);
+                reg = (double)regf;
+            } else {
+                // rare: a tail or an underflow.  The reference's fp64 arithmetic (u, then 1 - u by subtraction,
+                // safe_log clamps; :100-123, :217-233) on the staged row, one mixture at a time — rolled loops
+                // keep this branch's registers below the fast path's.
+                const double xd = (double)x;
+                double sed = 0.0, cdfd = 0.0, pdfd = 0.0;
+#pragma clang loop unroll(disable)
+                for (int k = 0; k < K; ++k) {
+                    const float lsf = a.msf ? apply_bound(my[2 + 2 * K + k], mt[k]) : my[2 + 2 * K + k];
+                    const double wd = exp((double)my[2 + k] - (double)mx);
+                    const double isd = exp(-(double)lsf);
+                    const double zd = (xd - (double)my[2 + K + k]) * isd;
+                    const double ed = exp(-fabs(zd));
+                    const double rd = 1.0 / (1.0 + ed);
+                    sed += wd;
+                    cdfd += wd * (zd >= 0.0 ? rd : ed * rd);
+                    pdfd += wd * isd * (ed * rd * rd);
+                }
+                const double ud = cdfd / sed;
+                double lpdfd;
+                if (pdfd > 1e-290) {
+                    lpdfd = log(pdfd / sed);
+                } else {
+                    // log-space form (:217-223)
+                    const double lse_pi = (double)mx + log(sed);
+                    double m = -INFINITY;
+#pragma clang loop unroll(disable)
+                    for (int k = 0; k < K; ++k) {
+                        const float lsf = a.msf ? apply_bound(my[2 + 2 * K + k], mt[k]) : my[2 + 2 * K + k];
+                        const double zd = (xd - (double)my[2 + K + k]) * exp(-(double)lsf);
+                        m = fmax(m, (double)my[2 + k] - lse_pi + zd - (double)lsf - 2.0 * softplus64(zd));
+                    }
+                    double ssum = 0.0;
+#pragma clang loop unroll(disable)
+                    for (int k = 0; k < K; ++k) {
+                        const float lsf = a.msf ? apply_bound(my[2 + 2 * K + k], mt[k]) : my[2 + 2 * K + k];
+                        const double zd = (xd - (double)my[2 + K + k]) * exp(-(double)lsf);
+                        ssum += exp((double)my[2 + k] - lse_pi + zd - (double)lsf - 2.0 * softplus64(zd) - m);
+                    }
+                    lpdfd = m + log(ssum);
+                }
+                const double lud = safe_log(ud), l1ud = safe_log(1.0 - ud);
+                if (a.use_reg) {
+                    const double r1 = lud / kLn10, r2 = l1ud / kLn10;
+                    reg = (fmin(r1, -a.reg_max) + a.reg_max) + (fmin(r2, -a.reg_max) + a.reg_max);
+                }
+                const double yd = ud >= 1e-22 ? lud - l1ud : -safe_log(1.0 / ud - 1.0);
+                of = (float)((yd + (double)t) * exp((double)log_s));
+                contrib = (double)log_s + (-lud - l1ud) + lpdfd + reg * a.reg_factor;
+            }
+            if (a.pad_output) of = of * pv;
+            a.z_out[elem] = of;
+            bad |= isnan(of);
+            if (a.use_reg && a.reg_out && reg != 0.0) atomicAdd(&a.reg_out[row], (float)reg);
+        }
+        if (valid) {
+            if (tl.rw == 1) acc1 += contrib;
+            else part[c] = contrib;
+        }
+        wave_lds_sync();      // the strip is overwritten by the next pass
+    }
+
+    auto finish = [&](int row, double sum) {
+        const float v = (a.ldj_in ? a.ldj_in[row] : 0.f) + (float)sum;
+        a.ldj_out[row] = v;
+        if (isnan(v)) raise_flag(a.flags, CNF_FLAG_NAN_LDJ);
+    };
+    if (tl.bpr) {
+        acc1 = wave_sum(acc1);
+        if (lane == 0) part[0] = acc1;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double tsum = 0.0;
+            for (int w = 0; w < W; ++w) tsum += reinterpret_cast<double*>(smem)[(size_t)w * strip];
+            finish(row0, tsum);
+        }
+    } else if (tl.rw == 1) {
+        acc1 = wave_sum(acc1);
+        if (lane == 0) finish(row0, acc1);
+    } else {
+        wave_lds_sync();
+        const int g = kWave / tl.p2;
+        const int sub = lane & (g - 1);
+        for (int r0 = 0; r0 < nrows; r0 += tl.p2) {
+            const int r = r0 + lane / g;
+            double acc = 0.0;
+            if (r < nrows)
+                for (int i = sub; i < ipr; i += g) acc += part[r * ipr + i];
+            acc = group_sum(acc, g);
+            if (sub == 0 && r < nrows) finish(row0 + r, acc);
+        }
+    }
+    if (bad) raise_flag(a.flags, CNF_FLAG_NAN_Z);
+}
+
 // get_mixt_params (:145-180): split + fp32 tanh bound + mask, widened to fp64
 __global__ __launch_bounds__(kBlock) void mixture_params_kernel(const float* nn, const float* sf,
                                                                 const float* msf, const float* mask,
@@ -556,6 +859,33 @@ static int launch_mixture(MixArgs& a, bool split, const int* act_host, int n_act
             a.cst_lds = 0;
             cst_bytes = 0;
             threads = kBlock;
+        }
+    }
+    // forward in fast math mode: fp32 kernel on LDS-staged parameter rows
+    if (!split && !a.reverse && math_mode() == 1) {
+        // smaller tiles than the fp64 kernel: at ~100 VGPRs four waves per SIMD are resident, and a
+        // config-sized batch (5e5 items) only fills them when a wave owns ~128 items
+        const RowTiling tl = make_row_tiling(a.B, a.N * a.DA, /*force_vec=*/1, mixture_tile_items());
+        const int PS = a.P | 1;                                   // odd row stride in LDS
+        const int upi = (a.P & 1) ? a.P : a.P / 2;
+        a.div_upi = make_fastdiv((uint32_t)upi);
+        const int strip = (tl.bpr || tl.rw == 1) ? 1 : tl.rw * tl.L;
+        const size_t tabs = (size_t)(a.D + a.D * a.K) * 3 * sizeof(float);
+        const int th = kBlock;
+        auto need = [&](int t) { return (size_t)(t / kWave) * ((size_t)strip * sizeof(double) + (size_t)kWave * PS * sizeof(float)) + tabs; };
+        // K > ~19: 64 staged rows per wave no longer fit four waves into 64 KiB; such layers (the language
+        // model's K = 51) stay on the fp64 kernel
+        if (need(th) <= 65536 && (size_t)kWave * upi < 65536) {
+            const int Wf = th / kWave;
+            const dim3 gridf(tl.bpr ? (unsigned)tl.ntiles : (unsigned)((tl.ntiles + Wf - 1) / Wf)), blockf(th);
+            const size_t lds = need(th);
+            switch (kt) {
+                case 4: hipLaunchKernelGGL((mixture_fwd_f32_kernel<4>), gridf, blockf, lds, st, a, tl, PS, strip); break;
+                case 8: hipLaunchKernelGGL((mixture_fwd_f32_kernel<8>), gridf, blockf, lds, st, a, tl, PS, strip); break;
+                case 16: hipLaunchKernelGGL((mixture_fwd_f32_kernel<16>), gridf, blockf, lds, st, a, tl, PS, strip); break;
+                default: hipLaunchKernelGGL((mixture_fwd_f32_kernel<0>), gridf, blockf, lds, st, a, tl, PS, strip); break;
+            }
+            return launch_status(who);
         }
     }
     const int W = threads / kWave;

@@ -61,6 +61,8 @@ void cnf_set_math_mode(int mode);
  * component quantiles mu_k + s_k logit(u) and started at their weighted mean, same stop: same root to
  * ~1e-10, several times fewer CDF evaluations. */
 void cnf_set_inverse_mode(int mode);
+/* Items (transformed elements) one wave of the fp32 mixture forward kernel owns, 64..512 (default 128). */
+void cnf_set_mixture_tile(int items);
 
 /* ---- affine coupling -------------------------------------------------------------------- */
 

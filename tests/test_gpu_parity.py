@@ -12,6 +12,7 @@ import torch.nn as nn
 
 from oracle import cnf_oracle as O
 from tests.golden_util import load_cases
+from categoricalnf_amd import _lib
 
 pytestmark = pytest.mark.gpu
 
@@ -179,6 +180,66 @@ def test_mixture_vs_oracle(B, N, D, K, kind):
     # round trip on the transformed, un-padded entries
     keep = (pad if pad is not None else torch.ones(B, N, 1)).expand(-1, -1, D) > 0
     assert ((zr.cpu() - z)[keep]).abs().max() < 5e-4
+
+
+@pytest.fixture
+def exact_math():
+    """math mode 0: the fp64 mixture kernel / libm affine kernel (default is 1 = fast)."""
+    lib = _lib.load()
+    lib.cnf_set_math_mode(0)
+    yield
+    lib.cnf_set_math_mode(1)
+
+
+@pytest.mark.parametrize("B,N,D,K,kind", [(40, 16, 4, 8, "channel"), (3, 288, 3, 51, "none"), (11, 13, 1, 8, "chess"),
+                                          (9, 38, 6, 16, "channel"), (70, 5, 3, 4, "channel"), (5, 20, 2, 10, "channel")])
+def test_mixture_exact_mode_vs_oracle(exact_math, B, N, D, K, kind):
+    """The fp64 forward kernel (math mode 0) against the oracle; the default-mode tests above run the fp32 kernel."""
+    gen = torch.Generator().manual_seed(B + 7 * N + 31 * D + K)
+    z = 1.5 * torch.randn(B, N, D, generator=gen)
+    nn_out = 0.6 * torch.randn(B, N, D * (2 + 3 * K), generator=gen)
+    sf, msf = 0.2 * torch.randn(D, generator=gen), 0.2 * torch.randn(D, K, generator=gen)
+    mask = None if kind == "none" else (O.chess_mask() if kind == "chess" else O.channel_mask(D))
+    ln = torch.randint(max(1, N // 2), N + 1, (B,), generator=gen)
+    pad = O.length_mask(ln, N) if kind != "none" else None
+    kw = dict(num_mixtures=K, reg_max=3.5, reg_factor=2.0, is_training=True)
+    zo, lo, ro = O.mixture_coupling(z, nn_out, mask, scaling_factor=sf, mixture_scaling_factor=msf, channel_padding_mask=pad, **kw)
+    zf, lf, rf = ops().mixture_coupling(g(z), g(nn_out), g(mask), scaling_factor=g(sf), mixture_scaling_factor=g(msf),
+                                        channel_padding_mask=g(pad), **kw)
+    close(zf, zo, **ELEM); close(lf, lo, **LDJ); close(rf, ro, **LDJ)
+
+
+@pytest.mark.parametrize("scale", [1.0, 4.0, 12.0, 40.0])
+def test_mixture_fast_vs_exact(scale):
+    """fp32 LDS-staged forward kernel vs the fp64 kernel on the same inputs, from the bulk (scale 1) to far tails
+    (scale 40: most elements take the kernel's fp64 fallback branch, u or 1-u < 1e-9)."""
+    B, N, D, K = 64, 16, 4, 8
+    gen = torch.Generator().manual_seed(int(scale * 10))
+    z = scale * torch.randn(B, N, D, generator=gen)
+    nn_out = 0.6 * torch.randn(B, N, D * (2 + 3 * K), generator=gen)
+    sf, msf = 0.2 * torch.randn(D, generator=gen), 0.2 * torch.randn(D, K, generator=gen)
+    mask = O.channel_mask(D)
+    kw = dict(num_mixtures=K, scaling_factor=g(sf), mixture_scaling_factor=g(msf), reg_max=3.5, reg_factor=2.0, is_training=True)
+    lib = _lib.load()
+    zf, lf, rf = ops().mixture_coupling(g(z), g(nn_out), g(mask), **kw)
+    lib.cnf_set_math_mode(0)
+    try:
+        ze, le, re_ = ops().mixture_coupling(g(z), g(nn_out), g(mask), **kw)
+    finally:
+        lib.cnf_set_math_mode(1)
+    fin = torch.isfinite(ze)
+    assert torch.equal(fin, torch.isfinite(zf))
+    close(zf[fin], ze[fin], rtol=1e-5, atol=1e-5)
+    close(lf, le, rtol=2e-5, atol=2e-4)
+    close(rf, re_, rtol=1e-4, atol=1e-4)
+    # and against the oracle.  Beyond |logit| ~ 36 (1 - u < 1e-16) the reference's fp64 `1 - u` is rounding noise of
+    # its log-space evaluation (it returns 36.7 or 50.6 depending on the last bit of u), so scale 40 is only
+    # compared kernel to kernel above.
+    if scale <= 12.0:
+        zo, lo, _ = O.mixture_coupling(z, nn_out, mask, num_mixtures=K, scaling_factor=sf, mixture_scaling_factor=msf,
+                                       reg_max=3.5, reg_factor=2.0, is_training=True)
+        fo = torch.isfinite(zo)
+        close(zf.cpu()[fo], zo[fo], rtol=1e-4, atol=1e-4); close(lf, lo, **LDJ)
 
 
 def test_mixture_underflow_fallback_matches_logspace():

@@ -32,9 +32,17 @@ for name, B, N, D, K, kind in shapes:
             ts.append(a.elapsed_time(b) / reps * 1e3)
         return min(ts)
     tf = timeit(fwd)
+    lib.cnf_set_math_mode(0)
+    tf64 = timeit(fwd)
+    lib.cnf_set_math_mode(1)
+    tiles = []
+    for tile in (64, 128, 256):
+        lib.cnf_set_mixture_tile(tile)
+        tiles.append("%d:%.1f" % (tile, timeit(fwd)))
+    lib.cnf_set_mixture_tile(128)
     elems = B * N * D
-    line = "%-26s B=%5d N=%3d D=%d K=%2d | fwd %8.1f us (%6.2f Gelem/s, %5.0f GB/s alg)" % (
-        name, B, N, D, K, tf, elems / tf / 1e3, elems * (16 + 12 * K) / tf / 1e3)
+    line = "%-26s B=%5d N=%3d D=%d K=%2d | fwd %8.1f us (%6.2f Gelem/s, %5.0f GB/s alg; fp64 kernel %7.1f us; tile %s)" % (
+        name, B, N, D, K, tf, elems / tf / 1e3, elems * (16 + 12 * K) / tf / 1e3, tf64, " ".join(tiles))
     if inv is not None:
         for mode in (0, 1):
             lib.cnf_set_inverse_mode(mode)
