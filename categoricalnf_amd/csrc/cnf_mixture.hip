@@ -505,8 +505,8 @@ __device__ __forceinline__ float apply_bound(float v, const BoundTab& b) {
     return fmaf(__builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(v * b.x3) + 1.f), b.m2f, b.f);
 }
 
-template <int KT>
-__global__ __launch_bounds__(kBlock) void mixture_fwd_f32_kernel(MixArgs a, RowTiling tl, int PS, int strip) {
+template <int KT, bool REVERSE>
+__global__ __launch_bounds__(kBlock) void mixture_f32_kernel(MixArgs a, RowTiling tl, int PS, int strip) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int W = blockDim.x >> 6;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -532,7 +532,7 @@ __global__ __launch_bounds__(kBlock) void mixture_fwd_f32_kernel(MixArgs a, RowT
     if (tile >= tl.ntiles) return;
     const int row0 = (int)(tile * tl.rw);
     const int nrows = min(tl.rw, tl.B - row0);
-    bool bad = false;
+    bool bad = false, range = false;
 
     // ---- phase 1: copy the elements that are not transformed (masked channel or padded token)
     {
@@ -609,7 +609,120 @@ __global__ __launch_bounds__(kBlock) void mixture_fwd_f32_kernel(MixArgs a, RowT
         }
         wave_lds_sync();
         double contrib = 0.0;
-        if (active) {
+        if (active && REVERSE) {
+            // ---- inverse (:125-134, :235-264) in fp32: safeguarded Newton on the two-sided CDF.  u = sigmoid(v)
+            // is clamped to [1e-5, 1 - 1e-5] by the reference, so the root lies where fp32 sums of positive
+            // terms are accurate to ~1e-6 relative in BOTH tails: solve cdf(x) = u se for u <= 1/2 and
+            // ccdf(x) = (1 - u) se otherwise.  A relative error eps of the sum moves x by ~eps * s_k.
+            float* my = stage + lane * PS;
+            const float t = my[0];
+            float log_s = my[1];
+            if (a.sf) log_s = apply_bound(log_s, sf_tab[d]);
+            const float v = x * __builtin_amdgcn_exp2f(-log_s * kLog2eF) - t;
+            const float ev = __builtin_amdgcn_exp2f(-fabsf(v) * kLog2eF);
+            const float rv = __builtin_amdgcn_rcpf(1.f + ev);
+            const float mixt_ldj = fabsf(v) + 2.f * kLn2F * __builtin_amdgcn_logf(1.f + ev);
+            float usmall = fmaxf(ev * rv, 1e-5f), ubig = fminf(rv, 1.f - 1e-5f);     // (:130) clamp
+            const bool upper = v >= 0.f;                    // u > 1/2
+            const float u = upper ? ubig : usmall, uc = upper ? usmall : ubig;
+            if (!(u > 0.f && u < 1.f)) range = true;
+            const float logit_u = (__builtin_amdgcn_logf(u) - __builtin_amdgcn_logf(uc)) * kLn2F;
+            const BoundTab* mt = msf_tab + d * K;
+            constexpr int KK = KT > 0 ? KT : 1;
+            float wr[KK], isr[KK], mur[KK];
+            float mx = -INFINITY;
+            if (KT > 0) {
+#pragma unroll
+                for (int k = 0; k < KK; ++k) mx = fmaxf(mx, my[2 + k]);
+            } else {
+                for (int k = 0; k < K; ++k) mx = fmaxf(mx, my[2 + k]);
+            }
+            float se = 0.f, spread = 0.f, lb = INFINITY, ub = -INFINITY, qsum = 0.f;
+            auto setup = [&](int k) {
+                const float lsk = my[2 + 2 * K + k];
+                const float ls = a.msf ? apply_bound(lsk, mt[k]) : lsk;
+                const float w = __builtin_amdgcn_exp2f((my[2 + k] - mx) * kLog2eF);
+                const float sk = __builtin_amdgcn_exp2f(ls * kLog2eF);
+                const float ik = __builtin_amdgcn_rcpf(sk);
+                const float mk = my[2 + K + k];
+                // every component's own u-quantile: the mixture quantile lies between their min and max
+                const float qk = fmaf(sk, logit_u, mk);
+                se += w;
+                spread += sk;
+                lb = fminf(lb, qk);
+                ub = fmaxf(ub, qk);
+                qsum = fmaf(w, qk, qsum);
+                if (KT > 0) {
+                    wr[k < KK ? k : 0] = w; isr[k < KK ? k : 0] = ik; mur[k < KK ? k : 0] = mk;
+                } else {
+                    my[2 + k] = w;              // run-time K: the constants replace the raw row in LDS
+                    my[2 + 2 * K + k] = ik;
+                }
+            };
+            if (KT > 0) {
+#pragma unroll
+                for (int k = 0; k < KK; ++k) setup(k);
+            } else {
+                for (int k = 0; k < K; ++k) setup(k);
+            }
+            const float target = (upper ? uc : u) * se;
+            const float tol_scale = 1e-7f * spread;
+            float xb = fminf(fmaxf(qsum * __builtin_amdgcn_rcpf(se), lb), ub);
+            float dx_prev = ub - lb, dens = 0.f, diff = INFINITY;
+            auto eval = [&](float xq, float& f_out, float& dens_out) {
+                float cdf = 0.f, ccdf = 0.f, dn = 0.f;
+                auto one = [&](float wk, float ik, float mk) {
+                    const float zk = (xq - mk) * ik;
+                    const float e = __builtin_amdgcn_exp2f(-fabsf(zk) * kLog2eF);
+                    const float rr = __builtin_amdgcn_rcpf(1.f + e);
+                    const float er = e * rr;
+                    const bool pos = zk >= 0.f;
+                    cdf = fmaf(wk, pos ? rr : er, cdf);
+                    ccdf = fmaf(wk, pos ? er : rr, ccdf);
+                    dn = fmaf(wk * ik, er * rr, dn);
+                };
+                if (KT > 0) {
+#pragma unroll
+                    for (int k = 0; k < KK; ++k) one(wr[k], isr[k], mur[k]);
+                } else {
+                    for (int k = 0; k < K; ++k) one(my[2 + k], my[2 + 2 * K + k], my[2 + K + k]);
+                }
+                f_out = upper ? target - ccdf : cdf - target;       // increasing in x either way
+                dens_out = dn;
+            };
+            for (int iter = 0; iter < 64; ++iter) {
+                float f;
+                eval(xb, f, dens);
+                float nx;
+                if (f > 0.f) {
+                    nx = 0.5f * (xb + lb);
+                    ub = xb;
+                } else {
+                    nx = 0.5f * (xb + ub);
+                    lb = xb;
+                }
+                // rtsafe: Newton step when it stays in the bracket and at least halves the previous step
+                if (dens > 0.f && fabsf(2.f * f) <= fabsf(dx_prev * dens)) {
+                    const float xn = xb - f * __builtin_amdgcn_rcpf(dens);
+                    if (xn >= lb && xn <= ub) nx = xn;
+                }
+                diff = fabsf(nx - xb);
+                dx_prev = diff;
+                xb = nx;
+                if (!(diff > fmaf(1e-7f, fabsf(xb), tol_scale))) break;
+            }
+            if (diff > 1e-5f * (fabsf(xb) + spread)) {      // left the loop far from converged: density at the final point
+                float f;
+                eval(xb, f, dens);
+            }
+            const float lpdf = (__builtin_amdgcn_logf(dens) - __builtin_amdgcn_logf(se)) * kLn2F;
+            float of = xb;
+            if (a.pad_output) of = of * pv;
+            a.z_out[elem] = of;
+            bad |= isnan(of);
+            contrib = (double)(log_s + mixt_ldj + lpdf);
+        }
+        if (active && !REVERSE) {
             const float* my = stage + lane * PS;
             const float t = my[0];
             float log_s = my[1];
@@ -732,7 +845,7 @@ __global__ __launch_bounds__(kBlock) void mixture_fwd_f32_kernel(MixArgs a, RowT
     }
 
     auto finish = [&](int row, double sum) {
-        const float v = (a.ldj_in ? a.ldj_in[row] : 0.f) + (float)sum;
+        const float v = (a.ldj_in ? a.ldj_in[row] : 0.f) + (float)(REVERSE ? -sum : sum);
         a.ldj_out[row] = v;
         if (isnan(v)) raise_flag(a.flags, CNF_FLAG_NAN_LDJ);
     };
@@ -762,6 +875,7 @@ __global__ __launch_bounds__(kBlock) void mixture_fwd_f32_kernel(MixArgs a, RowT
         }
     }
     if (bad) raise_flag(a.flags, CNF_FLAG_NAN_Z);
+    if (range) raise_flag(a.flags, CNF_FLAG_RANGE);
 }
 
 // get_mixt_params (:145-180): split + fp32 tanh bound + mask, widened to fp64
@@ -861,8 +975,8 @@ static int launch_mixture(MixArgs& a, bool split, const int* act_host, int n_act
             threads = kBlock;
         }
     }
-    // forward in fast math mode: fp32 kernel on LDS-staged parameter rows
-    if (!split && !a.reverse && math_mode() == 1) {
+    // fast math mode: fp32 kernel on LDS-staged parameter rows (forward; inverse when the Newton mode is selected)
+    if (!split && math_mode() == 1 && (!a.reverse || inverse_mode() == 1)) {
         // smaller tiles than the fp64 kernel: at ~100 VGPRs four waves per SIMD are resident, and a
         // config-sized batch (5e5 items) only fills them when a wave owns ~128 items
         const RowTiling tl = make_row_tiling(a.B, a.N * a.DA, /*force_vec=*/1, mixture_tile_items());
@@ -879,12 +993,16 @@ static int launch_mixture(MixArgs& a, bool split, const int* act_host, int n_act
             const int Wf = th / kWave;
             const dim3 gridf(tl.bpr ? (unsigned)tl.ntiles : (unsigned)((tl.ntiles + Wf - 1) / Wf)), blockf(th);
             const size_t lds = need(th);
+#define CNF_MIXF(KT_)                                                                                          \
+    if (a.reverse) hipLaunchKernelGGL((mixture_f32_kernel<KT_, true>), gridf, blockf, lds, st, a, tl, PS, strip); \
+    else hipLaunchKernelGGL((mixture_f32_kernel<KT_, false>), gridf, blockf, lds, st, a, tl, PS, strip)
             switch (kt) {
-                case 4: hipLaunchKernelGGL((mixture_fwd_f32_kernel<4>), gridf, blockf, lds, st, a, tl, PS, strip); break;
-                case 8: hipLaunchKernelGGL((mixture_fwd_f32_kernel<8>), gridf, blockf, lds, st, a, tl, PS, strip); break;
-                case 16: hipLaunchKernelGGL((mixture_fwd_f32_kernel<16>), gridf, blockf, lds, st, a, tl, PS, strip); break;
-                default: hipLaunchKernelGGL((mixture_fwd_f32_kernel<0>), gridf, blockf, lds, st, a, tl, PS, strip); break;
+                case 4: CNF_MIXF(4); break;
+                case 8: CNF_MIXF(8); break;
+                case 16: CNF_MIXF(16); break;
+                default: CNF_MIXF(0); break;
             }
+#undef CNF_MIXF
             return launch_status(who);
         }
     }

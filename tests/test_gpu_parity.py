@@ -207,6 +207,17 @@ def test_mixture_exact_mode_vs_oracle(exact_math, B, N, D, K, kind):
     zf, lf, rf = ops().mixture_coupling(g(z), g(nn_out), g(mask), scaling_factor=g(sf), mixture_scaling_factor=g(msf),
                                         channel_padding_mask=g(pad), **kw)
     close(zf, zo, **ELEM); close(lf, lo, **LDJ); close(rf, ro, **LDJ)
+    # fp64 inverse (safeguarded Newton and the reference's bisection)
+    zo2, lo2, _ = O.mixture_coupling(zo, nn_out, mask, scaling_factor=sf, mixture_scaling_factor=msf,
+                                     channel_padding_mask=pad, reverse=True, **kw)
+    for mode in (1, 0):
+        _lib.load().cnf_set_inverse_mode(mode)
+        try:
+            zr, lr, _ = ops().mixture_coupling(g(zo), g(nn_out), g(mask), scaling_factor=g(sf), mixture_scaling_factor=g(msf),
+                                               channel_padding_mask=g(pad), reverse=True, **kw)
+        finally:
+            _lib.load().cnf_set_inverse_mode(1)
+        close(zr, zo2, rtol=1e-4, atol=1e-4); close(lr, lo2, **LDJ)
 
 
 @pytest.mark.parametrize("scale", [1.0, 4.0, 12.0, 40.0])

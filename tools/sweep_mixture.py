@@ -43,11 +43,10 @@ for name, B, N, D, K, kind in shapes:
     elems = B * N * D
     line = "%-26s B=%5d N=%3d D=%d K=%2d | fwd %8.1f us (%6.2f Gelem/s, %5.0f GB/s alg; fp64 kernel %7.1f us; tile %s)" % (
         name, B, N, D, K, tf, elems / tf / 1e3, elems * (16 + 12 * K) / tf / 1e3, tf64, " ".join(tiles))
-    if inv is not None:
-        for mode in (0, 1):
-            lib.cnf_set_inverse_mode(mode)
-            ti = timeit(inv, reps=5)
-            err = (zr - z).abs().max().item()
-            line += " | inv[%s] %8.1f us err %.1e" % ("bisect" if mode == 0 else "newton", ti, err)
-        lib.cnf_set_inverse_mode(1)
+    for tag, math, mode in (("fp64 bisect", 0, 0), ("fp64 newton", 0, 1), ("fp32 newton", 1, 1)):
+        lib.cnf_set_math_mode(math); lib.cnf_set_inverse_mode(mode)
+        ti = timeit(inv, reps=5)
+        err = (zr - z).abs().max().item()
+        line += " | inv[%s] %7.1f us err %.1e" % (tag, ti, err)
+    lib.cnf_set_math_mode(1); lib.cnf_set_inverse_mode(1)
     print(line, flush=True)
