@@ -134,7 +134,7 @@ def mixture_measure(ops, dev, steps=20, warmup=3):
     tf, ti = tf / steps, ti / steps
     elems = B * N * D
     bytes_alg = elems * (16 + 12 * K)
-    return {"workload": "mixture_cdf_coupling B=16384 N=16 D=4 K=8 (configs[1])", "dtype": "f64",
+    return {"workload": "mixture_cdf_coupling B=16384 N=16 D=4 K=8 (configs[1])", "dtype": "f32 (fp64 fallback branch for |logit| > 20.7)",
             "fwd_ms": tf, "inv_ms": ti, "fwd_elems_per_s": elems / (tf * 1e-3), "inv_elems_per_s": elems / (ti * 1e-3),
             "fwd_inv_elems_per_s": elems / ((tf + ti) * 1e-3),
             "fwd_algorithmic_GBps": bytes_alg / (tf * 1e-3) / 1e9, "fwd_hbm_frac": bytes_alg / (tf * 1e-3) / 1e9 / HBM_PEAK_GBS}

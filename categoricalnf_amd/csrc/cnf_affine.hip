@@ -49,12 +49,6 @@ inline PriorConst make_prior_const(float sigma, float log_sigma) {
     c.log_sigma = log_sigma;
     return c;
 }
-// -(softplus pair) without the constant: lp + log_sigma, as two fused multiply-adds
-__device__ __forceinline__ float prior_logp_nc(float x, const PriorConst& c) {
-    const float ax = fabsf(x);
-    const float l2 = __builtin_amdgcn_logf(1.f + __builtin_amdgcn_exp2f(-ax * c.inv_sigma_log2e));
-    return fmaf(l2, -1.3862943611198906f, -ax * c.inv_sigma);
-}
 __device__ __forceinline__ float prior_logp(float x, const PriorConst& c) {
     const float ax = fabsf(x);
     const float l2 = __builtin_amdgcn_logf(1.f + __builtin_amdgcn_exp2f(-ax * c.inv_sigma_log2e));
@@ -204,7 +198,7 @@ __global__ __launch_bounds__(kBlock) void affine_coupling_kernel(AffineArgs a, R
         const size_t off = (size_t)row * a.L + e0;
         float out[VEC];
         const ChanTab* tb0 = tab + (e0 - (int)fdiv((uint32_t)e0, a.div_p) * a.P);   // e0 mod P
-        float acc = 0.f, lp_acc = 0.f;
+        float acc = 0.f, lp_acc = 0.f, lp_prod = 1.f;
         const float* padrow = NLLM == 2 ? a.pad + (size_t)row * a.N : nullptr;
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
@@ -217,15 +211,19 @@ __global__ __launch_bounds__(kBlock) void affine_coupling_kernel(AffineArgs a, R
             out[j] = REVERSE ? c.zv[j] * exp_m<FAST>(-1.f * s) - t : (c.zv[j] + t) * exp_m<FAST>(s);
             bad |= isnan(out[j]);
             acc += s;
-            if (NLL) {
-                if (NLLM == 2) lp_acc += prior_logp(out[j], a.prior) * padrow[fdiv((uint32_t)(e0 + j), a.div_d)];
-                else lp_acc += prior_logp_nc(out[j], a.prior);
+            if (NLLM == 2) lp_acc += prior_logp(out[j], a.prior) * padrow[fdiv((uint32_t)(e0 + j), a.div_d)];
+            if (NLLM == 1) {
+                // sum_j log(1 + e_j) = log prod_j (1 + e_j): one v_log_f32 per chunk (the product is in [1, 2^VEC])
+                const float ax = fabsf(out[j]);
+                lp_acc = fmaf(ax, -a.prior.inv_sigma, lp_acc);
+                lp_prod *= 1.f + __builtin_amdgcn_exp2f(-ax * a.prior.inv_sigma_log2e);
             }
         }
         VecIO<VEC>::store(a.z_out + off, out);
         if constexpr (NLL) {
-            // un-padded rows: the constant log(sigma) of every element is added once per chunk
-            if (NLLM == 1) lp_acc -= (float)VEC * a.prior.log_sigma;
+            // un-padded rows: the log term and the constant log(sigma) of the chunk's elements are added once
+            if (NLLM == 1)
+                lp_acc = fmaf(__builtin_amdgcn_logf(lp_prod), -1.3862943611198906f, lp_acc) - (float)VEC * a.prior.log_sigma;
             return Sum2(acc, lp_acc);
         } else {
             return acc;
@@ -484,10 +482,21 @@ __global__ __launch_bounds__(kBlock) void prior_nll_kernel(NllArgs a, RowTiling 
         int n = (int)fdiv((uint32_t)e0, a.div_d);
         int d = e0 - n * a.D;
         float acc = 0.f;
+        if (!a.pad) {
+            // sum_j log(1 + e_j) = log prod_j (1 + e_j): one v_log_f32 per chunk
+            float prod = 1.f;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const float ax = fabsf(c.v[j]);
+                acc = fmaf(ax, -a.prior.inv_sigma, acc);
+                prod *= 1.f + __builtin_amdgcn_exp2f(-ax * a.prior.inv_sigma_log2e);
+            }
+            return fmaf(__builtin_amdgcn_logf(prod), -1.3862943611198906f, acc) - (float)VEC * a.prior.log_sigma;
+        }
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             const float lp = prior_logp(c.v[j], a.prior);
-            acc += a.pad ? lp * a.pad[(size_t)row * a.N + n] : lp;
+            acc += lp * a.pad[(size_t)row * a.N + n];
             if (++d == a.D) {
                 d = 0;
                 ++n;

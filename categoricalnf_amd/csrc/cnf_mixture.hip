@@ -505,8 +505,33 @@ __device__ __forceinline__ float apply_bound(float v, const BoundTab& b) {
     return fmaf(__builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(v * b.x3) + 1.f), b.m2f, b.f);
 }
 
-template <int KT, bool REVERSE>
+// G = lanes per item: 1, or 4 for a run-time K too large to stage 64 rows per wave (the language model's K = 51
+// rows are 620 bytes): a pass then covers 16 items, lane g of an item takes the mixtures k = g (mod 4) and the four
+// partial sums are combined by xor-shuffles (symmetric, so the four lanes stay bit-identical and take the same
+// branches).
+template <int G>
+__device__ __forceinline__ float gsum(float v) {
+    if (G >= 2) v += __shfl_xor(v, 1, kWave);
+    if (G >= 4) v += __shfl_xor(v, 2, kWave);
+    return v;
+}
+template <int G>
+__device__ __forceinline__ float gmax(float v) {
+    if (G >= 2) v = fmaxf(v, __shfl_xor(v, 1, kWave));
+    if (G >= 4) v = fmaxf(v, __shfl_xor(v, 2, kWave));
+    return v;
+}
+template <int G>
+__device__ __forceinline__ float gmin(float v) {
+    if (G >= 2) v = fminf(v, __shfl_xor(v, 1, kWave));
+    if (G >= 4) v = fminf(v, __shfl_xor(v, 2, kWave));
+    return v;
+}
+
+template <int KT, bool REVERSE, int G = 1>
 __global__ __launch_bounds__(kBlock) void mixture_f32_kernel(MixArgs a, RowTiling tl, int PS, int strip) {
+    static_assert(G == 1 || KT == 0, "several lanes per item only with a run-time K");
+    constexpr int IPP = kWave / G;            // items per wave pass
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int W = blockDim.x >> 6;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -514,8 +539,8 @@ __global__ __launch_bounds__(kBlock) void mixture_f32_kernel(MixArgs a, RowTilin
     // LDS: [W][strip] fp64 row partials | [W][64 * PS] staged rows | [D] + [D*K] bound tables
     double* part = reinterpret_cast<double*>(smem) + (size_t)wave * strip;
     float* stage_all = reinterpret_cast<float*>(reinterpret_cast<double*>(smem) + (size_t)W * strip);
-    float* stage = stage_all + (size_t)wave * kWave * PS;
-    BoundTab* sf_tab = reinterpret_cast<BoundTab*>(stage_all + (size_t)W * kWave * PS);
+    float* stage = stage_all + (size_t)wave * IPP * PS;
+    BoundTab* sf_tab = reinterpret_cast<BoundTab*>(stage_all + (size_t)W * IPP * PS);
     BoundTab* msf_tab = sf_tab + a.D;
     __shared__ int s_act[kMaxAct];
     if (threadIdx.x < kMaxAct && ((a.act_bits >> threadIdx.x) & 1ull))
@@ -530,8 +555,10 @@ __global__ __launch_bounds__(kBlock) void mixture_f32_kernel(MixArgs a, RowTilin
     const long tile = tl.bpr ? (long)blockIdx.x : (long)blockIdx.x * W + wave;
     // a wave without a tile still has to reach no later barrier: none follow
     if (tile >= tl.ntiles) return;
-    const int row0 = (int)(tile * tl.rw);
+    const int row0 = __builtin_amdgcn_readfirstlane((int)(tile * tl.rw));      // wave-uniform by construction
     const int nrows = min(tl.rw, tl.B - row0);
+    const size_t tile_elem0 = (size_t)row0 * a.N * a.D;
+    const float* tile_nn = a.nn + tile_elem0 * (size_t)a.P;
     bool bad = false, range = false;
 
     // ---- phase 1: copy the elements that are not transformed (masked channel or padded token)
@@ -561,8 +588,9 @@ __global__ __launch_bounds__(kBlock) void mixture_f32_kernel(MixArgs a, RowTilin
     const int upi = vec2 ? P >> 1 : P;              // units per item
     const FastDiv div_upi = a.div_upi;
     double acc1 = 0.0;
-    for (int c0 = tl.bpr ? wave * kWave : 0; c0 < nitems; c0 += nlanes) {     // wave-uniform
-        const int c = c0 + lane;
+    const int sub = lane & (G - 1), li = lane / G;      // lane's share of the mixtures, lane's item in the pass
+    for (int c0 = tl.bpr ? wave * IPP : 0; c0 < nitems; c0 += nlanes / G) {     // wave-uniform
+        const int c = c0 + li;
         const bool valid = c < nitems;
         const int cc = valid ? c : nitems - 1;
         const int r = tl.rw == 1 ? 0 : (int)fdiv((uint32_t)cc, tl.div_cpr);
@@ -576,32 +604,34 @@ __global__ __launch_bounds__(kBlock) void mixture_f32_kernel(MixArgs a, RowTilin
         if (a.pad_in_transform && pv == 0.f) active = false;
         const size_t elem = ((size_t)row * a.N + n) * a.D + d;
         const float x = active ? a.z[elem] : 0.f;
-        // -- stage the 64 rows: unit q of the pass belongs to item q / upi; its row start comes from that lane
-        const unsigned long long rowbase = active ? (unsigned long long)(elem * (size_t)P) : ~0ull;
-        const unsigned lo = (unsigned)rowbase, hi = (unsigned)(rowbase >> 32);
-        const int total = kWave * upi;
-        for (int q0 = 0; q0 < total; q0 += kWave * 8) {
-            float2 v[8];
-            int itemv[8], offv[8];
+        // -- stage the rows of the pass: unit q belongs to item q / upi, whose row start (a 32-bit offset from
+        // the tile's first parameter row, which is wave-uniform -> scalar base + 32-bit vector offset addressing)
+        // comes from that item's lane by shuffle
+        const unsigned rowoff = active ? (unsigned)((elem - tile_elem0) * (size_t)P) : ~0u;
+        const int total = IPP * upi;
+        constexpr int UR = 8;           // units in flight per lane and round
+        for (int q0 = 0; q0 < total; q0 += kWave * UR) {
+            float2 v[UR];
+            unsigned ok = 0;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < UR; ++u) {
                 const int q = min(q0 + u * kWave + lane, total - 1);
                 const int item = (int)fdiv((uint32_t)q, div_upi);
                 const int off = q - item * upi;
-                const unsigned blo = __shfl(lo, item, kWave), bhi = __shfl(hi, item, kWave);
-                const unsigned long long b = ((unsigned long long)bhi << 32) | blo;
-                itemv[u] = b == ~0ull ? -1 : item;
-                offv[u] = off;
-                v[u] = make_float2(0.f, 0.f);
-                if (b != ~0ull) {
-                    if (vec2) v[u] = *reinterpret_cast<const float2*>(a.nn + b + 2 * off);
-                    else v[u].x = a.nn[b + off];
-                }
+                const unsigned b = __shfl(rowoff, item * G, kWave);
+                // unconditional loads (an inactive item reads the tile's first row): no branch per unit
+                const unsigned bs = b == ~0u ? 0u : b;
+                if (b != ~0u && q0 + u * kWave + lane < total) ok |= 1u << u;
+                if (vec2) v[u] = *reinterpret_cast<const float2*>(tile_nn + (bs + 2u * (unsigned)off));
+                else v[u] = make_float2(tile_nn[bs + (unsigned)off], 0.f);
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (q0 + u * kWave + lane < total && itemv[u] >= 0) {
-                    float* dst = stage + itemv[u] * PS + (vec2 ? 2 * offv[u] : offv[u]);
+            for (int u = 0; u < UR; ++u) {
+                if ((ok >> u) & 1u) {
+                    const int q = q0 + u * kWave + lane;
+                    const int item = (int)fdiv((uint32_t)q, div_upi);
+                    const int off = q - item * upi;
+                    float* dst = stage + item * PS + (vec2 ? 2 * off : off);
                     dst[0] = v[u].x;
                     if (vec2) dst[1] = v[u].y;
                 }
@@ -614,7 +644,7 @@ __global__ __launch_bounds__(kBlock) void mixture_f32_kernel(MixArgs a, RowTilin
             // is clamped to [1e-5, 1 - 1e-5] by the reference, so the root lies where fp32 sums of positive
             // terms are accurate to ~1e-6 relative in BOTH tails: solve cdf(x) = u se for u <= 1/2 and
             // ccdf(x) = (1 - u) se otherwise.  A relative error eps of the sum moves x by ~eps * s_k.
-            float* my = stage + lane * PS;
+            float* my = stage + li * PS;
             const float t = my[0];
             float log_s = my[1];
             if (a.sf) log_s = apply_bound(log_s, sf_tab[d]);
@@ -635,7 +665,8 @@ __global__ __launch_bounds__(kBlock) void mixture_f32_kernel(MixArgs a, RowTilin
 #pragma unroll
                 for (int k = 0; k < KK; ++k) mx = fmaxf(mx, my[2 + k]);
             } else {
-                for (int k = 0; k < K; ++k) mx = fmaxf(mx, my[2 + k]);
+                for (int k = sub; k < K; k += G) mx = fmaxf(mx, my[2 + k]);
+                mx = gmax<G>(mx);
             }
             float se = 0.f, spread = 0.f, lb = INFINITY, ub = -INFINITY, qsum = 0.f;
             auto setup = [&](int k) {
@@ -663,7 +694,9 @@ __global__ __launch_bounds__(kBlock) void mixture_f32_kernel(MixArgs a, RowTilin
 #pragma unroll
                 for (int k = 0; k < KK; ++k) setup(k);
             } else {
-                for (int k = 0; k < K; ++k) setup(k);
+                for (int k = sub; k < K; k += G) setup(k);
+                se = gsum<G>(se); spread = gsum<G>(spread); qsum = gsum<G>(qsum);
+                lb = gmin<G>(lb); ub = gmax<G>(ub);
             }
             const float target = (upper ? uc : u) * se;
             const float tol_scale = 1e-7f * spread;
@@ -685,7 +718,8 @@ __global__ __launch_bounds__(kBlock) void mixture_f32_kernel(MixArgs a, RowTilin
 #pragma unroll
                     for (int k = 0; k < KK; ++k) one(wr[k], isr[k], mur[k]);
                 } else {
-                    for (int k = 0; k < K; ++k) one(my[2 + k], my[2 + 2 * K + k], my[2 + K + k]);
+                    for (int k = sub; k < K; k += G) one(my[2 + k], my[2 + 2 * K + k], my[2 + K + k]);
+                    cdf = gsum<G>(cdf); ccdf = gsum<G>(ccdf); dn = gsum<G>(dn);
                 }
                 f_out = upper ? target - ccdf : cdf - target;       // increasing in x either way
                 dens_out = dn;
@@ -718,12 +752,14 @@ __global__ __launch_bounds__(kBlock) void mixture_f32_kernel(MixArgs a, RowTilin
             const float lpdf = (__builtin_amdgcn_logf(dens) - __builtin_amdgcn_logf(se)) * kLn2F;
             float of = xb;
             if (a.pad_output) of = of * pv;
-            a.z_out[elem] = of;
+            if (sub == 0) {
+                a.z_out[elem] = of;
+                contrib = (double)(log_s + mixt_ldj + lpdf);
+            }
             bad |= isnan(of);
-            contrib = (double)(log_s + mixt_ldj + lpdf);
         }
         if (active && !REVERSE) {
-            const float* my = stage + lane * PS;
+            const float* my = stage + li * PS;
             const float t = my[0];
             float log_s = my[1];
             if (a.sf) log_s = apply_bound(log_s, sf_tab[d]);
@@ -740,7 +776,8 @@ __global__ __launch_bounds__(kBlock) void mixture_f32_kernel(MixArgs a, RowTilin
 #pragma unroll
                 for (int k = 0; k < KK; ++k) mx = fmaxf(mx, lp[k]);
             } else {
-                for (int k = 0; k < K; ++k) mx = fmaxf(mx, my[2 + k]);
+                for (int k = sub; k < K; k += G) mx = fmaxf(mx, my[2 + k]);
+                mx = gmax<G>(mx);
             }
             const BoundTab* mt = msf_tab + d * K;
             float se = 0.f, cdf = 0.f, ccdf = 0.f, pdf = 0.f;
@@ -762,7 +799,8 @@ __global__ __launch_bounds__(kBlock) void mixture_f32_kernel(MixArgs a, RowTilin
 #pragma unroll
                 for (int k = 0; k < KK; ++k) one(lp[k], mu[k], lsr[k], k);
             } else {
-                for (int k = 0; k < K; ++k) one(my[2 + k], my[2 + K + k], my[2 + 2 * K + k], k);
+                for (int k = sub; k < K; k += G) one(my[2 + k], my[2 + K + k], my[2 + 2 * K + k], k);
+                se = gsum<G>(se); cdf = gsum<G>(cdf); ccdf = gsum<G>(ccdf); pdf = gsum<G>(pdf);
             }
             float of;
             double reg = 0.0;
@@ -833,11 +871,15 @@ __global__ __launch_bounds__(kBlock) void mixture_f32_kernel(MixArgs a, RowTilin
                 contrib = (double)log_s + (-lud - l1ud) + lpdfd + reg * a.reg_factor;
             }
             if (a.pad_output) of = of * pv;
-            a.z_out[elem] = of;
             bad |= isnan(of);
-            if (a.use_reg && a.reg_out && reg != 0.0) atomicAdd(&a.reg_out[row], (float)reg);
+            if (sub == 0) {
+                a.z_out[elem] = of;
+                if (a.use_reg && a.reg_out && reg != 0.0) atomicAdd(&a.reg_out[row], (float)reg);
+            } else {
+                contrib = 0.0;      // the item's log-det term is counted once
+            }
         }
-        if (valid) {
+        if (valid && sub == 0) {
             if (tl.rw == 1) acc1 += contrib;
             else part[c] = contrib;
         }
@@ -986,21 +1028,23 @@ static int launch_mixture(MixArgs& a, bool split, const int* act_host, int n_act
         const int strip = (tl.bpr || tl.rw == 1) ? 1 : tl.rw * tl.L;
         const size_t tabs = (size_t)(a.D + a.D * a.K) * 3 * sizeof(float);
         const int th = kBlock;
-        auto need = [&](int t) { return (size_t)(t / kWave) * ((size_t)strip * sizeof(double) + (size_t)kWave * PS * sizeof(float)) + tabs; };
-        // K > ~19: 64 staged rows per wave no longer fit four waves into 64 KiB; such layers (the language
-        // model's K = 51) stay on the fp64 kernel
-        if (need(th) <= 65536 && (size_t)kWave * upi < 65536) {
+        // 64 staged rows per wave while four waves fit into 64 KiB (K <= ~19); beyond that a wave stages 16 rows
+        // and four lanes share an item (the language model's K = 51)
+        auto need = [&](int ipp) { return (size_t)(th / kWave) * ((size_t)strip * sizeof(double) + (size_t)ipp * PS * sizeof(float)) + tabs; };
+        const int G = need(kWave) <= 65536 ? 1 : 4;
+        if (need(kWave / G) <= 65536 && (size_t)kWave * upi < 65536) {
             const int Wf = th / kWave;
             const dim3 gridf(tl.bpr ? (unsigned)tl.ntiles : (unsigned)((tl.ntiles + Wf - 1) / Wf)), blockf(th);
-            const size_t lds = need(th);
-#define CNF_MIXF(KT_)                                                                                          \
-    if (a.reverse) hipLaunchKernelGGL((mixture_f32_kernel<KT_, true>), gridf, blockf, lds, st, a, tl, PS, strip); \
-    else hipLaunchKernelGGL((mixture_f32_kernel<KT_, false>), gridf, blockf, lds, st, a, tl, PS, strip)
-            switch (kt) {
-                case 4: CNF_MIXF(4); break;
-                case 8: CNF_MIXF(8); break;
-                case 16: CNF_MIXF(16); break;
-                default: CNF_MIXF(0); break;
+            const size_t lds = need(kWave / G);
+#define CNF_MIXF(KT_, G_)                                                                                          \
+    if (a.reverse) hipLaunchKernelGGL((mixture_f32_kernel<KT_, true, G_>), gridf, blockf, lds, st, a, tl, PS, strip); \
+    else hipLaunchKernelGGL((mixture_f32_kernel<KT_, false, G_>), gridf, blockf, lds, st, a, tl, PS, strip)
+            if (G == 4) { CNF_MIXF(0, 4); }
+            else switch (kt) {
+                case 4: CNF_MIXF(4, 1); break;
+                case 8: CNF_MIXF(8, 1); break;
+                case 16: CNF_MIXF(16, 1); break;
+                default: CNF_MIXF(0, 1); break;
             }
 #undef CNF_MIXF
             return launch_status(who);
