@@ -75,6 +75,16 @@ def usable_cores():
     return max(1, n)
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(B, N, D, budget_s=15.0):
     """Oracle (torch CPU ops, all host threads) on the same step at the same shape."""
     from oracle import cnf_oracle as O
@@ -100,44 +110,100 @@ def cpu_baseline(B, N, D, budget_s=15.0):
         step()
         times.append(time.perf_counter() - t0)
     med = float(np.median(times))
-    return {"value": B * N * D / med, "unit": "elems/s", "cores": threads, "kind": "port",
+    return {"value": B * N * D / med, "unit": "elems/s", "cores": threads, "kind": "port", "cpu_model": cpu_model(),
             "sample": "%d steps of the same step (affine fwd + NLL + inv) at B=%d,N=%d,D=%d on torch CPU ops; median %.1f ms/step"
                       % (len(times), B, N, D, med * 1e3)}
 
 
-def mixture_measure(ops, dev, steps=20, warmup=3):
-    """Secondary measurement, BASELINE configs[1]: mixture-CDF coupling fwd + inv, B=16384, N=16, D=4, K=8."""
+def mixture_cpu_baseline(budget_s=8.0):
+    """Oracle (torch CPU ops, fp64 like the reference) on configs[1] with B reduced 16384 -> 1024; per-element rates
+    do not depend on B, so elems/s compares directly with the GPU figures."""
+    from oracle import cnf_oracle as O
+    torch.set_num_threads(usable_cores())
+    B, N, D, K = 1024, 16, 4, 8
+    g = torch.Generator().manual_seed(1)
+    z = torch.randn(B, N, D, generator=g)
+    nn_out = 0.5 * torch.randn(B, N, D * (2 + 3 * K), generator=g)
+    mask = O.channel_mask(D)
+
+    def timed(fn, min_runs):
+        fn()
+        ts, t_start = [], time.perf_counter()
+        while len(ts) < min_runs or (time.perf_counter() - t_start < budget_s / 2 and len(ts) < 30):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts)), len(ts)
+    zf, _, _ = O.mixture_coupling(z, nn_out, mask, K, None, None)
+    tf, nf = timed(lambda: O.mixture_coupling(z, nn_out, mask, K, None, None), 5)
+    ti, ni = timed(lambda: O.mixture_coupling(zf, nn_out, mask, K, None, None, reverse=True), 2)
+    e = B * N * D
+    return {"cpu_fwd_elems_per_s": e / tf, "cpu_inv_elems_per_s": e / ti, "cpu_cores": usable_cores(),
+            "cpu_sample": "oracle at B=1024 (configs[1] has 16384; rates are per element), median of %d fwd / %d inv runs "
+                          "(%.1f / %.1f ms)" % (nf, ni, tf * 1e3, ti * 1e3)}
+
+
+def padded_measure(ops, dev, B, N, D, R=4):
+    """SURVEY.md 8d padded variant: lengths ~ U{N/2..N}, the NLL epilogue masks the prior term per token."""
+    g = torch.Generator(device=dev).manual_seed(3)
+    ln = torch.randint(N // 2, N + 1, (B,), generator=g, device=dev)
+    pad = (torch.arange(N, device=dev)[None, :] < ln[:, None]).float()
+    zs = [torch.randn(B, N, D, generator=g, device=dev) * pad[:, :, None] for _ in range(R)]
+    nns = [0.5 * torch.randn(B, N, 2 * D, generator=g, device=dev) * pad[:, :, None] for _ in range(R)]
+    from categoricalnf_amd.layers.flows.coupling_layer import CouplingLayer
+    mask, sf = CouplingLayer.create_channel_mask(D).to(dev), torch.zeros(D, device=dev)
+    zo, lo = torch.empty_like(zs[0]), torch.empty(B, device=dev)
+    neglog, nll = torch.empty(B, device=dev), torch.empty(B, device=dev)
+    k = [ops.affine_coupling_nll_launch(zs[r], nns[r], sf, mask, zo, lo, ln.float(), neglog, nll, None,
+                                        channel_padding_mask=pad) for r in range(R)]
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    marks[0].record()
+    for b in range(3):
+        for i in range(200):
+            k[i % R]()
+        marks[b + 1].record()
+    torch.cuda.synchronize(dev)
+    ms = float(np.median([marks[b].elapsed_time(marks[b + 1]) / 200 for b in range(1, 3)]))
+    return {"workload": "affine fwd + NLL epilogue, lengths ~ U{%d..%d}, padding mask on the prior term" % (N // 2, N),
+            "kernel_ms": ms, "algorithmic_GBps": (16.0 * B * N * D + 4.0 * B * N) / (ms * 1e-3) / 1e9}
+
+
+def mixture_measure(ops, dev, R=4, reps=50):
+    """Secondary measurement, BASELINE configs[1]: mixture-CDF coupling fwd + inv, B=16384, N=16, D=4, K=8.
+    Steady-state start-to-start time of back-to-back launches on R rotating buffer sets (R x 126 MB > the 256 MB
+    Infinity Cache), first block discarded."""
     from categoricalnf_amd.layers.flows.coupling_layer import CouplingLayer
     channel_mask = CouplingLayer.create_channel_mask
     B, N, D, K = 16384, 16, 4, 8
     g = torch.Generator(device=dev).manual_seed(1)
-    z = torch.randn(B, N, D, generator=g, device=dev)
-    nn_out = 0.5 * torch.randn(B, N, D * (2 + 3 * K), generator=g, device=dev)
+    zs = [torch.randn(B, N, D, generator=g, device=dev) for _ in range(R)]
+    nns = [0.5 * torch.randn(B, N, D * (2 + 3 * K), generator=g, device=dev) for _ in range(R)]
     mask = channel_mask(D).to(dev)
-    zf, zr = torch.empty_like(z), torch.empty_like(z)
+    zfs, zrs = [torch.empty_like(zs[0]) for _ in range(R)], [torch.empty_like(zs[0]) for _ in range(R)]
     lf, lr = torch.empty(B, device=dev), torch.empty(B, device=dev)
-    fwd = ops.mixture_coupling_launch(z, nn_out, mask, K, zf, lf)
-    inv = ops.mixture_coupling_launch(zf, nn_out, mask, K, zr, lr, reverse=True)
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-    tf = ti = 0.0
-    for i in range(warmup + steps):
-        ev[0].record()
-        fwd()
-        ev[1].record()
-        inv()
-        ev[2].record()
+    fwd = [ops.mixture_coupling_launch(zs[r], nns[r], mask, K, zfs[r], lf) for r in range(R)]
+    inv = [ops.mixture_coupling_launch(zfs[r], nns[r], mask, K, zrs[r], lr, reverse=True) for r in range(R)]
+
+    def steady(launches, blocks=4):
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(blocks + 1)]
+        marks[0].record()
+        for b in range(blocks):
+            for i in range(reps):
+                launches[i % R]()
+            marks[b + 1].record()
         torch.cuda.synchronize(dev)
-        if i >= warmup:
-            tf += ev[0].elapsed_time(ev[1])
-            ti += ev[1].elapsed_time(ev[2])
-    assert (zr - z).abs().max().item() < 2e-4, "mixture inverse did not recover z"
-    tf, ti = tf / steps, ti / steps
+        return float(np.median([marks[b].elapsed_time(marks[b + 1]) / reps for b in range(1, blocks)]))
+    tf = steady(fwd)
+    ti = steady(inv)
+    assert (zrs[0] - zs[0]).abs().max().item() < 2e-4, "mixture inverse did not recover z"
     elems = B * N * D
     bytes_alg = elems * (16 + 12 * K)
     return {"workload": "mixture_cdf_coupling B=16384 N=16 D=4 K=8 (configs[1])", "dtype": "f32 (fp64 fallback branch for |logit| > 20.7)",
             "fwd_ms": tf, "inv_ms": ti, "fwd_elems_per_s": elems / (tf * 1e-3), "inv_elems_per_s": elems / (ti * 1e-3),
             "fwd_inv_elems_per_s": elems / ((tf + ti) * 1e-3),
-            "fwd_algorithmic_GBps": bytes_alg / (tf * 1e-3) / 1e9, "fwd_hbm_frac": bytes_alg / (tf * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            "fwd_algorithmic_GBps": bytes_alg / (tf * 1e-3) / 1e9, "fwd_hbm_frac": bytes_alg / (tf * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "fwd_bound": "hbm", "inv_bound": "valu (fp32 Newton iterations over the staged rows) on top of the same HBM stream",
+            "inv_hbm_frac": bytes_alg / (ti * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
 
 def main():
@@ -307,7 +373,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(B, N, D)
         if world == 1 and not args.no_mixture:
-            out["extra"] = {"mixture": mixture_measure(ops, dev)}
+            out["extra"] = {"mixture": mixture_measure(ops, dev), "affine_padded": padded_measure(ops, dev, B, N, D)}
+            if not args.no_cpu_baseline:
+                out["extra"]["mixture"].update(mixture_cpu_baseline())
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -1,0 +1,43 @@
+"""Training step of the reference's default set-modelling flow (8 flow steps, Transformer sub-network hidden 256 x 2
+layers, D=4, K=8, |S|=16): forward + NLL + backward + Adam.  Run under `rocprofv3 --kernel-trace --stats` to see how
+the step splits between this library's kernels (namespace cnf::) and the PyTorch-ROCm sub-networks."""
+import os, sys, time, io, contextlib
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from categoricalnf_amd.experiments.set_modeling import FlowSetModeling, SetShufflingDataset
+from categoricalnf_amd import functional as Fn
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+params = {"set_size": 16, "coupling_hidden_layers": 2, "coupling_hidden_size": 256, "coupling_num_flows": 8, "coupling_mask_ratio": 0.5,
+          "coupling_num_mixtures": 8, "categ_encoding": {"use_dequantization": False, "use_variational": False, "use_decoder": False,
+                                                         "num_dimensions": 4, "flow_config": {"num_flows": 0}, "decoder_config": {}}}
+torch.manual_seed(0)
+with contextlib.redirect_stdout(io.StringIO()):
+    model = FlowSetModeling(params, SetShufflingDataset).cuda().train()
+rng = np.random.RandomState(0)
+draw = lambda n: torch.from_numpy(np.stack([rng.permutation(16) for _ in range(n)])).long().cuda()
+ln = torch.full((B,), 16, dtype=torch.long, device="cuda")
+with contextlib.redirect_stdout(io.StringIO()):
+    model.initialize_data_dependent([(draw(B), {"length": ln}) for _ in range(2)])
+opt = torch.optim.Adam(model.parameters(), lr=7.5e-4)
+xs = [draw(B) for _ in range(4)]
+
+def step(i):
+    z, ldj = model(xs[i % 4], reverse=False, length=ln, beta=1)
+    loss = Fn.PriorNllFn.apply(z, ldj, ln, None).mean()
+    opt.zero_grad(set_to_none=True)
+    loss.backward()
+    torch.nn.utils.clip_grad_norm_(model.parameters(), 0.25)
+    opt.step()
+    return loss
+
+for i in range(5):
+    step(i)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for i in range(steps):
+    loss = step(i)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / steps
+print("batch %d: %.2f ms / training step (%.0f sets/s), loss %.4f" % (B, dt * 1e3, B / dt, float(loss)))
