@@ -43,11 +43,13 @@ __device__ __forceinline__ float logistic_logp0(float x, float sigma, float log_
     return -(kLn2 * sp_pair2(fabsf(x / sigma) * kLog2e) + log_sigma);
 }
 
-// LDS layout per class (stride 6D+1, odd -> no bank conflicts):
-//   [bias D | ts D | e^ts D | e^-ts D | (A, C) pairs 2D | sum_ts],  A = e^-ts log2e / sigma,  C = bias log2e / sigma
-// so that |z_back / sigma| log2e = |z A - C| is one FMA per (class, channel).
+// LDS layout per class (stride 6D+3, odd -> no bank conflicts):
+//   [bias D | ts D | e^ts D | e^-ts D | (A, C) pairs 2D | sum_ts | cst2 | -],
+//   A = e^-ts log2e / sigma,  C = bias log2e / sigma  so that |z_back / sigma| log2e = |z A - C| is one FMA per
+//   (class, channel);  cst2 = (prior - sum_ts - D log_sigma) log2e = the class score's constant in base-2 units.
+__device__ __forceinline__ int class_stride(int D) { return 6 * D + 3; }
 __device__ __forceinline__ void build_class_table(const EncArgs& a, float* tab) {
-    const int stride = 6 * a.D + 1;
+    const int stride = class_stride(a.D);
     const float k = kLog2e / a.sigma;
     for (int i = threadIdx.x; i < a.C * a.D; i += blockDim.x) {
         const int c = i / a.D, d = i - c * a.D;
@@ -68,20 +70,26 @@ __device__ __forceinline__ void build_class_table(const EncArgs& a, float* tab) 
         float s = 0.f;
         for (int d = 0; d < a.D; ++d) s += t[a.D + d];
         t[6 * a.D] = s;
+        t[6 * a.D + 1] = ((a.prior[c] - s) - (float)a.D * a.log_sigma) * kLog2e;
     }
     __syncthreads();
 }
 
-// score of class j at point z (reverse flow log-prob + ldj + prior), linear_encoding.py:159-164
+// score of class j at point z (reverse flow log-prob + ldj + prior, linear_encoding.py:159-164) in BASE-2 units:
+//   score log2e = cst2 - sum_d [vs_d + 2 log2(1 + 2^-vs_d)] = cst2 - sum_d vs_d - 2 log2 prod_d (1 + 2^-vs_d)
+// one v_exp_f32 per (class, channel) and one v_log_f32 per class (the product of D <= 16 factors in [1, 2]
+// cannot overflow)
 template <int DT>
-__device__ __forceinline__ float class_score(const float* t, const float* z, int D, float prior_j,
-                                             float sigma, float log_sigma) {
-    float acc = 0.f;
+__device__ __forceinline__ float class_score2(const float* t, const float* z, int D) {
+    float acc = 0.f, prod = 1.f;
     const int DD = DT > 0 ? DT : D;
 #pragma unroll
-    for (int d = 0; d < DD; ++d) acc += sp_pair2(fabsf(fmaf(z[d], t[4 * D + 2 * d], -t[4 * D + 2 * d + 1])));
-    const float lp = -(kLn2 * acc + (float)DD * log_sigma);
-    return (lp + (-t[6 * D])) + prior_j;
+    for (int d = 0; d < DD; ++d) {
+        const float vs = fabsf(fmaf(z[d], t[4 * D + 2 * d], -t[4 * D + 2 * d + 1]));
+        acc += vs;
+        prod *= 1.f + __builtin_amdgcn_exp2f(-vs);
+    }
+    return t[6 * D + 1] - fmaf(2.f, __builtin_amdgcn_logf(prod), acc);
 }
 
 constexpr int kEncMaxD = 16;
@@ -93,7 +101,7 @@ __global__ __launch_bounds__(kBlock) void encoder_forward_kernel(EncArgs a, RowT
     float* tab = part_all + kWavesPerBlock * kMaxTileChunks;
     build_class_table(a, tab);
     const int D = DT > 0 ? DT : a.D;
-    const int stride = 6 * D + 1;
+    const int stride = class_stride(D);
     bool bad = false;
 
     auto chunk = [&](int row, int n) -> float {
@@ -101,28 +109,32 @@ __global__ __launch_bounds__(kBlock) void encoder_forward_kernel(EncArgs a, RowT
         const int c = (int)a.categ[tok];
         const float* tc = tab + c * stride;
         float z[DT > 0 ? DT : kEncMaxD];
-        float init_lp = 0.f;
+        // log-prob of the noise under the logistic prior: same product form as class_score
+        float nacc = 0.f, nprod = 1.f;
+        const float kn = kLog2e / a.sigma;
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             const float e = a.eps[tok * D + d];
-            init_lp += logistic_logp0(e, a.sigma, a.log_sigma);
+            const float vs = fabsf(e) * kn;
+            nacc += vs;
+            nprod *= 1.f + __builtin_amdgcn_exp2f(-vs);
             z[d] = (e + tc[d]) * tc[2 * D + d];
         }
+        const float init_lp = -(kLn2 * fmaf(2.f, __builtin_amdgcn_logf(nprod), nacc) + (float)D * a.log_sigma);
         const float ldj_f = tc[6 * D];
         const float log_point = (init_lp - ldj_f) + a.prior[c];
-        // streamed log-sum-exp over the classes; the true class uses the forward value (:167-168)
-        float m = -INFINITY, s = 0.f;
+        // streamed base-2 log-sum-exp over the classes, branch-free (every lane scores every class, the true
+        // class then takes the forward value, :167-168)
+        const float lp2 = log_point * kLog2e;
+        float m = -3e38f, s = 0.f;
         for (int j = 0; j < a.C; ++j) {
-            const float v = j == c ? log_point
-                                   : class_score<DT>(tab + j * stride, z, D, a.prior[j], a.sigma, a.log_sigma);
-            if (v > m) {
-                s = s * __expf(m - v) + 1.f;
-                m = v;
-            } else {
-                s += __expf(v - m);
-            }
+            const float sc = class_score2<DT>(tab + j * stride, z, D);
+            const float v = j == c ? lp2 : sc;
+            const float mn = fmaxf(m, v);
+            s = fmaf(s, __builtin_amdgcn_exp2f(m - mn), __builtin_amdgcn_exp2f(v - mn));
+            m = mn;
         }
-        const float cpl = log_point - (m + __logf(s));
+        const float cpl = (lp2 - (m + __builtin_amdgcn_logf(s))) * kLn2;
         const float pv = a.pad ? a.pad[tok] : 1.f;
         if (a.cpl) a.cpl[tok] = cpl;
 #pragma unroll
@@ -148,7 +160,7 @@ __global__ __launch_bounds__(kBlock) void encoder_decode_kernel(EncArgs a, long 
     float* tab = reinterpret_cast<float*>(smem);
     build_class_table(a, tab);
     const int D = DT > 0 ? DT : a.D;
-    const int stride = 6 * D + 1;
+    const int stride = class_stride(D);
     for (long tok = (long)blockIdx.x * kBlock + threadIdx.x; tok < ntok; tok += (long)gridDim.x * kBlock) {
         float z[DT > 0 ? DT : kEncMaxD];
 #pragma unroll
@@ -156,7 +168,7 @@ __global__ __launch_bounds__(kBlock) void encoder_decode_kernel(EncArgs a, long 
         float best = -INFINITY;
         int arg = 0;
         for (int j = 0; j < a.C; ++j) {
-            const float v = class_score<DT>(tab + j * stride, z, D, a.prior[j], a.sigma, a.log_sigma);
+            const float v = class_score2<DT>(tab + j * stride, z, D);
             if (j == 0 || v > best) {   // first maximum wins, like torch.argmax
                 best = v;
                 arg = j;
@@ -170,7 +182,7 @@ __global__ __launch_bounds__(kBlock) void encoder_decode_kernel(EncArgs a, long 
 
 using namespace cnf;
 
-static size_t table_bytes(int C, int D) { return (size_t)C * (6 * D + 1) * sizeof(float); }
+static size_t table_bytes(int C, int D) { return (size_t)C * (6 * D + 3) * sizeof(float); }
 
 #define DISPATCH_D(D, CALL)                               \
     switch (D) {                                          \
