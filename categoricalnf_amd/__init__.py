@@ -21,12 +21,15 @@ _ENC_MODULES = ["decoder", "linear_encoding", "variational_dequantization", "mut
 def install(force=False):
     """Register this package's modules under the reference's import paths.
 
-    `layers.flows`, `layers.categorical_encoding` and `layers.networks.help_layers` resolve to
-    categoricalnf_amd; everything else of the reference (`layers.networks.graph_layers`, `general`,
-    `experiments`) is left alone and keeps importing from the reference checkout on sys.path."""
+    `layers.flows`, `layers.categorical_encoding`, `layers.networks.help_layers` and
+    `layers.networks.autoregressive_layers` (the LSTM sub-network, which needs the torch >= 2 index-dtype fix of
+    host_utils.create_T_one_hot to run at all) resolve to categoricalnf_amd; everything else of the reference
+    (`layers.networks.graph_layers`, `general`, `experiments`) is left alone and keeps importing from the reference
+    checkout on sys.path."""
     base = __name__ + ".layers"
     pairs = [("layers.flows", base + ".flows"), ("layers.categorical_encoding", base + ".categorical_encoding"),
-             ("layers.networks.help_layers", base + ".networks.help_layers")]
+             ("layers.networks.help_layers", base + ".networks.help_layers"),
+             ("layers.networks.autoregressive_layers", base + ".networks.autoregressive_layers")]
     pairs += [("layers.flows." + m, base + ".flows." + m) for m in _FLOW_MODULES]
     pairs += [("layers.categorical_encoding." + m, base + ".categorical_encoding." + m) for m in _ENC_MODULES]
     for alias, real in pairs:

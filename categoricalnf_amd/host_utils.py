@@ -45,6 +45,22 @@ def create_channel_mask(length, max_len=None, dtype=torch.float32):
     return _create_length_mask(length=length, max_len=max_len, dtype=dtype).unsqueeze(dim=-1)
 
 
+def create_T_one_hot(length, dataset_max_len, dtype=torch.float32):
+    """general/mutils.py:290-304 — per position the one-hot of its index from the start and of its distance to the
+    end of its sequence, zero beyond the end: [B, max(length), 2*dataset_max_len].  (The reference clamps the long
+    distance with a float bound, which torch >= 2 promotes to float and then refuses as a scatter index; the
+    integer arithmetic here is what it computed on torch 1.x.)"""
+    max_batch_len = int(length.max())
+    assert max_batch_len <= dataset_max_len, \
+        "[!] ERROR - T_one_hot: Max batch size (%s) was larger than given dataset max length (%s)" % (
+            str(max_batch_len), str(dataset_max_len))
+    pos = torch.arange(max_batch_len, device=length.device).view(1, -1).expand(length.size(0), -1)
+    to_end = (length.long().unsqueeze(dim=-1) - 1) - pos
+    inside = (to_end >= 0).to(dtype)
+    both = torch.cat([one_hot(pos, dataset_max_len, dtype), one_hot(to_end.clamp(min=0), dataset_max_len, dtype)], dim=-1)
+    return both * inside.unsqueeze(dim=-1)
+
+
 def grad_needed(*tensors):
     return torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors)
 

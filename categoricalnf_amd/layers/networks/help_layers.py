@@ -68,3 +68,17 @@ def run_sequential_with_mask(net, x, length=None, channel_padding_mask=None, src
             h = layer(h)
         out = h * channel_padding_mask
     return (out, dict()) if detail_out else out
+
+
+def run_padded_LSTM(x, lstm_cell, length, input_memory=None, return_final_states=False):
+    """layers/networks/help_layers.py:127-142.  The reference sorts by length, packs, runs the LSTM and pads back
+    (pack_padded_sequence wants the lengths on the host: one device sync per call).  Every caller here uses a
+    unidirectional LSTM, whose output at a position depends on earlier positions only, so running it on the padded
+    batch and zeroing the positions past each length gives the same tensor without the sync."""
+    if getattr(lstm_cell, "bidirectional", False):
+        raise NotImplementedError("run_padded_LSTM: unidirectional LSTMs only")
+    outputs, _ = lstm_cell(x, input_memory)
+    if length is not None:
+        keep = torch.arange(x.size(1), device=x.device).view(1, -1) < length.view(-1, 1)
+        outputs = outputs * keep.unsqueeze(dim=-1).to(outputs.dtype)
+    return outputs

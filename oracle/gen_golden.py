@@ -758,6 +758,62 @@ def gen_graph_node_flow():
     save("graph_node_flow", [c])
 
 
+def gen_language_model():
+    """configs[3]: language-modelling flow (experiments/language_modeling/flow_model.py) — linear-flow encoder + ActNorm /
+    1x1 conv / autoregressive mixture-CDF couplings with the LSTM sub-network, variable lengths, eval mode.
+    The reference's general.mutils.create_T_one_hot clamps a long tensor with a float bound; torch >= 2 promotes the
+    result to float and scatter_ then rejects it as an index.  The generator casts the index back to long inside
+    general.mutils.one_hot (in memory, for this run only) — the value is what torch 1.x computed."""
+    import general.mutils as gm
+    orig_one_hot = gm.one_hot
+    gm.one_hot = lambda x, num_classes, dtype=torch.float32: orig_one_hot(x.long() if isinstance(x, torch.Tensor) else x,
+                                                                            num_classes, dtype)
+    with contextlib.redirect_stdout(io.StringIO()):
+        from experiments.language_modeling.flow_model import FlowLanguageModeling
+
+    class Vocab:
+        vectors = None
+
+    cases = []
+    for ci, (K, D, flows, enc_flows, hidden) in enumerate([(5, 3, 2, 1, 32), (51, 3, 1, 0, 32)]):
+        torch.manual_seed(80 + ci)
+        np.random.seed(80 + ci)
+        V, T = 20, 24
+        params = {"max_seq_len": T, "coupling_hidden_layers": 1, "coupling_hidden_size": hidden, "coupling_num_flows": flows,
+                  "coupling_num_mixtures": K, "coupling_dropout": 0.0, "coupling_input_dropout": 0.0,
+                  "categ_encoding": {"use_dequantization": False, "use_variational": False, "use_decoder": False,
+                                     "num_dimensions": D, "flow_config": {"num_flows": enc_flows, "hidden_layers": 1, "hidden_size": 32},
+                                     "decoder_config": {"num_layers": 1, "hidden_size": 64}}}
+        with contextlib.redirect_stdout(io.StringIO()):
+            model = FlowLanguageModeling(params, None, vocab_size=V, vocab=Vocab())
+        for p_ in model.parameters():
+            p_.data = p_.data + 0.05 * torch.randn(p_.shape)
+        model.eval()
+        B = 6
+        g = torch.Generator().manual_seed(81 + ci)
+        ln = torch.randint(5, T + 1, (B,), generator=g)
+        ln[0] = T
+        valid = (torch.arange(T).view(1, T) < ln.view(B, 1))
+        x = torch.randint(0, V, (B, T), generator=g) * valid.long()
+        torch.manual_seed(82 + ci)
+        u = torch.rand(B * T, 1, D)
+        torch.manual_seed(82 + ci)
+        with torch.no_grad():
+            z, ldj = model(x, reverse=False, length=ln)
+            pad = create_channel_mask(ln, max_len=T)
+            sub_in = torch.randn(B, T, D, generator=g) * pad
+            sub = [l for l in model.flow_layers if l.__class__.__name__ == "AutoregressiveMixtureCDFCoupling"][0].nn
+            sub_out = sub(x=sub_in, length=ln, channel_padding_mask=pad)
+        c = dict(meta=dict(B=B, T=T, V=V, D=D, K=K, flows=flows, enc_flows=enc_flows, hidden=hidden,
+                           infos=[l.info() for l in model.flow_layers]),
+                 tokens=x, length=ln, u=u, z=z, ldj=ldj, sub_in=sub_in, sub_out=sub_out)
+        for k, v in model.state_dict().items():
+            c["sd_" + k] = v
+        cases.append(c)
+    gm.one_hot = orig_one_hot
+    save("language_model", cases)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
     gen_affine()
@@ -773,3 +829,4 @@ if __name__ == "__main__":
     gen_data_init()
     gen_grads()
     gen_graph_node_flow()
+    gen_language_model()

@@ -256,3 +256,48 @@ def test_graph_colouring_assembly_and_rgcn_subnet_match_reference():
     with torch.no_grad():
         out = model.flow_layers[3].nn(c.sub_in, adjacency=c.adjacency, channel_padding_mask=pad)
     torch.testing.assert_close(out, c.sub_out, rtol=1e-4, atol=1e-5)
+
+
+def _language_model(meta):
+    from categoricalnf_amd.experiments.language_modeling import FlowLanguageModeling
+
+    class Vocab:
+        vectors = None
+
+    params = {"max_seq_len": meta["T"], "coupling_hidden_layers": 1, "coupling_hidden_size": meta["hidden"],
+              "coupling_num_flows": meta["flows"], "coupling_num_mixtures": meta["K"], "coupling_dropout": 0.0,
+              "coupling_input_dropout": 0.0,
+              "categ_encoding": {"use_dequantization": False, "use_variational": False, "use_decoder": False,
+                                 "num_dimensions": meta["D"],
+                                 "flow_config": {"num_flows": meta["enc_flows"], "hidden_layers": 1, "hidden_size": 32},
+                                 "decoder_config": {"num_layers": 1, "hidden_size": 64}}}
+    return FlowLanguageModeling(params, None, vocab_size=meta["V"], vocab=Vocab())
+
+
+@pytest.mark.parametrize("c", load_cases("language_model"))
+def test_language_model_assembly_and_lstm_subnet_match_reference(c):
+    """FlowLanguageModeling mirror: reference checkpoint keys / info strings, and the autoregressive LSTM sub-network
+    (plain PyTorch on both sides; masks built by index arithmetic and applied functionally here, the padded LSTM run
+    without packing) reproduces the reference's output on variable-length sequences."""
+    model = _language_model(c.meta)
+    sd = {k[3:]: v for k, v in c.items() if k.startswith("sd_")}
+    assert sorted(model.state_dict().keys()) == sorted(sd.keys())
+    model.load_state_dict(sd)
+    model.eval()
+    assert [l.info() for l in model.flow_layers] == c.meta["infos"]
+    from categoricalnf_amd.host_utils import create_channel_mask
+    pad = create_channel_mask(c.length, max_len=c.meta["T"])
+    sub = [l for l in model.flow_layers if l.__class__.__name__ == "AutoregressiveMixtureCDFCoupling"][0].nn
+    with torch.no_grad():
+        out = sub(x=c.sub_in, length=c.length, channel_padding_mask=pad)
+    torch.testing.assert_close(out, c.sub_out, rtol=1e-4, atol=1e-5)
+
+
+def test_create_T_one_hot_positions_and_distances():
+    from categoricalnf_amd.host_utils import create_T_one_hot
+    ln = torch.tensor([4, 2])
+    oh = create_T_one_hot(ln, dataset_max_len=5)
+    assert oh.shape == (2, 4, 10)
+    assert oh[0, 1].tolist() == [0, 1, 0, 0, 0, 0, 0, 1, 0, 0]        # position 1, two steps before the end
+    assert oh[1, 1].tolist() == [0, 1, 0, 0, 0, 1, 0, 0, 0, 0]        # position 1 = last of a length-2 sequence
+    assert oh[1, 2].abs().sum() == 0 and oh[1, 3].abs().sum() == 0   # beyond the end
