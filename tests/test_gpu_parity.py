@@ -5,6 +5,8 @@ inputs, plus size-independent properties at the full benchmark shape.
 Tolerances: fp32 kernels 2e-5 abs/rel per element (1 ulp-level libm differences between ocml and
 the reference's SLEEF/MKL), per-sample log-det / log-likelihood 1e-4 relative (BASELINE.json
 north_star), integer category indices bit-exact."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -1036,3 +1038,16 @@ def test_language_model_flow_golden(c):
     nll_ref = O.nll_per_sample(c.z, c.ldj, c.length.float(), pad)
     _, nll = ops().prior_nll(z, ldj, g(c.length), g(pad))
     close(nll, nll_ref, rtol=1e-4, atol=1e-4)
+
+
+def test_two_rank_data_parallel_gradients_match_single_process():
+    """§8e/8f-1: one process per GPU, batch shards, DDP gradient all-reduce around the HIP backward kernels == the
+    whole batch in one process (2 ranks sharing cuda:0 over gloo here; RCCL on a multi-GPU node via --backend nccl)."""
+    import socket, subprocess, sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "tools", "ddp_check.py"),
+                        "--backend", "gloo", "--share-device"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0 and "DDP_CHECK OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
