@@ -210,33 +210,32 @@ struct ActConvArgs {
     int B, N, D, reverse;
     long ntok;
 };
+// One lane owns TP consecutive tokens so that its TP*D floats are whole 16-byte vectors (D = 6: two tokens = three
+// float4): 16-byte loads and nontemporal 16-byte stores, every byte of a line used by neighbouring lanes.  The
+// per-channel constants (bias, e^{+-scales}, W) are read ONCE into registers before the loop — inside it the
+// compiler could not keep them, the stores to z_out may alias them.
+typedef float ac_f4 __attribute__((ext_vector_type(4)));
 template <int D>
 __global__ __launch_bounds__(kBlock) void actnorm_invconv_kernel(ActConvArgs a) {
+    constexpr int TP = (D % 4 == 0) ? 1 : (D % 2 == 0 ? 2 : 4);
+    constexpr int NV = TP * D / 4;
+    float wk[D * D], bk[D], ek[D];
+#pragma unroll
+    for (int i = 0; i < D * D; ++i) wk[i] = a.w[i];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        bk[i] = a.bias[i];
+        ek[i] = expf(a.reverse ? -a.scales[i] : a.scales[i]);
+    }
     bool bad = false;
-    for (long t = (long)blockIdx.x * kBlock + threadIdx.x; t < a.ntok; t += (long)gridDim.x * kBlock) {
-        float xv[D], ov[D];
-        const float* src = a.z + t * D;
-        if (D % 4 == 0) {
+    auto token = [&](const float* xin, float* out, float p) {
+        float xv[D];
 #pragma unroll
-            for (int i = 0; i < D; i += 4) {
-                const float4 q = *reinterpret_cast<const float4*>(src + i);
-                xv[i] = q.x; xv[i + 1] = q.y; xv[i + 2] = q.z; xv[i + 3] = q.w;
-            }
-        } else if (D % 2 == 0) {
-#pragma unroll
-            for (int i = 0; i < D; i += 2) {
-                const float2 q = *reinterpret_cast<const float2*>(src + i);
-                xv[i] = q.x; xv[i + 1] = q.y;
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < D; ++i) xv[i] = src[i];
-        }
-        const float p = a.pad ? a.pad[t] : 1.f;
+        for (int i = 0; i < D; ++i) xv[i] = xin[i];
         if (!a.reverse) {
 #pragma unroll
             for (int i = 0; i < D; ++i) {
-                float y = (xv[i] + a.bias[i]) * expf(a.scales[i]);
+                float y = (xv[i] + bk[i]) * ek[i];
                 if (a.pad) y = y * p;
                 xv[i] = y;
             }
@@ -245,26 +244,55 @@ __global__ __launch_bounds__(kBlock) void actnorm_invconv_kernel(ActConvArgs a) 
         for (int j = 0; j < D; ++j) {
             float acc = 0.f;
 #pragma unroll
-            for (int i = 0; i < D; ++i) acc = fmaf(xv[i], a.w[i * D + j], acc);
+            for (int i = 0; i < D; ++i) acc = fmaf(xv[i], wk[i * D + j], acc);
             if (a.pad) acc = acc * p;
             if (a.reverse) {
-                acc = acc * expf(-a.scales[j]) - a.bias[j];
+                acc = acc * ek[j] - bk[j];
                 if (a.pad) acc = acc * p;
             }
             bad |= isnan(acc);
-            ov[j] = acc;
+            out[j] = acc;
         }
-        float* dst = a.z_out + t * D;
-        if (D % 4 == 0) {
+    };
+    const bool aligned = ((reinterpret_cast<uintptr_t>(a.z) | reinterpret_cast<uintptr_t>(a.z_out)) & 15) == 0;
+    const long ngroups = aligned ? a.ntok / TP : 0;
+    // two groups per trip, both loaded before the first is computed (the host sizes the grid for one trip)
+    const long stride = (long)gridDim.x * kBlock;
+    for (long g0 = (long)blockIdx.x * kBlock + threadIdx.x; g0 < ngroups; g0 += 2 * stride) {
+        float xin[2][TP * D], out[TP * D];
 #pragma unroll
-            for (int i = 0; i < D; i += 4) *reinterpret_cast<float4*>(dst + i) = make_float4(ov[i], ov[i + 1], ov[i + 2], ov[i + 3]);
-        } else if (D % 2 == 0) {
+        for (int h = 0; h < 2; ++h) {
+            const long g = min(g0 + h * stride, ngroups - 1);
+            const ac_f4* src = reinterpret_cast<const ac_f4*>(a.z + g * (TP * D));
 #pragma unroll
-            for (int i = 0; i < D; i += 2) *reinterpret_cast<float2*>(dst + i) = make_float2(ov[i], ov[i + 1]);
-        } else {
-#pragma unroll
-            for (int i = 0; i < D; ++i) dst[i] = ov[i];
+            for (int v = 0; v < NV; ++v) {
+                const ac_f4 q = src[v];
+                xin[h][4 * v] = q.x; xin[h][4 * v + 1] = q.y; xin[h][4 * v + 2] = q.z; xin[h][4 * v + 3] = q.w;
+            }
         }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const long g = g0 + h * stride;
+            if (g < ngroups) {
+#pragma unroll
+                for (int k = 0; k < TP; ++k) token(xin[h] + k * D, out + k * D, a.pad ? a.pad[g * TP + k] : 1.f);
+                ac_f4* dst = reinterpret_cast<ac_f4*>(a.z_out + g * (TP * D));
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    const ac_f4 q = {out[4 * v], out[4 * v + 1], out[4 * v + 2], out[4 * v + 3]};
+                    __builtin_nontemporal_store(q, dst + v);
+                }
+            }
+        }
+    }
+    // tokens that do not fill a group (or everything, for unaligned tensors): one token per lane
+    for (long t = ngroups * TP + (long)blockIdx.x * kBlock + threadIdx.x; t < a.ntok; t += (long)gridDim.x * kBlock) {
+        float xin[D], out[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) xin[i] = a.z[t * D + i];
+        token(xin, out, a.pad ? a.pad[t] : 1.f);
+#pragma unroll
+        for (int i = 0; i < D; ++i) a.z_out[t * D + i] = out[i];
     }
     if (bad) raise_flag(a.flags, CNF_FLAG_NAN_Z);
     // log-det of both layers: ActNorm uses length | sum(pad) | N, the convolution length | N
@@ -387,7 +415,10 @@ int cnf_actnorm_invconv(const float* z, const float* bias, const float* scales, 
     CNF_REQUIRE(B >= 0 && N > 0 && D > 0, "cnf_actnorm_invconv: bad shape");
     if (B == 0) return CNF_OK;
     ActConvArgs a{z, bias, scales, weight, sldj, pad, length, ldj_in, z_out, ldj_out, flags, B, N, D, reverse, (long)B * N};
-    const dim3 grid(stream_grid(std::max<long>(a.ntok, B))), block(kBlock);
+    // one lane per group of 1, 2 or 4 tokens (16-byte I/O); uncapped grid: every lane makes a single trip
+    const int tp = (D % 4 == 0) ? 1 : (D % 2 == 0 ? 2 : 4);
+    const long lanes = std::max<long>((a.ntok + 2 * tp - 1) / (2 * tp), 1);
+    const dim3 grid((unsigned)std::min<long>((lanes + kBlock - 1) / kBlock, 1 << 22)), block(kBlock);
     hipStream_t st = (hipStream_t)stream;
     switch (D) {
         case 1: hipLaunchKernelGGL((actnorm_invconv_kernel<1>), grid, block, 0, st, a); break;
