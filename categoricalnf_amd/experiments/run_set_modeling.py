@@ -1,0 +1,228 @@
+"""Train / evaluate the set-modelling flow on MI355X: the host side of the reference's
+`experiments/set_modeling/train.py` + `general/train.py` + `general/task.py` reduced to what this experiment needs.
+
+    python -m categoricalnf_amd.experiments.run_set_modeling --dataset shuffling --max_iterations 20000 \
+        --checkpoint_path checkpoints/shuffling
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m \
+        categoricalnf_amd.experiments.run_set_modeling --dataset summation ...           # one process per GPU
+
+Same hyper-parameter names and defaults as the reference's CLI (experiments/set_modeling/train.py:67-76,
+general/train.py:331-358: RAdam, lr 7.5e-4 decayed by 0.999975 per step, gradient norm clipped at 0.25, batch 64,
+evaluation every 2000 iterations on the 32768 fixed validation sets) and the same checkpoint files
+(`checkpoint_%07d.tar` holding `model_state_dict` [+ optimizer / scheduler state], `iteration`, `best_save_dict`,
+`evaluation_dict`; general/train.py:257-276), so checkpoints move between the two code bases.
+Not reproduced: tensorboard summaries, the discrete-flow baseline, parameter pickles.
+
+Multi-GPU replaces `nn.DataParallel` (general/train.py:36-44) by one process per GPU: every rank draws its own
+training batches of `batch_size / world` sets, DistributedDataParallel all-reduces the gradients over RCCL, and
+the validation sets are sharded by rank with ONE all-reduce of (sum nll, count) per evaluation."""
+import argparse
+import contextlib
+import glob
+import io
+import os
+import time
+
+import numpy as np
+import torch
+
+from .. import functional as Fn
+from .. import ops
+from ..distributed import allreduce_nll, init_process_group, shard_bounds, wrap_ddp
+from .set_modeling import FlowSetModeling, SetShufflingDataset, SetSummationDataset
+
+LOG2E = float(np.log2(np.e))
+
+
+def parse(argv=None):
+    p = argparse.ArgumentParser()
+    p.add_argument("--dataset", default="shuffling", choices=["shuffling", "summation"])
+    p.add_argument("--set_size", type=int, default=16)
+    p.add_argument("--max_iterations", type=int, default=100000)
+    p.add_argument("--batch_size", type=int, default=64)
+    p.add_argument("--eval_freq", type=int, default=2000)
+    p.add_argument("--save_freq", type=int, default=10000)
+    p.add_argument("--print_freq", type=int, default=250)
+    p.add_argument("--eval_batch_size", type=int, default=4096)
+    p.add_argument("--seed", type=int, default=42)
+    p.add_argument("--checkpoint_path", default=None)
+    p.add_argument("--only_eval", action="store_true")
+    p.add_argument("--learning_rate", type=float, default=7.5e-4)
+    p.add_argument("--lr_decay_factor", type=float, default=0.999975)
+    p.add_argument("--lr_decay_step", type=int, default=1)
+    p.add_argument("--lr_minimum", type=float, default=0.0)
+    p.add_argument("--max_gradient_norm", type=float, default=0.25)
+    p.add_argument("--encoding_dim", type=int, default=4)
+    p.add_argument("--coupling_hidden_size", type=int, default=256)
+    p.add_argument("--coupling_hidden_layers", type=int, default=2)
+    p.add_argument("--coupling_num_flows", type=int, default=8)
+    p.add_argument("--coupling_mask_ratio", type=float, default=0.5)
+    p.add_argument("--coupling_num_mixtures", type=int, default=8)
+    p.add_argument("--backend", default=None, help="torch.distributed backend (default: nccl = RCCL)")
+    return p.parse_args(argv)
+
+
+def model_params(args):
+    return {"set_size": args.set_size, "coupling_hidden_layers": args.coupling_hidden_layers,
+            "coupling_hidden_size": args.coupling_hidden_size, "coupling_num_flows": args.coupling_num_flows,
+            "coupling_mask_ratio": args.coupling_mask_ratio, "coupling_num_mixtures": args.coupling_num_mixtures,
+            "categ_encoding": {"use_dequantization": False, "use_variational": False, "use_decoder": False,
+                               "num_dimensions": args.encoding_dim,
+                               "flow_config": {"num_flows": 0, "hidden_layers": 2, "hidden_size": 128},
+                               "decoder_config": {"num_layers": 1, "hidden_size": 64}}}
+
+
+def checkpoint_file(path, iteration):
+    return os.path.join(path, "checkpoint_" + str(iteration).zfill(7) + ".tar")
+
+
+def save_checkpoint(path, iteration, model, optimizer=None, scheduler=None, **extra):
+    os.makedirs(path, exist_ok=True)
+    inner = model.module if hasattr(model, "module") else model
+    blob = {"model_state_dict": inner.state_dict(), "iteration": iteration}
+    if optimizer is not None:
+        blob["optimizer_state_dict"] = optimizer.state_dict()
+    if scheduler is not None:
+        blob["scheduler_state_dict"] = scheduler.state_dict()
+    blob.update(extra)
+    torch.save(blob, checkpoint_file(path, iteration))
+    return checkpoint_file(path, iteration)
+
+
+def load_checkpoint(path, model=None, optimizer=None, scheduler=None, device="cpu"):
+    """`path` = a checkpoint file or a directory (its newest `*.tar`); returns the non-state entries
+    (general/mutils.py:66-112)."""
+    if os.path.isdir(path):
+        files = sorted(glob.glob(os.path.join(path, "*.tar")))
+        if not files:
+            return {}
+        path = files[-1]
+    blob = torch.load(path, map_location=device, weights_only=False)
+    if model is not None:
+        inner = model.module if hasattr(model, "module") else model
+        state = inner.state_dict()
+        state.update(blob["model_state_dict"])
+        inner.load_state_dict(state)
+    if optimizer is not None and "optimizer_state_dict" in blob:
+        optimizer.load_state_dict(blob["optimizer_state_dict"])
+    if scheduler is not None and "scheduler_state_dict" in blob:
+        scheduler.load_state_dict(blob["scheduler_state_dict"])
+    return {k: v for k, v in blob.items() if "state_dict" not in k}
+
+
+@torch.no_grad()
+def evaluate(model, sets, device, rank=0, world=1, batch_size=4096):
+    """Mean NLL per element and bits/dim over `sets` (int64 numpy [M, set_size]); rows sharded over the ranks,
+    (sum nll, count) accumulated on the device and all-reduced once."""
+    inner = model.module if hasattr(model, "module") else model
+    was_training = inner.training
+    inner.eval()
+    lo, hi = shard_bounds(len(sets), rank, world)
+    total = torch.zeros(2, dtype=torch.float64, device=device)
+    part = torch.zeros(2, dtype=torch.float64, device=device)
+    for i in range(lo, hi, batch_size):
+        x = torch.from_numpy(sets[i:min(i + batch_size, hi)]).long().to(device)
+        ln = torch.full((x.size(0),), x.size(1), dtype=torch.long, device=device)
+        z, ldj = inner(x, reverse=False, length=ln, beta=1)
+        ops.prior_nll(z, ldj, ln, sums=part)
+        total += part
+    mean_nll, bpd = allreduce_nll(total)
+    inner.train(was_training)
+    return mean_nll, bpd
+
+
+def main(argv=None):
+    args = parse(argv)
+    rank, local_rank, world = init_process_group(args.backend)
+    device = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(device)
+    torch.manual_seed(args.seed)
+    np.random.seed(args.seed)
+    say = print if rank == 0 else (lambda *a, **k: None)
+
+    data_cls = SetShufflingDataset if args.dataset == "shuffling" else SetSummationDataset
+    train_set = data_cls(args.set_size, train=True)
+    val_sets = data_cls(args.set_size, train=False, val=True).eval_sets()
+    test_sets = data_cls(args.set_size, train=False, test=True).eval_sets()
+    optimum = (SetShufflingDataset.optimum_bpd(args.set_size) if args.dataset == "shuffling" else train_set.optimum_bpd())
+    with (contextlib.nullcontext() if rank == 0 else contextlib.redirect_stdout(io.StringIO())):
+        model = FlowSetModeling(model_params(args), data_cls).to(device)
+    rng = np.random.RandomState(args.seed + 1000 * rank)           # every rank draws different training sets
+    per_rank = max(1, args.batch_size // world)
+
+    def batch():
+        x = torch.from_numpy(train_set.sample(per_rank, rng)).long().to(device)
+        return x, torch.full((x.size(0),), x.size(1), dtype=torch.long, device=device)
+
+    optimizer = torch.optim.RAdam(model.parameters(), lr=args.learning_rate)
+    floor = args.lr_minimum / args.learning_rate
+    scheduler = torch.optim.lr_scheduler.LambdaLR(
+        optimizer, lambda step: max(floor, args.lr_decay_factor ** (step // max(1, args.lr_decay_step))))
+    state = {"iteration": 0, "best_save_dict": {"file": None, "metric": 1e6, "detailed_metrics": None, "test": None},
+             "evaluation_dict": {}}
+    if args.checkpoint_path and os.path.isdir(args.checkpoint_path):
+        state.update(load_checkpoint(args.checkpoint_path, model, optimizer, scheduler, device=device))
+    if state["iteration"] == 0 and not args.only_eval:
+        # data-dependent ActNorm initialisation on 16 batches (general/task.py: initialize); every rank uses the
+        # same sets so the replicas start identical
+        init_rng = np.random.RandomState(args.seed)
+        with contextlib.redirect_stdout(io.StringIO()):
+            model.initialize_data_dependent([
+                (torch.from_numpy(train_set.sample(args.batch_size, init_rng)).long().to(device),
+                 {"length": torch.full((args.batch_size,), args.set_size, dtype=torch.long, device=device)})
+                for _ in range(16)])
+    ddp = wrap_ddp(model, device)
+
+    if args.only_eval:
+        _, val_bpd = evaluate(ddp, val_sets, device, rank, world, args.eval_batch_size)
+        _, test_bpd = evaluate(ddp, test_sets, device, rank, world, args.eval_batch_size)
+        say("validation %.4f bpd, test %.4f bpd (optimum %.4f)" % (val_bpd, test_bpd, optimum))
+        return {"val_bpd": val_bpd, "test_bpd": test_bpd, "optimum_bpd": optimum}
+
+    ddp.train()
+    best = state["best_save_dict"]
+    t0, run_loss, seen = time.time(), 0.0, 0
+    for it in range(state["iteration"], args.max_iterations):
+        x, ln = batch()
+        z, ldj = ddp(x, reverse=False, length=ln, beta=1)
+        loss = Fn.PriorNllFn.apply(z, ldj, ln, None).mean()
+        optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(ddp.parameters(), args.max_gradient_norm)
+        optimizer.step()
+        scheduler.step()
+        run_loss += float(loss.detach())
+        seen += 1
+        step = it + 1
+        if step % args.print_freq == 0:
+            say("iteration %7d | train %.4f bpd | %.1f it/s" % (step, run_loss / seen * LOG2E, seen / (time.time() - t0)))
+            t0, run_loss, seen = time.time(), 0.0, 0
+        if step % args.eval_freq == 0 or step == args.max_iterations:
+            val_nll, val_bpd = evaluate(ddp, val_sets, device, rank, world, args.eval_batch_size)
+            state["evaluation_dict"][step] = val_nll
+            say("iteration %7d | validation %.4f bpd (optimum %.4f)" % (step, val_bpd, optimum))
+            if val_nll < best["metric"] and args.checkpoint_path and rank == 0:
+                if best["file"] and os.path.isfile(best["file"]):
+                    os.remove(best["file"])
+                best.update(file=checkpoint_file(args.checkpoint_path, step), metric=val_nll,
+                            detailed_metrics={"val_bpd": val_bpd})
+                save_checkpoint(args.checkpoint_path, step, ddp, best_save_dict=best, evaluation_dict=state["evaluation_dict"])
+        if step % args.save_freq == 0 and args.checkpoint_path and rank == 0 and not os.path.isfile(
+                checkpoint_file(args.checkpoint_path, step)):
+            save_checkpoint(args.checkpoint_path, step, ddp, optimizer, scheduler, best_save_dict=best,
+                            evaluation_dict=state["evaluation_dict"])
+    _, val_bpd = evaluate(ddp, val_sets, device, rank, world, args.eval_batch_size)
+    _, test_bpd = evaluate(ddp, test_sets, device, rank, world, args.eval_batch_size)
+    say("final: validation %.4f bpd, test %.4f bpd (optimum %.4f)" % (val_bpd, test_bpd, optimum))
+    if args.checkpoint_path and rank == 0:
+        with open(os.path.join(args.checkpoint_path, "results.txt"), "w") as f:
+            f.write("Best validation performance: %s\nFinal validation bpd: %.6f\nTest bpd: %.6f\nOptimum bpd: %.6f\n"
+                    % (str(best["metric"]), val_bpd, test_bpd, optimum))
+    if world > 1:
+        torch.distributed.barrier()
+    return {"val_bpd": val_bpd, "test_bpd": test_bpd, "optimum_bpd": optimum, "best_val_nll": best["metric"],
+            "best_file": best["file"]}
+
+
+if __name__ == "__main__":
+    main()

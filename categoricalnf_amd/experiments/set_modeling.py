@@ -111,3 +111,75 @@ class SetShufflingDataset:
     def optimum_bpd(set_size):
         import numpy as np
         return float(sum(np.log2(i) for i in range(1, set_size + 1)) / set_size)
+
+    def sample(self, batch_size, rng):
+        """One training batch: `batch_size` uniformly random permutations (int64 [B, set_size])."""
+        import numpy as np
+        return np.stack([rng.permutation(self.set_size) for _ in range(batch_size)])
+
+    def eval_sets(self):
+        return self.shuffle_set
+
+
+def bounded_partitions(total, parts, largest):
+    """All ways to write `total` as `parts` integers in [1, largest], each listed once as a non-increasing
+    sequence, in descending lexicographic order (the order of the reference's create_all_examples,
+    experiments/set_modeling/datasets/set_summation.py:84-116, so equal seeds draw equal validation sets)."""
+    out = []
+
+    def extend(prefix, remaining, slots, cap):
+        if slots == 0:
+            if remaining == 0:
+                out.append(prefix)
+            return
+        # the next part is at most `cap`, leaves >= 1 for every later slot and cannot undershoot slots * part
+        for k in range(min(cap, remaining - (slots - 1)), 0, -1):
+            if k * slots < remaining:
+                break
+            extend(prefix + [k], remaining - k, slots - 1, k)
+
+    extend([], total, parts, largest)
+    return out
+
+
+class SetSummationDataset:
+    """Set summation (set_summation.py:20-58): multisets of `set_size` numbers from 1..set_size that sum to `max_sum`,
+    drawn with probability proportional to their number of distinct orderings and presented in random order, shifted
+    to categories 0..set_size-1.  Validation / test: 32768 sets from numpy's legacy generator seeded 123 / 101 (the
+    same multisets as the reference; the reference orders each of them with Python's unseeded `random.shuffle`, here
+    a generator seeded 123 / 101 does, so the sets are reproducible)."""
+
+    def __init__(self, set_size, max_sum=42, train=True, val=False, test=False, **kwargs):
+        import math
+        from collections import Counter
+        import numpy as np
+        self.set_size = set_size
+        self.num_classes = set_size
+        self.max_sum = max_sum
+        self.multisets = np.array(bounded_partitions(max_sum, set_size, set_size), dtype=np.int64)
+        orderings = np.array([math.factorial(set_size) / np.prod([math.factorial(c) for c in Counter(m.tolist()).values()])
+                              for m in self.multisets])
+        self.num_orderings = float(orderings.sum())
+        self.probs = orderings / orderings.sum()
+        self.fixed = None
+        if val or test:
+            np.random.seed(123 if val else 101)             # the reference seeds the global generator (:33)
+            idx = np.random.choice(len(self.multisets), p=self.probs, size=(32768,))
+            order = np.random.RandomState(123 if val else 101)
+            self.fixed = np.stack([self.multisets[i][order.permutation(set_size)] for i in idx]) - 1
+
+    @staticmethod
+    def get_vocab_size(set_size):
+        return set_size
+
+    def optimum_bpd(self):
+        import numpy as np
+        return float(np.log2(self.num_orderings) / self.set_size)
+
+    def sample(self, batch_size, rng):
+        import numpy as np
+        idx = rng.choice(len(self.multisets), p=self.probs, size=(batch_size,))
+        return np.stack([self.multisets[i][rng.permutation(self.set_size)] for i in idx]) - 1
+
+    def eval_sets(self):
+        return self.fixed

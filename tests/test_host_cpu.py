@@ -301,3 +301,37 @@ def test_create_T_one_hot_positions_and_distances():
     assert oh[0, 1].tolist() == [0, 1, 0, 0, 0, 0, 0, 1, 0, 0]        # position 1, two steps before the end
     assert oh[1, 1].tolist() == [0, 1, 0, 0, 0, 1, 0, 0, 0, 0]        # position 1 = last of a length-2 sequence
     assert oh[1, 2].abs().sum() == 0 and oh[1, 3].abs().sum() == 0   # beyond the end
+
+
+def test_set_summation_dataset_matches_reference_enumeration():
+    """Facts taken from the reference's create_all_examples / calc_optimum (set_summation.py:84-133) for set size 16,
+    sum 42: 2200 multisets in its order (SHA-1 of the int64 table), 63 379 974 736 orderings, optimum 2.2427 bpd."""
+    import hashlib
+    from categoricalnf_amd.experiments.set_modeling import SetSummationDataset, bounded_partitions
+    table = np.array(bounded_partitions(42, 16, 16), dtype=np.int64)
+    assert table.shape == (2200, 16)
+    assert hashlib.sha1(table.tobytes()).hexdigest() == "e808d6c4f3f5654088df25a64ab9ef303eec905e"
+    assert len(bounded_partitions(20, 8, 8)) == 58
+    val = SetSummationDataset(16, train=False, val=True)
+    assert val.num_orderings == 63379974736.0 and abs(val.optimum_bpd() - 2.242706752094922) < 1e-12
+    assert val.eval_sets().shape == (32768, 16) and ((val.eval_sets() + 1).sum(axis=1) == 42).all()
+    again = SetSummationDataset(16, train=False, val=True)
+    assert np.array_equal(val.eval_sets(), again.eval_sets())                  # reproducible
+    train = SetSummationDataset(16, train=True)
+    b = train.sample(64, np.random.RandomState(0))
+    assert b.shape == (64, 16) and ((b + 1).sum(axis=1) == 42).all() and b.min() >= 0 and b.max() <= 15
+
+
+def test_checkpoint_files_follow_the_reference_format(tmp_path):
+    from categoricalnf_amd.experiments.run_set_modeling import checkpoint_file, load_checkpoint, save_checkpoint
+    net = torch.nn.Linear(3, 2)
+    opt = torch.optim.RAdam(net.parameters(), lr=1e-3)
+    sch = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: 0.99 ** s)
+    f = save_checkpoint(str(tmp_path), 1234, net, opt, sch, best_save_dict={"file": None, "metric": 3.0}, evaluation_dict={1000: 3.1})
+    assert os.path.basename(f) == "checkpoint_0001234.tar" and f == checkpoint_file(str(tmp_path), 1234)
+    blob = torch.load(f, weights_only=False)
+    assert set(blob) == {"model_state_dict", "optimizer_state_dict", "scheduler_state_dict", "iteration", "best_save_dict",
+                         "evaluation_dict"}
+    other = torch.nn.Linear(3, 2)
+    extra = load_checkpoint(str(tmp_path), other)                               # directory -> newest file
+    assert torch.equal(other.weight, net.weight) and extra["iteration"] == 1234 and extra["evaluation_dict"] == {1000: 3.1}
