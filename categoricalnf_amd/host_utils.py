@@ -66,9 +66,9 @@ def grad_needed(*tensors):
 
 
 def forbid_grad(what, *tensors):
-    """Backward kernels are the next scope row; refuse instead of silently
-    falling back to eager PyTorch."""
+    """For the few call forms that have a HIP forward but no backward kernel (e.g. SigmoidFlow with per-element
+    log-det): refuse instead of silently falling back to eager PyTorch."""
     if grad_needed(*tensors):
         raise NotImplementedError(
-            "%s: this build ships the forward / inverse / log-det HIP kernels only; gradients through them are "
-            "not implemented yet. Wrap the call in torch.no_grad()." % what)
+            "%s: this call form has no backward kernel; wrap the call in torch.no_grad() or use the differentiable "
+            "form of the layer." % what)

@@ -53,8 +53,12 @@ void cnf_set_tile_chunks(int chunks);
  * chunk's loads are issued before the current one is computed); 1..4 = that many chunks per lane
  * loaded back to back.  Default 2. */
 void cnf_set_unroll(int u);
-/* Affine coupling transcendental path: 1 (default) = hardware v_exp_f32-based exp / tanh
- * (absolute error ~1e-7, well inside the 1e-4 parity bar); 0 = ocml expf / tanhf. */
+/* Arithmetic mode.  1 (default, "fast"): hardware v_exp_f32 / v_log_f32 / v_rcp_f32 in the affine, prior and
+ * sampling kernels (absolute error ~1e-7), and the module-form mixture-CDF coupling (cnf_mixture_coupling,
+ * forward and Newton inverse) in fp32 on LDS-staged parameter rows with two-sided tail sums and an in-kernel
+ * fp64 branch for |logit| > 20.7 (<= 1e-5 from the fp64 kernel).
+ * 0 ("exact"): ocml expf / tanhf, fp64 logit in the sampler, fp64 mixture kernels throughout.
+ * The static fp64 API (cnf_mixture_transform) is fp64 in both modes. */
 void cnf_set_math_mode(int mode);
 /* Mixture-CDF inverse: 0 = the reference's bisection (mixture_cdf_layer.py:235-264, per-element stop at
  * |dx| <= 1e-10); 1 (default) = safeguarded Newton (rtsafe) on the same equation, bracketed by the
@@ -132,7 +136,8 @@ int cnf_actnorm_invconv(const float* z, const float* bias, const float* scales, 
 /* ---- logistic-mixture CDF coupling ----------------------------------------------------------- */
 
 /* MixtureCDFCoupling.forward after the subnet (mixture_cdf_layer.py:45-92) = get_mixt_params
- * (:145-180) + run_with_params (:95-142) + mixture_inv_cdf (:235-264), fp64 inside.
+ * (:145-180) + run_with_params (:95-142) + mixture_inv_cdf (:235-264); fp64 inside in math mode 0, fp32 with an
+ * fp64 tail branch in math mode 1 (cnf_set_math_mode).
  * nn_out [B,N,D*(2+3K)] channel-major blocks [t, log_s, log_pi[K], mixt_t[K], mixt_log_s[K]].
  * scaling_factor [D] / mixture_scaling_factor [D,K] nullable.  pad [B,N] nullable.
  * reg_out [B] (nullable) receives sum_{n,d} reg_ldj (detail "regularizer_ldj", :79-80).
@@ -177,7 +182,8 @@ int cnf_logistic_log_prob(const float* x, float* logp, int64_t n, float mu, floa
                           float log_sigma, int* flags, cnf_stream_t stream);
 
 /* LogisticDistribution.sample given the uniform draw (distributions.py:139-145,117-127):
- * u' = u(1-eps)+eps/2, x = logit(u') in fp64 -> fp32, x*sigma+mu. */
+ * u' = u(1-eps)+eps/2, x = logit(u') (fp64 -> fp32 in math mode 0; log u' - log(1-u') in fp32 in mode 1),
+ * x*sigma+mu. */
 int cnf_logistic_from_uniform(const float* u, float* x, int64_t n, float mu, float sigma, float eps,
                               cnf_stream_t stream);
 

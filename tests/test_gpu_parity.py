@@ -1086,3 +1086,46 @@ def test_set_modelling_driver_trains_checkpoints_and_reloads(tmp_path):
     assert out["best_file"] and os.path.isfile(out["best_file"])
     again = R.main(small + ["--only_eval"])
     assert abs(again["val_bpd"] - out["val_bpd"]) < 2e-3, (again, out)
+
+
+def test_graphed_training_step_matches_eager_steps():
+    """graphs.GraphedTrainStep: forward + NLL + HIP backward + clipping + RAdam captured in one HIP graph; replays on
+    new batches follow the eager optimisation trajectory (same injected noise on both sides)."""
+    import copy
+    from categoricalnf_amd import functional as Fn
+    from categoricalnf_amd.graphs import GraphedTrainStep
+    torch.manual_seed(0); np.random.seed(0)
+    model_a, _ = _set_model(dict(set_size=16, transformer_layers=1, hidden=32, flows=2, K=8, D=4))
+    model_a.cuda().train()
+    rng = np.random.RandomState(3)
+    draw = lambda n: torch.from_numpy(np.stack([rng.permutation(16) for _ in range(n)])).long().cuda()
+    B = 64
+    ln = torch.full((B,), 16, dtype=torch.long, device="cuda")
+    model_a.initialize_data_dependent([(draw(B), {"length": ln}) for _ in range(2)])
+    model_b = copy.deepcopy(model_a)
+    u = torch.rand(B * 16, 1, 4, device="cuda")
+    mk = lambda params: torch.optim.RAdam(params, lr=torch.tensor(2e-3), capturable=True)
+    x0 = draw(B)
+    step = GraphedTrainStep(model_a, mk, x0, ln, max_grad_norm=0.25, warmup=3, beta=1, noise=u)
+    opt_b = mk(model_b.parameters())
+    for g_ in opt_b.param_groups:
+        g_["lr"] = g_["lr"].cuda()
+
+    def eager(x):
+        z, ldj = model_b(x, reverse=False, length=ln, beta=1, noise=u)
+        loss = Fn.PriorNllFn.apply(z, ldj, ln, None).mean()
+        opt_b.zero_grad(set_to_none=True)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model_b.parameters(), 0.25)
+        opt_b.step()
+        return loss.detach()
+    for _ in range(3):
+        eager(x0)                                  # the three warm-up steps of the graphed twin
+    for i in range(6):
+        x = draw(B)
+        la, lb = step(x).clone(), eager(x)
+        assert torch.isfinite(la) and abs(la.item() - lb.item()) < 2e-3 * max(1.0, abs(lb.item())), (i, la.item(), lb.item())
+    worst = max((pa - pb).abs().max().item() for pa, pb in zip(model_a.parameters(), model_b.parameters()))
+    assert worst < 5e-3, worst
+    step.set_lr(1e-3)
+    assert all(float(g_["lr"]) == pytest.approx(1e-3) for g_ in step.optimizer.param_groups)

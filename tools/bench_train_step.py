@@ -40,4 +40,18 @@ for i in range(steps):
     loss = step(i)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
-print("batch %d: %.2f ms / training step (%.0f sets/s), loss %.4f" % (B, dt * 1e3, B / dt, float(loss)))
+print("batch %d eager  : %.2f ms / training step (%.0f sets/s), loss %.4f" % (B, dt * 1e3, B / dt, float(loss)))
+if len(sys.argv) > 3 and sys.argv[3] == "graph":
+    # the same step captured once in a HIP graph (graphs.GraphedTrainStep) and replayed
+    from categoricalnf_amd.graphs import GraphedTrainStep
+    gstep = GraphedTrainStep(model, lambda ps: torch.optim.Adam(ps, lr=torch.tensor(7.5e-4), capturable=True), xs[0], ln,
+                             max_grad_norm=0.25, beta=1)
+    for i in range(3):
+        gstep(xs[i % 4])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        loss = gstep(xs[i % 4])
+    torch.cuda.synchronize()
+    dg = (time.perf_counter() - t0) / steps
+    print("batch %d graphed: %.2f ms / training step (%.0f sets/s), loss %.4f  -> %.2fx" % (B, dg * 1e3, B / dg, float(loss), dt / dg))
