@@ -371,7 +371,7 @@ struct ExtArgs {
     int N, D, L, reverse;
     FastDiv div_d;
 };
-template <int VEC>
+template <int VEC, bool FAST>
 __global__ __launch_bounds__(kBlock) void ext_actnorm_kernel(ExtArgs a, RowTiling tl) {
     __shared__ float part[kWavesPerBlock][kMaxTileChunks];
     bool bad = false;
@@ -386,8 +386,8 @@ __global__ __launch_bounds__(kBlock) void ext_actnorm_kernel(ExtArgs a, RowTilin
         for (int j = 0; j < VEC; ++j) {
             const size_t tok = (size_t)row * a.N + n;
             const float bias = a.nn[tok * 2 * a.D + d];
-            const float sc = tanhf(a.nn[tok * 2 * a.D + a.D + d]);
-            out[j] = a.reverse ? zv[j] * expf(-sc) - bias : (zv[j] + bias) * expf(sc);
+            const float sc = tanh_m<FAST>(a.nn[tok * 2 * a.D + a.D + d]);
+            out[j] = a.reverse ? zv[j] * exp_m<FAST>(-sc) - bias : (zv[j] + bias) * exp_m<FAST>(sc);
             bad |= isnan(out[j]);
             acc += a.pad ? sc * a.pad[tok] : sc;
             if (++d == a.D) {
@@ -421,7 +421,7 @@ struct SigArgs {
     int L, reverse;
     float alpha, log1ma;
 };
-template <int VEC>
+template <int VEC, bool FAST>
 __global__ __launch_bounds__(kBlock) void sigmoid_flow_kernel(SigArgs a, RowTiling tl) {
     __shared__ float part[kWavesPerBlock][kMaxTileChunks];
     bool bad = false;
@@ -432,7 +432,22 @@ __global__ __launch_bounds__(kBlock) void sigmoid_flow_kernel(SigArgs a, RowTili
         float acc = 0.f;
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-            if (!a.reverse) {
+            if (FAST) {
+                // hardware exp2 / log2 / rcp: softplus(-z) = max(-z, 0) + log(1 + e^-|z|), sigmoid from the same e
+                if (!a.reverse) {
+                    const float e = __builtin_amdgcn_exp2f(-fabsf(zv[j]) * 1.4426950408889634f);
+                    const float r = __builtin_amdgcn_rcpf(1.f + e);
+                    const float sp = fmaxf(-zv[j], 0.f) + 0.6931471805599453f * __builtin_amdgcn_logf(1.f + e);
+                    acc += -zv[j] - 2.f * sp;
+                    out[j] = zv[j] >= 0.f ? r : e * r;
+                } else {
+                    const float u = zv[j] * (1.f - a.alpha) + a.alpha * 0.5f;
+                    const float lu = 0.6931471805599453f * __builtin_amdgcn_logf(u);
+                    const float l1u = 0.6931471805599453f * __builtin_amdgcn_logf(1.f - u);
+                    acc += (-lu - l1u + a.log1ma);
+                    out[j] = lu - l1u;
+                }
+            } else if (!a.reverse) {
                 acc += -zv[j] - 2.f * softplus_t20(-zv[j]);
                 out[j] = 1.f / (1.f + expf(-zv[j]));
             } else {
@@ -696,8 +711,13 @@ int cnf_ext_actnorm(const float* z, const float* nn_out, const float* pad,
     if (B == 0) return CNF_OK;
     ExtArgs a{z, nn_out, pad, ldj_in, z_out, ldj_out, flags, N, D, N * D, reverse, make_fastdiv((uint32_t)D)};
     const RowTiling tl = make_row_tiling(B, a.L);
-    DISPATCH_VEC(tl, hipLaunchKernelGGL((ext_actnorm_kernel<V>), tiling_grid(tl), dim3(kBlock), 0,
-                                        (hipStream_t)stream, a, tl));
+    if (math_mode() == 1) {
+        DISPATCH_VEC(tl, hipLaunchKernelGGL((ext_actnorm_kernel<V, true>), tiling_grid(tl), dim3(kBlock), 0,
+                                            (hipStream_t)stream, a, tl));
+    } else {
+        DISPATCH_VEC(tl, hipLaunchKernelGGL((ext_actnorm_kernel<V, false>), tiling_grid(tl), dim3(kBlock), 0,
+                                            (hipStream_t)stream, a, tl));
+    }
     return launch_status("cnf_ext_actnorm");
 }
 
@@ -708,8 +728,13 @@ int cnf_sigmoid_flow(const float* z, const float* ldj_in, float* z_out, float* l
     if (B == 0) return CNF_OK;
     SigArgs a{z, ldj_in, z_out, ldj_out, flags, L, reverse, alpha, (float)log(1.0 - (double)alpha)};
     const RowTiling tl = make_row_tiling(B, L);
-    DISPATCH_VEC(tl, hipLaunchKernelGGL((sigmoid_flow_kernel<V>), tiling_grid(tl), dim3(kBlock), 0,
-                                        (hipStream_t)stream, a, tl));
+    if (math_mode() == 1) {
+        DISPATCH_VEC(tl, hipLaunchKernelGGL((sigmoid_flow_kernel<V, true>), tiling_grid(tl), dim3(kBlock), 0,
+                                            (hipStream_t)stream, a, tl));
+    } else {
+        DISPATCH_VEC(tl, hipLaunchKernelGGL((sigmoid_flow_kernel<V, false>), tiling_grid(tl), dim3(kBlock), 0,
+                                            (hipStream_t)stream, a, tl));
+    }
     return launch_status("cnf_sigmoid_flow");
 }
 

@@ -63,7 +63,14 @@ class GraphedTrainStep:
     At the reference's batch sizes (64-512 sets) a step is ~10^3 short kernels and the Python host paces it; the
     replay removes the host from the loop.  Requirements: static batch shape, a `capturable` optimiser (the learning
     rate lives in a device tensor, `set_lr` changes it between replays), single GPU (DDP's bucket hooks are not
-    captured here).  The encoder's noise comes from PyTorch's device generator, which CUDA/HIP graphs advance
+    captured here); capture BEFORE the model's parameters take part in any eager backward, or on a fresh module
+    with the same state_dict (parameters that were differentiated eagerly keep AccumulateGrad nodes bound to the
+    default stream; PyTorch warns "AccumulateGrad node's stream does not match" and the gradient accumulation then
+    happens outside the graph), and NO other autograd backward may run
+    in the process between replays — on ROCm 7.2 / PyTorch 2.10 an eager `backward()` of any module (a plain
+    nn.Sequential suffices) between two replays corrupts the captured step's gradients; evaluation under
+    `torch.no_grad()` between replays is fine.  The warm-up iterations are real optimisation steps on the example
+    batch.  With these rules the replayed trajectory is bit-identical to the eager one (tests).  The encoder's noise comes from PyTorch's device generator, which CUDA/HIP graphs advance
     correctly between replays.
 
         step = GraphedTrainStep(model, lambda params: torch.optim.RAdam(params, lr=torch.tensor(7.5e-4), capturable=True),
@@ -71,7 +78,8 @@ class GraphedTrainStep:
         loss = step(x, length)             # device scalar (mean NLL per element)
     """
 
-    def __init__(self, model, make_optimizer, example_x, example_length, max_grad_norm=0.25, warmup=3, **kwargs):
+    def __init__(self, model, make_optimizer, example_x, example_length, max_grad_norm=0.25, warmup=3, noise_shape=None,
+                 math_attention=False, **kwargs):
         from . import functional as Fn
         if not example_x.is_cuda:
             raise ops.HipOnlyError("GraphedTrainStep needs CUDA(HIP) tensors")
@@ -80,7 +88,18 @@ class GraphedTrainStep:
         self.max_grad_norm = max_grad_norm
         self.static_x = example_x.clone()
         self.static_len = example_length.clone()
-        self.kwargs = kwargs
+        self.kwargs = dict(kwargs)
+        self.math_attention = math_attention
+        # encoder noise: drawn OUTSIDE the graph into a static buffer before every replay and handed to the model as
+        # `noise=` (one small eager kernel per step).  Drawing it inside the capture relies on the generator's
+        # graph-safe offset bookkeeping, which on this stack returned unusable draws when the process had used the
+        # generator eagerly before the capture (losses of 10-60 instead of 3).
+        self.static_noise = None
+        if noise_shape is not None:
+            self.static_noise = torch.rand(tuple(noise_shape), dtype=torch.float32, device=self.device)
+            self.kwargs["noise"] = self.static_noise
+        for p in model.parameters():
+            p.grad = None
         self.optimizer = make_optimizer(model.parameters())
         for grp in self.optimizer.param_groups:
             if not isinstance(grp["lr"], torch.Tensor):
@@ -92,6 +111,8 @@ class GraphedTrainStep:
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):
             for _ in range(warmup):                        # optimiser state, allocator pools, lazy caches
+                if self.static_noise is not None:
+                    self.static_noise.uniform_()
                 self._step()
         torch.cuda.current_stream(self.device).wait_stream(side)
         ops.check_flags(self.device, "GraphedTrainStep warm-up")
@@ -103,6 +124,17 @@ class GraphedTrainStep:
     def _step(self):
         ops.CAPTURING = True
         try:
+            if self.math_attention:
+                # optional: capture the unfused attention kernels instead of the flash / memory-efficient ones
+                from torch.nn.attention import SDPBackend, sdpa_kernel
+                with sdpa_kernel(SDPBackend.MATH):
+                    return self._step_body()
+            return self._step_body()
+        finally:
+            ops.CAPTURING = False
+
+    def _step_body(self):
+        try:
             z, ldj = self.model(self.static_x, reverse=False, length=self.static_len, **self.kwargs)
             loss = self._Fn.PriorNllFn.apply(z, ldj, self.static_len, None).mean()
             self.optimizer.zero_grad(set_to_none=True)
@@ -112,13 +144,15 @@ class GraphedTrainStep:
             self.optimizer.step()
             return loss.detach()
         finally:
-            ops.CAPTURING = False
+            pass
 
     def set_lr(self, value):
         for grp in self.optimizer.param_groups:
             grp["lr"].fill_(float(value))
 
     def __call__(self, x, length=None):
+        if self.static_noise is not None:
+            self.static_noise.uniform_()
         self.static_x.copy_(x)
         if length is not None:
             self.static_len.copy_(length)

@@ -1086,6 +1086,11 @@ def test_set_modelling_driver_trains_checkpoints_and_reloads(tmp_path):
     assert out["best_file"] and os.path.isfile(out["best_file"])
     again = R.main(small + ["--only_eval"])
     assert abs(again["val_bpd"] - out["val_bpd"]) < 2e-3, (again, out)
+    # the same run with the whole training step replayed from one HIP graph
+    g_dir = str(tmp_path / "graphed")
+    small_g = [a if a != str(tmp_path) else g_dir for a in small]
+    out_g = R.main(small_g + ["--max_iterations", "400", "--eval_freq", "400", "--batch_size", "128", "--learning_rate", "2e-3", "--graph"])
+    assert np.isfinite(out_g["val_bpd"]) and out_g["val_bpd"] < 3.6, out_g
 
 
 def test_graphed_training_step_matches_eager_steps():
@@ -1106,10 +1111,11 @@ def test_graphed_training_step_matches_eager_steps():
     u = torch.rand(B * 16, 1, 4, device="cuda")
     mk = lambda params: torch.optim.RAdam(params, lr=torch.tensor(2e-3), capturable=True)
     x0 = draw(B)
-    step = GraphedTrainStep(model_a, mk, x0, ln, max_grad_norm=0.25, warmup=3, beta=1, noise=u)
-    opt_b = mk(model_b.parameters())
-    for g_ in opt_b.param_groups:
-        g_["lr"] = g_["lr"].cuda()
+    batches = [draw(B) for _ in range(6)]
+    # the eager twin runs its whole trajectory FIRST: on ROCm 7.2 / PyTorch 2.10 any eager backward executed between
+    # replays corrupts a captured training step (reproduced with a plain nn.Sequential twin), so the two are not
+    # interleaved — the same rule the docstring of GraphedTrainStep states
+    opt_b = torch.optim.RAdam(model_b.parameters(), lr=2e-3)
 
     def eager(x):
         z, ldj = model_b(x, reverse=False, length=ln, beta=1, noise=u)
@@ -1118,14 +1124,16 @@ def test_graphed_training_step_matches_eager_steps():
         loss.backward()
         torch.nn.utils.clip_grad_norm_(model_b.parameters(), 0.25)
         opt_b.step()
-        return loss.detach()
+        return float(loss.detach())
     for _ in range(3):
         eager(x0)                                  # the three warm-up steps of the graphed twin
-    for i in range(6):
-        x = draw(B)
-        la, lb = step(x).clone(), eager(x)
-        assert torch.isfinite(la) and abs(la.item() - lb.item()) < 2e-3 * max(1.0, abs(lb.item())), (i, la.item(), lb.item())
+    losses_b = [eager(x) for x in batches]
+    opt_b.zero_grad(set_to_none=True)
+    step = GraphedTrainStep(model_a, mk, x0, ln, max_grad_norm=0.25, warmup=3, beta=1, noise=u)
+    losses_a = [float(step(x)) for x in batches]
+    for i, (la, lb) in enumerate(zip(losses_a, losses_b)):
+        assert np.isfinite(la) and abs(la - lb) < 1e-3 * max(1.0, abs(lb)), (i, losses_a, losses_b)
     worst = max((pa - pb).abs().max().item() for pa, pb in zip(model_a.parameters(), model_b.parameters()))
-    assert worst < 5e-3, worst
+    assert worst < 2e-3, worst
     step.set_lr(1e-3)
     assert all(float(g_["lr"]) == pytest.approx(1e-3) for g_ in step.optimizer.param_groups)
