@@ -23,6 +23,17 @@ def _g(t, like=None):
     return t.contiguous() if not t.is_contiguous() else t
 
 
+class _Hold(list):
+    """Raw pointers of upstream gradients for one kernel launch.  A non-contiguous gradient (e.g. the expanded
+    gradient of `.mean()`) is copied first; the copy must stay alive until the launch is enqueued — were it dropped
+    right after taking its address, the next temporary could be given the same block and overwrite it."""
+
+    def __call__(self, t):
+        c = _g(t)
+        self.append(c)
+        return _ptr(c)
+
+
 class AffineCouplingFn(torch.autograd.Function):
     """(z, nn_out, scaling_factor, ldj) -> (z', ldj + layer_ldj); mask / reverse are constants."""
 
@@ -35,6 +46,7 @@ class AffineCouplingFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_zout, g_ldj):
+        hold = _Hold()
         z_out, nn_out, sf, mask = ctx.saved_tensors
         sf = sf if ctx.has_sf else None
         mask = mask if ctx.has_mask else None
@@ -46,8 +58,8 @@ class AffineCouplingFn(torch.autograd.Function):
         g_z, g_nn = torch.empty_like(z_out), torch.empty_like(nn_c)
         g_sf = torch.empty(D, dtype=torch.float32, device=dev) if sf is not None else None
         ws = _ws(D, dev) if sf is not None else None
-        _launch(dev, "cnf_affine_coupling_bwd", _ptr(z_out), _ptr(nn_c), _ptr(sfc), _ptr(m), mr, mc, _ptr(_g(g_zout)),
-                                               _ptr(_g(g_ldj)), _ptr(g_z), _ptr(g_nn), _ptr(g_sf), _ptr(ws), B, N, D,
+        _launch(dev, "cnf_affine_coupling_bwd", _ptr(z_out), _ptr(nn_c), _ptr(sfc), _ptr(m), mr, mc, hold(g_zout),
+                                               hold(g_ldj), _ptr(g_z), _ptr(g_nn), _ptr(g_sf), _ptr(ws), B, N, D,
                                                int(ctx.reverse), _stream(dev))
         return g_z, g_nn.view_as(nn_out), (g_sf.view_as(sf) if sf is not None else None), (g_ldj if ctx.has_ldj else None), None, None
 
@@ -65,13 +77,14 @@ class ExtActNormFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_zout, g_ldj):
+        hold = _Hold()
         z_out, nn_out, pad = ctx.saved_tensors
         dev = z_out.device
         B, N, D = z_out.shape
         nn_c = _f32(nn_out, "nn_out")
         p2 = _pad2d(pad, B, N, dev) if ctx.has_pad else None
         g_z, g_nn = torch.empty_like(z_out), torch.empty_like(nn_c)
-        _launch(dev, "cnf_ext_actnorm_bwd", _ptr(z_out), _ptr(nn_c), _ptr(p2), _ptr(_g(g_zout)), _ptr(_g(g_ldj)), _ptr(g_z),
+        _launch(dev, "cnf_ext_actnorm_bwd", _ptr(z_out), _ptr(nn_c), _ptr(p2), hold(g_zout), hold(g_ldj), _ptr(g_z),
                                            _ptr(g_nn), B, N, D, int(ctx.reverse), _stream(dev))
         return g_z, g_nn.view_as(nn_out), (g_ldj if ctx.has_ldj else None), None, None
 
@@ -90,6 +103,7 @@ class ActNormFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_zout, g_ldj):
+        hold = _Hold()
         z_out, bias, scales, length, pad = ctx.saved_tensors
         dev = z_out.device
         B, N, D = z_out.shape
@@ -99,8 +113,9 @@ class ActNormFn(torch.autograd.Function):
         g_b = torch.empty(D, dtype=torch.float32, device=dev)
         g_s = torch.empty(D, dtype=torch.float32, device=dev)
         ws = _ws(2 * D, dev)
-        _launch(dev, "cnf_actnorm_bwd", _ptr(z_out), _ptr(_f32(bias.reshape(-1), "bias")), _ptr(_f32(scales.reshape(-1), "scales")),
-                                       _ptr(p2), _ptr(ln), _ptr(_g(g_zout)), _ptr(_g(g_ldj)), _ptr(g_z), _ptr(g_b), _ptr(g_s),
+        bias_c, scales_c = _f32(bias.reshape(-1), "bias"), _f32(scales.reshape(-1), "scales")
+        _launch(dev, "cnf_actnorm_bwd", _ptr(z_out), _ptr(bias_c), _ptr(scales_c),
+                                       _ptr(p2), _ptr(ln), hold(g_zout), hold(g_ldj), _ptr(g_z), _ptr(g_b), _ptr(g_s),
                                        _ptr(ws), B, N, D, int(ctx.reverse), _stream(dev))
         return g_z, g_b.view_as(bias), g_s.view_as(scales), (g_ldj if ctx.has_ldj else None), None, None, None
 
@@ -119,6 +134,7 @@ class InvConvFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_zout, g_ldj):
+        hold = _Hold()
         x, weight, sldj, length, pad = ctx.saved_tensors
         dev = x.device
         B, N, D = x.shape
@@ -129,7 +145,7 @@ class InvConvFn(torch.autograd.Function):
         g_w = torch.empty(D, D, dtype=torch.float32, device=dev)
         g_s = torch.empty(1, dtype=torch.float32, device=dev)
         ws = _ws(D * D + 1, dev)
-        _launch(dev, "cnf_invconv_bwd", _ptr(xc), _ptr(wc), _ptr(p2), _ptr(ln), _ptr(_g(g_zout)), _ptr(_g(g_ldj)), _ptr(g_x),
+        _launch(dev, "cnf_invconv_bwd", _ptr(xc), _ptr(wc), _ptr(p2), _ptr(ln), hold(g_zout), hold(g_ldj), _ptr(g_x),
                                        _ptr(g_w), _ptr(g_s), _ptr(ws), B, N, D, int(ctx.reverse), _stream(dev))
         return g_x, g_w, g_s.view_as(sldj), (g_ldj if ctx.has_ldj else None), None, None, None
 
@@ -144,10 +160,11 @@ class LogisticLogProbFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        hold = _Hold()
         (x,) = ctx.saved_tensors
         xc = _f32(x, "x")
         g_x = torch.empty_like(xc)
-        _launch(xc.device, "cnf_logistic_log_prob_bwd", _ptr(xc), _ptr(_g(g)), _ptr(g_x), xc.numel(), ctx.mu, ctx.sigma,
+        _launch(xc.device, "cnf_logistic_log_prob_bwd", _ptr(xc), hold(g), _ptr(g_x), xc.numel(), ctx.mu, ctx.sigma,
                                                  _stream(xc.device))
         return g_x.view_as(x), None, None, None
 
@@ -165,6 +182,7 @@ class PriorNllFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_nll):
+        hold = _Hold()
         z, length, pad = ctx.saved_tensors
         dev = z.device
         B, N, D = z.shape
@@ -173,7 +191,7 @@ class PriorNllFn(torch.autograd.Function):
         ln = _length(length, B, dev) if ctx.has_len else None
         g_z = torch.empty_like(zc)
         g_ldj = torch.empty(B, dtype=torch.float32, device=dev)
-        _launch(dev, "cnf_prior_nll_bwd", _ptr(zc), _ptr(p2), _ptr(ln), _ptr(_g(g_nll)), _ptr(g_z), _ptr(g_ldj), B, N, D,
+        _launch(dev, "cnf_prior_nll_bwd", _ptr(zc), _ptr(p2), _ptr(ln), hold(g_nll), _ptr(g_z), _ptr(g_ldj), B, N, D,
                                          float(ops.LOGISTIC_SIGMA), _stream(dev))
         return g_z, g_ldj, None, None
 
@@ -189,12 +207,13 @@ class SigmoidFlowFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_zout, g_ldj):
+        hold = _Hold()
         (z,) = ctx.saved_tensors
         zc = _f32(z, "z")
         B = zc.shape[0]
         L = zc.numel() // B
         g_z = torch.empty_like(zc)
-        _launch(zc.device, "cnf_sigmoid_flow_bwd", _ptr(zc), _ptr(_g(g_zout)), _ptr(_g(g_ldj)), _ptr(g_z), B, L, int(ctx.reverse),
+        _launch(zc.device, "cnf_sigmoid_flow_bwd", _ptr(zc), hold(g_zout), hold(g_ldj), _ptr(g_z), B, L, int(ctx.reverse),
                                             ctx.alpha, _stream(zc.device))
         return g_z, (g_ldj if ctx.has_ldj else None), None, None
 
@@ -217,6 +236,7 @@ class MixtureCouplingFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_zout, g_ldj, _g_reg):
+        hold = _Hold()
         z, nn_out, sf, msf, mask, pad = ctx.saved_tensors
         has_sf, has_msf, has_mask, has_pad, has_ldj = ctx.flags
         K, reg_max, reg_factor, is_training, pit, pout = ctx.cfg
@@ -232,7 +252,7 @@ class MixtureCouplingFn(torch.autograd.Function):
         g_msf = torch.empty(D, K, dtype=torch.float32, device=dev) if has_msf else None
         ws = _ws(D + D * K, dev)
         _launch(dev, "cnf_mixture_coupling_bwd", _ptr(zc), _ptr(nn_c), _ptr(sfc), _ptr(msfc), _ptr(m), mr, mc, _ptr(p2), int(pit), int(pout),
-                                                _ptr(_g(g_zout)), _ptr(_g(g_ldj)), _ptr(g_z), _ptr(g_nn), _ptr(g_sf), _ptr(g_msf), _ptr(ws),
+                                                hold(g_zout), hold(g_ldj), _ptr(g_z), _ptr(g_nn), _ptr(g_sf), _ptr(g_msf), _ptr(ws),
                                                 B, N, D, K, reg_max, reg_factor, int(is_training), _stream(dev))
         return (g_z, g_nn.view_as(nn_out), (g_sf.view_as(sf) if has_sf else None), (g_msf.view_as(msf) if has_msf else None),
                 (g_ldj if has_ldj else None), None, None, None, None, None, None, None, None)
@@ -254,6 +274,7 @@ class EncoderForwardFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_zout, g_ldj, _g_cpl):
+        hold = _Hold()
         table, categ, eps, prior, pad = ctx.saved_tensors
         dev = table.device
         B, N = categ.shape
@@ -262,8 +283,9 @@ class EncoderForwardFn(torch.autograd.Function):
         p2 = _pad2d(pad, B, N, dev) if ctx.has_pad else None
         g_table = torch.empty_like(tc)
         ws = _ws(C * 2 * D, dev)
-        _launch(dev, "cnf_encoder_forward_bwd", _ptr(categ.contiguous()), _ptr(ec), _ptr(tc), _ptr(pc), _ptr(p2), ctx.beta,
-                                               _ptr(_g(g_zout)), _ptr(_g(g_ldj)), _ptr(g_table), _ptr(ws), B, N, D, C,
+        categ_c = categ.contiguous()
+        _launch(dev, "cnf_encoder_forward_bwd", _ptr(categ_c), _ptr(ec), _ptr(tc), _ptr(pc), _ptr(p2), ctx.beta,
+                                               hold(g_zout), hold(g_ldj), _ptr(g_table), _ptr(ws), B, N, D, C,
                                                float(ops.LOGISTIC_SIGMA), float(ops.LOGISTIC_LOG_SIGMA), _stream(dev))
         return g_table, None, None, None, None, None, None
 
@@ -281,6 +303,7 @@ class AffineParamsFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_s, g_t):
+        hold = _Hold()
         nn_out, sf, mask = ctx.saved_tensors
         has_sf, has_mask = ctx.flags
         dev = nn_out.device
@@ -292,7 +315,7 @@ class AffineParamsFn(torch.autograd.Function):
         g_nn = torch.empty_like(nn_c)
         g_sf = torch.empty(D, dtype=torch.float32, device=dev) if has_sf else None
         ws = _ws(D, dev) if has_sf else None
-        _launch(dev, "cnf_affine_params_bwd", _ptr(nn_c), _ptr(sfc), _ptr(m), mr, mc, _ptr(_g(g_s)), _ptr(_g(g_t)), _ptr(g_nn),
+        _launch(dev, "cnf_affine_params_bwd", _ptr(nn_c), _ptr(sfc), _ptr(m), mr, mc, hold(g_s), hold(g_t), _ptr(g_nn),
                                              _ptr(g_sf), _ptr(ws), B, N, D, _stream(dev))
         return g_nn.view_as(nn_out), (g_sf.view_as(sf) if has_sf else None), None
 
@@ -309,11 +332,12 @@ class AffineTransformFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_zout, g_ldj):
+        hold = _Hold()
         z_out, s, t = ctx.saved_tensors
         dev = z_out.device
         B, N, D = z_out.shape
         g_z, g_s, g_t = torch.empty_like(z_out), torch.empty_like(z_out), torch.empty_like(z_out)
-        _launch(dev, "cnf_affine_transform_bwd", _ptr(z_out), _ptr(s), _ptr(t), _ptr(_g(g_zout)), _ptr(_g(g_ldj)), _ptr(g_z),
+        _launch(dev, "cnf_affine_transform_bwd", _ptr(z_out), _ptr(s), _ptr(t), hold(g_zout), hold(g_ldj), _ptr(g_z),
                                                 _ptr(g_s), _ptr(g_t), B, N, D, int(ctx.reverse), _stream(dev))
         return g_z, g_s.sum_to_size(ctx.shapes[0]), g_t.sum_to_size(ctx.shapes[1]), None
 
@@ -386,9 +410,11 @@ class MixtureTransformFn(torch.autograd.Function):
         p2 = _pad2d(pad, B, N, dev) if has_pad else None
         g_z, g_t, g_s = torch.empty_like(z64), torch.empty_like(z64), torch.empty_like(z64)
         g_pi, g_mu, g_ls = torch.empty_like(pi64), torch.empty_like(pi64), torch.empty_like(pi64)
-        dd = lambda x: None if x is None else x.double().contiguous()
+        # fp64 copies of the upstream gradients: named, so that both stay alive until the launch is enqueued
+        gz64 = None if g_zout is None else g_zout.double().contiguous()
+        gl64 = None if g_ldj is None else g_ldj.double().contiguous()
         _launch(dev, "cnf_mixture_transform_bwd", _ptr(z64), _ptr(t64), _ptr(s64), _ptr(pi64), _ptr(mu64), _ptr(ls64), _ptr(m), mr, mc, _ptr(p2),
-                                                 _ptr(dd(g_zout)), _ptr(dd(g_ldj)), _ptr(g_z), _ptr(g_t), _ptr(g_s), _ptr(g_pi), _ptr(g_mu), _ptr(g_ls),
+                                                 _ptr(gz64), _ptr(gl64), _ptr(g_z), _ptr(g_t), _ptr(g_s), _ptr(g_pi), _ptr(g_mu), _ptr(g_ls),
                                                  B, N, D, K, reg_max, reg_factor, int(is_training), _stream(dev))
         return (g_z.to(z.dtype), g_t.sum_to_size(t.shape), g_s.sum_to_size(log_s.shape), g_pi.sum_to_size(log_pi.shape),
                 g_mu.sum_to_size(mu.shape), g_ls.sum_to_size(ls.shape), None, None, None, None, None)

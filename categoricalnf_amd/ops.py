@@ -262,7 +262,8 @@ def actnorm_data_init(x, channel_padding_mask=None):
     _launch(dev, "cnf_actnorm_stats", _ptr(x), _ptr(pad), None, _ptr(acc), B, N, D, 0, _stream(dev))
     mean = acc[:D] / acc[D]
     acc2 = torch.zeros(D + 1, dtype=torch.float64, device=dev)
-    _launch(dev, "cnf_actnorm_stats", _ptr(x), _ptr(pad), _ptr(mean.contiguous()), _ptr(acc2), B, N, D, 1,
+    mean_c = mean.contiguous()
+    _launch(dev, "cnf_actnorm_stats", _ptr(x), _ptr(pad), _ptr(mean_c), _ptr(acc2), B, N, D, 1,
                                      _stream(dev))
     var = acc2[:D] / acc[D]
     bias = (-mean).float().view(1, 1, D)

@@ -1137,3 +1137,34 @@ def test_graphed_training_step_matches_eager_steps():
     assert worst < 2e-3, worst
     step.set_lr(1e-3)
     assert all(float(g_["lr"]) == pytest.approx(1e-3) for g_ in step.optimizer.param_groups)
+
+
+def test_backward_with_non_contiguous_upstream_gradients():
+    """Both upstream gradients of a layer arrive non-contiguous (a transposed view and the expanded gradient of a
+    mean): each is copied for the kernel and both copies must stay alive until the launch (they once could be handed
+    the same block).  Affine coupling and the static (s, t) split API against the oracle's autograd."""
+    from categoricalnf_amd import functional as Fn
+    gen = torch.Generator().manual_seed(21)
+    B, N, D = 37, 11, 6
+    z = torch.randn(B, N, D, generator=gen)
+    nn_out = 0.5 * torch.randn(B, N, 2 * D, generator=gen)
+    sf = 0.2 * torch.randn(D, generator=gen)
+    w = torch.randn(B, D, N, generator=gen)
+    mask = O.channel_mask(D)
+
+    def loss_of(zo, lo):
+        return (zo.transpose(1, 2) * (w.to(zo.device))).sum() + 3.0 * lo.mean()
+    zc, nc, sc = (t.clone().requires_grad_() for t in (z, nn_out, sf))
+    loss_of(*O.affine_coupling(zc, nc, mask, sc)).backward()
+    zg, ng, sg = (g(t).requires_grad_() for t in (z, nn_out, sf))
+    loss_of(*Fn.AffineCouplingFn.apply(zg, ng, sg, None, g(mask), False)).backward()
+    close(zg.grad, zc.grad, **GRAD); close(ng.grad, nc.grad, **GRAD); close(sg.grad, sc.grad, **GRAD)
+    # static API: s and t come back separately, their gradients are both views of one transposed tensor
+    nc2, sc2 = nn_out.clone().requires_grad_(), sf.clone().requires_grad_()
+    s_o, t_o = O.affine_params(nc2, O.expand_mask(mask, z), sc2)
+    ws_, wt_ = torch.randn(B, D, N, generator=gen), torch.randn(B, D, N, generator=gen)
+    ((s_o.transpose(1, 2) * ws_).sum() + (t_o.transpose(1, 2) * wt_).sum()).backward()
+    ng2, sg2 = g(nn_out).requires_grad_(), g(sf).requires_grad_()
+    s_g, t_g = Fn.AffineParamsFn.apply(ng2, sg2, g(mask))
+    ((s_g.transpose(1, 2) * g(ws_)).sum() + (t_g.transpose(1, 2) * g(wt_)).sum()).backward()
+    close(ng2.grad, nc2.grad, **GRAD); close(sg2.grad, sc2.grad, **GRAD)
