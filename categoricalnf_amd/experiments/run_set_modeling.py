@@ -59,9 +59,6 @@ def parse(argv=None):
     p.add_argument("--coupling_mask_ratio", type=float, default=0.5)
     p.add_argument("--coupling_num_mixtures", type=int, default=8)
     p.add_argument("--backend", default=None, help="torch.distributed backend (default: nccl = RCCL)")
-    p.add_argument("--graph", action="store_true",
-                   help="single GPU: capture the whole training step (forward, backward, clipping, RAdam) in one HIP graph "
-                        "and replay it per batch (graphs.GraphedTrainStep) — removes the Python host from the loop")
     return p.parse_args(argv)
 
 
@@ -185,31 +182,15 @@ def main(argv=None):
     ddp.train()
     best = state["best_save_dict"]
     t0, run_loss, seen = time.time(), torch.zeros((), device=device), 0       # the loss stays on the device between prints
-    graphed = None
-    if args.graph:
-        if world > 1:
-            raise SystemExit("--graph captures a single-GPU step; run without it under torch.distributed.run")
-        from ..graphs import GraphedTrainStep
-        x, ln = batch()
-        graphed = GraphedTrainStep(
-            model, lambda ps: torch.optim.RAdam(ps, lr=torch.tensor(args.learning_rate), capturable=True), x, ln,
-            max_grad_norm=args.max_gradient_norm, warmup=3, beta=1,
-            noise_shape=(x.size(0) * args.set_size, 1, args.encoding_dim))
-        optimizer = graphed.optimizer
-        lr_at = lambda step: args.learning_rate * max(floor, args.lr_decay_factor ** (step // max(1, args.lr_decay_step)))
     for it in range(state["iteration"], args.max_iterations):
         x, ln = batch()
-        if graphed is not None:
-            graphed.set_lr(lr_at(it))
-            loss = graphed(x, ln)
-        else:
-            z, ldj = ddp(x, reverse=False, length=ln, beta=1)
-            loss = Fn.PriorNllFn.apply(z, ldj, ln, None).mean()
-            optimizer.zero_grad(set_to_none=True)
-            loss.backward()
-            torch.nn.utils.clip_grad_norm_(ddp.parameters(), args.max_gradient_norm)
-            optimizer.step()
-            scheduler.step()
+        z, ldj = ddp(x, reverse=False, length=ln, beta=1)
+        loss = Fn.PriorNllFn.apply(z, ldj, ln, None).mean()
+        optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(ddp.parameters(), args.max_gradient_norm)
+        optimizer.step()
+        scheduler.step()
         run_loss += loss.detach()
         seen += 1
         step = it + 1

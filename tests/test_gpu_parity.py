@@ -1086,11 +1086,7 @@ def test_set_modelling_driver_trains_checkpoints_and_reloads(tmp_path):
     assert out["best_file"] and os.path.isfile(out["best_file"])
     again = R.main(small + ["--only_eval"])
     assert abs(again["val_bpd"] - out["val_bpd"]) < 2e-3, (again, out)
-    # the same run with the whole training step replayed from one HIP graph
-    g_dir = str(tmp_path / "graphed")
-    small_g = [a if a != str(tmp_path) else g_dir for a in small]
-    out_g = R.main(small_g + ["--max_iterations", "400", "--eval_freq", "400", "--batch_size", "128", "--learning_rate", "2e-3", "--graph"])
-    assert np.isfinite(out_g["val_bpd"]) and out_g["val_bpd"] < 3.6, out_g
+
 
 
 def test_graphed_training_step_matches_eager_steps():
