@@ -18,7 +18,14 @@ for r in rows[1:8]:
 shutil.copy(os.path.join(G, "traffic.json"), os.path.join(P, "traffic.json"))
 shutil.copy(os.path.join(G, "traffic.txt"), os.path.join(P, tag + "_pmc_traffic.txt"))
 for src, dst in (("sweep_affine.log", "_sweep_affine.txt"), ("sweep_mixture.log", "_sweep_mixture.txt"),
-                 ("bench_kernels.log", "_bench_kernels.txt"), ("flow_graph.txt", "_flow_graph.txt")):
+                 ("bench_kernels.log", "_bench_kernels.txt"), ("flow_graph.txt", "_flow_graph.txt"),
+                 ("affine_probe.txt", "_affine_probe.txt"), ("encoder_probe.txt", "_encoder_probe.txt"),
+                 ("train_step.txt", "_train_step.txt")):
     if os.path.exists(os.path.join(G, src)):
         shutil.copy(os.path.join(G, src), os.path.join(P, tag + dst))
+lay = os.path.join(G, "prof_layers", "layers_kernel_stats.csv")
+if os.path.exists(lay):
+    rows = list(csv.reader(open(lay)))
+    with open(os.path.join(P, tag + "_layer_kernel_stats.csv"), "w", newline="") as fh:
+        csv.writer(fh).writerows([rows[0]] + [[r[0][:120]] + r[1:] for r in rows[1:] if "cnf::" in r[0]])
 print(line[:400])

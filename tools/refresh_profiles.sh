@@ -26,3 +26,10 @@ timeout 300 python tools/sweep_affine.py > "$OUT/sweep_affine.log" 2>&1; tail -4
 timeout 300 python tools/sweep_mixture.py > "$OUT/sweep_mixture.log" 2>&1; tail -4 "$OUT/sweep_mixture.log"
 timeout 300 python tools/bench_kernels.py > "$OUT/bench_kernels.log" 2>&1; tail -30 "$OUT/bench_kernels.log"
 timeout 300 python tools/bench_flow_graph.py > "$OUT/flow_graph.txt" 2>&1; tail -6 "$OUT/flow_graph.txt"
+timeout 200 python tools/affine_probe.py > "$OUT/affine_probe.txt" 2>&1; tail -5 "$OUT/affine_probe.txt"
+timeout 200 python tools/encoder_probe.py > "$OUT/encoder_probe.txt" 2>&1; tail -3 "$OUT/encoder_probe.txt"
+rm -rf "$OUT/prof_layers"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_layers" -o layers -- \
+    python tools/layer_probe.py > "$OUT/layer_probe.log" 2>&1
+rm -f "$OUT"/prof_layers/*kernel_trace.csv
+( for b in 64 256 1024; do timeout 300 python tools/bench_train_step.py $b 20 graph 2>&1 | grep "^batch"; done ) > "$OUT/train_step.txt"; cat "$OUT/train_step.txt"
