@@ -1164,3 +1164,20 @@ def test_backward_with_non_contiguous_upstream_gradients():
     s_g, t_g = Fn.AffineParamsFn.apply(ng2, sg2, g(mask))
     ((s_g.transpose(1, 2) * g(ws_)).sum() + (t_g.transpose(1, 2) * g(wt_)).sum()).backward()
     close(ng2.grad, nc2.grad, **GRAD); close(sg2.grad, sc2.grad, **GRAD)
+
+
+def test_c_abi_without_torch(tmp_path):
+    """The boundary is a plain C ABI: tests/abi/abi_roundtrip.cpp (hipMalloc'ed buffers, no torch, no Python) is
+    compiled against include/cnf_hip.h, linked to libcnf_hip.so and run in its own process; it checks the fused
+    coupling + NLL kernel, the batch sum and the inverse against a scalar fp64 loop."""
+    import shutil, subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_dir = os.path.join(root, "categoricalnf_amd", "lib")
+    exe = str(tmp_path / "abi_roundtrip")
+    build = subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", os.path.join(root, "tests", "abi", "abi_roundtrip.cpp"),
+                            "-I", os.path.join(root, "include"), "-L", lib_dir, "-lcnf_hip", "-Wl,-rpath," + lib_dir, "-o", exe],
+                           capture_output=True, text=True, timeout=600)
+    assert build.returncode == 0, build.stderr[-2000:]
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0 and "ABI_C OK" in run.stdout, (run.stdout[-1000:], run.stderr[-1000:])
