@@ -27,6 +27,7 @@ class FlowModel(nn.Module):
         self.print_overview()
 
     def forward(self, z, ldj=None, reverse=False, get_ldj_per_layer=False, **kwargs):
+        nll_request = kwargs.pop("_nll", None)           # set by nll(): assemble the NLL, fused into the last layer if possible
         if ldj is None:
             ldj = z.new_zeros(z.size(0), dtype=torch.float32)
         order = list(enumerate(self.flow_layers))
@@ -48,6 +49,16 @@ class FlowModel(nn.Module):
                                                  channel_padding_mask=kwargs.get("channel_padding_mask", None), ldj=ldj)
                     skip = order[pos + 1][0]
                     continue
+            if (nll_request is not None and pos == len(order) - 1 and type(layer).__name__ == "CouplingLayer"
+                    and not reverse and not torch.is_grad_enabled()):
+                # last layer = affine coupling: transform + prior log-prob + NLL in one kernel
+                net_kwargs = {k: v for k, v in kwargs.items() if k != "channel_padding_mask"}
+                nn_out = layer.run_network(x=z * layer._prepare_mask(layer.mask, z), **net_kwargs)
+                z, ldj, _, nll_request["nll"] = ops.affine_coupling_nll(
+                    z, nn_out, layer.scaling_factor, layer.mask, ldj=ldj, length=nll_request["length"],
+                    channel_padding_mask=kwargs.get("channel_padding_mask", None), sums=nll_request["sums"],
+                    sigma=nll_request["sigma"], log_sigma=nll_request["log_sigma"])
+                continue
             res = layer(z, reverse=reverse, get_ldj_per_layer=get_ldj_per_layer, **kwargs)
             if len(res) == 2:
                 z, layer_ldj = res
@@ -63,11 +74,36 @@ class FlowModel(nn.Module):
                 per_layer += detail
             else:
                 per_layer.append(detail)
+        if nll_request is not None and "nll" not in nll_request:
+            _, nll_request["nll"] = ops.prior_nll(z, ldj, nll_request["length"], kwargs.get("channel_padding_mask", None),
+                                                  sums=nll_request["sums"], sigma=nll_request["sigma"],
+                                                  log_sigma=nll_request["log_sigma"])
         if z.is_cuda:
             ops.check_flags(z.device, "Flow: %s" % self.name)
         if get_ldj_per_layer:
             return z, ldj, per_layer
         return z, ldj
+
+    @torch.no_grad()
+    def nll(self, z, length=None, prior=None, sums=None, **kwargs):
+        """Evaluation shortcut: per-sample negative log-likelihood per element of `z` under the flow and a logistic
+        prior, i.e. `forward` followed by the NLL assembly of the task classes (experiments/set_modeling/task.py:96-118:
+        nll_b = (-ldj_b - sum_{n,d} log p(z_bnd) * pad_bn) / length_b).  Returns (z, ldj, nll [B]); `sums` (fp64 [2],
+        optional) receives (sum_b nll_b, B) — the pair that is all-reduced over ranks.
+
+        When the last flow layer is an affine `CouplingLayer`, that layer and the NLL assembly run as ONE kernel
+        (cnf_affine_coupling_nll: the prior term is accumulated while z is still in registers); otherwise the
+        separate prior kernel is used.  Same numbers either way (tests).  Goes through `self.forward`, so the masks a
+        subclass builds from `length` reach the layers as usual."""
+        from .distributions import LogisticDistribution
+        prior = prior if prior is not None else LogisticDistribution()
+        if type(prior) is not LogisticDistribution or float(prior.mu) != 0.0:
+            raise NotImplementedError("FlowModel.nll: zero-mean LogisticDistribution prior only")
+        request = {"sigma": float(prior.sigma), "log_sigma": float(prior.log_sigma), "sums": sums, "length": length}
+        if length is not None:
+            kwargs["length"] = length
+        z, ldj = self.forward(z, reverse=False, _nll=request, **kwargs)
+        return z, ldj, request["nll"]
 
     def _fusable(self, z, get_ldj_per_layer):
         """Layer fusion only where it is unobservable: no autograd, no per-layer log-det report, CUDA tensors."""

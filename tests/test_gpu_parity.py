@@ -545,6 +545,12 @@ def test_flow_stack_config0(c):
     bpd = float(np.log2(np.exp(1)) * nll.mean().item())
     assert abs(bpd - float(c.bpd)) < 0.01
     assert torch.equal(dec.cpu(), c.decoded)
+    # FlowModel.nll: the last affine coupling and the NLL assembly as one kernel — same latents, log-det and NLL
+    sums = torch.zeros(2, dtype=torch.float64, device="cuda")
+    z2, ldj2, nll2 = model.nll(g(c.categ), length=ln, noise=g(c.u), sums=sums)
+    assert torch.equal(z2, z) and torch.equal(ldj2, ldj)
+    close(nll2, nll, rtol=2e-6, atol=2e-5); close(nll2, c.nll, **LDJ)
+    assert sums[1].item() == m["B"] and abs(sums[0].item() - nll2.double().sum().item()) < 1e-6 * abs(sums[0].item()) + 1e-9
 
 
 def test_nan_raises_reference_assertion():
@@ -617,6 +623,12 @@ def test_set_shuffling_trained_model_bits_per_dim():
     mean_nll, bpd = allreduce_nll(total)
     assert abs(bpd - meta["val_bpd"]) < 0.01, (bpd, meta["val_bpd"])
     assert bpd > dataset.optimum_bpd(S) - 1e-3
+    # FlowModel.nll on a flow that ends in a mixture coupling: the separate prior kernel, same numbers as the oracle
+    x64 = torch.from_numpy(data["x256"][:64]).long().cuda()
+    l64 = torch.full((64,), S, dtype=torch.long, device="cuda")
+    u64 = torch.from_numpy(data["u256"][:64 * S]).cuda()
+    zq, lq, nq = model.nll(x64, length=l64, noise=u64, beta=1)
+    close(nq, torch.from_numpy(data["nll256"][:64]), **LDJ)
 
 
 # ------------------------------------------------------------------------------------------------
