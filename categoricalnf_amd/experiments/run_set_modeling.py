@@ -27,7 +27,6 @@ import numpy as np
 import torch
 
 from .. import functional as Fn
-from .. import ops
 from ..distributed import allreduce_nll, init_process_group, shard_bounds, wrap_ddp
 from .set_modeling import FlowSetModeling, SetShufflingDataset, SetSummationDataset
 
@@ -123,8 +122,7 @@ def evaluate(model, sets, device, rank=0, world=1, batch_size=4096):
     for i in range(lo, hi, batch_size):
         x = torch.from_numpy(sets[i:min(i + batch_size, hi)]).long().to(device)
         ln = torch.full((x.size(0),), x.size(1), dtype=torch.long, device=device)
-        z, ldj = inner(x, reverse=False, length=ln, beta=1)
-        ops.prior_nll(z, ldj, ln, sums=part)
+        inner.nll(x, length=ln, beta=1, sums=part)            # (sum nll, count) of this batch, on the device
         total += part
     mean_nll, bpd = allreduce_nll(total)
     inner.train(was_training)
