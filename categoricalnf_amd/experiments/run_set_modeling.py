@@ -136,7 +136,7 @@ def main(argv=None):
     torch.cuda.set_device(device)
     torch.manual_seed(args.seed)
     np.random.seed(args.seed)
-    say = print if rank == 0 else (lambda *a, **k: None)
+    say = (lambda *a, **k: print(*a, flush=True, **k)) if rank == 0 else (lambda *a, **k: None)     # flushed: logs survive a kill
 
     data_cls = SetShufflingDataset if args.dataset == "shuffling" else SetSummationDataset
     train_set = data_cls(args.set_size, train=True)
