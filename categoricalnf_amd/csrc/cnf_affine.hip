@@ -408,6 +408,63 @@ __global__ __launch_bounds__(kBlock) void ext_actnorm_kernel(ExtArgs a, RowTilin
     if (bad) raise_flag(a.flags, CNF_FLAG_NAN_Z);
 }
 
+// ExtActNorm, grouped-token form: one lane owns TP consecutive tokens so that its TP*D latents and its 2*TP*D
+// conditioning values ([bias D | scales D] per token) are whole 16-byte vectors: 3*NV coalescable 16-byte loads
+// instead of 2 scalar gathers per element.  A "chunk" of the row walk is one token group; needs N % TP == 0.
+typedef float ea_f4 __attribute__((ext_vector_type(4)));
+template <int D, bool FAST>
+__global__ __launch_bounds__(kBlock) void ext_actnorm_group_kernel(ExtArgs a, RowTiling tl) {
+    constexpr int TP = (D % 4 == 0) ? 1 : (D % 2 == 0 ? 2 : 4);
+    constexpr int NV = TP * D / 4;
+    __shared__ float part[kWavesPerBlock][kMaxTileChunks];
+    bool bad = false;
+    auto chunk = [&](int row, int gidx) -> float {
+        const size_t tok0 = (size_t)row * a.N + (size_t)gidx * TP;
+        float zv[TP * D], cv[2 * TP * D], out[TP * D];
+        const ea_f4* zs = reinterpret_cast<const ea_f4*>(a.z + tok0 * D);
+        const ea_f4* cs = reinterpret_cast<const ea_f4*>(a.nn + tok0 * 2 * D);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const ea_f4 q = zs[v];
+            zv[4 * v] = q.x; zv[4 * v + 1] = q.y; zv[4 * v + 2] = q.z; zv[4 * v + 3] = q.w;
+        }
+#pragma unroll
+        for (int v = 0; v < 2 * NV; ++v) {
+            const ea_f4 q = cs[v];
+            cv[4 * v] = q.x; cv[4 * v + 1] = q.y; cv[4 * v + 2] = q.z; cv[4 * v + 3] = q.w;
+        }
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < TP; ++k) {
+            const float pv = a.pad ? a.pad[tok0 + k] : 1.f;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const float bias = cv[k * 2 * D + d];
+                const float sc = tanh_m<FAST>(cv[k * 2 * D + D + d]);
+                const float o = a.reverse ? zv[k * D + d] * exp_m<FAST>(-sc) - bias : (zv[k * D + d] + bias) * exp_m<FAST>(sc);
+                bad |= isnan(o);
+                out[k * D + d] = o;
+                acc += a.pad ? sc * pv : sc;
+            }
+        }
+        ea_f4* dst = reinterpret_cast<ea_f4*>(a.z_out + tok0 * D);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const ea_f4 q = {out[4 * v], out[4 * v + 1], out[4 * v + 2], out[4 * v + 3]};
+            __builtin_nontemporal_store(q, dst + v);
+        }
+        return acc;
+    };
+    auto finish = [&](int row, float sum) {
+        const float base = a.ldj_in ? a.ldj_in[row] : 0.f;
+        const float v = a.reverse ? base - sum : base + sum;
+        a.ldj_out[row] = v;
+        if (isnan(v)) raise_flag(a.flags, CNF_FLAG_NAN_LDJ);
+    };
+    walk_row_tile<float>(tl, part[threadIdx.x >> 6], chunk, finish);
+    if (bad) raise_flag(a.flags, CNF_FLAG_NAN_Z);
+}
+
 // ---- sigmoid / logit flow (sigmoid_layer.py:24-47) ---------------------------------------------
 __device__ __forceinline__ float softplus_t20(float x) {   // F.softplus, beta 1, threshold 20
     return x > 20.f ? x : log1pf(expf(x));
@@ -710,6 +767,26 @@ int cnf_ext_actnorm(const float* z, const float* nn_out, const float* pad,
     CNF_REQUIRE(B >= 0 && N > 0 && D > 0 && (long)N * D < 65536, "cnf_ext_actnorm: bad shape");
     if (B == 0) return CNF_OK;
     ExtArgs a{z, nn_out, pad, ldj_in, z_out, ldj_out, flags, N, D, N * D, reverse, make_fastdiv((uint32_t)D)};
+    // grouped-token kernel (16-byte I/O) for the common channel counts when the tokens of a row fill whole groups
+    const int tp = (D % 4 == 0) ? 1 : (D % 2 == 0 ? 2 : 4);
+    const bool aligned = ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(nn_out) | reinterpret_cast<uintptr_t>(z_out)) & 15) == 0;
+    if (aligned && N % tp == 0 && N / tp >= 8 && (D == 2 || D == 3 || D == 4 || D == 6 || D == 8)) {
+        const RowTiling tg = make_row_tiling(B, N / tp, /*force_vec=*/1);
+        const dim3 grid = tiling_grid(tg), block(kBlock);
+        hipStream_t st = (hipStream_t)stream;
+#define CNF_EXTG(D_)                                                                                              \
+    if (math_mode() == 1) hipLaunchKernelGGL((ext_actnorm_group_kernel<D_, true>), grid, block, 0, st, a, tg);   \
+    else hipLaunchKernelGGL((ext_actnorm_group_kernel<D_, false>), grid, block, 0, st, a, tg)
+        switch (D) {
+            case 2: CNF_EXTG(2); break;
+            case 3: CNF_EXTG(3); break;
+            case 4: CNF_EXTG(4); break;
+            case 6: CNF_EXTG(6); break;
+            default: CNF_EXTG(8); break;
+        }
+#undef CNF_EXTG
+        return launch_status("cnf_ext_actnorm");
+    }
     const RowTiling tl = make_row_tiling(B, a.L);
     if (math_mode() == 1) {
         DISPATCH_VEC(tl, hipLaunchKernelGGL((ext_actnorm_kernel<V, true>), tiling_grid(tl), dim3(kBlock), 0,

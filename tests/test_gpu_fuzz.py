@@ -166,3 +166,35 @@ def test_fuzz_encoder(B, N, D, seed):
     if not bool(same.all()):
         # a differing index is only acceptable on a numerical tie of the two class scores (never seen so far)
         raise AssertionError("decoded categories differ at %d of %d tokens" % (int((~same).sum()), same.numel()))
+
+
+@pytest.mark.parametrize("B,N,D,seed", _shapes(5, 20, dims=(1, 2, 3, 4, 6, 8)) + [(64, 64, 6, 11), (33, 16, 3, 12), (9, 32, 8, 13), (7, 24, 2, 14)])
+@pytest.mark.parametrize("mode", [1, 0])
+def test_fuzz_ext_actnorm_and_sigmoid(B, N, D, seed, mode):
+    """ExtActNorm (per-element kernel and the grouped-token kernel, which needs N % {1,2,4} == 0 and N/TP >= 8) and
+    the sigmoid / logit flow, both directions, both arithmetic modes."""
+    gen = torch.Generator().manual_seed(seed)
+    z = torch.randn(B, N, D, generator=gen)
+    cond = torch.cat([torch.randn(B, N, D, generator=gen), 0.7 * torch.randn(B, N, D, generator=gen)], dim=-1)
+    _, ln, pad = _mask_and_pad("chess", B, N, D, gen)
+    pad_arg = pad if seed % 2 else None
+    ldj0 = torch.randn(B, generator=gen)
+    lib = _lib.load()
+    lib.cnf_set_math_mode(mode)
+    try:
+        zo, lo = O.ext_actnorm(z, cond, channel_padding_mask=pad_arg, ldj=ldj0.clone())
+        zf, lf = ops().ext_actnorm(g(z), g(cond), channel_padding_mask=g(pad_arg), ldj=g(ldj0.clone()))
+        close(zf, zo, **ELEM); close(lf, lo, **LDJ)
+        zo2, lo2 = O.ext_actnorm(zo, cond, reverse=True, channel_padding_mask=pad_arg, ldj=lo.clone())
+        zr, lr = ops().ext_actnorm(g(zo), g(cond), reverse=True, channel_padding_mask=g(pad_arg), ldj=g(lo.clone()))
+        close(zr, zo2, rtol=1e-4, atol=1e-4); close(lr, lo2, **LDJ)
+        x = torch.randn(B, N, 1, generator=gen) * 3.0
+        so, slo = O.sigmoid_flow(x, ldj=ldj0.clone())
+        sg, slg = ops().sigmoid_flow(g(x), ldj=g(ldj0.clone()))
+        close(sg, so, rtol=1e-5, atol=1e-6); close(slg, slo, **LDJ)
+        u = torch.rand(B, N, 1, generator=gen)
+        ro, rlo = O.sigmoid_flow(u, reverse=True, ldj=ldj0.clone())
+        rg, rlg = ops().sigmoid_flow(g(u), reverse=True, ldj=g(ldj0.clone()))
+        close(rg, ro, rtol=1e-4, atol=1e-4); close(rlg, rlo, **LDJ)
+    finally:
+        lib.cnf_set_math_mode(1)
