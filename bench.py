@@ -241,7 +241,6 @@ def main():
     length = torch.full((B,), float(N), device=dev)
     sums = torch.zeros(2, dtype=torch.float64, device=dev)
     total = torch.zeros(2, dtype=torch.float64, device=dev)
-    sums_all = torch.zeros(max(args.steps, 64), 2, dtype=torch.float64, device=dev)
     EV = max(1, args.event_every)
     n_ev = (args.steps + EV - 1) // EV
     ev_a = [torch.cuda.Event(enable_timing=True) for _ in range(n_ev)]
@@ -254,22 +253,26 @@ def main():
     lfs = [torch.empty(B, device=dev) for _ in range(R)]
     lrs = [torch.empty(B, device=dev) for _ in range(R)]
     neglog, nll = torch.empty(B, device=dev), torch.empty(B, device=dev)
-    # forward coupling with the NLL assembly as its epilogue, then the single-block batch sum of nll[B]
-    fwd = [ops.affine_coupling_nll_launch(zs[r], nns[r], sf, mask, zfs[r], lfs[r], length, neglog, nll, None) for r in range(R)]
-    nsum = ops.nll_sum_launch(nll, sums)
+    # forward coupling with the NLL assembly AND the batch sum as its epilogue: every row adds its NLL in 31.32 fixed
+    # point to one of 64 int64 words with integer atomics (deterministic; cnf_affine_coupling_nll_acc).  Every step
+    # has its own 64 words; they are turned into (sum nll, count) once, in finalize().
+    acc_all = torch.zeros(max(args.steps, 64), ops.NLL_ACC_SLOTS, dtype=torch.int64, device=dev)
+    fwd = [ops.affine_coupling_nll_acc_launch(zs[r], nns[r], sf, mask, zfs[r], lfs[r], length, neglog, nll, acc_all[0])
+           for r in range(R)]
+    ACC_ARG = 13
     inv = [ops.affine_coupling_launch(zfs[r], nns[r], sf, mask, zrs[r], lrs[r], reverse=True) for r in range(R)]
+
+    steps_counted = [0]
 
     def step(i, timed=-1):
         r = i % R
         if timed >= 0:
             ev_a[timed].record()
+        fwd[r].args[ACC_ARG] = ctypes.c_void_p(acc_all.data_ptr() + 8 * ops.NLL_ACC_SLOTS * (i % acc_all.size(0)))
         fwd[r]()
         if timed >= 0:
             ev_b[timed].record()
             ev_c[timed].record()
-        # every step writes its (sum NLL, count) pair into its own slot: no per-step accumulate kernel
-        nsum.args[2] = ctypes.c_void_p(sums_all.data_ptr() + 16 * (i % sums_all.size(0)))
-        nsum()
         inv[r]()
         return zrs[r], lrs[r]
 
@@ -284,7 +287,9 @@ def main():
         step(i)
 
     def finalize():
-        total.copy_(sums_all.sum(dim=0))
+        # per-step fixed-point sums -> (sum of per-sample NLL, number of samples) of this rank, on the device
+        total[0] = (acc_all.sum(dim=1).double() / 4294967296.0).sum()
+        total[1] = float(B) * steps_counted[0]
         if world > 1:
             dist.all_reduce(total, op=dist.ReduceOp.SUM)        # the single collective of the job
 
@@ -296,7 +301,8 @@ def main():
         torch.cuda.synchronize(dev)
 
     barrier()
-    sums_all.zero_()
+    acc_all.zero_()
+    steps_counted[0] = args.steps
     t0 = time.perf_counter()
     for i in range(args.steps):
         zr, lr = step(i, timed=(i // EV if i % EV == 0 else -1))
@@ -360,7 +366,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "affine coupling fwd+logdet with NLL epilogue, inverse+logdet on z~N(0,1) [B=%d,N=%d,D=%d] per GPU, "
+            "config": {"workload": "affine coupling fwd+logdet with NLL + batch-sum epilogue, inverse+logdet on z~N(0,1) [B=%d,N=%d,D=%d] per GPU, "
                                    "nn_out~0.5N(0,1), channel mask 0.5, scaling_factor=0" % (B, N, D),
                        "batch_per_gpu": B, "seq": N, "d_latent": D, "elems_per_step_per_gpu": elems,
                        "buffer_sets_rotated": R, "parallelism": "dp%d (batch shards, one all-reduce of 2 fp64 per job)" % world},

@@ -41,6 +41,8 @@ SIGNATURES = {
     "cnf_logistic_from_uniform": [_p, _p, _i64, _f, _f, _f, _p],
     "cnf_affine_coupling_nll": [_p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _p, _p],
     "cnf_nll_sum": [_p, _i, _p, _p],
+    "cnf_affine_coupling_nll_acc": [_p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _p, _p],
+    "cnf_nll_acc_read": [_p, _i64, _d, _p, _p],
     "cnf_prior_nll": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _p],
     "cnf_encoder_forward": [_p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p, _p],
     "cnf_encoder_decode": [_p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],

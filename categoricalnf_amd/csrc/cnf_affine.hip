@@ -29,6 +29,7 @@ __device__ __forceinline__ float tanh_m(float x) {
     return 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
 }
 constexpr int kMaxTab = 64;     // (mask period) x D entries, one private copy per wave
+constexpr int kAccStride = 16;  // int64 words between two of the 64 batch-sum accumulators (128 B: one cache line each)
 
 // logistic prior log-prob (distributions.py:129-136,154-163):
 // softplus(v) + softplus(-v) = |v| + 2 log(1 + e^{-|v|}); one exp and one log instead of two each
@@ -73,6 +74,7 @@ struct AffineArgs {
     const float* length;
     float* neglog_out;
     float* nll_out;
+    long long* acc;        // optional: 64 fixed-point partial sums of nll (see cnf_affine_coupling_nll_acc)
     PriorConst prior;
 };
 
@@ -150,6 +152,11 @@ template <int VEC, int U, bool HAS_SF, bool REVERSE, bool FAST, int NLLM = 0>
 __global__ __launch_bounds__(kBlock) void affine_coupling_kernel(AffineArgs a, RowTiling tl) {
     constexpr bool NLL = NLLM != 0;
     using Acc = typename std::conditional<NLL, Sum2, float>::type;
+    __shared__ unsigned long long blk_acc;          // NLL variants: this workgroup's fixed-point sum of nll
+    if (NLL && a.acc) {
+        if (threadIdx.x == 0) blk_acc = 0ull;
+        __syncthreads();
+    }
     // per-wave strip of row partials, sized by the host to the tile (rw * cpr entries; unused when rw == 1)
     extern __shared__ __attribute__((aligned(16))) char part_raw[];
     Acc* part = reinterpret_cast<Acc*>(part_raw) + (size_t)(threadIdx.x >> 6) * (tl.rw * tl.cpr);
@@ -243,12 +250,22 @@ __global__ __launch_bounds__(kBlock) void affine_coupling_kernel(AffineArgs a, R
             const float neglog = -sum.b;
             const float len = a.length ? a.length[row] : (float)a.N;
             if (a.neglog_out) a.neglog_out[row] = neglog;
-            a.nll_out[row] = (-ldj) / len + neglog / len;
+            const float nll = (-ldj) / len + neglog / len;
+            a.nll_out[row] = nll;
+            // batch sum without a second kernel: signed 31.32 fixed point and integer adds (associative, so the result
+            // does not depend on the order the waves arrive in): rows -> workgroup word in LDS -> one global atomic
+            // per workgroup into one of 64 words that sit in 64 different cache lines
+            if (a.acc) atomicAdd(&blk_acc, (unsigned long long)__double2ll_rn((double)nll * 4294967296.0));
         } else {
             ldj_of(row, sum);
         }
     };
     walk_row_tile_split<(U == 0 ? 1 : U), Acc, AffineChunk<VEC>, U == 0>(tl, part, load, proc, finish, pre);
+    if (NLL && a.acc) {
+        __syncthreads();
+        if (threadIdx.x == 0 && blk_acc != 0ull)
+            atomicAdd(reinterpret_cast<unsigned long long*>(a.acc) + (size_t)(blockIdx.x & 63) * kAccStride, blk_acc);
+    }
     if (bad) raise_flag(a.flags, CNF_FLAG_NAN_Z);
 }
 
@@ -687,7 +704,8 @@ static int affine_coupling_impl(const char* who, const float* z, const float* nn
                                 const float* ldj_in, float* z_out, float* ldj_out,
                                 int B, int N, int D, int reverse,
                                 const float* pad, const float* length, float* neglog_out, float* nll_out,
-                                double* sums, float sigma, float log_sigma, int* flags, cnf_stream_t stream) {
+                                double* sums, float sigma, float log_sigma, int* flags, cnf_stream_t stream,
+                                long long* acc = nullptr) {
     CNF_REQUIRE(z && nn_out && z_out && ldj_out, "%s: null tensor", who);
     CNF_REQUIRE(B >= 0 && N > 0 && D > 0, "%s: bad shape B=%d N=%d D=%d", who, B, N, D);
     if (B == 0) return CNF_OK;
@@ -704,7 +722,7 @@ static int affine_coupling_impl(const char* who, const float* z, const float* nn
     a.div_d = make_fastdiv((uint32_t)D);
     a.P = mask_rows * D;
     a.div_p = make_fastdiv((uint32_t)a.P);
-    a.pad = pad; a.length = length; a.neglog_out = neglog_out; a.nll_out = nll_out;
+    a.pad = pad; a.length = length; a.neglog_out = neglog_out; a.nll_out = nll_out; a.acc = acc;
     a.prior = make_prior_const(sigma, log_sigma);
     const RowTiling tl = make_row_tiling(B, a.L, 0, tile_chunks_target());
     DISPATCH_VEC(tl, launch_affine<V>(a, tl, scaling_factor != nullptr, reverse != 0, (hipStream_t)stream));
@@ -732,6 +750,37 @@ int cnf_affine_coupling_nll(const float* z, const float* nn_out, const float* sc
     return affine_coupling_impl("cnf_affine_coupling_nll", z, nn_out, scaling_factor, mask, mask_rows, mask_cols,
                                 ldj_in, z_out, ldj_out, B, N, D, 0, pad, length, neglog_out, nll_out, sums,
                                 sigma, log_sigma, flags, stream);
+}
+
+int cnf_affine_coupling_nll_acc(const float* z, const float* nn_out, const float* scaling_factor,
+                                const float* mask, int mask_rows, int mask_cols,
+                                const float* ldj_in, float* z_out, float* ldj_out,
+                                const float* pad, const float* length,
+                                float* neglog_out, float* nll_out, int64_t* acc,
+                                int B, int N, int D, float sigma, float log_sigma,
+                                int* flags, cnf_stream_t stream) {
+    CNF_REQUIRE(nll_out && acc, "cnf_affine_coupling_nll_acc: nll_out and acc are required");
+    return affine_coupling_impl("cnf_affine_coupling_nll_acc", z, nn_out, scaling_factor, mask, mask_rows, mask_cols,
+                                ldj_in, z_out, ldj_out, B, N, D, 0, pad, length, neglog_out, nll_out, nullptr,
+                                sigma, log_sigma, flags, stream, reinterpret_cast<long long*>(acc));
+}
+
+__global__ void nll_acc_read_kernel(const long long* acc, long n, double count, double* sums) {
+    // n <= a few thousand slots: one wave, fixed order
+    double t = 0.0;
+    for (long i = threadIdx.x; i < n; i += 64) t += (double)acc[i] * (1.0 / 4294967296.0);       // unused padding words are 0
+    t = cnf::wave_sum(t);
+    if (threadIdx.x == 0) {
+        sums[0] = t;
+        sums[1] = count;
+    }
+}
+
+int cnf_nll_acc_read(const int64_t* acc, int64_t n_slots, double count, double* sums, cnf_stream_t stream) {
+    CNF_REQUIRE(acc && sums && n_slots > 0, "cnf_nll_acc_read: bad argument");
+    hipLaunchKernelGGL(nll_acc_read_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream,
+                       reinterpret_cast<const long long*>(acc), (long)n_slots, count, sums);
+    return launch_status("cnf_nll_acc_read");
 }
 
 int cnf_affine_params(const float* nn_out, const float* scaling_factor,

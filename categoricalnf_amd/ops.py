@@ -183,7 +183,7 @@ def affine_coupling(z, nn_out, scaling_factor, mask, reverse=False, ldj=None):
 
 
 def affine_coupling_nll(z, nn_out, scaling_factor, mask, ldj=None, length=None, channel_padding_mask=None, sums=None,
-                        sigma=LOGISTIC_SIGMA, log_sigma=LOGISTIC_LOG_SIGMA):
+                        sigma=LOGISTIC_SIGMA, log_sigma=LOGISTIC_LOG_SIGMA, acc=None):
     """Last coupling layer + NLL assembly in one kernel: == affine_coupling(reverse=False) then prior_nll on its
     outputs.  Returns (z_out, ldj_out, neglog [B], nll [B])."""
     z = _f32(z, "z")
@@ -200,10 +200,19 @@ def affine_coupling_nll(z, nn_out, scaling_factor, mask, ldj=None, length=None, 
     z_out = torch.empty_like(z)
     neglog = torch.empty(B, dtype=torch.float32, device=dev)
     nll = torch.empty(B, dtype=torch.float32, device=dev)
-    _launch(dev, "cnf_affine_coupling_nll", _ptr(z), _ptr(nn_out), _ptr(sf), _ptr(m), mr, mc, _ptr(ldj_in),
-                                           _ptr(z_out), _ptr(ldj_out), _ptr(pad), _ptr(ln), _ptr(neglog), _ptr(nll),
-                                           _ptr(sums), B, N, D, float(sigma), float(log_sigma),
-                                           _ptr(flag_word(dev)), _stream(dev))
+    if acc is not None:
+        # batch sum inside the kernel (int64 [64] fixed-point partials, accumulated; read with nll_acc_read)
+        if acc.dtype != torch.int64 or acc.numel() < NLL_ACC_SLOTS or not acc.is_contiguous() or sums is not None:
+            raise ValueError("acc must be a contiguous int64 tensor with at least %d elements (and excludes `sums`)" % NLL_ACC_SLOTS)
+        _launch(dev, "cnf_affine_coupling_nll_acc", _ptr(z), _ptr(nn_out), _ptr(sf), _ptr(m), mr, mc, _ptr(ldj_in),
+                                                   _ptr(z_out), _ptr(ldj_out), _ptr(pad), _ptr(ln), _ptr(neglog), _ptr(nll),
+                                                   _ptr(acc), B, N, D, float(sigma), float(log_sigma),
+                                                   _ptr(flag_word(dev)), _stream(dev))
+    else:
+        _launch(dev, "cnf_affine_coupling_nll", _ptr(z), _ptr(nn_out), _ptr(sf), _ptr(m), mr, mc, _ptr(ldj_in),
+                                               _ptr(z_out), _ptr(ldj_out), _ptr(pad), _ptr(ln), _ptr(neglog), _ptr(nll),
+                                               _ptr(sums), B, N, D, float(sigma), float(log_sigma),
+                                               _ptr(flag_word(dev)), _stream(dev))
     _after(dev, "affine coupling + NLL")
     return z_out, ldj_out, neglog, nll
 
@@ -556,6 +565,37 @@ def affine_coupling_nll_launch(z, nn_out, scaling_factor, mask, z_out, ldj_out, 
             _ptr(neglog), _ptr(nll), _ptr(sums), B, N, D, float(sigma), float(log_sigma), _ptr(flag_word(dev)), None]
     return Launch("cnf_affine_coupling_nll", lib.cnf_affine_coupling_nll, args, dev,
                   (z, nn_out, sf, m, ldj, z_out, ldj_out, pad, ln, neglog, nll, sums))
+
+
+NLL_ACC_SLOTS = 1024          # int64 words of one accumulator (64 used, one per 128-byte line)
+
+
+def affine_coupling_nll_acc_launch(z, nn_out, scaling_factor, mask, z_out, ldj_out, length, neglog, nll, acc, ldj=None,
+                                   channel_padding_mask=None, sigma=LOGISTIC_SIGMA, log_sigma=LOGISTIC_LOG_SIGMA):
+    """Pre-bound cnf_affine_coupling_nll_acc: the batch sum is accumulated inside the kernel into `acc` (int64 [64])."""
+    z, nn_out = _f32(z, "z"), _f32(nn_out, "nn_out")
+    dev = z.device
+    B, N, D = z.shape
+    if acc.dtype != torch.int64 or acc.numel() < NLL_ACC_SLOTS or not acc.is_contiguous():
+        raise ValueError("acc must be a contiguous int64 tensor with at least %d elements" % NLL_ACC_SLOTS)
+    sf = _opt_f32(scaling_factor, "scaling_factor", dev)
+    m, mr, mc = _mask_desc(mask, D, dev)
+    pad = _pad2d(channel_padding_mask, B, N, dev)
+    ln = _length(length, B, dev)
+    lib = _lib.load()
+    args = [_ptr(z), _ptr(nn_out), _ptr(sf), _ptr(m), mr, mc, _ptr(ldj), _ptr(z_out), _ptr(ldj_out), _ptr(pad), _ptr(ln),
+            _ptr(neglog), _ptr(nll), _ptr(acc), B, N, D, float(sigma), float(log_sigma), _ptr(flag_word(dev)), None]
+    return Launch("cnf_affine_coupling_nll_acc", lib.cnf_affine_coupling_nll_acc, args, dev,
+                  (z, nn_out, sf, m, ldj, z_out, ldj_out, pad, ln, neglog, nll, acc))
+
+
+def nll_acc_read(acc, count, sums=None):
+    """(sum, count) in fp64 from the fixed-point partial sums that cnf_affine_coupling_nll_acc accumulated."""
+    dev = acc.device
+    if sums is None:
+        sums = torch.empty(2, dtype=torch.float64, device=dev)
+    _launch(dev, "cnf_nll_acc_read", _ptr(acc), int(acc.numel()), float(count), _ptr(sums), _stream(dev))
+    return sums
 
 
 def nll_sum_launch(nll, sums):

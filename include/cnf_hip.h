@@ -212,6 +212,22 @@ int cnf_affine_coupling_nll(const float* z, const float* nn_out, const float* sc
                             int B, int N, int D, float sigma, float log_sigma,
                             int* flags, cnf_stream_t stream);
 
+/* The same with the batch sum taken INSIDE the kernel: the rows of a workgroup add nll[b] * 2^32 (rounded, signed
+ * 64-bit fixed point) into an LDS word and the workgroup adds that to one of 64 global words with ONE integer atomic —
+ * integer adds are associative, so the sum is deterministic; the 64 words sit 128 bytes apart (one cache line each) so
+ * that the atomics hide behind the streaming.  `acc` = CNF_NLL_ACC_WORDS int64 (only every 16th is used), zeroed by
+ * the caller; it may be accumulated over several calls (|sum| < 2^31).  cnf_nll_acc_read turns n such words into
+ * sums = {sum / 2^32, count}. */
+#define CNF_NLL_ACC_WORDS 1024
+int cnf_affine_coupling_nll_acc(const float* z, const float* nn_out, const float* scaling_factor,
+                                const float* mask, int mask_rows, int mask_cols,
+                                const float* ldj_in, float* z_out, float* ldj_out,
+                                const float* pad, const float* length,
+                                float* neglog_out, float* nll_out, int64_t* acc,
+                                int B, int N, int D, float sigma, float log_sigma,
+                                int* flags, cnf_stream_t stream);
+int cnf_nll_acc_read(const int64_t* acc, int64_t n_words, double count, double* sums, cnf_stream_t stream);
+
 /* ---- mixture-model categorical encoder --------------------------------------------------------- */
 
 /* LinearCategoricalEncoding.forward, num_flows == 0 (linear_encoding.py:59-106,120-133,153-174).

@@ -400,6 +400,16 @@ def test_affine_coupling_nll_fused_vs_oracle_and_split(B, N, D, kind, has_sf):
     assert torch.equal(zf, z2) and torch.equal(lf, l2)
     close(neglog, neglog2.cpu(), rtol=2e-6, atol=1e-4); close(nll, nll2.cpu(), rtol=2e-6, atol=2e-5)
     assert sums[1].item() == B and abs(sums[0].item() - nll.double().sum().item()) < 1e-6 * max(1.0, abs(sums[0].item()))
+    # batch sum inside the kernel: fixed-point integer atomics -> exact to 2^-32 per row and bit-reproducible
+    acc1 = torch.zeros(ops().NLL_ACC_SLOTS, dtype=torch.int64, device="cuda")
+    acc2 = torch.zeros(ops().NLL_ACC_SLOTS, dtype=torch.int64, device="cuda")
+    for acc in (acc1, acc2):
+        za, la, _, na = ops().affine_coupling_nll(g(z), g(nn_out), g(sf), g(mask), ldj=g(ldj0), length=g(ln),
+                                                  channel_padding_mask=g(pad), acc=acc)
+    assert torch.equal(acc1, acc2) and torch.equal(za, zf) and torch.equal(na, nll)
+    s_acc = ops().nll_acc_read(acc1, B)
+    want = nll.double().sum().item()
+    assert s_acc[1].item() == B and abs(s_acc[0].item() - want) <= B * 2.0 ** -32 + 1e-12 * abs(want)
     # without padding / length (defaults: every token counts, length = N)
     zf, lf, neglog, nll = ops().affine_coupling_nll(g(z), g(nn_out), g(sf), g(mask))
     zo, lo = O.affine_coupling(z, nn_out, mask, scaling_factor=sf)
