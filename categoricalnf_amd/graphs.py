@@ -107,7 +107,7 @@ class GraphedTrainStep:
         # made long runs go wrong on this stack, so nothing but the input copies happens between replays
         self.lr_decay, self.lr_minimum = float(lr_decay), float(lr_minimum)
         self.loss_sum = torch.zeros((), dtype=torch.float32, device=self.device)
-        self.max_in_flight = int(__import__("os").environ.get("CNF_GRAPH_IN_FLIGHT", "4"))
+        self.max_in_flight = 4
         self._in_flight = []
         # encoder noise: drawn OUTSIDE the graph into a static buffer before every replay and handed to the model as
         # `noise=` (one small eager kernel per step).  Drawing it inside the capture relies on the generator's
