@@ -152,11 +152,7 @@ template <int VEC, int U, bool HAS_SF, bool REVERSE, bool FAST, int NLLM = 0>
 __global__ __launch_bounds__(kBlock) void affine_coupling_kernel(AffineArgs a, RowTiling tl) {
     constexpr bool NLL = NLLM != 0;
     using Acc = typename std::conditional<NLL, Sum2, float>::type;
-    __shared__ unsigned long long blk_acc;          // NLL variants: this workgroup's fixed-point sum of nll
-    if (NLL && a.acc) {
-        if (threadIdx.x == 0) blk_acc = 0ull;
-        __syncthreads();
-    }
+
     // per-wave strip of row partials, sized by the host to the tile (rw * cpr entries; unused when rw == 1)
     extern __shared__ __attribute__((aligned(16))) char part_raw[];
     Acc* part = reinterpret_cast<Acc*>(part_raw) + (size_t)(threadIdx.x >> 6) * (tl.rw * tl.cpr);
@@ -252,20 +248,18 @@ __global__ __launch_bounds__(kBlock) void affine_coupling_kernel(AffineArgs a, R
             if (a.neglog_out) a.neglog_out[row] = neglog;
             const float nll = (-ldj) / len + neglog / len;
             a.nll_out[row] = nll;
-            // batch sum without a second kernel: signed 31.32 fixed point and integer adds (associative, so the result
-            // does not depend on the order the waves arrive in): rows -> workgroup word in LDS -> one global atomic
-            // per workgroup into one of 64 words that sit in 64 different cache lines
-            if (a.acc) atomicAdd(&blk_acc, (unsigned long long)__double2ll_rn((double)nll * 4294967296.0));
+            // batch sum without a second kernel: signed 31.32 fixed point and integer atomics (associative, so the
+            // result does not depend on the order the rows arrive in) into one of 64 words that sit in 64 different
+            // cache lines: 256 atomics per line for B = 16384, hidden behind the streaming (64 ADJACENT words, i.e.
+            // four lines, serialised them: 55 us per launch)
+            if (a.acc)
+                atomicAdd(reinterpret_cast<unsigned long long*>(a.acc) + (size_t)(row & 63) * kAccStride,
+                          (unsigned long long)__double2ll_rn((double)nll * 4294967296.0));
         } else {
             ldj_of(row, sum);
         }
     };
     walk_row_tile_split<(U == 0 ? 1 : U), Acc, AffineChunk<VEC>, U == 0>(tl, part, load, proc, finish, pre);
-    if (NLL && a.acc) {
-        __syncthreads();
-        if (threadIdx.x == 0 && blk_acc != 0ull)
-            atomicAdd(reinterpret_cast<unsigned long long*>(a.acc) + (size_t)(blockIdx.x & 63) * kAccStride, blk_acc);
-    }
     if (bad) raise_flag(a.flags, CNF_FLAG_NAN_Z);
 }
 

@@ -212,12 +212,11 @@ int cnf_affine_coupling_nll(const float* z, const float* nn_out, const float* sc
                             int B, int N, int D, float sigma, float log_sigma,
                             int* flags, cnf_stream_t stream);
 
-/* The same with the batch sum taken INSIDE the kernel: the rows of a workgroup add nll[b] * 2^32 (rounded, signed
- * 64-bit fixed point) into an LDS word and the workgroup adds that to one of 64 global words with ONE integer atomic —
- * integer adds are associative, so the sum is deterministic; the 64 words sit 128 bytes apart (one cache line each) so
- * that the atomics hide behind the streaming.  `acc` = CNF_NLL_ACC_WORDS int64 (only every 16th is used), zeroed by
- * the caller; it may be accumulated over several calls (|sum| < 2^31).  cnf_nll_acc_read turns n such words into
- * sums = {sum / 2^32, count}. */
+/* The same with the batch sum taken INSIDE the kernel: every row adds nll[b] * 2^32 (rounded, signed 64-bit fixed point)
+ * with one integer atomic to one of 64 words — integer adds are associative, so the sum is deterministic; the 64
+ * words sit 128 bytes apart (one cache line each) so that the atomics hide behind the streaming.  `acc` =
+ * CNF_NLL_ACC_WORDS int64 (only every 16th is used), zeroed by the caller; it may be accumulated over several calls
+ * (|sum| < 2^31).  cnf_nll_acc_read turns n such words into sums = {sum / 2^32, count}. */
 #define CNF_NLL_ACC_WORDS 1024
 int cnf_affine_coupling_nll_acc(const float* z, const float* nn_out, const float* scaling_factor,
                                 const float* mask, int mask_rows, int mask_cols,
