@@ -335,3 +335,12 @@ def test_checkpoint_files_follow_the_reference_format(tmp_path):
     other = torch.nn.Linear(3, 2)
     extra = load_checkpoint(str(tmp_path), other)                               # directory -> newest file
     assert torch.equal(other.weight, net.weight) and extra["iteration"] == 1234 and extra["evaluation_dict"] == {1000: 3.1}
+
+
+def test_every_c_entry_point_is_documented_for_integrators():
+    """include/cnf_hip.h and INTEGRATION.md stay in step: every exported function appears in the binding table."""
+    import re
+    names = set(re.findall(r"\b(cnf_[a-z0-9_]+)\s*\(", open(os.path.join(ROOT, "include", "cnf_hip.h")).read()))
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    missing = sorted(n for n in names if n not in doc)
+    assert not missing, missing
