@@ -3,23 +3,23 @@
 coupling over one synthetic [B, N, D] batch per step (BASELINE.json metric "coupling fwd+inv+logdet
 elems/s"; workload = the north-star shape B=16384, N=64, d_latent=6).
 
-    python bench.py --gpus 1 --steps 200 --warmup 20
+    python bench.py --gpus N --steps K --warmup W        (N > 1 without a torchrun environment: starts the N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
 One step on every rank (weak scaling: each rank owns its own B samples, no data-path collective):
-    1. cnf_affine_coupling   forward  z -> z', ldj            (16 B/elem)
-    2. cnf_prior_nll         z', ldj -> per-sample NLL, (sum, count)   (4 B/elem)
-    3. cnf_affine_coupling   inverse  z' -> z, -ldj           (16 B/elem)
-    4. the per-batch (sum NLL, count) pair is added to a running device total; after the last step ONE all-reduce
-       of that pair over RCCL gives every rank the mean NLL / bits-per-dim of the whole job (the reference's eval
-       loop also averages once after its batch loop, general/task.py:118-139).
+    1. cnf_affine_coupling_nll_acc   forward  z -> z', ldj, per-sample NLL, fixed-point batch sum   (16 B/elem)
+    2. cnf_affine_coupling           inverse  z' -> z, -ldj                                          (16 B/elem)
+After the last step ONE launch of cnf_nll_acc_read turns the fixed-point sums into (sum NLL, count) and ONE
+all-reduce of that pair over RCCL gives every rank the mean NLL / bits-per-dim of the whole job (the reference's eval
+loop also averages once after its batch loop, general/task.py:118-139).
 `value` = B*N*D elements pushed through forward+inverse(+log-det) per second, summed over ranks, with
 all inputs resident in HBM.  Prints ONE JSON line on rank 0.
 
 The CPU baseline (`cpu_baseline`, kind "port") times the oracle's torch-CPU restatement of the same
 step on the host cores; it is a reported baseline, never the target.  `roofline` prices the
-dominant kernel (affine forward) by its algorithmic bytes against the 8 TB/s HBM3E peak.
+dominant kernel (affine forward) by its algorithmic bytes against the 8 TB/s HBM3E peak; the kernel's
+duration comes from HIP event pairs bound to forward launches INSIDE the timed region (cnf_prof_arm).
 """
 import argparse
 import ctypes
@@ -57,8 +57,7 @@ def parse():
     p.add_argument("--share-device", action="store_true",
                    help="TEST ONLY: all ranks use cuda:0 (exercise the multi-rank path on a 1-GPU box, with --backend gloo)")
     p.add_argument("--event-every", type=int, default=8,
-                   help="bracket the forward kernel of every n-th timed step with a HIP event pair (each marker costs ~2 us "
-                        "of queue time, so bracketing every step would slow the measured path by ~10%%)")
+                   help="the forward launch of every n-th timed step carries a dispatch-bound HIP event pair (cnf_prof_arm)")
     p.add_argument("--rotate", type=int, default=4, help="buffer sets rotated through (defeats the 256 MB Infinity Cache)")
     return p.parse_args()
 
@@ -206,8 +205,43 @@ def mixture_measure(ops, dev, R=4, reps=50):
             "inv_hbm_frac": bytes_alg / (ti * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
 
+def kernel_sources_sha():
+    """sha256 over the kernel sources; profiles/traffic.json carries the same stamp (tools/pmc_summarize.py) and its
+    numbers are only reported while the sources they were measured on are the ones that are built."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "categoricalnf_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a torchrun environment: start the N ranks ourselves (one process per GPU,
+    the same command line the driver would use) and hand their exit code back."""
+    import socket
+    import subprocess
+    if not args.share_device:
+        n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if n_dev < args.gpus:
+            raise SystemExit("bench.py --gpus %d: only %d HIP device(s) visible" % (args.gpus, n_dev))
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     from categoricalnf_amd import _lib, ops
     if os.environ.get("CNF_LIB_OVERRIDE"):          # A/B of alternative builds of the same ABI (tools only)
         _lib.LIB_PATH = os.environ["CNF_LIB_OVERRIDE"]
@@ -218,8 +252,12 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no CUDA(HIP) device visible")
     rank, local_rank, world = init_process_group(args.backend if not args.share_device else "gloo")
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if world > 1 and dist.get_world_size() != args.gpus:
+        raise SystemExit("process group has %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
+    if world > 1 and not args.share_device and torch.cuda.device_count() < world:
+        raise SystemExit("--gpus %d but only %d HIP device(s) visible" % (world, torch.cuda.device_count()))
     dev = torch.device("cuda", local_rank if (world > 1 and not args.share_device) else 0)
     torch.cuda.set_device(dev)
     lib = _lib.load()
@@ -239,13 +277,8 @@ def main():
     sf = torch.zeros(D, device=dev)
     mask = channel_mask(D).to(dev)
     length = torch.full((B,), float(N), device=dev)
-    sums = torch.zeros(2, dtype=torch.float64, device=dev)
     total = torch.zeros(2, dtype=torch.float64, device=dev)
     EV = max(1, args.event_every)
-    n_ev = (args.steps + EV - 1) // EV
-    ev_a = [torch.cuda.Event(enable_timing=True) for _ in range(n_ev)]
-    ev_b = [torch.cuda.Event(enable_timing=True) for _ in range(n_ev)]
-    ev_c = [torch.cuda.Event(enable_timing=True) for _ in range(n_ev)]   # empty pair: event overhead
 
     # outputs and pre-bound launches per buffer set (host cost per launch ~2 us)
     zfs = [torch.empty_like(zs[0]) for _ in range(R)]
@@ -254,25 +287,25 @@ def main():
     lrs = [torch.empty(B, device=dev) for _ in range(R)]
     neglog, nll = torch.empty(B, device=dev), torch.empty(B, device=dev)
     # forward coupling with the NLL assembly AND the batch sum as its epilogue: every row adds its NLL in 31.32 fixed
-    # point to one of 64 int64 words with integer atomics (deterministic; cnf_affine_coupling_nll_acc).  Every step
-    # has its own 64 words; they are turned into (sum nll, count) once, in finalize().
-    acc_all = torch.zeros(max(args.steps, 64), ops.NLL_ACC_SLOTS, dtype=torch.int64, device=dev)
+    # point to one of 64 int64 words with integer atomics (deterministic; cnf_affine_coupling_nll_acc).  The steps
+    # rotate over ACC_SETS accumulators (a word then holds < 2^31 after ~10^6 steps at this shape); ONE launch of
+    # cnf_nll_acc_read turns them into (sum nll, count) in finalize().
+    ACC_SETS = 16
+    acc_all = torch.zeros(ACC_SETS, ops.NLL_ACC_SLOTS, dtype=torch.int64, device=dev)
     fwd = [ops.affine_coupling_nll_acc_launch(zs[r], nns[r], sf, mask, zfs[r], lfs[r], length, neglog, nll, acc_all[0])
            for r in range(R)]
     ACC_ARG = 13
+    acc_ptrs = [ctypes.c_void_p(acc_all.data_ptr() + 8 * ops.NLL_ACC_SLOTS * k) for k in range(ACC_SETS)]
     inv = [ops.affine_coupling_launch(zfs[r], nns[r], sf, mask, zrs[r], lrs[r], reverse=True) for r in range(R)]
 
     steps_counted = [0]
 
-    def step(i, timed=-1):
+    def step(i, timed=False):
         r = i % R
-        if timed >= 0:
-            ev_a[timed].record()
-        fwd[r].args[ACC_ARG] = ctypes.c_void_p(acc_all.data_ptr() + 8 * ops.NLL_ACC_SLOTS * (i % acc_all.size(0)))
+        fwd[r].args[ACC_ARG] = acc_ptrs[i % ACC_SETS]
+        if timed:
+            lib.cnf_prof_arm(1)          # this forward launch carries its own start/stop timestamps (no marker packets)
         fwd[r]()
-        if timed >= 0:
-            ev_b[timed].record()
-            ev_c[timed].record()
         inv[r]()
         return zrs[r], lrs[r]
 
@@ -284,35 +317,56 @@ def main():
             step(i)
         torch.cuda.synchronize(dev)
     for i in range(args.warmup):
-        step(i)
+        step(i, timed=(i == 0))
+    lib.cnf_prof_collect(None, 0)
 
     def finalize():
-        # per-step fixed-point sums -> (sum of per-sample NLL, number of samples) of this rank, on the device
-        total[0] = (acc_all.sum(dim=1).double() / 4294967296.0).sum()
-        total[1] = float(B) * steps_counted[0]
+        # fixed-point sums -> (sum of per-sample NLL, number of samples) of this rank: one launch, then the job's
+        # single collective
+        ops.nll_acc_read(acc_all, float(B) * steps_counted[0], sums=total)
         if world > 1:
-            dist.all_reduce(total, op=dist.ReduceOp.SUM)        # the single collective of the job
+            dist.all_reduce(total, op=dist.ReduceOp.SUM)
 
-    finalize()          # untimed: first-call costs of the reduction op and of the RCCL communicator
+    finalize()          # untimed: first-call costs of the read kernel and of the RCCL communicator
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    ev_loop = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     barrier()
     acc_all.zero_()
     steps_counted[0] = args.steps
+    torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
+    ev_loop[0].record()
     for i in range(args.steps):
-        zr, lr = step(i, timed=(i // EV if i % EV == 0 else -1))
+        zr, lr = step(i, timed=(i % EV == 0))
+    ev_loop[1].record()
     finalize()
     barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed_rank = time.perf_counter() - t0
+    elapsed = elapsed_rank
+    per_rank = [elapsed_rank]
+    allreduce_us = None
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        t = torch.tensor([elapsed_rank], dtype=torch.float64, device=dev)
+        gathered = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(gathered, t)
+        per_rank = [float(x.item()) for x in gathered]
+        elapsed = max(per_rank)
+        # latency of the job's one collective (2 fp64), measured after the timed region
+        probe = torch.zeros(2, dtype=torch.float64, device=dev)
+        for _ in range(5):
+            dist.all_reduce(probe)
+        torch.cuda.synchronize(dev)
+        ta = time.perf_counter()
+        for _ in range(20):
+            dist.all_reduce(probe)
+        torch.cuda.synchronize(dev)
+        allreduce_us = (time.perf_counter() - ta) / 20 * 1e6
+    gpu_loop_ms = ev_loop[0].elapsed_time(ev_loop[1])
     ops.check_flags(dev, "bench")
     r_last = (args.steps - 1) % R
     err = (zrs[r_last] - zs[r_last]).abs().max().item()
@@ -320,16 +374,17 @@ def main():
     assert torch.equal(lfs[r_last], -lrs[r_last]), "ldj_fwd + ldj_inv != 0"
     mean_nll = float(total[0].item() / max(total[1].item(), 1.0))
 
-    # Duration of the dominant kernel (affine forward), with HIP events on the launch stream:
-    #  (1) inside the timed region the forward launch of every EV-th step is bracketed by an event pair (raw_ms;
-    #      it carries the record-to-record latency of two markers, ovh_ms is that latency for an empty pair);
-    #  (2) `kern_ms`, the figure the roofline uses, is the steady-state mean over back-to-back forward launches
-    #      on the same rotating buffer sets: one uninterrupted stream of 6 x 200 launches with an
-    #      event between the blocks, the first block discarded (the GPU clocks down during the host-side
-    #      bookkeeping above and takes ~1 ms of load to ramp back), median of the other five.  Start-to-start
-    #      time: it contains the inter-kernel boundary, so it is not below rocprofv3's kernel-only average.
-    raw_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev_a, ev_b)]))
-    ovh_ms = float(np.mean([b.elapsed_time(c) for b, c in zip(ev_b, ev_c)]))
+    # Duration of the dominant kernel (affine forward + NLL epilogue):
+    #  (1) `kern_ms`, the figure the roofline uses: inside the timed region the forward launch of every EV-th step
+    #      went out through hipExtLaunchKernelGGL with an event pair bound to ITS dispatch packet (cnf_prof_arm), so
+    #      the pair's elapsed time is the kernel's own start-to-end time on the launch stream — the quantity
+    #      rocprofv3 --kernel-trace reports — and no marker packets perturb the queue;
+    #  (2) `steady_ms`, a cross-check: start-to-start time of back-to-back forward launches after the timed region
+    #      (6 x 200 launches, first block discarded); it contains the inter-kernel boundary.
+    n_ev = (args.steps + EV - 1) // EV
+    buf = (ctypes.c_float * n_ev)()
+    got = lib.cnf_prof_collect(buf, n_ev)
+    in_step = [buf[i] for i in range(got) if buf[i] > 0]
     reps, blocks = 200, 6
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(blocks + 1)]
     marks[0].record()
@@ -339,18 +394,26 @@ def main():
         marks[k + 1].record()
     torch.cuda.synchronize(dev)
     rounds = [marks[k].elapsed_time(marks[k + 1]) / reps for k in range(1, blocks)]
-    kern_ms = float(np.median(rounds))
+    steady_ms = float(np.median(rounds))
+    kern_ms = float(np.mean(in_step)) if in_step else steady_ms
     alg_bytes = 16.0 * elems + 4.0 * B            # z 4 + (s,t) 8 + z' 4 per elem, + ldj per sample
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-    traffic = None
+    traffic, traffic_note = None, "profiles/traffic.json absent"
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
             # HBM bytes per launch from the rocprofv3 --pmc passes (FETCH_SIZE x2 per the gfx950 correction,
-            # WRITE_SIZE x1, both calibrated on a known-size copy; tools/pmc_summarize.py)
-            traffic = json.load(open(tpath)).get("affine_coupling_fwd_bytes_per_launch")
-        except Exception:
-            traffic = None
+            # WRITE_SIZE x1, both calibrated on a known-size copy; tools/pmc_summarize.py), valid only for the
+            # kernel sources they were collected on
+            tj = json.load(open(tpath))
+            if tj.get("kernel_sources_sha") == kernel_sources_sha():
+                traffic = tj.get("affine_coupling_fwd_bytes_per_launch")
+                traffic_note = "rocprofv3 --pmc passes of tools/pmc_workload.py on these kernel sources (sha %s)" % tj["kernel_sources_sha"]
+            else:
+                traffic_note = "profiles/traffic.json was collected on other kernel sources (%s != %s): not reported" % (
+                    tj.get("kernel_sources_sha"), kernel_sources_sha())
+        except Exception as e:
+            traffic_note = "profiles/traffic.json unreadable: %s" % e
 
     if rank == 0:
         out = {
@@ -371,9 +434,16 @@ def main():
                        "batch_per_gpu": B, "seq": N, "d_latent": D, "elems_per_step_per_gpu": elems,
                        "buffer_sets_rotated": R, "parallelism": "dp%d (batch shards, one all-reduce of 2 fp64 per job)" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "affine_coupling_kernel<VEC=4,fwd,NLL>", "kernel_ms": kern_ms, "in_step_event_pair_ms": raw_ms, "empty_event_pair_ms": ovh_ms,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
+                         "frac_of_achievable_6300": achieved / 6300.0,
+                         "kernel": "affine_coupling_kernel<VEC=4,fwd,NLL>", "kernel_ms": kern_ms,
+                         "kernel_ms_source": "dispatch-bound HIP event pairs on %d forward launches inside the timed region" % len(in_step)
+                                             if in_step else "steady-state stream after the timed region (no in-step samples)",
+                         "steady_state_start_to_start_ms": steady_ms,
                          "algorithmic_bytes_per_launch": alg_bytes},
+            "gpu_ms_per_step": gpu_loop_ms / args.steps,
+            "per_rank_elems_per_s": [elems * args.steps / t for t in per_rank],
+            "allreduce_latency_us": allreduce_us,
             "mean_nll": mean_nll,
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -384,6 +454,7 @@ def main():
                 out["extra"]["mixture"].update(mixture_cpu_baseline())
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -66,7 +66,8 @@ SIGNATURES = {
 _PLAIN = {"cnf_abi_version": ([], _i), "cnf_last_error": ([], ctypes.c_char_p),
           "cnf_set_tile_chunks": ([_i], None), "cnf_set_unroll": ([_i], None),
           "cnf_set_math_mode": ([_i], None), "cnf_set_inverse_mode": ([_i], None), "cnf_set_mixture_tile": ([_i], None),
-          "cnf_bwd_workspace_floats": ([_i], _i64)}
+          "cnf_bwd_workspace_floats": ([_i], _i64),
+          "cnf_prof_arm": ([_i], _i), "cnf_prof_collect": ([ctypes.POINTER(ctypes.c_float), _i], _i)}
 
 _lib = None
 

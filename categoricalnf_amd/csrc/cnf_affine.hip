@@ -272,21 +272,21 @@ static void launch_affine_u(const AffineArgs& a, const RowTiling& tl, bool has_s
         const size_t lds = kWavesPerBlock * strip * sizeof(Sum2);
         constexpr int UN = (U == 1) ? 1 : 2;      // the epilogue variants are built for 1 and 2 chunks in flight only
         if (a.pad) {
-            if (has_sf) hipLaunchKernelGGL((affine_coupling_kernel<VEC, UN, true, false, FAST, 2>), grid, block, lds, st, a, tl);
-            else hipLaunchKernelGGL((affine_coupling_kernel<VEC, UN, false, false, FAST, 2>), grid, block, lds, st, a, tl);
+            if (has_sf) CNF_LAUNCH((affine_coupling_kernel<VEC, UN, true, false, FAST, 2>), grid, block, lds, st, a, tl);
+            else CNF_LAUNCH((affine_coupling_kernel<VEC, UN, false, false, FAST, 2>), grid, block, lds, st, a, tl);
         } else {
-            if (has_sf) hipLaunchKernelGGL((affine_coupling_kernel<VEC, UN, true, false, FAST, 1>), grid, block, lds, st, a, tl);
-            else hipLaunchKernelGGL((affine_coupling_kernel<VEC, UN, false, false, FAST, 1>), grid, block, lds, st, a, tl);
+            if (has_sf) CNF_LAUNCH((affine_coupling_kernel<VEC, UN, true, false, FAST, 1>), grid, block, lds, st, a, tl);
+            else CNF_LAUNCH((affine_coupling_kernel<VEC, UN, false, false, FAST, 1>), grid, block, lds, st, a, tl);
         }
         return;
     }
     const size_t lds = kWavesPerBlock * strip * sizeof(float);
     if (has_sf) {
-        if (reverse) hipLaunchKernelGGL((affine_coupling_kernel<VEC, U, true, true, FAST>), grid, block, lds, st, a, tl);
-        else hipLaunchKernelGGL((affine_coupling_kernel<VEC, U, true, false, FAST>), grid, block, lds, st, a, tl);
+        if (reverse) CNF_LAUNCH((affine_coupling_kernel<VEC, U, true, true, FAST>), grid, block, lds, st, a, tl);
+        else CNF_LAUNCH((affine_coupling_kernel<VEC, U, true, false, FAST>), grid, block, lds, st, a, tl);
     } else {
-        if (reverse) hipLaunchKernelGGL((affine_coupling_kernel<VEC, U, false, true, FAST>), grid, block, lds, st, a, tl);
-        else hipLaunchKernelGGL((affine_coupling_kernel<VEC, U, false, false, FAST>), grid, block, lds, st, a, tl);
+        if (reverse) CNF_LAUNCH((affine_coupling_kernel<VEC, U, false, true, FAST>), grid, block, lds, st, a, tl);
+        else CNF_LAUNCH((affine_coupling_kernel<VEC, U, false, false, FAST>), grid, block, lds, st, a, tl);
     }
 }
 
@@ -720,7 +720,7 @@ static int affine_coupling_impl(const char* who, const float* z, const float* nn
     a.prior = make_prior_const(sigma, log_sigma);
     const RowTiling tl = make_row_tiling(B, a.L, 0, tile_chunks_target());
     DISPATCH_VEC(tl, launch_affine<V>(a, tl, scaling_factor != nullptr, reverse != 0, (hipStream_t)stream));
-    if (sums) hipLaunchKernelGGL(nll_sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, nll_out, B, sums);
+    if (sums) CNF_LAUNCH(nll_sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, nll_out, B, sums);
     return launch_status(who);
 }
 
@@ -772,7 +772,7 @@ __global__ void nll_acc_read_kernel(const long long* acc, long n, double count, 
 
 int cnf_nll_acc_read(const int64_t* acc, int64_t n_slots, double count, double* sums, cnf_stream_t stream) {
     CNF_REQUIRE(acc && sums && n_slots > 0, "cnf_nll_acc_read: bad argument");
-    hipLaunchKernelGGL(nll_acc_read_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream,
+    CNF_LAUNCH(nll_acc_read_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream,
                        reinterpret_cast<const long long*>(acc), (long)n_slots, count, sums);
     return launch_status("cnf_nll_acc_read");
 }
@@ -785,7 +785,7 @@ int cnf_affine_params(const float* nn_out, const float* scaling_factor,
     if (B == 0) return CNF_OK;
     if (mask && mask_rows > N) mask_rows = N;
     const long total = (long)B * N * D;
-    hipLaunchKernelGGL(affine_params_kernel, dim3(stream_grid(total)), dim3(kBlock), 0, (hipStream_t)stream,
+    CNF_LAUNCH(affine_params_kernel, dim3(stream_grid(total)), dim3(kBlock), 0, (hipStream_t)stream,
                        nn_out, scaling_factor, mask, mask_rows, mask_cols, s_out, t_out, total, N, D);
     return launch_status("cnf_affine_params");
 }
@@ -798,7 +798,7 @@ int cnf_affine_transform(const float* z, const float* s, const float* t,
     if (B == 0) return CNF_OK;
     TransformArgs a{z, s, t, ldj_in, z_out, ldj_out, flags, N * D, reverse};
     const RowTiling tl = make_row_tiling(B, a.L);
-    DISPATCH_VEC(tl, hipLaunchKernelGGL((affine_transform_kernel<V>), tiling_grid(tl), dim3(kBlock), 0,
+    DISPATCH_VEC(tl, CNF_LAUNCH((affine_transform_kernel<V>), tiling_grid(tl), dim3(kBlock), 0,
                                         (hipStream_t)stream, a, tl));
     return launch_status("cnf_affine_transform");
 }
@@ -818,8 +818,8 @@ int cnf_ext_actnorm(const float* z, const float* nn_out, const float* pad,
         const dim3 grid = tiling_grid(tg), block(kBlock);
         hipStream_t st = (hipStream_t)stream;
 #define CNF_EXTG(D_)                                                                                              \
-    if (math_mode() == 1) hipLaunchKernelGGL((ext_actnorm_group_kernel<D_, true>), grid, block, 0, st, a, tg);   \
-    else hipLaunchKernelGGL((ext_actnorm_group_kernel<D_, false>), grid, block, 0, st, a, tg)
+    if (math_mode() == 1) CNF_LAUNCH((ext_actnorm_group_kernel<D_, true>), grid, block, 0, st, a, tg);   \
+    else CNF_LAUNCH((ext_actnorm_group_kernel<D_, false>), grid, block, 0, st, a, tg)
         switch (D) {
             case 2: CNF_EXTG(2); break;
             case 3: CNF_EXTG(3); break;
@@ -832,10 +832,10 @@ int cnf_ext_actnorm(const float* z, const float* nn_out, const float* pad,
     }
     const RowTiling tl = make_row_tiling(B, a.L);
     if (math_mode() == 1) {
-        DISPATCH_VEC(tl, hipLaunchKernelGGL((ext_actnorm_kernel<V, true>), tiling_grid(tl), dim3(kBlock), 0,
+        DISPATCH_VEC(tl, CNF_LAUNCH((ext_actnorm_kernel<V, true>), tiling_grid(tl), dim3(kBlock), 0,
                                             (hipStream_t)stream, a, tl));
     } else {
-        DISPATCH_VEC(tl, hipLaunchKernelGGL((ext_actnorm_kernel<V, false>), tiling_grid(tl), dim3(kBlock), 0,
+        DISPATCH_VEC(tl, CNF_LAUNCH((ext_actnorm_kernel<V, false>), tiling_grid(tl), dim3(kBlock), 0,
                                             (hipStream_t)stream, a, tl));
     }
     return launch_status("cnf_ext_actnorm");
@@ -849,10 +849,10 @@ int cnf_sigmoid_flow(const float* z, const float* ldj_in, float* z_out, float* l
     SigArgs a{z, ldj_in, z_out, ldj_out, flags, L, reverse, alpha, (float)log(1.0 - (double)alpha)};
     const RowTiling tl = make_row_tiling(B, L);
     if (math_mode() == 1) {
-        DISPATCH_VEC(tl, hipLaunchKernelGGL((sigmoid_flow_kernel<V, true>), tiling_grid(tl), dim3(kBlock), 0,
+        DISPATCH_VEC(tl, CNF_LAUNCH((sigmoid_flow_kernel<V, true>), tiling_grid(tl), dim3(kBlock), 0,
                                             (hipStream_t)stream, a, tl));
     } else {
-        DISPATCH_VEC(tl, hipLaunchKernelGGL((sigmoid_flow_kernel<V, false>), tiling_grid(tl), dim3(kBlock), 0,
+        DISPATCH_VEC(tl, CNF_LAUNCH((sigmoid_flow_kernel<V, false>), tiling_grid(tl), dim3(kBlock), 0,
                                             (hipStream_t)stream, a, tl));
     }
     return launch_status("cnf_sigmoid_flow");
@@ -862,7 +862,7 @@ int cnf_logistic_log_prob(const float* x, float* logp, int64_t n, float mu, floa
                           float log_sigma, int* flags, cnf_stream_t stream) {
     CNF_REQUIRE(x && logp && n >= 0, "cnf_logistic_log_prob: bad argument");
     if (n == 0) return CNF_OK;
-    hipLaunchKernelGGL(logistic_log_prob_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, (hipStream_t)stream,
+    CNF_LAUNCH(logistic_log_prob_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, (hipStream_t)stream,
                        x, logp, (long)n, mu, sigma, log_sigma, flags);
     return launch_status("cnf_logistic_log_prob");
 }
@@ -872,17 +872,17 @@ int cnf_logistic_from_uniform(const float* u, float* x, int64_t n, float mu, flo
     CNF_REQUIRE(u && x && n >= 0, "cnf_logistic_from_uniform: bad argument");
     if (n == 0) return CNF_OK;
     if (math_mode() == 1)
-        hipLaunchKernelGGL(logistic_from_uniform_kernel<true>, dim3(stream_grid((n + 3) / 4)), dim3(kBlock), 0,
+        CNF_LAUNCH(logistic_from_uniform_kernel<true>, dim3(stream_grid((n + 3) / 4)), dim3(kBlock), 0,
                            (hipStream_t)stream, u, x, (long)n, mu, sigma, eps);
     else
-        hipLaunchKernelGGL(logistic_from_uniform_kernel<false>, dim3(stream_grid(n)), dim3(kBlock), 0,
+        CNF_LAUNCH(logistic_from_uniform_kernel<false>, dim3(stream_grid(n)), dim3(kBlock), 0,
                            (hipStream_t)stream, u, x, (long)n, mu, sigma, eps);
     return launch_status("cnf_logistic_from_uniform");
 }
 
 int cnf_nll_sum(const float* nll, int B, double* sums, cnf_stream_t stream) {
     CNF_REQUIRE(nll && sums && B >= 0, "cnf_nll_sum: bad argument");
-    hipLaunchKernelGGL(nll_sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, nll, B, sums);
+    CNF_LAUNCH(nll_sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, nll, B, sums);
     return launch_status("cnf_nll_sum");
 }
 
@@ -896,9 +896,9 @@ int cnf_prior_nll(const float* z, const float* pad, const float* ldj, const floa
     NllArgs a{z, pad, ldj, length, neglog_out, nll_out, sums, N, D, N * D, make_prior_const(sigma, log_sigma),
               make_fastdiv((uint32_t)D)};
     const RowTiling tl = make_row_tiling(B, a.L);
-    DISPATCH_VEC(tl, hipLaunchKernelGGL((prior_nll_kernel<V>), tiling_grid(tl), dim3(kBlock), 0,
+    DISPATCH_VEC(tl, CNF_LAUNCH((prior_nll_kernel<V>), tiling_grid(tl), dim3(kBlock), 0,
                                         (hipStream_t)stream, a, tl));
-    if (sums) hipLaunchKernelGGL(nll_sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, nll_out, B, sums);
+    if (sums) CNF_LAUNCH(nll_sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, nll_out, B, sums);
     return launch_status("cnf_prior_nll");
 }
 

@@ -360,7 +360,7 @@ static inline int bwd_grid(long n) {
 }
 
 static int reduce_partials(const float* partials, int rows, int P, float* out, hipStream_t st) {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(P), dim3(kBlock), 0, st, partials, rows, P, out);
+    CNF_LAUNCH(reduce_partials_kernel, dim3(P), dim3(kBlock), 0, st, partials, rows, P, out);
     return CNF_OK;
 }
 
@@ -388,7 +388,7 @@ int cnf_affine_coupling_bwd(const float* z_out, const float* nn_out, const float
     AffBwdArgs a{z_out, nn_out, scaling_factor, mask, g_zout, g_ldj, g_z, g_nn, workspace, (long)B * N * D,
                  N, D, N * D, mask_rows, mask_cols, reverse};
     const int grid = bwd_grid(a.total);
-    hipLaunchKernelGGL(affine_bwd_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a);
+    CNF_LAUNCH(affine_bwd_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a);
     if (scaling_factor) reduce_partials(workspace, grid, D, g_scaling_factor, (hipStream_t)stream);
     return launch_status("cnf_affine_coupling_bwd");
 }
@@ -402,7 +402,7 @@ int cnf_affine_params_bwd(const float* nn_out, const float* scaling_factor, cons
     if (mask && mask_rows > N) mask_rows = N;
     const long total = (long)B * N * D;
     const int grid = bwd_grid(total);
-    hipLaunchKernelGGL(affine_params_bwd_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, nn_out, scaling_factor, mask,
+    CNF_LAUNCH(affine_params_bwd_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, nn_out, scaling_factor, mask,
                        mask_rows, mask_cols, g_s, g_t, g_nn, workspace, total, N, D);
     if (scaling_factor) reduce_partials(workspace, grid, D, g_scaling_factor, (hipStream_t)stream);
     return launch_status("cnf_affine_params_bwd");
@@ -413,7 +413,7 @@ int cnf_affine_transform_bwd(const float* z_out, const float* s, const float* t,
     CNF_REQUIRE(z_out && s && t && g_z && g_s && g_t, "cnf_affine_transform_bwd: null tensor");
     CNF_REQUIRE(B > 0 && N > 0 && D > 0, "cnf_affine_transform_bwd: bad shape");
     const long total = (long)B * N * D;
-    hipLaunchKernelGGL(affine_transform_bwd_kernel, dim3(bwd_grid(total)), dim3(kBlock), 0, (hipStream_t)stream, z_out, s, t,
+    CNF_LAUNCH(affine_transform_bwd_kernel, dim3(bwd_grid(total)), dim3(kBlock), 0, (hipStream_t)stream, z_out, s, t,
                        g_zout, g_ldj, g_z, g_s, g_t, total, N * D, reverse);
     return launch_status("cnf_affine_transform_bwd");
 }
@@ -425,7 +425,7 @@ int cnf_ext_actnorm_bwd(const float* z_out, const float* nn_out, const float* pa
     CNF_REQUIRE(B >= 0 && N > 0 && D > 0, "cnf_ext_actnorm_bwd: bad shape");
     if (B == 0) return CNF_OK;
     ExtBwdArgs a{z_out, nn_out, pad, g_zout, g_ldj, g_z, g_nn, (long)B * N * D, N, D, N * D, reverse};
-    hipLaunchKernelGGL(ext_actnorm_bwd_kernel, dim3(bwd_grid(a.total)), dim3(kBlock), 0, (hipStream_t)stream, a);
+    CNF_LAUNCH(ext_actnorm_bwd_kernel, dim3(bwd_grid(a.total)), dim3(kBlock), 0, (hipStream_t)stream, a);
     return launch_status("cnf_ext_actnorm_bwd");
 }
 
@@ -438,9 +438,9 @@ int cnf_actnorm_bwd(const float* z_out, const float* bias, const float* scales,
     ActBwdArgs a{z_out, bias, scales, pad, length, g_zout, g_ldj, g_z, workspace, (long)B * N * D, B, N, D, N * D, reverse};
     const int grid = bwd_grid(a.total);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(actnorm_bwd_kernel, dim3(grid), dim3(kBlock), 0, st, a);
+    CNF_LAUNCH(actnorm_bwd_kernel, dim3(grid), dim3(kBlock), 0, st, a);
     // partial rows are [d bias (D) | d scales (D)]
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(2 * D), dim3(kBlock), 0, st, workspace, grid, 2 * D, workspace + (size_t)kBwdGrid * 2 * D);
+    CNF_LAUNCH(reduce_partials_kernel, dim3(2 * D), dim3(kBlock), 0, st, workspace, grid, 2 * D, workspace + (size_t)kBwdGrid * 2 * D);
     hipMemcpyAsync(g_bias, workspace + (size_t)kBwdGrid * 2 * D, sizeof(float) * D, hipMemcpyDeviceToDevice, st);
     hipMemcpyAsync(g_scales, workspace + (size_t)kBwdGrid * 2 * D + D, sizeof(float) * D, hipMemcpyDeviceToDevice, st);
     return launch_status("cnf_actnorm_bwd");
@@ -456,9 +456,9 @@ int cnf_invconv_bwd(const float* x, const float* weight, const float* pad, const
     const int P = D * D + 1;
     const int grid = bwd_grid(a.ntok * D);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(invconv_bwd_kernel, dim3(grid), dim3(kBlock), 0, st, a);
+    CNF_LAUNCH(invconv_bwd_kernel, dim3(grid), dim3(kBlock), 0, st, a);
     float* red = workspace + (size_t)kBwdGrid * P;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(P), dim3(kBlock), 0, st, workspace, grid, P, red);
+    CNF_LAUNCH(reduce_partials_kernel, dim3(P), dim3(kBlock), 0, st, workspace, grid, P, red);
     hipMemcpyAsync(g_weight, red, sizeof(float) * D * D, hipMemcpyDeviceToDevice, st);
     hipMemcpyAsync(g_sldj, red + D * D, sizeof(float), hipMemcpyDeviceToDevice, st);
     return launch_status("cnf_invconv_bwd");
@@ -468,7 +468,7 @@ int cnf_logistic_log_prob_bwd(const float* x, const float* g_logp, float* g_x, i
                               cnf_stream_t stream) {
     CNF_REQUIRE(x && g_logp && g_x && n >= 0, "cnf_logistic_log_prob_bwd: bad argument");
     if (n == 0) return CNF_OK;
-    hipLaunchKernelGGL(logistic_log_prob_bwd_kernel, dim3(bwd_grid(n)), dim3(kBlock), 0, (hipStream_t)stream,
+    CNF_LAUNCH(logistic_log_prob_bwd_kernel, dim3(bwd_grid(n)), dim3(kBlock), 0, (hipStream_t)stream,
                        x, g_logp, g_x, (long)n, mu, sigma);
     return launch_status("cnf_logistic_log_prob_bwd");
 }
@@ -478,7 +478,7 @@ int cnf_prior_nll_bwd(const float* z, const float* pad, const float* length, con
     CNF_REQUIRE(z && g_nll && g_z, "cnf_prior_nll_bwd: null tensor");
     CNF_REQUIRE(B > 0 && N > 0 && D > 0, "cnf_prior_nll_bwd: bad shape");
     NllBwdArgs a{z, pad, length, g_nll, g_z, g_ldj, (long)B * N * D, B, N, D, N * D, sigma};
-    hipLaunchKernelGGL(prior_nll_bwd_kernel, dim3(bwd_grid(a.total)), dim3(kBlock), 0, (hipStream_t)stream, a);
+    CNF_LAUNCH(prior_nll_bwd_kernel, dim3(bwd_grid(a.total)), dim3(kBlock), 0, (hipStream_t)stream, a);
     return launch_status("cnf_prior_nll_bwd");
 }
 
@@ -487,7 +487,7 @@ int cnf_sigmoid_flow_bwd(const float* z_in, const float* g_zout, const float* g_
     CNF_REQUIRE(z_in && g_z, "cnf_sigmoid_flow_bwd: null tensor");
     CNF_REQUIRE(B > 0 && L > 0, "cnf_sigmoid_flow_bwd: bad shape");
     const long total = (long)B * L;
-    hipLaunchKernelGGL(sigmoid_flow_bwd_kernel, dim3(bwd_grid(total)), dim3(kBlock), 0, (hipStream_t)stream,
+    CNF_LAUNCH(sigmoid_flow_bwd_kernel, dim3(bwd_grid(total)), dim3(kBlock), 0, (hipStream_t)stream,
                        z_in, g_zout, g_ldj, g_z, total, L, reverse, alpha);
     return launch_status("cnf_sigmoid_flow_bwd");
 }

@@ -2,6 +2,7 @@
 // CDNA4 only: wave = 64 lanes, no CUDA compatibility paths.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
@@ -23,6 +24,19 @@ int unroll_target();
 int math_mode();
 int inverse_mode();
 int mixture_tile_items();
+// kernel timing (cnf_prof_arm / cnf_prof_collect): true = the launch that asked takes this event pair
+bool prof_take(hipEvent_t* start, hipEvent_t* stop);
+
+// Every kernel of the library is launched through this: an armed launch goes out with the dispatch's own start /
+// stop timestamps bound to an event pair (hipExtLaunchKernelGGL: no extra marker packets in the queue).
+#define CNF_LAUNCH(kernel, grid, block, lds, st, ...)                                                        \
+    do {                                                                                                     \
+        hipEvent_t cnf_ps_, cnf_pe_;                                                                         \
+        if (cnf::prof_take(&cnf_ps_, &cnf_pe_))                                                              \
+            hipExtLaunchKernelGGL(kernel, grid, block, lds, st, cnf_ps_, cnf_pe_, 0, __VA_ARGS__);           \
+        else                                                                                                 \
+            hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                                   \
+    } while (0)
 
 #define CNF_REQUIRE(cond, ...)                \
     do {                                      \

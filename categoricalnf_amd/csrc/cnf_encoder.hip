@@ -214,7 +214,7 @@ int cnf_encoder_forward(const int64_t* categ, const float* eps, const float* tab
     a.ldj_in = ldj_in; a.z_out = z_out; a.ldj_out = ldj_out; a.cpl = class_prob_log; a.flags = flags;
     a.B = B; a.N = N; a.D = D; a.C = C; a.beta = beta; a.sigma = sigma; a.log_sigma = log_sigma;
     const RowTiling tl = make_row_tiling(B, N, /*force_vec=*/1);
-    DISPATCH_D(D, hipLaunchKernelGGL((encoder_forward_kernel<DT>), tiling_grid(tl), dim3(kBlock), smem,
+    DISPATCH_D(D, CNF_LAUNCH((encoder_forward_kernel<DT>), tiling_grid(tl), dim3(kBlock), smem,
                                      (hipStream_t)stream, a, tl));
     return launch_status("cnf_encoder_forward");
 }
@@ -233,7 +233,7 @@ int cnf_encoder_decode(const float* z, const float* table, const float* category
     a.B = B; a.N = N; a.D = D; a.C = C; a.sigma = sigma; a.log_sigma = log_sigma;
     const long ntok = (long)B * N;
     const int grid = (int)std::min<long>((ntok + kBlock - 1) / kBlock, 256 * 8);
-    DISPATCH_D(D, hipLaunchKernelGGL((encoder_decode_kernel<DT>), dim3(grid), dim3(kBlock), smem,
+    DISPATCH_D(D, CNF_LAUNCH((encoder_decode_kernel<DT>), dim3(grid), dim3(kBlock), smem,
                                      (hipStream_t)stream, a, ntok));
     return launch_status("cnf_encoder_decode");
 }

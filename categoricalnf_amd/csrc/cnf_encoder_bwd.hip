@@ -155,8 +155,8 @@ int cnf_encoder_forward_bwd(const int64_t* categ, const float* eps, const float*
     const size_t smem = sizeof(float) * ((size_t)C * 2 * D + (size_t)C * 3 * D);
     const int grid = (int)std::min<long>(std::max<long>((a.ntok + kBlock - 1) / kBlock, 1), kEncBwdGrid);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(encoder_fwd_bwd_kernel, dim3(grid), dim3(kBlock), smem, st, a);
-    hipLaunchKernelGGL(enc_reduce_partials_kernel, dim3(P), dim3(kBlock), 0, st, workspace, grid, P, g_table);
+    CNF_LAUNCH(encoder_fwd_bwd_kernel, dim3(grid), dim3(kBlock), smem, st, a);
+    CNF_LAUNCH(enc_reduce_partials_kernel, dim3(P), dim3(kBlock), 0, st, workspace, grid, P, g_table);
     return launch_status("cnf_encoder_forward_bwd");
 }
 

@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <string.h>
+#include <vector>
 
 namespace cnf {
 
@@ -33,6 +34,36 @@ int unroll_target() { return g_unroll; }
 int math_mode() { return g_math; }
 int inverse_mode() { return g_inverse; }
 int mixture_tile_items() { return g_mix_tile; }
+
+// ---- kernel timing: event pairs bound to the dispatch packets of armed launches (host thread local) ----------
+struct ProfState {
+    std::vector<hipEvent_t> start, stop;
+    int used = 0;       // pairs handed out since the last collect
+    int armed = 0;      // launches still to be timed
+};
+static thread_local ProfState g_prof;
+constexpr int kMaxProfPairs = 8192;
+
+bool prof_take(hipEvent_t* start, hipEvent_t* stop) {
+    ProfState& p = g_prof;
+    if (p.armed <= 0) return false;
+    --p.armed;
+    if (p.used >= kMaxProfPairs) return false;
+    if (p.used == (int)p.start.size()) {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess) return false;
+        if (hipEventCreate(&b) != hipSuccess) {
+            (void)hipEventDestroy(a);
+            return false;
+        }
+        p.start.push_back(a);
+        p.stop.push_back(b);
+    }
+    *start = p.start[p.used];
+    *stop = p.stop[p.used];
+    ++p.used;
+    return true;
+}
 
 RowTiling make_row_tiling(int B, int L, int force_vec, int target_chunks) {
     RowTiling t;
@@ -97,6 +128,27 @@ void cnf_set_mixture_tile(int items) {
 
 void cnf_set_inverse_mode(int mode) {
     if (mode == 0 || mode == 1) cnf::g_inverse = mode;
+}
+
+int cnf_prof_arm(int launches) {
+    cnf::g_prof.armed = launches > 0 ? launches : 0;
+    return CNF_OK;
+}
+
+int cnf_prof_collect(float* ms_out, int capacity) {
+    cnf::ProfState& p = cnf::g_prof;
+    int n = 0;
+    for (int i = 0; i < p.used; ++i) {
+        if (hipEventSynchronize(p.stop[i]) != hipSuccess) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.start[i], p.stop[i]) != hipSuccess) continue;
+        if (ms_out && n < capacity) ms_out[n] = ms;
+        ++n;
+    }
+    p.used = 0;
+    p.armed = 0;
+    (void)hipGetLastError();
+    return n < capacity ? n : capacity;
 }
 
 }  // extern "C"

@@ -392,9 +392,9 @@ int cnf_actnorm(const float* z, const float* bias, const float* scales,
     ActNormArgs a{z, bias, scales, pad, length, ldj_in, z_out, ldj_out, flags, B, N, D, reverse, (long)B * N * D};
     const long work = std::max<long>(a.total / 4, B);
     if (a.total % 4 == 0)
-        hipLaunchKernelGGL((actnorm_kernel<4>), dim3(stream_grid(work)), dim3(kBlock), 0, (hipStream_t)stream, a);
+        CNF_LAUNCH((actnorm_kernel<4>), dim3(stream_grid(work)), dim3(kBlock), 0, (hipStream_t)stream, a);
     else
-        hipLaunchKernelGGL((actnorm_kernel<1>), dim3(stream_grid(a.total)), dim3(kBlock), 0, (hipStream_t)stream, a);
+        CNF_LAUNCH((actnorm_kernel<1>), dim3(stream_grid(a.total)), dim3(kBlock), 0, (hipStream_t)stream, a);
     return launch_status("cnf_actnorm");
 }
 
@@ -405,7 +405,7 @@ int cnf_actnorm_stats(const float* z, const float* pad, const double* mean, doub
     const long ntok = (long)B * N;
     const int tpb = kBlock / D;
     const int grid = (int)std::min<long>((ntok + tpb - 1) / tpb, 1024);
-    hipLaunchKernelGGL(actnorm_stats_kernel, dim3(std::max(grid, 1)), dim3(kBlock), 0, (hipStream_t)stream,
+    CNF_LAUNCH(actnorm_stats_kernel, dim3(std::max(grid, 1)), dim3(kBlock), 0, (hipStream_t)stream,
                        z, pad, mean, out, ntok, D, pass);
     return launch_status("cnf_actnorm_stats");
 }
@@ -421,15 +421,15 @@ int cnf_invconv(const float* x, const float* weight, const float* sldj,
     const dim3 grid(stream_grid(std::max<long>(a.ntok, B))), block(kBlock);
     hipStream_t st = (hipStream_t)stream;
     switch (D) {
-        case 1: hipLaunchKernelGGL((invconv_kernel<1>), grid, block, 0, st, a); break;
-        case 2: hipLaunchKernelGGL((invconv_kernel<2>), grid, block, 0, st, a); break;
-        case 3: hipLaunchKernelGGL((invconv_kernel<3>), grid, block, 0, st, a); break;
-        case 4: hipLaunchKernelGGL((invconv_kernel<4>), grid, block, 0, st, a); break;
-        case 5: hipLaunchKernelGGL((invconv_kernel<5>), grid, block, 0, st, a); break;
-        case 6: hipLaunchKernelGGL((invconv_kernel<6>), grid, block, 0, st, a); break;
-        case 8: hipLaunchKernelGGL((invconv_kernel<8>), grid, block, 0, st, a); break;
+        case 1: CNF_LAUNCH((invconv_kernel<1>), grid, block, 0, st, a); break;
+        case 2: CNF_LAUNCH((invconv_kernel<2>), grid, block, 0, st, a); break;
+        case 3: CNF_LAUNCH((invconv_kernel<3>), grid, block, 0, st, a); break;
+        case 4: CNF_LAUNCH((invconv_kernel<4>), grid, block, 0, st, a); break;
+        case 5: CNF_LAUNCH((invconv_kernel<5>), grid, block, 0, st, a); break;
+        case 6: CNF_LAUNCH((invconv_kernel<6>), grid, block, 0, st, a); break;
+        case 8: CNF_LAUNCH((invconv_kernel<8>), grid, block, 0, st, a); break;
         default:
-            hipLaunchKernelGGL(invconv_generic_kernel, dim3(stream_grid(a.ntok * D)), block, 0, st, a);
+            CNF_LAUNCH(invconv_generic_kernel, dim3(stream_grid(a.ntok * D)), block, 0, st, a);
     }
     return launch_status("cnf_invconv");
 }
@@ -448,13 +448,13 @@ int cnf_actnorm_invconv(const float* z, const float* bias, const float* scales, 
     const dim3 grid((unsigned)std::min<long>((lanes + kBlock - 1) / kBlock, 1 << 22)), block(kBlock);
     hipStream_t st = (hipStream_t)stream;
     switch (D) {
-        case 1: hipLaunchKernelGGL((actnorm_invconv_kernel<1>), grid, block, 0, st, a); break;
-        case 2: hipLaunchKernelGGL((actnorm_invconv_kernel<2>), grid, block, 0, st, a); break;
-        case 3: hipLaunchKernelGGL((actnorm_invconv_kernel<3>), grid, block, 0, st, a); break;
-        case 4: hipLaunchKernelGGL((actnorm_invconv_kernel<4>), grid, block, 0, st, a); break;
-        case 5: hipLaunchKernelGGL((actnorm_invconv_kernel<5>), grid, block, 0, st, a); break;
-        case 6: hipLaunchKernelGGL((actnorm_invconv_kernel<6>), grid, block, 0, st, a); break;
-        case 8: hipLaunchKernelGGL((actnorm_invconv_kernel<8>), grid, block, 0, st, a); break;
+        case 1: CNF_LAUNCH((actnorm_invconv_kernel<1>), grid, block, 0, st, a); break;
+        case 2: CNF_LAUNCH((actnorm_invconv_kernel<2>), grid, block, 0, st, a); break;
+        case 3: CNF_LAUNCH((actnorm_invconv_kernel<3>), grid, block, 0, st, a); break;
+        case 4: CNF_LAUNCH((actnorm_invconv_kernel<4>), grid, block, 0, st, a); break;
+        case 5: CNF_LAUNCH((actnorm_invconv_kernel<5>), grid, block, 0, st, a); break;
+        case 6: CNF_LAUNCH((actnorm_invconv_kernel<6>), grid, block, 0, st, a); break;
+        case 8: CNF_LAUNCH((actnorm_invconv_kernel<8>), grid, block, 0, st, a); break;
         default:
             set_error("cnf_actnorm_invconv: fused kernel is built for D in {1,2,3,4,5,6,8}; run the two layers separately for D=%d", D);
             return CNF_ERR_UNSUPPORTED;

@@ -1037,8 +1037,8 @@ static int launch_mixture(MixArgs& a, bool split, const int* act_host, int n_act
             const dim3 gridf(tl.bpr ? (unsigned)tl.ntiles : (unsigned)((tl.ntiles + Wf - 1) / Wf)), blockf(th);
             const size_t lds = need(kWave / G);
 #define CNF_MIXF(KT_, G_)                                                                                          \
-    if (a.reverse) hipLaunchKernelGGL((mixture_f32_kernel<KT_, true, G_>), gridf, blockf, lds, st, a, tl, PS, strip); \
-    else hipLaunchKernelGGL((mixture_f32_kernel<KT_, false, G_>), gridf, blockf, lds, st, a, tl, PS, strip)
+    if (a.reverse) CNF_LAUNCH((mixture_f32_kernel<KT_, true, G_>), gridf, blockf, lds, st, a, tl, PS, strip); \
+    else CNF_LAUNCH((mixture_f32_kernel<KT_, false, G_>), gridf, blockf, lds, st, a, tl, PS, strip)
             if (G == 4) { CNF_MIXF(0, 4); }
             else switch (kt) {
                 case 4: CNF_MIXF(4, 1); break;
@@ -1055,7 +1055,7 @@ static int launch_mixture(MixArgs& a, bool split, const int* act_host, int n_act
     const dim3 grid(tl.bpr ? (unsigned)tl.ntiles : (unsigned)((tl.ntiles + W - 1) / W)), block(threads);
     const bool newton = inverse_mode() == 1;
 #define CNF_MIX_LAUNCH(SPLIT_, REV_, KT_, NEWT_) \
-    hipLaunchKernelGGL((mixture_kernel<SPLIT_, REV_, KT_, NEWT_>), grid, block, smem, st, a, tl)
+    CNF_LAUNCH((mixture_kernel<SPLIT_, REV_, KT_, NEWT_>), grid, block, smem, st, a, tl)
 #define CNF_MIX_K(SPLIT_, REV_, NEWT_)                                   \
     switch (kt) {                                                        \
         case 4: CNF_MIX_LAUNCH(SPLIT_, REV_, 4, NEWT_); break;           \
@@ -1133,7 +1133,7 @@ int cnf_mixture_params(const float* nn_out, const float* scaling_factor,
     const long nelem = (long)B * N * D;
     const long total = nelem * (2 + 3 * K);
     const int grid = (int)std::min<long>((total + kBlock - 1) / kBlock, 256 * 16);
-    hipLaunchKernelGGL(mixture_params_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream,
+    CNF_LAUNCH(mixture_params_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream,
                        nn_out, scaling_factor, mixture_scaling_factor, mask, mask_rows, mask_cols,
                        t, log_s, log_pi, mixt_t, mixt_log_s, nelem, N, D, K);
     return launch_status("cnf_mixture_params");

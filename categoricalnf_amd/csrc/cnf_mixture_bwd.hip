@@ -287,10 +287,10 @@ int cnf_mixture_coupling_bwd(const float* z, const float* nn_out,
     // parameters of untransformed elements get no gradient
     hipMemsetAsync(g_nn, 0, sizeof(float) * (size_t)a.total * a.P, st);
     const int grid = (int)std::min<long>(std::max<long>((a.total + kBlock - 1) / kBlock, 1), kMixBwdGrid);
-    hipLaunchKernelGGL((mixture_fwd_bwd_kernel<false>), dim3(grid), dim3(kBlock), 0, st, a);
+    CNF_LAUNCH((mixture_fwd_bwd_kernel<false>), dim3(grid), dim3(kBlock), 0, st, a);
     const int PP = D + D * K;
     float* red = workspace + (size_t)kMixBwdGrid * PP;
-    hipLaunchKernelGGL(mix_reduce_partials_kernel, dim3(PP), dim3(kBlock), 0, st, workspace, grid, PP, red);
+    CNF_LAUNCH(mix_reduce_partials_kernel, dim3(PP), dim3(kBlock), 0, st, workspace, grid, PP, red);
     if (scaling_factor) hipMemcpyAsync(g_scaling_factor, red, sizeof(float) * D, hipMemcpyDeviceToDevice, st);
     if (mixture_scaling_factor) hipMemcpyAsync(g_mixture_scaling_factor, red + D, sizeof(float) * D * K, hipMemcpyDeviceToDevice, st);
     return launch_status("cnf_mixture_coupling_bwd");
@@ -326,7 +326,7 @@ int cnf_mixture_transform_bwd(const double* z, const double* t, const double* lo
     hipMemsetAsync(g_mixt_t, 0, sizeof(double) * n * K, st);
     hipMemsetAsync(g_mixt_log_s, 0, sizeof(double) * n * K, st);
     const int grid = (int)std::min<long>(std::max<long>((a.total + kBlock - 1) / kBlock, 1), kMixBwdGrid);
-    hipLaunchKernelGGL((mixture_fwd_bwd_kernel<true>), dim3(grid), dim3(kBlock), 0, st, a);
+    CNF_LAUNCH((mixture_fwd_bwd_kernel<true>), dim3(grid), dim3(kBlock), 0, st, a);
     return launch_status("cnf_mixture_transform_bwd");
 }
 
@@ -344,10 +344,10 @@ int cnf_mixture_params_bwd(const float* nn_out, const float* scaling_factor, con
                        g_nn, workspace, (long)B * N * D, N, D, K, mask_rows, mask_cols};
     const long total = a.nelem * (2 + 3 * K);
     const int grid = (int)std::min<long>(std::max<long>((total + kBlock - 1) / kBlock, 1), kMixBwdGrid);
-    hipLaunchKernelGGL(mixture_params_bwd_kernel, dim3(grid), dim3(kBlock), 0, st, a);
+    CNF_LAUNCH(mixture_params_bwd_kernel, dim3(grid), dim3(kBlock), 0, st, a);
     const int PP = D + D * K;
     float* red = workspace + (size_t)kMixBwdGrid * PP;
-    hipLaunchKernelGGL(mix_reduce_partials_kernel, dim3(PP), dim3(kBlock), 0, st, workspace, grid, PP, red);
+    CNF_LAUNCH(mix_reduce_partials_kernel, dim3(PP), dim3(kBlock), 0, st, workspace, grid, PP, red);
     if (scaling_factor && g_scaling_factor) hipMemcpyAsync(g_scaling_factor, red, sizeof(float) * D, hipMemcpyDeviceToDevice, st);
     if (mixture_scaling_factor && g_mixture_scaling_factor)
         hipMemcpyAsync(g_mixture_scaling_factor, red + D, sizeof(float) * D * K, hipMemcpyDeviceToDevice, st);

@@ -1096,6 +1096,52 @@ def test_two_rank_data_parallel_gradients_match_single_process():
     assert r.returncode == 0 and "DDP_CHECK OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
 
 
+def test_bench_self_launches_n_ranks():
+    """a plain `python bench.py --gpus 2` (no torchrun environment) must start 2 ranks itself and
+    report n_gpus == 2 (both ranks on cuda:0 over gloo here; RCCL with --backend nccl on a multi-GPU node)."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-device", "--backend", "gloo",
+                        "--steps", "5", "--warmup", "2", "--batch", "2048", "--prewarm-seconds", "0.2"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and len(out["per_rank_elems_per_s"]) == 2 and out["allreduce_latency_us"] > 0
+    assert out["value"] > 0 and out["roofline"]["kernel_ms"] > 0 and np.isfinite(out["mean_nll"])
+
+
+def test_dispatch_bound_kernel_timing_matches_event_brackets():
+    """cnf_prof_arm / cnf_prof_collect (bench.py's roofline clock): the dispatch-bound duration of a big launch is
+    positive, below a marker-bracketed measurement of the same launch and within 2x of it."""
+    import ctypes
+    lib = _lib.load()
+    B, N, D = 16384, 64, 6
+    z, nn_out = torch.randn(B, N, D, device="cuda"), torch.randn(B, N, 2 * D, device="cuda")
+    mask = torch.tensor([[1., 1., 1., 0., 0., 0.]], device="cuda")
+    zo, lo = torch.empty_like(z), torch.empty(B, device="cuda")
+    k = ops().affine_coupling_launch(z, nn_out, torch.zeros(D, device="cuda"), mask, zo, lo)
+    for _ in range(20):
+        k()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    a.record(); k(); b.record()
+    lib.cnf_prof_arm(3)
+    for _ in range(5):
+        k()
+    buf = (ctypes.c_float * 8)()
+    n = lib.cnf_prof_collect(buf, 8)
+    torch.cuda.synchronize()
+    assert n == 3
+    bracket = a.elapsed_time(b)
+    for i in range(n):
+        assert 0.005 < buf[i] < 0.2, list(buf)
+    assert min(buf[:n]) <= bracket * 1.05
+    assert lib.cnf_prof_collect(buf, 8) == 0
+
+
 def test_set_modelling_driver_trains_checkpoints_and_reloads(tmp_path):
     """The host template (run_set_modeling): a short run on set summation lowers the validation bits/dim well below
     the uniform 4 bpd, writes a reference-format checkpoint, and --only_eval from that checkpoint reproduces the

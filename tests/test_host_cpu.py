@@ -344,3 +344,23 @@ def test_every_c_entry_point_is_documented_for_integrators():
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     missing = sorted(n for n in names if n not in doc)
     assert not missing, missing
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the refusal on a box without enough GPUs")
+def test_bench_refuses_more_gpus_than_visible():
+    """`bench.py --gpus N` must either run N ranks or stop: never print an n_gpus=1 line for an N-GPU request."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "HIP device(s) visible" in r.stderr and "{" not in r.stdout
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "{" not in r.stdout
+
+
+def test_traffic_file_carries_the_kernel_source_stamp():
+    import json
+    from bench import kernel_sources_sha
+    tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    assert "kernel_sources_sha" in tj and len(kernel_sources_sha()) == 16

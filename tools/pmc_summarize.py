@@ -39,7 +39,10 @@ for tag, key in names.items():
     raw[tag] = {"FETCH_SIZE_KB": med(f), "WRITE_SIZE_KB": med(w), "launches": len(f)}
 cf = COPY_BYTES / (raw["copy"]["FETCH_SIZE_KB"] * 1024.0) if raw["copy"]["FETCH_SIZE_KB"] else None
 cw = COPY_BYTES / (raw["copy"]["WRITE_SIZE_KB"] * 1024.0) if raw["copy"]["WRITE_SIZE_KB"] else None
-out = {"calibration": {"copy_bytes_each_way": COPY_BYTES, "fetch_factor": cf, "write_factor": cw,
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernel_sources_sha
+out = {"kernel_sources_sha": kernel_sources_sha(),
+       "calibration": {"copy_bytes_each_way": COPY_BYTES, "fetch_factor": cf, "write_factor": cw,
                        "note": "factor = known bytes / (counter KB * 1024) on the 100.66 MB d2d copy (__amd_rocclr_copyBuffer) of the "
                                "same pass; MI355X_MICROARCH.md: FETCH_SIZE reports 1/2 of a wide coalesced read on gfx950"},
        "raw_median_per_launch": raw}
