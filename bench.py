@@ -218,6 +218,25 @@ def kernel_sources_sha():
     return h.hexdigest()[:16]
 
 
+def read_traffic(path=None):
+    """HBM bytes per launch of the dominant kernel from the rocprofv3 --pmc passes (FETCH_SIZE x2 per the gfx950
+    correction, WRITE_SIZE x1, both calibrated on a known-size copy; tools/pmc_summarize.py) — reported only while
+    the kernel sources they were collected on are the ones in the tree.  Returns (bytes or None, provenance)."""
+    path = path or os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(path):
+        return None, "profiles/traffic.json absent"
+    try:
+        tj = json.load(open(path))
+    except Exception as e:
+        return None, "profiles/traffic.json unreadable: %s" % e
+    sha = kernel_sources_sha()
+    if tj.get("kernel_sources_sha") != sha:
+        return None, "profiles/traffic.json was collected on other kernel sources (%s != %s): not reported" % (
+            tj.get("kernel_sources_sha"), sha)
+    return tj.get("affine_coupling_fwd_bytes_per_launch"), \
+        "rocprofv3 --pmc passes of tools/pmc_workload.py on these kernel sources (sha %s)" % sha
+
+
 def self_launch(args):
     """`python bench.py --gpus N` without a torchrun environment: start the N ranks ourselves (one process per GPU,
     the same command line the driver would use) and hand their exit code back."""
@@ -398,22 +417,7 @@ def main():
     kern_ms = float(np.mean(in_step)) if in_step else steady_ms
     alg_bytes = 16.0 * elems + 4.0 * B            # z 4 + (s,t) 8 + z' 4 per elem, + ldj per sample
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-    traffic, traffic_note = None, "profiles/traffic.json absent"
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        try:
-            # HBM bytes per launch from the rocprofv3 --pmc passes (FETCH_SIZE x2 per the gfx950 correction,
-            # WRITE_SIZE x1, both calibrated on a known-size copy; tools/pmc_summarize.py), valid only for the
-            # kernel sources they were collected on
-            tj = json.load(open(tpath))
-            if tj.get("kernel_sources_sha") == kernel_sources_sha():
-                traffic = tj.get("affine_coupling_fwd_bytes_per_launch")
-                traffic_note = "rocprofv3 --pmc passes of tools/pmc_workload.py on these kernel sources (sha %s)" % tj["kernel_sources_sha"]
-            else:
-                traffic_note = "profiles/traffic.json was collected on other kernel sources (%s != %s): not reported" % (
-                    tj.get("kernel_sources_sha"), kernel_sources_sha())
-        except Exception as e:
-            traffic_note = "profiles/traffic.json unreadable: %s" % e
+    traffic, traffic_note = read_traffic()
 
     if rank == 0:
         out = {

@@ -359,8 +359,14 @@ def test_bench_refuses_more_gpus_than_visible():
     assert r.returncode != 0 and "{" not in r.stdout
 
 
-def test_traffic_file_carries_the_kernel_source_stamp():
+def test_traffic_is_reported_only_for_the_sources_it_was_measured_on(tmp_path):
     import json
-    from bench import kernel_sources_sha
-    tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-    assert "kernel_sources_sha" in tj and len(kernel_sources_sha()) == 16
+    import bench
+    sha = bench.kernel_sources_sha()
+    assert len(sha) == 16
+    good, stale = tmp_path / "good.json", tmp_path / "stale.json"
+    good.write_text(json.dumps({"kernel_sources_sha": sha, "affine_coupling_fwd_bytes_per_launch": 123.0}))
+    stale.write_text(json.dumps({"kernel_sources_sha": "0" * 16, "affine_coupling_fwd_bytes_per_launch": 123.0}))
+    assert bench.read_traffic(str(good))[0] == 123.0
+    assert bench.read_traffic(str(stale))[0] is None and "other kernel sources" in bench.read_traffic(str(stale))[1]
+    assert bench.read_traffic(str(tmp_path / "none.json"))[0] is None
