@@ -34,6 +34,10 @@ SIGNATURES = {
     "cnf_actnorm_invconv": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p],
     "cnf_mixture_coupling": [_p, _p, _p, _p, _p, _i, _i, _p, _i, _p, _i, _i, _p, _p, _p, _p,
                              _i, _i, _i, _i, _i, _d, _d, _i, _p, _p],
+    "cnf_mixture_coupling_ws": [_p, _p, _p, _p, _p, _i, _i, _p, _i, _p, _i, _i, _p, _p, _p, _p,
+                                _i, _i, _i, _i, _i, _d, _d, _i, _p, _i64, _p, _p],
+    "cnf_mixture_coupling_nll": [_p, _p, _p, _p, _p, _i, _i, _p, _i, _p, _i, _i, _p, _p, _p, _p,
+                                 _p, _p, _p, _p, _i, _i, _i, _i, _d, _d, _i, _f, _f, _p, _i64, _p, _p],
     "cnf_mixture_params": [_p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "cnf_mixture_transform": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _i, _p, _p, _p, _p,
                               _i, _i, _i, _i, _i, _d, _d, _i, _p, _p],
@@ -67,6 +71,8 @@ _PLAIN = {"cnf_abi_version": ([], _i), "cnf_last_error": ([], ctypes.c_char_p),
           "cnf_set_tile_chunks": ([_i], None), "cnf_set_unroll": ([_i], None),
           "cnf_set_math_mode": ([_i], None), "cnf_set_inverse_mode": ([_i], None), "cnf_set_mixture_tile": ([_i], None),
           "cnf_bwd_workspace_floats": ([_i], _i64),
+          "cnf_mixture_workspace_bytes": ([_i], _i64), "cnf_set_mixture_kernel": ([_i], None),
+          "cnf_set_mixture_lanes": ([_i], None), "cnf_set_mixture_split": ([_i], None),
           "cnf_prof_arm": ([_i], _i), "cnf_prof_collect": ([ctypes.POINTER(ctypes.c_float), _i], _i)}
 
 _lib = None

@@ -29,7 +29,6 @@ __device__ __forceinline__ float tanh_m(float x) {
     return 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
 }
 constexpr int kMaxTab = 64;     // (mask period) x D entries, one private copy per wave
-constexpr int kAccStride = 16;  // int64 words between two of the 64 batch-sum accumulators (128 B: one cache line each)
 
 // logistic prior log-prob (distributions.py:129-136,154-163):
 // softplus(v) + softplus(-v) = |v| + 2 log(1 + e^{-|v|}); one exp and one log instead of two each
@@ -38,24 +37,6 @@ __device__ __forceinline__ float logistic_logp(float x, float mu, float sigma, f
     const float v = fabsf((x - mu) / sigma);
     return -((v + 2.f * __logf(1.f + __expf(-v))) + log_sigma);
 }
-// the same for mu = 0 with the constants folded on the host: a = 1/sigma, a2 = log2(e)/sigma; the hardware
-// exp2 / log2 are used directly (no range-scaling code, no fp32 division): 8 VALU instructions per element
-struct PriorConst {
-    float inv_sigma, inv_sigma_log2e, log_sigma;
-};
-inline PriorConst make_prior_const(float sigma, float log_sigma) {
-    PriorConst c;
-    c.inv_sigma = (float)(1.0 / (double)sigma);
-    c.inv_sigma_log2e = (float)(1.4426950408889634 / (double)sigma);
-    c.log_sigma = log_sigma;
-    return c;
-}
-__device__ __forceinline__ float prior_logp(float x, const PriorConst& c) {
-    const float ax = fabsf(x);
-    const float l2 = __builtin_amdgcn_logf(1.f + __builtin_amdgcn_exp2f(-ax * c.inv_sigma_log2e));
-    return -((ax * c.inv_sigma + 1.3862943611198906f * l2) + c.log_sigma);
-}
-
 struct AffineArgs {
     const float* z;
     const float* nn;

@@ -12,54 +12,11 @@
 //     pdf = sum_k w_k e^{-ls_k} sigma(z_k)(1 - sigma(z_k)) / sum_k w_k,
 // which is the same quantity to fp64 rounding (3 exp + 1 divide per mixture instead of ~6
 // transcendentals); if the PDF sum underflows, the element falls back to the log-space form.
-#include "cnf_common.h"
+#include "cnf_mixture.h"
 
 #include <algorithm>
 
 namespace cnf {
-
-constexpr int kMaxAct = 64;          // channels per token
-constexpr double kLn10 = 2.302585092994045684;
-
-struct MixArgs {
-    // fused (module) form: fp32 z / nn_out
-    const float* z;
-    const float* nn;
-    const float* sf;
-    const float* msf;
-    // split (static API) form: fp64 tensors
-    const double* z64;
-    const double* p_t;
-    const double* p_log_s;
-    const double* p_log_pi;
-    const double* p_mu;
-    const double* p_ls;
-    const float* mask;
-    const float* pad;
-    const float* ldj_in;
-    float* z_out;
-    float* ldj_out;
-    float* reg_out;
-    double* z_out64;
-    double* ldj_out64;
-    double* reg_elem64;
-    int* flags;
-    int B, N, D, K, P, L;
-    int mr, mc;
-    int DA;                 // transformed channels per token (channel mask) or D (per-item test)
-    unsigned long long act_bits;   // bit d set = channel d is transformed (a list cannot be indexed per lane)
-    int per_item_mask;      // 1: mask varies along N (chess) -> test every item
-    int cst_lds;            // inverse with run-time K: 1 = per-mixture constants cached in LDS
-    int reverse, pad_in_transform, pad_output, use_reg;
-    double reg_max, reg_factor;
-    FastDiv div_d, div_da;
-    FastDiv div_upi;        // fp32 forward kernel: staging units per item
-};
-
-__device__ __forceinline__ double safe_log(double x) { return log(fmax(x, 1e-22)); }
-
-// F.softplus (beta 1, threshold 20) and F.logsigmoid in fp64, as torch evaluates them
-__device__ __forceinline__ double softplus64(double x) { return x > 20.0 ? x : log1p(exp(x)); }
 
 // Per-element parameter access.  FUSED: read the fp32 subnet row and apply the tanh bounds in fp32
 // exactly like get_mixt_params (:156-162) before widening; SPLIT: read the fp64 tensors.
@@ -487,47 +444,6 @@ __global__ __launch_bounds__(kBlock) void mixture_kernel(MixArgs a, RowTiling tl
 //     element routine, which reproduces the reference's clamps (safe_log 1e-22) and rounding there.
 // Differences to the fp64 kernel on the fast branch: <= 3e-6 absolute in z_out / per-element log-det
 // (tests/test_gpu_parity.py::test_mixture_fast_vs_exact).  The per-sample log-det is still summed in fp64.
-constexpr float kLog2eF = 1.4426950408889634f;
-constexpr float kLn2F = 0.6931471805599453f;
-
-struct BoundTab {       // tanh bound of one raw parameter: v -> f tanh(v / max(f,1)) = f - 2f / (2^{v x3} + 1)
-    float x3, m2f, f;
-};
-__device__ __forceinline__ BoundTab make_bound(float raw_sf) {
-    const float f = expf(raw_sf);
-    BoundTab b;
-    b.x3 = 2.8853900817779268f / fmaxf(f, 1.f);
-    b.m2f = -2.f * f;
-    b.f = f;
-    return b;
-}
-__device__ __forceinline__ float apply_bound(float v, const BoundTab& b) {
-    return fmaf(__builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(v * b.x3) + 1.f), b.m2f, b.f);
-}
-
-// G = lanes per item: 1, or 4 for a run-time K too large to stage 64 rows per wave (the language model's K = 51
-// rows are 620 bytes): a pass then covers 16 items, lane g of an item takes the mixtures k = g (mod 4) and the four
-// partial sums are combined by xor-shuffles (symmetric, so the four lanes stay bit-identical and take the same
-// branches).
-template <int G>
-__device__ __forceinline__ float gsum(float v) {
-    if (G >= 2) v += __shfl_xor(v, 1, kWave);
-    if (G >= 4) v += __shfl_xor(v, 2, kWave);
-    return v;
-}
-template <int G>
-__device__ __forceinline__ float gmax(float v) {
-    if (G >= 2) v = fmaxf(v, __shfl_xor(v, 1, kWave));
-    if (G >= 4) v = fmaxf(v, __shfl_xor(v, 2, kWave));
-    return v;
-}
-template <int G>
-__device__ __forceinline__ float gmin(float v) {
-    if (G >= 2) v = fminf(v, __shfl_xor(v, 1, kWave));
-    if (G >= 4) v = fminf(v, __shfl_xor(v, 2, kWave));
-    return v;
-}
-
 template <int KT, bool REVERSE, int G = 1>
 __global__ __launch_bounds__(kBlock) void mixture_f32_kernel(MixArgs a, RowTiling tl, int PS, int strip) {
     static_assert(G == 1 || KT == 0, "several lanes per item only with a run-time K");
@@ -958,6 +874,17 @@ __global__ __launch_bounds__(kBlock) void mixture_params_kernel(const float* nn,
     }
 }
 
+// fallback of cnf_mixture_coupling_nll: per-sample NLL -> the 64 fixed-point batch-sum words
+__global__ void nll_to_acc_kernel(const float* nll, long long* acc, int B) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row < B)
+        atomicAdd(reinterpret_cast<unsigned long long*>(acc) + (size_t)(row & 63) * kAccStride,
+                  (unsigned long long)__double2ll_rn((double)nll[row] * 4294967296.0));
+}
+
+static int g_mix_kernel = 0;     // 0: token-pass kernel first; 1: round-1 fp32 kernel (A/B and tests)
+static int g_mix_lanes = 0;      // lanes per item of the token-pass kernel with a run-time K: 0 = automatic, 1 / 2 / 4
+
 // Which channels are transformed.  The caller knows the (tiny, constant) coupling mask on the host
 // and passes the list of transformed channels; without it every item tests the mask itself.
 static void fill_act(MixArgs& a, const int* act_host, int n_act) {
@@ -1017,7 +944,26 @@ static int launch_mixture(MixArgs& a, bool split, const int* act_host, int n_act
             threads = kBlock;
         }
     }
-    // fast math mode: fp32 kernel on LDS-staged parameter rows (forward; inverse when the Newton mode is selected)
+    // fast math mode: fp32 kernels on LDS-staged parameter rows (forward; inverse when the Newton mode is selected).
+    // First choice is the token-pass kernel on DMA-staged rows (cnf_mixture_tok.hip); shapes it is not built for
+    // (transformed channels not a contiguous range, unaligned nn_out) take the round-1 kernel below.
+    if (!split && math_mode() == 1 && (!a.reverse || inverse_mode() == 1) && g_mix_kernel != 1) {
+        if (launch_mixture_tok(a, st, g_mix_lanes)) return launch_status(who);
+    }
+    if (a.nll_out) {
+        // the token-pass kernel declined (or another math / inverse mode is selected): same results from the plain
+        // coupling followed by the separate prior / NLL kernel (and one tiny launch for the fixed-point batch sum)
+        MixArgs b = a;
+        b.nll_out = nullptr; b.neglog_out = nullptr; b.nll_acc = nullptr; b.length = nullptr;
+        const int rc = launch_mixture(b, split, act_host, n_act, st, who);
+        if (rc != CNF_OK) return rc;
+        const float sigma = 1.f / a.prior.inv_sigma;
+        const int rc2 = cnf_prior_nll(a.z_out, a.pad, a.ldj_out, a.length, a.neglog_out, a.nll_out, nullptr, a.B, a.N, a.D,
+                                      sigma, a.prior.log_sigma, (cnf_stream_t)st);
+        if (rc2 != CNF_OK) return rc2;
+        if (a.nll_acc) CNF_LAUNCH(nll_to_acc_kernel, dim3((a.B + kBlock - 1) / kBlock), dim3(kBlock), 0, st, a.nll_out, a.nll_acc, a.B);
+        return launch_status(who);
+    }
     if (!split && math_mode() == 1 && (!a.reverse || inverse_mode() == 1)) {
         // smaller tiles than the fp64 kernel: at ~100 VGPRs four waves per SIMD are resident, and a
         // config-sized batch (5e5 items) only fills them when a wave owns ~128 items
@@ -1096,6 +1042,83 @@ int cnf_mixture_coupling(const float* z, const float* nn_out,
     a.use_reg = (!reverse && reg_max > 0 && is_training) ? 1 : 0;
     a.reg_max = reg_max; a.reg_factor = reg_factor;
     return launch_mixture(a, false, act_host, n_act, (hipStream_t)stream, "cnf_mixture_coupling");
+}
+
+static void split_workspace(MixArgs& a, void* workspace, int64_t workspace_bytes) {
+    // [2B] int64 row sums | [B] int32 tickets
+    if (workspace && workspace_bytes >= (int64_t)a.B * 20 && (reinterpret_cast<uintptr_t>(workspace) & 7) == 0) {
+        a.ws_acc = reinterpret_cast<long long*>(workspace);
+        a.ws_cnt = reinterpret_cast<int*>(a.ws_acc + (size_t)2 * a.B);
+    }
+}
+
+int64_t cnf_mixture_workspace_bytes(int B) { return B > 0 ? (int64_t)B * 20 : 0; }
+
+void cnf_set_mixture_kernel(int which) {
+    if (which == 0 || which == 1) g_mix_kernel = which;
+}
+
+void cnf_set_mixture_lanes(int lanes_per_item) {
+    if (lanes_per_item == 0 || lanes_per_item == 1 || lanes_per_item == 2 || lanes_per_item == 4) g_mix_lanes = lanes_per_item;
+}
+
+void cnf_set_mixture_split(int waves) {
+    if (waves >= 256 && waves <= 65536) set_mixture_split_waves(waves);
+}
+
+int cnf_mixture_coupling_ws(const float* z, const float* nn_out,
+                            const float* scaling_factor, const float* mixture_scaling_factor,
+                            const float* mask, int mask_rows, int mask_cols,
+                            const int* act_host, int n_act,
+                            const float* pad, int pad_in_transform, int pad_output,
+                            const float* ldj_in, float* z_out, float* ldj_out, float* reg_out,
+                            int B, int N, int D, int K, int reverse,
+                            double reg_max, double reg_factor, int is_training,
+                            void* workspace, int64_t workspace_bytes,
+                            int* flags, cnf_stream_t stream) {
+    CNF_REQUIRE(z && nn_out && z_out && ldj_out, "cnf_mixture_coupling_ws: null tensor");
+    MixArgs a = {};
+    a.z = z; a.nn = nn_out; a.sf = scaling_factor; a.msf = mixture_scaling_factor;
+    a.mask = mask; a.pad = pad; a.ldj_in = ldj_in; a.z_out = z_out; a.ldj_out = ldj_out;
+    a.reg_out = reg_out; a.flags = flags;
+    a.B = B; a.N = N; a.D = D; a.K = K; a.mr = mask_rows; a.mc = mask_cols;
+    a.reverse = reverse != 0;
+    a.pad_in_transform = pad ? pad_in_transform : 0;
+    a.pad_output = pad ? pad_output : 0;
+    a.use_reg = (!reverse && reg_max > 0 && is_training) ? 1 : 0;
+    a.reg_max = reg_max; a.reg_factor = reg_factor;
+    split_workspace(a, workspace, workspace_bytes);
+    return launch_mixture(a, false, act_host, n_act, (hipStream_t)stream, "cnf_mixture_coupling_ws");
+}
+
+int cnf_mixture_coupling_nll(const float* z, const float* nn_out,
+                             const float* scaling_factor, const float* mixture_scaling_factor,
+                             const float* mask, int mask_rows, int mask_cols,
+                             const int* act_host, int n_act,
+                             const float* pad, int pad_in_transform, int pad_output,
+                             const float* ldj_in, float* z_out, float* ldj_out, float* reg_out,
+                             const float* length, float* neglog_out, float* nll_out, int64_t* nll_acc,
+                             int B, int N, int D, int K,
+                             double reg_max, double reg_factor, int is_training,
+                             float sigma, float log_sigma,
+                             void* workspace, int64_t workspace_bytes,
+                             int* flags, cnf_stream_t stream) {
+    CNF_REQUIRE(z && nn_out && z_out && ldj_out && nll_out, "cnf_mixture_coupling_nll: null tensor");
+    MixArgs a = {};
+    a.z = z; a.nn = nn_out; a.sf = scaling_factor; a.msf = mixture_scaling_factor;
+    a.mask = mask; a.pad = pad; a.ldj_in = ldj_in; a.z_out = z_out; a.ldj_out = ldj_out;
+    a.reg_out = reg_out; a.flags = flags;
+    a.B = B; a.N = N; a.D = D; a.K = K; a.mr = mask_rows; a.mc = mask_cols;
+    a.reverse = 0;
+    a.pad_in_transform = pad ? pad_in_transform : 0;
+    a.pad_output = pad ? pad_output : 0;
+    a.use_reg = (reg_max > 0 && is_training) ? 1 : 0;
+    a.reg_max = reg_max; a.reg_factor = reg_factor;
+    a.length = length; a.neglog_out = neglog_out; a.nll_out = nll_out;
+    a.nll_acc = reinterpret_cast<long long*>(nll_acc);
+    a.prior = make_prior_const(sigma, log_sigma);
+    split_workspace(a, workspace, workspace_bytes);
+    return launch_mixture(a, false, act_host, n_act, (hipStream_t)stream, "cnf_mixture_coupling_nll");
 }
 
 int cnf_mixture_transform(const double* z, const double* t, const double* log_s,

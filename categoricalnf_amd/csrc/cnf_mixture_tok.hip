@@ -1,0 +1,611 @@
+// Logistic-mixture CDF coupling, fp32 "token-pass" kernel (math mode 1): forward, Newton inverse, log-det and the
+// optional NLL epilogue, following mixture_cdf_layer.py:95-180, 197-276 of the reference.
+//
+// Data movement.  The coupling sub-network's output holds, per token (b, n), D blocks of P = 2 + 3K floats; only the
+// blocks of the DA transformed channels (a contiguous channel range: a channel mask keeps the first or the last
+// channels) are needed, and they are ONE contiguous span of DA * P floats per token.  A wave works in passes of
+// TPP = 64 / (DA * G) consecutive tokens: the spans of the pass are copied global -> LDS by the DMA path
+// (global_load_lds_dwordx4: 16 bytes per lane, 1 KiB per instruction, no staging registers, no ds_write), each token
+// into its own slot at the span's own 16-byte phase, so every global address is 16-byte aligned and every 128-byte
+// line of a span is fetched once.  Without a mask (D == DA) the whole pass is one contiguous span.  Then lane
+// (token, channel, g) reads its P-float row from LDS; G = 1, 2 or 4 lanes share an item (run-time K only) and
+// split its mixtures, so that a pass of the K = 51 language-model rows (620 B each) still fits ~10 KiB per wave.
+//
+// Work decomposition.  Many short rows (samples): a wave owns `rw` whole rows and adds the per-item log-det terms
+// to per-row LDS accumulators in 31.32 fixed point (integer adds are associative: the sum is independent of the
+// order, bit-reproducible).  Few long rows (training-sized batches of graphs / sentences): S workgroups x 4 waves
+// share one row, so that B = 128 rows still put thousands of waves on the 256 CUs; a workgroup combines its four
+// partial sums in wave order and, when S > 1, adds them to the row's fixed-point words in a caller-provided
+// workspace with device-scope integer atomics; the workgroup that draws the last ticket of a row finishes it and
+// leaves the workspace zeroed for the next launch.
+//
+// Arithmetic (unchanged from round 1): fp32 on hardware exp2 / log2 / rcp with BOTH tails as
+// sums of positive terms; elements with u or 1 - u below 1e-9, or an underflowing PDF sum, take the fp64 branch that
+// reproduces the reference's clamps.
+#include "cnf_mixture.h"
+
+#include <algorithm>
+
+namespace cnf {
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_void_t;
+
+constexpr double kFix32 = 4294967296.0;
+constexpr int kMaxRowSlots = 64;       // rows one wave tile may hold
+constexpr int kMaxDmaInstr = 24;       // 1 KiB DMA instructions per pass
+
+struct TokGeom {
+    int d0;             // first transformed channel
+    int DA;             // transformed channels per token
+    int lpt;            // lanes per token = DA * G
+    int TPP;            // tokens per pass
+    int ncopy;          // D - DA channels per token that pass through
+    int contig;         // D == DA: a pass is one contiguous span
+    int tokstride;      // bytes between the spans of consecutive tokens = D * P * 4
+    int slot;           // LDS bytes per token slot (contig: == tokstride)
+    int stage_bytes;    // LDS bytes of one wave's stage (multiple of 1 KiB)
+    int acc_off;        // byte offset of the accumulator region in dynamic LDS
+    int split;          // 0: rw whole rows per wave tile; 1: S workgroups x 4 waves per row
+    int rw;             // rows per wave tile (split == 0)
+    int S;              // workgroups per row (split == 1)
+    int ppr;            // passes per row = ceil(N / TPP)
+    long ntiles;        // wave tiles (split == 0)
+    FastDiv div_slot, div_n, div_lpt, div_nc;
+};
+
+__device__ __forceinline__ long long to_fix(double v) { return __double2ll_rn(v * kFix32); }
+
+template <int KT, bool REVERSE, int G, bool NLL>
+__global__ __launch_bounds__(kBlock) void mixture_tok_kernel(MixArgs a, TokGeom gm) {
+    static_assert(G == 1 || KT == 0, "several lanes per item only with a run-time K");
+    static_assert(!(NLL && REVERSE), "the NLL epilogue belongs to the forward pass");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int K = KT > 0 ? KT : a.K;
+    const int P = a.P;
+    char* stage_b = smem + (size_t)wave * gm.stage_bytes;
+    BoundTab* sf_tab = reinterpret_cast<BoundTab*>(smem + (size_t)kWavesPerBlock * gm.stage_bytes);
+    BoundTab* msf_tab = sf_tab + a.D;
+    // accumulators: split == 0: [wave][rw][2] fixed-point row sums; split == 1: [wave][2] fp64 wave partials
+    long long* rowacc = reinterpret_cast<long long*>(smem + gm.acc_off) + (size_t)wave * gm.rw * 2;
+    double* wpart = reinterpret_cast<double*>(smem + gm.acc_off);
+    for (int i = threadIdx.x; i < a.D; i += blockDim.x)
+        if (a.sf) sf_tab[i] = make_bound(a.sf[i]);
+    for (int i = threadIdx.x; i < a.D * K; i += blockDim.x)
+        if (a.msf) msf_tab[i] = make_bound(a.msf[i]);
+    if (!gm.split)
+        for (int i = lane; i < gm.rw * 2; i += kWave) rowacc[i] = 0;
+    __syncthreads();
+
+    // ---- this wave's tile: tokens [0, ntok) counted from (row0, n_first)
+    int row0, nrows, n_first, ntok;
+    if (!gm.split) {
+        const long tile = (long)blockIdx.x * kWavesPerBlock + wave;
+        if (tile >= gm.ntiles) return;            // no barrier follows in this mode
+        row0 = (int)(tile * gm.rw);
+        nrows = min(gm.rw, a.B - row0);
+        n_first = 0;
+        ntok = nrows * a.N;
+    } else {
+        // the row's passes are dealt to its 4 S waves in contiguous, balanced runs (they differ by at most one pass)
+        row0 = (int)(blockIdx.x / (unsigned)gm.S);
+        const int seg = (int)blockIdx.x - row0 * gm.S;
+        const int w = seg * kWavesPerBlock + wave, nw = gm.S * kWavesPerBlock;
+        const int p_lo = (w * gm.ppr) / nw, p_hi = ((w + 1) * gm.ppr) / nw;
+        n_first = p_lo * gm.TPP;
+        ntok = max(0, min(a.N, p_hi * gm.TPP) - n_first);
+        nrows = 1;
+    }
+    const size_t tok_g0 = (size_t)row0 * a.N + n_first;
+    const float* z_tile = a.z + tok_g0 * a.D;
+    float* zo_tile = a.z_out + tok_g0 * a.D;
+    const float* pad_tile = a.pad ? a.pad + tok_g0 : nullptr;
+    const char* nn_lo = reinterpret_cast<const char*>(a.nn);
+    const char* nn_last = nn_lo + ((size_t)a.B * a.N * a.D * P - 4) * sizeof(float);      // last aligned 16-byte chunk
+    const char* span0 = nn_lo + (tok_g0 * a.D + gm.d0) * (size_t)P * sizeof(float);        // first token's span
+
+    // lane -> (token in pass, channel, share of the mixtures)
+    const int tli = (int)fdiv((uint32_t)lane, gm.div_lpt);
+    const int rem = lane - tli * gm.lpt;
+    const int j = rem / G, sub = rem - j * G;
+    const int d = gm.d0 + j;
+    const BoundTab* mt = msf_tab + d * K;
+    const PriorConst prior = a.prior;
+    bool bad = false, range = false, badl = false;
+    double acc_ldj = 0.0, acc_nlp = 0.0;          // split mode: this lane's running sums
+
+    for (int tp = 0; tp < ntok; tp += gm.TPP) {                                   // wave-uniform
+        const int npt = min(gm.TPP, ntok - tp);
+        const bool valid = tli < npt;
+        const int tokl = tp + (valid ? tli : 0);
+        int rl = 0, n = n_first + tokl;
+        if (!gm.split) {
+            rl = (int)fdiv((uint32_t)tokl, gm.div_n);
+            n = tokl - rl * a.N;
+        }
+        const float pv = pad_tile ? pad_tile[tokl] : 1.f;
+        const float x = valid ? z_tile[(size_t)tokl * a.D + d] : 0.f;
+        bool active = valid;
+        if (a.per_item_mask) active = active && mask_at(a.mask, a.mr, a.mc, n, d) == 0.f;
+        if (a.pad_in_transform && pv == 0.f) active = false;
+
+        // ---- stage the parameter spans of the pass: DMA, 16 bytes per lane, 1 KiB of LDS per instruction
+        const char* pass_addr = span0 + (size_t)tp * gm.tokstride;
+        int my_pos;             // byte offset of this lane's row in the stage
+        if (gm.contig) {
+            const int off0 = __builtin_amdgcn_readfirstlane((int)(reinterpret_cast<uintptr_t>(pass_addr) & 15));
+            const char* abase = pass_addr - off0;
+            const int ni = (npt * gm.tokstride + off0 + 1023) >> 10;
+            for (int i = 0; i < ni; ++i) {
+                const char* gp = abase + ((size_t)(i * kWave + lane) << 4);
+                gp = gp > nn_last ? nn_last : gp;
+                __builtin_amdgcn_global_load_lds((glb_void_t*)gp, (lds_void_t*)(stage_b + (i << 10)), 16, 0, 0);
+            }
+            my_pos = off0 + tli * gm.tokstride + j * P * 4;
+        } else {
+            const int ni = (npt * gm.slot + 1023) >> 10;
+            for (int i = 0; i < ni; ++i) {
+                const uint32_t cb = (uint32_t)(i * kWave + lane) << 4;              // byte offset in the stage
+                const uint32_t s = fdiv(cb, gm.div_slot);
+                const uint32_t o = cb - s * (uint32_t)gm.slot;
+                const char* ta = pass_addr + (size_t)s * gm.tokstride;
+                const char* gp = ta - (reinterpret_cast<uintptr_t>(ta) & 15) + o;
+                gp = gp > nn_last ? nn_last : gp;
+                __builtin_amdgcn_global_load_lds((glb_void_t*)gp, (lds_void_t*)(stage_b + (i << 10)), 16, 0, 0);
+            }
+            const char* ta = pass_addr + (size_t)tli * gm.tokstride;
+            my_pos = tli * gm.slot + (int)(reinterpret_cast<uintptr_t>(ta) & 15) + j * P * 4;
+        }
+        if (!valid) my_pos = 0;
+        float* my = reinterpret_cast<float*>(stage_b + my_pos);
+        wave_lds_sync();
+
+        float of = a.pad_output ? x * pv : x;       // a lane that transforms nothing copies its element through
+        float contrib = 0.f;
+        double contrib64 = 0.0;
+        bool use64 = false;
+        if (active && REVERSE) {
+            // ---- inverse (:125-134, :235-264) in fp32: safeguarded Newton on the two-sided CDF.  u = sigmoid(v)
+            // is clamped to [1e-5, 1 - 1e-5] by the reference, so the root lies where fp32 sums of positive
+            // terms are accurate to ~1e-6 relative in BOTH tails: solve cdf(x) = u se for u <= 1/2 and
+            // ccdf(x) = (1 - u) se otherwise.  A relative error eps of the sum moves x by ~eps * s_k.
+            const float t = my[0];
+            float log_s = my[1];
+            if (a.sf) log_s = apply_bound(log_s, sf_tab[d]);
+            const float v = x * __builtin_amdgcn_exp2f(-log_s * kLog2eF) - t;
+            const float ev = __builtin_amdgcn_exp2f(-fabsf(v) * kLog2eF);
+            const float rv = __builtin_amdgcn_rcpf(1.f + ev);
+            const float mixt_ldj = fabsf(v) + 2.f * kLn2F * __builtin_amdgcn_logf(1.f + ev);
+            float usmall = fmaxf(ev * rv, 1e-5f), ubig = fminf(rv, 1.f - 1e-5f);     // (:130) clamp
+            const bool upper = v >= 0.f;                    // u > 1/2
+            const float u = upper ? ubig : usmall, uc = upper ? usmall : ubig;
+            if (!(u > 0.f && u < 1.f)) range = true;
+            const float logit_u = (__builtin_amdgcn_logf(u) - __builtin_amdgcn_logf(uc)) * kLn2F;
+            constexpr int KK = KT > 0 ? KT : 1;
+            float wr[KK], isr[KK], mur[KK];
+            float mx = -INFINITY;
+            if (KT > 0) {
+#pragma unroll
+                for (int k = 0; k < KK; ++k) mx = fmaxf(mx, my[2 + k]);
+            } else {
+                for (int k = sub; k < K; k += G) mx = fmaxf(mx, my[2 + k]);
+                mx = gmax<G>(mx);
+            }
+            float se = 0.f, spread = 0.f, lb = INFINITY, ub = -INFINITY, qsum = 0.f;
+            auto setup = [&](int k) {
+                const float lsk = my[2 + 2 * K + k];
+                const float ls = a.msf ? apply_bound(lsk, mt[k]) : lsk;
+                const float w = __builtin_amdgcn_exp2f((my[2 + k] - mx) * kLog2eF);
+                const float sk = __builtin_amdgcn_exp2f(ls * kLog2eF);
+                const float ik = __builtin_amdgcn_rcpf(sk);
+                const float mk = my[2 + K + k];
+                // every component's own u-quantile: the mixture quantile lies between their min and max
+                const float qk = fmaf(sk, logit_u, mk);
+                se += w;
+                spread += sk;
+                lb = fminf(lb, qk);
+                ub = fmaxf(ub, qk);
+                qsum = fmaf(w, qk, qsum);
+                if (KT > 0) {
+                    wr[k < KK ? k : 0] = w; isr[k < KK ? k : 0] = ik; mur[k < KK ? k : 0] = mk;
+                } else {
+                    my[2 + k] = w;              // run-time K: the constants replace the raw row in LDS
+                    my[2 + 2 * K + k] = ik;
+                }
+            };
+            if (KT > 0) {
+#pragma unroll
+                for (int k = 0; k < KK; ++k) setup(k);
+            } else {
+                for (int k = sub; k < K; k += G) setup(k);
+                se = gsum<G>(se); spread = gsum<G>(spread); qsum = gsum<G>(qsum);
+                lb = gmin<G>(lb); ub = gmax<G>(ub);
+            }
+            const float target = (upper ? uc : u) * se;
+            const float tol_scale = 1e-7f * spread;
+            float xb = fminf(fmaxf(qsum * __builtin_amdgcn_rcpf(se), lb), ub);
+            float dx_prev = ub - lb, dens = 0.f, diff = INFINITY;
+            auto eval = [&](float xq, float& f_out, float& dens_out) {
+                float cdf = 0.f, ccdf = 0.f, dn = 0.f;
+                auto one = [&](float wk, float ik, float mk) {
+                    const float zk = (xq - mk) * ik;
+                    const float e = __builtin_amdgcn_exp2f(-fabsf(zk) * kLog2eF);
+                    const float rr = __builtin_amdgcn_rcpf(1.f + e);
+                    const float er = e * rr;
+                    const bool pos = zk >= 0.f;
+                    cdf = fmaf(wk, pos ? rr : er, cdf);
+                    ccdf = fmaf(wk, pos ? er : rr, ccdf);
+                    dn = fmaf(wk * ik, er * rr, dn);
+                };
+                if (KT > 0) {
+#pragma unroll
+                    for (int k = 0; k < KK; ++k) one(wr[k], isr[k], mur[k]);
+                } else {
+                    for (int k = sub; k < K; k += G) one(my[2 + k], my[2 + 2 * K + k], my[2 + K + k]);
+                    cdf = gsum<G>(cdf); ccdf = gsum<G>(ccdf); dn = gsum<G>(dn);
+                }
+                f_out = upper ? target - ccdf : cdf - target;       // increasing in x either way
+                dens_out = dn;
+            };
+            for (int iter = 0; iter < 64; ++iter) {
+                float f;
+                eval(xb, f, dens);
+                float nx;
+                if (f > 0.f) {
+                    nx = 0.5f * (xb + lb);
+                    ub = xb;
+                } else {
+                    nx = 0.5f * (xb + ub);
+                    lb = xb;
+                }
+                // rtsafe: Newton step when it stays in the bracket and at least halves the previous step
+                if (dens > 0.f && fabsf(2.f * f) <= fabsf(dx_prev * dens)) {
+                    const float xn = xb - f * __builtin_amdgcn_rcpf(dens);
+                    if (xn >= lb && xn <= ub) nx = xn;
+                }
+                diff = fabsf(nx - xb);
+                dx_prev = diff;
+                xb = nx;
+                if (!(diff > fmaf(1e-7f, fabsf(xb), tol_scale))) break;
+            }
+            if (diff > 1e-5f * (fabsf(xb) + spread)) {      // left the loop far from converged: density at the final point
+                float f;
+                eval(xb, f, dens);
+            }
+            const float lpdf = (__builtin_amdgcn_logf(dens) - __builtin_amdgcn_logf(se)) * kLn2F;
+            of = xb;
+            if (a.pad_output) of = of * pv;
+            contrib = log_s + mixt_ldj + lpdf;
+        }
+        if (active && !REVERSE) {
+            const float t = my[0];
+            float log_s = my[1];
+            if (a.sf) log_s = apply_bound(log_s, sf_tab[d]);
+            constexpr int KK = KT > 0 ? KT : 1;
+            float lp[KK], mu[KK], lsr[KK];
+            float mx = -INFINITY;
+            if (KT > 0) {
+#pragma unroll
+                for (int k = 0; k < KK; ++k) {
+                    lp[k] = my[2 + k];
+                    mu[k] = my[2 + KK + k];
+                    lsr[k] = my[2 + 2 * KK + k];
+                }
+#pragma unroll
+                for (int k = 0; k < KK; ++k) mx = fmaxf(mx, lp[k]);
+            } else {
+                for (int k = sub; k < K; k += G) mx = fmaxf(mx, my[2 + k]);
+                mx = gmax<G>(mx);
+            }
+            float se = 0.f, cdf = 0.f, ccdf = 0.f, pdf = 0.f;
+            auto one = [&](float lpk, float muk, float lsk, int k) {
+                const float ls = a.msf ? apply_bound(lsk, mt[k]) : lsk;
+                const float inv_s = __builtin_amdgcn_exp2f(-ls * kLog2eF);
+                const float w = __builtin_amdgcn_exp2f((lpk - mx) * kLog2eF);
+                const float zk = (x - muk) * inv_s;
+                const float e = __builtin_amdgcn_exp2f(-fabsf(zk) * kLog2eF);
+                const float rr = __builtin_amdgcn_rcpf(1.f + e);
+                const float er = e * rr;
+                const bool pos = zk >= 0.f;
+                se += w;
+                cdf = fmaf(w, pos ? rr : er, cdf);
+                ccdf = fmaf(w, pos ? er : rr, ccdf);
+                pdf = fmaf(w * inv_s, er * rr, pdf);
+            };
+            if (KT > 0) {
+#pragma unroll
+                for (int k = 0; k < KK; ++k) one(lp[k], mu[k], lsr[k], k);
+            } else {
+                for (int k = sub; k < K; k += G) one(my[2 + k], my[2 + K + k], my[2 + 2 * K + k], k);
+                se = gsum<G>(se); cdf = gsum<G>(cdf); ccdf = gsum<G>(ccdf); pdf = gsum<G>(pdf);
+            }
+            double reg = 0.0;
+            const float inv_se = __builtin_amdgcn_rcpf(se);
+            const float u = cdf * inv_se, uc = ccdf * inv_se;
+            if (u > 1e-9f && uc > 1e-9f && pdf > 1e-30f) {
+                const float l2se = __builtin_amdgcn_logf(se);
+                const float lu = (__builtin_amdgcn_logf(cdf) - l2se) * kLn2F;
+                const float l1u = (__builtin_amdgcn_logf(ccdf) - l2se) * kLn2F;
+                const float lpdf = (__builtin_amdgcn_logf(pdf) - l2se) * kLn2F;
+                float regf = 0.f;
+                if (a.use_reg) {
+                    const float rmax = (float)a.reg_max;
+                    const float r1 = lu * 0.43429448190325176f, r2 = l1u * 0.43429448190325176f;
+                    regf = (fminf(r1, -rmax) + rmax) + (fminf(r2, -rmax) + rmax);
+                }
+                of = ((lu - l1u) + t) * __builtin_amdgcn_exp2f(log_s * kLog2eF);
+                contrib = log_s + (-lu - l1u) + lpdf + regf * (float)a.reg_factor;
+                reg = (double)regf;
+            } else {
+                // rare: a tail or an underflow.  The reference's fp64 arithmetic (u, then 1 - u by subtraction,
+                // safe_log clamps; :100-123, :217-233) on the staged row, one mixture at a time — rolled loops
+                // keep this branch's registers below the fast path's.
+                const double xd = (double)x;
+                double sed = 0.0, cdfd = 0.0, pdfd = 0.0;
+#pragma clang loop unroll(disable)
+                for (int k = 0; k < K; ++k) {
+                    const float lsf = a.msf ? apply_bound(my[2 + 2 * K + k], mt[k]) : my[2 + 2 * K + k];
+                    const double wd = exp((double)my[2 + k] - (double)mx);
+                    const double isd = exp(-(double)lsf);
+                    const double zd = (xd - (double)my[2 + K + k]) * isd;
+                    const double ed = exp(-fabs(zd));
+                    const double rd = 1.0 / (1.0 + ed);
+                    sed += wd;
+                    cdfd += wd * (zd >= 0.0 ? rd : ed * rd);
+                    pdfd += wd * isd * (ed * rd * rd);
+                }
+                const double ud = cdfd / sed;
+                double lpdfd;
+                if (pdfd > 1e-290) {
+                    lpdfd = log(pdfd / sed);
+                } else {
+                    // log-space form (:217-223)
+                    const double lse_pi = (double)mx + log(sed);
+                    double m = -INFINITY;
+#pragma clang loop unroll(disable)
+                    for (int k = 0; k < K; ++k) {
+                        const float lsf = a.msf ? apply_bound(my[2 + 2 * K + k], mt[k]) : my[2 + 2 * K + k];
+                        const double zd = (xd - (double)my[2 + K + k]) * exp(-(double)lsf);
+                        m = fmax(m, (double)my[2 + k] - lse_pi + zd - (double)lsf - 2.0 * softplus64(zd));
+                    }
+                    double ssum = 0.0;
+#pragma clang loop unroll(disable)
+                    for (int k = 0; k < K; ++k) {
+                        const float lsf = a.msf ? apply_bound(my[2 + 2 * K + k], mt[k]) : my[2 + 2 * K + k];
+                        const double zd = (xd - (double)my[2 + K + k]) * exp(-(double)lsf);
+                        ssum += exp((double)my[2 + k] - lse_pi + zd - (double)lsf - 2.0 * softplus64(zd) - m);
+                    }
+                    lpdfd = m + log(ssum);
+                }
+                const double lud = safe_log(ud), l1ud = safe_log(1.0 - ud);
+                if (a.use_reg) {
+                    const double r1 = lud / kLn10, r2 = l1ud / kLn10;
+                    reg = (fmin(r1, -a.reg_max) + a.reg_max) + (fmin(r2, -a.reg_max) + a.reg_max);
+                }
+                const double yd = ud >= 1e-22 ? lud - l1ud : -safe_log(1.0 / ud - 1.0);
+                of = (float)((yd + (double)t) * exp((double)log_s));
+                contrib64 = (double)log_s + (-lud - l1ud) + lpdfd + reg * a.reg_factor;
+                use64 = true;
+            }
+            if (a.pad_output) of = of * pv;
+            if (sub == 0 && a.use_reg && a.reg_out && reg != 0.0) atomicAdd(&a.reg_out[row0 + rl], (float)reg);
+        }
+        // ---- outputs of the item lanes
+        const bool owner = valid && sub == 0;       // one lane per element stores and accounts
+        if (owner) {
+            zo_tile[(size_t)tokl * a.D + d] = of;
+            bad |= isnan(of);
+        }
+        double cd = use64 ? contrib64 : (double)contrib;
+        if (!owner || !active) cd = 0.0;
+        badl |= isnan(cd);
+        double nlp = 0.0;
+        if (NLL && owner) nlp = (double)(-prior_logp(of, prior) * (pad_tile ? pv : 1.f));
+        if (gm.split) {
+            acc_ldj += cd;
+            if (NLL) acc_nlp += nlp;
+        } else if (owner) {
+            if (active) atomicAdd(reinterpret_cast<unsigned long long*>(rowacc + rl * 2), (unsigned long long)to_fix(cd));
+            if (NLL) atomicAdd(reinterpret_cast<unsigned long long*>(rowacc + rl * 2 + 1), (unsigned long long)to_fix(nlp));
+        }
+        // ---- the pass's channels that are not transformed: copied through (times the padding mask)
+        if (gm.ncopy > 0) {
+            const int ne = npt * gm.ncopy;
+            for (int e = lane; e < ne; e += kWave) {
+                const int tk = (int)fdiv((uint32_t)e, gm.div_nc);
+                const int jj = e - tk * gm.ncopy;
+                const int c = jj < gm.d0 ? jj : jj + gm.DA;
+                const int tl2 = tp + tk;
+                const float zv = z_tile[(size_t)tl2 * a.D + c];
+                const float pv2 = pad_tile ? pad_tile[tl2] : 1.f;
+                const float o = a.pad_output ? zv * pv2 : zv;
+                zo_tile[(size_t)tl2 * a.D + c] = o;
+                if (NLL) {
+                    const double lp2 = (double)(-prior_logp(o, prior) * (pad_tile ? pv2 : 1.f));
+                    if (gm.split) {
+                        acc_nlp += lp2;
+                    } else {
+                        const int rl2 = (int)fdiv((uint32_t)tl2, gm.div_n);
+                        atomicAdd(reinterpret_cast<unsigned long long*>(rowacc + rl2 * 2 + 1), (unsigned long long)to_fix(lp2));
+                    }
+                }
+            }
+        }
+        wave_lds_sync();      // the stage is overwritten by the next pass
+    }
+
+    // ---- per-sample results
+    auto finish = [&](int row, double ldj_sum, double nlp_sum) {
+        const float v = (a.ldj_in ? a.ldj_in[row] : 0.f) + (float)(REVERSE ? -ldj_sum : ldj_sum);
+        a.ldj_out[row] = v;
+        if (isnan(v)) raise_flag(a.flags, CNF_FLAG_NAN_LDJ);
+        if (NLL) {
+            // task.py:96-118: nll = (-ldj + neglog) / length
+            const float neglog = (float)nlp_sum;
+            const float len = a.length ? a.length[row] : (float)a.N;
+            if (a.neglog_out) a.neglog_out[row] = neglog;
+            const float nll = (-v) / len + neglog / len;
+            a.nll_out[row] = nll;
+            if (a.nll_acc)
+                atomicAdd(reinterpret_cast<unsigned long long*>(a.nll_acc) + (size_t)(row & 63) * kAccStride,
+                          (unsigned long long)__double2ll_rn((double)nll * kFix32));
+        }
+    };
+    if (!gm.split) {
+        wave_lds_sync();
+        if (lane < nrows)
+            finish(row0 + lane, (double)rowacc[lane * 2] * (1.0 / kFix32), (double)rowacc[lane * 2 + 1] * (1.0 / kFix32));
+    } else {
+        acc_ldj = wave_sum(acc_ldj);
+        if (NLL) acc_nlp = wave_sum(acc_nlp);
+        if (lane == 0) {
+            wpart[wave * 2] = acc_ldj;
+            wpart[wave * 2 + 1] = acc_nlp;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t0 = 0.0, t1 = 0.0;
+            for (int w = 0; w < kWavesPerBlock; ++w) {
+                t0 += wpart[w * 2];
+                t1 += wpart[w * 2 + 1];
+            }
+            if (gm.S == 1) {
+                finish(row0, t0, t1);
+            } else {
+                // fixed-point row words in the workspace: device-scope integer atomics on both sides.  The adds
+                // return (and are waited for) before the ticket is drawn, so the last arriver sees every term.
+                unsigned long long* wa = reinterpret_cast<unsigned long long*>(a.ws_acc) + (size_t)row0 * 2;
+                unsigned long long o0 = atomicAdd(wa, (unsigned long long)to_fix(t0));
+                unsigned long long o1 = NLL ? atomicAdd(wa + 1, (unsigned long long)to_fix(t1)) : 0ull;
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(o0), "+v"(o1) : : "memory");
+                const int ticket = atomicAdd(a.ws_cnt + row0, 1);
+                if (ticket == gm.S - 1) {
+                    const long long s0 = (long long)atomicExch(wa, 0ull);
+                    const long long s1 = NLL ? (long long)atomicExch(wa + 1, 0ull) : 0ll;
+                    atomicExch(a.ws_cnt + row0, 0);
+                    finish(row0, (double)s0 * (1.0 / kFix32), (double)s1 * (1.0 / kFix32));
+                }
+            }
+        }
+    }
+    if (bad) raise_flag(a.flags, CNF_FLAG_NAN_Z);
+    if (badl) raise_flag(a.flags, CNF_FLAG_NAN_LDJ);
+    if (range) raise_flag(a.flags, CNF_FLAG_RANGE);
+}
+
+// ---- host side: geometry ------------------------------------------------------------------------------------
+static int g_split_waves = 2048;      // waves a split launch aims at (cnf_set_mixture_split)
+void set_mixture_split_waves(int w) { g_split_waves = w; }
+
+// Returns false when the shape is outside what this kernel is built for (the caller falls back to the fp64 kernel).
+static bool make_tok_geom(const MixArgs& a, int kt, int force_g, TokGeom& gm, int& G, size_t& lds) {
+    const int P = a.P;
+    // transformed channels must be one contiguous range
+    int d0 = 0, DA = a.D;
+    if (!a.per_item_mask) {
+        if (a.act_bits == 0) return false;
+        d0 = __builtin_ctzll(a.act_bits);
+        DA = __builtin_popcountll(a.act_bits);
+        const unsigned long long run = (DA >= 64 ? ~0ull : ((1ull << DA) - 1ull)) << d0;
+        if (run != a.act_bits) return false;
+    }
+    if ((reinterpret_cast<uintptr_t>(a.nn) & 15) != 0) return false;
+    if (((size_t)a.B * a.N * a.D * P) % 4 != 0) return false;
+    const int span = DA * P * 4;
+    const int tokstride = a.D * P * 4;
+    const bool contig = DA == a.D;
+    const bool phase0 = tokstride % 16 == 0 && (d0 * P * 4) % 16 == 0;       // every span starts on a 16-byte boundary
+    const int slot = contig ? tokstride : ((span + (phase0 ? 0 : 12) + 15) & ~15);
+    if (slot >= 32768) return false;
+    auto stage_of = [&](int g, int& tpp) {
+        tpp = kWave / (DA * g);
+        if (tpp < 1) return -1;
+        const int bytes = contig ? tpp * tokstride + 12 : tpp * slot;
+        return ((bytes + 1023) >> 10) << 10;
+    };
+    G = 1;
+    int tpp = 0, stage = stage_of(1, tpp);
+    if (kt == 0) {
+        const int cands[3] = {1, 2, 4};
+        for (int c = 0; c < 3; ++c) {
+            int tp2 = 0;
+            const int st = stage_of(cands[c], tp2);
+            if (st < 0) break;
+            G = cands[c]; tpp = tp2; stage = st;
+            if (force_g ? cands[c] == force_g : st <= 12 * 1024) break;
+        }
+    }
+    if (stage < 0 || stage > kMaxDmaInstr * 1024) return false;
+    gm.d0 = d0; gm.DA = DA; gm.lpt = DA * G; gm.TPP = tpp; gm.ncopy = a.D - DA; gm.contig = contig ? 1 : 0;
+    gm.tokstride = tokstride; gm.slot = slot; gm.stage_bytes = stage;
+    gm.div_slot = make_fastdiv((uint32_t)slot);
+    gm.div_n = make_fastdiv((uint32_t)a.N);
+    gm.div_lpt = make_fastdiv((uint32_t)gm.lpt);
+    gm.div_nc = make_fastdiv((uint32_t)std::max(gm.ncopy, 1));
+    if (a.N >= 65536) return false;
+
+    // decomposition
+    const int ppr = (a.N + tpp - 1) / tpp;                      // passes per row
+    const int target_tokens = std::max(tpp, mixture_tile_items() / std::max(DA, 1));
+    int rw = 1;
+    {
+        double best = -1.0;
+        const int rmax = std::max(1, std::min(std::min(kMaxRowSlots, a.B), target_tokens / a.N));
+        for (int r = 1; r <= rmax; ++r) {
+            const int tk = r * a.N;
+            const double eff = (double)tk / (double)(((tk + tpp - 1) / tpp) * tpp);
+            if (eff >= best - 1e-9) {
+                best = std::max(best, eff);
+                rw = r;
+            }
+        }
+    }
+    const long tiles0 = ((long)a.B + rw - 1) / rw;
+    gm.split = 0; gm.rw = rw; gm.S = 1; gm.ntiles = tiles0;
+    gm.ppr = ppr;
+    if (tiles0 < 2048 && ppr >= 2 && (long)ppr * kWavesPerBlock * 64 < 0x7fffffffL) {
+        // few long rows: S workgroups x 4 waves per row, each wave a run of whole passes
+        int S = (int)std::max<long>(1, (g_split_waves + 4L * a.B - 1) / (4L * a.B));
+        S = std::min(S, std::max(1, ppr / kWavesPerBlock));
+        if (S > 1 && !(a.ws_acc && a.ws_cnt)) S = 1;      // no workspace: the four waves of ONE workgroup share a row
+        if ((long)a.B * S * kWavesPerBlock > tiles0) {
+            gm.split = 1; gm.S = S; gm.rw = 1;
+        }
+    }
+    if ((long)gm.rw * a.N >= 65536) return false;
+    const size_t tabs = (((size_t)(a.D + a.D * a.K) * sizeof(BoundTab)) + 15) & ~(size_t)15;
+    gm.acc_off = (int)((size_t)kWavesPerBlock * stage + tabs);
+    const size_t accb = gm.split ? (size_t)kWavesPerBlock * 2 * sizeof(double)
+                                 : (size_t)kWavesPerBlock * gm.rw * 2 * sizeof(long long);
+    lds = (size_t)gm.acc_off + accb;
+    return lds <= 65536;
+}
+
+// forward (optionally with the NLL epilogue) or Newton inverse on the token-pass kernel; false = not handled
+bool launch_mixture_tok(MixArgs& a, hipStream_t st, int force_g) {
+    const int kt = (a.K == 4 || a.K == 8 || a.K == 16) ? a.K : 0;
+    TokGeom gm;
+    int G = 1;
+    size_t lds = 0;
+    if (!make_tok_geom(a, kt, force_g, gm, G, lds)) return false;
+    const bool nll = a.nll_out != nullptr;
+    const dim3 block(kBlock);
+    const dim3 grid(gm.split ? (unsigned)((long)a.B * gm.S) : (unsigned)((gm.ntiles + kWavesPerBlock - 1) / kWavesPerBlock));
+#define CNF_TOK(KT_, G_)                                                                                            \
+    do {                                                                                                            \
+        if (a.reverse) CNF_LAUNCH((mixture_tok_kernel<KT_, true, G_, false>), grid, block, lds, st, a, gm);         \
+        else if (nll) CNF_LAUNCH((mixture_tok_kernel<KT_, false, G_, true>), grid, block, lds, st, a, gm);          \
+        else CNF_LAUNCH((mixture_tok_kernel<KT_, false, G_, false>), grid, block, lds, st, a, gm);                  \
+    } while (0)
+    if (kt == 4) CNF_TOK(4, 1);
+    else if (kt == 8) CNF_TOK(8, 1);
+    else if (kt == 16) CNF_TOK(16, 1);
+    else if (G == 1) CNF_TOK(0, 1);
+    else if (G == 2) CNF_TOK(0, 2);
+    else CNF_TOK(0, 4);
+#undef CNF_TOK
+    return true;
+}
+
+}  // namespace cnf

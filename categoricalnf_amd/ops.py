@@ -5,6 +5,7 @@ hot path is done with torch ops and there is no CPU path — CPU tensors raise.
 import ctypes
 import math
 import os
+import weakref
 
 import numpy as np
 import torch
@@ -334,23 +335,49 @@ def actnorm_invconv(z, bias, scales, weight, sldj, reverse=False, length=None, c
     return z_out, ldj_out
 
 
-def _act_list(mask2d, rows, cols, D):
-    """host list of transformed channels for a channel mask (rows == 1), else None"""
+def _act_list(mask, mask2d, rows, cols, D):
+    """Host list of the transformed channels of a channel mask (rows == 1), else (None, 0).
+
+    Reading the D mask values costs a device-to-host copy, so the list is cached — per mask TENSOR OBJECT (a module's
+    registered buffer is the same object on every call), validated by a weak reference and the tensor's version
+    counter: another tensor that happens to live at the same address, or an in-place update (load_state_dict), is
+    read again."""
     if mask2d is None or rows != 1 or cols != D:
         return None, 0
-    key = (mask2d.data_ptr(), mask2d._version, D)
+    key = id(mask)
     hit = _act_cache.get(key)
-    if hit is None:
-        host = mask2d.detach().reshape(-1).cpu().tolist()      # D floats, once per mask buffer
-        idx = [i for i, v in enumerate(host) if v == 0.0]
-        hit = ((ctypes.c_int * max(len(idx), 1))(*idx), len(idx))
-        if len(_act_cache) > 256:
-            _act_cache.clear()
-        _act_cache[key] = hit
-    return hit
+    if hit is not None and hit[0]() is mask and hit[1] == mask._version and hit[2] == D:
+        return hit[3]
+    host = mask2d.detach().reshape(-1).cpu().tolist()      # D floats
+    idx = [i for i, v in enumerate(host) if v == 0.0]
+    res = ((ctypes.c_int * max(len(idx), 1))(*idx), len(idx))
+    if len(_act_cache) > 256:
+        _act_cache.clear()
+    try:
+        _act_cache[key] = (weakref.ref(mask), mask._version, D, res)
+    except TypeError:
+        pass
+    return res
 
 
 _act_cache = {}
+
+
+_mix_ws = {}
+
+
+def _mixture_workspace(dev, B):
+    """Zero-filled scratch through which several workgroups share one long row (cnf_mixture_coupling_ws): one per
+    (device, stream); the kernels leave it zeroed, so it is filled once."""
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream)
+    need = int(_lib.load().cnf_mixture_workspace_bytes(int(B)))
+    w = _mix_ws.get(key)
+    if w is None or w.numel() < need:
+        w = torch.zeros(max(need, 1 << 16), dtype=torch.uint8, device=dev)
+        if len(_mix_ws) > 64:
+            _mix_ws.clear()
+        _mix_ws[key] = w
+    return w
 
 
 def mixture_coupling(z, nn_out, mask, num_mixtures, scaling_factor=None, mixture_scaling_factor=None,
@@ -367,19 +394,60 @@ def mixture_coupling(z, nn_out, mask, num_mixtures, scaling_factor=None, mixture
     sf = _opt_f32(scaling_factor, "scaling_factor", dev)
     msf = _opt_f32(mixture_scaling_factor, "mixture_scaling_factor", dev)
     m, mr, mc = _mask_desc(mask, D, dev)
-    act, n_act = _act_list(m, mr, mc, D)
+    act, n_act = _act_list(mask, m, mr, mc, D)
     pad = _pad2d(channel_padding_mask, B, N, dev)
     ldj_in, ldj_out = _ldj_io(ldj, B, dev, inplace=False)
     z_out = torch.empty_like(z)
     use_reg = (not reverse) and reg_max > 0 and is_training
     reg = torch.zeros(B, dtype=torch.float32, device=dev) if want_reg else None
-    _launch(dev, "cnf_mixture_coupling", _ptr(z), _ptr(nn_out), _ptr(sf), _ptr(msf), _ptr(m), mr, mc,
-                                        act, n_act, _ptr(pad), int(bool(pad_in_transform)), int(bool(pad_output)),
-                                        _ptr(ldj_in), _ptr(z_out), _ptr(ldj_out), _ptr(reg if use_reg else None),
-                                        B, N, D, K, int(bool(reverse)), float(reg_max), float(reg_factor),
-                                        int(bool(is_training)), _ptr(flag_word(dev)), _stream(dev))
+    ws = _mixture_workspace(dev, B)
+    _launch(dev, "cnf_mixture_coupling_ws", _ptr(z), _ptr(nn_out), _ptr(sf), _ptr(msf), _ptr(m), mr, mc,
+                                           act, n_act, _ptr(pad), int(bool(pad_in_transform)), int(bool(pad_output)),
+                                           _ptr(ldj_in), _ptr(z_out), _ptr(ldj_out), _ptr(reg if use_reg else None),
+                                           B, N, D, K, int(bool(reverse)), float(reg_max), float(reg_factor),
+                                           int(bool(is_training)), _ptr(ws), int(ws.numel()),
+                                           _ptr(flag_word(dev)), _stream(dev))
     _after(dev, "mixture-CDF coupling")
     return z_out, ldj_out, reg
+
+
+def mixture_coupling_nll(z, nn_out, mask, num_mixtures, scaling_factor=None, mixture_scaling_factor=None,
+                         channel_padding_mask=None, reg_max=-1, reg_factor=1, is_training=True,
+                         pad_in_transform=True, pad_output=True, ldj=None, length=None, want_reg=True, acc=None,
+                         sigma=LOGISTIC_SIGMA, log_sigma=LOGISTIC_LOG_SIGMA):
+    """Forward mixture coupling as the last layer of a flow + the NLL assembly in one kernel: == mixture_coupling then
+    prior_nll on its outputs.  Returns (z_out, ldj_out, reg or None, neglog [B], nll [B])."""
+    z = _f32(z, "z")
+    dev = z.device
+    B, N, D = z.shape
+    K = int(num_mixtures)
+    nn_out = _f32(nn_out, "nn_out")
+    if nn_out.numel() != z.numel() * (2 + 3 * K):
+        raise ValueError("nn_out must be [B,N,D*(2+3K)]; got %s for z %s, K=%d" % (tuple(nn_out.shape), tuple(z.shape), K))
+    sf = _opt_f32(scaling_factor, "scaling_factor", dev)
+    msf = _opt_f32(mixture_scaling_factor, "mixture_scaling_factor", dev)
+    m, mr, mc = _mask_desc(mask, D, dev)
+    act, n_act = _act_list(mask, m, mr, mc, D)
+    pad = _pad2d(channel_padding_mask, B, N, dev)
+    ln = _length(length, B, dev)
+    ldj_in, ldj_out = _ldj_io(ldj, B, dev, inplace=False)
+    z_out = torch.empty_like(z)
+    neglog = torch.empty(B, dtype=torch.float32, device=dev)
+    nll = torch.empty(B, dtype=torch.float32, device=dev)
+    use_reg = reg_max > 0 and is_training
+    reg = torch.zeros(B, dtype=torch.float32, device=dev) if want_reg else None
+    if acc is not None and (acc.dtype != torch.int64 or acc.numel() < NLL_ACC_SLOTS or not acc.is_contiguous()):
+        raise ValueError("acc must be a contiguous int64 tensor with at least %d elements" % NLL_ACC_SLOTS)
+    ws = _mixture_workspace(dev, B)
+    _launch(dev, "cnf_mixture_coupling_nll", _ptr(z), _ptr(nn_out), _ptr(sf), _ptr(msf), _ptr(m), mr, mc,
+                                            act, n_act, _ptr(pad), int(bool(pad_in_transform)), int(bool(pad_output)),
+                                            _ptr(ldj_in), _ptr(z_out), _ptr(ldj_out), _ptr(reg if use_reg else None),
+                                            _ptr(ln), _ptr(neglog), _ptr(nll), _ptr(acc),
+                                            B, N, D, K, float(reg_max), float(reg_factor), int(bool(is_training)),
+                                            float(sigma), float(log_sigma), _ptr(ws), int(ws.numel()),
+                                            _ptr(flag_word(dev)), _stream(dev))
+    _after(dev, "mixture-CDF coupling + NLL")
+    return z_out, ldj_out, reg, neglog, nll
 
 
 def mixture_params(nn_out, mask, num_mixtures, scaling_factor=None, mixture_scaling_factor=None):
@@ -422,7 +490,7 @@ def mixture_transform(orig_z, t, log_s, log_pi, mixt_t, mixt_log_s, reverse=Fals
     kshape = tuple(z.shape) + (K,)
     log_pi, mixt_t, mixt_log_s = _f64(log_pi, "log_pi", kshape), _f64(mixt_t, "mixt_t", kshape), _f64(mixt_log_s, "mixt_log_s", kshape)
     m, mr, mc = _mask_desc(mask, D, dev)
-    act, n_act = _act_list(m, mr, mc, D)
+    act, n_act = _act_list(mask, m, mr, mc, D)
     pad = _pad2d(channel_padding_mask, B, N, dev)
     z_out = torch.empty_like(z)
     ldj = torch.empty(B, dtype=torch.float64, device=dev)
@@ -635,11 +703,34 @@ def mixture_coupling_launch(z, nn_out, mask, num_mixtures, z_out, ldj_out, scali
     sf = _opt_f32(scaling_factor, "scaling_factor", dev)
     msf = _opt_f32(mixture_scaling_factor, "mixture_scaling_factor", dev)
     m, mr, mc = _mask_desc(mask, D, dev)
-    act, n_act = _act_list(m, mr, mc, D)
+    act, n_act = _act_list(mask, m, mr, mc, D)
     pad = _pad2d(channel_padding_mask, B, N, dev)
     lib = _lib.load()
+    ws = _mixture_workspace(dev, B)
     args = [_ptr(z), _ptr(nn_out), _ptr(sf), _ptr(msf), _ptr(m), mr, mc, act, n_act, _ptr(pad), 1, 1, None,
             _ptr(z_out), _ptr(ldj_out), None, B, N, D, int(num_mixtures), int(bool(reverse)), -1.0, 1.0, 0,
-            _ptr(flag_word(dev)), None]
-    return Launch("cnf_mixture_coupling", lib.cnf_mixture_coupling, args, dev,
-                  (z, nn_out, sf, msf, m, act, pad, z_out, ldj_out))
+            _ptr(ws), int(ws.numel()), _ptr(flag_word(dev)), None]
+    return Launch("cnf_mixture_coupling_ws", lib.cnf_mixture_coupling_ws, args, dev,
+                  (z, nn_out, sf, msf, m, act, pad, z_out, ldj_out, ws))
+
+
+def mixture_coupling_nll_launch(z, nn_out, mask, num_mixtures, z_out, ldj_out, length, neglog, nll, acc=None,
+                                scaling_factor=None, mixture_scaling_factor=None, channel_padding_mask=None,
+                                sigma=LOGISTIC_SIGMA, log_sigma=LOGISTIC_LOG_SIGMA):
+    z, nn_out = _f32(z, "z"), _f32(nn_out, "nn_out")
+    dev = z.device
+    B, N, D = z.shape
+    sf = _opt_f32(scaling_factor, "scaling_factor", dev)
+    msf = _opt_f32(mixture_scaling_factor, "mixture_scaling_factor", dev)
+    m, mr, mc = _mask_desc(mask, D, dev)
+    act, n_act = _act_list(mask, m, mr, mc, D)
+    pad = _pad2d(channel_padding_mask, B, N, dev)
+    ln = _length(length, B, dev)
+    lib = _lib.load()
+    ws = _mixture_workspace(dev, B)
+    args = [_ptr(z), _ptr(nn_out), _ptr(sf), _ptr(msf), _ptr(m), mr, mc, act, n_act, _ptr(pad), 1, 1, None,
+            _ptr(z_out), _ptr(ldj_out), None, _ptr(ln), _ptr(neglog), _ptr(nll), _ptr(acc),
+            B, N, D, int(num_mixtures), -1.0, 1.0, 0, float(sigma), float(log_sigma),
+            _ptr(ws), int(ws.numel()), _ptr(flag_word(dev)), None]
+    return Launch("cnf_mixture_coupling_nll", lib.cnf_mixture_coupling_nll, args, dev,
+                  (z, nn_out, sf, msf, m, act, pad, ln, z_out, ldj_out, neglog, nll, acc, ws))

@@ -164,6 +164,49 @@ int cnf_mixture_coupling(const float* z, const float* nn_out,
                          double reg_max, double reg_factor, int is_training,
                          int* flags, cnf_stream_t stream);
 
+/* The same with a workspace for small batches of long rows (B < ~2000 samples of >= 2 passes each: graphs,
+ * sentences).  There a row is shared by several workgroups so that the 256 CUs are filled; their partial log-det
+ * sums meet in fixed-point words of `workspace` (cnf_mixture_workspace_bytes(B) bytes, 8-byte aligned, device
+ * memory).  The caller zero-fills the workspace ONCE; every launch leaves it zeroed.  One workspace per stream that
+ * may run these kernels concurrently.  workspace == NULL: as cnf_mixture_coupling (one workgroup per row at most). */
+int64_t cnf_mixture_workspace_bytes(int B);
+int cnf_mixture_coupling_ws(const float* z, const float* nn_out,
+                            const float* scaling_factor, const float* mixture_scaling_factor,
+                            const float* mask, int mask_rows, int mask_cols,
+                            const int* act_host, int n_act,
+                            const float* pad, int pad_in_transform, int pad_output,
+                            const float* ldj_in, float* z_out, float* ldj_out, float* reg_out,
+                            int B, int N, int D, int K, int reverse,
+                            double reg_max, double reg_factor, int is_training,
+                            void* workspace, int64_t workspace_bytes,
+                            int* flags, cnf_stream_t stream);
+
+/* Forward mixture coupling as the LAST layer of a flow, with the NLL assembly as its epilogue
+ * (mixture_cdf_layer.py:45-92 followed by the task's loss: experiments/set_modeling/task.py:96-118,
+ * graph_coloring/task.py:122-130, general/task.py:148-149): besides z' and ldj_out it writes
+ * neglog_out[b] = -sum_{n,d} log p(z'[b,n,d]) pad[b,n]  (logistic prior, mu = 0; nullable) and
+ * nll_out[b] = (neglog_out[b] - ldj_out[b]) / length[b]  (length NULL = N), so the prior term never re-reads z'.
+ * nll_acc (nullable): the batch sum in 64 fixed-point words, as cnf_affine_coupling_nll_acc.  Needs math mode 1. */
+int cnf_mixture_coupling_nll(const float* z, const float* nn_out,
+                             const float* scaling_factor, const float* mixture_scaling_factor,
+                             const float* mask, int mask_rows, int mask_cols,
+                             const int* act_host, int n_act,
+                             const float* pad, int pad_in_transform, int pad_output,
+                             const float* ldj_in, float* z_out, float* ldj_out, float* reg_out,
+                             const float* length, float* neglog_out, float* nll_out, int64_t* nll_acc,
+                             int B, int N, int D, int K,
+                             double reg_max, double reg_factor, int is_training,
+                             float sigma, float log_sigma,
+                             void* workspace, int64_t workspace_bytes,
+                             int* flags, cnf_stream_t stream);
+
+/* Tuning / A-B knobs of the fp32 mixture kernels: which kernel serves math mode 1 (0 = token-pass kernel on
+ * DMA-staged rows, default; 1 = the round-1 kernel), lanes per item for a run-time K (0 = automatic, 1, 2, 4),
+ * and the number of waves a split-row launch aims at (default 4096). */
+void cnf_set_mixture_kernel(int which);
+void cnf_set_mixture_lanes(int lanes_per_item);
+void cnf_set_mixture_split(int waves);
+
 /* MixtureCDFCoupling.get_mixt_params (mixture_cdf_layer.py:145-180): split + bound + mask in
  * fp32, results cast to fp64: t, log_s [B,N,D]; log_pi, mixt_t, mixt_log_s [B,N,D,K]. */
 int cnf_mixture_params(const float* nn_out, const float* scaling_factor,

@@ -1,0 +1,189 @@
+"""GPU tests of the fp32 token-pass mixture kernel (cnf_mixture_tok.hip): DMA-staged rows, rows split over several
+workgroups through the fixed-point workspace, NLL epilogue.  Checked against the oracle, against the round-1 fp32
+kernel (cnf_set_mixture_kernel(1)) and through properties at the real configuration sizes."""
+import numpy as np
+import pytest
+import torch
+
+from categoricalnf_amd import _lib
+from oracle import cnf_oracle as O
+
+pytestmark = pytest.mark.gpu
+ELEM = dict(rtol=2e-5, atol=2e-5)
+LDJ = dict(rtol=1e-4, atol=1e-4)
+
+
+def ops():
+    from categoricalnf_amd import ops as o
+    return o
+
+
+def g(t):
+    return None if t is None else t.cuda()
+
+
+def close(a, b, **kw):
+    torch.testing.assert_close(a.detach().cpu(), b.detach().cpu(), **kw)
+
+
+def rel_ll(a, b, floor=1.0):
+    """max |a - b| / max(|b|, floor): the north-star bar is 1e-4 on per-sample log-likelihood."""
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).abs() / b.abs().clamp(min=floor)).max().item()
+
+
+def _case(B, N, D, K, kind, seed, padded=True):
+    gen = torch.Generator().manual_seed(seed)
+    z = 1.5 * torch.randn(B, N, D, generator=gen)
+    nn_out = 0.6 * torch.randn(B, N, D * (2 + 3 * K), generator=gen)
+    sf, msf = 0.2 * torch.randn(D, generator=gen), 0.2 * torch.randn(D, K, generator=gen)
+    if kind == "none":
+        mask = None
+    elif kind == "chess":
+        mask = O.chess_mask()
+    elif kind == "channel_inv":
+        mask = 1.0 - O.channel_mask(D)
+    else:
+        mask = O.channel_mask(D)
+    ln = torch.randint(max(1, N // 2), N + 1, (B,), generator=gen)
+    ln[0] = N
+    pad = O.length_mask(ln, N) if (padded and kind != "none") else None
+    return z, nn_out, sf, msf, mask, ln, pad
+
+
+# shapes of the reference's configurations (scaled-down batch) and awkward ones: rows shorter / longer than a pass,
+# odd K (run-time K path, 1/2/4 lanes per item), D = 1 chess mask, inverted channel mask (first channels transformed)
+SHAPES = [(40, 16, 4, 8, "channel"), (12, 288, 3, 51, "none"), (24, 38, 6, 16, "channel"), (6, 703, 2, 8, "channel"),
+          (16, 50, 6, 16, "channel_inv"), (11, 13, 1, 8, "chess"), (70, 5, 3, 4, "channel"), (300, 1, 2, 8, "channel"),
+          (5, 97, 5, 9, "channel"), (3, 400, 2, 23, "none"), (2, 1500, 3, 5, "channel_inv"), (33, 20, 2, 8, "channel"),
+          (1, 2048, 4, 8, "channel"), (130, 64, 6, 8, "channel")]
+
+
+@pytest.mark.parametrize("B,N,D,K,kind", SHAPES)
+def test_tok_kernel_vs_oracle_and_round1_kernel(B, N, D, K, kind):
+    z, nn_out, sf, msf, mask, ln, pad = _case(B, N, D, K, kind, B + 7 * N + 31 * D + K)
+    kw = dict(num_mixtures=K, reg_max=3.5, reg_factor=2.0, is_training=True)
+    gk = dict(scaling_factor=g(sf), mixture_scaling_factor=g(msf), channel_padding_mask=g(pad), **kw)
+    zo, lo, ro = O.mixture_coupling(z, nn_out, mask, scaling_factor=sf, mixture_scaling_factor=msf, channel_padding_mask=pad, **kw)
+    ldj0 = torch.randn(B, generator=torch.Generator().manual_seed(5))
+    zf, lf, rf = ops().mixture_coupling(g(z), g(nn_out), g(mask), ldj=g(ldj0), **gk)
+    close(zf, zo, **ELEM); close(lf, lo + ldj0, **LDJ); close(rf, ro, **LDJ)
+    assert rel_ll(lf, lo + ldj0) < 1e-4
+    lib = _lib.load()
+    lib.cnf_set_mixture_kernel(1)
+    try:
+        z1, l1, r1 = ops().mixture_coupling(g(z), g(nn_out), g(mask), ldj=g(ldj0), **gk)
+        zr1, lr1, _ = ops().mixture_coupling(g(zo), g(nn_out), g(mask), reverse=True, **gk)
+    finally:
+        lib.cnf_set_mixture_kernel(0)
+    # same arithmetic per element (up to the lanes-per-item split of a run-time K); the per-sample sum order differs
+    close(zf, z1, rtol=1e-5, atol=1e-5)
+    close(lf, l1, rtol=1e-5, atol=5e-5)
+    zr, lr, _ = ops().mixture_coupling(g(zo), g(nn_out), g(mask), reverse=True, **gk)
+    close(zr, zr1, rtol=1e-5, atol=1e-5)
+    close(lr, lr1, rtol=1e-5, atol=5e-5)
+    zo2, lo2, _ = O.mixture_coupling(zo, nn_out, mask, scaling_factor=sf, mixture_scaling_factor=msf,
+                                     channel_padding_mask=pad, reverse=True, **kw)
+    close(zr, zo2, rtol=1e-4, atol=1e-4); close(lr, lo2, **LDJ)
+    ops().check_flags(torch.device("cuda"), "tok kernel")
+
+
+@pytest.mark.parametrize("B,N,D,K,kind", [(12, 288, 3, 51, "none"), (24, 38, 6, 16, "channel"), (6, 703, 2, 8, "channel"),
+                                          (40, 16, 4, 8, "channel"), (2, 1500, 3, 5, "channel_inv"), (11, 13, 1, 8, "chess")])
+@pytest.mark.parametrize("split_waves", [256, 4096, 65536])
+def test_split_rows_are_deterministic_and_leave_the_workspace_zeroed(B, N, D, K, kind, split_waves):
+    """Rows shared by S workgroups (S depends on the wave target): the fixed-point meeting point makes the per-sample
+    log-det bit-identical from launch to launch, and every launch hands the workspace back zeroed."""
+    z, nn_out, sf, msf, mask, ln, pad = _case(B, N, D, K, kind, 99 + B + N)
+    lib = _lib.load()
+    lib.cnf_set_mixture_split(split_waves)
+    try:
+        outs = [ops().mixture_coupling(g(z), g(nn_out), g(mask), K, scaling_factor=g(sf), mixture_scaling_factor=g(msf),
+                                       channel_padding_mask=g(pad)) for _ in range(3)]
+    finally:
+        lib.cnf_set_mixture_split(4096)
+    for zf, lf, _ in outs[1:]:
+        assert torch.equal(zf, outs[0][0]) and torch.equal(lf, outs[0][1])
+    zo, lo, _ = O.mixture_coupling(z, nn_out, mask, K, sf, msf, channel_padding_mask=pad)
+    close(outs[0][0], zo, **ELEM); close(outs[0][1], lo, **LDJ)
+    torch.cuda.synchronize()
+    for w in ops()._mix_ws.values():
+        assert int(w.count_nonzero().item()) == 0
+
+
+@pytest.mark.parametrize("lanes", [1, 2, 4])
+def test_lanes_per_item_agree(lanes):
+    """Run-time K with 1, 2 or 4 lanes per item: same results to rounding of the partial-sum order."""
+    B, N, D, K = 9, 60, 3, 23
+    z, nn_out, sf, msf, mask, ln, pad = _case(B, N, D, K, "channel", 4242)
+    lib = _lib.load()
+    lib.cnf_set_mixture_lanes(lanes)
+    try:
+        zf, lf, _ = ops().mixture_coupling(g(z), g(nn_out), g(mask), K, scaling_factor=g(sf), mixture_scaling_factor=g(msf),
+                                           channel_padding_mask=g(pad))
+        zo, lo, _ = O.mixture_coupling(z, nn_out, mask, K, sf, msf, channel_padding_mask=pad)
+        close(zf, zo, **ELEM); close(lf, lo, **LDJ)
+        zr, lr, _ = ops().mixture_coupling(zf, g(nn_out), g(mask), K, scaling_factor=g(sf), mixture_scaling_factor=g(msf),
+                                           channel_padding_mask=g(pad), reverse=True)
+        keep = pad.expand(-1, -1, D) > 0
+        assert ((zr.cpu() - z)[keep]).abs().max() < 5e-4
+    finally:
+        lib.cnf_set_mixture_lanes(0)
+
+
+@pytest.mark.parametrize("B,N,D,K,kind", SHAPES)
+def test_mixture_nll_epilogue_equals_coupling_then_prior_nll(B, N, D, K, kind):
+    """cnf_mixture_coupling_nll == cnf_mixture_coupling followed by cnf_prior_nll on its outputs (z', ldj bit-equal;
+    per-sample NLL within 1e-4 relative of the oracle's assembly, task.py:96-118)."""
+    z, nn_out, sf, msf, mask, ln, pad = _case(B, N, D, K, kind, 17 + B + N + K)
+    if pad is None:
+        ln = torch.full((B,), N)
+    gk = dict(scaling_factor=g(sf), mixture_scaling_factor=g(msf), channel_padding_mask=g(pad))
+    ldj0 = torch.randn(B, generator=torch.Generator().manual_seed(6))
+    zf, lf, _ = ops().mixture_coupling(g(z), g(nn_out), g(mask), K, ldj=g(ldj0), **gk)
+    neglog_s, nll_s = ops().prior_nll(zf, lf, g(ln), g(pad))
+    acc = torch.zeros(ops().NLL_ACC_SLOTS, dtype=torch.int64, device="cuda")
+    zn, lnl, _, neglog, nll = ops().mixture_coupling_nll(g(z), g(nn_out), g(mask), K, ldj=g(ldj0), length=g(ln), acc=acc, **gk)
+    assert torch.equal(zn, zf) and torch.equal(lnl, lf)
+    close(neglog, neglog_s, rtol=1e-5, atol=1e-4)
+    close(nll, nll_s, rtol=1e-5, atol=1e-5)
+    zo, lo, _ = O.mixture_coupling(z, nn_out, mask, K, sf, msf, channel_padding_mask=pad)
+    nll_o = O.nll_per_sample(zo, lo + ldj0, ln.float(), pad)
+    assert rel_ll(nll, nll_o) < 1e-4
+    sums = ops().nll_acc_read(acc, B)
+    assert abs(sums[0].item() - nll.double().sum().item()) < 1e-6 * max(1.0, abs(nll.double().sum().item())) + 1e-6 * B
+    assert sums[1].item() == B
+
+
+def test_config_shapes_round_trip_at_full_size():
+    """PTB (B=128,N=288,D=3,K=51, no mask), Zinc nodes / edges, graph colouring large: forward then inverse recovers z,
+    ldj antisymmetric, a slice equals the oracle."""
+    for (B, N, D, K, kind) in [(128, 288, 3, 51, "none"), (512, 38, 6, 16, "channel"), (512, 703, 2, 8, "channel"),
+                               (128, 50, 6, 16, "channel"), (384, 20, 2, 8, "channel")]:
+        gen = torch.Generator(device="cuda").manual_seed(B + N)
+        z = torch.randn(B, N, D, generator=gen, device="cuda")
+        nn_out = 0.5 * torch.randn(B, N, D * (2 + 3 * K), generator=gen, device="cuda")
+        mask = None if kind == "none" else g(O.channel_mask(D))
+        zf, lf, _ = ops().mixture_coupling(z, nn_out, mask, K)
+        zr, lr, _ = ops().mixture_coupling(zf, nn_out, mask, K, reverse=True)
+        assert (zr - z).abs().max().item() < 3e-4, (B, N, D, K)
+        assert ((lf + lr).abs() / lf.abs().clamp(min=1.0)).max().item() < 1e-4
+        zo, lo, _ = O.mixture_coupling(z[:4].cpu(), nn_out[:4].cpu(), None if mask is None else mask.cpu(), K, None, None)
+        close(zf[:4], zo, **ELEM); close(lf[:4], lo, **LDJ)
+        assert rel_ll(lf[:4], lo) < 1e-4
+    ops().check_flags(torch.device("cuda"), "config shapes")
+
+
+def test_unaligned_nn_out_takes_the_fallback_kernel():
+    """A view that starts 4 bytes into an allocation is not 16-byte aligned: the DMA kernel declines, the round-1
+    kernel serves it, results unchanged."""
+    B, N, D, K = 6, 10, 4, 8
+    z, nn_out, sf, msf, mask, ln, pad = _case(B, N, D, K, "channel", 77)
+    buf = torch.empty(nn_out.numel() + 1, device="cuda")
+    view = buf[1:].view_as(nn_out)
+    view.copy_(nn_out)
+    assert view.data_ptr() % 16 != 0
+    zf, lf, _ = ops().mixture_coupling(g(z), view, g(mask), K, scaling_factor=g(sf), mixture_scaling_factor=g(msf),
+                                       channel_padding_mask=g(pad))
+    zo, lo, _ = O.mixture_coupling(z, nn_out, mask, K, sf, msf, channel_padding_mask=pad)
+    close(zf, zo, **ELEM); close(lf, lo, **LDJ)

@@ -32,6 +32,22 @@ for name, B, N, D, K, kind in shapes:
             ts.append(a.elapsed_time(b) / reps * 1e3)
         return min(ts)
     tf = timeit(fwd)
+    lib.cnf_set_mixture_kernel(1)
+    tf_r1 = timeit(fwd)
+    ti_r1 = timeit(inv, reps=5)
+    lib.cnf_set_mixture_kernel(0)
+    splits = []
+    if B < 2048:
+        for w in (1024, 2048, 4096, 8192, 16384):
+            lib.cnf_set_mixture_split(w)
+            splits.append("%d:%.1f/%.1f" % (w, timeit(fwd), timeit(inv, reps=5)))
+        lib.cnf_set_mixture_split(4096)
+    lanes = []
+    if K not in (4, 8, 16):
+        for l in (1, 2, 4):
+            lib.cnf_set_mixture_lanes(l)
+            lanes.append("%d:%.1f/%.1f" % (l, timeit(fwd), timeit(inv, reps=5)))
+        lib.cnf_set_mixture_lanes(0)
     lib.cnf_set_math_mode(0)
     tf64 = timeit(fwd)
     lib.cnf_set_math_mode(1)
@@ -41,8 +57,9 @@ for name, B, N, D, K, kind in shapes:
         tiles.append("%d:%.1f" % (tile, timeit(fwd)))
     lib.cnf_set_mixture_tile(128)
     elems = B * N * D
-    line = "%-26s B=%5d N=%3d D=%d K=%2d | fwd %8.1f us (%6.2f Gelem/s, %5.0f GB/s alg; fp64 kernel %7.1f us; tile %s)" % (
-        name, B, N, D, K, tf, elems / tf / 1e3, elems * (16 + 12 * K) / tf / 1e3, tf64, " ".join(tiles))
+    line = "%-26s B=%5d N=%3d D=%d K=%2d | fwd %8.1f us (%6.2f Gelem/s, %5.0f GB/s alg = %.2f of 8 TB/s; round-1 kernel %.1f us fwd / %.1f us inv; fp64 kernel %7.1f us; tile %s; split-waves fwd/inv %s; lanes fwd/inv %s)" % (
+        name, B, N, D, K, tf, elems / tf / 1e3, elems * (16 + 12 * K) / tf / 1e3, elems * (16 + 12 * K) / tf / 1e3 / 8000.0,
+        tf_r1, ti_r1, tf64, " ".join(tiles), " ".join(splits), " ".join(lanes))
     for tag, math, mode in (("fp64 bisect", 0, 0), ("fp64 newton", 0, 1), ("fp32 newton", 1, 1)):
         lib.cnf_set_math_mode(math); lib.cnf_set_inverse_mode(mode)
         ti = timeit(inv, reps=5)
