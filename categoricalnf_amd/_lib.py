@@ -38,6 +38,8 @@ SIGNATURES = {
                                 _i, _i, _i, _i, _i, _d, _d, _i, _p, _i64, _p, _p],
     "cnf_mixture_coupling_nll": [_p, _p, _p, _p, _p, _i, _i, _p, _i, _p, _i, _i, _p, _p, _p, _p,
                                  _p, _p, _p, _p, _i, _i, _i, _i, _d, _d, _i, _f, _f, _p, _i64, _p, _p],
+    "cnf_mixture_coupling_actconv": [_p, _p, _p, _p, _p, _i, _i, _p, _i, _p, _p, _p, _p, _p,
+                                     _p, _p, _p, _p, _p, _i, _i, _i, _i, _d, _d, _i, _p, _i64, _p, _p],
     "cnf_mixture_params": [_p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "cnf_mixture_transform": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _i, _p, _p, _p, _p,
                               _i, _i, _i, _i, _i, _d, _d, _i, _p, _p],

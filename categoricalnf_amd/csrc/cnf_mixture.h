@@ -49,6 +49,13 @@ struct MixArgs {
     long long* ws_acc;      // [2B] fixed-point row sums, zero before and after every launch (or null)
     int* ws_cnt;            // [B] arrival tickets, zero before and after every launch (or null)
     PriorConst prior;
+    // optional epilogue of the forward kernel: ActNorm and 1x1 convolution of the NEXT flow step applied to z' before
+    // it is written (cnf_mixture_coupling_actconv); e_w non-null selects it
+    const float* e_bias;    // [D]
+    const float* e_scales;  // [D]
+    const float* e_w;       // [D, D], z'' = z' @ W
+    const float* e_sldj;    // [1]
+    const float* e_length;  // [B] or null: the `length` the two layers receive
 };
 
 // cnf_mixture_tok.hip

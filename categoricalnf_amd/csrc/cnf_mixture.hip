@@ -950,6 +950,15 @@ static int launch_mixture(MixArgs& a, bool split, const int* act_host, int n_act
     if (!split && math_mode() == 1 && (!a.reverse || inverse_mode() == 1) && g_mix_kernel != 1) {
         if (launch_mixture_tok(a, st, g_mix_lanes)) return launch_status(who);
     }
+    if (a.e_w) {
+        // the token-pass kernel declined: the plain coupling, then the fused ActNorm + 1x1 convolution kernel in place
+        MixArgs b = a;
+        b.e_w = nullptr; b.e_bias = nullptr; b.e_scales = nullptr; b.e_sldj = nullptr; b.e_length = nullptr;
+        const int rc = launch_mixture(b, split, act_host, n_act, st, who);
+        if (rc != CNF_OK) return rc;
+        return cnf_actnorm_invconv(a.z_out, a.e_bias, a.e_scales, a.e_w, a.e_sldj, a.pad, a.e_length, a.ldj_out, a.z_out, a.ldj_out,
+                                   a.B, a.N, a.D, 0, a.flags, (cnf_stream_t)st);
+    }
     if (a.nll_out) {
         // the token-pass kernel declined (or another math / inverse mode is selected): same results from the plain
         // coupling followed by the separate prior / NLL kernel (and one tiny launch for the fixed-point batch sum)
@@ -1119,6 +1128,37 @@ int cnf_mixture_coupling_nll(const float* z, const float* nn_out,
     a.prior = make_prior_const(sigma, log_sigma);
     split_workspace(a, workspace, workspace_bytes);
     return launch_mixture(a, false, act_host, n_act, (hipStream_t)stream, "cnf_mixture_coupling_nll");
+}
+
+int cnf_mixture_coupling_actconv(const float* z, const float* nn_out,
+                                 const float* scaling_factor, const float* mixture_scaling_factor,
+                                 const float* mask, int mask_rows, int mask_cols,
+                                 const int* act_host, int n_act,
+                                 const float* pad,
+                                 const float* ldj_in, float* z_out, float* ldj_out, float* reg_out,
+                                 const float* an_bias, const float* an_scales, const float* conv_weight, const float* conv_sldj,
+                                 const float* length,
+                                 int B, int N, int D, int K,
+                                 double reg_max, double reg_factor, int is_training,
+                                 void* workspace, int64_t workspace_bytes,
+                                 int* flags, cnf_stream_t stream) {
+    CNF_REQUIRE(z && nn_out && z_out && ldj_out && an_bias && an_scales && conv_weight && conv_sldj,
+                "cnf_mixture_coupling_actconv: null tensor");
+    CNF_REQUIRE(D == 1 || D == 2 || D == 3 || D == 4 || D == 5 || D == 6 || D == 8,
+                "cnf_mixture_coupling_actconv: D=%d is outside the fused ActNorm + convolution kernels", D);
+    MixArgs a = {};
+    a.z = z; a.nn = nn_out; a.sf = scaling_factor; a.msf = mixture_scaling_factor;
+    a.mask = mask; a.pad = pad; a.ldj_in = ldj_in; a.z_out = z_out; a.ldj_out = ldj_out;
+    a.reg_out = reg_out; a.flags = flags;
+    a.B = B; a.N = N; a.D = D; a.K = K; a.mr = mask_rows; a.mc = mask_cols;
+    a.reverse = 0;
+    a.pad_in_transform = pad ? 1 : 0;
+    a.pad_output = pad ? 1 : 0;
+    a.use_reg = (reg_max > 0 && is_training) ? 1 : 0;
+    a.reg_max = reg_max; a.reg_factor = reg_factor;
+    a.e_bias = an_bias; a.e_scales = an_scales; a.e_w = conv_weight; a.e_sldj = conv_sldj; a.e_length = length;
+    split_workspace(a, workspace, workspace_bytes);
+    return launch_mixture(a, false, act_host, n_act, (hipStream_t)stream, "cnf_mixture_coupling_actconv");
 }
 
 int cnf_mixture_transform(const double* z, const double* t, const double* log_s,

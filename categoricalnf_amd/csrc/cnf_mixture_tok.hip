@@ -46,6 +46,7 @@ struct TokGeom {
     int slot;           // LDS bytes per token slot (contig: == tokstride)
     int stage_bytes;    // LDS bytes of one wave's stage (multiple of 1 KiB)
     int acc_off;        // byte offset of the accumulator region in dynamic LDS
+    int epi_off;        // byte offset of the epilogue tables + strips
     int split;          // 0: rw whole rows per wave tile; 1: S workgroups x 4 waves per row
     int rw;             // rows per wave tile (split == 0)
     int S;              // workgroups per row (split == 1)
@@ -56,10 +57,14 @@ struct TokGeom {
 
 __device__ __forceinline__ long long to_fix(double v) { return __double2ll_rn(v * kFix32); }
 
-template <int KT, bool REVERSE, int G, bool NLL>
+// ED > 0: the ActNorm + 1x1 convolution of the next flow step (D = ED channels) are applied to the coupling's output
+// while it is on chip (forward only): the [B,N,D] round trip between the two kernels (8 B/elem) disappears.  Same
+// arithmetic, in the same order, as actnorm_invconv_kernel (cnf_linear.hip): results are bit-identical to the chain.
+template <int KT, bool REVERSE, int G, bool NLL, int ED = 0>
 __global__ __launch_bounds__(kBlock) void mixture_tok_kernel(MixArgs a, TokGeom gm) {
     static_assert(G == 1 || KT == 0, "several lanes per item only with a run-time K");
     static_assert(!(NLL && REVERSE), "the NLL epilogue belongs to the forward pass");
+    static_assert(ED == 0 || (!REVERSE && !NLL), "the ActNorm + convolution epilogue belongs to a forward pass inside a flow");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int K = KT > 0 ? KT : a.K;
@@ -70,6 +75,21 @@ __global__ __launch_bounds__(kBlock) void mixture_tok_kernel(MixArgs a, TokGeom 
     // accumulators: split == 0: [wave][rw][2] fixed-point row sums; split == 1: [wave][2] fp64 wave partials
     long long* rowacc = reinterpret_cast<long long*>(smem + gm.acc_off) + (size_t)wave * gm.rw * 2;
     double* wpart = reinterpret_cast<double*>(smem + gm.acc_off);
+    // epilogue: constants [bias D | e^scales D | W D*D | sum scales] and this wave's strip of one pass of tokens
+    float* etab = reinterpret_cast<float*>(smem + gm.epi_off);
+    float* ep = etab + (2 * ED + ED * ED + 4) + (size_t)wave * gm.TPP * ED;
+    if (ED > 0) {
+        for (int i = threadIdx.x; i < ED; i += blockDim.x) {
+            etab[i] = a.e_bias[i];
+            etab[ED + i] = expf(a.e_scales[i]);
+        }
+        for (int i = threadIdx.x; i < ED * ED; i += blockDim.x) etab[2 * ED + i] = a.e_w[i];
+        if (threadIdx.x == 0) {
+            float ssum = 0.f;
+            for (int i = 0; i < ED; ++i) ssum += a.e_scales[i];
+            etab[2 * ED + ED * ED] = ssum;
+        }
+    }
     for (int i = threadIdx.x; i < a.D; i += blockDim.x)
         if (a.sf) sf_tab[i] = make_bound(a.sf[i]);
     for (int i = threadIdx.x; i < a.D * K; i += blockDim.x)
@@ -394,7 +414,8 @@ __global__ __launch_bounds__(kBlock) void mixture_tok_kernel(MixArgs a, TokGeom 
         // ---- outputs of the item lanes
         const bool owner = valid && sub == 0;       // one lane per element stores and accounts
         if (owner) {
-            zo_tile[(size_t)tokl * a.D + d] = of;
+            if (ED > 0) ep[tli * ED + d] = of;
+            else zo_tile[(size_t)tokl * a.D + d] = of;
             bad |= isnan(of);
         }
         double cd = use64 ? contrib64 : (double)contrib;
@@ -420,7 +441,8 @@ __global__ __launch_bounds__(kBlock) void mixture_tok_kernel(MixArgs a, TokGeom 
                 const float zv = z_tile[(size_t)tl2 * a.D + c];
                 const float pv2 = pad_tile ? pad_tile[tl2] : 1.f;
                 const float o = a.pad_output ? zv * pv2 : zv;
-                zo_tile[(size_t)tl2 * a.D + c] = o;
+                if (ED > 0) ep[tk * ED + c] = o;
+                else zo_tile[(size_t)tl2 * a.D + c] = o;
                 if (NLL) {
                     const double lp2 = (double)(-prior_logp(o, prior) * (pad_tile ? pv2 : 1.f));
                     if (gm.split) {
@@ -432,12 +454,54 @@ __global__ __launch_bounds__(kBlock) void mixture_tok_kernel(MixArgs a, TokGeom 
                 }
             }
         }
+        if (ED > 0) {
+            // ActNorm -> 1x1 convolution on the pass's tokens, one lane per token (activation_normalization.py:24-48,
+            // permutation_layers.py:106-136), then a coalesced store of the strip
+            wave_lds_sync();
+            if (lane < npt) {
+                float xv[ED > 0 ? ED : 1];
+                const float p = pad_tile ? pad_tile[tp + lane] : 1.f;
+#pragma unroll
+                for (int i = 0; i < ED; ++i) {
+                    float y = (ep[lane * ED + i] + etab[i]) * etab[ED + i];
+                    if (pad_tile) y = y * p;
+                    xv[i] = y;
+                }
+#pragma unroll
+                for (int jo = 0; jo < ED; ++jo) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int i = 0; i < ED; ++i) acc = fmaf(xv[i], etab[2 * ED + i * ED + jo], acc);
+                    if (pad_tile) acc = acc * p;
+                    bad |= isnan(acc);
+                    ep[lane * ED + jo] = acc;
+                }
+            }
+            wave_lds_sync();
+            for (int e = lane; e < npt * ED; e += kWave) zo_tile[(size_t)tp * ED + e] = ep[e];
+        }
         wave_lds_sync();      // the stage is overwritten by the next pass
     }
 
     // ---- per-sample results
     auto finish = [&](int row, double ldj_sum, double nlp_sum) {
-        const float v = (a.ldj_in ? a.ldj_in[row] : 0.f) + (float)(REVERSE ? -ldj_sum : ldj_sum);
+        float v = (a.ldj_in ? a.ldj_in[row] : 0.f) + (float)(REVERSE ? -ldj_sum : ldj_sum);
+        if (ED > 0) {
+            // log-det of the two layers, same association as run in sequence: ActNorm uses length | sum(pad) | N,
+            // the convolution length | N
+            float len_a, len_c;
+            if (a.e_length) {
+                len_a = len_c = a.e_length[row];
+            } else {
+                len_c = (float)a.N;
+                len_a = (float)a.N;
+                if (a.pad) {
+                    len_a = 0.f;
+                    for (int n = 0; n < a.N; ++n) len_a += a.pad[(size_t)row * a.N + n];
+                }
+            }
+            v = (v + etab[2 * ED + ED * ED] * len_a) + a.e_sldj[0] * len_c;
+        }
         a.ldj_out[row] = v;
         if (isnan(v)) raise_flag(a.flags, CNF_FLAG_NAN_LDJ);
         if (NLL) {
@@ -578,7 +642,12 @@ static bool make_tok_geom(const MixArgs& a, int kt, int force_g, TokGeom& gm, in
     gm.acc_off = (int)((size_t)kWavesPerBlock * stage + tabs);
     const size_t accb = gm.split ? (size_t)kWavesPerBlock * 2 * sizeof(double)
                                  : (size_t)kWavesPerBlock * gm.rw * 2 * sizeof(long long);
-    lds = (size_t)gm.acc_off + accb;
+    gm.epi_off = (int)(((size_t)gm.acc_off + accb + 15) & ~(size_t)15);
+    lds = (size_t)gm.epi_off;
+    if (a.e_w) {
+        if (a.reverse || a.nll_out || (a.pad && !a.pad_output)) return false;
+        lds += ((size_t)(2 * a.D + a.D * a.D + 4) + (size_t)kWavesPerBlock * tpp * a.D) * sizeof(float);
+    }
     return lds <= 65536;
 }
 
@@ -596,8 +665,18 @@ bool launch_mixture_tok(MixArgs& a, hipStream_t st, int force_g) {
     do {                                                                                                            \
         if (a.reverse) CNF_LAUNCH((mixture_tok_kernel<KT_, true, G_, false>), grid, block, lds, st, a, gm);         \
         else if (nll) CNF_LAUNCH((mixture_tok_kernel<KT_, false, G_, true>), grid, block, lds, st, a, gm);          \
+        else if (a.e_w && G_ == 1) {                                                                                \
+            switch (a.D) {                                                                                          \
+                case 2: CNF_LAUNCH((mixture_tok_kernel<KT_, false, 1, false, 2>), grid, block, lds, st, a, gm); break; \
+                case 3: CNF_LAUNCH((mixture_tok_kernel<KT_, false, 1, false, 3>), grid, block, lds, st, a, gm); break; \
+                case 4: CNF_LAUNCH((mixture_tok_kernel<KT_, false, 1, false, 4>), grid, block, lds, st, a, gm); break; \
+                case 6: CNF_LAUNCH((mixture_tok_kernel<KT_, false, 1, false, 6>), grid, block, lds, st, a, gm); break; \
+                default: return false;                                                                              \
+            }                                                                                                       \
+        } else if (a.e_w) return false;                                                                             \
         else CNF_LAUNCH((mixture_tok_kernel<KT_, false, G_, false>), grid, block, lds, st, a, gm);                  \
     } while (0)
+    if (a.e_w && (G != 1 || !(a.D == 2 || a.D == 3 || a.D == 4 || a.D == 6))) return false;
     if (kt == 4) CNF_TOK(4, 1);
     else if (kt == 8) CNF_TOK(8, 1);
     else if (kt == 16) CNF_TOK(16, 1);

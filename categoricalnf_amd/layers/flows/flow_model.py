@@ -35,9 +35,26 @@ class FlowModel(nn.Module):
             order.reverse()
         per_layer = []
         fuse = self._fusable(z, get_ldj_per_layer)
-        skip = -1
+        skip = set()
         for pos, (index, layer) in enumerate(order):
-            if index == skip:
+            if index in skip:
+                continue
+            if (fuse and not reverse and pos + 2 < len(order) and type(layer).__name__ == "MixtureCDFCoupling"
+                    and type(order[pos + 1][1]) is ActNormFlow and type(order[pos + 2][1]) is InvertibleConv
+                    and layer.c_in in ops.FUSED_ACTCONV_DIMS):
+                # mixture coupling of this flow step + ActNorm + 1x1 conv of the next one in ONE kernel: the coupling's
+                # output never goes to HBM in between (same arithmetic as the three layers, bit for bit)
+                act, conv = order[pos + 1][1], order[pos + 2][1]
+                pad = kwargs.get("channel_padding_mask", None)
+                net_kwargs = {k: v for k, v in kwargs.items() if k != "channel_padding_mask"}
+                nn_out = layer.run_network(x=z * layer._prepare_mask(layer.mask, z), **net_kwargs)
+                weight, sldj = conv._get_weight(device_name=str(z.device), inverse=False)
+                z, ldj, _ = ops.mixture_coupling_actconv(
+                    z, nn_out, layer.mask, layer.num_mixtures, act.bias, act.scales, weight, sldj,
+                    scaling_factor=layer.scaling_factor, mixture_scaling_factor=layer.mixture_scaling_factor,
+                    channel_padding_mask=pad, length=kwargs.get("length", None), reg_max=layer.regularizer_max,
+                    reg_factor=layer.regularizer_factor, is_training=layer.training, ldj=ldj, want_reg=False)
+                skip.update((order[pos + 1][0], order[pos + 2][0]))
                 continue
             if fuse and pos + 1 < len(order):
                 pair = (layer, order[pos + 1][1]) if not reverse else (order[pos + 1][1], layer)
@@ -47,7 +64,7 @@ class FlowModel(nn.Module):
                     z, ldj = ops.actnorm_invconv(z, pair[0].bias, pair[0].scales, weight, sldj, reverse=reverse,
                                                  length=kwargs.get("length", None),
                                                  channel_padding_mask=kwargs.get("channel_padding_mask", None), ldj=ldj)
-                    skip = order[pos + 1][0]
+                    skip.add(order[pos + 1][0])
                     continue
             if (nll_request is not None and pos == len(order) - 1 and type(layer).__name__ == "CouplingLayer"
                     and not reverse and not torch.is_grad_enabled()):
@@ -58,6 +75,21 @@ class FlowModel(nn.Module):
                     z, nn_out, layer.scaling_factor, layer.mask, ldj=ldj, length=nll_request["length"],
                     channel_padding_mask=kwargs.get("channel_padding_mask", None), sums=nll_request["sums"],
                     sigma=nll_request["sigma"], log_sigma=nll_request["log_sigma"])
+                continue
+            if (nll_request is not None and pos == len(order) - 1 and type(layer).__name__ == "MixtureCDFCoupling"
+                    and not reverse and not torch.is_grad_enabled() and z.is_cuda):
+                # last layer = mixture-CDF coupling (every flow of the four experiments ends in one, e.g.
+                # experiments/set_modeling/flow_model.py:58-62): transform + prior log-prob + NLL in one kernel
+                pad = kwargs.get("channel_padding_mask", None)
+                net_kwargs = {k: v for k, v in kwargs.items() if k != "channel_padding_mask"}
+                nn_out = layer.run_network(x=z * layer._prepare_mask(layer.mask, z), **net_kwargs)
+                z, ldj, reg, _, nll_request["nll"] = ops.mixture_coupling_nll(
+                    z, nn_out, layer.mask, layer.num_mixtures, layer.scaling_factor, layer.mixture_scaling_factor,
+                    channel_padding_mask=pad, reg_max=layer.regularizer_max, reg_factor=layer.regularizer_factor,
+                    is_training=layer.training, ldj=ldj, length=nll_request["length"],
+                    sigma=nll_request["sigma"], log_sigma=nll_request["log_sigma"])
+                if nll_request["sums"] is not None:
+                    ops.nll_sum(nll_request["nll"], nll_request["sums"])
                 continue
             res = layer(z, reverse=reverse, get_ldj_per_layer=get_ldj_per_layer, **kwargs)
             if len(res) == 2:
@@ -91,9 +123,9 @@ class FlowModel(nn.Module):
         nll_b = (-ldj_b - sum_{n,d} log p(z_bnd) * pad_bn) / length_b).  Returns (z, ldj, nll [B]); `sums` (fp64 [2],
         optional) receives (sum_b nll_b, B) — the pair that is all-reduced over ranks.
 
-        When the last flow layer is an affine `CouplingLayer`, that layer and the NLL assembly run as ONE kernel
-        (cnf_affine_coupling_nll: the prior term is accumulated while z is still in registers); otherwise the
-        separate prior kernel is used.  Same numbers either way (tests).  Goes through `self.forward`, so the masks a
+        When the last flow layer is an affine `CouplingLayer` or a `MixtureCDFCoupling`, that layer and the NLL
+        assembly run as ONE kernel (cnf_affine_coupling_nll / cnf_mixture_coupling_nll: the prior term is accumulated
+        while z is still in registers); otherwise the separate prior kernel is used.  Same numbers either way (tests).  Goes through `self.forward`, so the masks a
         subclass builds from `length` reach the layers as usual."""
         from .distributions import LogisticDistribution
         prior = prior if prior is not None else LogisticDistribution()

@@ -450,6 +450,40 @@ def mixture_coupling_nll(z, nn_out, mask, num_mixtures, scaling_factor=None, mix
     return z_out, ldj_out, reg, neglog, nll
 
 
+def mixture_coupling_actconv(z, nn_out, mask, num_mixtures, an_bias, an_scales, conv_weight, conv_sldj,
+                             scaling_factor=None, mixture_scaling_factor=None, channel_padding_mask=None, length=None,
+                             reg_max=-1, reg_factor=1, is_training=True, ldj=None, want_reg=True):
+    """Forward mixture coupling of one flow step + ActNorm + 1x1 convolution of the next step in one kernel
+    (== mixture_coupling then actnorm_invconv, bit for bit).  Returns (z_out, ldj_out, reg or None)."""
+    z = _f32(z, "z")
+    dev = z.device
+    B, N, D = z.shape
+    K = int(num_mixtures)
+    nn_out = _f32(nn_out, "nn_out")
+    if nn_out.numel() != z.numel() * (2 + 3 * K):
+        raise ValueError("nn_out must be [B,N,D*(2+3K)]; got %s for z %s, K=%d" % (tuple(nn_out.shape), tuple(z.shape), K))
+    sf = _opt_f32(scaling_factor, "scaling_factor", dev)
+    msf = _opt_f32(mixture_scaling_factor, "mixture_scaling_factor", dev)
+    m, mr, mc = _mask_desc(mask, D, dev)
+    act, n_act = _act_list(mask, m, mr, mc, D)
+    pad = _pad2d(channel_padding_mask, B, N, dev)
+    ln = _length(length, B, dev) if isinstance(length, torch.Tensor) else None
+    b, sc = _f32(an_bias.reshape(-1), "bias"), _f32(an_scales.reshape(-1), "scales")
+    w, sl = _f32(conv_weight, "weight"), _f32(conv_sldj.reshape(1), "sldj")
+    ldj_in, ldj_out = _ldj_io(ldj, B, dev, inplace=False)
+    z_out = torch.empty_like(z)
+    use_reg = reg_max > 0 and is_training
+    reg = torch.zeros(B, dtype=torch.float32, device=dev) if want_reg else None
+    ws = _mixture_workspace(dev, B)
+    _launch(dev, "cnf_mixture_coupling_actconv", _ptr(z), _ptr(nn_out), _ptr(sf), _ptr(msf), _ptr(m), mr, mc, act, n_act,
+                                                _ptr(pad), _ptr(ldj_in), _ptr(z_out), _ptr(ldj_out), _ptr(reg if use_reg else None),
+                                                _ptr(b), _ptr(sc), _ptr(w), _ptr(sl), _ptr(ln),
+                                                B, N, D, K, float(reg_max), float(reg_factor), int(bool(is_training)),
+                                                _ptr(ws), int(ws.numel()), _ptr(flag_word(dev)), _stream(dev))
+    _after(dev, "mixture-CDF coupling + ActNorm + InvertibleConv")
+    return z_out, ldj_out, reg
+
+
 def mixture_params(nn_out, mask, num_mixtures, scaling_factor=None, mixture_scaling_factor=None):
     nn_out = _f32(nn_out, "nn_out")
     dev = nn_out.device

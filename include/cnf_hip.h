@@ -200,6 +200,26 @@ int cnf_mixture_coupling_nll(const float* z, const float* nn_out,
                              void* workspace, int64_t workspace_bytes,
                              int* flags, cnf_stream_t stream);
 
+/* MixtureCDFCoupling.forward of flow step i (mixture_cdf_layer.py:45-92, with z' *= pad) followed by the ActNormFlow
+ * and InvertibleConv of step i+1 (activation_normalization.py:24-48, permutation_layers.py:106-136; forward direction)
+ * in ONE pass: the coupling's output gets z'' = (((z' + bias) e^{scales}) pad) @ W pad before it is written, and
+ * ldj_out = ldj_in + coupling log-det + sum(scales) len_a + sldj len_c  (len = length[b] if given, else sum(pad) for
+ * the ActNorm and N for the convolution).  Bit-identical to cnf_mixture_coupling(_ws) followed by cnf_actnorm_invconv;
+ * the intermediate [B,N,D] tensor is neither written nor read (8 B/elem of HBM traffic less per flow step).
+ * conv_weight [D,D] is the forward weight (InvertibleConv._get_weight), conv_sldj [1] its log|det|. */
+int cnf_mixture_coupling_actconv(const float* z, const float* nn_out,
+                                 const float* scaling_factor, const float* mixture_scaling_factor,
+                                 const float* mask, int mask_rows, int mask_cols,
+                                 const int* act_host, int n_act,
+                                 const float* pad,
+                                 const float* ldj_in, float* z_out, float* ldj_out, float* reg_out,
+                                 const float* an_bias, const float* an_scales, const float* conv_weight, const float* conv_sldj,
+                                 const float* length,
+                                 int B, int N, int D, int K,
+                                 double reg_max, double reg_factor, int is_training,
+                                 void* workspace, int64_t workspace_bytes,
+                                 int* flags, cnf_stream_t stream);
+
 /* Tuning / A-B knobs of the fp32 mixture kernels: which kernel serves math mode 1 (0 = token-pass kernel on
  * DMA-staged rows, default; 1 = the round-1 kernel), lanes per item for a run-time K (0 = automatic, 1, 2, 4),
  * and the number of waves a split-row launch aims at (default 4096). */
