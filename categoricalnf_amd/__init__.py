@@ -37,4 +37,15 @@ def install(force=False):
             raise RuntimeError("%s is already imported from %s; call categoricalnf_amd.install() before importing the "
                                "reference's layers (or pass force=True)" % (alias, sys.modules[alias].__name__))
         sys.modules[alias] = importlib.import_module(real)
+    # sub-modules this package does not provide (e.g. layers.categorical_encoding.variational_encoding, which the
+    # reference's own mutils.py imports) keep resolving to the reference checkout on sys.path
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    for alias in ("layers.flows", "layers.categorical_encoding"):
+        pkg = sys.modules[alias]
+        rel = os.path.join(*alias.split("."))
+        for entry in sys.path:
+            cand = os.path.join(entry or os.getcwd(), rel)
+            if os.path.isdir(cand) and not os.path.abspath(cand).startswith(here) and cand not in pkg.__path__:
+                pkg.__path__.append(cand)
     return [a for a, _ in pairs]

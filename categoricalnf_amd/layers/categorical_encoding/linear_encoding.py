@@ -57,8 +57,11 @@ class LinearCategoricalEncoding(FlowLayer):
 
     # ---- helpers -------------------------------------------------------------------------------
     def _is_mixture_model(self):
+        """One ExtActNorm conditioned on the class only AND a vocabulary the one-kernel encoder holds in LDS; larger
+        vocabularies take the composed path (same ExtActNorm kernel over the expanded [T*C, 1, D] tensor)."""
         return (len(self.flow_layers) == 1 and isinstance(self.flow_layers[0], ExtActNormFlow)
-                and not self.flow_layers[0].make_unique and not self.use_decoder)
+                and not self.flow_layers[0].make_unique and not self.use_decoder
+                and ops.encoder_fused_supported(self.num_categories, self.D))
 
     def class_table(self):
         """[C, 2D] rows [bias | scales_raw] = pred_net(embed_layer(c)) for every class (one tiny GEMM)."""

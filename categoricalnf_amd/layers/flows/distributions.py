@@ -9,6 +9,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from ... import compat
 from ... import functional as Fn
 from ... import ops
 from ...host_utils import get_param_val
@@ -54,21 +55,6 @@ class PriorDistribution(nn.Module):
     @staticmethod
     def get_string_of_distributions():
         return "%i - Gaussian, %i - Logistic" % (PriorDistribution.GAUSSIAN, PriorDistribution.LOGISTIC)
-
-
-class GaussianDistribution(PriorDistribution):
-    """Optional Gaussian prior; plain torch.distributions (not on the hot path of any default config)."""
-
-    def __init__(self, mu=0.0, sigma=1.0, **kwargs):
-        super().__init__(mu=mu, sigma=sigma, **kwargs)
-        self.mu = mu
-        self.sigma = sigma
-
-    def _create_distribution(self, mu=0.0, sigma=1.0, **kwargs):
-        return torch.distributions.normal.Normal(loc=mu, scale=sigma)
-
-    def info(self):
-        return "Gaussian distribution with mu=%f and sigma=%f" % (self.mu, self.sigma)
 
 
 class LogisticDistribution(PriorDistribution):
@@ -123,35 +109,19 @@ class LogisticDistribution(PriorDistribution):
 
 
 def create_prior_distribution(distribution_params):
-    """distributions.py:190-200."""
+    """distributions.py:190-200.  The logistic prior (the default of every experiment) runs on the HIP kernels; the
+    optional Gaussian prior is plain torch.distributions host code and is served by the reference's own class."""
     kind = get_param_val(distribution_params, "distribution_type", PriorDistribution.LOGISTIC)
     params = {k: v for k, v in distribution_params.items() if v is not None}
     if kind == PriorDistribution.GAUSSIAN:
-        return GaussianDistribution(**params)
+        return compat.fall_through("layers.flows.distributions", "GaussianDistribution")(**params)
     if kind == PriorDistribution.LOGISTIC:
         return LogisticDistribution(**params)
     print("[!] ERROR: Unknown distribution type %s" % str(kind))
     sys.exit(1)
 
 
-def add_prior_distribution_parameters(parser, add_name=""):
-    parser.add_argument("--%sprior_dist_type" % add_name, type=int, default=PriorDistribution.LOGISTIC,
-                        help="Selecting the prior distribution that should be used. Options are: " +
-                             PriorDistribution.get_string_of_distributions())
-    parser.add_argument("--%sprior_dist_mu" % add_name, type=float, default=None, help="Center location of the distribution.")
-    parser.add_argument("--%sprior_dist_sigma" % add_name, type=float, default=None, help="Scaling of the distribution.")
-    parser.add_argument("--%sprior_dist_start_x" % add_name, type=float, default=None,
-                        help="If distribution is bounded, but should be shifted, this parameter determines the start position.")
-    parser.add_argument("--%sprior_dist_stop_x" % add_name, type=float, default=None,
-                        help="If distribution is bounded, but should be shifted, this parameter determines the end position.")
-    return parser
-
-
-def prior_distribution_args_to_params(args, add_name=""):
-    return {
-        "distribution_type": getattr(args, "%sprior_dist_type" % add_name),
-        "mu": getattr(args, "%sprior_dist_mu" % add_name),
-        "sigma": getattr(args, "%sprior_dist_sigma" % add_name),
-        "start_x": getattr(args, "%sprior_dist_start_x" % add_name),
-        "stop_x": getattr(args, "%sprior_dist_stop_x" % add_name),
-    }
+def __getattr__(name):
+    # GaussianDistribution and the argparse helpers (add_prior_distribution_parameters, prior_distribution_args_to_params)
+    # are host-side code of the reference: served from its checkout, not re-typed here
+    return compat.fall_through("layers.flows.distributions", name)

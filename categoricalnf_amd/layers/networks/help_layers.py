@@ -53,7 +53,10 @@ class LinearNet(nn.Module):
         return self.main_net(feat)
 
     def set_bias(self, bias):
-        self.main_net[-1].bias.data = bias
+        # the reference assigns the tensor as it comes (help_layers.py:106); a float64 numpy prior then makes the bias
+        # double, which torch >= 2 refuses to mix with float activations — keep the parameter's own dtype
+        last = self.main_net[-1].bias
+        last.data = bias.to(device=last.device, dtype=last.dtype)
 
 
 def run_sequential_with_mask(net, x, length=None, channel_padding_mask=None, src_key_padding_mask=None,

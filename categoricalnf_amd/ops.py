@@ -572,6 +572,13 @@ def prior_nll(z, ldj, length=None, channel_padding_mask=None, sums=None,
     return neglog, nll
 
 
+def encoder_fused_supported(C, D):
+    """Whether the one-kernel mixture-model encoder (cnf_encoder_forward / cnf_encoder_decode) takes this vocabulary:
+    the derived class table [C, 6D+3] and the row partials must fit its 64 KiB of LDS, D <= 16 (C <= 530 at D = 4,
+    <= 227 at D = 10).  Larger vocabularies (wikitext: 10^4 classes) run the composed layer kernels instead."""
+    return D <= 16 and 4 * 512 * 4 + C * (6 * D + 3) * 4 <= 64 * 1024
+
+
 def encoder_forward(categ, eps, table, category_prior, beta=1.0, channel_padding_mask=None, ldj=None,
                     want_class_prob=False, sigma=LOGISTIC_SIGMA, log_sigma=LOGISTIC_LOG_SIGMA):
     dev = _dev(categ)

@@ -704,6 +704,49 @@ def gen_grads():
     save("grads", cases)
 
 
+def one_graph_case(GraphNodeFlow, Colours, seed, B, N, D, K, lo, hi):
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    params = {"coupling_num_flows": 2, "coupling_hidden_size": 32, "coupling_hidden_layers": 2, "coupling_num_mixtures": K,
+              "coupling_mask_ratio": 0.5, "coupling_dropout": 0.0,
+              "categ_encoding": {"use_dequantization": False, "use_variational": False, "use_decoder": False, "num_dimensions": D,
+                                 "flow_config": {"num_flows": 0, "hidden_layers": 2, "hidden_size": 128},
+                                 "decoder_config": {"num_layers": 1, "hidden_size": 64}}}
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = GraphNodeFlow(params, Colours)
+    for p in model.parameters():
+        p.data = p.data + 0.05 * torch.randn(p.shape)
+    model.eval()
+    g = torch.Generator().manual_seed(seed + 1)
+    ln = torch.randint(lo, hi + 1, (B,), generator=g)
+    ln[0] = N
+    adj = (torch.rand(B, N, N, generator=g) < 0.3).long()
+    adj = torch.triu(adj, 1)
+    adj = adj + adj.transpose(1, 2)
+    valid = (torch.arange(N).view(1, N) < ln.view(B, 1))
+    adj = adj * (valid.unsqueeze(1) & valid.unsqueeze(2)).long()
+    cat = torch.randint(0, 3, (B, N), generator=g) * valid.long()
+    torch.manual_seed(seed + 2)
+    u = torch.rand(B * N, 1, D)
+    torch.manual_seed(seed + 2)
+    with torch.no_grad():
+        z, ldj = model(cat, adjacency=adj, reverse=False, length=ln)
+        dec, _ = model(z, adjacency=adj, reverse=True, length=ln)
+        with contextlib.redirect_stdout(io.StringIO()):
+            rev_ok = bool(model.test_reversibility(cat, adj, ln))
+            perm_ok = bool(model.test_permutation(cat, adj, ln))
+        # the RGCN-attention sub-network of the first coupling in isolation (a plain PyTorch module on both sides)
+        pad = create_channel_mask(ln, max_len=N)
+        sub_in = torch.randn(B, N, D, generator=g) * pad
+        sub_out = model.flow_layers[3].nn(sub_in, adjacency=adj, channel_padding_mask=pad)
+    c = dict(meta=dict(B=B, N=N, D=D, K=K, hidden=32, layers=2, flows=2, rev_ok=rev_ok, perm_ok=perm_ok,
+                       infos=[l.info() for l in model.flow_layers]),
+             categ=cat, adjacency=adj, length=ln, u=u, z=z, ldj=ldj, decoded=dec, sub_in=sub_in, sub_out=sub_out)
+    for k, v in model.state_dict().items():
+        c["sd_" + k] = v
+    return c
+
+
 def gen_graph_node_flow():
     """configs[2]: node-based GraphCNF for graph colouring (experiments/graph_coloring/graph_node_flow.py) with the
     RGCN-attention sub-network, 3 colours, synthetic sparse graphs of 6..10 nodes, reg_max 3.5 x 2, eval mode."""
@@ -715,47 +758,12 @@ def gen_graph_node_flow():
         def num_node_types():
             return 3
 
-    torch.manual_seed(70)
-    np.random.seed(70)
-    params = {"coupling_num_flows": 2, "coupling_hidden_size": 32, "coupling_hidden_layers": 2, "coupling_num_mixtures": 8,
-              "coupling_mask_ratio": 0.5, "coupling_dropout": 0.0,
-              "categ_encoding": {"use_dequantization": False, "use_variational": False, "use_decoder": False, "num_dimensions": 2,
-                                 "flow_config": {"num_flows": 0, "hidden_layers": 2, "hidden_size": 128},
-                                 "decoder_config": {"num_layers": 1, "hidden_size": 64}}}
-    with contextlib.redirect_stdout(io.StringIO()):
-        model = GraphNodeFlow(params, Colours)
-    for p in model.parameters():
-        p.data = p.data + 0.05 * torch.randn(p.shape)
-    model.eval()
-    B, N = 8, 10
-    g = torch.Generator().manual_seed(71)
-    ln = torch.randint(6, N + 1, (B,), generator=g)
-    ln[0] = N
-    adj = (torch.rand(B, N, N, generator=g) < 0.3).long()
-    adj = torch.triu(adj, 1)
-    adj = adj + adj.transpose(1, 2)
-    valid = (torch.arange(N).view(1, N) < ln.view(B, 1))
-    adj = adj * (valid.unsqueeze(1) & valid.unsqueeze(2)).long()
-    cat = torch.randint(0, 3, (B, N), generator=g) * valid.long()
-    torch.manual_seed(72)
-    u = torch.rand(B * N, 1, 2)
-    torch.manual_seed(72)
-    with torch.no_grad():
-        z, ldj = model(cat, adjacency=adj, reverse=False, length=ln)
-        dec, _ = model(z, adjacency=adj, reverse=True, length=ln)
-        with contextlib.redirect_stdout(io.StringIO()):
-            rev_ok = bool(model.test_reversibility(cat, adj, ln))
-            perm_ok = bool(model.test_permutation(cat, adj, ln))
-        # the RGCN-attention sub-network of the first coupling in isolation (a plain PyTorch module on both sides)
-        pad = create_channel_mask(ln, max_len=N)
-        sub_in = torch.randn(B, N, 2, generator=g) * pad
-        sub_out = model.flow_layers[3].nn(sub_in, adjacency=adj, channel_padding_mask=pad)
-    c = dict(meta=dict(B=B, N=N, D=2, K=8, hidden=32, layers=2, flows=2, rev_ok=rev_ok, perm_ok=perm_ok,
-                       infos=[l.info() for l in model.flow_layers]),
-             categ=cat, adjacency=adj, length=ln, u=u, z=z, ldj=ldj, decoded=dec, sub_in=sub_in, sub_out=sub_out)
-    for k, v in model.state_dict().items():
-        c["sd_" + k] = v
-    save("graph_node_flow", [c])
+    cases = []
+    # case 0: 6..10-node graphs (round 1); cases 1, 2: the sizes of the reference's tiny_3 (10..20 nodes, D = 2, K = 8)
+    # and large_3 (25..50 nodes, D = 6, K = 16) data sets (experiments/graph_coloring/README.md:19-43)
+    for seed, B, N, D, K, lo, hi in [(70, 8, 10, 2, 8, 6, 10), (170, 6, 20, 2, 8, 10, 20), (270, 3, 50, 6, 16, 25, 50)]:
+        cases.append(one_graph_case(GraphNodeFlow, Colours, seed, B, N, D, K, lo, hi))
+    save("graph_node_flow", cases)
 
 
 def gen_language_model():
@@ -775,10 +783,12 @@ def gen_language_model():
         vectors = None
 
     cases = []
-    for ci, (K, D, flows, enc_flows, hidden) in enumerate([(5, 3, 2, 1, 32), (51, 3, 1, 0, 32)]):
+    # cases 0, 1: T = 24 (round 1); case 2: the Penn Treebank configuration's sizes — sequence length 288, 51 symbols,
+    # D = 3, K = 51, one flow (experiments/language_modeling/README.md:8-21), LSTM hidden size reduced to 48
+    for ci, (K, D, flows, enc_flows, hidden, V, T, B) in enumerate([(5, 3, 2, 1, 32, 20, 24, 6), (51, 3, 1, 0, 32, 20, 24, 6),
+                                                                      (51, 3, 1, 0, 48, 51, 288, 3)]):
         torch.manual_seed(80 + ci)
         np.random.seed(80 + ci)
-        V, T = 20, 24
         params = {"max_seq_len": T, "coupling_hidden_layers": 1, "coupling_hidden_size": hidden, "coupling_num_flows": flows,
                   "coupling_num_mixtures": K, "coupling_dropout": 0.0, "coupling_input_dropout": 0.0,
                   "categ_encoding": {"use_dequantization": False, "use_variational": False, "use_decoder": False,
@@ -789,9 +799,8 @@ def gen_language_model():
         for p_ in model.parameters():
             p_.data = p_.data + 0.05 * torch.randn(p_.shape)
         model.eval()
-        B = 6
         g = torch.Generator().manual_seed(81 + ci)
-        ln = torch.randint(5, T + 1, (B,), generator=g)
+        ln = torch.randint(5 if T < 100 else 40, T + 1, (B,), generator=g)
         ln[0] = T
         valid = (torch.arange(T).view(1, T) < ln.view(B, 1))
         x = torch.randint(0, V, (B, T), generator=g) * valid.long()
@@ -814,6 +823,132 @@ def gen_language_model():
     save("language_model", cases)
 
 
+def gen_graph_cnf():
+    """configs[4]: the three-stage molecule GraphCNF (experiments/molecule_generation/graphCNF.py) assembled by the
+    REFERENCE from its own layers, with every coupling sub-network (RGCN in stage 1, Edge-GNN in stages 2 / 3 — the
+    latter cannot run on torch >= 2, layers/networks/graph_layers.py:527,668) replaced by a stub that returns a
+    pre-drawn tensor.  Captured: the three encoders' uniform noise, the injected sub-network outputs, node / edge latents
+    after every stage, the log-det after every layer, the final outputs, and one reverse (sampling) pass from given
+    latents: decoded node types and adjacency."""
+    with contextlib.redirect_stdout(io.StringIO()):
+        from experiments.molecule_generation.graphCNF import GraphCNF
+        from experiments.molecule_generation.graph_node_edge_coupling import NodeEdgeCoupling
+
+    NT, ET, NMAX = 5, 3, 9
+
+    class Molecules:
+        @staticmethod
+        def max_num_nodes():
+            return NMAX
+
+        @staticmethod
+        def num_node_types():
+            return NT
+
+        @staticmethod
+        def num_edge_types():
+            return ET
+
+        @staticmethod
+        def num_max_neighbours():
+            return 4
+
+        @staticmethod
+        def get_node_prior(data_root=None):
+            return np.array([0.4, 0.3, 0.15, 0.1, 0.05], dtype=np.float32)
+
+        @staticmethod
+        def get_edge_prior(data_root=None):
+            return np.array([0.7, 0.2, 0.1], dtype=np.float32)
+
+    class InjectPair(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.value = None
+
+        def forward(self, **kwargs):
+            return self.value
+
+    torch.manual_seed(90)
+    np.random.seed(90)
+    enc = lambda d: {"use_dequantization": False, "use_variational": False, "use_decoder": False, "num_dimensions": d,
+                     "flow_config": {"num_flows": 0, "hidden_layers": 2, "hidden_size": 128},
+                     "decoder_config": {"num_layers": 1, "hidden_size": 64}}
+    DN, DE, KN, KE = 4, 2, 8, 4
+    params = {"categ_encoding_nodes": enc(DN), "categ_encoding_edges": enc(DE), "encoding_virtual_num_flows": 0,
+              "coupling_hidden_size_nodes": 16, "coupling_hidden_size_edges": 8, "coupling_num_flows": "1,2,2",
+              "coupling_hidden_layers": 1, "coupling_num_mixtures_nodes": KN, "coupling_num_mixtures_edges": KE,
+              "coupling_mask_ratio": 0.5, "coupling_dropout": 0.0}
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = GraphCNF(params, Molecules)
+    # the reference hands the decoder's last bias a float64 numpy prior (graphCNF.py:77); torch >= 2 no longer mixes
+    # a double bias with float activations in addmm, so the bias is cast to fp32 here (in memory, this run only)
+    model.edge_virtual_decoder.float()
+    B, N = 5, NMAX
+    E = N * (N - 1) // 2
+    g = torch.Generator().manual_seed(91)
+    injected = []
+    for flows in (model.step1_flows, model.step2_flows, model.step3_flows):
+        for layer in flows:
+            if isinstance(layer, NodeEdgeCoupling):
+                layer.nn = InjectPair()
+                layer.nn.value = (0.5 * torch.randn(B, N, layer.c_out_nodes, generator=g), 0.5 * torch.randn(B, E, layer.c_out_edges, generator=g))
+                injected += list(layer.nn.value)
+            elif layer.__class__.__name__ == "MixtureCDFCoupling":
+                layer.nn = Inject()
+                layer.nn.value = 0.5 * torch.randn(B, N, DN * (2 + 3 * KN), generator=g)
+                injected.append(layer.nn.value)
+    for p_ in model.parameters():
+        p_.data = p_.data + 0.1 * torch.randn(p_.shape, generator=g)
+    model.eval()
+    ln = torch.randint(4, N + 1, (B,), generator=g)
+    ln[0] = N
+    valid = (torch.arange(N).view(1, N) < ln.view(B, 1))
+    nodes = torch.randint(0, NT, (B, N), generator=g) * valid.long()
+    adj = torch.randint(0, ET + 1, (B, N, N), generator=g) * (torch.rand(B, N, N, generator=g) < 0.35).long()
+    adj = torch.triu(adj, 1)
+    adj = (adj + adj.transpose(1, 2)) * (valid.unsqueeze(1) & valid.unsqueeze(2)).long()
+
+    stage_out = {}
+    hooks = [model.step1_flows[-1].register_forward_hook(lambda m, i, o: stage_out.__setitem__("s1", o)),
+             model.step2_flows[-1].register_forward_hook(lambda m, i, o: stage_out.__setitem__("s2", o)),
+             model.step3_flows[-1].register_forward_hook(lambda m, i, o: stage_out.__setitem__("s3", o))]
+    torch.manual_seed(92)
+    u_nodes, u_attr, u_virtual = torch.rand(B * N, 1, DN), torch.rand(B * E, 1, DE), torch.rand(B * E, 1, DE)
+    torch.manual_seed(92)
+    with torch.no_grad():
+        z, ldj, per_layer = model(nodes, adjacency=adj, reverse=False, get_ldj_per_layer=True, length=ln)
+    for h in hooks:
+        h.remove()
+
+    def layer_value(d):
+        if isinstance(d, torch.Tensor):
+            return d
+        if "ldj" in d:
+            return d["ldj"]
+        if len(d) == 0:
+            return torch.full((B,), float("nan"))         # an encoder in eval mode reports nothing
+        return list(d.values())[0]
+    layer_ldj = torch.stack([layer_value(d).float() for d in per_layer])
+    # reverse (sampling) pass from fixed latents: node latents = the forward output, edge latents drawn like the reference
+    torch.manual_seed(93)
+    edge_latents = model.prior_distribution.sample(shape=(B, E, DE))
+    torch.manual_seed(93)
+    with torch.no_grad():
+        (dec_nodes, dec_adj), ldj_rev = model(z, reverse=True, length=ln)
+    c = dict(meta=dict(B=B, N=N, E=E, DN=DN, DE=DE, KN=KN, KE=KE, NT=NT, ET=ET, params=params,
+                       infos=[l.info() for l in list(model.step1_flows) + list(model.step2_flows) + list(model.step3_flows)]),
+             nodes=nodes, adjacency=adj, length=ln, u_nodes=u_nodes, u_attr=u_attr, u_virtual=u_virtual,
+             z=z, ldj=ldj, layer_ldj=layer_ldj, s1_z=stage_out["s1"][0], s2_z_nodes=stage_out["s2"][0], s2_z_edges=stage_out["s2"][1],
+             s3_z_nodes=stage_out["s3"][0], s3_z_edges=stage_out["s3"][1], edge_latents=edge_latents, dec_nodes=dec_nodes,
+             dec_adjacency=dec_adj, ldj_rev=ldj_rev)
+    for i, t in enumerate(injected):
+        c["inj_%02d" % i] = t
+    for k, v in model.state_dict().items():
+        c["sd_" + k] = v
+    save("graph_cnf", [c])
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
     gen_affine()
@@ -830,3 +965,4 @@ if __name__ == "__main__":
     gen_grads()
     gen_graph_node_flow()
     gen_language_model()
+    gen_graph_cnf()

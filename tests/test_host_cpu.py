@@ -242,10 +242,11 @@ def _graph_model(meta):
     return GraphNodeFlow(params, Colours)
 
 
-def test_graph_colouring_assembly_and_rgcn_subnet_match_reference():
+@pytest.mark.parametrize("c", load_cases("graph_node_flow"))
+def test_graph_colouring_assembly_and_rgcn_subnet_match_reference(c):
     """GraphNodeFlow mirror: reference checkpoint keys / info strings, and the RGCN-attention sub-network (a plain
-    PyTorch module, dense masked attention here vs. neighbour gathering in the reference) gives the reference's output."""
-    c = load_cases("graph_node_flow")[0]
+    PyTorch module, dense masked attention here vs. neighbour gathering in the reference) gives the reference's output
+    (6..10-, 10..20- and 25..50-node graphs)."""
     model = _graph_model(c.meta)
     sd = {k[3:]: v for k, v in c.items() if k.startswith("sd_")}
     assert sorted(model.state_dict().keys()) == sorted(sd.keys())
@@ -370,3 +371,148 @@ def test_traffic_is_reported_only_for_the_sources_it_was_measured_on(tmp_path):
     assert bench.read_traffic(str(good))[0] == 123.0
     assert bench.read_traffic(str(stale))[0] is None and "other kernel sources" in bench.read_traffic(str(stale))[1]
     assert bench.read_traffic(str(tmp_path / "none.json"))[0] is None
+
+
+class _InjectNodes(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.value = None
+
+    def forward(self, x=None, **kwargs):
+        return self.value
+
+
+class _InjectPair(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.value = None
+
+    def forward(self, **kwargs):
+        return self.value
+
+
+def _graph_cnf_model(c):
+    """The molecule GraphCNF of this package with the golden case's weights and injected sub-network outputs."""
+    import contextlib, io
+    from categoricalnf_amd.experiments.molecule_generation import GraphCNF
+    from categoricalnf_amd.experiments.graph_node_edge_coupling import NodeEdgeCoupling
+    m = c.meta
+
+    class Molecules:
+        max_num_nodes = staticmethod(lambda: m["N"])
+        num_node_types = staticmethod(lambda: m["NT"])
+        num_edge_types = staticmethod(lambda: m["ET"])
+        num_max_neighbours = staticmethod(lambda: 4)
+        get_node_prior = staticmethod(lambda data_root=None: np.array([0.4, 0.3, 0.15, 0.1, 0.05], dtype=np.float32))
+        get_edge_prior = staticmethod(lambda data_root=None: np.array([0.7, 0.2, 0.1], dtype=np.float32))
+
+    import copy
+    params = copy.deepcopy(m["params"])
+    for key in ("categ_encoding_nodes", "categ_encoding_edges"):      # create_encoding pops these two from the dict it is given
+        params[key].setdefault("use_dequantization", False)
+        params[key].setdefault("use_variational", False)
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = GraphCNF(params, Molecules, node_subnet=lambda c_out: _InjectNodes(),
+                         edge_subnet=lambda stage, c_out_nodes, c_out_edges: _InjectPair())
+    model.load_state_dict({k[3:]: v for k, v in c.items() if k.startswith("sd_")}, strict=True)
+    inj = [c["inj_%02d" % i] for i in range(sum(1 for k in c.keys() if k.startswith("inj_")))]
+    it = iter(inj)
+    for flows in (model.step1_flows, model.step2_flows, model.step3_flows):
+        for layer in flows:
+            if isinstance(layer, NodeEdgeCoupling):
+                layer.nn.value = (next(it), next(it))
+            elif type(layer).__name__ == "MixtureCDFCoupling":
+                layer.nn.value = next(it)
+    return model.eval()
+
+
+def test_graph_cnf_assembly_matches_reference_names_and_edge_list_helpers():
+    """Molecule GraphCNF (configs[4]): the assembly of this package takes the reference's state_dict as is (strict),
+    prints the reference's layer descriptions, and its vectorised edge-list helpers agree with the reference's outputs
+    (the golden adjacency decodes back through pairs <-> adjacency)."""
+    from categoricalnf_amd.experiments.molecule_generation import adjacency2pairs, pairs2adjacency, get_adjacency_indices
+    c = load_cases("graph_cnf")[0]
+    model = _graph_cnf_model(c)
+    infos = [l.info() for l in list(model.step1_flows) + list(model.step2_flows) + list(model.step3_flows)]
+    assert infos == c.meta["infos"]
+    pairs, (i, j), valid = adjacency2pairs(c.adjacency, c.length)
+    N = c.meta["N"]
+    ref_i = torch.tensor([a for a in range(N) for b in range(a + 1, N)])
+    ref_j = torch.tensor([b for a in range(N) for b in range(a + 1, N)])
+    assert torch.equal(i, ref_i) and torch.equal(j, ref_j)
+    assert torch.equal(pairs, c.adjacency.reshape(-1, N * N)[:, ref_i + ref_j * N])
+    assert torch.equal(valid, ((ref_i[None] < c.length[:, None]) & (ref_j[None] < c.length[:, None])).float())
+    assert torch.equal(pairs2adjacency(N, pairs, c.length, (i, j)), c.adjacency)
+    assert torch.equal(get_adjacency_indices(N, c.length)[0], valid)
+    assert model.edge_virtual_decoder.layers.main_net[-1].bias.dtype == torch.float32
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/experiments"), reason="reference checkout only exists in the build container")
+def test_reference_edge_gnn_runs_on_torch2_through_compat_and_plugs_into_graph_cnf():
+    """§8 f-2: the Edge-GNN sub-network is NOT re-typed in this package; categoricalnf_amd.compat imports the reference's
+    own graph_layers.py with the integer-division fix applied in memory (its sparse attention stops on torch >= 2
+    otherwise) and the molecule GraphCNF of this package takes it as its stage-2/3 sub-network.  Also: CLI helpers and
+    the Gaussian prior fall through to the reference's files after install()."""
+    code = r'''
+import sys, io, contextlib
+sys.path.insert(0, "%s"); sys.path.insert(1, "/root/reference")
+import numpy as np, torch
+import categoricalnf_amd
+from categoricalnf_amd import compat
+categoricalnf_amd.install()
+from layers.flows.distributions import add_prior_distribution_parameters, GaussianDistribution, LogisticDistribution
+from layers.categorical_encoding.mutils import add_encoding_parameters, create_encoding
+assert add_prior_distribution_parameters.__module__.startswith("_cnf_reference") and GaussianDistribution.__module__.startswith("_cnf_reference")
+assert LogisticDistribution.__module__.startswith("categoricalnf_amd") and create_encoding.__module__.startswith("categoricalnf_amd")
+with contextlib.redirect_stdout(io.StringIO()):
+    gl = compat.reference_module("layers.networks.graph_layers")
+from categoricalnf_amd.experiments.molecule_generation import GraphCNF, adjacency2pairs
+HN, HE = 16, 8
+
+
+class Molecules:
+    max_num_nodes = staticmethod(lambda: 9)
+    num_node_types = staticmethod(lambda: 5)
+    num_edge_types = staticmethod(lambda: 3)
+    num_max_neighbours = staticmethod(lambda: 4)
+    get_node_prior = staticmethod(lambda data_root=None: np.full(5, 0.2, dtype=np.float32))
+    get_edge_prior = staticmethod(lambda data_root=None: np.full(3, 1 / 3, dtype=np.float32))
+
+
+def edge_subnet(stage, c_out_nodes, c_out_edges):
+    e2n = (lambda: gl.Edge2NodeAttnLayer(hidden_size_nodes=HN, hidden_size_edges=HE, skip_config=2)) if stage == 1 else \
+          (lambda: gl.Edge2NodeQKVAttnLayer(hidden_size_nodes=HN, hidden_size_edges=HE, skip_config=2))
+    n2e = lambda: gl.Node2EdgePlainLayer(hidden_size_nodes=HN, hidden_size_edges=HE, skip_config=2)
+    return gl.EdgeGNN(c_in_nodes=4, c_in_edges=2, c_out_nodes=c_out_nodes, c_out_edges=c_out_edges,
+                      edge_gnn_layer_func=lambda: gl.EdgeGNNLayer(edge2node_layer_func=e2n, node2edge_layer_func=n2e),
+                      max_neighbours=4, num_layers=1)
+
+
+enc = lambda d: {"use_dequantization": False, "use_variational": False, "use_decoder": False, "num_dimensions": d,
+                 "flow_config": {"num_flows": 0}, "decoder_config": {}}
+params = {"categ_encoding_nodes": enc(4), "categ_encoding_edges": enc(2), "encoding_virtual_num_flows": 0, "coupling_hidden_size_nodes": HN,
+          "coupling_hidden_size_edges": HE, "coupling_num_flows": "1,1,1", "coupling_hidden_layers": 1, "coupling_num_mixtures_nodes": 4,
+          "coupling_num_mixtures_edges": 4}
+with contextlib.redirect_stdout(io.StringIO()):
+    model = GraphCNF(params, Molecules, edge_subnet=edge_subnet)
+B, N = 3, 9
+g = torch.Generator().manual_seed(0)
+ln = torch.tensor([9, 6, 4])
+valid = torch.arange(N)[None] < ln[:, None]
+adj = torch.triu((torch.rand(B, N, N, generator=g) < 0.3).long() * torch.randint(1, 4, (B, N, N), generator=g), 1)
+adj = (adj + adj.transpose(1, 2)) * (valid[:, None] & valid[:, :, None]).long()
+pairs, x_indices, mv = adjacency2pairs(adj, ln)
+real = mv * (pairs != 0).float()
+coupling = model.step2_flows[2]
+zn, ze = torch.randn(B, N, 4, generator=g), torch.randn(B, pairs.size(1), 2, generator=g)
+with torch.no_grad():
+    out_n, out_e = coupling.nn(z_nodes=zn, z_edges=ze, length=ln, channel_padding_mask=valid.float().unsqueeze(-1), x_indices=x_indices,
+                               mask_valid=real, binary_adjacency=(adj > 0).long())
+assert out_n.shape == (B, N, coupling.c_out_nodes) and out_e.shape == (B, pairs.size(1), coupling.c_out_edges)
+assert torch.isfinite(out_n).all() and torch.isfinite(out_e).all()
+print("OK", sum(p.numel() for p in model.parameters()))
+''' % ROOT
+    env = dict(os.environ, MPLBACKEND="Agg", PYTHONDONTWRITEBYTECODE="1")
+    out = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd="/tmp")
+    assert out.returncode == 0, out.stderr[-2500:]
+    assert "OK" in out.stdout

@@ -12,8 +12,6 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 params = {"set_size": 16, "coupling_hidden_layers": 2, "coupling_hidden_size": 256, "coupling_num_flows": 8, "coupling_mask_ratio": 0.5,
           "coupling_num_mixtures": 8, "categ_encoding": {"use_dequantization": False, "use_variational": False, "use_decoder": False,
                                                          "num_dimensions": 4, "flow_config": {"num_flows": 0}, "decoder_config": {}}}
-import copy
-params_fresh = copy.deepcopy(params)            # create_encoding consumes keys of the dictionary it is given
 torch.manual_seed(0)
 with contextlib.redirect_stdout(io.StringIO()):
     model = FlowSetModeling(params, SetShufflingDataset).cuda().train()
@@ -43,24 +41,3 @@ for i in range(steps):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
 print("batch %d eager  : %.2f ms / training step (%.0f sets/s), loss %.4f" % (B, dt * 1e3, B / dt, float(loss.detach())))
-if len(sys.argv) > 3 and sys.argv[3] == "graph":
-    # the same step captured once in a HIP graph (graphs.GraphedTrainStep) and replayed
-    from categoricalnf_amd.graphs import GraphedTrainStep
-    loss = float(loss.detach())
-    # capture on a FRESH module with the same weights: parameters that already took part in an eager backward keep
-    # AccumulateGrad nodes bound to the default stream, which are not captured (see GraphedTrainStep's docstring)
-    with contextlib.redirect_stdout(io.StringIO()):
-        fresh = FlowSetModeling(params_fresh, SetShufflingDataset).cuda().train()
-    fresh.load_state_dict(model.state_dict())
-    del model, opt
-    gstep = GraphedTrainStep(fresh, lambda ps: torch.optim.RAdam(ps, lr=torch.tensor(7.5e-4), capturable=True), xs[0], ln,
-                             max_grad_norm=0.25, beta=1, noise_shape=(B * 16, 1, 4))
-    for i in range(3):
-        gstep(xs[i % 4])
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        loss = gstep(xs[i % 4])
-    torch.cuda.synchronize()
-    dg = (time.perf_counter() - t0) / steps
-    print("batch %d graphed: %.2f ms / training step (%.0f sets/s), loss %.4f  -> %.2fx" % (B, dg * 1e3, B / dg, float(loss), dt / dg))

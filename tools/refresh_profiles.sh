@@ -32,7 +32,7 @@ rm -rf "$OUT/prof_layers"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_layers" -o layers -- \
     python tools/layer_probe.py > "$OUT/layer_probe.log" 2>&1
 rm -f "$OUT"/prof_layers/*kernel_trace.csv
-( for b in 64 256 1024; do timeout 300 python tools/bench_train_step.py $b 20 graph 2>&1 | grep "^batch"; done ) > "$OUT/train_step.txt"; cat "$OUT/train_step.txt"
+( for b in 64 256 1024; do timeout 300 python tools/bench_train_step.py $b 20 2>&1 | grep "^batch"; done ) > "$OUT/train_step.txt"; cat "$OUT/train_step.txt"
 rm -rf "$OUT/prof_train"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_train" -o train -- \
     python tools/bench_train_step.py 8192 10 > "$OUT/train_prof.log" 2>&1
