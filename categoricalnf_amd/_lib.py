@@ -62,6 +62,8 @@ SIGNATURES = {
     "cnf_sigmoid_flow_bwd": [_p, _p, _p, _p, _i, _i, _i, _f, _p],
     "cnf_mixture_coupling_bwd": [_p, _p, _p, _p, _p, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p,
                                  _i, _i, _i, _i, _d, _d, _i, _p],
+    "cnf_mixture_coupling_bwd_f32": [_p, _p, _p, _p, _p, _i, _i, _p, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p,
+                                     _i, _i, _i, _i, _d, _d, _i, _p],
     "cnf_encoder_forward_bwd": [_p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
     "cnf_affine_params_bwd": [_p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     "cnf_affine_transform_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],

@@ -699,6 +699,9 @@ static int affine_coupling_impl(const char* who, const float* z, const float* nn
     a.div_p = make_fastdiv((uint32_t)a.P);
     a.pad = pad; a.length = length; a.neglog_out = neglog_out; a.nll_out = nll_out; a.acc = acc;
     a.prior = make_prior_const(sigma, log_sigma);
+    // one tiling for the plain and the NLL variant: the per-row summation order depends on it, and the fused kernel's
+    // log-det must stay bit-equal to the plain forward's (and exactly minus the inverse's).  A larger tile (384 chunks)
+    // would save the NLL variant 0.5 us at the benchmark shape (tools/sweep_nll.py) at the price of that equality.
     const RowTiling tl = make_row_tiling(B, a.L, 0, tile_chunks_target());
     DISPATCH_VEC(tl, launch_affine<V>(a, tl, scaling_factor != nullptr, reverse != 0, (hipStream_t)stream));
     if (sums) CNF_LAUNCH(nll_sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, nll_out, B, sums);

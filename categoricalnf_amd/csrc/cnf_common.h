@@ -74,7 +74,7 @@ struct RowTiling {
     long ntiles;
     FastDiv div_cpr;
 };
-RowTiling make_row_tiling(int B, int L, int force_vec = 0, int target_chunks = 256);
+RowTiling make_row_tiling(int B, int L, int force_vec = 0, int target_chunks = 256, int gran = kWave);
 inline dim3 tiling_grid(const RowTiling& t) {
     if (t.bpr) return dim3((unsigned)t.B);
     return dim3((unsigned)((t.ntiles + kWavesPerBlock - 1) / kWavesPerBlock));

@@ -65,7 +65,7 @@ bool prof_take(hipEvent_t* start, hipEvent_t* stop) {
     return true;
 }
 
-RowTiling make_row_tiling(int B, int L, int force_vec, int target_chunks) {
+RowTiling make_row_tiling(int B, int L, int force_vec, int target_chunks, int gran) {
     RowTiling t;
     t.B = B;
     t.L = L;
@@ -79,7 +79,8 @@ RowTiling make_row_tiling(int B, int L, int force_vec, int target_chunks) {
         const int rmax = std::max(1, std::min(target / t.cpr, std::max(1, B)));
         for (int r = 1; r <= rmax; ++r) {
             const int ch = r * t.cpr;
-            const double eff = (double)ch / (double)(((ch + kWave - 1) / kWave) * kWave);
+            // `gran` chunks are walked per iteration (64 lanes x chunks in flight per lane)
+            const double eff = (double)ch / (double)(((ch + gran - 1) / gran) * gran);
             if (eff >= best_eff - 1e-9) {
                 best_eff = std::max(eff, best_eff);
                 best = r;

@@ -61,6 +61,9 @@ struct MixArgs {
 // cnf_mixture_tok.hip
 bool launch_mixture_tok(MixArgs& a, hipStream_t st, int force_g);
 void set_mixture_split_waves(int w);
+// cnf_mixture_tok_bwd.hip
+bool launch_mixture_tok_bwd(MixArgs& a, const float* g_zout, const float* g_ldj, float* g_z, float* g_nn,
+                            float* g_sf, float* g_msf, float* workspace, hipStream_t st, int force_g);
 
 __device__ __forceinline__ double safe_log(double x) { return log(fmax(x, 1e-22)); }
 

@@ -1161,6 +1161,44 @@ int cnf_mixture_coupling_actconv(const float* z, const float* nn_out,
     return launch_mixture(a, false, act_host, n_act, (hipStream_t)stream, "cnf_mixture_coupling_actconv");
 }
 
+int cnf_mixture_coupling_bwd_f32(const float* z, const float* nn_out,
+                                 const float* scaling_factor, const float* mixture_scaling_factor,
+                                 const float* mask, int mask_rows, int mask_cols,
+                                 const int* act_host, int n_act,
+                                 const float* pad, int pad_in_transform, int pad_output,
+                                 const float* g_zout, const float* g_ldj,
+                                 float* g_z, float* g_nn, float* g_scaling_factor, float* g_mixture_scaling_factor,
+                                 float* workspace,
+                                 int B, int N, int D, int K, double reg_max, double reg_factor, int is_training,
+                                 cnf_stream_t stream) {
+    CNF_REQUIRE(z && nn_out && g_z && g_nn && workspace, "cnf_mixture_coupling_bwd_f32: null tensor");
+    CNF_REQUIRE(B > 0 && N > 0 && D > 0 && K > 0, "cnf_mixture_coupling_bwd_f32: bad shape");
+    CNF_REQUIRE(!scaling_factor || g_scaling_factor, "cnf_mixture_coupling_bwd_f32: g_scaling_factor missing");
+    CNF_REQUIRE(!mixture_scaling_factor || g_mixture_scaling_factor, "cnf_mixture_coupling_bwd_f32: g_mixture_scaling_factor missing");
+    if (math_mode() == 1 && g_mix_kernel != 1 && D <= kMaxAct && (long)N * D < 65536) {
+        MixArgs a = {};
+        a.z = z; a.nn = nn_out; a.sf = scaling_factor; a.msf = mixture_scaling_factor; a.mask = mask; a.pad = pad;
+        a.B = B; a.N = N; a.D = D; a.K = K; a.mr = mask ? mask_rows : 1; a.mc = mask ? mask_cols : D;
+        if (a.mr > N) a.mr = N;
+        a.P = 2 + 3 * K; a.L = N * D;
+        a.pad_in_transform = pad ? pad_in_transform : 0;
+        a.pad_output = pad ? pad_output : 0;
+        a.use_reg = (reg_max > 0 && is_training) ? 1 : 0;
+        a.reg_max = reg_max; a.reg_factor = reg_factor;
+        a.div_d = make_fastdiv((uint32_t)D);
+        if (a.mr >= 1 && (a.mc == D || a.mc == 1)) {
+            fill_act(a, act_host, n_act);
+            a.div_da = make_fastdiv((uint32_t)a.DA);
+            if (launch_mixture_tok_bwd(a, g_zout, g_ldj, g_z, g_nn, g_scaling_factor, g_mixture_scaling_factor, workspace,
+                                       (hipStream_t)stream, g_mix_lanes))
+                return launch_status("cnf_mixture_coupling_bwd_f32");
+        }
+    }
+    return cnf_mixture_coupling_bwd(z, nn_out, scaling_factor, mixture_scaling_factor, mask, mask_rows, mask_cols, pad,
+                                    pad_in_transform, pad_output, g_zout, g_ldj, g_z, g_nn, g_scaling_factor,
+                                    g_mixture_scaling_factor, workspace, B, N, D, K, reg_max, reg_factor, is_training, stream);
+}
+
 int cnf_mixture_transform(const double* z, const double* t, const double* log_s,
                           const double* log_pi, const double* mixt_t, const double* mixt_log_s,
                           const float* mask, int mask_rows, int mask_cols,

@@ -238,7 +238,10 @@ __global__ __launch_bounds__(kBlock) void mixture_params_bwd_kernel(MixParamsBwd
     for (int i = threadIdx.x; i < PP; i += kBlock) a.partials[(size_t)blockIdx.x * PP + i] = acc[i];
 }
 
-__global__ __launch_bounds__(kBlock) void mix_reduce_partials_kernel(const float* partials, int nrows, int P, float* out) {
+// partials [nrows, P] -> column sums in fp64, fixed order; columns [0, split) go to out_a, the rest to out_b (either may
+// be null): the parameter-gradient tensors are written directly (two device-to-device copies cost ~10 us each)
+__global__ __launch_bounds__(kBlock) void mix_reduce_partials_kernel(const float* partials, int nrows, int P, float* out_a,
+                                                                     float* out_b, int split) {
     const int p = blockIdx.x;
     double accd = 0.0;
     for (int r = threadIdx.x; r < nrows; r += kBlock) accd += (double)partials[(size_t)r * P + p];
@@ -249,7 +252,11 @@ __global__ __launch_bounds__(kBlock) void mix_reduce_partials_kernel(const float
     if (threadIdx.x == 0) {
         double t = 0.0;
         for (int w = 0; w < kWavesPerBlock; ++w) t += sh[w];
-        out[p] = (float)t;
+        if (p < split) {
+            if (out_a) out_a[p] = (float)t;
+        } else if (out_b) {
+            out_b[p - split] = (float)t;
+        }
     }
 }
 
@@ -289,10 +296,8 @@ int cnf_mixture_coupling_bwd(const float* z, const float* nn_out,
     const int grid = (int)std::min<long>(std::max<long>((a.total + kBlock - 1) / kBlock, 1), kMixBwdGrid);
     CNF_LAUNCH((mixture_fwd_bwd_kernel<false>), dim3(grid), dim3(kBlock), 0, st, a);
     const int PP = D + D * K;
-    float* red = workspace + (size_t)kMixBwdGrid * PP;
-    CNF_LAUNCH(mix_reduce_partials_kernel, dim3(PP), dim3(kBlock), 0, st, workspace, grid, PP, red);
-    if (scaling_factor) hipMemcpyAsync(g_scaling_factor, red, sizeof(float) * D, hipMemcpyDeviceToDevice, st);
-    if (mixture_scaling_factor) hipMemcpyAsync(g_mixture_scaling_factor, red + D, sizeof(float) * D * K, hipMemcpyDeviceToDevice, st);
+    CNF_LAUNCH(mix_reduce_partials_kernel, dim3(PP), dim3(kBlock), 0, st, workspace, grid, PP,
+               scaling_factor ? g_scaling_factor : nullptr, mixture_scaling_factor ? g_mixture_scaling_factor : nullptr, D);
     return launch_status("cnf_mixture_coupling_bwd");
 }
 
@@ -346,11 +351,8 @@ int cnf_mixture_params_bwd(const float* nn_out, const float* scaling_factor, con
     const int grid = (int)std::min<long>(std::max<long>((total + kBlock - 1) / kBlock, 1), kMixBwdGrid);
     CNF_LAUNCH(mixture_params_bwd_kernel, dim3(grid), dim3(kBlock), 0, st, a);
     const int PP = D + D * K;
-    float* red = workspace + (size_t)kMixBwdGrid * PP;
-    CNF_LAUNCH(mix_reduce_partials_kernel, dim3(PP), dim3(kBlock), 0, st, workspace, grid, PP, red);
-    if (scaling_factor && g_scaling_factor) hipMemcpyAsync(g_scaling_factor, red, sizeof(float) * D, hipMemcpyDeviceToDevice, st);
-    if (mixture_scaling_factor && g_mixture_scaling_factor)
-        hipMemcpyAsync(g_mixture_scaling_factor, red + D, sizeof(float) * D * K, hipMemcpyDeviceToDevice, st);
+    CNF_LAUNCH(mix_reduce_partials_kernel, dim3(PP), dim3(kBlock), 0, st, workspace, grid, PP,
+               scaling_factor ? g_scaling_factor : nullptr, mixture_scaling_factor ? g_mixture_scaling_factor : nullptr, D);
     return launch_status("cnf_mixture_params_bwd");
 }
 

@@ -22,40 +22,11 @@
 // Arithmetic (unchanged from round 1): fp32 on hardware exp2 / log2 / rcp with BOTH tails as
 // sums of positive terms; elements with u or 1 - u below 1e-9, or an underflowing PDF sum, take the fp64 branch that
 // reproduces the reference's clamps.
-#include "cnf_mixture.h"
+#include "cnf_mixture_tok.h"
 
 #include <algorithm>
 
 namespace cnf {
-
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef __attribute__((address_space(1))) const void glb_void_t;
-
-constexpr double kFix32 = 4294967296.0;
-constexpr int kMaxRowSlots = 64;       // rows one wave tile may hold
-constexpr int kMaxDmaInstr = 24;       // 1 KiB DMA instructions per pass
-
-struct TokGeom {
-    int d0;             // first transformed channel
-    int DA;             // transformed channels per token
-    int lpt;            // lanes per token = DA * G
-    int TPP;            // tokens per pass
-    int ncopy;          // D - DA channels per token that pass through
-    int contig;         // D == DA: a pass is one contiguous span
-    int tokstride;      // bytes between the spans of consecutive tokens = D * P * 4
-    int slot;           // LDS bytes per token slot (contig: == tokstride)
-    int stage_bytes;    // LDS bytes of one wave's stage (multiple of 1 KiB)
-    int acc_off;        // byte offset of the accumulator region in dynamic LDS
-    int epi_off;        // byte offset of the epilogue tables + strips
-    int split;          // 0: rw whole rows per wave tile; 1: S workgroups x 4 waves per row
-    int rw;             // rows per wave tile (split == 0)
-    int S;              // workgroups per row (split == 1)
-    int ppr;            // passes per row = ceil(N / TPP)
-    long ntiles;        // wave tiles (split == 0)
-    FastDiv div_slot, div_n, div_lpt, div_nc;
-};
-
-__device__ __forceinline__ long long to_fix(double v) { return __double2ll_rn(v * kFix32); }
 
 // ED > 0: the ActNorm + 1x1 convolution of the next flow step (D = ED channels) are applied to the coupling's output
 // while it is on chip (forward only): the [B,N,D] round trip between the two kernels (8 B/elem) disappears.  Same
@@ -152,31 +123,7 @@ __global__ __launch_bounds__(kBlock) void mixture_tok_kernel(MixArgs a, TokGeom 
 
         // ---- stage the parameter spans of the pass: DMA, 16 bytes per lane, 1 KiB of LDS per instruction
         const char* pass_addr = span0 + (size_t)tp * gm.tokstride;
-        int my_pos;             // byte offset of this lane's row in the stage
-        if (gm.contig) {
-            const int off0 = __builtin_amdgcn_readfirstlane((int)(reinterpret_cast<uintptr_t>(pass_addr) & 15));
-            const char* abase = pass_addr - off0;
-            const int ni = (npt * gm.tokstride + off0 + 1023) >> 10;
-            for (int i = 0; i < ni; ++i) {
-                const char* gp = abase + ((size_t)(i * kWave + lane) << 4);
-                gp = gp > nn_last ? nn_last : gp;
-                __builtin_amdgcn_global_load_lds((glb_void_t*)gp, (lds_void_t*)(stage_b + (i << 10)), 16, 0, 0);
-            }
-            my_pos = off0 + tli * gm.tokstride + j * P * 4;
-        } else {
-            const int ni = (npt * gm.slot + 1023) >> 10;
-            for (int i = 0; i < ni; ++i) {
-                const uint32_t cb = (uint32_t)(i * kWave + lane) << 4;              // byte offset in the stage
-                const uint32_t s = fdiv(cb, gm.div_slot);
-                const uint32_t o = cb - s * (uint32_t)gm.slot;
-                const char* ta = pass_addr + (size_t)s * gm.tokstride;
-                const char* gp = ta - (reinterpret_cast<uintptr_t>(ta) & 15) + o;
-                gp = gp > nn_last ? nn_last : gp;
-                __builtin_amdgcn_global_load_lds((glb_void_t*)gp, (lds_void_t*)(stage_b + (i << 10)), 16, 0, 0);
-            }
-            const char* ta = pass_addr + (size_t)tli * gm.tokstride;
-            my_pos = tli * gm.slot + (int)(reinterpret_cast<uintptr_t>(ta) & 15) + j * P * 4;
-        }
+        int my_pos = stage_pass(gm, stage_b, pass_addr, nn_last, npt, lane, tli, j, P);     // byte offset of this lane's row
         if (!valid) my_pos = 0;
         float* my = reinterpret_cast<float*>(stage_b + my_pos);
         wave_lds_sync();
@@ -563,7 +510,7 @@ static int g_split_waves = 2048;      // waves a split launch aims at (cnf_set_m
 void set_mixture_split_waves(int w) { g_split_waves = w; }
 
 // Returns false when the shape is outside what this kernel is built for (the caller falls back to the fp64 kernel).
-static bool make_tok_geom(const MixArgs& a, int kt, int force_g, TokGeom& gm, int& G, size_t& lds) {
+bool make_tok_geom(const MixArgs& a, int kt, int force_g, TokGeom& gm, int& G, size_t& lds) {
     const int P = a.P;
     // transformed channels must be one contiguous range
     int d0 = 0, DA = a.D;
@@ -611,7 +558,11 @@ static bool make_tok_geom(const MixArgs& a, int kt, int force_g, TokGeom& gm, in
 
     // decomposition
     const int ppr = (a.N + tpp - 1) / tpp;                      // passes per row
-    const int target_tokens = std::max(tpp, mixture_tile_items() / std::max(DA, 1));
+    // tokens per wave tile: ~128 items by default; fewer for mid-sized batches, so that a few thousand waves exist
+    // (a wave walks its passes one after the other: at 10^4 tokens, one pass per wave beats four)
+    int target_tokens = std::max(tpp, mixture_tile_items() / std::max(DA, 1));
+    const long total_tokens = (long)a.B * a.N;
+    if (total_tokens / target_tokens < 2048) target_tokens = (int)std::max<long>(tpp, total_tokens / 2048);
     int rw = 1;
     {
         double best = -1.0;

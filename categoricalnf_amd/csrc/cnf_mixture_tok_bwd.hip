@@ -1,0 +1,483 @@
+// Backward of the logistic-mixture CDF coupling FORWARD transform (mixture_cdf_layer.py:95-123,145-180), fp32 token-pass
+// kernel: the training-side twin of mixture_tok_kernel (cnf_mixture_tok.hip).  The reference differentiates its eager op
+// chain with autograd; here ONE kernel produces g_z, g_nn (through the tanh bounds and the channel mask) and the
+// partial sums of g_scaling_factor [D] / g_mixture_scaling_factor [D, K].
+//
+// Data movement: the parameter rows of a pass are DMA-staged into LDS exactly like in the forward kernel; the
+// per-parameter gradients then overwrite the staged row IN PLACE (slot k is read, then replaced by its own gradient),
+// and the stage goes back to g_nn with coalesced stores (16 / 8 / 4 bytes per lane, the widest the spans' alignment
+// allows).  The parameter blocks of channels that are not transformed get their zeros from the same kernel (no separate
+// memset pass over g_nn: at K = 8 that tensor is 26x the latents).
+//
+// Arithmetic: fp32 with both tails as sums of positive terms — 1/u = se/cdf and 1/(1-u) = se/ccdf are exact to fp32
+// rounding, (1 - 2 sigma) is formed as sigma(-z) - sigma(z) — and an fp64 branch, the arithmetic of the fp64 kernel
+// (cnf_mixture_bwd.hip), for elements whose u, 1 - u or pdf sum underflows the fp32 forms.
+//
+// Parameter gradients: every lane always works on the same channel (and the same mixtures when several lanes share an
+// item), so it keeps its partial sums in registers (compile-time K) or in lane-private LDS slots (run-time K) across
+// all its passes; they are combined once per wave, then per workgroup, in a fixed order — no atomics, bit-reproducible —
+// and one row per workgroup goes to the partials buffer that mix_reduce_partials_kernel sums in fp64.
+#include "cnf_mixture_tok.h"
+
+#include <algorithm>
+
+namespace cnf {
+
+constexpr int kTokBwdGrid = 1024;       // rows of the partials buffer (cnf_bwd_workspace_floats)
+
+struct TokBwdArgs {
+    const float* g_zout;      // [B,N,D] or null
+    const float* g_ldj;       // [B] or null
+    float* g_z;               // [B,N,D]
+    float* g_nn;              // [B,N,D*P]
+    float* partials;          // [gridDim.x, D + D*K]
+    int wb_align;             // 16, 8 or 4: bytes per lane of the write-back
+    int nacc;                 // run-time K: lane-private accumulator slots = 1 + ceil(K / G)
+    int lacc_off;             // byte offset of the lane-private accumulators / the reduction scratch in dynamic LDS
+    int wrow_off;             // byte offset of the per-wave parameter-gradient rows [4][PP]
+    long nunits;              // wave work units: tiles (whole rows) or (row, wave-of-row) pairs
+    FastDiv div_ncp, div_span;   // by the zero-fill units per token ((D - DA) * P * 4 / wb_align); by DA * P * 4 bytes (one span)
+};
+
+// tanh bound f tanh(raw / max(f,1)) and its derivatives w.r.t. raw and w.r.t. the log-factor sf (f = e^sf; the clamp
+// passes the gradient for f >= 1), from the forward's table entry (x3 = 2 log2e / fc, m2f = -2 f, f)
+__device__ __forceinline__ void bound_grads_f(float raw, const BoundTab& b, float& d_raw, float& d_sf) {
+    const float inv_fc = b.x3 * 0.34657359027997264f;              // 1 / max(f, 1)
+    const float th = fmaf(__builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(raw * b.x3) + 1.f), -2.f, 1.f);
+    const float sech2 = 1.f - th * th;
+    const float uu = raw * inv_fc;
+    d_raw = b.f * sech2 * inv_fc;
+    d_sf = b.f >= 1.f ? b.f * (th - uu * sech2) : b.f * th;
+}
+
+template <int KT, int G>
+__global__ __launch_bounds__(kBlock) void mixture_tok_bwd_kernel(MixArgs a, TokGeom gm, TokBwdArgs w) {
+    static_assert(G == 1 || KT == 0, "several lanes per item only with a run-time K");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int K = KT > 0 ? KT : a.K;
+    const int P = a.P;
+    const int PP = a.D + a.D * K;
+    char* stage_b = smem + (size_t)wave * gm.stage_bytes;
+    BoundTab* sf_tab = reinterpret_cast<BoundTab*>(smem + (size_t)kWavesPerBlock * gm.stage_bytes);
+    BoundTab* msf_tab = sf_tab + a.D;
+    // lane-private partial sums [64][nacc] per wave: a region of their own for a run-time K (they live there during the
+    // passes); with a compile-time K they live in registers and only visit LDS for the final reduction, in the stage
+    float* lacc = KT > 0 ? reinterpret_cast<float*>(stage_b)
+                         : reinterpret_cast<float*>(smem + w.lacc_off) + (size_t)wave * kWave * w.nacc;
+    float* wrow = reinterpret_cast<float*>(smem + w.wrow_off) + (size_t)wave * PP;             // [PP] per wave
+    for (int i = threadIdx.x; i < a.D; i += blockDim.x)
+        sf_tab[i] = make_bound(a.sf ? a.sf[i] : 0.f);
+    for (int i = threadIdx.x; i < a.D * K; i += blockDim.x)
+        msf_tab[i] = make_bound(a.msf ? a.msf[i] : 0.f);
+    if (KT == 0)
+        for (int i = lane; i < kWave * w.nacc; i += kWave) lacc[i] = 0.f;
+    for (int i = lane; i < PP; i += kWave) wrow[i] = 0.f;
+    __syncthreads();
+
+    const int tli = (int)fdiv((uint32_t)lane, gm.div_lpt);
+    const int rem = lane - tli * gm.lpt;
+    const int j = rem / G, sub = rem - j * G;
+    const int d = gm.d0 + j;
+    const BoundTab* mt = msf_tab + d * K;
+    const char* nn_lo = reinterpret_cast<const char*>(a.nn);
+    const char* nn_last = nn_lo + ((size_t)a.B * a.N * a.D * P - 4) * sizeof(float);
+    constexpr int KK = KT > 0 ? KT : 1;
+    float acc_sf = 0.f, acc_m[KK];
+#pragma unroll
+    for (int k = 0; k < KK; ++k) acc_m[k] = 0.f;
+    float* my_acc = lacc + lane * w.nacc;       // run-time K: slot 0 = scaling_factor, slot 1 + i = mixture k = sub + i G
+
+    for (long unit = (long)blockIdx.x * kWavesPerBlock + wave; unit < w.nunits; unit += (long)gridDim.x * kWavesPerBlock) {
+        int row0, n_first, ntok;
+        if (!gm.split) {
+            row0 = (int)(unit * gm.rw);
+            n_first = 0;
+            ntok = min(gm.rw, a.B - row0) * a.N;
+        } else {
+            const int nw = gm.S * kWavesPerBlock;
+            row0 = (int)(unit / nw);
+            const int wv = (int)(unit - (long)row0 * nw);
+            const int p_lo = (wv * gm.ppr) / nw, p_hi = ((wv + 1) * gm.ppr) / nw;
+            n_first = p_lo * gm.TPP;
+            ntok = max(0, min(a.N, p_hi * gm.TPP) - n_first);
+        }
+        const size_t tok_g0 = (size_t)row0 * a.N + n_first;
+        const float* z_tile = a.z + tok_g0 * a.D;
+        const float* gzo_tile = w.g_zout ? w.g_zout + tok_g0 * a.D : nullptr;
+        float* gz_tile = w.g_z + tok_g0 * a.D;
+        const float* pad_tile = a.pad ? a.pad + tok_g0 : nullptr;
+        const char* span0 = nn_lo + (tok_g0 * a.D + gm.d0) * (size_t)P * sizeof(float);
+        float* gnn_tile = w.g_nn + tok_g0 * a.D * (size_t)P;          // first token's first block
+
+        for (int tp = 0; tp < ntok; tp += gm.TPP) {
+            const int npt = min(gm.TPP, ntok - tp);
+            const bool valid = tli < npt;
+            const int tokl = tp + (valid ? tli : 0);
+            int rl = 0, n = n_first + tokl;
+            if (!gm.split) {
+                rl = (int)fdiv((uint32_t)tokl, gm.div_n);
+                n = tokl - rl * a.N;
+            }
+            const float pv = pad_tile ? pad_tile[tokl] : 1.f;
+            const float x = valid ? z_tile[(size_t)tokl * a.D + d] : 0.f;
+            const float outscale = a.pad_output ? pv : 1.f;
+            const float gzo = (valid && gzo_tile) ? gzo_tile[(size_t)tokl * a.D + d] * outscale : 0.f;
+            const float gl = (valid && w.g_ldj) ? w.g_ldj[row0 + rl] : 0.f;
+            bool active = valid;
+            if (a.per_item_mask) active = active && mask_at(a.mask, a.mr, a.mc, n, d) == 0.f;
+            if (a.pad_in_transform && pv == 0.f) active = false;
+
+            const char* pass_addr = span0 + (size_t)tp * gm.tokstride;
+            int my_pos = stage_pass(gm, stage_b, pass_addr, nn_last, npt, lane, tli, j, P);
+            if (!valid) my_pos = 0;
+            float* my = reinterpret_cast<float*>(stage_b + my_pos);
+            wave_lds_sync();
+
+            float g_x = gzo;                       // an element that is not transformed passes its gradient through
+            if (active) {
+                const float t = my[0];
+                const float raw_ls = my[1];
+                const float log_s = a.sf ? apply_bound(raw_ls, sf_tab[d]) : raw_ls;
+                float lp[KK], mu[KK], lsr[KK];
+                float mx = -INFINITY;
+                if (KT > 0) {
+#pragma unroll
+                    for (int k = 0; k < KK; ++k) {
+                        lp[k] = my[2 + k];
+                        mu[k] = my[2 + KK + k];
+                        lsr[k] = my[2 + 2 * KK + k];
+                    }
+#pragma unroll
+                    for (int k = 0; k < KK; ++k) mx = fmaxf(mx, lp[k]);
+                } else {
+                    for (int k = sub; k < K; k += G) mx = fmaxf(mx, my[2 + k]);
+                    mx = gmax<G>(mx);
+                }
+                // pass 1: the mixture sums
+                float se = 0.f, cdf = 0.f, ccdf = 0.f, pdf = 0.f, dpdf = 0.f;
+                auto sums = [&](float lpk, float muk, float lsk, int k) {
+                    const float ls = a.msf ? apply_bound(lsk, mt[k]) : lsk;
+                    const float inv_s = __builtin_amdgcn_exp2f(-ls * kLog2eF);
+                    const float wk = __builtin_amdgcn_exp2f((lpk - mx) * kLog2eF);
+                    const float zk = (x - muk) * inv_s;
+                    const float e = __builtin_amdgcn_exp2f(-fabsf(zk) * kLog2eF);
+                    const float rr = __builtin_amdgcn_rcpf(1.f + e);
+                    const float er = e * rr;
+                    const bool pos = zk >= 0.f;
+                    const float sig = pos ? rr : er, sigc = pos ? er : rr;
+                    const float wpk = wk * inv_s * (er * rr);
+                    se += wk;
+                    cdf = fmaf(wk, sig, cdf);
+                    ccdf = fmaf(wk, sigc, ccdf);
+                    pdf += wpk;
+                    dpdf = fmaf(wpk * inv_s, sigc - sig, dpdf);
+                };
+                if (KT > 0) {
+#pragma unroll
+                    for (int k = 0; k < KK; ++k) sums(lp[k], mu[k], lsr[k], k);
+                } else {
+                    for (int k = sub; k < K; k += G) sums(my[2 + k], my[2 + K + k], my[2 + 2 * K + k], k);
+                    se = gsum<G>(se); cdf = gsum<G>(cdf); ccdf = gsum<G>(ccdf); pdf = gsum<G>(pdf); dpdf = gsum<G>(dpdf);
+                }
+                const float inv_se = __builtin_amdgcn_rcpf(se);
+                const float u = cdf * inv_se, uc = ccdf * inv_se;
+                float g_t, g_ls_raw_main, g_logs;
+                if (u > 1e-9f && uc > 1e-9f && pdf > 1e-30f) {
+                    const float a_s = __builtin_amdgcn_exp2f(log_s * kLog2eF);
+                    const float dlu = se * __builtin_amdgcn_rcpf(cdf);             // 1 / u
+                    const float dl1u = -se * __builtin_amdgcn_rcpf(ccdf);          // -1 / (1 - u)
+                    const float l2se = __builtin_amdgcn_logf(se);
+                    const float lu = (__builtin_amdgcn_logf(cdf) - l2se) * kLn2F;
+                    const float l1u = (__builtin_amdgcn_logf(ccdf) - l2se) * kLn2F;
+                    const float zt = ((lu - l1u) + t) * a_s;
+                    float g_u = gzo * a_s * (dlu - dl1u) + gl * (-dlu - dl1u);
+                    if (a.use_reg) {
+                        const float rmax = (float)a.reg_max;
+                        float dreg = 0.f;
+                        if (lu * 0.43429448190325176f <= -rmax) dreg += dlu * 0.43429448190325176f;
+                        if (l1u * 0.43429448190325176f <= -rmax) dreg += dl1u * 0.43429448190325176f;
+                        g_u = fmaf(gl * (float)a.reg_factor, dreg, g_u);
+                    }
+                    const float inv_pdf_se = __builtin_amdgcn_rcpf(pdf);          // 1 / (se pdf_n)
+                    g_x = g_u * pdf * inv_se + gl * dpdf * inv_pdf_se;
+                    g_logs = fmaf(gzo, zt, gl);
+                    g_t = gzo * a_s;
+                    // pass 2: per-mixture gradients, written over the staged parameters
+                    auto grads = [&](float lpk, float muk, float lsk, int k, float& acc_slot) {
+                        float ls = lsk, d_raw = 1.f, d_sf = 0.f;
+                        if (a.msf) {
+                            ls = apply_bound(lsk, mt[k]);
+                            bound_grads_f(lsk, mt[k], d_raw, d_sf);
+                        }
+                        const float inv_s = __builtin_amdgcn_exp2f(-ls * kLog2eF);
+                        const float wk = __builtin_amdgcn_exp2f((lpk - mx) * kLog2eF);
+                        const float zk = (x - muk) * inv_s;
+                        const float e = __builtin_amdgcn_exp2f(-fabsf(zk) * kLog2eF);
+                        const float rr = __builtin_amdgcn_rcpf(1.f + e);
+                        const float er = e * rr;
+                        const bool pos = zk >= 0.f;
+                        const float sig = pos ? rr : er, sigc = pos ? er : rr;
+                        const float s1s = er * rr;
+                        const float pk = s1s * inv_s;
+                        const float pi = wk * inv_se;
+                        const float resp = wk * pk * inv_pdf_se;                   // pi_k p_k / pdf
+                        const float dsg = sigc - sig;                              // 1 - 2 sigma
+                        // sigma_k - u without cancellation: near u = 1 both are 1 - O(1e-7), so use the complements there
+                        const float dsu = u <= 0.5f ? sig - u : uc - sigc;
+                        const float g_lp = g_u * pi * dsu + gl * (resp - pi);
+                        const float g_mu = -g_u * pi * pk - gl * resp * dsg * inv_s;
+                        const float g_ls = -g_u * pi * zk * s1s + gl * resp * (-1.f - zk * dsg);
+                        my[2 + k] = g_lp;
+                        my[2 + K + k] = g_mu;
+                        my[2 + 2 * K + k] = g_ls * d_raw;
+                        acc_slot = fmaf(g_ls, d_sf, acc_slot);
+                    };
+                    if (KT > 0) {
+#pragma unroll
+                        for (int k = 0; k < KK; ++k) grads(lp[k], mu[k], lsr[k], k, acc_m[k]);
+                    } else {
+                        int slot = 1;
+                        for (int k = sub; k < K; k += G, ++slot) grads(my[2 + k], my[2 + K + k], my[2 + 2 * K + k], k, my_acc[slot]);
+                    }
+                } else {
+                    // rare: a tail or an underflow — the fp64 kernel's arithmetic (cnf_mixture_bwd.hip) on the staged row;
+                    // with several lanes per item every lane walks all mixtures and keeps its own
+                    const double xd = (double)x, gzd = (double)gzo, gld = (double)gl;
+                    double sed = 0.0, cdfd = 0.0, pdfd = 0.0, dpdfd = 0.0;
+#pragma clang loop unroll(disable)
+                    for (int k = 0; k < K; ++k) {
+                        const float lsf = a.msf ? apply_bound(my[2 + 2 * K + k], mt[k]) : my[2 + 2 * K + k];
+                        const double wd = exp((double)my[2 + k] - (double)mx);
+                        const double isd = exp(-(double)lsf);
+                        const double zd = (xd - (double)my[2 + K + k]) * isd;
+                        const double ed = exp(-fabs(zd));
+                        const double rd = 1.0 / (1.0 + ed);
+                        const double sg = zd >= 0.0 ? rd : ed * rd;
+                        const double pk = ed * rd * rd * isd;
+                        sed += wd;
+                        cdfd += wd * sg;
+                        pdfd += wd * pk;
+                        dpdfd += wd * pk * (1.0 - 2.0 * sg) * isd;
+                    }
+                    const double ud = cdfd / sed, pdf_n = pdfd / sed;
+                    const double a_s = exp((double)log_s);
+                    const double ucl = fmax(ud, 1e-22), u1cl = fmax(1.0 - ud, 1e-22);
+                    const double lud = log(ucl), l1ud = log(u1cl);
+                    const double dlu = ud > 1e-22 ? 1.0 / ud : 0.0;
+                    const double dl1u = (1.0 - ud) > 1e-22 ? -1.0 / (1.0 - ud) : 0.0;
+                    const double zt = ((lud - l1ud) + (double)t) * a_s;
+                    double g_ud = gzd * a_s * (dlu - dl1u) + gld * (-dlu - dl1u);
+                    if (a.use_reg) {
+                        double dreg = 0.0;
+                        if (lud / kLn10 <= -a.reg_max) dreg += dlu / kLn10;
+                        if (l1ud / kLn10 <= -a.reg_max) dreg += dl1u / kLn10;
+                        g_ud += gld * a.reg_factor * dreg;
+                    }
+                    const double inv_pdf = pdf_n > 1e-290 ? 1.0 / pdf_n : 0.0;
+                    g_x = (float)(g_ud * pdf_n + gld * (dpdfd / sed) * inv_pdf);
+                    g_logs = (float)(gzd * zt + gld);
+                    g_t = (float)(gzd * a_s);
+                    // per-mixture gradients.  All lanes of the item (G of them) walk all mixtures in lockstep: iteration k
+                    // reads slots k, then the lane that owns mixture k overwrites them; later iterations read other slots
+#pragma clang loop unroll(disable)
+                    for (int k = 0; k < K; ++k) {
+                        const float raw = my[2 + 2 * K + k];
+                        float lsf = raw, d_raw = 1.f, d_sf = 0.f;
+                        if (a.msf) {
+                            lsf = apply_bound(raw, mt[k]);
+                            bound_grads_f(raw, mt[k], d_raw, d_sf);
+                        }
+                        const double pi = exp((double)my[2 + k] - (double)mx) / sed;
+                        const double isd = exp(-(double)lsf);
+                        const double zd = (xd - (double)my[2 + K + k]) * isd;
+                        const double ed = exp(-fabs(zd));
+                        const double rd = 1.0 / (1.0 + ed);
+                        const double sg = zd >= 0.0 ? rd : ed * rd;
+                        const double s1s = ed * rd * rd;
+                        const double pk = s1s * isd;
+                        const double resp = pi * pk * inv_pdf;
+                        const double g_lp = g_ud * pi * (sg - ud) + gld * (resp - pi);
+                        const double g_mu = g_ud * (-pi * pk) + gld * (-resp * (1.0 - 2.0 * sg) * isd);
+                        const double g_ls = g_ud * (-pi * zd * s1s) + gld * (resp * (-1.0 - zd * (1.0 - 2.0 * sg)));
+                        if (G == 1 || (k % G) == sub) {
+                            const float add = (float)g_ls * d_sf;
+                            if (KT > 0) {
+#pragma unroll
+                                for (int kk = 0; kk < KK; ++kk) acc_m[kk] += kk == k ? add : 0.f;      // no dynamic register index
+                            } else {
+                                my_acc[1 + (k - sub) / G] += add;
+                            }
+                            my[2 + k] = (float)g_lp;
+                            my[2 + K + k] = (float)g_mu;
+                            my[2 + 2 * K + k] = (float)(g_ls * (double)d_raw);
+                        }
+                    }
+                }
+                // t and log_s (the shared first two slots: one lane of the item writes)
+                float d_raw = 1.f, d_sf = 0.f;
+                if (a.sf) bound_grads_f(raw_ls, sf_tab[d], d_raw, d_sf);
+                if (sub == 0) {
+                    my[0] = g_t;
+                    my[1] = g_logs * d_raw;
+                    if (KT > 0) acc_sf = fmaf(g_logs, d_sf, acc_sf);
+                    else my_acc[0] = fmaf(g_logs, d_sf, my_acc[0]);
+                }
+            } else if (valid) {
+                // padded token / masked item: its parameters get no gradient
+                for (int i = sub; i < P; i += G) my[i] = 0.f;
+            }
+            if (valid && sub == 0) gz_tile[(size_t)tokl * a.D + d] = g_x;
+            wave_lds_sync();
+
+            // ---- the staged gradient rows go back to g_nn: the transformed spans of the pass's tokens
+            {
+                const int span_b = gm.DA * P * 4;
+                const int total_b = npt * span_b;
+                float* gspan0 = gnn_tile + ((size_t)tp * a.D + gm.d0) * P;       // first token's span in g_nn
+                const uintptr_t src0 = reinterpret_cast<uintptr_t>(span0 + (size_t)tp * gm.tokstride);
+                if (w.wb_align == 16) {
+                    for (int b = lane * 16; b < total_b; b += kWave * 16) {
+                        const int s = (int)fdiv((uint32_t)b, w.div_span);
+                        const int r = b - s * span_b;
+                        const int lpos = gm.contig ? (int)(src0 & 15) + s * gm.tokstride + r
+                                                   : s * gm.slot + (int)((src0 + (uintptr_t)s * gm.tokstride) & 15) + r;
+                        const float4 v = *reinterpret_cast<const float4*>(stage_b + lpos);
+                        *reinterpret_cast<float4*>(reinterpret_cast<char*>(gspan0) + (size_t)s * gm.tokstride + r) = v;
+                    }
+                } else if (w.wb_align == 8) {
+                    for (int b = lane * 8; b < total_b; b += kWave * 8) {
+                        const int s = (int)fdiv((uint32_t)b, w.div_span);
+                        const int r = b - s * span_b;
+                        const int lpos = gm.contig ? (int)(src0 & 15) + s * gm.tokstride + r
+                                                   : s * gm.slot + (int)((src0 + (uintptr_t)s * gm.tokstride) & 15) + r;
+                        const float2 v = *reinterpret_cast<const float2*>(stage_b + lpos);
+                        *reinterpret_cast<float2*>(reinterpret_cast<char*>(gspan0) + (size_t)s * gm.tokstride + r) = v;
+                    }
+                } else {
+                    for (int b = lane * 4; b < total_b; b += kWave * 4) {
+                        const int s = (int)fdiv((uint32_t)b, w.div_span);
+                        const int r = b - s * span_b;
+                        const int lpos = gm.contig ? (int)(src0 & 15) + s * gm.tokstride + r
+                                                   : s * gm.slot + (int)((src0 + (uintptr_t)s * gm.tokstride) & 15) + r;
+                        const float v = *reinterpret_cast<const float*>(stage_b + lpos);
+                        *reinterpret_cast<float*>(reinterpret_cast<char*>(gspan0) + (size_t)s * gm.tokstride + r) = v;
+                    }
+                }
+            }
+            // ---- channels that are not transformed: their latents pass the gradient through, their parameter blocks get zeros
+            if (gm.ncopy > 0) {
+                const int ne = npt * gm.ncopy;
+                for (int e = lane; e < ne; e += kWave) {
+                    const int tk = (int)fdiv((uint32_t)e, gm.div_nc);
+                    const int jj = e - tk * gm.ncopy;
+                    const int c = jj < gm.d0 ? jj : jj + gm.DA;
+                    const int tl2 = tp + tk;
+                    const float pv2 = (pad_tile && a.pad_output) ? pad_tile[tl2] : 1.f;
+                    gz_tile[(size_t)tl2 * a.D + c] = gzo_tile ? gzo_tile[(size_t)tl2 * a.D + c] * pv2 : 0.f;
+                }
+                // zeros for the parameter blocks of the untransformed channels, as wide as the write-back
+                const int ncp_b = gm.ncopy * P * 4;            // bytes of untransformed parameter blocks per token
+                const int head_b = gm.d0 * P * 4, span_b2 = gm.DA * P * 4;
+                char* gtok0 = reinterpret_cast<char*>(gnn_tile + (size_t)tp * a.D * P);
+                auto zero_fill = [&](auto zero, int width) {
+                    const int upt = ncp_b / width;             // units per token
+                    const int nz = npt * upt;
+                    for (int e = lane; e < nz; e += kWave) {
+                        const int tk = (int)fdiv((uint32_t)e, w.div_ncp);
+                        const int rb = (e - tk * upt) * width;
+                        const int col = rb < head_b ? rb : rb + span_b2;
+                        *reinterpret_cast<decltype(zero)*>(gtok0 + (size_t)tk * gm.tokstride + col) = zero;
+                    }
+                };
+                if (w.wb_align == 16) zero_fill(make_float4(0.f, 0.f, 0.f, 0.f), 16);
+                else if (w.wb_align == 8) zero_fill(make_float2(0.f, 0.f), 8);
+                else zero_fill(0.f, 4);
+            }
+            wave_lds_sync();      // the stage is overwritten by the next pass
+        }
+    }
+
+    // ---- parameter gradients: lanes -> wave row -> workgroup row (fixed orders)
+    if (KT > 0) {
+        my_acc[0] = acc_sf;
+#pragma unroll
+        for (int k = 0; k < KK; ++k) my_acc[1 + k] = acc_m[k];
+    }
+    wave_lds_sync();
+    if (lane < gm.lpt) {
+        // lane (tli = 0, j, sub) sums its column over the tokens of a pass
+        const int jj = lane / G, ss = lane - jj * G;
+        const int dd = gm.d0 + jj;
+        for (int slot = 0; slot < w.nacc; ++slot) {
+            float t = 0.f;
+            for (int tk = 0; tk < gm.TPP; ++tk) t += lacc[(tk * gm.lpt + lane) * w.nacc + slot];
+            if (slot == 0) {
+                if (ss == 0) wrow[dd] = t;
+            } else {
+                const int k = ss + (slot - 1) * G;
+                if (k < K) wrow[a.D + dd * K + k] = t;
+            }
+        }
+    }
+    __syncthreads();
+    const float* rows = reinterpret_cast<const float*>(smem + w.wrow_off);
+    for (int i = threadIdx.x; i < PP; i += blockDim.x) {
+        float t = 0.f;
+        for (int wv = 0; wv < kWavesPerBlock; ++wv) t += rows[wv * PP + i];
+        w.partials[(size_t)blockIdx.x * PP + i] = t;
+    }
+}
+
+}  // namespace cnf
+
+using namespace cnf;
+
+namespace cnf {
+// cnf_mixture_bwd.hip
+__global__ void mix_reduce_partials_kernel(const float* partials, int nrows, int P, float* out_a, float* out_b, int split);
+
+// false = shape outside what the token-pass backward is built for (the caller runs the fp64 kernel)
+bool launch_mixture_tok_bwd(MixArgs& a, const float* g_zout, const float* g_ldj, float* g_z, float* g_nn,
+                            float* g_sf, float* g_msf, float* workspace, hipStream_t st, int force_g) {
+    const int kt = (a.K == 4 || a.K == 8 || a.K == 16) ? a.K : 0;
+    TokGeom gm;
+    int G = 1;
+    size_t lds_fwd = 0;
+    MixArgs probe = a;
+    probe.ws_acc = reinterpret_cast<long long*>(8);      // rows may be split freely: the backward has no per-row sums
+    probe.ws_cnt = reinterpret_cast<int*>(8);
+    if (!make_tok_geom(probe, kt, force_g, gm, G, lds_fwd)) return false;
+    const int K = a.K, P = a.P, PP = a.D + a.D * K;
+    TokBwdArgs w = {};
+    w.g_zout = g_zout; w.g_ldj = g_ldj; w.g_z = g_z; w.g_nn = g_nn; w.partials = workspace;
+    w.nacc = kt > 0 ? 1 + kt : 1 + (K + G - 1) / G;
+    const size_t tabs = (((size_t)(a.D + a.D * K) * sizeof(BoundTab)) + 15) & ~(size_t)15;
+    w.lacc_off = (int)((size_t)kWavesPerBlock * gm.stage_bytes + tabs);
+    w.wrow_off = w.lacc_off + (kt > 0 ? 0 : (int)((size_t)kWavesPerBlock * kWave * w.nacc * sizeof(float)));
+    if (kt > 0 && (size_t)gm.stage_bytes < (size_t)kWave * w.nacc * sizeof(float)) return false;
+    const size_t lds = (size_t)w.wrow_off + (size_t)kWavesPerBlock * PP * sizeof(float);
+    if (lds > 65536) return false;
+    const int span_b = gm.DA * P * 4;
+    const int first_b = gm.d0 * P * 4;
+    const bool base16 = (reinterpret_cast<uintptr_t>(g_nn) & 15) == 0;
+    if (base16 && span_b % 16 == 0 && gm.tokstride % 16 == 0 && first_b % 16 == 0 && (gm.contig || gm.slot % 16 == 0)) w.wb_align = 16;
+    else if ((reinterpret_cast<uintptr_t>(g_nn) & 7) == 0 && span_b % 8 == 0 && gm.tokstride % 8 == 0 && first_b % 8 == 0) w.wb_align = 8;
+    else w.wb_align = 4;
+    w.nunits = gm.split ? (long)a.B * gm.S * kWavesPerBlock : gm.ntiles;
+    w.div_ncp = make_fastdiv((uint32_t)std::max(gm.ncopy * P * 4 / w.wb_align, 1));        // zero-fill units per token
+    w.div_span = make_fastdiv((uint32_t)span_b);
+    if (span_b >= 65536 || gm.TPP * span_b >= 65536 || gm.ncopy * P * gm.TPP >= 65536) return false;
+    const int grid = (int)std::min<long>((w.nunits + kWavesPerBlock - 1) / kWavesPerBlock, kTokBwdGrid);
+    const dim3 g(grid), b(kBlock);
+    if (kt == 4) CNF_LAUNCH((mixture_tok_bwd_kernel<4, 1>), g, b, lds, st, a, gm, w);
+    else if (kt == 8) CNF_LAUNCH((mixture_tok_bwd_kernel<8, 1>), g, b, lds, st, a, gm, w);
+    else if (kt == 16) CNF_LAUNCH((mixture_tok_bwd_kernel<16, 1>), g, b, lds, st, a, gm, w);
+    else if (G == 1) CNF_LAUNCH((mixture_tok_bwd_kernel<0, 1>), g, b, lds, st, a, gm, w);
+    else if (G == 2) CNF_LAUNCH((mixture_tok_bwd_kernel<0, 2>), g, b, lds, st, a, gm, w);
+    else CNF_LAUNCH((mixture_tok_bwd_kernel<0, 4>), g, b, lds, st, a, gm, w);
+    CNF_LAUNCH(mix_reduce_partials_kernel, dim3(PP), dim3(kBlock), 0, st, workspace, grid, PP,
+               a.sf ? g_sf : nullptr, a.msf ? g_msf : nullptr, a.D);
+    return true;
+}
+}  // namespace cnf

@@ -251,9 +251,11 @@ class MixtureCouplingFn(torch.autograd.Function):
         g_sf = torch.empty(D, dtype=torch.float32, device=dev) if has_sf else None
         g_msf = torch.empty(D, K, dtype=torch.float32, device=dev) if has_msf else None
         ws = _ws(D + D * K, dev)
-        _launch(dev, "cnf_mixture_coupling_bwd", _ptr(zc), _ptr(nn_c), _ptr(sfc), _ptr(msfc), _ptr(m), mr, mc, _ptr(p2), int(pit), int(pout),
-                                                hold(g_zout), hold(g_ldj), _ptr(g_z), _ptr(g_nn), _ptr(g_sf), _ptr(g_msf), _ptr(ws),
-                                                B, N, D, K, reg_max, reg_factor, int(is_training), _stream(dev))
+        act, n_act = ops._act_list(mask if has_mask else None, m, mr, mc, D)
+        _launch(dev, "cnf_mixture_coupling_bwd_f32", _ptr(zc), _ptr(nn_c), _ptr(sfc), _ptr(msfc), _ptr(m), mr, mc, act, n_act,
+                                                    _ptr(p2), int(pit), int(pout),
+                                                    hold(g_zout), hold(g_ldj), _ptr(g_z), _ptr(g_nn), _ptr(g_sf), _ptr(g_msf), _ptr(ws),
+                                                    B, N, D, K, reg_max, reg_factor, int(is_training), _stream(dev))
         return (g_z, g_nn.view_as(nn_out), (g_sf.view_as(sf) if has_sf else None), (g_msf.view_as(msf) if has_msf else None),
                 (g_ldj if has_ldj else None), None, None, None, None, None, None, None, None)
 

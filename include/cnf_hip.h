@@ -388,6 +388,21 @@ int cnf_mixture_coupling_bwd(const float* z, const float* nn_out,
                              int B, int N, int D, int K, double reg_max, double reg_factor, int is_training,
                              cnf_stream_t stream);
 
+/* The same gradients from the fp32 token-pass kernel (math mode 1; DMA-staged parameter rows, gradients written over
+ * the staged rows and stored back coalesced, zeros for untransformed blocks from the same kernel, fp64 branch for the
+ * tails); act_host / n_act as in cnf_mixture_coupling.  Shapes the kernel is not built for, and math mode 0, run
+ * cnf_mixture_coupling_bwd.  Same workspace. */
+int cnf_mixture_coupling_bwd_f32(const float* z, const float* nn_out,
+                                 const float* scaling_factor, const float* mixture_scaling_factor,
+                                 const float* mask, int mask_rows, int mask_cols,
+                                 const int* act_host, int n_act,
+                                 const float* pad, int pad_in_transform, int pad_output,
+                                 const float* g_zout, const float* g_ldj,
+                                 float* g_z, float* g_nn, float* g_scaling_factor, float* g_mixture_scaling_factor,
+                                 float* workspace,
+                                 int B, int N, int D, int K, double reg_max, double reg_factor, int is_training,
+                                 cnf_stream_t stream);
+
 /* d(MixtureCDFCoupling.run_with_params, reverse=False) on fp64 split parameters (static API, :95-123):
  * fp64 gradients for z and the five parameter tensors (zero where nothing is transformed). */
 int cnf_mixture_transform_bwd(const double* z, const double* t, const double* log_s, const double* log_pi,

@@ -282,3 +282,63 @@ def test_flow_model_uses_the_fused_kernels_and_matches_the_layer_by_layer_pass()
     assert "cnf_mixture_coupling_actconv" not in calls and calls.count("cnf_mixture_coupling_ws") == 3
     assert torch.equal(zf, zu) and torch.equal(lf, lu)
     close(nf, nu, rtol=1e-5, atol=1e-5)
+
+
+def _bwd(kernel, z, nn_out, sf, msf, mask, pad, K, gz, gl, reg):
+    """gradients of the mixture coupling through MixtureCouplingFn with the fp32 token-pass backward (kernel 0) or the
+    fp64 backward (kernel 1 selects the round-1 forward and the fp64 backward)."""
+    from categoricalnf_amd import functional as Fn
+    lib = _lib.load()
+    lib.cnf_set_mixture_kernel(kernel)
+    try:
+        zz, nn_ = g(z).requires_grad_(True), g(nn_out).requires_grad_(True)
+        sf_, msf_ = g(sf).requires_grad_(True), g(msf).requires_grad_(True)
+        zo, lo, _ = Fn.MixtureCouplingFn.apply(zz, nn_, sf_, msf_, None, g(mask), g(pad), K, reg[0], reg[1], True, True, True)
+        torch.autograd.backward([zo, lo], [g(gz), g(gl)])
+        return [t.grad.detach().cpu() for t in (zz, nn_, sf_, msf_)]
+    finally:
+        lib.cnf_set_mixture_kernel(0)
+
+
+@pytest.mark.parametrize("B,N,D,K,kind", SHAPES)
+def test_fp32_token_pass_backward_matches_fp64_backward(B, N, D, K, kind):
+    """cnf_mixture_coupling_bwd_f32 (DMA-staged rows, in-place gradients, coalesced write-back, zeros for untransformed
+    blocks written by the kernel) against the fp64 backward kernel: g_z, g_nn, g_scaling_factor, g_mixture_scaling_factor,
+    with the CDF regulariser, padding, every mask kind, rows split over workgroups and 1 / 2 / 4 lanes per item."""
+    z, nn_out, sf, msf, mask, ln, pad = _case(B, N, D, K, kind, 555 + B + N)
+    gen = torch.Generator().manual_seed(B + K)
+    gz, gl = torch.randn(B, N, D, generator=gen), torch.randn(B, generator=gen)
+    new = _bwd(0, z, nn_out, sf, msf, mask, pad, K, gz, gl, (3.5, 2.0))
+    old = _bwd(1, z, nn_out, sf, msf, mask, pad, K, gz, gl, (3.5, 2.0))
+    for name, a, b in zip(("g_z", "g_nn", "g_sf", "g_msf"), new, old):
+        scale = b.abs().max().item() + 1e-6
+        err = (a - b).abs().max().item()
+        assert err <= 2e-4 * scale + 2e-5, (name, err, scale)
+    # untransformed parameter blocks get exact zeros
+    P = 2 + 3 * K
+    g_nn = new[1].reshape(B, N, D, P)
+    if kind == "channel":
+        assert g_nn[:, :, : D // 2].abs().max().item() == 0.0
+    if pad is not None:
+        dead = (pad.squeeze(-1) == 0)
+        assert g_nn[dead].abs().max().item() == 0.0 if dead.any() else True
+
+
+def test_fp32_backward_is_deterministic_and_handles_tails():
+    """Same inputs twice -> bit-identical gradients (no atomics in the parameter-gradient reduction); inputs far in
+    the tails (|z| up to 40 sigma) take the kernel's fp64 branch and still agree with the fp64 kernel."""
+    B, N, D, K = 48, 16, 4, 8
+    z, nn_out, sf, msf, mask, ln, pad = _case(B, N, D, K, "channel", 31337)
+    z = z * 12.0
+    gen = torch.Generator().manual_seed(9)
+    gz, gl = torch.randn(B, N, D, generator=gen), torch.randn(B, generator=gen)
+    a = _bwd(0, z, nn_out, sf, msf, mask, pad, K, gz, gl, (-1.0, 1.0))
+    b = _bwd(0, z, nn_out, sf, msf, mask, pad, K, gz, gl, (-1.0, 1.0))
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    ref = _bwd(1, z, nn_out, sf, msf, mask, pad, K, gz, gl, (-1.0, 1.0))
+    for name, x, y in zip(("g_z", "g_nn", "g_sf", "g_msf"), a, ref):
+        fin = torch.isfinite(y)
+        assert torch.equal(fin, torch.isfinite(x)), name
+        scale = y[fin].abs().max().item() + 1e-6
+        assert (x[fin] - y[fin]).abs().max().item() <= 3e-4 * scale + 2e-5, name
