@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libcnf_hip.so")
 
 CNF_OK = 0
-FLAG_NAN_Z, FLAG_NAN_LDJ, FLAG_RANGE = 1, 2, 4
+FLAG_NAN_Z, FLAG_NAN_LDJ, FLAG_RANGE, FLAG_CATEGORY = 1, 2, 4, 8
 
 _p = ctypes.c_void_p
 _i = ctypes.c_int
@@ -89,8 +89,11 @@ class CnfLibraryError(RuntimeError):
 def load():
     """Load libcnf_hip.so once; raise CnfLibraryError if it is absent or incomplete."""
     global _lib
+    global LIB_PATH
     if _lib is not None:
         return _lib
+    if os.environ.get("CNF_LIB_OVERRIDE"):          # A/B of alternative builds of the same ABI (tools/build_variant.sh)
+        LIB_PATH = os.environ["CNF_LIB_OVERRIDE"]
     if not os.path.exists(LIB_PATH):
         raise CnfLibraryError(
             "HIP extension %s not found — build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -87,7 +87,7 @@ __device__ __forceinline__ float class_score2(const float* t, const float* z, in
     for (int d = 0; d < DD; ++d) {
         const float vs = fabsf(fmaf(z[d], t[4 * D + 2 * d], -t[4 * D + 2 * d + 1]));
         acc += vs;
-        prod *= 1.f + __builtin_amdgcn_exp2f(-vs);
+        prod = fmaf(prod, __builtin_amdgcn_exp2f(-vs), prod);        // prod * (1 + 2^-vs) in one instruction
     }
     return t[6 * D + 1] - fmaf(2.f, __builtin_amdgcn_logf(prod), acc);
 }
@@ -106,7 +106,11 @@ __global__ __launch_bounds__(kBlock) void encoder_forward_kernel(EncArgs a, RowT
 
     auto chunk = [&](int row, int n) -> float {
         const size_t tok = (size_t)row * a.N + n;
-        const int c = (int)a.categ[tok];
+        // an index outside [0, C) would read past the class table: clamp it and report it (the reference asserts in
+        // one_hot, general/mutils.py:264)
+        const long long craw = a.categ[tok];
+        if (craw < 0 || craw >= a.C) raise_flag(a.flags, CNF_FLAG_CATEGORY);
+        const int c = (int)(craw < 0 ? 0 : (craw >= a.C ? a.C - 1 : craw));
         const float* tc = tab + c * stride;
         float z[DT > 0 ? DT : kEncMaxD];
         // log-prob of the noise under the logistic prior: same product form as class_score
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(kBlock) void encoder_forward_kernel(EncArgs a, RowT
             const float e = a.eps[tok * D + d];
             const float vs = fabsf(e) * kn;
             nacc += vs;
-            nprod *= 1.f + __builtin_amdgcn_exp2f(-vs);
+            nprod = fmaf(nprod, __builtin_amdgcn_exp2f(-vs), nprod);
             z[d] = (e + tc[d]) * tc[2 * D + d];
         }
         const float init_lp = -(kLn2 * fmaf(2.f, __builtin_amdgcn_logf(nprod), nacc) + (float)D * a.log_sigma);

@@ -51,7 +51,8 @@ __global__ __launch_bounds__(kBlock) void encoder_fwd_bwd_kernel(EncBwdArgs a) {
     }
     __syncthreads();
     for (long tok = (long)blockIdx.x * kBlock + threadIdx.x; tok < a.ntok; tok += (long)gridDim.x * kBlock) {
-        const int c = (int)a.categ[tok];
+        const long long craw = a.categ[tok];      // range-checked (and reported) by the forward kernel; clamped here
+        const int c = (int)(craw < 0 ? 0 : (craw >= a.C ? a.C - 1 : craw));
         const float pv = a.pad ? a.pad[tok] : 1.f;
         const float G = (a.g_ldj ? a.g_ldj[tok / a.N] : 0.f) * pv;     // d loss / d ldj_tok (before padding)
         const float* tc = tab + c * 3 * D;

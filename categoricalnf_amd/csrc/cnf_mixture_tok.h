@@ -22,6 +22,7 @@ struct TokGeom {
     int tokstride;      // bytes between the spans of consecutive tokens = D * P * 4
     int slot;           // LDS bytes per token slot (contig: == tokstride)
     int stage_bytes;    // LDS bytes of one wave's stage (multiple of 1 KiB)
+    int tab_off;        // byte offset of the bound tables in dynamic LDS
     int acc_off;        // byte offset of the accumulator region in dynamic LDS
     int epi_off;        // byte offset of the epilogue tables + strips
     int split;          // 0: rw whole rows per wave tile; 1: S workgroups x 4 waves per row

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(kBlock) void mixture_tok_kernel(MixArgs a, TokGeom 
     const int K = KT > 0 ? KT : a.K;
     const int P = a.P;
     char* stage_b = smem + (size_t)wave * gm.stage_bytes;
-    BoundTab* sf_tab = reinterpret_cast<BoundTab*>(smem + (size_t)kWavesPerBlock * gm.stage_bytes);
+    BoundTab* sf_tab = reinterpret_cast<BoundTab*>(smem + gm.tab_off);
     BoundTab* msf_tab = sf_tab + a.D;
     // accumulators: split == 0: [wave][rw][2] fixed-point row sums; split == 1: [wave][2] fp64 wave partials
     long long* rowacc = reinterpret_cast<long long*>(smem + gm.acc_off) + (size_t)wave * gm.rw * 2;
@@ -106,8 +106,9 @@ __global__ __launch_bounds__(kBlock) void mixture_tok_kernel(MixArgs a, TokGeom 
     bool bad = false, range = false, badl = false;
     double acc_ldj = 0.0, acc_nlp = 0.0;          // split mode: this lane's running sums
 
-    for (int tp = 0; tp < ntok; tp += gm.TPP) {                                   // wave-uniform
-        const int npt = min(gm.TPP, ntok - tp);
+    // one pass of tokens [tp, tp + npt) of the tile, its parameter rows staged at `stg`; `zload` / `padload` fetch a latent
+    // (index relative to the tile) / a token's padding value from wherever the caller keeps them
+    auto pass_body = [&](int tp, int npt, char* stg, int my_pos_in, auto zload, auto padload) {
         const bool valid = tli < npt;
         const int tokl = tp + (valid ? tli : 0);
         int rl = 0, n = n_first + tokl;
@@ -115,19 +116,12 @@ __global__ __launch_bounds__(kBlock) void mixture_tok_kernel(MixArgs a, TokGeom 
             rl = (int)fdiv((uint32_t)tokl, gm.div_n);
             n = tokl - rl * a.N;
         }
-        const float pv = pad_tile ? pad_tile[tokl] : 1.f;
-        const float x = valid ? z_tile[(size_t)tokl * a.D + d] : 0.f;
+        const float pv = pad_tile ? padload(tokl) : 1.f;
+        const float x = valid ? zload((size_t)tokl * a.D + d) : 0.f;
         bool active = valid;
         if (a.per_item_mask) active = active && mask_at(a.mask, a.mr, a.mc, n, d) == 0.f;
         if (a.pad_in_transform && pv == 0.f) active = false;
-
-        // ---- stage the parameter spans of the pass: DMA, 16 bytes per lane, 1 KiB of LDS per instruction
-        const char* pass_addr = span0 + (size_t)tp * gm.tokstride;
-        int my_pos = stage_pass(gm, stage_b, pass_addr, nn_last, npt, lane, tli, j, P);     // byte offset of this lane's row
-        if (!valid) my_pos = 0;
-        float* my = reinterpret_cast<float*>(stage_b + my_pos);
-        wave_lds_sync();
-
+        float* my = reinterpret_cast<float*>(stg + (valid ? my_pos_in : 0));
         float of = a.pad_output ? x * pv : x;       // a lane that transforms nothing copies its element through
         float contrib = 0.f;
         double contrib64 = 0.0;
@@ -385,8 +379,8 @@ __global__ __launch_bounds__(kBlock) void mixture_tok_kernel(MixArgs a, TokGeom 
                 const int jj = e - tk * gm.ncopy;
                 const int c = jj < gm.d0 ? jj : jj + gm.DA;
                 const int tl2 = tp + tk;
-                const float zv = z_tile[(size_t)tl2 * a.D + c];
-                const float pv2 = pad_tile ? pad_tile[tl2] : 1.f;
+                const float zv = zload((size_t)tl2 * a.D + c);
+                const float pv2 = pad_tile ? padload(tl2) : 1.f;
                 const float o = a.pad_output ? zv * pv2 : zv;
                 if (ED > 0) ep[tk * ED + c] = o;
                 else zo_tile[(size_t)tl2 * a.D + c] = o;
@@ -407,7 +401,7 @@ __global__ __launch_bounds__(kBlock) void mixture_tok_kernel(MixArgs a, TokGeom 
             wave_lds_sync();
             if (lane < npt) {
                 float xv[ED > 0 ? ED : 1];
-                const float p = pad_tile ? pad_tile[tp + lane] : 1.f;
+                const float p = pad_tile ? padload(tp + lane) : 1.f;
 #pragma unroll
                 for (int i = 0; i < ED; ++i) {
                     float y = (ep[lane * ED + i] + etab[i]) * etab[ED + i];
@@ -427,6 +421,18 @@ __global__ __launch_bounds__(kBlock) void mixture_tok_kernel(MixArgs a, TokGeom 
             wave_lds_sync();
             for (int e = lane; e < npt * ED; e += kWave) zo_tile[(size_t)tp * ED + e] = ep[e];
         }
+    };
+
+    // one stage per wave: DMA (the compiler waits for it before the first LDS read), compute, next pass; the other waves of
+    // the CU cover the latency.  (A second stage per wave with the next pass's DMA in flight during the compute — inline
+    // assembly DMA, explicit vmcnt waits — was built and measured: slower at equal LDS, 16.7 vs 15.3 us at K = 4, because the
+    // doubled stages halve the resident waves)
+    for (int tp = 0; tp < ntok; tp += gm.TPP) {                               // wave-uniform
+        const int npt = min(gm.TPP, ntok - tp);
+        const char* pass_addr = span0 + (size_t)tp * gm.tokstride;
+        const int my_pos = stage_pass(gm, stage_b, pass_addr, nn_last, npt, lane, tli, j, P);
+        wave_lds_sync();
+        pass_body(tp, npt, stage_b, my_pos, [&](size_t i) { return z_tile[i]; }, [&](int t) { return pad_tile[t]; });
         wave_lds_sync();      // the stage is overwritten by the next pass
     }
 
@@ -590,7 +596,8 @@ bool make_tok_geom(const MixArgs& a, int kt, int force_g, TokGeom& gm, int& G, s
     }
     if ((long)gm.rw * a.N >= 65536) return false;
     const size_t tabs = (((size_t)(a.D + a.D * a.K) * sizeof(BoundTab)) + 15) & ~(size_t)15;
-    gm.acc_off = (int)((size_t)kWavesPerBlock * stage + tabs);
+    gm.tab_off = kWavesPerBlock * stage;
+    gm.acc_off = (int)((size_t)gm.tab_off + tabs);
     const size_t accb = gm.split ? (size_t)kWavesPerBlock * 2 * sizeof(double)
                                  : (size_t)kWavesPerBlock * gm.rw * 2 * sizeof(long long);
     gm.epi_off = (int)(((size_t)gm.acc_off + accb + 15) & ~(size_t)15);

@@ -106,6 +106,15 @@ def load_checkpoint(path, model=None, optimizer=None, scheduler=None, device="cp
         optimizer.load_state_dict(blob["optimizer_state_dict"])
     if scheduler is not None and "scheduler_state_dict" in blob:
         scheduler.load_state_dict(blob["scheduler_state_dict"])
+    elif scheduler is not None and blob.get("iteration", 0) > 0:
+        # a best-validation checkpoint holds the model only: continue the learning-rate schedule where the run stopped
+        # (the optimiser's moment estimates start afresh) instead of silently jumping back to the initial rate
+        print("[#] WARNING: %s has no optimizer / scheduler state; the schedule is advanced to iteration %d and the "
+              "optimizer moments restart" % (path, blob["iteration"]))
+        scheduler.last_epoch = int(blob["iteration"])
+        for group, base, fn in zip(scheduler.optimizer.param_groups, scheduler.base_lrs, scheduler.lr_lambdas):
+            group["lr"] = base * fn(scheduler.last_epoch)
+        scheduler._last_lr = [g["lr"] for g in scheduler.optimizer.param_groups]
     return {k: v for k, v in blob.items() if "state_dict" not in k}
 
 
@@ -206,8 +215,8 @@ def main(argv=None):
                 best.update(file=checkpoint_file(args.checkpoint_path, step), metric=val_nll,
                             detailed_metrics={"val_bpd": val_bpd})
                 save_checkpoint(args.checkpoint_path, step, ddp, best_save_dict=best, evaluation_dict=state["evaluation_dict"])
-        if step % args.save_freq == 0 and args.checkpoint_path and rank == 0 and not os.path.isfile(
-                checkpoint_file(args.checkpoint_path, step)):
+        if step % args.save_freq == 0 and args.checkpoint_path and rank == 0:
+            # always the full state (a best-validation file of the same step is a subset of it and is replaced)
             save_checkpoint(args.checkpoint_path, step, ddp, optimizer, scheduler, best_save_dict=best,
                             evaluation_dict=state["evaluation_dict"])
     _, val_bpd = evaluate(ddp, val_sets, device, rank, world, args.eval_batch_size)

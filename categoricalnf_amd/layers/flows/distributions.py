@@ -104,6 +104,26 @@ class LogisticDistribution(PriorDistribution):
             return Fn.LogisticLogProbFn.apply(x, self.mu, self.sigma, float(self.log_sigma))
         return ops.logistic_log_prob(x, mu=self.mu, sigma=self.sigma, log_sigma=float(self.log_sigma))
 
+    def icdf(self, x, return_ldj=False):
+        """Logistic quantile function z = mu + sigma logit(x) (distributions.py:166-173, shift_x :117-127): the
+        uniform->logistic kernel without its eps squeeze; the log-det -log x - log(1-x) - log sigma is formed in fp64
+        like the reference.  Not on the flows' path (no layer calls it); kept for API parity."""
+        assert ((x < 0) | (x > 1)).sum() == 0, \
+            "[!] ERROR: Found values outside the range of 0 to 1 as input to the inverse cumulative distribution function."
+        z = ops.logistic_from_uniform(x.to(torch.float32), mu=self.mu, sigma=self.sigma, eps=0.0)
+        if not return_ldj:
+            return z
+        xd = x.double()
+        return z, (-torch.log(xd) - torch.log(1.0 - xd)).float() - float(self.log_sigma)
+
+    def cdf(self, x, return_ldj=False):
+        """Logistic CDF sigmoid((x - mu) / sigma) (distributions.py:176-181, unshift_x :129-136); its log-det is
+        -log_prob(x), from the HIP log-prob kernel."""
+        z = torch.sigmoid((x - self.mu) / self.sigma)
+        if not return_ldj:
+            return z
+        return z, -self.log_prob(x)
+
     def info(self):
         return "Sigmoid Uniform distribution with mu=%.2f and sigma=%.2f" % (self.mu, self.sigma)
 

@@ -103,6 +103,9 @@ def check_flags(device=None, where=""):
             w.zero_()
             if bits & _lib.FLAG_RANGE:
                 raise RuntimeError('Inverse logisitic CDF got y outside (0, 1)')
+            if bits & _lib.FLAG_CATEGORY:
+                raise AssertionError("[!] ERROR: One-hot tensor has larger entries than classes (category index outside "
+                                     "[0, num_classes)). %s" % where)
             what = []
             if bits & _lib.FLAG_NAN_Z:
                 what.append("latent values (z)")

@@ -41,6 +41,7 @@ extern "C" {
 #define CNF_FLAG_NAN_Z 1       /* a latent output is NaN          (flow_model.py:42) */
 #define CNF_FLAG_NAN_LDJ 2     /* a log-det output is NaN         (activation_normalization.py:46) */
 #define CNF_FLAG_RANGE 4       /* inverse-CDF input outside (0,1) (mixture_cdf_layer.py:238-239) */
+#define CNF_FLAG_CATEGORY 8    /* a category index outside [0, C)     (general/mutils.py:264, the one_hot assert) */
 
 typedef void* cnf_stream_t;
 
