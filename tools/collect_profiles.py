@@ -1,15 +1,22 @@
 """Copy the summaries tools/refresh_profiles.sh left under gpurun_out/ into profiles/ (tracked).
-Usage: python tools/collect_profiles.py [round_tag]   (default r01)"""
+Usage: python tools/collect_profiles.py [round_tag]   (default r02)"""
 import csv, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 
-line = [l for l in open(os.path.join(G, "bench.log")) if l.startswith("{")][-1]
+
+def last_json_line(path):
+    return [l for l in open(path) if l.startswith("{")][-1]
+
+
+line = last_json_line(os.path.join(G, "bench.log"))
 open(os.path.join(P, tag + "_bench.json"), "w").write(line)
+if os.path.exists(os.path.join(G, "bench_steps20.log")):
+    open(os.path.join(P, tag + "_bench_steps20.json"), "w").write(last_json_line(os.path.join(G, "bench_steps20.log")))
 
-rows = list(csv.reader(open(os.path.join(G, "prof_r01", "bench_kernel_stats.csv"))))
+rows = list(csv.reader(open(os.path.join(G, "prof_bench", "bench_kernel_stats.csv"))))
 with open(os.path.join(P, tag + "_bench_kernel_stats.csv"), "w", newline="") as fh:
     csv.writer(fh).writerows([rows[0]] + [[r[0][:120]] + r[1:] for r in rows[1:]])
 for r in rows[1:8]:
@@ -17,17 +24,15 @@ for r in rows[1:8]:
 
 shutil.copy(os.path.join(G, "traffic.json"), os.path.join(P, "traffic.json"))
 shutil.copy(os.path.join(G, "traffic.txt"), os.path.join(P, tag + "_pmc_traffic.txt"))
-for src, dst in (("sweep_affine.log", "_sweep_affine.txt"), ("sweep_mixture.log", "_sweep_mixture.txt"),
-                 ("bench_kernels.log", "_bench_kernels.txt"), ("flow_graph.txt", "_flow_graph.txt"),
-                 ("affine_probe.txt", "_affine_probe.txt"), ("encoder_probe.txt", "_encoder_probe.txt"),
-                 ("train_step.txt", "_train_step.txt")):
+for src, dst in (("sweep_affine.log", "_sweep_affine.txt"), ("sweep_nll.log", "_sweep_nll.txt"), ("sweep_mixture.log", "_sweep_mixture.txt"),
+                 ("sweep_mixture_bwd.log", "_sweep_mixture_bwd.txt"), ("bench_kernels.log", "_bench_kernels.txt"),
+                 ("flow_graph.txt", "_flow_graph.txt"), ("encoder_probe.txt", "_encoder_probe.txt"), ("train_step.txt", "_train_step.txt"),
+                 ("ceilings/ceilings.txt", "_ceilings.txt"), ("ceilings/ceilings.json", "_ceilings.json"),
+                 ("pmc_small/table.txt", "_pmc_small_mixture.txt"), ("flow_traffic.txt", "_flow_traffic.txt"),
+                 ("flow_traffic.json", "_flow_traffic.json"), ("mfma_set/mfma_util.txt", "_mfma_util_set_modelling.txt"),
+                 ("mfma_set/mfma_util.json", "_mfma_util_set_modelling.json")):
     if os.path.exists(os.path.join(G, src)):
         shutil.copy(os.path.join(G, src), os.path.join(P, tag + dst))
-lay = os.path.join(G, "prof_layers", "layers_kernel_stats.csv")
-if os.path.exists(lay):
-    rows = list(csv.reader(open(lay)))
-    with open(os.path.join(P, tag + "_layer_kernel_stats.csv"), "w", newline="") as fh:
-        csv.writer(fh).writerows([rows[0]] + [[r[0][:120]] + r[1:] for r in rows[1:] if "cnf::" in r[0]])
 tr = os.path.join(G, "prof_train", "train_kernel_stats.csv")
 if os.path.exists(tr):
     rows = list(csv.reader(open(tr)))

@@ -28,7 +28,7 @@ COPY_BYTES = 16384 * 64 * 6 * 4 * 4.0         # bytes read (= bytes written) per
 names = {"affine_coupling_fwd": "affine_coupling_kernel<4, 2, true, false, true, 1>",
          "affine_coupling_fwd_plain": "affine_coupling_kernel<4, 2, true, false, true, 0>",
          "affine_coupling_inv": "affine_coupling_kernel<4, 2, true, true, true, 0>",
-         "mixture_fwd": "mixture_f32_kernel<8, false", "copy": "__amd_rocclr_copyBuffer"}
+         "mixture_fwd": "mixture_tok_kernel<8, false, 1, false, 0>", "copy": "__amd_rocclr_copyBuffer"}
 med = lambda x: sorted(x)[len(x) // 2] if x else None
 big = lambda x: [v for v in x if v > 0.5 * max(x)] if x else x      # the calibration copies, not the tiny H2D/D2H ones
 raw = {}
