@@ -182,6 +182,143 @@ __global__ __launch_bounds__(kBlock) void encoder_decode_kernel(EncArgs a, long 
     }
 }
 
+
+// ---- large vocabularies: the class table does not fit LDS, so it is walked in chunks ---------------------------------
+//
+// A workgroup owns 256 consecutive tokens per round (one per thread) and walks the classes in chunks of CC: the chunk's
+// score constants (A, C pairs and cst2, 2D + 1 floats per class) are built cooperatively in LDS from the raw [C, 2D]
+// table (tanhf / expf per (class, channel): 1 / 256 of the scoring work that follows), every thread scores the chunk
+// against its token and keeps the streamed log-sum-exp (forward) or the running arg-max (decode).  The reference
+// materialises [T * C, 1, D] tensors for this (linear_encoding.py:155-160) — 13 GB per tensor at 32 k tokens and 10 k
+// classes; here nothing of that size exists.  Token log-det terms go to a [B * N] buffer; a second small kernel sums
+// the rows in a fixed order.
+__device__ __forceinline__ void build_class_chunk(const EncArgs& a, float* tab, int j0, int cc, int D) {
+    const int stride = 2 * D + 1;
+    const float k = kLog2e / a.sigma;
+    for (int i = threadIdx.x; i < cc * D; i += blockDim.x) {
+        const int c = i / D, d = i - c * D;
+        const float* row = a.table + (size_t)(j0 + c) * 2 * D;
+        const float ts = tanhf(row[D + d]);
+        tab[c * stride + 2 * d] = expf(-ts) * k;
+        tab[c * stride + 2 * d + 1] = row[d] * k;
+    }
+    for (int c = threadIdx.x; c < cc; c += blockDim.x) {
+        const float* row = a.table + (size_t)(j0 + c) * 2 * D;
+        float ssum = 0.f;
+        for (int d = 0; d < D; ++d) ssum += tanhf(row[D + d]);
+        tab[c * stride + 2 * D] = ((a.prior[j0 + c] - ssum) - (float)D * a.log_sigma) * kLog2e;
+    }
+}
+template <int DT>
+__device__ __forceinline__ float chunk_score2(const float* t, const float* z, int D) {
+    float acc = 0.f, prod = 1.f;
+    const int DD = DT > 0 ? DT : D;
+#pragma unroll
+    for (int d = 0; d < DD; ++d) {
+        const float vs = fabsf(fmaf(z[d], t[2 * d], -t[2 * d + 1]));
+        acc += vs;
+        prod = fmaf(prod, __builtin_amdgcn_exp2f(-vs), prod);
+    }
+    return t[2 * D] - fmaf(2.f, __builtin_amdgcn_logf(prod), acc);
+}
+
+template <int DT, bool DECODE>
+__global__ __launch_bounds__(kBlock) void encoder_tiled_kernel(EncArgs a, long ntok, int CC, float* tok_ldj) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* tab = reinterpret_cast<float*>(smem);
+    const int D = DT > 0 ? DT : a.D;
+    const int stride = 2 * D + 1;
+    bool bad = false;
+    const long rounds = (ntok + kBlock - 1) / kBlock;
+    for (long r = blockIdx.x; r < rounds; r += gridDim.x) {             // block-uniform: barriers inside are safe
+        const long tok = r * kBlock + threadIdx.x;
+        const bool live = tok < ntok;
+        float z[DT > 0 ? DT : kEncMaxD];
+        int c = 0;
+        float lp2 = 0.f, init_lp = 0.f, ldj_f = 0.f;
+        if (live && DECODE) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) z[d] = a.z_in[tok * D + d];
+        } else if (live) {
+            const long long craw = a.categ[tok];
+            if (craw < 0 || craw >= a.C) raise_flag(a.flags, CNF_FLAG_CATEGORY);
+            c = (int)(craw < 0 ? 0 : (craw >= a.C ? a.C - 1 : craw));
+            const float* row = a.table + (size_t)c * 2 * D;
+            float nacc = 0.f, nprod = 1.f;
+            const float kn = kLog2e / a.sigma;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const float e = a.eps[tok * D + d];
+                const float vs = fabsf(e) * kn;
+                nacc += vs;
+                nprod = fmaf(nprod, __builtin_amdgcn_exp2f(-vs), nprod);
+                const float ts = tanhf(row[D + d]);
+                z[d] = (e + row[d]) * expf(ts);
+                ldj_f += ts;
+            }
+            init_lp = -(kLn2 * fmaf(2.f, __builtin_amdgcn_logf(nprod), nacc) + (float)D * a.log_sigma);
+            lp2 = ((init_lp - ldj_f) + a.prior[c]) * kLog2e;
+        } else {
+#pragma unroll
+            for (int d = 0; d < D; ++d) z[d] = 0.f;
+        }
+        float m = -3e38f, ssum = 0.f, best = -INFINITY;
+        int arg = 0;
+        for (int j0 = 0; j0 < a.C; j0 += CC) {
+            const int cc = min(CC, a.C - j0);
+            __syncthreads();                                   // the previous chunk has been read by everyone
+            build_class_chunk(a, tab, j0, cc, D);
+            __syncthreads();
+            for (int jj = 0; jj < cc; ++jj) {
+                const float sc = chunk_score2<DT>(tab + jj * stride, z, D);
+                if (DECODE) {
+                    if ((j0 + jj == 0) || sc > best) {          // first maximum wins, like torch.argmax
+                        best = sc;
+                        arg = j0 + jj;
+                    }
+                } else {
+                    const float v = (j0 + jj) == c ? lp2 : sc;  // the true class takes the forward value (:167-168)
+                    const float mn = fmaxf(m, v);
+                    ssum = fmaf(ssum, __builtin_amdgcn_exp2f(m - mn), __builtin_amdgcn_exp2f(v - mn));
+                    m = mn;
+                }
+            }
+        }
+        if (!live) continue;
+        if (DECODE) {
+            a.categ_out[tok] = (int64_t)arg;
+        } else {
+            const float cpl = (lp2 - (m + __builtin_amdgcn_logf(ssum))) * kLn2;
+            const float pv = a.pad ? a.pad[tok] : 1.f;
+            if (a.cpl) a.cpl[tok] = cpl;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const float o = z[d] * pv;
+                bad |= isnan(o);
+                a.z_out[tok * D + d] = o;
+            }
+            tok_ldj[tok] = (a.beta * cpl - (init_lp - ldj_f)) * pv;
+        }
+    }
+    if (bad) raise_flag(a.flags, CNF_FLAG_NAN_Z);
+}
+
+// ldj_out[b] = ldj_in[b] + sum_n tok_ldj[b, n]: one wave per row, lane-strided partial sums, fixed butterfly
+__global__ __launch_bounds__(kBlock) void encoder_row_sum_kernel(const float* tok_ldj, const float* ldj_in, float* ldj_out,
+                                                                 int B, int N, int* flags) {
+    const int row = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (row >= B) return;
+    const int lane = threadIdx.x & 63;
+    float acc = 0.f;
+    for (int n = lane; n < N; n += kWave) acc += tok_ldj[(size_t)row * N + n];
+    acc = wave_sum(acc);
+    if (lane == 0) {
+        const float v = (ldj_in ? ldj_in[row] : 0.f) + acc;
+        ldj_out[row] = v;
+        if (isnan(v)) raise_flag(flags, CNF_FLAG_NAN_LDJ);
+    }
+}
+
 }  // namespace cnf
 
 using namespace cnf;
@@ -240,6 +377,52 @@ int cnf_encoder_decode(const float* z, const float* table, const float* category
     DISPATCH_D(D, CNF_LAUNCH((encoder_decode_kernel<DT>), dim3(grid), dim3(kBlock), smem,
                                      (hipStream_t)stream, a, ntok));
     return launch_status("cnf_encoder_decode");
+}
+
+static int tiled_chunk_classes(int D) { return std::max(1, (int)(32768 / ((2 * D + 1) * sizeof(float)))); }
+
+int64_t cnf_encoder_workspace_floats(int B, int N) { return (int64_t)B * N; }
+
+int cnf_encoder_forward_tiled(const int64_t* categ, const float* eps, const float* table,
+                              const float* category_prior, const float* pad, float beta,
+                              const float* ldj_in, float* z_out, float* ldj_out, float* class_prob_log,
+                              float* workspace,
+                              int B, int N, int D, int C, float sigma, float log_sigma,
+                              int* flags, cnf_stream_t stream) {
+    CNF_REQUIRE(categ && eps && table && category_prior && z_out && ldj_out && workspace, "cnf_encoder_forward_tiled: null tensor");
+    CNF_REQUIRE(B >= 0 && N > 0 && D > 0 && C > 0 && D <= kEncMaxD, "cnf_encoder_forward_tiled: bad shape");
+    if (B == 0) return CNF_OK;
+    EncArgs a = {};
+    a.categ = categ; a.eps = eps; a.table = table; a.prior = category_prior; a.pad = pad;
+    a.z_out = z_out; a.cpl = class_prob_log; a.flags = flags;
+    a.B = B; a.N = N; a.D = D; a.C = C; a.beta = beta; a.sigma = sigma; a.log_sigma = log_sigma;
+    const long ntok = (long)B * N;
+    const int CC = std::min(C, tiled_chunk_classes(D));
+    const size_t smem = (size_t)CC * (2 * D + 1) * sizeof(float);
+    const int grid = (int)std::min<long>((ntok + kBlock - 1) / kBlock, 256 * 8);
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_D(D, CNF_LAUNCH((encoder_tiled_kernel<DT, false>), dim3(grid), dim3(kBlock), smem, st, a, ntok, CC, workspace));
+    CNF_LAUNCH(encoder_row_sum_kernel, dim3((B + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kBlock), 0, st,
+               (const float*)workspace, ldj_in, ldj_out, B, N, flags);
+    return launch_status("cnf_encoder_forward_tiled");
+}
+
+int cnf_encoder_decode_tiled(const float* z, const float* table, const float* category_prior,
+                             int64_t* categ_out, int B, int N, int D, int C, float sigma, float log_sigma,
+                             cnf_stream_t stream) {
+    CNF_REQUIRE(z && table && category_prior && categ_out, "cnf_encoder_decode_tiled: null tensor");
+    CNF_REQUIRE(B >= 0 && N > 0 && D > 0 && C > 0 && D <= kEncMaxD, "cnf_encoder_decode_tiled: bad shape");
+    if (B == 0) return CNF_OK;
+    EncArgs a = {};
+    a.z_in = z; a.table = table; a.prior = category_prior; a.categ_out = categ_out;
+    a.B = B; a.N = N; a.D = D; a.C = C; a.sigma = sigma; a.log_sigma = log_sigma;
+    const long ntok = (long)B * N;
+    const int CC = std::min(C, tiled_chunk_classes(D));
+    const size_t smem = (size_t)CC * (2 * D + 1) * sizeof(float);
+    const int grid = (int)std::min<long>((ntok + kBlock - 1) / kBlock, 256 * 8);
+    DISPATCH_D(D, CNF_LAUNCH((encoder_tiled_kernel<DT, true>), dim3(grid), dim3(kBlock), smem, (hipStream_t)stream, a, ntok, CC,
+                             (float*)nullptr));
+    return launch_status("cnf_encoder_decode_tiled");
 }
 
 }  // extern "C"

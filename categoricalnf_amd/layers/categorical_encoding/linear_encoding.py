@@ -57,11 +57,15 @@ class LinearCategoricalEncoding(FlowLayer):
 
     # ---- helpers -------------------------------------------------------------------------------
     def _is_mixture_model(self):
-        """One ExtActNorm conditioned on the class only AND a vocabulary the one-kernel encoder holds in LDS; larger
-        vocabularies take the composed path (same ExtActNorm kernel over the expanded [T*C, 1, D] tensor)."""
+        """One ExtActNorm conditioned on the class only: the class-conditional flow is a [C, 2D] table."""
         return (len(self.flow_layers) == 1 and isinstance(self.flow_layers[0], ExtActNormFlow)
-                and not self.flow_layers[0].make_unique and not self.use_decoder
-                and ops.encoder_fused_supported(self.num_categories, self.D))
+                and not self.flow_layers[0].make_unique and not self.use_decoder and self.D <= 16)
+
+    def _kernel_path(self, needs_grad):
+        """The one-kernel encoder: always for vocabularies whose class table fits LDS; beyond that the class-tiled
+        kernels serve passes that need no gradient, and training takes the composed layer kernels (autograd through the
+        ExtActNorm kernel over the expanded [T*C, 1, D] tensor, like the reference)."""
+        return self._is_mixture_model() and (ops.encoder_fused_supported(self.num_categories, self.D) or not needs_grad)
 
     def class_table(self):
         """[C, 2D] rows [bias | scales_raw] = pred_net(embed_layer(c)) for every class (one tiny GEMM)."""
@@ -78,8 +82,8 @@ class LinearCategoricalEncoding(FlowLayer):
         batch_size, seq_length = z.size(0), z.size(1)
         detailed_ldj = {}
         if not reverse:
-            if self._is_mixture_model():
-                table = self.class_table()
+            table = self.class_table() if self._is_mixture_model() else None
+            if table is not None and self._kernel_path(Fn.needs_grad(table)):
                 eps = self._noise(batch_size * seq_length, z.device, noise)
                 if Fn.needs_grad(table):
                     z_out, ldj_loc, cpl = Fn.EncoderForwardFn.apply(table, z, eps, self.category_prior, channel_padding_mask,
@@ -95,7 +99,7 @@ class LinearCategoricalEncoding(FlowLayer):
         else:
             assert z.size(-1) == self.D, \
                 "[!] ERROR in categorical decoding: Input must have %i latent dimensions but got %i" % (self.D, z.shape[-1])
-            if self._is_mixture_model():
+            if self._kernel_path(False):
                 z_out = ops.encoder_decode(z, self.class_table().detach(), self.category_prior)
             elif self.use_decoder:
                 z_out = self.decoder(z.reshape(batch_size * seq_length, 1, self.D)).argmax(dim=-1).reshape(batch_size, seq_length)

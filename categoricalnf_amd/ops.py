@@ -576,14 +576,17 @@ def prior_nll(z, ldj, length=None, channel_padding_mask=None, sums=None,
 
 
 def encoder_fused_supported(C, D):
-    """Whether the one-kernel mixture-model encoder (cnf_encoder_forward / cnf_encoder_decode) takes this vocabulary:
-    the derived class table [C, 6D+3] and the row partials must fit its 64 KiB of LDS, D <= 16 (C <= 530 at D = 4,
-    <= 227 at D = 10).  Larger vocabularies (wikitext: 10^4 classes) run the composed layer kernels instead."""
+    """Whether the LDS-resident mixture-model encoder kernels (cnf_encoder_forward / cnf_encoder_decode / the backward)
+    take this vocabulary: the derived class table [C, 6D+3] and the row partials must fit 64 KiB of LDS, D <= 16
+    (C <= 530 at D = 4, <= 227 at D = 10).  Larger vocabularies (wikitext: 10^4 classes) run the class-tiled kernels
+    (cnf_encoder_forward_tiled / cnf_encoder_decode_tiled) when no gradient is needed, the composed layer kernels
+    otherwise."""
     return D <= 16 and 4 * 512 * 4 + C * (6 * D + 3) * 4 <= 64 * 1024
 
 
 def encoder_forward(categ, eps, table, category_prior, beta=1.0, channel_padding_mask=None, ldj=None,
-                    want_class_prob=False, sigma=LOGISTIC_SIGMA, log_sigma=LOGISTIC_LOG_SIGMA):
+                    want_class_prob=False, sigma=LOGISTIC_SIGMA, log_sigma=LOGISTIC_LOG_SIGMA, tiled=None):
+    """`tiled`: None = by vocabulary size; True forces the class-tiled kernel (tests)."""
     dev = _dev(categ)
     if categ.dtype != torch.int64:
         categ = categ.long()
@@ -599,14 +602,20 @@ def encoder_forward(categ, eps, table, category_prior, beta=1.0, channel_padding
     ldj_in, ldj_out = _ldj_io(ldj, B, dev, inplace=False)
     z = torch.empty(B, N, D, dtype=torch.float32, device=dev)
     cpl = torch.empty(B * N, dtype=torch.float32, device=dev) if want_class_prob else None
-    _launch(dev, "cnf_encoder_forward", _ptr(categ), _ptr(eps), _ptr(table), _ptr(prior), _ptr(pad), float(beta),
-                                       _ptr(ldj_in), _ptr(z), _ptr(ldj_out), _ptr(cpl), B, N, D, C, float(sigma),
-                                       float(log_sigma), _ptr(flag_word(dev)), _stream(dev))
+    if encoder_fused_supported(C, D) and not tiled:
+        _launch(dev, "cnf_encoder_forward", _ptr(categ), _ptr(eps), _ptr(table), _ptr(prior), _ptr(pad), float(beta),
+                                           _ptr(ldj_in), _ptr(z), _ptr(ldj_out), _ptr(cpl), B, N, D, C, float(sigma),
+                                           float(log_sigma), _ptr(flag_word(dev)), _stream(dev))
+    else:
+        ws = torch.empty(B * N, dtype=torch.float32, device=dev)          # token log-det terms
+        _launch(dev, "cnf_encoder_forward_tiled", _ptr(categ), _ptr(eps), _ptr(table), _ptr(prior), _ptr(pad), float(beta),
+                                                 _ptr(ldj_in), _ptr(z), _ptr(ldj_out), _ptr(cpl), _ptr(ws), B, N, D, C,
+                                                 float(sigma), float(log_sigma), _ptr(flag_word(dev)), _stream(dev))
     _after(dev, "categorical encoder")
     return z, ldj_out, cpl
 
 
-def encoder_decode(z, table, category_prior, sigma=LOGISTIC_SIGMA, log_sigma=LOGISTIC_LOG_SIGMA):
+def encoder_decode(z, table, category_prior, sigma=LOGISTIC_SIGMA, log_sigma=LOGISTIC_LOG_SIGMA, tiled=None):
     z = _f32(z, "z")
     dev = z.device
     B, N, D = z.shape
@@ -614,8 +623,8 @@ def encoder_decode(z, table, category_prior, sigma=LOGISTIC_SIGMA, log_sigma=LOG
     C = table.shape[0]
     prior = _f32(category_prior, "category_prior")
     out = torch.empty(B, N, dtype=torch.int64, device=dev)
-    _launch(dev, "cnf_encoder_decode", _ptr(z), _ptr(table), _ptr(prior), _ptr(out), B, N, D, C, float(sigma),
-                                      float(log_sigma), _stream(dev))
+    name = "cnf_encoder_decode" if (encoder_fused_supported(C, D) and not tiled) else "cnf_encoder_decode_tiled"
+    _launch(dev, name, _ptr(z), _ptr(table), _ptr(prior), _ptr(out), B, N, D, C, float(sigma), float(log_sigma), _stream(dev))
     return out
 
 

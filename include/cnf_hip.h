@@ -319,6 +319,22 @@ int cnf_encoder_decode(const float* z, const float* table, const float* category
                        int64_t* categ_out, int B, int N, int D, int C, float sigma, float log_sigma,
                        cnf_stream_t stream);
 
+/* The same two for vocabularies whose class table does not fit LDS (wikitext: 10^4 classes): the classes are walked
+ * in chunks whose score constants a workgroup rebuilds in LDS, the streamed log-sum-exp / arg-max runs across chunks,
+ * and nothing of size [T*C, ...] is materialised (linear_encoding.py:155-160 expands to [T*C, 1, D]).  Same results as
+ * cnf_encoder_forward / cnf_encoder_decode.  workspace: cnf_encoder_workspace_floats(B, N) floats (token log-det terms;
+ * a second kernel sums the rows in a fixed order). */
+int64_t cnf_encoder_workspace_floats(int B, int N);
+int cnf_encoder_forward_tiled(const int64_t* categ, const float* eps, const float* table,
+                              const float* category_prior, const float* pad, float beta,
+                              const float* ldj_in, float* z_out, float* ldj_out, float* class_prob_log,
+                              float* workspace,
+                              int B, int N, int D, int C, float sigma, float log_sigma,
+                              int* flags, cnf_stream_t stream);
+int cnf_encoder_decode_tiled(const float* z, const float* table, const float* category_prior,
+                             int64_t* categ_out, int B, int N, int D, int C, float sigma, float log_sigma,
+                             cnf_stream_t stream);
+
 /* ---- sigmoid / logit flow ------------------------------------------------------------------- */
 
 /* SigmoidFlow.forward (sigmoid_layer.py:24-47) after the XOR of the two reverse flags:

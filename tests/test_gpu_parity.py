@@ -1253,3 +1253,58 @@ def test_molecule_graph_cnf_three_stage_flow_golden():
         (nodes, adjacency), ldj_rev = model(g(c.z), reverse=True, length=g(c.length), edge_latents=g(c.edge_latents))
     assert torch.equal(nodes.cpu(), c.dec_nodes) and torch.equal(adjacency.cpu(), c.dec_adjacency)
     loglik_close(ldj_rev, c.ldj_rev)
+
+
+@pytest.mark.parametrize("B,N,D,C", [(9, 16, 4, 16), (5, 33, 3, 51), (3, 20, 10, 700), (2, 12, 6, 3000), (4, 7, 1, 2), (70, 5, 2, 1200)])
+def test_class_tiled_encoder_kernels(B, N, D, C):
+    """cnf_encoder_forward_tiled / cnf_encoder_decode_tiled (vocabularies beyond the LDS-resident class table):
+    equal to the LDS-resident kernels where both apply, equal to the oracle at 700 / 1200 / 3000 classes — latents,
+    per-sample log-det (1e-4 relative), class posterior, decoded indices bit-exact."""
+    gen = torch.Generator().manual_seed(B * 31 + C)
+    cat = torch.randint(0, C, (B, N), generator=gen)
+    table = torch.randn(C, 2 * D, generator=gen)
+    prior = torch.log_softmax(torch.randn(C, generator=gen), 0)
+    eps = O.logistic_from_uniform(torch.rand(B * N, 1, D, generator=gen))
+    ln = torch.randint(max(1, N // 2), N + 1, (B,), generator=gen)
+    pad = O.length_mask(ln, N)
+    ldj0 = torch.randn(B, generator=gen)
+    zt, lt, ct = ops().encoder_forward(g(cat), g(eps), g(table), g(prior), beta=1.5, channel_padding_mask=g(pad), ldj=g(ldj0),
+                                       want_class_prob=True, tiled=True)
+    zo, lo, co = O.encoder_forward(cat, eps, table, prior, beta=1.5, channel_padding_mask=pad)
+    close(zt, zo, **ELEM); loglik_close(lt, lo + ldj0)
+    close(ct, co.reshape(-1), rtol=1e-4, atol=1e-4)
+    dt = ops().encoder_decode(zt, g(table), g(prior), tiled=True)
+    assert torch.equal(dt.cpu(), O.encoder_decode(zt.cpu(), table, prior)[0])
+    if ops().encoder_fused_supported(C, D):
+        zf, lf, cf = ops().encoder_forward(g(cat), g(eps), g(table), g(prior), beta=1.5, channel_padding_mask=g(pad), ldj=g(ldj0),
+                                           want_class_prob=True)
+        close(zt, zf, rtol=1e-6, atol=1e-6); close(lt, lf, rtol=1e-5, atol=1e-4); close(ct, cf, rtol=1e-5, atol=1e-5)
+        assert torch.equal(dt, ops().encoder_decode(zt, g(table), g(prior)))
+    else:
+        # the automatic choice is the tiled kernel
+        z2, l2, _ = ops().encoder_forward(g(cat), g(eps), g(table), g(prior), beta=1.5, channel_padding_mask=g(pad), ldj=g(ldj0))
+        assert torch.equal(z2, zt) and torch.equal(l2, lt)
+    ops().check_flags(torch.device("cuda"), "tiled encoder")
+
+
+def test_large_vocabulary_encoder_module_runs_on_the_tiled_kernels():
+    """LinearCategoricalEncoding with 2000 classes: evaluation passes go through the class-tiled kernels (no [T*C,1,D]
+    tensor), decode(encode(x)) agrees with the composed path's posterior arg-max, an out-of-range index raises."""
+    from categoricalnf_amd.layers.categorical_encoding.linear_encoding import LinearCategoricalEncoding
+    torch.manual_seed(3)
+    enc = LinearCategoricalEncoding(num_dimensions=6, flow_config={"num_flows": 0}, vocab_size=2000).cuda().eval()
+    assert enc._is_mixture_model() and not ops().encoder_fused_supported(2000, 6)
+    x = torch.randint(0, 2000, (4, 24), device="cuda")
+    u = torch.rand(4 * 24, 1, 6, device="cuda")
+    with torch.no_grad():
+        z, ldj, _ = enc(x, noise=u)
+        zc, ldjc, _ = enc._forward_composed(x, 1, None, u)
+        dec, _, _ = enc(z, reverse=True)
+        ref = enc._posterior_sample(z.reshape(-1, 1, 6)).reshape(4, 24)
+    close(z, zc, **ELEM); loglik_close(ldj, ldjc)
+    assert torch.equal(dec, ref)
+    with pytest.raises(AssertionError):
+        bad = x.clone(); bad[0, 0] = 2000
+        with torch.no_grad():
+            enc(bad, noise=u)
+        ops().check_flags(torch.device("cuda"), "range")
