@@ -419,6 +419,23 @@ def main():
     rounds = [marks[k].elapsed_time(marks[k + 1]) / reps for k in range(1, blocks)]
     steady_ms = float(np.median(rounds))
     kern_ms = float(np.mean(in_step)) if in_step else steady_ms
+    # measured ceiling for this traffic mix on this device, same run, same rotating buffers: a streaming kernel that
+    # reads 4 + 8 bytes and writes 4 bytes per element and computes nothing (cnf_stream_probe); dispatch-bound pairs
+    stream_ms = {}
+    for cpl in (1, 2, 4):
+        def probe(r, cpl=cpl):
+            ops._launch(dev, "cnf_stream_probe", zs[r].data_ptr(), nns[r].data_ptr(), zrs[r].data_ptr(), elems, cpl,
+                        ops._stream(dev))
+        for i in range(20):
+            probe(i % R)
+        lib.cnf_prof_arm(100)
+        for i in range(100):
+            probe(i % R)
+        pb = (ctypes.c_float * 100)()
+        n_pb = lib.cnf_prof_collect(pb, 100)
+        stream_ms[cpl] = float(np.median([pb[i] for i in range(n_pb)]))
+    ceil_ms = min(stream_ms.values())
+    ceil_gbs = 16.0 * elems / (ceil_ms * 1e-3) / 1e9
     alg_bytes = 16.0 * elems + 4.0 * B            # z 4 + (s,t) 8 + z' 4 per elem, + ldj per sample
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
     traffic, traffic_note = read_traffic()
@@ -444,6 +461,10 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                          "frac_of_achievable_6300": achieved / 6300.0,
+                         "measured_stream_ceiling": {"GBps": ceil_gbs, "kernel_ms": ceil_ms, "frac_of_it": achieved / ceil_gbs,
+                                                     "what": "cnf_stream_probe: 12 B read + 4 B written per element, no "
+                                                             "arithmetic, same buffers and clock; best of 1/2/4 chunks per lane",
+                                                     "ms_by_chunks_per_lane": stream_ms},
                          "kernel": "affine_coupling_kernel<VEC=4,fwd,NLL>", "kernel_ms": kern_ms,
                          "kernel_ms_source": "dispatch-bound HIP event pairs on %d forward launches inside the timed region" % len(in_step)
                                              if in_step else "steady-state stream after the timed region (no in-step samples)",

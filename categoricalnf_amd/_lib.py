@@ -72,6 +72,7 @@ SIGNATURES = {
     "cnf_mixture_transform_bwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p,
                                   _i, _i, _i, _i, _d, _d, _i, _p],
     "cnf_mixture_params_bwd": [_p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "cnf_stream_probe": [_p, _p, _p, ctypes.c_long, _i, _p],
 }
 _PLAIN = {"cnf_abi_version": ([], _i), "cnf_last_error": ([], ctypes.c_char_p),
           "cnf_set_tile_chunks": ([_i], None), "cnf_set_unroll": ([_i], None),

@@ -1,0 +1,59 @@
+// Diagnostic only: a streaming kernel with the affine coupling's traffic mix (reads 4 + 8 bytes, writes 4 bytes per
+// element, 16-byte accesses, nontemporal stores) and next to no arithmetic.  bench.py times it beside the coupling
+// kernel so that `roofline` can be read against what THIS device sustains for this read/write mix, not only against
+// the 8 TB/s data-sheet figure ("also report a measured stream-copy ceiling from the same run").
+// Not part of the reference's interface; nothing in the layers calls it.
+#include "cnf_common.h"
+
+namespace cnf {
+namespace {
+
+typedef float pf4 __attribute__((ext_vector_type(4)));
+
+template <int U>
+__global__ __launch_bounds__(256) void stream_mix_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                         float* __restrict__ out, long nchunks) {
+    // a block owns 256*U consecutive 16-byte chunks of `a` / `out` and the matching 32-byte pairs of `b`
+    const long base = (long)blockIdx.x * (256 * U) + threadIdx.x;
+    pf4 va[U], vb0[U], vb1[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const long c = base + (long)u * 256;
+        if (c < nchunks) {
+            va[u] = *reinterpret_cast<const pf4*>(a + 4 * c);
+            vb0[u] = *reinterpret_cast<const pf4*>(b + 8 * c);
+            vb1[u] = *reinterpret_cast<const pf4*>(b + 8 * c + 4);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const long c = base + (long)u * 256;
+        if (c < nchunks) {
+            pf4 r;
+            r.x = va[u].x + vb0[u].x * vb0[u].y;
+            r.y = va[u].y + vb0[u].z * vb0[u].w;
+            r.z = va[u].z + vb1[u].x * vb1[u].y;
+            r.w = va[u].w + vb1[u].z * vb1[u].w;
+            __builtin_nontemporal_store(r, reinterpret_cast<pf4*>(out + 4 * c));
+        }
+    }
+}
+
+}  // namespace
+}  // namespace cnf
+
+extern "C" int cnf_stream_probe(const float* a, const float* b, float* out, long n, int chunks_per_lane, void* stream) {
+    using namespace cnf;
+    CNF_REQUIRE(a && b && out && n > 0 && n % 4 == 0, "cnf_stream_probe: n must be a positive multiple of 4");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const long nchunks = n / 4;
+    const int U = chunks_per_lane;
+    const long blocks = (nchunks + 256L * U - 1) / (256L * U);
+    switch (U) {
+        case 1: CNF_LAUNCH((stream_mix_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, st, a, b, out, nchunks); break;
+        case 2: CNF_LAUNCH((stream_mix_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, st, a, b, out, nchunks); break;
+        case 4: CNF_LAUNCH((stream_mix_kernel<4>), dim3((unsigned)blocks), dim3(256), 0, st, a, b, out, nchunks); break;
+        default: CNF_REQUIRE(false, "cnf_stream_probe: chunks_per_lane must be 1, 2 or 4");
+    }
+    return launch_status("cnf_stream_probe");
+}

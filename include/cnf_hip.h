@@ -77,6 +77,12 @@ void cnf_set_mixture_tile(int items);
  * (HOST pointer), returns how many were written, and disarms. */
 int cnf_prof_arm(int launches);
 int cnf_prof_collect(float* ms_out_host, int capacity);
+/* Diagnostic: a streaming kernel with the affine coupling's traffic mix and no real arithmetic — a [n] fp32 read,
+ * b [2n] fp32 read, out [n] fp32 written (out = a + b_even * b_odd), 16-byte accesses, `chunks_per_lane` in {1,2,4}.
+ * bench.py times it in the same run as the coupling kernel: the measured ceiling for 12 B read + 4 B written per
+ * element on this device ("a measured stream-copy ceiling from the same run").  No reference
+ * counterpart. */
+int cnf_stream_probe(const float* a, const float* b, float* out, long n, int chunks_per_lane, cnf_stream_t stream);
 
 /* ---- affine coupling -------------------------------------------------------------------- */
 

@@ -1293,6 +1293,8 @@ def test_large_vocabulary_encoder_module_runs_on_the_tiled_kernels():
     from categoricalnf_amd.layers.categorical_encoding.linear_encoding import LinearCategoricalEncoding
     torch.manual_seed(3)
     enc = LinearCategoricalEncoding(num_dimensions=6, flow_config={"num_flows": 0}, vocab_size=2000).cuda().eval()
+    for p in enc.parameters():                       # the conditioner's last layer starts at zero: make classes differ
+        p.data.normal_(0.0, 0.5)
     assert enc._is_mixture_model() and not ops().encoder_fused_supported(2000, 6)
     x = torch.randint(0, 2000, (4, 24), device="cuda")
     u = torch.rand(4 * 24, 1, 6, device="cuda")
@@ -1300,11 +1302,24 @@ def test_large_vocabulary_encoder_module_runs_on_the_tiled_kernels():
         z, ldj, _ = enc(x, noise=u)
         zc, ldjc, _ = enc._forward_composed(x, 1, None, u)
         dec, _, _ = enc(z, reverse=True)
-        ref = enc._posterior_sample(z.reshape(-1, 1, 6)).reshape(4, 24)
+        scores = enc._all_class_scores(z.reshape(-1, 1, 6))
     close(z, zc, **ELEM); loglik_close(ldj, ldjc)
-    assert torch.equal(dec, ref)
+    best = scores.max(dim=-1).values
+    picked = scores.gather(1, dec.reshape(-1, 1)).squeeze(1)
+    assert (dec.reshape(-1) == scores.argmax(dim=-1)).float().mean() > 0.98
+    assert float((best - picked).max()) < 1e-3       # any disagreement is a tie at fp32 resolution
     with pytest.raises(AssertionError):
         bad = x.clone(); bad[0, 0] = 2000
         with torch.no_grad():
             enc(bad, noise=u)
         ops().check_flags(torch.device("cuda"), "range")
+
+
+@pytest.mark.parametrize("cpl", [1, 2, 4])
+def test_stream_probe_moves_what_it_says(cpl):
+    """bench.py's measured-ceiling kernel: out = a + b_even * b_odd over n elements, ragged last block."""
+    n = 4 * (256 * 7 + 33)
+    a, b = torch.randn(n, device="cuda"), torch.randn(2 * n, device="cuda")
+    out = torch.zeros(n, device="cuda")
+    ops()._launch(a.device, "cnf_stream_probe", a.data_ptr(), b.data_ptr(), out.data_ptr(), n, cpl, ops()._stream(a.device))
+    assert torch.equal(out, a + b[0::2] * b[1::2])
