@@ -100,3 +100,39 @@ class GraphNodeFlow(FlowModel):
                 rb = flow(zb, reverse=False, adjacency=adj_p, **kw)
                 za, la, zb, lb = ra[0], la + ra[1], rb[0], lb + rb[1]
         return bool(((za - zb[:, inv]).abs() > tol_z).sum() == 0 and ((la - lb).abs() > tol_ldj).sum() == 0)
+
+
+def flow_nll(model, prior, nodes, adjacency, length, beta=1.0):
+    """Per-graph negative log-likelihood per node, task.py:84-130 (`_train_batch_flow` / `_eval_batch_flow`):
+    (-sum over valid nodes of log p(z) - ldj) / length.  Returns ([B] nll, per-layer log-det list)."""
+    z, ldj, ldj_per_layer = model(nodes, adjacency, reverse=False, get_ldj_per_layer=True, beta=beta, length=length)
+    pad = create_channel_mask(length, max_len=nodes.size(1))
+    neglog = -(prior.log_prob(z) * pad).sum(dim=[1, 2])
+    return (neglog - ldj) / length.float(), ldj_per_layer
+
+
+def sample_colorings(model, prior, adjacency, length, temp=1.0, noise=None):
+    """One generation pass, task.py:170-190: latents from the prior for every node of the given graphs, the flow
+    backwards, the encoder's arg-max decode.  Returns int64 [B, N] colours (padding positions are whatever the decode
+    gives there; the validity count looks at the first `length` nodes only)."""
+    shape = (adjacency.shape[0], adjacency.shape[1], model.embed_dim)
+    with torch.no_grad():
+        if noise is not None:
+            z = prior.sample(shape=shape, device=adjacency.device, uniform=noise.reshape(shape))
+        else:
+            z = prior.sample(shape=shape, device=adjacency.device, temp=temp)
+        nodes, _ = model(z, adjacency=adjacency, length=length, reverse=True)
+    return nodes
+
+
+def generation_validity(model, prior, batches, dataset_class):
+    """`_eval_finalize_metrics` (task.py:194-215) without the host round trips: sample a colouring for every graph of
+    `batches` (iterable of (nodes, adjacency, length) on the model's device) and count the valid ones where they lie.
+    Returns {"valid_ratio": ..., "num_graphs": ...}."""
+    valid, total = 0.0, 0
+    for _, adjacency, length in batches:
+        nodes = sample_colorings(model, prior, adjacency, length)
+        ratio = dataset_class.evaluate_generations(nodes=nodes, adjacency=adjacency, length=length)["valid_ratio"]
+        valid += ratio * adjacency.shape[0]
+        total += adjacency.shape[0]
+    return {"valid_ratio": valid / max(total, 1), "num_graphs": total}

@@ -1323,3 +1323,32 @@ def test_stream_probe_moves_what_it_says(cpl):
     out = torch.zeros(n, device="cuda")
     ops()._launch(a.device, "cnf_stream_probe", a.data_ptr(), b.data_ptr(), out.data_ptr(), n, cpl, ops()._stream(a.device))
     assert torch.equal(out, a + b[0::2] * b[1::2])
+
+
+def test_graph_colouring_generation_and_validity_on_device():
+    """task.py:170-215 on the drop-in: latents from the prior -> flow backwards -> decoded colours -> validity counted on
+    the device; the count equals the reference's per-graph numpy rule (restated here) on the same samples, and the
+    per-node NLL helper equals the oracle's assembly."""
+    from tests.test_host_cpu import _graph_model
+    from categoricalnf_amd.experiments.graph_coloring import sample_colorings, generation_validity, flow_nll
+    from categoricalnf_amd.experiments.graph_coloring_data import GraphColoringDataset, coloring_validity
+    from categoricalnf_amd.layers.flows.distributions import LogisticDistribution
+    c = load_cases("graph_node_flow")[0]
+    model = _graph_model(c.meta)
+    model.load_state_dict({k[3:]: v for k, v in c.items() if k.startswith("sd_")})
+    model.cuda().eval()
+    prior = LogisticDistribution(mu=0.0, sigma=1.0)
+    adj, ln = g(c.adjacency), g(c.length)
+    u = torch.rand(adj.shape[0], adj.shape[1], model.embed_dim, device="cuda")
+    nodes = sample_colorings(model, prior, adj, ln, noise=u)
+    assert nodes.dtype == torch.int64 and nodes.shape == adj.shape[:2] and int(nodes.min()) >= 0 and int(nodes.max()) < 3
+    valid = coloring_validity(nodes, adj, ln)
+    n_, a_, l_ = nodes.cpu().numpy(), c.adjacency.numpy(), c.length.numpy()
+    ref = [bool(np.all((n_[i, :l_[i]] + 1)[:, None] != a_[i, :l_[i], :l_[i]] * (n_[i, :l_[i]] + 1)[None, :])) for i in range(len(l_))]
+    assert valid.cpu().tolist() == ref
+    torch.manual_seed(0)
+    out = generation_validity(model, prior, [(None, adj, ln), (None, adj[:3], ln[:3])], GraphColoringDataset)
+    assert out["num_graphs"] == adj.shape[0] + 3 and 0.0 <= out["valid_ratio"] <= 1.0
+    with torch.no_grad():
+        nll, per_layer = flow_nll(model, prior, g(c.categ), adj, ln)
+    assert nll.shape == (adj.shape[0],) and torch.isfinite(nll).all() and len(per_layer) == len(model.flow_layers)

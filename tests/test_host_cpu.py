@@ -516,3 +516,76 @@ print("OK", sum(p.numel() for p in model.parameters()))
     out = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd="/tmp")
     assert out.returncode == 0, out.stderr[-2500:]
     assert "OK" in out.stdout
+
+
+# ---- graph-colouring host utilities -----------------------------------------------------------
+@pytest.fixture
+def coloring_golden():
+    import random
+    from categoricalnf_amd.experiments.graph_coloring_data import GraphColoringDataset as DS
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "graph_coloring_data.npz"))
+    saved = (DS.DATASET_NODES, DS.DATASET_ADJACENCIES, DS.DATASET_TRAIN_IDX, DS.DATASET_VAL_IDX, DS.DATASET_TEST_IDX)
+    DS.DATASET_NODES, DS.DATASET_ADJACENCIES = gold["nodes"], gold["adjacency"]
+    DS.DATASET_TRAIN_IDX, DS.DATASET_VAL_IDX, DS.DATASET_TEST_IDX = gold["train_idx"], gold["val_idx"], gold["test_idx"]
+    yield DS, gold, random
+    (DS.DATASET_NODES, DS.DATASET_ADJACENCIES, DS.DATASET_TRAIN_IDX, DS.DATASET_VAL_IDX, DS.DATASET_TEST_IDX) = saved
+
+
+def test_coloring_validity_matches_reference(coloring_golden):
+    """graph_coloring.py:114-135 — per-graph validity and the valid ratio of a padded batch, as the reference counts them."""
+    from categoricalnf_amd.experiments.graph_coloring_data import coloring_validity
+    DS, gold, _ = coloring_golden
+    val = DS(val=True)
+    items = [val[i] for i in range(len(val))]
+    nodes, adj, ln = (np.stack([it[k] for it in items]) for k in range(3))
+    assert np.array_equal(nodes, gold["val_nodes"]) and np.array_equal(adj, gold["val_adjacency"])
+    assert np.array_equal(ln, gold["val_length"])
+    valid = coloring_validity(torch.from_numpy(nodes), torch.from_numpy(adj), torch.from_numpy(ln))
+    assert np.array_equal(valid.numpy(), gold["val_valid"])
+    assert 0 < valid.sum() < valid.numel()                                   # the set holds both kinds
+    ratio = DS.evaluate_generations(torch.from_numpy(nodes), adj, ln)["valid_ratio"]
+    assert ratio == float(gold["val_valid_ratio"])
+    # without lengths every node counts: a valid graph stays valid when its padding (colour 0, no edges) is included
+    full = coloring_validity(nodes, adj)
+    assert bool((full.numpy() == gold["val_valid"]).all())
+
+
+def test_bucket_sampler_visits_graphs_in_the_reference_order(coloring_golden):
+    """datasets/mutils.py:9-61 — same index stream under the same np.random seed; batches hold one length bucket."""
+    from categoricalnf_amd.experiments.graph_coloring_data import BucketSampler
+    DS, gold, _ = coloring_golden
+    train = DS(train=True)
+    for bs in (16, 7):
+        for seed in (0, 5):
+            np.random.seed(seed)
+            got = np.array(list(iter(BucketSampler(train, bs))), dtype=np.int64)
+            assert np.array_equal(got, gold["sampler_bs%d_seed%d" % (bs, seed)])
+            assert sorted(got.tolist()) == list(range(len(train)))           # every graph once
+    np.random.seed(3)
+    batches = np.array(list(train.get_sampler(16, drop_last=True)), dtype=np.int64)
+    assert np.array_equal(batches, gold["batch_sampler_bs16_seed3"])
+    lengths = (gold["nodes"][gold["train_idx"]] >= 0).sum(-1)
+    same = [len(set(lengths[b].tolist())) == 1 for b in batches]
+    assert sum(same) >= len(same) - len(set(lengths.tolist()))               # only bucket-boundary batches mix lengths
+
+
+@pytest.mark.parametrize("order", ["none", "rand", "largest_first", "smallest_first"])
+def test_coloring_dataset_items_match_reference(coloring_golden, order):
+    """graph_coloring.py:49-84 — colour permutation, padding to 0, node orderings, under the same `random` / np seeds."""
+    DS, gold, random = coloring_golden
+    ds = DS(train=True, order_graphs=order)
+    random.seed(11); np.random.seed(11)
+    items = [ds[i] for i in range(24)]
+    for k, name in enumerate(("nodes", "adjacency", "length")):
+        assert np.array_equal(np.stack([it[k] for it in items]), gold["item_%s_%s" % (order, name)]), name
+
+
+def test_coloring_dataset_missing_file_message(tmp_path):
+    from categoricalnf_amd.experiments.graph_coloring_data import GraphColoringDataset as DS
+    saved = DS.DATASET_NODES
+    DS.DATASET_NODES = None
+    try:
+        with pytest.raises(AssertionError, match="could not be loaded due to a missing file"):
+            DS(val=True, data_root=str(tmp_path))
+    finally:
+        DS.DATASET_NODES = saved
