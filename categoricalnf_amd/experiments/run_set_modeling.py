@@ -11,7 +11,9 @@ general/train.py:331-358: RAdam, lr 7.5e-4 decayed by 0.999975 per step, gradien
 evaluation every 2000 iterations on the 32768 fixed validation sets) and the same checkpoint files
 (`checkpoint_%07d.tar` holding `model_state_dict` [+ optimizer / scheduler state], `iteration`, `best_save_dict`,
 `evaluation_dict`; general/train.py:257-276), so checkpoints move between the two code bases.
-Not reproduced: tensorboard summaries, the discrete-flow baseline, parameter pickles.
+`param_config.pik` (the pickled argument namespace, general/train.py:428-432) is written beside them and read back by
+`--only_eval`, which then rebuilds the model from the run's own hyper-parameters.
+Not reproduced: tensorboard summaries, the discrete-flow baseline.
 
 Multi-GPU replaces `nn.DataParallel` (general/train.py:36-44) by one process per GPU: every rank draws its own
 training batches of `batch_size / world` sets, DistributedDataParallel all-reduces the gradients over RCCL, and
@@ -21,6 +23,7 @@ import contextlib
 import glob
 import io
 import os
+import pickle
 import time
 
 import numpy as np
@@ -46,6 +49,8 @@ def parse(argv=None):
     p.add_argument("--seed", type=int, default=42)
     p.add_argument("--checkpoint_path", default=None)
     p.add_argument("--only_eval", action="store_true")
+    p.add_argument("--load_best_model", action="store_true",
+                   help="with --only_eval: evaluate the best-validation checkpoint instead of the newest")
     p.add_argument("--learning_rate", type=float, default=7.5e-4)
     p.add_argument("--lr_decay_factor", type=float, default=0.999975)
     p.add_argument("--lr_decay_step", type=int, default=1)
@@ -88,15 +93,44 @@ def save_checkpoint(path, iteration, model, optimizer=None, scheduler=None, **ex
     return checkpoint_file(path, iteration)
 
 
-def load_checkpoint(path, model=None, optimizer=None, scheduler=None, device="cpu"):
-    """`path` = a checkpoint file or a directory (its newest `*.tar`); returns the non-state entries
-    (general/mutils.py:66-112)."""
-    if os.path.isdir(path):
+PARAM_CONFIG_FILE = "param_config.pik"          # general/mutils.py:15
+
+
+def save_args(path, args):
+    """The run's argument namespace beside its checkpoints (general/train.py:428-432), so that evaluation can rebuild
+    the model without repeating the command line."""
+    os.makedirs(path, exist_ok=True)
+    with open(os.path.join(path, PARAM_CONFIG_FILE), "wb") as f:
+        pickle.dump(args, f)
+
+
+def load_args(path):
+    """general/mutils.py:123-133: `path` = the checkpoint directory or a file in it."""
+    if os.path.isfile(path):
+        path = os.path.dirname(path)
+    with open(os.path.join(path, PARAM_CONFIG_FILE), "rb") as f:
+        return pickle.load(f)
+
+
+def load_checkpoint(path, model=None, optimizer=None, scheduler=None, device="cpu", load_best_model=False):
+    """`path` = a checkpoint file or a directory (its newest `*.tar`, or with `load_best_model` the file its
+    `best_save_dict` names); returns the non-state entries (general/mutils.py:66-112)."""
+    was_dir = os.path.isdir(path)
+    if was_dir:
         files = sorted(glob.glob(os.path.join(path, "*.tar")))
         if not files:
+            print("No checkpoint files found at", path)
             return {}
         path = files[-1]
     blob = torch.load(path, map_location=device, weights_only=False)
+    if was_dir and load_best_model:
+        best_file = (blob.get("best_save_dict") or {}).get("file")
+        if best_file and not os.path.isfile(best_file):         # the directory may have moved since the run
+            best_file = os.path.join(os.path.dirname(path), os.path.basename(best_file))
+        if best_file and os.path.isfile(best_file):
+            return load_checkpoint(best_file, model, optimizer, scheduler, device=device)
+        print("[!] WARNING: Best save dict file is listed as \"%s\", but file could not been found. Using default one..."
+              % str((blob.get("best_save_dict") or {}).get("file")))
     if model is not None:
         inner = model.module if hasattr(model, "module") else model
         state = inner.state_dict()
@@ -138,8 +172,19 @@ def evaluate(model, sets, device, rank=0, world=1, batch_size=4096):
     return mean_nll, bpd
 
 
+MODEL_ARGS = ("dataset", "set_size", "encoding_dim", "coupling_hidden_size", "coupling_hidden_layers",
+              "coupling_num_flows", "coupling_mask_ratio", "coupling_num_mixtures")
+
+
 def main(argv=None):
     args = parse(argv)
+    if args.only_eval and args.checkpoint_path and os.path.isfile(
+            os.path.join(args.checkpoint_path if os.path.isdir(args.checkpoint_path) else os.path.dirname(args.checkpoint_path),
+                         PARAM_CONFIG_FILE)):
+        saved = load_args(args.checkpoint_path)          # the model is the one the run trained, whatever the flags say
+        for name in MODEL_ARGS:
+            if hasattr(saved, name):
+                setattr(args, name, getattr(saved, name))
     rank, local_rank, world = init_process_group(args.backend)
     device = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(device)
@@ -167,8 +212,9 @@ def main(argv=None):
         optimizer, lambda step: max(floor, args.lr_decay_factor ** (step // max(1, args.lr_decay_step))))
     state = {"iteration": 0, "best_save_dict": {"file": None, "metric": 1e6, "detailed_metrics": None, "test": None},
              "evaluation_dict": {}}
-    if args.checkpoint_path and os.path.isdir(args.checkpoint_path):
-        state.update(load_checkpoint(args.checkpoint_path, model, optimizer, scheduler, device=device))
+    if args.checkpoint_path and os.path.exists(args.checkpoint_path):
+        state.update(load_checkpoint(args.checkpoint_path, model, optimizer, scheduler, device=device,
+                                     load_best_model=args.only_eval and args.load_best_model))
     if state["iteration"] == 0 and not args.only_eval:
         # data-dependent ActNorm initialisation on 16 batches (general/task.py: initialize); every rank uses the
         # same sets so the replicas start identical
@@ -180,6 +226,8 @@ def main(argv=None):
                 for _ in range(16)])
     ddp = wrap_ddp(model, device)
 
+    if not args.only_eval and args.checkpoint_path and rank == 0:
+        save_args(args.checkpoint_path, args)
     if args.only_eval:
         _, val_bpd = evaluate(ddp, val_sets, device, rank, world, args.eval_batch_size)
         _, test_bpd = evaluate(ddp, test_sets, device, rank, world, args.eval_batch_size)

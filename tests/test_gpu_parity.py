@@ -1165,6 +1165,11 @@ def test_set_modelling_driver_trains_checkpoints_and_reloads(tmp_path):
     assert out["best_file"] and os.path.isfile(out["best_file"])
     again = R.main(small + ["--only_eval"])
     assert abs(again["val_bpd"] - out["val_bpd"]) < 2e-3, (again, out)
+    # param_config.pik (general/train.py:428-432): evaluation needs the directory only, the model is rebuilt from it
+    assert os.path.isfile(os.path.join(str(tmp_path), R.PARAM_CONFIG_FILE))
+    assert R.load_args(out["best_file"]).coupling_hidden_size == 32
+    bare = R.main(["--checkpoint_path", str(tmp_path), "--only_eval", "--load_best_model"])
+    assert abs(bare["val_bpd"] - out["val_bpd"]) < 2e-3, (bare, out)
 
 
 

@@ -338,6 +338,29 @@ def test_checkpoint_files_follow_the_reference_format(tmp_path):
     assert torch.equal(other.weight, net.weight) and extra["iteration"] == 1234 and extra["evaluation_dict"] == {1000: 3.1}
 
 
+def test_best_model_and_argument_pickle_round_trip(tmp_path):
+    """general/mutils.py:84-90 (`load_best_model`) and :123-133 / train.py:428-432 (`param_config.pik`)."""
+    import shutil
+    from categoricalnf_amd.experiments import run_set_modeling as R
+    run = tmp_path / "run"
+    best_net, last_net = torch.nn.Linear(3, 2), torch.nn.Linear(3, 2)
+    best = {"file": R.checkpoint_file(str(run), 100), "metric": 2.5}
+    R.save_checkpoint(str(run), 100, best_net, best_save_dict=best)
+    R.save_checkpoint(str(run), 200, last_net, best_save_dict=best)
+    probe = torch.nn.Linear(3, 2)
+    assert R.load_checkpoint(str(run), probe)["iteration"] == 200 and torch.equal(probe.weight, last_net.weight)
+    assert R.load_checkpoint(str(run), probe, load_best_model=True)["iteration"] == 100 and torch.equal(probe.weight, best_net.weight)
+    moved = tmp_path / "moved"                                    # the stored absolute path no longer exists
+    shutil.move(str(run), str(moved))
+    assert R.load_checkpoint(str(moved), probe, load_best_model=True)["iteration"] == 100
+    os.remove(R.checkpoint_file(str(moved), 100))                 # best file gone: warn and use the newest
+    assert R.load_checkpoint(str(moved), probe, load_best_model=True)["iteration"] == 200
+    args = R.parse(["--dataset", "summation", "--coupling_num_flows", "3"])
+    R.save_args(str(moved), args)
+    back = R.load_args(R.checkpoint_file(str(moved), 200))
+    assert back.dataset == "summation" and back.coupling_num_flows == 3 and vars(back) == vars(args)
+
+
 def test_every_c_entry_point_is_documented_for_integrators():
     """include/cnf_hip.h and INTEGRATION.md stay in step: every exported function appears in the binding table."""
     import re
