@@ -67,6 +67,7 @@ SIGNATURES = {
     "cnf_mixture_coupling_bwd_f32": [_p, _p, _p, _p, _p, _i, _i, _p, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p,
                                      _i, _i, _i, _i, _d, _d, _i, _p],
     "cnf_encoder_forward_bwd": [_p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
+    "cnf_encoder_forward_bwd_tiled": [_p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
     "cnf_affine_params_bwd": [_p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     "cnf_affine_transform_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "cnf_mixture_transform_bwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p,
@@ -78,7 +79,8 @@ _PLAIN = {"cnf_abi_version": ([], _i), "cnf_last_error": ([], ctypes.c_char_p),
           "cnf_set_tile_chunks": ([_i], None), "cnf_set_unroll": ([_i], None),
           "cnf_set_math_mode": ([_i], None), "cnf_set_inverse_mode": ([_i], None), "cnf_set_mixture_tile": ([_i], None),
           "cnf_bwd_workspace_floats": ([_i], _i64),
-          "cnf_mixture_workspace_bytes": ([_i], _i64), "cnf_encoder_workspace_floats": ([_i, _i], _i64), "cnf_set_mixture_kernel": ([_i], None),
+          "cnf_mixture_workspace_bytes": ([_i], _i64), "cnf_encoder_workspace_floats": ([_i, _i], _i64),
+          "cnf_encoder_bwd_tiled_workspace_floats": ([_i, _i, _i, _i], _i64), "cnf_set_mixture_kernel": ([_i], None),
           "cnf_set_mixture_lanes": ([_i], None), "cnf_set_mixture_split": ([_i], None),
           "cnf_prof_arm": ([_i], _i), "cnf_prof_collect": ([ctypes.POINTER(ctypes.c_float), _i], _i)}
 

@@ -264,9 +264,10 @@ class EncoderForwardFn(torch.autograd.Function):
     """class table [C,2D] -> (z, ldj, class_prob_log); categories, noise, prior and padding are constants."""
 
     @staticmethod
-    def forward(ctx, table, categ, eps, prior, pad, beta, want_class_prob):
+    def forward(ctx, table, categ, eps, prior, pad, beta, want_class_prob, tiled=None):
         z, ldj, cpl = ops.encoder_forward(categ, eps, table, prior, beta=beta, channel_padding_mask=pad,
-                                          want_class_prob=want_class_prob)
+                                          want_class_prob=want_class_prob, tiled=tiled)
+        ctx.tiled = bool(tiled)
         ctx.save_for_backward(table, categ, eps, prior, pad if isinstance(pad, torch.Tensor) else z.new_empty(0))
         ctx.has_pad, ctx.beta = isinstance(pad, torch.Tensor), float(beta)
         if cpl is None:
@@ -284,12 +285,17 @@ class EncoderForwardFn(torch.autograd.Function):
         tc, ec, pc = _f32(table, "table"), _f32(eps, "eps"), _f32(prior, "category_prior")
         p2 = _pad2d(pad, B, N, dev) if ctx.has_pad else None
         g_table = torch.empty_like(tc)
-        ws = _ws(C * 2 * D, dev)
         categ_c = categ.contiguous()
-        _launch(dev, "cnf_encoder_forward_bwd", _ptr(categ_c), _ptr(ec), _ptr(tc), _ptr(pc), _ptr(p2), ctx.beta,
+        if ctx.tiled or C * 2 * D > ops.ENCODER_BWD_LDS_ENTRIES:
+            name = "cnf_encoder_forward_bwd_tiled"       # any vocabulary size
+            ws = torch.empty(int(_lib.load().cnf_encoder_bwd_tiled_workspace_floats(B, N, D, C)), dtype=torch.float32, device=dev)
+        else:
+            name = "cnf_encoder_forward_bwd"              # table gradient accumulated in LDS
+            ws = _ws(C * 2 * D, dev)
+        _launch(dev, name, _ptr(categ_c), _ptr(ec), _ptr(tc), _ptr(pc), _ptr(p2), ctx.beta,
                                                hold(g_zout), hold(g_ldj), _ptr(g_table), _ptr(ws), B, N, D, C,
                                                float(ops.LOGISTIC_SIGMA), float(ops.LOGISTIC_LOG_SIGMA), _stream(dev))
-        return g_table, None, None, None, None, None, None
+        return g_table, None, None, None, None, None, None, None
 
 
 class AffineParamsFn(torch.autograd.Function):

@@ -62,10 +62,9 @@ class LinearCategoricalEncoding(FlowLayer):
                 and not self.flow_layers[0].make_unique and not self.use_decoder and self.D <= 16)
 
     def _kernel_path(self, needs_grad):
-        """The one-kernel encoder: always for vocabularies whose class table fits LDS; beyond that the class-tiled
-        kernels serve passes that need no gradient, and training takes the composed layer kernels (autograd through the
-        ExtActNorm kernel over the expanded [T*C, 1, D] tensor, like the reference)."""
-        return self._is_mixture_model() and (ops.encoder_fused_supported(self.num_categories, self.D) or not needs_grad)
+        """The one-kernel encoder for every mixture-model vocabulary: class table resident in LDS when it fits, the
+        class-tiled kernels (forward, decode and backward) beyond that."""
+        return self._is_mixture_model()
 
     def class_table(self):
         """[C, 2D] rows [bias | scales_raw] = pred_net(embed_layer(c)) for every class (one tiny GEMM)."""

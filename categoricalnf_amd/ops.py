@@ -575,12 +575,14 @@ def prior_nll(z, ldj, length=None, channel_padding_mask=None, sums=None,
     return neglog, nll
 
 
+ENCODER_BWD_LDS_ENTRIES = 2048      # cnf_encoder_forward_bwd keeps the [C, 2D] gradient table in LDS up to this size
+
+
 def encoder_fused_supported(C, D):
     """Whether the LDS-resident mixture-model encoder kernels (cnf_encoder_forward / cnf_encoder_decode / the backward)
     take this vocabulary: the derived class table [C, 6D+3] and the row partials must fit 64 KiB of LDS, D <= 16
     (C <= 530 at D = 4, <= 227 at D = 10).  Larger vocabularies (wikitext: 10^4 classes) run the class-tiled kernels
-    (cnf_encoder_forward_tiled / cnf_encoder_decode_tiled) when no gradient is needed, the composed layer kernels
-    otherwise."""
+    (cnf_encoder_forward_tiled / cnf_encoder_decode_tiled / cnf_encoder_forward_bwd_tiled)."""
     return D <= 16 and 4 * 512 * 4 + C * (6 * D + 3) * 4 <= 64 * 1024
 
 

@@ -452,6 +452,15 @@ int cnf_encoder_forward_bwd(const int64_t* categ, const float* eps, const float*
                             const float* category_prior, const float* pad, float beta,
                             const float* g_zout, const float* g_ldj, float* g_table, float* workspace,
                             int B, int N, int D, int C, float sigma, float log_sigma, cnf_stream_t stream);
+/* The same gradient for tables of any size (required when C * 2D > 2048, e.g. word-level vocabularies): a token-lane
+ * pass (log-denominator and d loss / d z per token in one sweep over the class chunks) and a class-lane pass (every
+ * lane owns one class and accumulates its table row over the token records), partial tables summed in a fixed order;
+ * no [T*C] tensor, no floating-point atomics.  workspace = cnf_encoder_bwd_tiled_workspace_floats(B, N, D, C) floats. */
+int64_t cnf_encoder_bwd_tiled_workspace_floats(int B, int N, int D, int C);
+int cnf_encoder_forward_bwd_tiled(const int64_t* categ, const float* eps, const float* table,
+                                  const float* category_prior, const float* pad, float beta,
+                                  const float* g_zout, const float* g_ldj, float* g_table, float* workspace,
+                                  int B, int N, int D, int C, float sigma, float log_sigma, cnf_stream_t stream);
 
 /* d(SigmoidFlow.forward) w.r.t. its input (sigmoid_layer.py:31-37). */
 int cnf_sigmoid_flow_bwd(const float* z_in, const float* g_zout, const float* g_ldj, float* g_z,
