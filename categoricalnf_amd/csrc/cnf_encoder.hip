@@ -445,13 +445,17 @@ __global__ __launch_bounds__(kBlock) void encoder_bwd_token_kernel(EncBwdTiledAr
 constexpr int kEncBwdStage = 64;     // token records staged per barrier pair
 
 template <int DT>
-__global__ __launch_bounds__(kBlock) void encoder_bwd_class_kernel(EncBwdTiledArgs b) {
+__global__ __launch_bounds__(kBlock) void encoder_bwd_class_kernel(EncBwdTiledArgs b, int cl_shift) {
+    // 256 lanes = CL class lanes x TL token lanes (CL = 2^cl_shift >= min(C, 256)): small vocabularies keep the whole
+    // workgroup busy by giving every class TL lanes that take every TL-th token record of a stage
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* stage = reinterpret_cast<float*>(smem);
     const int D = DT > 0 ? DT : b.D;
     constexpr int DM = DT > 0 ? DT : kEncMaxD;
     const int R = 3 * D + 3;
-    const int j = blockIdx.x * kBlock + threadIdx.x;
+    const int CL = 1 << cl_shift, TL = kBlock >> cl_shift;
+    const int jl = threadIdx.x & (CL - 1), tl = threadIdx.x >> cl_shift;
+    const int j = blockIdx.x * CL + jl;
     const bool live = j < b.C;
     float A[DM], Cb[DM], gb[DM], gt[DM], dts[DM];
     float cst2 = 0.f;
@@ -471,7 +475,7 @@ __global__ __launch_bounds__(kBlock) void encoder_bwd_class_kernel(EncBwdTiledAr
         }
         cst2 = ((b.prior[live ? j : 0] - ssum) - (float)D * b.log_sigma) * kLog2e;
     }
-    // token range of this split (whole stages, so that every split but the last is barrier-uniform anyway)
+    // token range of this split, in whole stages
     const long per = ((b.ntok + b.S - 1) / b.S + kEncBwdStage - 1) / kEncBwdStage * kEncBwdStage;
     const long t0 = (long)blockIdx.y * per, t1 = min(t0 + per, b.ntok);
     const float inv_sigma = 1.f / b.sigma;
@@ -481,10 +485,10 @@ __global__ __launch_bounds__(kBlock) void encoder_bwd_class_kernel(EncBwdTiledAr
         for (int i = threadIdx.x; i < nt * R; i += kBlock) stage[i] = b.rec[(size_t)ts0 * R + i];
         __syncthreads();
         if (!live) continue;
-        for (int t = 0; t < nt; ++t) {
-            const float* rec = stage + t * R;            // same address for every lane: LDS broadcast
+        for (int t = tl; t < nt; t += TL) {
+            const float* rec = stage + t * R;            // one address per token lane: LDS broadcast within it
             const int c = __float_as_int(rec[3 * D + 2]);
-            if (c == j) {                                // one lane per token across the whole grid
+            if (c == j) {                                // exactly one lane of the whole grid per token
 #pragma unroll
                 for (int d = 0; d < D; ++d) { gb[d] += rec[D + d]; gt[d] += rec[2 * D + d]; }
                 continue;
@@ -504,18 +508,38 @@ __global__ __launch_bounds__(kBlock) void encoder_bwd_class_kernel(EncBwdTiledAr
 #pragma unroll
             for (int d = 0; d < D; ++d) {
                 // d v_j / d bias = tanh / sigma;  d v_j / d ts = tanh z e^{-ts} / sigma - 1  (A ln2 = e^{-ts} / sigma)
-                const float tl = th[d] * gv;
-                gb[d] = fmaf(tl, inv_sigma, gb[d]);
-                gt[d] += fmaf(tl * kLn2, rec[d] * A[d], -gv);
+                const float tg = th[d] * gv;
+                gb[d] = fmaf(tg, inv_sigma, gb[d]);
+                gt[d] += fmaf(tg * kLn2, rec[d] * A[d], -gv);
             }
         }
     }
-    if (!live) return;
+    // combine the token lanes of a class in lane order, then through tanh to the raw scale
+    if (TL > 1) {
+        __syncthreads();
+        float* red = stage;                              // [TL][CL][2D]
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            red[((size_t)tl * CL + jl) * 2 * D + d] = gb[d];
+            red[((size_t)tl * CL + jl) * 2 * D + D + d] = gt[d];
+        }
+        __syncthreads();
+        if (tl == 0) {
+            for (int o = 1; o < TL; ++o) {
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    gb[d] += red[((size_t)o * CL + jl) * 2 * D + d];
+                    gt[d] += red[((size_t)o * CL + jl) * 2 * D + D + d];
+                }
+            }
+        }
+    }
+    if (!live || tl != 0) return;
     float* out = b.partials + ((size_t)blockIdx.y * b.C + j) * 2 * D;
 #pragma unroll
     for (int d = 0; d < D; ++d) {
         out[d] = gb[d];
-        out[D + d] = gt[d] * dts[d];                    // through tanh to the raw scale
+        out[D + d] = gt[d] * dts[d];
     }
 }
 
@@ -634,6 +658,11 @@ int cnf_encoder_decode_tiled(const float* z, const float* table, const float* ca
     return launch_status("cnf_encoder_decode_tiled");
 }
 
+static int bwd_class_shift(int C) {
+    int sh = 0;
+    while ((1 << sh) < std::min(C, kBlock)) ++sh;
+    return sh;
+}
 static int bwd_tiled_splits(long ntok, int C) {
     const int groups = (C + kBlock - 1) / kBlock;
     const long by_tokens = std::max<long>(1, ntok / 256);           // at least 256 tokens per split
@@ -663,9 +692,10 @@ int cnf_encoder_forward_bwd_tiled(const int64_t* categ, const float* eps, const 
     const size_t smem_a = (size_t)CC * (2 * D + 1) * sizeof(float);
     const int grid_a = (int)std::min<long>((b.ntok + kBlock - 1) / kBlock, 256 * 8);
     DISPATCH_D(D, CNF_LAUNCH((encoder_bwd_token_kernel<DT>), dim3(grid_a), dim3(kBlock), smem_a, st, b, CC));
-    const size_t smem_b = (size_t)kEncBwdStage * (3 * D + 3) * sizeof(float);
-    const dim3 grid_b((C + kBlock - 1) / kBlock, b.S);
-    DISPATCH_D(D, CNF_LAUNCH((encoder_bwd_class_kernel<DT>), grid_b, dim3(kBlock), smem_b, st, b));
+    const int sh = bwd_class_shift(C);
+    const size_t smem_b = std::max((size_t)kEncBwdStage * (3 * D + 3), (size_t)(sh < 8 ? kBlock * 2 * D : 0)) * sizeof(float);
+    const dim3 grid_b((C + (1 << sh) - 1) >> sh, b.S);
+    DISPATCH_D(D, CNF_LAUNCH((encoder_bwd_class_kernel<DT>), grid_b, dim3(kBlock), smem_b, st, b, sh));
     const long P = (long)C * 2 * D;
     CNF_LAUNCH(encoder_bwd_splits_kernel, dim3((unsigned)((P + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
                (const float*)b.partials, b.S, P, g_table);
