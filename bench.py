@@ -426,7 +426,7 @@ def main():
         def probe(r, cpl=cpl):
             ops._launch(dev, "cnf_stream_probe", zs[r].data_ptr(), nns[r].data_ptr(), zrs[r].data_ptr(), elems, cpl,
                         ops._stream(dev))
-        for i in range(20):
+        for i in range(300):                 # sustained stream first: short bursts run at boost clocks
             probe(i % R)
         lib.cnf_prof_arm(100)
         for i in range(100):
