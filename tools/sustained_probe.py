@@ -1,0 +1,79 @@
+"""Is the bench's dominant kernel slower inside the timed loop than in short bursts because of what runs around it, or
+because of how long the device has been busy?  Dispatch-bound durations (cnf_prof_arm) of the affine forward + NLL +
+batch-sum kernel at B=16384,N=64,D=6 on 4 rotating buffer sets, in three streams:
+  (a) bursts: 100 launches, host sync, repeat (what tools/sweep_nll.py times),
+  (b) sustained forward-only: 6000 launches back to back, every 8th timed,
+  (c) sustained alternating forward / inverse (the bench step), every 8th forward timed,
+and the stream-probe kernel (same traffic, no arithmetic) in (a)- and (b)-style streams."""
+import ctypes, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from categoricalnf_amd import _lib, ops
+dev = torch.device("cuda:0")
+lib = _lib.load()
+B, N, D, R = 16384, 64, 6, 4
+g = torch.Generator(device=dev).manual_seed(0)
+zs = [torch.randn(B, N, D, generator=g, device=dev) for _ in range(R)]
+nns = [0.5 * torch.randn(B, N, 2 * D, generator=g, device=dev) for _ in range(R)]
+sf = torch.zeros(D, device=dev); mask = torch.tensor([[1., 1., 1., 0., 0., 0.]], device=dev)
+zf = [torch.empty_like(zs[0]) for _ in range(R)]; zr = [torch.empty_like(zs[0]) for _ in range(R)]
+lf = [torch.empty(B, device=dev) for _ in range(R)]; lr = [torch.empty(B, device=dev) for _ in range(R)]
+ln = torch.full((B,), float(N), device=dev)
+neglog, nll = torch.empty(B, device=dev), torch.empty(B, device=dev)
+acc = torch.zeros(ops.NLL_ACC_SLOTS, dtype=torch.int64, device=dev)
+fwd = [ops.affine_coupling_nll_acc_launch(zs[r], nns[r], sf, mask, zf[r], lf[r], ln, neglog, nll, acc) for r in range(R)]
+inv = [ops.affine_coupling_launch(zf[r], nns[r], sf, mask, zr[r], lr[r], reverse=True) for r in range(R)]
+elems = B * N * D
+
+
+def probe(r):
+    ops._launch(dev, "cnf_stream_probe", zs[r].data_ptr(), nns[r].data_ptr(), zr[r].data_ptr(), elems, 2, ops._stream(dev))
+
+
+def collect(n):
+    buf = (ctypes.c_float * n)()
+    got = lib.cnf_prof_collect(buf, n)
+    return np.array([buf[i] for i in range(got)]) * 1e3
+
+
+def bursts(launch, rounds=20):
+    out = []
+    for _ in range(rounds):
+        for i in range(92):
+            launch(i % R)
+        lib.cnf_prof_arm(8)
+        for i in range(8):
+            launch(i % R)
+        torch.cuda.synchronize()
+        out.append(collect(8))
+    return np.concatenate(out[2:])
+
+
+def sustained(launch, between=None, n=6000, every=8):
+    out = []
+    for i in range(n):
+        if i % every == 0:
+            lib.cnf_prof_arm(1)
+        launch(i % R)
+        if between is not None:
+            between(i % R)
+    torch.cuda.synchronize()
+    out.append(collect(4096))
+    return np.concatenate(out)
+
+
+def show(name, v):
+    q = len(v) // 4
+    print("%-46s n=%4d  mean %6.2f us | first quarter %6.2f | last quarter %6.2f | min %6.2f" %
+          (name, len(v), v.mean(), v[:q].mean(), v[-q:].mean(), v.min()), flush=True)
+
+
+for i in range(300):
+    fwd[i % R]()
+torch.cuda.synchronize()
+show("(a) forward+NLL, bursts of 100", bursts(lambda r: fwd[r]()))
+show("(b) forward+NLL, sustained forward-only", sustained(lambda r: fwd[r]()))
+show("(c) forward+NLL, sustained fwd/inv alternating", sustained(lambda r: fwd[r](), between=lambda r: inv[r]()))
+show("(a) stream probe, bursts of 100", bursts(probe))
+show("(b) stream probe, sustained", sustained(probe))
+show("(c) stream probe alternating with the inverse", sustained(probe, between=lambda r: inv[r]()))
