@@ -31,7 +31,8 @@ timeout 300 python tools/sweep_mixture.py > "$OUT/sweep_mixture.log" 2>&1; tail 
 timeout 300 python tools/sweep_mixture_bwd.py > "$OUT/sweep_mixture_bwd.log" 2>&1; tail -7 "$OUT/sweep_mixture_bwd.log" | cut -c1-200
 timeout 300 python tools/bench_kernels.py > "$OUT/bench_kernels.log" 2>&1; tail -14 "$OUT/bench_kernels.log"
 timeout 300 python tools/bench_flow_graph.py > "$OUT/flow_graph.txt" 2>&1; tail -6 "$OUT/flow_graph.txt"
-timeout 200 python tools/encoder_probe.py > "$OUT/encoder_probe.txt" 2>&1; tail -3 "$OUT/encoder_probe.txt"
+timeout 400 python tools/encoder_probe.py > "$OUT/encoder_probe.txt" 2>&1; tail -7 "$OUT/encoder_probe.txt"
+timeout 200 python tools/sustained_probe.py > "$OUT/sustained_probe.txt" 2>&1; tail -6 "$OUT/sustained_probe.txt"
 bash tools/pmc_ceilings.sh ceilings > "$OUT/ceilings.log" 2>&1; tail -10 "$OUT/ceilings.log"
 bash tools/pmc_passes.sh pmc_small python tools/pmc_small_mixture.py > "$OUT/pmc_small.log" 2>&1
 bash tools/pmc_passes.sh flow_fused python tools/flow_traffic_workload.py fused > /dev/null 2>&1
