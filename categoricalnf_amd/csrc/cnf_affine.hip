@@ -170,6 +170,14 @@ __global__ __launch_bounds__(kBlock) void affine_coupling_kernel(AffineArgs a, R
         wave_lds_sync();
     };
 
+    // row scalars of the row this lane will finish, fetched now (see first_finish_row)
+    const int myrow = first_finish_row(tl);
+    float my_ldj = 0.f, my_len = (float)a.N;
+    if (myrow >= 0) {
+        if (a.ldj_in) my_ldj = a.ldj_in[myrow];
+        if (NLL && a.length) my_len = a.length[myrow];
+    }
+
     bool bad = false;
     auto load = [&](int row, int e0) {
         const size_t off = (size_t)row * a.L + e0;
@@ -213,19 +221,17 @@ __global__ __launch_bounds__(kBlock) void affine_coupling_kernel(AffineArgs a, R
             return acc;
         }
     };
-    auto ldj_of = [&](int row, float sum) {
-        const float base = a.ldj_in ? a.ldj_in[row] : 0.f;
+    auto ldj_of = [&](int row, float sum, float base) {
         const float v = REVERSE ? base - sum : base + sum;
         a.ldj_out[row] = v;
         if (isnan(v)) raise_flag(a.flags, CNF_FLAG_NAN_LDJ);
         return v;
     };
-    auto finish = [&](int row, const Acc& sum) {
+    auto emit = [&](int row, const Acc& sum, float base, float len) {
         if constexpr (NLL) {
             // task.py:96-118: nll = (-ldj + neglog) / length
-            const float ldj = ldj_of(row, sum.a);
+            const float ldj = ldj_of(row, sum.a, base);
             const float neglog = -sum.b;
-            const float len = a.length ? a.length[row] : (float)a.N;
             if (a.neglog_out) a.neglog_out[row] = neglog;
             const float nll = (-ldj) / len + neglog / len;
             a.nll_out[row] = nll;
@@ -237,8 +243,13 @@ __global__ __launch_bounds__(kBlock) void affine_coupling_kernel(AffineArgs a, R
                 atomicAdd(reinterpret_cast<unsigned long long*>(a.acc) + (size_t)(row & 63) * kAccStride,
                           (unsigned long long)__double2ll_rn((double)nll * 4294967296.0));
         } else {
-            ldj_of(row, sum);
+            ldj_of(row, sum, base);
         }
+    };
+    auto finish = [&](int row, const Acc& sum) {
+        // two separate bodies: the usual one has no load in it, so nothing waits on the z' stores still in flight
+        if (row == myrow) emit(row, sum, my_ldj, my_len);
+        else emit(row, sum, a.ldj_in ? a.ldj_in[row] : 0.f, (NLL && a.length) ? a.length[row] : (float)a.N);
     };
     walk_row_tile_split<(U == 0 ? 1 : U), Acc, AffineChunk<VEC>, U == 0>(tl, part, load, proc, finish, pre);
     if (bad) raise_flag(a.flags, CNF_FLAG_NAN_Z);

@@ -238,6 +238,21 @@ __device__ __forceinline__ void walk_row_tile_split(const RowTiling& tl, T* part
     }
 }
 
+// The row whose finish_fn this lane will run first in walk_row_tile_split (-1: none).  Kernels use it to fetch the
+// row's scalars (incoming log-det, length) at the START of the wave: loaded inside finish_fn they cost every wave one
+// more serial memory round trip at its very end, with nothing else in flight.
+__device__ __forceinline__ int first_finish_row(const RowTiling& tl) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (tl.bpr) return threadIdx.x == 0 ? (int)blockIdx.x : -1;
+    const long tile = (long)blockIdx.x * kWavesPerBlock + wave;
+    if (tile >= tl.ntiles) return -1;
+    const int row0 = (int)(tile * tl.rw);
+    if (tl.rw == 1) return lane == 0 ? row0 : -1;
+    const int g = kWave / tl.p2;
+    const int r = lane / g;
+    return ((lane & (g - 1)) == 0 && r < min(tl.rw, tl.B - row0)) ? row0 + r : -1;
+}
+
 // Single-functor form: chunk_fn(row, e0) loads, computes, stores and returns the contribution.
 template <typename T, typename ChunkFn, typename FinishFn>
 __device__ __forceinline__ void walk_row_tile(const RowTiling& tl, T* part, ChunkFn&& chunk_fn,
