@@ -89,6 +89,14 @@ __global__ __launch_bounds__(kBlock) void mixture_tok_kernel(MixArgs a, TokGeom 
         nrows = 1;
     }
     const size_t tok_g0 = (size_t)row0 * a.N + n_first;
+    // row scalars of the row this lane finishes, fetched now: loaded in `finish` they would cost every wave one more
+    // serial memory round trip at its very end (whole rows per wave; a split row is finished by one workgroup only)
+    const bool own_row = !gm.split && lane < nrows;
+    float my_ldj = 0.f, my_len = (float)a.N;
+    if (own_row) {
+        if (a.ldj_in) my_ldj = a.ldj_in[row0 + lane];
+        if (NLL && a.length) my_len = a.length[row0 + lane];
+    }
     const float* z_tile = a.z + tok_g0 * a.D;
     float* zo_tile = a.z_out + tok_g0 * a.D;
     const float* pad_tile = a.pad ? a.pad + tok_g0 : nullptr;
@@ -437,8 +445,8 @@ __global__ __launch_bounds__(kBlock) void mixture_tok_kernel(MixArgs a, TokGeom 
     }
 
     // ---- per-sample results
-    auto finish = [&](int row, double ldj_sum, double nlp_sum) {
-        float v = (a.ldj_in ? a.ldj_in[row] : 0.f) + (float)(REVERSE ? -ldj_sum : ldj_sum);
+    auto finish = [&](int row, double ldj_sum, double nlp_sum, float base, float len) {
+        float v = base + (float)(REVERSE ? -ldj_sum : ldj_sum);
         if (ED > 0) {
             // log-det of the two layers, same association as run in sequence: ActNorm uses length | sum(pad) | N,
             // the convolution length | N
@@ -460,7 +468,6 @@ __global__ __launch_bounds__(kBlock) void mixture_tok_kernel(MixArgs a, TokGeom 
         if (NLL) {
             // task.py:96-118: nll = (-ldj + neglog) / length
             const float neglog = (float)nlp_sum;
-            const float len = a.length ? a.length[row] : (float)a.N;
             if (a.neglog_out) a.neglog_out[row] = neglog;
             const float nll = (-v) / len + neglog / len;
             a.nll_out[row] = nll;
@@ -471,8 +478,9 @@ __global__ __launch_bounds__(kBlock) void mixture_tok_kernel(MixArgs a, TokGeom 
     };
     if (!gm.split) {
         wave_lds_sync();
-        if (lane < nrows)
-            finish(row0 + lane, (double)rowacc[lane * 2] * (1.0 / kFix32), (double)rowacc[lane * 2 + 1] * (1.0 / kFix32));
+        if (own_row)
+            finish(row0 + lane, (double)rowacc[lane * 2] * (1.0 / kFix32), (double)rowacc[lane * 2 + 1] * (1.0 / kFix32),
+                   my_ldj, my_len);
     } else {
         acc_ldj = wave_sum(acc_ldj);
         if (NLL) acc_nlp = wave_sum(acc_nlp);
@@ -488,7 +496,7 @@ __global__ __launch_bounds__(kBlock) void mixture_tok_kernel(MixArgs a, TokGeom 
                 t1 += wpart[w * 2 + 1];
             }
             if (gm.S == 1) {
-                finish(row0, t0, t1);
+                finish(row0, t0, t1, a.ldj_in ? a.ldj_in[row0] : 0.f, (NLL && a.length) ? a.length[row0] : (float)a.N);
             } else {
                 // fixed-point row words in the workspace: device-scope integer atomics on both sides.  The adds
                 // return (and are waited for) before the ticket is drawn, so the last arriver sees every term.
@@ -501,7 +509,8 @@ __global__ __launch_bounds__(kBlock) void mixture_tok_kernel(MixArgs a, TokGeom 
                     const long long s0 = (long long)atomicExch(wa, 0ull);
                     const long long s1 = NLL ? (long long)atomicExch(wa + 1, 0ull) : 0ll;
                     atomicExch(a.ws_cnt + row0, 0);
-                    finish(row0, (double)s0 * (1.0 / kFix32), (double)s1 * (1.0 / kFix32));
+                    finish(row0, (double)s0 * (1.0 / kFix32), (double)s1 * (1.0 / kFix32),
+                           a.ldj_in ? a.ldj_in[row0] : 0.f, (NLL && a.length) ? a.length[row0] : (float)a.N);
                 }
             }
         }
