@@ -267,7 +267,7 @@ class EncoderForwardFn(torch.autograd.Function):
     def forward(ctx, table, categ, eps, prior, pad, beta, want_class_prob, tiled=None):
         z, ldj, cpl = ops.encoder_forward(categ, eps, table, prior, beta=beta, channel_padding_mask=pad,
                                           want_class_prob=want_class_prob, tiled=tiled)
-        ctx.tiled = bool(tiled)
+        ctx.tiled = tiled
         ctx.save_for_backward(table, categ, eps, prior, pad if isinstance(pad, torch.Tensor) else z.new_empty(0))
         ctx.has_pad, ctx.beta = isinstance(pad, torch.Tensor), float(beta)
         if cpl is None:
@@ -286,8 +286,10 @@ class EncoderForwardFn(torch.autograd.Function):
         p2 = _pad2d(pad, B, N, dev) if ctx.has_pad else None
         g_table = torch.empty_like(tc)
         categ_c = categ.contiguous()
-        if ctx.tiled or C * 2 * D > ops.ENCODER_BWD_LDS_ENTRIES:
-            name = "cnf_encoder_forward_bwd_tiled"       # any vocabulary size
+        if ctx.tiled is not False or C * 2 * D > ops.ENCODER_BWD_LDS_ENTRIES:
+            # token-lane + class-lane passes: any vocabulary size, bit-reproducible, 4-12x faster than the LDS-table
+            # kernel at 16-160 classes (profiles/r02_encoder_probe.txt); `tiled=False` keeps the latter for A/B tests
+            name = "cnf_encoder_forward_bwd_tiled"
             ws = torch.empty(int(_lib.load().cnf_encoder_bwd_tiled_workspace_floats(B, N, D, C)), dtype=torch.float32, device=dev)
         else:
             name = "cnf_encoder_forward_bwd"              # table gradient accumulated in LDS

@@ -46,8 +46,9 @@ def bwd_time(categ, eps, table, prior, tiled):
     return steady(step, reps=10)
 
 
-print("\nB*N tokens x C classes, D=6: forward / decode / forward+backward, us (LDS-resident | class-tiled)")
-for T_B, T_N, C in ((16384, 64, 16), (16384, 64, 51), (2048, 64, 160), (512, 64, 2000), (128, 64, 10000), (128, 288, 10000)):
+print("\nB*N tokens x C classes, D=6: forward / decode / forward+backward, us (LDS-resident | default: forward by size, tiled backward | class-tiled)")
+for T_B, T_N, C in ((16384, 64, 16), (16384, 64, 51), (4096, 64, 32), (4096, 64, 64), (4096, 64, 96), (4096, 64, 128), (2048, 64, 160),
+                    (512, 64, 2000), (128, 64, 10000), (128, 288, 10000)):
     g = torch.Generator(device=dev).manual_seed(1)
     categ = torch.randint(0, C, (T_B, T_N), generator=g, device=dev)
     table = 0.5 * torch.randn(C, 2 * D, generator=g, device=dev)
@@ -55,10 +56,10 @@ for T_B, T_N, C in ((16384, 64, 16), (16384, 64, 51), (2048, 64, 160), (512, 64,
     eps = ops.logistic_from_uniform(torch.rand(T_B * T_N, D, generator=g, device=dev))
     z, _, _ = ops.encoder_forward(categ, eps, table, prior)
     row = []
-    for tiled in ((None, True) if ops.encoder_fused_supported(C, D) else (True,)):
+    for tiled in ((False, None, True) if ops.encoder_fused_supported(C, D) else (True,)):
         f = steady(lambda: ops.encoder_forward(categ, eps, table, prior, tiled=tiled), reps=10)
         d = steady(lambda: ops.encoder_decode(z, table, prior, tiled=tiled), reps=10)
-        if tiled is None and C * 2 * D > ops.ENCODER_BWD_LDS_ENTRIES:
+        if tiled is False and C * 2 * D > ops.ENCODER_BWD_LDS_ENTRIES:
             fb = float("nan")
         else:
             fb = bwd_time(categ, eps, table, prior, tiled)
