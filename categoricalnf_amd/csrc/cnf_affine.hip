@@ -262,7 +262,7 @@ static void launch_affine_u(const AffineArgs& a, const RowTiling& tl, bool has_s
     const size_t strip = (tl.bpr || tl.rw == 1) ? 0 : (size_t)tl.rw * tl.cpr;      // partials per wave
     if (a.nll_out) {   // forward + NLL epilogue
         const size_t lds = kWavesPerBlock * strip * sizeof(Sum2);
-        constexpr int UN = (U == 0) ? 0 : ((U == 1) ? 1 : ((U == 3) ? 3 : 2));   // prefetch, 1, 2 or 3 chunks in flight
+        constexpr int UN = (U == 1) ? 1 : 2;      // the epilogue variants are built for 1 and 2 chunks in flight only (prefetch and 3 measured: no gain)
         if (a.pad) {
             if (has_sf) CNF_LAUNCH((affine_coupling_kernel<VEC, UN, true, false, FAST, 2>), grid, block, lds, st, a, tl);
             else CNF_LAUNCH((affine_coupling_kernel<VEC, UN, false, false, FAST, 2>), grid, block, lds, st, a, tl);

@@ -543,13 +543,30 @@ __global__ __launch_bounds__(kBlock) void encoder_bwd_class_kernel(EncBwdTiledAr
     }
 }
 
-// g_table[p] = sum over splits in split order (fp64, one lane per entry, coalesced over p)
+// g_table[p] = sum over the splits, fixed order: a workgroup owns 16 table entries, 16 lanes per entry each add every
+// 16th split (fp64), then the 16 lane sums are combined in lane order.  (One lane per entry walking all S splits was
+// a chain of S dependent-latency loads: 380 us of the 430 us backward at S = 1024.)
 __global__ __launch_bounds__(kBlock) void encoder_bwd_splits_kernel(const float* partials, int S, long P, float* out) {
-    const long p = (long)blockIdx.x * kBlock + threadIdx.x;
-    if (p >= P) return;
+    __shared__ double red[16][17];
+    const int pl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const long p = (long)blockIdx.x * 16 + pl;
     double acc = 0.0;
-    for (int s = 0; s < S; ++s) acc += (double)partials[(size_t)s * P + p];
-    out[p] = (float)acc;
+    if (p < P) {
+        int s = sl;
+        for (; s + 48 < S; s += 64) {                   // four independent loads in flight per lane
+            const float v0 = partials[(size_t)s * P + p], v1 = partials[(size_t)(s + 16) * P + p];
+            const float v2 = partials[(size_t)(s + 32) * P + p], v3 = partials[(size_t)(s + 48) * P + p];
+            acc += (double)v0; acc += (double)v1; acc += (double)v2; acc += (double)v3;
+        }
+        for (; s < S; s += 16) acc += (double)partials[(size_t)s * P + p];
+    }
+    red[sl][pl] = acc;
+    __syncthreads();
+    if (sl == 0 && p < P) {
+        double t = 0.0;
+        for (int k = 0; k < 16; ++k) t += red[k][pl];
+        out[p] = (float)t;
+    }
 }
 
 }  // namespace cnf
@@ -697,7 +714,7 @@ int cnf_encoder_forward_bwd_tiled(const int64_t* categ, const float* eps, const 
     const dim3 grid_b((C + (1 << sh) - 1) >> sh, b.S);
     DISPATCH_D(D, CNF_LAUNCH((encoder_bwd_class_kernel<DT>), grid_b, dim3(kBlock), smem_b, st, b, sh));
     const long P = (long)C * 2 * D;
-    CNF_LAUNCH(encoder_bwd_splits_kernel, dim3((unsigned)((P + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
+    CNF_LAUNCH(encoder_bwd_splits_kernel, dim3((unsigned)((P + 15) / 16)), dim3(kBlock), 0, st,
                (const float*)b.partials, b.S, P, g_table);
     return launch_status("cnf_encoder_forward_bwd_tiled");
 }

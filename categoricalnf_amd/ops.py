@@ -586,9 +586,16 @@ def encoder_fused_supported(C, D):
     return D <= 16 and 4 * 512 * 4 + C * (6 * D + 3) * 4 <= 64 * 1024
 
 
+def encoder_prefers_tiled_forward(C, D):
+    """Forward pass: the class-tiled kernel when the LDS-resident table would not fit or would exceed ~10 KB (64 classes
+    at D = 6) — from there on the tiled kernel is faster (32.9 vs 36.2 us at 64 classes, 40.7 vs 77.9 at 160;
+    profiles/r02_encoder_probe.txt).  Decode keeps the LDS table whenever it fits (equal or slightly faster)."""
+    return not encoder_fused_supported(C, D) or C * (6 * D + 3) * 4 >= 10000
+
+
 def encoder_forward(categ, eps, table, category_prior, beta=1.0, channel_padding_mask=None, ldj=None,
                     want_class_prob=False, sigma=LOGISTIC_SIGMA, log_sigma=LOGISTIC_LOG_SIGMA, tiled=None):
-    """`tiled`: None = by vocabulary size; True forces the class-tiled kernel (tests)."""
+    """`tiled`: None = by vocabulary size; True / False force the class-tiled / the LDS-resident kernel (tests)."""
     dev = _dev(categ)
     if categ.dtype != torch.int64:
         categ = categ.long()
@@ -604,7 +611,9 @@ def encoder_forward(categ, eps, table, category_prior, beta=1.0, channel_padding
     ldj_in, ldj_out = _ldj_io(ldj, B, dev, inplace=False)
     z = torch.empty(B, N, D, dtype=torch.float32, device=dev)
     cpl = torch.empty(B * N, dtype=torch.float32, device=dev) if want_class_prob else None
-    if encoder_fused_supported(C, D) and not tiled:
+    if tiled is None:
+        tiled = encoder_prefers_tiled_forward(C, D)
+    if not tiled:
         _launch(dev, "cnf_encoder_forward", _ptr(categ), _ptr(eps), _ptr(table), _ptr(prior), _ptr(pad), float(beta),
                                            _ptr(ldj_in), _ptr(z), _ptr(ldj_out), _ptr(cpl), B, N, D, C, float(sigma),
                                            float(log_sigma), _ptr(flag_word(dev)), _stream(dev))

@@ -15,7 +15,7 @@ ln = torch.full((B,), float(N), device=dev)
 neglog, nll = torch.empty(B, device=dev), torch.empty(B, device=dev)
 acc = torch.zeros(ops.NLL_ACC_SLOTS, dtype=torch.int64, device=dev)
 k = [ops.affine_coupling_nll_acc_launch(zs[r], nns[r], sf, mask, zo[r], lo[r], ln, neglog, nll, acc) for r in range(R)]
-cfgs = list(itertools.product([128, 192, 256, 384, 512, 768], [0, 1, 2, 3]))
+cfgs = list(itertools.product([64, 96, 128, 192, 256, 384, 512], [1, 2]))
 res = {c: [] for c in cfgs}
 for _ in range(300):
     k[0]()
