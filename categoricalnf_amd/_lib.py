@@ -53,7 +53,7 @@ SIGNATURES = {
     "cnf_encoder_forward": [_p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p, _p],
     "cnf_encoder_decode": [_p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
     "cnf_encoder_forward_tiled": [_p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p, _p],
-    "cnf_encoder_decode_tiled": [_p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
+    "cnf_encoder_decode_tiled": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
     "cnf_sigmoid_flow": [_p, _p, _p, _p, _i, _i, _i, _f, _p, _p],
     "cnf_affine_coupling_bwd": [_p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "cnf_ext_actnorm_bwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
@@ -79,7 +79,7 @@ _PLAIN = {"cnf_abi_version": ([], _i), "cnf_last_error": ([], ctypes.c_char_p),
           "cnf_set_tile_chunks": ([_i], None), "cnf_set_unroll": ([_i], None),
           "cnf_set_math_mode": ([_i], None), "cnf_set_inverse_mode": ([_i], None), "cnf_set_mixture_tile": ([_i], None),
           "cnf_bwd_workspace_floats": ([_i], _i64),
-          "cnf_mixture_workspace_bytes": ([_i], _i64), "cnf_encoder_workspace_floats": ([_i, _i], _i64),
+          "cnf_mixture_workspace_bytes": ([_i], _i64), "cnf_encoder_workspace_floats": ([_i, _i, _i, _i], _i64),
           "cnf_encoder_bwd_tiled_workspace_floats": ([_i, _i, _i, _i], _i64), "cnf_set_mixture_kernel": ([_i], None),
           "cnf_set_mixture_lanes": ([_i], None), "cnf_set_mixture_split": ([_i], None),
           "cnf_prof_arm": ([_i], _i), "cnf_prof_collect": ([ctypes.POINTER(ctypes.c_float), _i], _i)}

@@ -222,13 +222,21 @@ __device__ __forceinline__ float chunk_score2(const float* t, const float* z, in
     return t[2 * D] - fmaf(2.f, __builtin_amdgcn_logf(prod), acc);
 }
 
-template <int DT, bool DECODE>
-__global__ __launch_bounds__(kBlock) void encoder_tiled_kernel(EncArgs a, long ntok, int CC, float* tok_ldj) {
+// PHASE 0: the whole class range and the epilogue in one kernel.  Very large vocabularies with moderate token counts
+// (10^4 classes x 10^4..10^5 tokens: 40-400 token workgroups) would leave most of the chip idle, so the class range is
+// also split over blockIdx.y: PHASE 1 sweeps one split and writes the token's partial (max, sum) / (best, arg-max) to
+// part[split][tok]; PHASE 2 (token lanes again, no class sweep) merges the partials in split order and runs the
+// epilogue.  The number of splits depends on C only, so a sample's result does not depend on the batch it is in.
+template <int DT, bool DECODE, int PHASE>
+__global__ __launch_bounds__(kBlock) void encoder_tiled_kernel(EncArgs a, long ntok, int CC, float* tok_ldj, float* part, int KS) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* tab = reinterpret_cast<float*>(smem);
     const int D = DT > 0 ? DT : a.D;
     const int stride = 2 * D + 1;
     bool bad = false;
+    const int per = (a.C + KS - 1) / KS;
+    const int j_lo = PHASE == 1 ? (int)blockIdx.y * per : 0;
+    const int j_hi = PHASE == 1 ? min(a.C, j_lo + per) : a.C;
     const long rounds = (ntok + kBlock - 1) / kBlock;
     for (long r = blockIdx.x; r < rounds; r += gridDim.x) {             // block-uniform: barriers inside are safe
         const long tok = r * kBlock + threadIdx.x;
@@ -264,27 +272,51 @@ __global__ __launch_bounds__(kBlock) void encoder_tiled_kernel(EncArgs a, long n
         }
         float m = -3e38f, ssum = 0.f, best = -INFINITY;
         int arg = 0;
-        for (int j0 = 0; j0 < a.C; j0 += CC) {
-            const int cc = min(CC, a.C - j0);
-            __syncthreads();                                   // the previous chunk has been read by everyone
-            build_class_chunk(a, tab, j0, cc, D);
-            __syncthreads();
-            for (int jj = 0; jj < cc; ++jj) {
-                const float sc = chunk_score2<DT>(tab + jj * stride, z, D);
+        if (PHASE != 2) {
+            bool first = true;
+            for (int j0 = j_lo; j0 < j_hi; j0 += CC) {
+                const int cc = min(CC, j_hi - j0);
+                __syncthreads();                               // the previous chunk has been read by everyone
+                build_class_chunk(a, tab, j0, cc, D);
+                __syncthreads();
+                for (int jj = 0; jj < cc; ++jj) {
+                    const float sc = chunk_score2<DT>(tab + jj * stride, z, D);
+                    if (DECODE) {
+                        if (first || sc > best) {               // first maximum wins, like torch.argmax
+                            best = sc;
+                            arg = j0 + jj;
+                            first = false;
+                        }
+                    } else {
+                        const float v = (j0 + jj) == c ? lp2 : sc;  // the true class takes the forward value (:167-168)
+                        const float mn = fmaxf(m, v);
+                        ssum = fmaf(ssum, __builtin_amdgcn_exp2f(m - mn), __builtin_amdgcn_exp2f(v - mn));
+                        m = mn;
+                    }
+                }
+            }
+        } else if (live) {
+            for (int k = 0; k < KS; ++k) {                     // split order: deterministic, ties go to the lower class
+                const float p0 = part[((size_t)k * ntok + tok) * 2], p1 = part[((size_t)k * ntok + tok) * 2 + 1];
                 if (DECODE) {
-                    if ((j0 + jj == 0) || sc > best) {          // first maximum wins, like torch.argmax
-                        best = sc;
-                        arg = j0 + jj;
+                    if (k == 0 || p0 > best) {
+                        best = p0;
+                        arg = __float_as_int(p1);
                     }
                 } else {
-                    const float v = (j0 + jj) == c ? lp2 : sc;  // the true class takes the forward value (:167-168)
-                    const float mn = fmaxf(m, v);
-                    ssum = fmaf(ssum, __builtin_amdgcn_exp2f(m - mn), __builtin_amdgcn_exp2f(v - mn));
+                    const float mn = fmaxf(m, p0);
+                    ssum = fmaf(ssum, __builtin_amdgcn_exp2f(m - mn), p1 * __builtin_amdgcn_exp2f(p0 - mn));
                     m = mn;
                 }
             }
         }
         if (!live) continue;
+        if (PHASE == 1) {
+            float* o = part + ((size_t)blockIdx.y * ntok + tok) * 2;
+            o[0] = DECODE ? best : m;
+            o[1] = DECODE ? __int_as_float(arg) : ssum;
+            continue;
+        }
         if (DECODE) {
             a.categ_out[tok] = (int64_t)arg;
         } else {
@@ -352,8 +384,8 @@ struct EncBwdTiledArgs {
     float beta, sigma, log_sigma;
 };
 
-template <int DT>
-__global__ __launch_bounds__(kBlock) void encoder_bwd_token_kernel(EncBwdTiledArgs b, int CC) {
+template <int DT, int PHASE>      // PHASE as in encoder_tiled_kernel; a partial is (max, sum, D accumulators)
+__global__ __launch_bounds__(kBlock) void encoder_bwd_token_kernel(EncBwdTiledArgs b, int CC, float* part, int KS) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* tab = reinterpret_cast<float*>(smem);
     const int D = DT > 0 ? DT : b.D;
@@ -361,6 +393,10 @@ __global__ __launch_bounds__(kBlock) void encoder_bwd_token_kernel(EncBwdTiledAr
     const int stride = 2 * D + 1, R = 3 * D + 3;
     EncArgs a = {};
     a.table = b.table; a.prior = b.prior; a.D = D; a.C = b.C; a.sigma = b.sigma; a.log_sigma = b.log_sigma;
+    const int per = (b.C + KS - 1) / KS;
+    const int j_lo = PHASE == 1 ? (int)blockIdx.y * per : 0;
+    const int j_hi = PHASE == 1 ? min(b.C, j_lo + per) : b.C;
+    const int PS = 2 + D;
     const long rounds = (b.ntok + kBlock - 1) / kBlock;
     for (long r = blockIdx.x; r < rounds; r += gridDim.x) {
         const long tok = r * kBlock + threadIdx.x;
@@ -393,35 +429,55 @@ __global__ __launch_bounds__(kBlock) void encoder_bwd_token_kernel(EncBwdTiledAr
             G = (b.g_ldj ? b.g_ldj[tok / b.N] : 0.f) * pv;
         }
         float m = -3e38f, ssum = 0.f;
-        for (int j0 = 0; j0 < b.C; j0 += CC) {
-            const int cc = min(CC, b.C - j0);
-            __syncthreads();
-            build_class_chunk(a, tab, j0, cc, D);
-            __syncthreads();
-            for (int jj = 0; jj < cc; ++jj) {
-                const float* t = tab + jj * stride;
-                float acc = 0.f, prod = 1.f, ta[DM];
+        if (PHASE != 2) {
+            for (int j0 = j_lo; j0 < j_hi; j0 += CC) {
+                const int cc = min(CC, j_hi - j0);
+                __syncthreads();
+                build_class_chunk(a, tab, j0, cc, D);
+                __syncthreads();
+                for (int jj = 0; jj < cc; ++jj) {
+                    const float* t = tab + jj * stride;
+                    float acc = 0.f, prod = 1.f, ta[DM];
 #pragma unroll
-                for (int d = 0; d < D; ++d) {
-                    const float xk = fmaf(z[d], t[2 * d], -t[2 * d + 1]);
-                    const float vs = fabsf(xk);
-                    const float e = __builtin_amdgcn_exp2f(-vs);
-                    acc += vs;
-                    prod = fmaf(prod, e, prod);
-                    // tanh(x / 2 sigma) A = sign(x) (1 - e) / (1 + e) A
-                    ta[d] = copysignf((1.f - e) * __builtin_amdgcn_rcpf(1.f + e), xk) * t[2 * d];
+                    for (int d = 0; d < D; ++d) {
+                        const float xk = fmaf(z[d], t[2 * d], -t[2 * d + 1]);
+                        const float vs = fabsf(xk);
+                        const float e = __builtin_amdgcn_exp2f(-vs);
+                        acc += vs;
+                        prod = fmaf(prod, e, prod);
+                        // tanh(x / 2 sigma) A = sign(x) (1 - e) / (1 + e) A
+                        ta[d] = copysignf((1.f - e) * __builtin_amdgcn_rcpf(1.f + e), xk) * t[2 * d];
+                    }
+                    const bool own = (j0 + jj) == c;
+                    const float v = own ? lp2 : t[2 * D] - fmaf(2.f, __builtin_amdgcn_logf(prod), acc);
+                    const float mn = fmaxf(m, v);
+                    const float scale = __builtin_amdgcn_exp2f(m - mn), w = __builtin_amdgcn_exp2f(v - mn);
+                    ssum = fmaf(ssum, scale, w);
+                    const float wg = own ? 0.f : w;
+#pragma unroll
+                    for (int d = 0; d < D; ++d) acc_g[d] = fmaf(acc_g[d], scale, wg * ta[d]);
+                    m = mn;
                 }
-                const bool own = (j0 + jj) == c;
-                const float v = own ? lp2 : t[2 * D] - fmaf(2.f, __builtin_amdgcn_logf(prod), acc);
-                const float mn = fmaxf(m, v);
-                const float scale = __builtin_amdgcn_exp2f(m - mn), w = __builtin_amdgcn_exp2f(v - mn);
-                ssum = fmaf(ssum, scale, w);
-                const float wg = own ? 0.f : w;
+            }
+        } else if (live) {
+            for (int k = 0; k < KS; ++k) {
+                const float* pk = part + ((size_t)k * b.ntok + tok) * PS;
+                const float mn = fmaxf(m, pk[0]);
+                const float scale = __builtin_amdgcn_exp2f(m - mn), w = __builtin_amdgcn_exp2f(pk[0] - mn);
+                ssum = fmaf(ssum, scale, pk[1] * w);
 #pragma unroll
-                for (int d = 0; d < D; ++d) acc_g[d] = fmaf(acc_g[d], scale, wg * ta[d]);
+                for (int d = 0; d < D; ++d) acc_g[d] = fmaf(acc_g[d], scale, pk[2 + d] * w);
                 m = mn;
             }
         }
+        if (live && PHASE == 1) {
+            float* o = part + ((size_t)blockIdx.y * b.ntok + tok) * PS;
+            o[0] = m;
+            o[1] = ssum;
+#pragma unroll
+            for (int d = 0; d < D; ++d) o[2 + d] = acc_g[d];
+        }
+        if (PHASE == 1) continue;
         if (!live) continue;
         const float lse2 = m + __builtin_amdgcn_logf(ssum);
         const float Gb = G * b.beta;
@@ -631,7 +687,19 @@ int cnf_encoder_decode(const float* z, const float* table, const float* category
 
 static int tiled_chunk_classes(int D) { return std::max(1, (int)(32768 / ((2 * D + 1) * sizeof(float)))); }
 
-int64_t cnf_encoder_workspace_floats(int B, int N) { return (int64_t)B * N; }
+// class splits of the token-lane kernels: a function of C only (see encoder_tiled_kernel), no empty split
+static int tiled_class_splits(int C) {
+    if (C <= 1024) return 1;
+    const int ks = std::min(32, (C + 511) / 512);
+    const int per = (C + ks - 1) / ks;
+    return (C + per - 1) / per;
+}
+
+int64_t cnf_encoder_workspace_floats(int B, int N, int D, int C) {
+    (void)D;
+    const int ks = tiled_class_splits(C);
+    return (int64_t)B * N * (1 + (ks > 1 ? 2 * ks : 0));
+}
 
 int cnf_encoder_forward_tiled(const int64_t* categ, const float* eps, const float* table,
                               const float* category_prior, const float* pad, float beta,
@@ -651,16 +719,27 @@ int cnf_encoder_forward_tiled(const int64_t* categ, const float* eps, const floa
     const size_t smem = (size_t)CC * (2 * D + 1) * sizeof(float);
     const int grid = (int)std::min<long>((ntok + kBlock - 1) / kBlock, 256 * 8);
     hipStream_t st = (hipStream_t)stream;
-    DISPATCH_D(D, CNF_LAUNCH((encoder_tiled_kernel<DT, false>), dim3(grid), dim3(kBlock), smem, st, a, ntok, CC, workspace));
+    const int KS = tiled_class_splits(C);
+    float* part = workspace + ntok;
+    if (KS == 1) {
+        DISPATCH_D(D, CNF_LAUNCH((encoder_tiled_kernel<DT, false, 0>), dim3(grid), dim3(kBlock), smem, st, a, ntok, CC, workspace,
+                                 (float*)nullptr, 1));
+    } else {
+        DISPATCH_D(D, CNF_LAUNCH((encoder_tiled_kernel<DT, false, 1>), dim3(grid, KS), dim3(kBlock), smem, st, a, ntok, CC, workspace,
+                                 part, KS));
+        DISPATCH_D(D, CNF_LAUNCH((encoder_tiled_kernel<DT, false, 2>), dim3(grid), dim3(kBlock), 0, st, a, ntok, CC, workspace,
+                                 part, KS));
+    }
     CNF_LAUNCH(encoder_row_sum_kernel, dim3((B + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kBlock), 0, st,
                (const float*)workspace, ldj_in, ldj_out, B, N, flags);
     return launch_status("cnf_encoder_forward_tiled");
 }
 
 int cnf_encoder_decode_tiled(const float* z, const float* table, const float* category_prior,
-                             int64_t* categ_out, int B, int N, int D, int C, float sigma, float log_sigma,
+                             int64_t* categ_out, float* workspace, int B, int N, int D, int C, float sigma, float log_sigma,
                              cnf_stream_t stream) {
     CNF_REQUIRE(z && table && category_prior && categ_out, "cnf_encoder_decode_tiled: null tensor");
+    CNF_REQUIRE(workspace || tiled_class_splits(C) == 1, "cnf_encoder_decode_tiled: this vocabulary needs the workspace");
     CNF_REQUIRE(B >= 0 && N > 0 && D > 0 && C > 0 && D <= kEncMaxD, "cnf_encoder_decode_tiled: bad shape");
     if (B == 0) return CNF_OK;
     EncArgs a = {};
@@ -670,8 +749,18 @@ int cnf_encoder_decode_tiled(const float* z, const float* table, const float* ca
     const int CC = std::min(C, tiled_chunk_classes(D));
     const size_t smem = (size_t)CC * (2 * D + 1) * sizeof(float);
     const int grid = (int)std::min<long>((ntok + kBlock - 1) / kBlock, 256 * 8);
-    DISPATCH_D(D, CNF_LAUNCH((encoder_tiled_kernel<DT, true>), dim3(grid), dim3(kBlock), smem, (hipStream_t)stream, a, ntok, CC,
-                             (float*)nullptr));
+    hipStream_t st = (hipStream_t)stream;
+    const int KS = tiled_class_splits(C);
+    float* part = workspace ? workspace + ntok : nullptr;
+    if (KS == 1) {
+        DISPATCH_D(D, CNF_LAUNCH((encoder_tiled_kernel<DT, true, 0>), dim3(grid), dim3(kBlock), smem, st, a, ntok, CC,
+                                 (float*)nullptr, (float*)nullptr, 1));
+    } else {
+        DISPATCH_D(D, CNF_LAUNCH((encoder_tiled_kernel<DT, true, 1>), dim3(grid, KS), dim3(kBlock), smem, st, a, ntok, CC,
+                                 (float*)nullptr, part, KS));
+        DISPATCH_D(D, CNF_LAUNCH((encoder_tiled_kernel<DT, true, 2>), dim3(grid), dim3(kBlock), 0, st, a, ntok, CC,
+                                 (float*)nullptr, part, KS));
+    }
     return launch_status("cnf_encoder_decode_tiled");
 }
 
@@ -688,7 +777,8 @@ static int bwd_tiled_splits(long ntok, int C) {
 
 int64_t cnf_encoder_bwd_tiled_workspace_floats(int B, int N, int D, int C) {
     const long ntok = (long)B * N;
-    return (int64_t)ntok * (3 * D + 3) + (int64_t)bwd_tiled_splits(ntok, C) * C * 2 * D;
+    const int ks = tiled_class_splits(C);
+    return (int64_t)ntok * (3 * D + 3) + (int64_t)bwd_tiled_splits(ntok, C) * C * 2 * D + (ks > 1 ? (int64_t)ks * ntok * (2 + D) : 0);
 }
 
 int cnf_encoder_forward_bwd_tiled(const int64_t* categ, const float* eps, const float* table,
@@ -708,7 +798,14 @@ int cnf_encoder_forward_bwd_tiled(const int64_t* categ, const float* eps, const 
     const int CC = std::min(C, tiled_chunk_classes(D));
     const size_t smem_a = (size_t)CC * (2 * D + 1) * sizeof(float);
     const int grid_a = (int)std::min<long>((b.ntok + kBlock - 1) / kBlock, 256 * 8);
-    DISPATCH_D(D, CNF_LAUNCH((encoder_bwd_token_kernel<DT>), dim3(grid_a), dim3(kBlock), smem_a, st, b, CC));
+    const int KS = tiled_class_splits(C);
+    float* part = b.partials + (size_t)b.S * C * 2 * D;
+    if (KS == 1) {
+        DISPATCH_D(D, CNF_LAUNCH((encoder_bwd_token_kernel<DT, 0>), dim3(grid_a), dim3(kBlock), smem_a, st, b, CC, (float*)nullptr, 1));
+    } else {
+        DISPATCH_D(D, CNF_LAUNCH((encoder_bwd_token_kernel<DT, 1>), dim3(grid_a, KS), dim3(kBlock), smem_a, st, b, CC, part, KS));
+        DISPATCH_D(D, CNF_LAUNCH((encoder_bwd_token_kernel<DT, 2>), dim3(grid_a), dim3(kBlock), 0, st, b, CC, part, KS));
+    }
     const int sh = bwd_class_shift(C);
     const size_t smem_b = std::max((size_t)kEncBwdStage * (3 * D + 3), (size_t)(sh < 8 ? kBlock * 2 * D : 0)) * sizeof(float);
     const dim3 grid_b((C + (1 << sh) - 1) >> sh, b.S);

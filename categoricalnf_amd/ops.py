@@ -618,7 +618,8 @@ def encoder_forward(categ, eps, table, category_prior, beta=1.0, channel_padding
                                            _ptr(ldj_in), _ptr(z), _ptr(ldj_out), _ptr(cpl), B, N, D, C, float(sigma),
                                            float(log_sigma), _ptr(flag_word(dev)), _stream(dev))
     else:
-        ws = torch.empty(B * N, dtype=torch.float32, device=dev)          # token log-det terms
+        # token log-det terms (+ the per-split partials above 1024 classes)
+        ws = torch.empty(int(_lib.load().cnf_encoder_workspace_floats(B, N, D, C)), dtype=torch.float32, device=dev)
         _launch(dev, "cnf_encoder_forward_tiled", _ptr(categ), _ptr(eps), _ptr(table), _ptr(prior), _ptr(pad), float(beta),
                                                  _ptr(ldj_in), _ptr(z), _ptr(ldj_out), _ptr(cpl), _ptr(ws), B, N, D, C,
                                                  float(sigma), float(log_sigma), _ptr(flag_word(dev)), _stream(dev))
@@ -634,8 +635,13 @@ def encoder_decode(z, table, category_prior, sigma=LOGISTIC_SIGMA, log_sigma=LOG
     C = table.shape[0]
     prior = _f32(category_prior, "category_prior")
     out = torch.empty(B, N, dtype=torch.int64, device=dev)
-    name = "cnf_encoder_decode" if (encoder_fused_supported(C, D) and not tiled) else "cnf_encoder_decode_tiled"
-    _launch(dev, name, _ptr(z), _ptr(table), _ptr(prior), _ptr(out), B, N, D, C, float(sigma), float(log_sigma), _stream(dev))
+    if encoder_fused_supported(C, D) and not tiled:
+        _launch(dev, "cnf_encoder_decode", _ptr(z), _ptr(table), _ptr(prior), _ptr(out), B, N, D, C, float(sigma),
+                                          float(log_sigma), _stream(dev))
+    else:
+        ws = torch.empty(int(_lib.load().cnf_encoder_workspace_floats(B, N, D, C)), dtype=torch.float32, device=dev)
+        _launch(dev, "cnf_encoder_decode_tiled", _ptr(z), _ptr(table), _ptr(prior), _ptr(out), _ptr(ws), B, N, D, C,
+                                                float(sigma), float(log_sigma), _stream(dev))
     return out
 
 

@@ -328,9 +328,12 @@ int cnf_encoder_decode(const float* z, const float* table, const float* category
 /* The same two for vocabularies whose class table does not fit LDS (wikitext: 10^4 classes): the classes are walked
  * in chunks whose score constants a workgroup rebuilds in LDS, the streamed log-sum-exp / arg-max runs across chunks,
  * and nothing of size [T*C, ...] is materialised (linear_encoding.py:155-160 expands to [T*C, 1, D]).  Same results as
- * cnf_encoder_forward / cnf_encoder_decode.  workspace: cnf_encoder_workspace_floats(B, N) floats (token log-det terms;
- * a second kernel sums the rows in a fixed order). */
-int64_t cnf_encoder_workspace_floats(int B, int N);
+ * cnf_encoder_forward / cnf_encoder_decode.  Beyond 1024 classes the class range is also split over workgroups (up to 32
+ * splits, a function of C only, so a sample's result does not depend on its batch): a second launch merges the per-split
+ * (max, sum) / (best, arg-max) pairs in split order.  workspace: cnf_encoder_workspace_floats(B, N, D, C) floats (token
+ * log-det terms, which a small kernel sums per row in a fixed order, and the split partials); decode needs it only
+ * above 1024 classes (else it may be null). */
+int64_t cnf_encoder_workspace_floats(int B, int N, int D, int C);
 int cnf_encoder_forward_tiled(const int64_t* categ, const float* eps, const float* table,
                               const float* category_prior, const float* pad, float beta,
                               const float* ldj_in, float* z_out, float* ldj_out, float* class_prob_log,
@@ -338,7 +341,7 @@ int cnf_encoder_forward_tiled(const int64_t* categ, const float* eps, const floa
                               int B, int N, int D, int C, float sigma, float log_sigma,
                               int* flags, cnf_stream_t stream);
 int cnf_encoder_decode_tiled(const float* z, const float* table, const float* category_prior,
-                             int64_t* categ_out, int B, int N, int D, int C, float sigma, float log_sigma,
+                             int64_t* categ_out, float* workspace, int B, int N, int D, int C, float sigma, float log_sigma,
                              cnf_stream_t stream);
 
 /* ---- sigmoid / logit flow ------------------------------------------------------------------- */

@@ -1423,3 +1423,18 @@ def test_large_vocabulary_encoder_trains_on_the_tiled_kernels():
     close(z, zc, **ELEM); loglik_close(ldj, ldjc)
     for n, p in enc.named_parameters():
         close(got[n], p.grad, rtol=3e-3, atol=3e-4 * max(float(p.grad.abs().max()), 1.0))
+
+
+def test_class_split_encoder_results_do_not_depend_on_the_batch():
+    """Above 1024 classes the class range is split over workgroups; the number of splits is a function of C only, so
+    a sample's latents, log-det, decoded class and table gradient contribution are the same whatever batch it sits in."""
+    B, N, D, C = 12, 19, 4, 2500
+    cat, table, prior, eps, pad, _, _ = _encoder_grad_inputs(B, N, D, C, seed=77)
+    z, ldj, cpl = ops().encoder_forward(g(cat), g(eps), g(table), g(prior), channel_padding_mask=g(pad), want_class_prob=True)
+    h = 5
+    zh, ldjh, cplh = ops().encoder_forward(g(cat[:h]), g(eps[:h * N]), g(table), g(prior), channel_padding_mask=g(pad[:h]),
+                                           want_class_prob=True)
+    assert torch.equal(zh, z[:h]) and torch.equal(ldjh, ldj[:h]) and torch.equal(cplh, cpl[:h * N])
+    dec = ops().encoder_decode(z, g(table), g(prior))
+    assert torch.equal(ops().encoder_decode(z[:h], g(table), g(prior)), dec[:h])
+    assert torch.equal(dec.cpu(), O.encoder_decode(z.cpu(), table, prior)[0])
