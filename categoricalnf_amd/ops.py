@@ -587,10 +587,10 @@ def encoder_fused_supported(C, D):
 
 
 def encoder_prefers_tiled_forward(C, D):
-    """Forward pass: the class-tiled kernel when the LDS-resident table would not fit or would exceed ~10 KB (64 classes
+    """Forward pass: the class-tiled kernel when the LDS-resident table would not fit or would exceed ~9 KB (64 classes
     at D = 6) — from there on the tiled kernel is faster (32.9 vs 36.2 us at 64 classes, 40.7 vs 77.9 at 160;
     profiles/r02_encoder_probe.txt).  Decode keeps the LDS table whenever it fits (equal or slightly faster)."""
-    return not encoder_fused_supported(C, D) or C * (6 * D + 3) * 4 >= 10000
+    return not encoder_fused_supported(C, D) or C * (6 * D + 3) * 4 >= 9000
 
 
 def encoder_forward(categ, eps, table, category_prior, beta=1.0, channel_padding_mask=None, ldj=None,
