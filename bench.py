@@ -357,17 +357,15 @@ def main():
     barrier()
     acc_all.zero_()
     steps_counted[0] = args.steps
+    ev_loop[0].record()             # GPU-side clock of the job (steps + read-out); its start marker goes in before t0
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    ev_loop[0].record()
     for i in range(args.steps):
         zr, lr = step(i, timed=(i % EV == 0))
-    ev_loop[1].record()
     finalize()
-    ev_done = torch.cuda.Event()
-    ev_done.record()
-    while not ev_done.query():      # poll instead of sleeping in the driver: a blocking wait wakes up tens of us late,
-        pass                        # which at K = 20 steps of 38 us is ~10 % of the timed region
+    ev_loop[1].record()
+    while not ev_loop[1].query():   # poll instead of sleeping in the driver: a blocking wait wakes up tens of us late,
+        pass                        # which at K = 20 steps of 37 us is ~10 % of the timed region
     barrier()
     elapsed_rank = time.perf_counter() - t0
     elapsed = elapsed_rank
