@@ -548,6 +548,13 @@ struct ZChunk {
 template <int VEC>
 __global__ __launch_bounds__(kBlock) void prior_nll_kernel(NllArgs a, RowTiling tl) {
     __shared__ float part[kWavesPerBlock][kMaxTileChunks];
+    // row scalars of the row this lane will finish, fetched now (see first_finish_row)
+    const int myrow = first_finish_row(tl);
+    float my_len = (float)a.N, my_ldj = 0.f;
+    if (myrow >= 0) {
+        if (a.length) my_len = a.length[myrow];
+        if (a.ldj) my_ldj = a.ldj[myrow];
+    }
     auto load = [&](int row, int e0) {
         ZChunk<VEC> c;
         VecIO<VEC>::load_z(a.z + (size_t)row * a.L + e0, c.v);
@@ -579,13 +586,15 @@ __global__ __launch_bounds__(kBlock) void prior_nll_kernel(NllArgs a, RowTiling 
         }
         return acc;
     };
-    auto finish = [&](int row, float sum) {
+    auto emit = [&](int row, float sum, float len, float ldj) {
         const float neglog = -sum;
-        const float len = a.length ? a.length[row] : (float)a.N;
-        const float ldj = a.ldj ? a.ldj[row] : 0.f;
         const float nll = (-ldj) / len + neglog / len;
         if (a.neglog_out) a.neglog_out[row] = neglog;
         if (a.nll_out) a.nll_out[row] = nll;
+    };
+    auto finish = [&](int row, float sum) {
+        if (row == myrow) emit(row, sum, my_len, my_ldj);
+        else emit(row, sum, a.length ? a.length[row] : (float)a.N, a.ldj ? a.ldj[row] : 0.f);
     };
     // read-only stream: all (up to 4) chunks of a lane are loaded back to back
     walk_row_tile_split<4, float, ZChunk<VEC>>(tl, part[threadIdx.x >> 6], load, proc, finish);
