@@ -366,7 +366,10 @@ def main():
     ev_loop[1].record()
     while not ev_loop[1].query():   # poll instead of sleeping in the driver: a blocking wait wakes up tens of us late,
         pass                        # which at K = 20 steps of 37 us is ~10 % of the timed region
-    barrier()
+    # closing bracket: with N > 1 ranks the job's one collective (the all-reduce in finalize()) IS the barrier — no
+    # rank can leave an all-reduce before every rank has entered it with its K steps and read-out done — so a second
+    # collective (dist.barrier = another all-reduce, tens of us at K = 20) is not added; then the device sync
+    torch.cuda.synchronize(dev)
     elapsed_rank = time.perf_counter() - t0
     elapsed = elapsed_rank
     per_rank = [elapsed_rank]
@@ -467,7 +470,9 @@ def main():
             "config": {"workload": "affine coupling fwd+logdet with NLL + batch-sum epilogue, inverse+logdet on z~N(0,1) [B=%d,N=%d,D=%d] per GPU, "
                                    "nn_out~0.5N(0,1), channel mask 0.5, scaling_factor=0" % (B, N, D),
                        "batch_per_gpu": B, "seq": N, "d_latent": D, "elems_per_step_per_gpu": elems,
-                       "buffer_sets_rotated": R, "parallelism": "dp%d (batch shards, one all-reduce of 2 fp64 per job)" % world},
+                       "buffer_sets_rotated": R, "parallelism": "dp%d (batch shards, one all-reduce of 2 fp64 per job)" % world,
+                       "timed_region": "barrier + device sync | K steps + read-out of the batch sums + the job's all-reduce "
+                                       "(the closing barrier when N > 1) | device sync; max over ranks"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                          "frac_of_achievable_6300": achieved / 6300.0,
