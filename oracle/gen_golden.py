@@ -340,6 +340,50 @@ def gen_encoder():
     save("encoder", cases)
 
 
+def gen_encoder_large_vocab():
+    """Vocabularies beyond the drop-in's LDS-resident class table (its class-tiled kernels, with and without class
+    splits): the reference's own encoder — latents, log-det, decoded classes and, through its autograd, the parameter
+    gradients.  Small embedding width keeps the fixture small."""
+    cases = []
+    for i, (B, N, D, C, beta, prior, padded) in enumerate([(2, 5, 6, 300, 1.0, True, True), (2, 4, 4, 1100, 1.5, True, False),
+                                                            (3, 3, 3, 1300, 1.0, False, True)]):
+        torch.manual_seed(1100 + i)
+        np.random.seed(1100 + i)
+        cp = torch.randn(C) if prior else None
+        with contextlib.redirect_stdout(io.StringIO()):
+            enc = LinearCategoricalEncoding(num_dimensions=D, flow_config={"num_flows": 0}, vocab_size=C, category_prior=cp,
+                                            default_embed_layer_dims=8)
+        lin = enc.flow_layers[0].pred_net.layer
+        lin.weight.data[D:, :] = 0.2 * torch.randn(D, lin.weight.shape[1])
+        lin.bias.data = 0.1 * torch.randn(2 * D)
+        enc.embed_layer.weight.data = 1.5 * torch.randn(C, 8)           # spread the classes
+        enc.eval()
+        cat = torch.randint(0, C, (B, N))
+        ln = lengths(B, N, torch.Generator().manual_seed(i))
+        pad = create_channel_mask(ln, max_len=N)
+        kw = dict(channel_padding_mask=pad) if padded else {}
+        torch.manual_seed(1200 + i)
+        u = torch.rand(B * N, 1, D)
+        torch.manual_seed(1200 + i)
+        z, ldj, _ = enc(cat, reverse=False, beta=beta, **kw)
+        wz, wl = torch.randn(B, N, D), torch.randn(B)
+        ((z * wz).sum() + (ldj * wl).sum()).backward()
+        with torch.no_grad():
+            dec, _, _ = enc(z, reverse=True)
+            z_probe = z + 0.7 * torch.randn(z.shape)
+            dec_probe, _, _ = enc(z_probe, reverse=True)
+            table = enc.flow_layers[0].pred_net(enc.embed_layer.weight)
+        c = dict(meta=dict(B=B, N=N, D=D, C=C, beta=beta, prior=prior, padded=padded, training=False),
+                 categ=cat, u=u, table=table, category_prior=enc.category_prior, pad=pad, z=z.detach(), ldj=ldj.detach(),
+                 decoded=dec, z_probe=z_probe.detach(), decoded_probe=dec_probe, wz=wz, wl=wl)
+        for k, v in enc.state_dict().items():
+            c["sd_" + k] = v
+        for k, v in enc.named_parameters():
+            c["gp_" + k] = v.grad
+        cases.append(c)
+    save("encoder_large_vocab", cases)
+
+
 def gen_sigmoid_dequant():
     cases = []
     g = torch.Generator().manual_seed(48)
@@ -966,3 +1010,4 @@ if __name__ == "__main__":
     gen_graph_node_flow()
     gen_language_model()
     gen_graph_cnf()
+    gen_encoder_large_vocab()

@@ -143,3 +143,16 @@ def test_sigmoid():
             a, la = O.sigmoid_flow(c.u, reverse=True)
             b, lb = O.sigmoid_flow(c.z, reverse=False)
         close(a, c.out_fwd); close(la, c.ldj_fwd); close(b, c.out_rev); close(lb, c.ldj_rev)
+
+
+@pytest.mark.parametrize("c", load_cases("encoder_large_vocab"))
+def test_encoder_large_vocab(c):
+    """300 / 1100 / 1300 classes (the drop-in's class-tiled kernels, without and with class splits): the oracle against
+    the reference's latents, log-det, decoded classes and — through autograd — the gradient of the class table."""
+    m = c.meta
+    eps = O.logistic_from_uniform(c.u)
+    pad = c.pad if m["padded"] else None
+    z, ldj, _ = O.encoder_forward(c.categ, eps, c.table, c.category_prior, beta=m["beta"], channel_padding_mask=pad)
+    close(z, c.z); close(ldj, c.ldj, atol=5e-6)
+    assert torch.equal(O.encoder_decode(c.z, c.table, c.category_prior)[0], c.decoded)
+    assert torch.equal(O.encoder_decode(c.z_probe, c.table, c.category_prior)[0], c.decoded_probe)
