@@ -409,6 +409,8 @@ def main():
     buf = (ctypes.c_float * n_ev)()
     got = lib.cnf_prof_collect(buf, n_ev)
     in_step = [buf[i] for i in range(got) if buf[i] > 0]
+    if os.environ.get("CNF_BENCH_DUMP_IN_STEP") and rank == 0:      # per-launch durations in launch order (diagnostics)
+        print("in-step forward kernel us:", " ".join("%.1f" % (v * 1e3) for v in in_step), file=sys.stderr)
     reps, blocks = 200, 6
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(blocks + 1)]
     marks[0].record()
