@@ -28,7 +28,7 @@ int mixture_tile_items();
 bool prof_take(hipEvent_t* start, hipEvent_t* stop);
 
 // Every kernel of the library is launched through this: an armed launch goes out with the dispatch's own start /
-// stop timestamps bound to an event pair (hipExtLaunchKernelGGL: no extra marker packets in the queue).
+// stop timestamps bound to an event pair (hipExtLaunchKernelGGL; measured cost ~4 us of queue time per timed launch).
 #define CNF_LAUNCH(kernel, grid, block, lds, st, ...)                                                        \
     do {                                                                                                     \
         hipEvent_t cnf_ps_, cnf_pe_;                                                                         \

@@ -69,7 +69,7 @@ void cnf_set_inverse_mode(int mode);
 /* Items (transformed elements) one wave of the fp32 mixture forward kernel owns, 64..512 (default 128). */
 void cnf_set_mixture_tile(int items);
 
-/* Kernel timing without marker packets (bench.py's `roofline`; the reference has no counterpart — its
+/* Kernel timing bound to the dispatch (bench.py's `roofline`; a timed launch costs ~4 us of queue time; the reference has no counterpart — its
  * only clock is the host-side time_per_step tracker, general/train.py:147-157).  cnf_prof_arm(n): the next n
  * kernel launches made by this host thread through this library carry their dispatch's own start / stop
  * timestamps (hipExtLaunchKernelGGL event pair; at most 8192 pairs between two collects).
