@@ -198,3 +198,42 @@ def test_fuzz_ext_actnorm_and_sigmoid(B, N, D, seed, mode):
         close(rg, ro, rtol=1e-4, atol=1e-4); close(rlg, rlo, **LDJ)
     finally:
         lib.cnf_set_math_mode(1)
+
+
+@pytest.mark.parametrize("B,N,D,seed", _shapes(6, 26, max_b=40, max_n=24, dims=(1, 2, 3, 4, 5, 6, 7, 8, 10, 13, 16)))
+def test_fuzz_encoder_class_tiled(B, N, D, seed):
+    """The class-tiled encoder kernels (forward, decode, backward) on random shapes: every latent width 1..16 (templated and
+    generic paths), vocabularies from 2 to a few thousand classes around the chunk / split boundaries (1024, 1025, one
+    class in the last split), fewer tokens than a workgroup, padding, beta != 1 — against the oracle and its autograd."""
+    from categoricalnf_amd import functional as Fn
+    gen = torch.Generator().manual_seed(seed)
+    C = int([2, 17, 64, 300, 1023, 1024, 1025, 1537, 2049, 3100][seed % 10])
+    if B * N * C > 400000:                       # keep the oracle's [T*C, 1, D] tensors small
+        N = max(1, 400000 // (B * C))
+    categ = torch.randint(0, C, (B, N), generator=gen)
+    categ[0, 0], categ[-1, -1] = 0, C - 1
+    table = torch.cat([1.5 * torch.randn(C, D, generator=gen), 0.5 * torch.randn(C, D, generator=gen)], dim=1)
+    prior = torch.log_softmax(torch.randn(C, generator=gen), 0)
+    eps = O.logistic_from_uniform(torch.rand(B * N, 1, D, generator=gen))
+    _, ln, pad = _mask_and_pad("chess", B, N, D, gen)
+    pad_arg = pad if seed % 2 else None
+    beta = [1.0, 0.6][seed % 2]
+    wz, wl = torch.randn(B, N, D, generator=gen), torch.randn(B, generator=gen)
+    tc = table.clone().requires_grad_()
+    zo, lo, cpo = O.encoder_forward(categ, eps, tc, prior, beta=beta, channel_padding_mask=pad_arg)
+    ((zo * wz).sum() + (lo * wl).sum()).backward()
+    tg = g(table).requires_grad_()
+    zg, lg, cpg = Fn.EncoderForwardFn.apply(tg, g(categ), g(eps), g(prior), g(pad_arg), beta, True, True)
+    close(zg, zo, **ELEM); close(lg, lo, rtol=1e-4, atol=1e-4 * max(1.0, float(lo.abs().max())))
+    close(cpg, cpo.reshape(-1), rtol=1e-4, atol=2e-4)
+    ((zg * g(wz)).sum() + (lg * g(wl)).sum()).backward()
+    scale = max(float(tc.grad.abs().max()), 1.0)
+    close(tg.grad, tc.grad, rtol=3e-3, atol=3e-4 * scale)
+    do, score = O.encoder_decode(zo.detach(), table, prior)
+    dg = ops().encoder_decode(g(zo.detach()), g(table), g(prior), tiled=True).cpu()
+    if not torch.equal(dg, do):
+        # a different index is acceptable only on a tie of the two class scores at fp32 resolution
+        s = score.reshape(-1, C)
+        gap = (s.gather(1, do.reshape(-1, 1)) - s.gather(1, dg.reshape(-1, 1))).abs().max()
+        assert float(gap) < 1e-4, "decoded categories differ beyond a numerical tie (score gap %g)" % float(gap)
+    ops().check_flags(torch.device("cuda"), "tiled encoder fuzz")
