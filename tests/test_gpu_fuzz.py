@@ -224,7 +224,7 @@ def test_fuzz_encoder_class_tiled(B, N, D, seed):
     ((zo * wz).sum() + (lo * wl).sum()).backward()
     tg = g(table).requires_grad_()
     zg, lg, cpg = Fn.EncoderForwardFn.apply(tg, g(categ), g(eps), g(prior), g(pad_arg), beta, True, True)
-    close(zg, zo, **ELEM); close(lg, lo, rtol=1e-4, atol=1e-4 * max(1.0, float(lo.abs().max())))
+    close(zg, zo, **ELEM); close(lg, lo, rtol=1e-4, atol=1e-4 * max(1.0, float(lo.detach().abs().max())))
     close(cpg, cpo.reshape(-1), rtol=1e-4, atol=2e-4)
     ((zg * g(wz)).sum() + (lg * g(wl)).sum()).backward()
     scale = max(float(tc.grad.abs().max()), 1.0)
