@@ -127,6 +127,24 @@ struct NoPre {
     __device__ __forceinline__ void operator()() const {}
 };
 
+// Logical workgroup index of the row walkers.  The hardware deals workgroups round-robin to the 8 XCDs; taken as is,
+// every XCD walks the whole tensor with a stride of 8 workgroups.  The remap gives each XCD one contiguous eighth of the
+// workgroups' work instead (a bijection on [0, gridDim.x)).  Interleaved A/B on one box (tools/ab_nll.sh), affine forward
+// + NLL, sustained stream: 20.2 -> 19.2 us at B = 16384, 35.1 -> 33.4 at 32768, equal within 1 % at 2048-8192 and at
+// 65536; runs of 4 / 32 / 256 workgroups per XCD instead of the full eighth: 20.0 / 19.7 / 19.5.  The token-pass mixture
+// kernel loses 8 % with it at 654 MB per launch and the ActNorm / 1x1-conv kernels gain nothing: they keep the
+// hardware order.  -DCNF_NO_XCD_SWIZZLE builds the as-dealt order for A/B (tools/build_variant.sh).
+__device__ __forceinline__ unsigned xcd_block(unsigned bid, unsigned nb) {
+#if defined(CNF_NO_XCD_SWIZZLE)
+    return bid;
+#else
+    const unsigned xcd = bid & 7u, idx = bid >> 3;
+    const unsigned per = nb >> 3, rem = nb & 7u;
+    return xcd * per + (xcd < rem ? xcd : rem) + idx;
+#endif
+}
+__device__ __forceinline__ unsigned walker_block() { return xcd_block(blockIdx.x, gridDim.x); }
+
 // pre_fn() runs once per wave AFTER the first group of loads has been issued and before the first
 // proc_fn: per-wave setup (LDS tables) hides behind the HBM latency of those loads.
 template <int U, typename T, typename Data, bool PREFETCH = false, typename LoadFn, typename ProcFn, typename FinishFn,
@@ -165,7 +183,7 @@ __device__ __forceinline__ void walk_row_tile_split(const RowTiling& tl, T* part
         }
         return;
     }
-    const long tile = (long)blockIdx.x * kWavesPerBlock + wave;
+    const long tile = (long)walker_block() * kWavesPerBlock + wave;
     if (tile >= tl.ntiles) return;
     const int row0 = (int)(tile * tl.rw);
     const int nrows = min(tl.rw, tl.B - row0);
@@ -244,7 +262,7 @@ __device__ __forceinline__ void walk_row_tile_split(const RowTiling& tl, T* part
 __device__ __forceinline__ int first_finish_row(const RowTiling& tl) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (tl.bpr) return threadIdx.x == 0 ? (int)blockIdx.x : -1;
-    const long tile = (long)blockIdx.x * kWavesPerBlock + wave;
+    const long tile = (long)walker_block() * kWavesPerBlock + wave;
     if (tile >= tl.ntiles) return -1;
     const int row0 = (int)(tile * tl.rw);
     if (tl.rw == 1) return lane == 0 ? row0 : -1;

@@ -14,7 +14,7 @@ template <int U>
 __global__ __launch_bounds__(256) void stream_mix_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                          float* __restrict__ out, long nchunks) {
     // a block owns 256*U consecutive 16-byte chunks of `a` / `out` and the matching 32-byte pairs of `b`
-    const long base = (long)blockIdx.x * (256 * U) + threadIdx.x;
+    const long base = (long)xcd_block(blockIdx.x, gridDim.x) * (256 * U) + threadIdx.x;     // same workgroup -> XCD layout as the kernels
     pf4 va[U], vb0[U], vb1[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {

@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from categoricalnf_amd import _lib, ops
 dev = torch.device("cuda:0")
 lib = _lib.load()
-B, N, D, R = 16384, 64, 6, 4
+B, N, D, R = int(os.environ.get("CNF_PROBE_B", 16384)), 64, 6, int(os.environ.get("CNF_PROBE_R", 4))
 g = torch.Generator(device=dev).manual_seed(0)
 zs = [torch.randn(B, N, D, generator=g, device=dev) for _ in range(R)]
 nns = [0.5 * torch.randn(B, N, 2 * D, generator=g, device=dev) for _ in range(R)]
