@@ -127,20 +127,19 @@ struct NoPre {
     __device__ __forceinline__ void operator()() const {}
 };
 
-// Logical workgroup index of the row walkers.  The hardware deals workgroups round-robin to the 8 XCDs; taken as is,
-// every XCD walks the whole tensor with a stride of 8 workgroups.  The remap gives each XCD one contiguous eighth of the
-// workgroups' work instead (a bijection on [0, gridDim.x)).  Interleaved A/B on one box (tools/ab_nll.sh), affine forward
-// + NLL, sustained stream: 20.2 -> 19.2 us at B = 16384, 35.1 -> 33.4 at 32768, equal within 1 % at 2048-8192 and at
-// 65536; runs of 4 / 32 / 256 workgroups per XCD instead of the full eighth: 20.0 / 19.7 / 19.5.  The token-pass mixture
-// kernel loses 8 % with it at 654 MB per launch and the ActNorm / 1x1-conv kernels gain nothing: they keep the
-// hardware order.  -DCNF_NO_XCD_SWIZZLE builds the as-dealt order for A/B (tools/build_variant.sh).
+// Logical workgroup index of the row walkers = the hardware's (round-robin over the 8 XCDs).  Giving each XCD one
+// contiguous eighth of the workgroups instead (-DCNF_XCD_EIGHTHS) shortens the dispatch-timestamp duration of the affine
+// forward + NLL kernel in a forward-only stream (20.2 -> 19.2 us) but changes neither its start-to-start time nor the
+// bench step (36.0 us either way, interleaved A/B on one box): what shrinks is the overlap of a launch's timestamps
+// with the drain of the launch before it, not the work.  Kept as a build option for A/B only.
 __device__ __forceinline__ unsigned xcd_block(unsigned bid, unsigned nb) {
-#if defined(CNF_NO_XCD_SWIZZLE)
-    return bid;
-#else
+#if defined(CNF_XCD_EIGHTHS)
     const unsigned xcd = bid & 7u, idx = bid >> 3;
     const unsigned per = nb >> 3, rem = nb & 7u;
     return xcd * per + (xcd < rem ? xcd : rem) + idx;
+#else
+    (void)nb;
+    return bid;
 #endif
 }
 __device__ __forceinline__ unsigned walker_block() { return xcd_block(blockIdx.x, gridDim.x); }
