@@ -410,10 +410,25 @@ def main():
     #      rocprofv3 --kernel-trace reports; a timed launch still costs ~4 us of queue time, hence only ~32 of them per run;
     #  (2) `steady_ms`, a cross-check: start-to-start time of back-to-back forward launches after the timed region
     #      (6 x 200 launches, first block discarded); it contains the inter-kernel boundary.
-    n_ev = (args.steps + EV - 1) // EV
+    #  The two kernels of a step are coupled through the memory-side cache (the inverse re-reads what the forward just
+    #  touched and runs faster than in a stream of its own, the forward slower), and timestamps of consecutive launches
+    #  overlap by a few tenths of a microsecond: `both_kernels_of_a_step` reports both durations and the step as a whole.
+    n_ev = (args.steps + EV - 1) // EV + 1
     buf = (ctypes.c_float * n_ev)()
     got = lib.cnf_prof_collect(buf, n_ev)
     in_step = [buf[i] for i in range(got) if buf[i] > 0]
+    # the same step stream once more after the timed region, with BOTH launches of every 8th step timed
+    n_ov = 400
+    for i in range(n_ov + 100):
+        if i >= 100 and i % 8 == 4:
+            lib.cnf_prof_arm(2)
+        fwd[i % R]()
+        inv[i % R]()
+    torch.cuda.synchronize(dev)
+    ovb = (ctypes.c_float * (n_ov // 4 + 4))()
+    n_ovb = lib.cnf_prof_collect(ovb, n_ov // 4 + 4)
+    ov_fwd = float(np.mean([ovb[i] for i in range(0, n_ovb, 2)])) if n_ovb >= 2 else None
+    ov_inv = float(np.mean([ovb[i] for i in range(1, n_ovb, 2)])) if n_ovb >= 2 else None
     if os.environ.get("CNF_BENCH_DUMP_IN_STEP") and rank == 0:      # per-launch durations in launch order (diagnostics)
         print("in-step forward kernel us:", " ".join("%.1f" % (v * 1e3) for v in in_step), file=sys.stderr)
     reps, blocks = 200, 6
@@ -493,6 +508,16 @@ def main():
                          "kernel_ms_source": "dispatch-bound HIP event pairs on %d forward launches inside the timed region" % len(in_step)
                                              if in_step else "steady-state stream after the timed region (no in-step samples)",
                          "steady_state_start_to_start_ms": steady_ms,
+                         "both_kernels_of_a_step": {
+                             "forward_kernel_ms": ov_fwd, "inverse_kernel_ms": ov_inv,
+                             "sum_minus_timed_step_ms": (ov_fwd + ov_inv - elapsed / args.steps * 1e3) if ov_fwd is not None else None,
+                             "step_frac": 2.0 * alg_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
+                             "what": "400 more steps after the timed region with both launches of every 8th step timed: in "
+                                     "the alternating stream the forward runs slower and the inverse faster than in streams "
+                                     "of their own (the inverse re-reads what the forward just touched; the forward pays the "
+                                     "write-back of both), so the pair is also priced as a whole: step_frac = 2 x algorithmic "
+                                     "bytes / timed step / 8 TB/s"},
+                         "frac_from_start_to_start": alg_bytes / (steady_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_launch": alg_bytes},
             "gpu_ms_per_step": gpu_loop_ms / args.steps,
             "per_rank_elems_per_s": [elems * args.steps / t for t in per_rank],

@@ -68,12 +68,50 @@ def show(name, v):
           (name, len(v), v.mean(), v[:q].mean(), v[-q:].mean(), v.min()), flush=True)
 
 
+def s2s_bursts(launch, rounds=20, n=100):
+    """start-to-start time from one event pair around each burst (no per-launch timestamps involved)"""
+    out = []
+    for _ in range(rounds):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for i in range(n):
+            launch(i % R)
+        b.record()
+        torch.cuda.synchronize()
+        out.append(a.elapsed_time(b) / n * 1e3)
+    return np.array(out[2:])
+
+
+def s2s_sustained(launch, between=None, blocks=30, n=200):
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(blocks + 1)]
+    marks[0].record()
+    for k in range(blocks):
+        for i in range(n):
+            launch(i % R)
+            if between is not None:
+                between(i % R)
+        marks[k + 1].record()
+    torch.cuda.synchronize()
+    return np.array([marks[k].elapsed_time(marks[k + 1]) / n * 1e3 for k in range(blocks)])
+
+
 for i in range(300):
     fwd[i % R]()
 torch.cuda.synchronize()
+print("dispatch-timestamp durations (cnf_prof_arm); a launch's timestamps overlap the drain of the launch before it")
 show("(a) forward+NLL, bursts of 100", bursts(lambda r: fwd[r]()))
 show("(b) forward+NLL, sustained forward-only", sustained(lambda r: fwd[r]()))
 show("(c) forward+NLL, sustained fwd/inv alternating", sustained(lambda r: fwd[r](), between=lambda r: inv[r]()))
 show("(a) stream probe, bursts of 100", bursts(probe))
 show("(b) stream probe, sustained", sustained(probe))
 show("(c) stream probe alternating with the inverse", sustained(probe, between=lambda r: inv[r]()))
+
+print("start-to-start times (one event pair around a block of launches: throughput, no per-launch timestamps)")
+show("(a) forward+NLL, bursts of 100", s2s_bursts(lambda r: fwd[r]()))
+show("(b) forward+NLL, sustained 30 x 200", s2s_sustained(lambda r: fwd[r]()))
+show("(c) forward+NLL + inverse (one bench step)", s2s_sustained(lambda r: fwd[r](), between=lambda r: inv[r]()))
+show("(a) inverse, bursts of 100", s2s_bursts(lambda r: inv[r]()))
+show("(b) inverse, sustained 30 x 200", s2s_sustained(lambda r: inv[r]()))
+show("(a) stream probe, bursts of 100", s2s_bursts(probe))
+show("(b) stream probe, sustained 30 x 200", s2s_sustained(probe))
+show("(c) stream probe + inverse", s2s_sustained(probe, between=lambda r: inv[r]()))
