@@ -445,7 +445,7 @@ def main():
     # measured ceiling for this traffic mix on this device, same run, same rotating buffers: a streaming kernel that
     # reads 4 + 8 bytes and writes 4 bytes per element and computes nothing (cnf_stream_probe), timed with
     # dispatch-bound pairs (a) where the forward kernel sits — the timed loop again with the probe in the forward's
-    # place, alternating with the inverse, every EV-th probe timed — and (b) in a short burst of its own (boost clocks)
+    # place, alternating with the inverse, every EV-th probe timed — and (b) in a short burst of its own (spaced launches: no overlap with a neighbour)
     def probe(r, cpl):
         ops._launch(dev, "cnf_stream_probe", zs[r].data_ptr(), nns[r].data_ptr(), zfs[r].data_ptr(), elems, cpl,
                     ops._stream(dev))
@@ -468,7 +468,7 @@ def main():
         inv[i % R]()
     pb = (ctypes.c_float * (n_loop // EV + 1))()
     n_pb = lib.cnf_prof_collect(pb, n_loop // EV + 1)
-    tail = [pb[i] for i in range(n_pb)][n_pb // 4:]            # the stream's first quarter still runs at burst clocks
+    tail = [pb[i] for i in range(n_pb)][n_pb // 4:]            # first quarter dropped: the stream settles
     ceil_ms = float(np.mean(tail)) if tail else burst_ms[best_cpl]
     ceil_gbs = 16.0 * elems / (ceil_ms * 1e-3) / 1e9
     alg_bytes = 16.0 * elems + 4.0 * B            # z 4 + (s,t) 8 + z' 4 per elem, + ldj per sample

@@ -1,10 +1,13 @@
-"""Is the bench's dominant kernel slower inside the timed loop than in short bursts because of what runs around it, or
-because of how long the device has been busy?  Dispatch-bound durations (cnf_prof_arm) of the affine forward + NLL +
-batch-sum kernel at B=16384,N=64,D=6 on 4 rotating buffer sets, in three streams:
+"""What does a launch of the bench's dominant kernel cost, and what do per-launch timestamps say?  The affine forward + NLL
++ batch-sum kernel at B=16384,N=64,D=6 on 4 rotating buffer sets, the inverse, and the stream-probe kernel (same traffic,
+no arithmetic), each in three streams:
   (a) bursts: 100 launches, host sync, repeat (what tools/sweep_nll.py times),
-  (b) sustained forward-only: 6000 launches back to back, every 8th timed,
-  (c) sustained alternating forward / inverse (the bench step), every 8th forward timed,
-and the stream-probe kernel (same traffic, no arithmetic) in (a)- and (b)-style streams."""
+  (b) sustained: thousands of launches back to back,
+  (c) the bench step: forward (or the probe in its place) alternating with the inverse,
+measured twice: per-launch dispatch timestamps (cnf_prof_arm; every 8th launch, or the last 8 of a burst) and
+start-to-start times from one event pair around a block of launches.  Findings: consecutive
+launches overlap, so timestamps in a continuous stream exceed the stream's advance per launch; there is no burst-versus-
+sustained clock effect; in the bench step the inverse runs faster and the forward slower than in streams of their own."""
 import ctypes, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
