@@ -49,13 +49,6 @@ def allreduce_nll(sums):
     return mean, float(np.log2(np.exp(1)) * mean)
 
 
-def allreduce_actnorm_stats(acc):
-    """fp64 [D+1] (per-channel sums + count) partials of the ActNorm data-dependent init (§8e)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(acc, op=dist.ReduceOp.SUM)
-    return acc
-
-
 def wrap_ddp(model, device, bucket_cap_mb=25):
     """Data-parallel training wrapper replacing the reference's nn.DataParallel (general/mutils.py:243-249):
     one process per GPU, gradients all-reduced by RCCL in buckets that overlap with the HIP backward kernels.
