@@ -131,7 +131,25 @@ __global__ __launch_bounds__(kBlock) void encoder_forward_kernel(EncArgs a, RowT
         // class then takes the forward value, :167-168)
         const float lp2 = log_point * kLog2e;
         float m = -3e38f, s = 0.f;
-        for (int j = 0; j < a.C; ++j) {
+        int j = 0;
+#ifndef CNF_ENC_NO_BLOCK_LSE
+        // four classes per update of the running (max, sum): 5 exp2 per 4 classes instead of 8, and four independent
+        // score chains for the scheduler
+        for (; j + 4 <= a.C; j += 4) {
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float sc = class_score2<DT>(tab + (j + i) * stride, z, D);
+                v[i] = (j + i) == c ? lp2 : sc;
+            }
+            const float mn = fmaxf(m, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+            const float blk = (__builtin_amdgcn_exp2f(v[0] - mn) + __builtin_amdgcn_exp2f(v[1] - mn)) +
+                              (__builtin_amdgcn_exp2f(v[2] - mn) + __builtin_amdgcn_exp2f(v[3] - mn));
+            s = fmaf(s, __builtin_amdgcn_exp2f(m - mn), blk);
+            m = mn;
+        }
+#endif
+        for (; j < a.C; ++j) {
             const float sc = class_score2<DT>(tab + j * stride, z, D);
             const float v = j == c ? lp2 : sc;
             const float mn = fmaxf(m, v);
