@@ -61,15 +61,26 @@ struct AffineArgs {
 
 template <int VEC>
 struct VecIO;
-// bit 0: nontemporal loads, bit 1: nontemporal stores in the 16-byte row-streaming I/O.  Streamed-once data does
-// not need to displace L2 / Infinity-Cache lines: stores-only measured 19.7-20.3 us vs 21.4 us for the forward
-// kernel at B=16384,N=64,D=6 with the whole bench step unchanged (interleaved builds, MI355X)
+// Cache hints of the 16-byte row-streaming I/O.  bit 0: nontemporal loads of the conditioning values (s, t); bit 1:
+// nontemporal stores; bit 2: nontemporal loads of the latents z.  Interleaved A/B on one box, bench step (forward + NLL,
+// then inverse on its output) / forward-only start-to-start, us:  stores only (2): 36.0 / 19.0;  + z loads (6, the
+// default): 34.8 / 18.2;  all loads (3): 38.2 / 19.6;  none (0): 38.0 / 21.5;  loads only (1): 37.2 / 19.7.
+// z is read exactly once by every kernel of the path; (s, t) is read again by the inverse that follows the forward in
+// the bench (and hits in the memory-side cache: the inverse takes 16.4 us after a forward, 18.0 us in a stream of its own).
 #ifndef CNF_NT
-#define CNF_NT 2
+#define CNF_NT 6
 #endif
 typedef float nt_f4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 ld4(const float* p) {
 #if (CNF_NT & 1)
+    const nt_f4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *reinterpret_cast<const float4*>(p);
+#endif
+}
+__device__ __forceinline__ float4 ld4_z(const float* p) {
+#if (CNF_NT & 4)
     const nt_f4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(p));
     return make_float4(v.x, v.y, v.z, v.w);
 #else
@@ -90,6 +101,12 @@ struct VecIO<4> {
         const float4 a = ld4(p);
         v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
     }
+    // the coupling kernels' latents (three streams: z, (s, t), z'): nontemporal per CNF_NT bit 2; the two-stream kernels
+    // (sigmoid flow: 10.2 -> 11.4 us with it) keep the plain load
+    static __device__ __forceinline__ void load_z_stream(const float* p, float* v) {
+        const float4 a = ld4_z(p);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+    }
     static __device__ __forceinline__ void load_st(const float* p, float* s, float* t) {
         const float4 a = ld4(p);
         const float4 b = ld4(p + 4);
@@ -104,6 +121,7 @@ struct VecIO<2> {
         const float2 a = *reinterpret_cast<const float2*>(p);
         v[0] = a.x; v[1] = a.y;
     }
+    static __device__ __forceinline__ void load_z_stream(const float* p, float* v) { load_z(p, v); }
     static __device__ __forceinline__ void load_st(const float* p, float* s, float* t) {
         const float4 a = *reinterpret_cast<const float4*>(p);
         s[0] = a.x; t[0] = a.y; s[1] = a.z; t[1] = a.w;
@@ -115,6 +133,7 @@ struct VecIO<2> {
 template <>
 struct VecIO<1> {
     static __device__ __forceinline__ void load_z(const float* p, float* v) { v[0] = *p; }
+    static __device__ __forceinline__ void load_z_stream(const float* p, float* v) { load_z(p, v); }
     static __device__ __forceinline__ void load_st(const float* p, float* s, float* t) {
         const float2 a = *reinterpret_cast<const float2*>(p);
         s[0] = a.x; t[0] = a.y;
@@ -182,7 +201,7 @@ __global__ __launch_bounds__(kBlock) void affine_coupling_kernel(AffineArgs a, R
     auto load = [&](int row, int e0) {
         const size_t off = (size_t)row * a.L + e0;
         AffineChunk<VEC> c;
-        VecIO<VEC>::load_z(a.z + off, c.zv);
+        VecIO<VEC>::load_z_stream(a.z + off, c.zv);
         VecIO<VEC>::load_st(a.nn + 2 * off, c.sr, c.tr);
         return c;
     };

@@ -1,6 +1,10 @@
 // Token-pass machinery shared by the fp32 mixture kernels (forward / inverse: cnf_mixture_tok.hip, backward:
 // cnf_mixture_tok_bwd.hip): pass geometry, the DMA staging of one pass of parameter spans, fixed-point helpers.
 #pragma once
+// cache-policy bits of the DMA loads (gfx94x/95x: 1 = sc0, 2 = nt, 16 = sc1)
+#ifndef CNF_MIX_DMA_AUX
+#define CNF_MIX_DMA_AUX 0
+#endif
 #include "cnf_mixture.h"
 
 namespace cnf {
@@ -49,7 +53,7 @@ __device__ __forceinline__ int stage_pass(const TokGeom& gm, char* stage_b, cons
         for (int i = 0; i < ni; ++i) {
             const char* gp = abase + ((size_t)(i * kWave + lane) << 4);
             gp = gp > nn_last ? nn_last : gp;
-            __builtin_amdgcn_global_load_lds((glb_void_t*)gp, (lds_void_t*)(stage_b + (i << 10)), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void_t*)gp, (lds_void_t*)(stage_b + (i << 10)), 16, 0, CNF_MIX_DMA_AUX);
         }
         return off0 + tli * gm.tokstride + j * P * 4;
     }
@@ -61,7 +65,7 @@ __device__ __forceinline__ int stage_pass(const TokGeom& gm, char* stage_b, cons
         const char* ta = pass_addr + (size_t)s * gm.tokstride;
         const char* gp = ta - (reinterpret_cast<uintptr_t>(ta) & 15) + o;
         gp = gp > nn_last ? nn_last : gp;
-        __builtin_amdgcn_global_load_lds((glb_void_t*)gp, (lds_void_t*)(stage_b + (i << 10)), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_void_t*)gp, (lds_void_t*)(stage_b + (i << 10)), 16, 0, CNF_MIX_DMA_AUX);
     }
     const char* ta = pass_addr + (size_t)tli * gm.tokstride;
     return tli * gm.slot + (int)(reinterpret_cast<uintptr_t>(ta) & 15) + j * P * 4;
