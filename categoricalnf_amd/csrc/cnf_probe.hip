@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256) void stream_mix_kernel(const float* __restrict
     for (int u = 0; u < U; ++u) {
         const long c = base + (long)u * 256;
         if (c < nchunks) {
-            va[u] = *reinterpret_cast<const pf4*>(a + 4 * c);
+            va[u] = __builtin_nontemporal_load(reinterpret_cast<const pf4*>(a + 4 * c));     // read once: 16.3 -> 15.8 us
             vb0[u] = *reinterpret_cast<const pf4*>(b + 8 * c);
             vb1[u] = *reinterpret_cast<const pf4*>(b + 8 * c + 4);
         }
