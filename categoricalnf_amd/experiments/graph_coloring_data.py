@@ -164,3 +164,37 @@ class GraphColoringDataset(data.Dataset):
 
     def get_sampler(self, batch_size, drop_last=False, **kwargs):
         return data.BatchSampler(BucketSampler(self, batch_size, len_step=1), batch_size, drop_last=drop_last)
+
+
+def generate_planted_dataset(data_root, prefix="_tiny", num_colors=3, num_graphs=60000, n_min=10, n_max=20, mean_degree=3.5,
+                             val_fraction=0.1, test_fraction=0.1, seed=0):
+    """Write a synthetic data set in the reference's two-file format (the published files are not reachable from here):
+    random graphs with a PLANTED colouring — every node gets a random colour and edges are drawn only between nodes of
+    different colours, with probability `mean_degree / n` per pair — so every graph is `num_colors`-colourable and the
+    stored colouring is valid.  (The reference's own generator samples hard instances and solves them with a CSP solver,
+    datasets/graph_coloring_generation.py; the statistics differ, the file format and the task do not.)  Isolated nodes
+    get one edge to a node of another colour so that no node is unconstrained."""
+    rng = np.random.RandomState(seed)
+    nodes = -np.ones((num_graphs, n_max), dtype=np.int8)
+    adjacency = -np.ones((num_graphs, n_max, n_max), dtype=np.int8)
+    for g in range(num_graphs):
+        n = rng.randint(n_min, n_max + 1)
+        colours = rng.randint(0, num_colors, size=n)
+        if len(set(colours.tolist())) < 2:
+            colours[0], colours[1] = 0, 1
+        differ = colours[:, None] != colours[None, :]
+        a = np.triu((rng.rand(n, n) < mean_degree / n) & differ, 1)
+        a = a | a.T
+        for i in np.where(a.sum(1) == 0)[0]:
+            j = rng.choice(np.where(differ[i])[0])
+            a[i, j] = a[j, i] = True
+        nodes[g, :n] = colours
+        adjacency[g, :n, :n] = a
+    os.makedirs(data_root, exist_ok=True)
+    order = rng.permutation(num_graphs)
+    n_val, n_test = int(num_graphs * val_fraction), int(num_graphs * test_fraction)
+    np.savez_compressed(os.path.join(data_root, "graph_coloring_compressed_%i%s.npz" % (num_colors, prefix)),
+                        nodes=nodes, adjacency=adjacency)
+    np.savez_compressed(os.path.join(data_root, "graph_coloring_dataidx_%i%s.npz" % (num_colors, prefix)),
+                        train_idx=order[n_val + n_test:], val_idx=order[:n_val], test_idx=order[n_val:n_val + n_test])
+    return nodes, adjacency
