@@ -6,7 +6,8 @@ class-level arrays, `__getitem__` -> (nodes, adjacency, length), `evaluate_gener
 `set_dataset`, `get_sampler`) and experiments/graph_coloring/datasets/mutils.py:9-61 (`BucketSampler`).  The data files
 (`graph_coloring_compressed_<colors><prefix>.npz` with `nodes [G, Nmax]` (-1 = padding) and `adjacency [G, Nmax, Nmax]`,
 `graph_coloring_dataidx_<colors><prefix>.npz` with `train_idx / val_idx / test_idx`) are the reference's own; they are
-not shipped (no network), the loader asserts with the reference's message when they are absent.
+not shipped (no network), the loader asserts with the reference's message when they are absent;
+`generate_planted_dataset` writes a synthetic set in the same two-file format (random graphs with a planted colouring).
 
 The validity check is one vectorised pass on whatever device the samples live on (the reference loops over graphs in
 numpy): a colouring is valid iff no edge joins two nodes of the same colour inside the first `length` nodes.

@@ -612,3 +612,31 @@ def test_coloring_dataset_missing_file_message(tmp_path):
             DS(val=True, data_root=str(tmp_path))
     finally:
         DS.DATASET_NODES = saved
+
+
+def test_planted_colouring_data_set_has_the_reference_file_format(tmp_path):
+    """generate_planted_dataset: the two .npz files GraphColoringDataset (and the reference's) read — padded int8 arrays,
+    disjoint splits — every stored colouring valid, no isolated node, node counts inside the requested range."""
+    from categoricalnf_amd.experiments.graph_coloring_data import GraphColoringDataset as DS, coloring_validity, generate_planted_dataset
+    saved = (DS.DATASET_NODES, DS.DATASET_ADJACENCIES, DS.DATASET_TRAIN_IDX, DS.DATASET_VAL_IDX, DS.DATASET_TEST_IDX,
+             DS.PREFIX, DS.NUM_COLORS, DS.DATA_FILENAME, DS.IDX_FILENAME)
+    try:
+        generate_planted_dataset(str(tmp_path), prefix="_tiny", num_colors=3, num_graphs=400, n_min=10, n_max=20, seed=3)
+        DS.set_dataset(prefix="_tiny", num_colors=3)
+        DS.DATASET_NODES = DS.DATASET_VAL_IDX = None
+        arr = np.load(os.path.join(str(tmp_path), DS.DATA_FILENAME))
+        assert arr["nodes"].dtype == np.int8 and arr["nodes"].shape == (400, 20) and arr["adjacency"].shape == (400, 20, 20)
+        idx = np.load(os.path.join(str(tmp_path), DS.IDX_FILENAME))
+        parts = [idx[k] for k in ("train_idx", "val_idx", "test_idx")]
+        assert sorted(np.concatenate(parts).tolist()) == list(range(400))
+        val = DS(val=True, data_root=str(tmp_path))
+        items = [val[i] for i in range(len(val))]
+        nodes, adj, ln = (np.stack([it[k] for it in items]) for k in range(3))
+        assert ln.min() >= 10 and ln.max() <= 20
+        assert bool(coloring_validity(nodes, adj, ln).all())
+        inside = np.arange(20)[None, :] < ln[:, None]
+        assert bool(((adj > 0).sum(-1) >= 1)[inside].all())                 # no unconstrained node
+        assert np.array_equal(adj, adj.transpose(0, 2, 1))
+    finally:
+        (DS.DATASET_NODES, DS.DATASET_ADJACENCIES, DS.DATASET_TRAIN_IDX, DS.DATASET_VAL_IDX, DS.DATASET_TEST_IDX,
+         DS.PREFIX, DS.NUM_COLORS, DS.DATA_FILENAME, DS.IDX_FILENAME) = saved
