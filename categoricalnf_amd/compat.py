@@ -26,7 +26,12 @@ PATCHES = {
     # a long index divided with `/` is a float tensor since torch 1.5 and cannot index (graph_layers.py:527, :668)
     "layers.networks.graph_layers": [("* edge_indices[...,0]) / 2 +", "* edge_indices[...,0]) // 2 +")],
     # a long tensor clamped with a float bound is promoted to float and then refused by scatter_ (general/mutils.py:300)
-    "general.mutils": [("inv_time_range = inv_time_range.clamp(min=0.0)", "inv_time_range = inv_time_range.clamp(min=0)")],
+    "general.mutils": [("inv_time_range = inv_time_range.clamp(min=0.0)", "inv_time_range = inv_time_range.clamp(min=0)"),
+                       # torch >= 2.6 loads with weights_only=True by default and refuses the numpy scalars the template
+                       # stores in `best_save_dict` / `evaluation_dict` (load_model, general/mutils.py:80, :82)
+                       ("torch.load(checkpoint_file)", "torch.load(checkpoint_file, weights_only=False)"),
+                       ("torch.load(checkpoint_file, map_location='cpu')",
+                        "torch.load(checkpoint_file, map_location='cpu', weights_only=False)")],
 }
 _loaded = {}
 

@@ -640,3 +640,96 @@ def test_planted_colouring_data_set_has_the_reference_file_format(tmp_path):
     finally:
         (DS.DATASET_NODES, DS.DATASET_ADJACENCIES, DS.DATASET_TRAIN_IDX, DS.DATASET_VAL_IDX, DS.DATASET_TEST_IDX,
          DS.PREFIX, DS.NUM_COLORS, DS.DATA_FILENAME, DS.IDX_FILENAME) = saved
+
+
+# ---------------------------------------------------------------- §8 f-3: the reference's own CLI through the launcher
+
+def test_run_reference_summary_writer_and_patch_finder(tmp_path):
+    """Launcher pieces that need no checkout: the tensorboard stand-in records scalars and swallows the other writer
+    calls; the import hook serves a module named in compat.PATCHES from a checkout with the fix applied, and refuses a
+    checkout whose line it cannot find."""
+    import importlib
+    import json
+    from categoricalnf_amd import compat, run_reference
+    w = run_reference.JsonlSummaryWriter(str(tmp_path / "log"))
+    w.add_scalar("train/loss", torch.tensor(1.5), 7)
+    w.add_scalar("train/text", "not a number", 7)
+    w.add_histogram("h", torch.zeros(3), 7)
+    w.add_text("t", "x")
+    w.flush()
+    w.close()
+    lines = [json.loads(l) for l in open(tmp_path / "log" / "scalars.jsonl")]
+    assert lines == [{"tag": "train/loss", "value": 1.5, "step": 7}]
+    with pytest.raises(AttributeError):
+        w.no_such_call
+
+    root = tmp_path / "checkout"
+    (root / "general").mkdir(parents=True)
+    (root / "general" / "__init__.py").write_text("")
+    old, new = compat.PATCHES["general.mutils"][0]
+    loads = [o for o, _ in compat.PATCHES["general.mutils"][1:]]            # the two torch.load call sites
+    (root / "general" / "mutils.py").write_text("def f(inv_time_range):\n    %s\n    return inv_time_range\nSRC = \"\"\"%s\"\"\"\n"
+                                                % (old, " | ".join(loads)))
+    saved_path, saved_meta = list(sys.path), list(sys.meta_path)
+    saved_mods = {k: sys.modules.pop(k) for k in list(sys.modules) if k == "general" or k.startswith("general.")}
+    try:
+        sys.path.insert(0, str(root))
+        run_reference.install_patch_finder()
+        run_reference.install_patch_finder()                               # idempotent
+        assert sum(isinstance(f, run_reference.PatchFinder) for f in sys.meta_path) == 1
+        mod = importlib.import_module("general.mutils")
+        assert mod.__file__ == str(root / "general" / "mutils.py")
+        assert mod.SRC == "torch.load(checkpoint_file, weights_only=False) | torch.load(checkpoint_file, map_location='cpu', weights_only=False)"
+        assert mod.f(torch.tensor([-2, 3])).dtype == torch.int64           # clamp(min=0) keeps the long dtype
+        (root / "general" / "mutils.py").write_text("x = 1\n")
+        sys.modules.pop("general.mutils")
+        with pytest.raises(ImportError, match="torch >= 2 fix"):
+            importlib.import_module("general.mutils")
+    finally:
+        sys.path[:], sys.meta_path[:] = saved_path, saved_meta
+        for k in [k for k in sys.modules if k == "general" or k.startswith("general.")]:
+            sys.modules.pop(k)
+        sys.modules.update(saved_mods)
+
+
+def test_run_reference_finds_the_checkout_root(tmp_path):
+    from categoricalnf_amd import run_reference
+    root = tmp_path / "ref"
+    (root / "general").mkdir(parents=True)
+    (root / "general" / "train.py").write_text("")
+    (root / "layers" / "flows").mkdir(parents=True)
+    script = root / "experiments" / "task" / "train.py"
+    script.parent.mkdir(parents=True)
+    script.write_text("")
+    assert run_reference.find_root(str(script)) == str(root)
+    with pytest.raises(SystemExit):
+        run_reference.find_root(str(tmp_path / "elsewhere.py"))
+    with pytest.raises(SystemExit, match="unknown launcher flag"):
+        run_reference.main(["--frobnicate", str(script)])
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/experiments"), reason="reference checkout only exists in the build container")
+def test_reference_cli_runs_unchanged_up_to_the_kernel_boundary(tmp_path):
+    """§8 f-3 "run the reference's CLI unchanged": experiments/set_modeling/train.py of the checkout, started through
+    the launcher with its own flags, parses them, writes its param_config.pik, builds FlowSetModeling on the drop-in
+    layers and the task's data loaders, opens the (stand-in) summary writer and starts its data-dependent
+    initialisation — whose first layer call stops at the package's boundary on a machine without a GPU: HipOnlyError,
+    no silent CPU path.  (On an MI355X the same command trains; the layers it reaches are covered by the GPU suite.)"""
+    ckpt = tmp_path / "ckpt"
+    env = dict(os.environ, MPLBACKEND="Agg", PYTHONDONTWRITEBYTECODE="1", PYTHONPATH=ROOT, CUDA_VISIBLE_DEVICES="",
+               HIP_VISIBLE_DEVICES="")
+    out = subprocess.run([sys.executable, "-m", "categoricalnf_amd.run_reference", "--reference_root", "/root/reference",
+                          "experiments/set_modeling/train.py", "--dataset", "shuffling", "--set_size", "4",
+                          "--max_iterations", "4", "--eval_freq", "2", "--batch_size", "16", "--coupling_num_flows", "2",
+                          "--coupling_hidden_size", "32", "--checkpoint_path", str(ckpt), "--cluster"],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=str(tmp_path), timeout=600)
+    assert out.returncode != 0
+    assert "MI355X kernels" in out.stdout and "Initializing data dependent" in out.stdout, out.stdout[-1500:]
+    assert "HipOnlyError" in out.stderr and "/root/reference/general/train.py" in out.stderr, out.stderr[-1500:]
+    assert "categoricalnf_amd/layers/flows" in out.stderr
+    import pickle
+    with open(ckpt / "param_config.pik", "rb") as f:
+        args = pickle.load(f)                                              # written by general/train.py:428-432
+    args = args if isinstance(args, dict) else vars(args)
+    assert args["dataset"] == "shuffling" and args["set_size"] == 4 and args["coupling_num_flows"] == 2
+    assert (ckpt / "scalars.jsonl").exists()
