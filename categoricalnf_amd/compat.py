@@ -32,6 +32,9 @@ PATCHES = {
                        ("torch.load(checkpoint_file)", "torch.load(checkpoint_file, weights_only=False)"),
                        ("torch.load(checkpoint_file, map_location='cpu')",
                         "torch.load(checkpoint_file, map_location='cpu', weights_only=False)")],
+    # torch >= 2.2: data.Sampler.__init__ no longer takes the data source (datasets/mutils.py:12, set_summation.py:64)
+    "experiments.graph_coloring.datasets.mutils": [("super().__init__(dataset)", "super().__init__()")],
+    "experiments.set_modeling.datasets.set_summation": [("super().__init__(dataset)", "super().__init__()")],
 }
 _loaded = {}
 

@@ -19,7 +19,9 @@ nothing of it is copied here.  Before the script starts this launcher
    unconditionally): `SummaryWriter.add_scalar` lines go to `<log_dir>/scalars.jsonl`, every other writer call is
    accepted and dropped;
 4. changes into the script's directory (the scripts append "../../" to `sys.path` and open `data/...` relative to it,
-   README of the reference: "cd experiments/<task>; python train.py ...") and runs it as `__main__`.
+   README of the reference: "cd experiments/<task>; python train.py ...") and runs it as `__main__`;
+   `--workdir DIR` runs it from DIR instead (a read-only checkout, or `data/` and `checkpoints/` kept elsewhere — the
+   checkout's root is on `sys.path` either way).
 
 The reference's checkpoints (`checkpoint_%07d.tar`), `param_config.pik` and `results.txt` are written by its own
 template, so they are the reference's by construction.  Multi-GPU: the reference's `--use_multi_gpu` wraps the model in
@@ -155,13 +157,15 @@ def prepare(root, install=True):
 
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
-    reference_root, install = None, True
+    reference_root, install, workdir = None, True, None
     while argv and argv[0].startswith("--"):
         flag = argv.pop(0)
         if flag == "--reference_root":
             reference_root = argv.pop(0)
         elif flag == "--no_install":
             install = False
+        elif flag == "--workdir":
+            workdir = argv.pop(0)
         else:
             raise SystemExit("run_reference: unknown launcher flag %s (the script's own flags go after the script name)" % flag)
     if not argv:
@@ -172,13 +176,16 @@ def main(argv=None):
     if not os.path.isfile(script):
         raise SystemExit("run_reference: %s is not a file" % script)
     script = os.path.abspath(script)
+    workdir = os.path.abspath(workdir) if workdir is not None else None
     root = find_root(script, reference_root)
     done = prepare(root, install)
     print("[categoricalnf_amd] %s on %s; layers: %s; torch >= 2 fixes: %s; summary writer: %s" % (
         os.path.relpath(script, root), root,
         "MI355X kernels (%d module aliases)" % len(done["installed"]) if install else "the reference's own",
         ", ".join(sorted(compat.PATCHES)), done["tensorboard"]), flush=True)
-    os.chdir(os.path.dirname(script))
+    if workdir is not None:
+        os.makedirs(workdir, exist_ok=True)
+    os.chdir(workdir if workdir is not None else os.path.dirname(script))
     sys.argv = [script] + argv
     runpy.run_path(script, run_name="__main__")
 

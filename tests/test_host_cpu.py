@@ -714,12 +714,13 @@ def test_reference_cli_runs_unchanged_up_to_the_kernel_boundary(tmp_path):
     the launcher with its own flags, parses them, writes its param_config.pik, builds FlowSetModeling on the drop-in
     layers and the task's data loaders, opens the (stand-in) summary writer and starts its data-dependent
     initialisation — whose first layer call stops at the package's boundary on a machine without a GPU: HipOnlyError,
-    no silent CPU path.  (On an MI355X the same command trains; the layers it reaches are covered by the GPU suite.)"""
+    no silent CPU path.  (On an MI355X the same command trains; the layers it reaches are covered by the GPU suite.)
+    Set summation at set size 16 is BASELINE configs[1]; its `PreSampler` needs the torch >= 2.2 constructor fix."""
     ckpt = tmp_path / "ckpt"
     env = dict(os.environ, MPLBACKEND="Agg", PYTHONDONTWRITEBYTECODE="1", PYTHONPATH=ROOT, CUDA_VISIBLE_DEVICES="",
                HIP_VISIBLE_DEVICES="")
     out = subprocess.run([sys.executable, "-m", "categoricalnf_amd.run_reference", "--reference_root", "/root/reference",
-                          "experiments/set_modeling/train.py", "--dataset", "shuffling", "--set_size", "4",
+                          "experiments/set_modeling/train.py", "--dataset", "summation",
                           "--max_iterations", "4", "--eval_freq", "2", "--batch_size", "16", "--coupling_num_flows", "2",
                           "--coupling_hidden_size", "32", "--checkpoint_path", str(ckpt), "--cluster"],
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=str(tmp_path), timeout=600)
@@ -731,5 +732,54 @@ def test_reference_cli_runs_unchanged_up_to_the_kernel_boundary(tmp_path):
     with open(ckpt / "param_config.pik", "rb") as f:
         args = pickle.load(f)                                              # written by general/train.py:428-432
     args = args if isinstance(args, dict) else vars(args)
-    assert args["dataset"] == "shuffling" and args["set_size"] == 4 and args["coupling_num_flows"] == 2
+    assert args["dataset"] == "summation" and args["set_size"] == 16 and args["coupling_num_flows"] == 2
     assert (ckpt / "scalars.jsonl").exists()
+
+
+@pytest.fixture(scope="module")
+def planted_workdir(tmp_path_factory):
+    """A working directory outside the (read-only) checkout holding `data/` in the reference's graph-colouring format."""
+    from categoricalnf_amd.experiments.graph_coloring_data import generate_planted_dataset
+    work = tmp_path_factory.mktemp("gc_work")
+    generate_planted_dataset(str(work / "data"), num_graphs=600)
+    return work
+
+
+def _run_graph_colouring_cli(work, ckpt, *launcher_flags):
+    env = dict(os.environ, MPLBACKEND="Agg", PYTHONDONTWRITEBYTECODE="1", PYTHONPATH=ROOT, CUDA_VISIBLE_DEVICES="",
+               HIP_VISIBLE_DEVICES="")
+    return subprocess.run([sys.executable, "-m", "categoricalnf_amd.run_reference", *launcher_flags, "--reference_root",
+                           "/root/reference", "--workdir", str(work), "experiments/graph_coloring/train.py", "--dataset", "tiny_3",
+                           "--max_iterations", "4", "--eval_freq", "2", "--batch_size", "16", "--coupling_num_flows", "2",
+                           "--coupling_hidden_size", "32", "--checkpoint_path", str(ckpt), "--cluster"],
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd="/tmp", timeout=600)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/experiments"), reason="reference checkout only exists in the build container")
+def test_reference_graph_colouring_cli_trains_through_the_launcher_on_torch2(planted_workdir):
+    """The launcher without the drop-in (`--no_install`): the reference's experiments/graph_coloring/train.py trains,
+    evaluates, samples, checkpoints, reloads its best checkpoint and tests — on torch 2.10, which it cannot do by itself
+    (Sampler constructor, long-index division, torch.load default; compat.PATCHES applied by the import hook) — from a
+    working directory outside the checkout, on the data set `generate_planted_dataset` wrote in its file format."""
+    ckpt = planted_workdir / "ckpt_plain"
+    out = _run_graph_colouring_cli(planted_workdir, ckpt, "--no_install")
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "the reference's own" in out.stdout and "Num training examples: 480" in out.stdout
+    assert "Validity ratio" in out.stdout and "Reversibility test passed" in out.stdout and "Test performance" in out.stdout
+    files = sorted(os.listdir(ckpt))
+    assert "param_config.pik" in files and "results.txt" in files and "scalars.jsonl" in files
+    assert any(re.fullmatch(r"checkpoint_\d{7}\.tar", f) for f in files)
+    import json
+    tags = {json.loads(l)["tag"] for l in open(ckpt / "scalars.jsonl")}
+    assert any(t.startswith("eval/") for t in tags), sorted(tags)[:10]
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/experiments"), reason="reference checkout only exists in the build container")
+def test_reference_graph_colouring_cli_reaches_the_kernel_boundary(planted_workdir):
+    """Same command with the drop-in installed: GraphNodeFlow of the checkout is assembled from this package's layers and
+    the checkout's (fixed) RGCN sub-network, the task loads the data, and the first layer call refuses the CPU tensor."""
+    out = _run_graph_colouring_cli(planted_workdir, planted_workdir / "ckpt_hip")
+    assert out.returncode != 0
+    assert "MI355X kernels" in out.stdout and "Preparing data dependent initialization" in out.stdout
+    assert "HipOnlyError" in out.stderr and "categoricalnf_amd/layers/" in out.stderr
+    assert "/root/reference/experiments/graph_coloring/train.py" in out.stderr
