@@ -5,6 +5,10 @@ transcendental (v_exp / v_log / v_rcp) for 8 (quarter rate); MI355X has 1024 SIM
     valu_frac = ((INSTS_VALU - TRANS) * 2 + TRANS * 8) / (128 * GRBM_GUI_ACTIVE)
 (MI355X_MICROARCH.md: v_fma_f32 wave64 = 2 cycles on a SIMD-32; GRBM_GUI_ACTIVE is summed over the 8 XCDs, each with
 128 SIMDs: for a 136 us launch it reads 2.73e6 = 8 x 2.5 GHz x 136 us).
+That is a MODEL of the issue cost; beside it `valu_busy` is the MEASURED share of SIMD cycles in which the VALU executed,
+    valu_busy = SQ_ACTIVE_INST_VALU * 4 / (128 * GRBM_GUI_ACTIVE)          (SQ cycle counters tick in quad-cycles)
+and `cyc/inst` = SQ_ACTIVE_INST_VALU * 4 / SQ_INSTS_VALU.  Where the two disagree (the encoder kernels: 0.40 by the
+model, 0.60 measured, 4.8 cycles per instruction) the measured one is what the kernel does; `binds` uses the larger.
 Usage: ceilings.py <pmc dir> [out.json]"""
 import csv, glob, json, os, sys
 from collections import defaultdict
@@ -20,7 +24,7 @@ for path in glob.glob(os.path.join(d, "stats", "**", "*kernel_stats.csv"), recur
     for row in csv.DictReader(open(path)):
         dur[row["Name"]] = float(row["AverageNs"])
 out = []
-print("%-40s %9s %9s %9s %9s %9s %9s  %s" % ("kernel", "us", "alg GB/s", "hbm_frac", "valu_frac", "wait %", "HBM MB", "binds"))
+print("%-40s %9s %9s %9s %9s %9s %9s %9s %9s  %s" % ("kernel", "us", "alg GB/s", "hbm_frac", "valu_frac", "valu_busy", "cyc/inst", "wait %", "HBM MB", "binds"))
 for frag, info in manifest.items():
     names = [k for k in vals if frag in k]
     if not names:
@@ -35,15 +39,19 @@ for frag, info in manifest.items():
     valu = c.get("SQ_INSTS_VALU", 0.0)
     gui = c.get("GRBM_GUI_ACTIVE", 0.0)
     valu_frac = ((valu - trans) * 2 + trans * 8) / (128.0 * gui) if gui else None
+    act = c.get("SQ_ACTIVE_INST_VALU")
+    valu_busy = act * 4.0 / (128.0 * gui) if (gui and act) else None
+    cyc_inst = act * 4.0 / valu if (act and valu) else None
     wait = 100.0 * c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAVE_CYCLES") else None
     mb = (c.get("FETCH_SIZE", 0) * 2 + c.get("WRITE_SIZE", 0)) * 1024 / 1e6 if "FETCH_SIZE" in c else None
-    binds = "hbm" if (valu_frac is None or hbm >= valu_frac) else "valu"
+    binds = "hbm" if hbm >= max(valu_frac or 0.0, valu_busy or 0.0) else "valu"
     row = {"kernel": frag, "what": info["what"], "avg_us": t_ns / 1e3, "alg_GBps": info["alg_bytes"] / t_ns, "hbm_frac": hbm,
-           "valu_frac": valu_frac, "wave_wait_pct": wait, "hbm_MB_per_launch": mb, "valu_insts": valu, "trans_insts": trans,
+           "valu_frac": valu_frac, "valu_busy": valu_busy, "cycles_per_valu_inst": cyc_inst, "wave_wait_pct": wait, "hbm_MB_per_launch": mb, "valu_insts": valu, "trans_insts": trans,
            "clock_GHz_if_unprofiled_duration": gui / 8.0 / t_ns if gui else None, "binds": binds}
     out.append(row)
-    print("%-40s %9.1f %9.0f %9.3f %9s %9s %9s  %s" % (info["what"][:40], t_ns / 1e3, info["alg_bytes"] / t_ns, hbm,
-          "%.3f" % valu_frac if valu_frac is not None else "-", "%.0f" % wait if wait is not None else "-",
+    print("%-40s %9.1f %9.0f %9.3f %9s %9s %9s %9s %9s  %s" % (info["what"][:40], t_ns / 1e3, info["alg_bytes"] / t_ns, hbm,
+          "%.3f" % valu_frac if valu_frac is not None else "-", "%.3f" % valu_busy if valu_busy is not None else "-",
+          "%.1f" % cyc_inst if cyc_inst is not None else "-", "%.0f" % wait if wait is not None else "-",
           "%.1f" % mb if mb is not None else "-", binds))
 if len(sys.argv) > 2:
     json.dump(out, open(sys.argv[2], "w"), indent=1)

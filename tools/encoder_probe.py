@@ -31,6 +31,9 @@ for C in (16, 3, 51):
     ok = (ops.encoder_decode(z, table, prior) == categ).float().mean().item()
     print("C=%2d  sample %6.1f us | forward %6.1f us | decode %6.1f us | decode==categ %.4f" % (C, t_s, t_f, t_d, ok), flush=True)
 
+if os.environ.get("CNF_PROBE_SHORT"):
+    sys.exit(0)
+
 # ---- LDS-resident vs class-tiled kernels at the same shapes, backward included; large vocabularies ----------------
 from categoricalnf_amd import functional as Fn
 
