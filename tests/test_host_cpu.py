@@ -783,3 +783,19 @@ def test_reference_graph_colouring_cli_reaches_the_kernel_boundary(planted_workd
     assert "MI355X kernels" in out.stdout and "Preparing data dependent initialization" in out.stdout
     assert "HipOnlyError" in out.stderr and "categoricalnf_amd/layers/" in out.stderr
     assert "/root/reference/experiments/graph_coloring/train.py" in out.stderr
+
+
+def test_markov_corpus_statistics():
+    """The synthetic language-modelling source: stationary pair distribution, entropy rate between 0 and the
+    context-free entropy, samples that follow the transition table (cross-entropy of a large sample under the true model
+    equals the entropy rate), reproducible under a seed."""
+    from categoricalnf_amd.experiments.run_language_modeling import MarkovCorpus
+    c = MarkovCorpus(vocab_size=9, alpha=0.3, seed=5)
+    assert abs(c.pair_stationary.sum() - 1) < 1e-12
+    assert np.abs(np.einsum("ab,abc->bc", c.pair_stationary, c.T) - c.pair_stationary).max() < 1e-12
+    assert 0 < c.entropy_rate() < c.unigram_entropy() <= np.log2(9) + 1e-9
+    x = c.sample(400, 200, np.random.RandomState(0))
+    assert x.shape == (400, 200) and x.min() >= 0 and x.max() < 9
+    assert np.array_equal(x, c.sample(400, 200, np.random.RandomState(0)))
+    nll = -np.log2(c.T[x[:, :-2], x[:, 1:-1], x[:, 2:]]).mean()
+    assert abs(nll - c.entropy_rate()) < 0.03, (nll, c.entropy_rate())
