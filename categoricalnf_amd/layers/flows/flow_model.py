@@ -143,7 +143,9 @@ class FlowModel(nn.Module):
                 and z.dtype == torch.float32 and ops.FUSE_LAYERS)
 
     def reverse(self, z):
-        return self.forward(z, reverse)
+        """The inverse pass.  (The reference's one-liner, flow_model.py:56-57, passes an undefined name and can only
+        raise NameError; nothing calls it.)"""
+        return self.forward(z, reverse=True)
 
     def test_reversibility(self, z, **kwargs):
         """flow_model.py:60-78 — per-layer fwd∘inv check, exact-zero criterion like the reference."""
