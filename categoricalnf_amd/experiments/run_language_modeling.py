@@ -127,7 +127,7 @@ def draw_batch(corpus, args, num, rng, device):
     x = corpus.sample(num, args.max_seq_len, rng)
     if args.variable_length:
         length = rng.randint(max(2, args.max_seq_len // 4), args.max_seq_len + 1, size=num)
-        length[0] = args.max_seq_len                      # the batch keeps its full width (task.py:123 clips to the maximum)
+        length[0] = args.max_seq_len                      # training batches keep one shape (no clipping, no reallocation)
         x[np.arange(args.max_seq_len)[None, :] >= length[:, None]] = 0
     else:
         length = np.full(num, args.max_seq_len)
@@ -136,6 +136,7 @@ def draw_batch(corpus, args, num, rng, device):
 
 def sentence_nll(model, prior, x, length, beta=1.0):
     """[B] negative log-likelihood per character, task.py:75-119 (`_train_batch_flow`, `_calc_loss`)."""
+    x = x[:, :int(length.max())]                          # the batch is as wide as its longest sentence (task.py:123)
     z, ldj = model(x, reverse=False, beta=beta, length=length)
     pad = create_channel_mask(length, max_len=x.size(1))
     neglog = -(prior.log_prob(z) * pad).sum(dim=[1, 2])
