@@ -15,7 +15,12 @@ files — is reachable from here.  The data set is therefore a synthetic charact
 Dirichlet distribution (`MarkovCorpus`).  That gives the run a yardstick no real corpus has: the bits per character of a
 perfect model are `corpus.entropy_rate()` exactly, and a model that ignores context cannot do better than
 `corpus.unigram_entropy()`.  `--variable_length` draws sentence lengths uniformly from [max_seq_len / 4, max_seq_len] and
-pads, which exercises the padding masks the way Penn Treebank does.  Single GPU."""
+pads, which exercises the padding masks the way Penn Treebank does.
+
+Multi-GPU: one process per GPU under `python -m torch.distributed.run --nproc-per-node N ... -m
+categoricalnf_amd.experiments.run_language_modeling ...` — every rank draws its own `batch_size / N` sentences, gradients
+are all-reduced by DistributedDataParallel over RCCL, the held-out sentences are sharded over the ranks and their
+(sum of NLL, count) pair is all-reduced once per evaluation (`categoricalnf_amd.distributed`)."""
 import argparse
 import contextlib
 import io
@@ -25,6 +30,7 @@ import time
 import numpy as np
 import torch
 
+from ..distributed import allreduce_nll, init_process_group, shard_bounds, wrap_ddp
 from ..host_utils import create_channel_mask
 from ..layers.flows.distributions import LogisticDistribution
 from .language_modeling import FlowLanguageModeling
@@ -104,6 +110,8 @@ def parse(argv=None):
     p.add_argument("--beta_scheduler_end_val", type=float, default=2.0)
     p.add_argument("--beta_scheduler_step_size", type=int, default=5000)
     p.add_argument("--beta_scheduler_logit", type=float, default=2.0)
+    p.add_argument("--backend", default=None, help="torch.distributed backend when started with WORLD_SIZE > 1 (nccl = RCCL)")
+    p.add_argument("--share_device", action="store_true", help="TEST ONLY: every rank on cuda:0 (1-GPU box, --backend gloo)")
     return p.parse_args(argv)
 
 
@@ -144,27 +152,37 @@ def sentence_nll(model, prior, x, length, beta=1.0):
 
 
 @torch.no_grad()
-def evaluate(model, prior, val, batch_size):
+def evaluate(model, prior, val, batch_size, rank=0, world=1):
     """Bits per character on the held-out sentences: every sentence weighs the same, like the reference's mean of
-    per-sentence losses (task.py:107-113)."""
-    model.eval()
+    per-sentence losses (task.py:107-113).  The sentences are sharded over the ranks; one all-reduce of (sum, count)."""
+    inner = model.module if hasattr(model, "module") else model
+    inner.eval()
     x_all, len_all = val
-    total = 0.0
-    for i in range(0, x_all.shape[0], batch_size):
-        total += float(sentence_nll(model, prior, x_all[i:i + batch_size], len_all[i:i + batch_size]).double().sum())
-    model.train()
-    return total / x_all.shape[0] * LOG2E
+    lo, hi = shard_bounds(x_all.shape[0], rank, world)
+    total = torch.zeros(2, dtype=torch.float64, device=x_all.device)
+    for i in range(lo, hi, batch_size):
+        j = min(i + batch_size, hi)
+        total[0] += sentence_nll(inner, prior, x_all[i:j], len_all[i:j]).double().sum()
+        total[1] += j - i
+    mean_nll, bpc = allreduce_nll(total)
+    inner.train()
+    return bpc
 
 
 def main(argv=None):
     args = parse(argv)
-    device = torch.device("cuda", 0)
+    rank, local_rank, world = init_process_group("gloo" if args.share_device else args.backend)
+    device = torch.device("cuda", local_rank if (world > 1 and not args.share_device) else 0)
+    torch.cuda.set_device(device)
     torch.manual_seed(args.seed)
+    say = (lambda *a: print(*a, flush=True)) if rank == 0 else (lambda *a: None)
     corpus = MarkovCorpus(args.vocab_size, args.source_alpha, args.source_seed)
-    print("synthetic source: %d symbols, entropy rate %.4f bits per character (context-free optimum %.4f)"
-          % (args.vocab_size, corpus.entropy_rate(), corpus.unigram_entropy()), flush=True)
+    say("synthetic source: %d symbols, entropy rate %.4f bits per character (context-free optimum %.4f)"
+        % (args.vocab_size, corpus.entropy_rate(), corpus.unigram_entropy()))
     val = draw_batch(corpus, args, args.num_val, np.random.RandomState(123), device)      # fixed held-out sentences
-    rng = np.random.RandomState(args.seed)
+    init_rng = np.random.RandomState(args.seed)                    # the same on every rank: replicas start identical
+    rng = np.random.RandomState(args.seed + 1000 * rank + 1)       # every rank draws different training sentences
+    per_rank = max(1, args.batch_size // world)
 
     class Vocab:
         vectors = None
@@ -180,50 +198,53 @@ def main(argv=None):
     if state["iteration"] == 0 and not args.only_eval:
         init = []                                         # data-dependent ActNorm initialisation (general/task.py:112-128)
         for _ in range(8):
-            x, length = draw_batch(corpus, args, args.batch_size, rng, device)
+            x, length = draw_batch(corpus, args, args.batch_size, init_rng, device)
             init.append((x, {"length": length}))
         with contextlib.redirect_stdout(io.StringIO()):
             model.initialize_data_dependent(init)
-    if not args.only_eval and args.checkpoint_path:
+    ddp = wrap_ddp(model, device)
+    if not args.only_eval and args.checkpoint_path and rank == 0:
         save_args(args.checkpoint_path, args)
     if args.only_eval:
-        bpc = evaluate(model, prior, val, args.batch_size)
-        print("validation %.4f bits per character (source %.4f)" % (bpc, corpus.entropy_rate()), flush=True)
+        bpc = evaluate(ddp, prior, val, args.batch_size, rank, world)
+        say("validation %.4f bits per character (source %.4f)" % (bpc, corpus.entropy_rate()))
         return {"val_bpc": bpc, "entropy_rate": corpus.entropy_rate()}
 
-    model.train()
+    ddp.train()
     best = state["best_save_dict"]
     t0, run_loss, seen = time.time(), torch.zeros((), device=device), 0
     for it in range(state["iteration"], args.max_iterations):
-        x, length = draw_batch(corpus, args, args.batch_size, rng, device)
-        loss = sentence_nll(model, prior, x, length, beta=beta_at(args, it)).mean()
+        x, length = draw_batch(corpus, args, per_rank, rng, device)
+        loss = sentence_nll(ddp, prior, x, length, beta=beta_at(args, it)).mean()
         optimizer.zero_grad(set_to_none=True)
         loss.backward()
-        torch.nn.utils.clip_grad_norm_(model.parameters(), args.max_gradient_norm)
+        torch.nn.utils.clip_grad_norm_(ddp.parameters(), args.max_gradient_norm)
         optimizer.step()
         scheduler.step()
         run_loss += loss.detach()
         seen += 1
         step = it + 1
         if step % args.print_freq == 0:
-            print("iteration %7d | train %.4f bits per character (beta %.2f) | %.1f it/s"
-                  % (step, float(run_loss) / seen * LOG2E, beta_at(args, it), seen / (time.time() - t0)), flush=True)
+            say("iteration %7d | train %.4f bits per character (beta %.2f) | %.1f it/s"
+                % (step, float(run_loss) / seen * LOG2E, beta_at(args, it), seen / (time.time() - t0)))
             t0, seen = time.time(), 0
             run_loss.zero_()
         if step % args.eval_freq == 0 or step == args.max_iterations:
-            bpc = evaluate(model, prior, val, args.batch_size)
+            bpc = evaluate(ddp, prior, val, args.batch_size, rank, world)
             state["evaluation_dict"][step] = bpc
-            print("iteration %7d | validation %.4f bits per character (source %.4f, context-free %.4f)"
-                  % (step, bpc, corpus.entropy_rate(), corpus.unigram_entropy()), flush=True)
-            if bpc < best["metric"] and args.checkpoint_path:
+            say("iteration %7d | validation %.4f bits per character (source %.4f, context-free %.4f)"
+                % (step, bpc, corpus.entropy_rate(), corpus.unigram_entropy()))
+            if bpc < best["metric"] and args.checkpoint_path and rank == 0:
                 if best["file"] and os.path.isfile(best["file"]):
                     os.remove(best["file"])
                 best.update(file=checkpoint_file(args.checkpoint_path, step), metric=bpc, detailed_metrics={"val_bpc": bpc})
-                save_checkpoint(args.checkpoint_path, step, model, optimizer, scheduler, best_save_dict=best,
+                save_checkpoint(args.checkpoint_path, step, ddp, optimizer, scheduler, best_save_dict=best,
                                 evaluation_dict=state["evaluation_dict"])
-    bpc = evaluate(model, prior, val, args.batch_size)
-    print("final: validation %.4f bits per character; source entropy rate %.4f, context-free optimum %.4f"
-          % (bpc, corpus.entropy_rate(), corpus.unigram_entropy()), flush=True)
+    bpc = evaluate(ddp, prior, val, args.batch_size, rank, world)
+    say("final: validation %.4f bits per character; source entropy rate %.4f, context-free optimum %.4f"
+        % (bpc, corpus.entropy_rate(), corpus.unigram_entropy()))
+    if world > 1:
+        torch.distributed.barrier()
     return {"val_bpc": bpc, "entropy_rate": corpus.entropy_rate(), "unigram_entropy": corpus.unigram_entropy(),
             "best_file": best["file"]}
 

@@ -562,6 +562,9 @@ def test_flow_stack_config0(c):
     bpd = float(np.log2(np.exp(1)) * nll.mean().item())
     assert abs(bpd - float(c.bpd)) < 0.01
     assert torch.equal(dec.cpu(), c.decoded)
+    with torch.no_grad():
+        dec_r, _ = model.reverse(g(c.z))                     # the convenience method = forward(reverse=True); no padding here
+    assert torch.equal(dec_r.cpu(), c.decoded)
     # FlowModel.nll: the last affine coupling and the NLL assembly as one kernel — same latents, log-det and NLL
     sums = torch.zeros(2, dtype=torch.float64, device="cuda")
     z2, ldj2, nll2 = model.nll(g(c.categ), length=ln, noise=g(c.u), sums=sums)
@@ -1499,3 +1502,25 @@ def test_language_modelling_driver_trains_towards_the_source_entropy(tmp_path):
     assert out["best_file"] and os.path.isfile(out["best_file"])
     again = R.main(common + ["--only_eval"])
     assert abs(again["val_bpc"] - out["val_bpc"]) < 0.05, (again, out)
+
+
+def test_language_modelling_driver_two_ranks(tmp_path):
+    """§8e on the third host loop: 2 ranks (sharing cuda:0 over gloo here; RCCL with the default backend on a multi-GPU
+    node) train under DDP on their own sentences, evaluate shards of the held-out set with one all-reduce, and only rank 0
+    prints and writes the checkpoint."""
+    import re, socket, subprocess, sys
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), "-m", "categoricalnf_amd.experiments.run_language_modeling",
+                        "--share_device", "--vocab_size", "9", "--source_alpha", "0.3", "--max_seq_len", "32", "--batch_size", "64",
+                        "--num_val", "250", "--coupling_hidden_size", "64", "--coupling_hidden_layers", "1",
+                        "--coupling_num_mixtures", "9", "--variable_length", "--max_iterations", "60", "--eval_freq", "30",
+                        "--print_freq", "30", "--checkpoint_path", str(tmp_path / "lm2")],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    finals = re.findall(r"final: validation ([0-9.]+) bits per character", r.stdout)
+    assert len(finals) == 1 and 1.9 < float(finals[0]) < 4.0, r.stdout[-1500:]
+    assert len(re.findall(r"iteration +30 \| validation", r.stdout)) == 1
+    assert any(f.endswith(".tar") for f in os.listdir(tmp_path / "lm2"))
