@@ -72,3 +72,53 @@ def forbid_grad(what, *tensors):
         raise NotImplementedError(
             "%s: this call form has no backward kernel; wrap the call in torch.no_grad() or use the differentiable "
             "form of the layer." % what)
+
+
+class FlatParameters:
+    """The trainable parameters of a module re-pointed at slices of ONE buffer, their gradients at slices of another.
+
+    The host cost of an optimiser step, of gradient clipping and of zeroing gradients grows with the NUMBER of parameter
+    tensors (the default set-modelling flow has 827; at the reference's batch sizes the training step is host-paced).
+    Element-wise optimisers (Adam, RAdam, SGD) and a global gradient norm compute the same thing on the flat buffer in a
+    handful of launches.  Measured on the default set-modelling flow at batch 64: 23.0 -> 21.8 ms per step (the profiler's
+    5.8 ms for RAdam + clipping, `profiles/r02_host_profile_train_step.txt`, is inflated by its own per-call overhead);
+    at batch 1024 the step is no longer host-bound and nothing changes (33.5 -> 33.0 ms).
+
+    Use after the model is on its device and after the data-dependent initialisation (ActNorm re-binds `.data` there):
+
+        flat = FlatParameters(model)
+        optimizer = torch.optim.RAdam(flat.parameters(), lr=...)
+        ...
+        flat.zero_grad(); loss.backward(); torch.nn.utils.clip_grad_norm_(flat.parameters(), 0.25); optimizer.step()
+
+    Autograd accumulates into the existing `.grad` views in place, so `zero_grad` must keep them (never set them to None),
+    and the module's parameters must not be re-bound afterwards (`load_state_dict` copies in place and is fine).  Not for
+    DistributedDataParallel, whose gradient buckets own the `.grad` views."""
+
+    def __init__(self, module):
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        if not self.params:
+            raise ValueError("FlatParameters: the module has no trainable parameters")
+        first = self.params[0]
+        if any(p.device != first.device or p.dtype != first.dtype for p in self.params):
+            raise ValueError("FlatParameters: parameters on several devices / of several dtypes")
+        self.flat = torch.nn.Parameter(torch.cat([p.detach().reshape(-1) for p in self.params]))
+        self.flat.grad = torch.zeros_like(self.flat)
+        offset = 0
+        for p in self.params:
+            n = p.numel()
+            p.data = self.flat.data[offset:offset + n].view(p.shape)
+            p.grad = self.flat.grad[offset:offset + n].view(p.shape)
+            offset += n
+
+    def parameters(self):
+        return [self.flat]
+
+    def zero_grad(self):
+        self.flat.grad.zero_()
+
+    def intact(self):
+        """True while every parameter and gradient still lives in the flat buffers."""
+        lo, hi = self.flat.data_ptr(), self.flat.data_ptr() + self.flat.numel() * self.flat.element_size()
+        glo, ghi = self.flat.grad.data_ptr(), self.flat.grad.data_ptr() + self.flat.numel() * self.flat.element_size()
+        return all(lo <= p.data_ptr() < hi and p.grad is not None and glo <= p.grad.data_ptr() < ghi for p in self.params)

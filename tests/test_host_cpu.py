@@ -799,3 +799,36 @@ def test_markov_corpus_statistics():
     assert np.array_equal(x, c.sample(400, 200, np.random.RandomState(0)))
     nll = -np.log2(c.T[x[:, :-2], x[:, 1:-1], x[:, 2:]]).mean()
     assert abs(nll - c.entropy_rate()) < 0.03, (nll, c.entropy_rate())
+
+
+def test_flat_parameters_train_like_per_tensor_parameters():
+    """FlatParameters: RAdam + global-norm clipping on one flat buffer == the same on the separate tensors (same updates up
+    to the rounding of the clipping norm), gradients accumulate into the views, load_state_dict keeps the views."""
+    from categoricalnf_amd.host_utils import FlatParameters
+
+    def make():
+        torch.manual_seed(0)
+        return nn.Sequential(nn.Linear(5, 16), nn.Tanh(), nn.Linear(16, 16), nn.LayerNorm(16), nn.Linear(16, 3))
+    a, b = make(), make()
+    flat = FlatParameters(b)
+    assert flat.intact() and flat.flat.numel() == sum(p.numel() for p in a.parameters())
+    opt_a = torch.optim.RAdam(a.parameters(), lr=1e-2)
+    opt_b = torch.optim.RAdam(flat.parameters(), lr=1e-2)
+    g = torch.Generator().manual_seed(1)
+    for _ in range(12):
+        x, y = torch.randn(32, 5, generator=g), torch.randn(32, 3, generator=g)
+        opt_a.zero_grad(set_to_none=True)
+        ((a(x) - y) ** 2).mean().backward()
+        na = torch.nn.utils.clip_grad_norm_(a.parameters(), 0.25)
+        opt_a.step()
+        flat.zero_grad()
+        ((b(x) - y) ** 2).mean().backward()
+        nb = torch.nn.utils.clip_grad_norm_(flat.parameters(), 0.25)
+        opt_b.step()
+        assert flat.intact()
+        torch.testing.assert_close(na, nb, rtol=1e-5, atol=1e-7)
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        torch.testing.assert_close(pa, pb, rtol=1e-5, atol=1e-6)
+    b.load_state_dict(a.state_dict())
+    assert flat.intact()
+    torch.testing.assert_close(flat.flat.detach(), torch.cat([p.detach().reshape(-1) for p in a.parameters()]))

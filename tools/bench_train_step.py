@@ -20,15 +20,23 @@ draw = lambda n: torch.from_numpy(np.stack([rng.permutation(16) for _ in range(n
 ln = torch.full((B,), 16, dtype=torch.long, device="cuda")
 with contextlib.redirect_stdout(io.StringIO()):
     model.initialize_data_dependent([(draw(B), {"length": ln}) for _ in range(2)])
-opt = torch.optim.RAdam(model.parameters(), lr=7.5e-4)        # the reference's default optimiser
+FLAT = len(sys.argv) > 3 and sys.argv[3] == "flat"             # optimiser / clipping / zero_grad on one flat buffer
+flat = None
+if FLAT:
+    from categoricalnf_amd.host_utils import FlatParameters
+    flat = FlatParameters(model)
+opt = torch.optim.RAdam(flat.parameters() if FLAT else model.parameters(), lr=7.5e-4)        # the reference's default optimiser
 xs = [draw(B) for _ in range(4)]
 
 def step(i):
     z, ldj = model(xs[i % 4], reverse=False, length=ln, beta=1)
     loss = Fn.PriorNllFn.apply(z, ldj, ln, None).mean()
-    opt.zero_grad(set_to_none=True)
+    if FLAT:
+        flat.zero_grad()
+    else:
+        opt.zero_grad(set_to_none=True)
     loss.backward()
-    torch.nn.utils.clip_grad_norm_(model.parameters(), 0.25)
+    torch.nn.utils.clip_grad_norm_(flat.parameters() if FLAT else model.parameters(), 0.25)
     opt.step()
     return loss
 
@@ -40,4 +48,4 @@ for i in range(steps):
     loss = step(i)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
-print("batch %d eager  : %.2f ms / training step (%.0f sets/s), loss %.4f" % (B, dt * 1e3, B / dt, float(loss.detach())))
+print("batch %d eager%s: %.2f ms / training step (%.0f sets/s), loss %.4f" % (B, " (flat optimiser)" if FLAT else "  ", dt * 1e3, B / dt, float(loss.detach())))
