@@ -39,6 +39,9 @@ bash tools/pmc_passes.sh flow_fused python tools/flow_traffic_workload.py fused 
 bash tools/pmc_passes.sh flow_unfused python tools/flow_traffic_workload.py unfused > /dev/null 2>&1
 python tools/flow_traffic.py "$OUT/flow_fused" "$OUT/flow_unfused" "$OUT/flow_traffic.json" > "$OUT/flow_traffic.txt" 2>&1; head -12 "$OUT/flow_traffic.txt"
 ( for b in 64 256 1024; do timeout 300 python tools/bench_train_step.py $b 20 2>&1 | grep "^batch"; done ) > "$OUT/train_step.txt"; cat "$OUT/train_step.txt"
+( for b in 64 1024; do timeout 300 python tools/bench_train_step.py $b 30 2>&1 | grep "^batch"; timeout 300 python tools/bench_train_step.py $b 30 flat 2>&1 | grep "^batch"; done ) > "$OUT/train_step_flat.txt"; cat "$OUT/train_step_flat.txt"
+timeout 200 python tools/host_profile_train_step.py 64 30 > "$OUT/host_profile.txt" 2>&1; head -6 "$OUT/host_profile.txt"
+bash tools/pmc_passes.sh enc python tools/pmc_encoder_workload.py > "$OUT/pmc_enc.log" 2>&1
 bash tools/mfma_util.sh mfma_set python tools/bench_train_step.py 8192 6 > "$OUT/mfma.log" 2>&1; tail -3 "$OUT/mfma.log" | cut -c1-300
 rm -rf "$OUT/prof_train"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_train" -o train -- \
