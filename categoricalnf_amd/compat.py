@@ -35,6 +35,11 @@ PATCHES = {
     # torch >= 2.2: data.Sampler.__init__ no longer takes the data source (datasets/mutils.py:12, set_summation.py:64)
     "experiments.graph_coloring.datasets.mutils": [("super().__init__(dataset)", "super().__init__()")],
     "experiments.set_modeling.datasets.set_summation": [("super().__init__(dataset)", "super().__init__()")],
+    # a float64 numpy prior handed to the last bias (graphCNF.py:77 -> decoder.py:51-54 -> help_layers.py:106-107): torch >= 2
+    # refuses to add a double bias to float activations.  Only reached without install(): the drop-in's own
+    # layers.networks.help_layers keeps the parameter's dtype
+    "layers.networks.help_layers": [("self.main_net[-1].bias.data = bias",
+                                     "self.main_net[-1].bias.data = bias.to(self.main_net[-1].bias.dtype)")],
 }
 _loaded = {}
 
