@@ -11,7 +11,12 @@ come from the length-bucketed sampler, the loss is the per-node negative log-lik
 reports bits per node on the validation graphs and the share of VALID colourings among samples drawn for them
 (task.py:170-215), checkpoints use the reference's file format (`run_set_modeling.save_checkpoint`).  The reference's
 data files are not reachable from here: `--generate_data` writes a synthetic set in the same format (planted colourings,
-`graph_coloring_data.generate_planted_dataset`) when the files are missing.  Single GPU."""
+`graph_coloring_data.generate_planted_dataset`) when the files are missing.
+
+Multi-GPU: one process per GPU under `python -m torch.distributed.run --nproc-per-node N ... -m
+categoricalnf_amd.experiments.run_graph_coloring ...`: every rank walks its own bucketed order of the training graphs with
+`batch_size / N` graphs per step, gradients are all-reduced by DistributedDataParallel over RCCL, evaluation batches are dealt
+out to the ranks round-robin and (sum of NLL, graphs, valid colourings) is all-reduced once."""
 import argparse
 import contextlib
 import io
@@ -21,6 +26,7 @@ import time
 import numpy as np
 import torch
 
+from ..distributed import init_process_group, wrap_ddp
 from ..layers.flows.distributions import LogisticDistribution
 from .graph_coloring import GraphNodeFlow, flow_nll, generation_validity
 from .graph_coloring_data import GraphColoringDataset, generate_planted_dataset
@@ -58,6 +64,8 @@ def parse(argv=None):
     p.add_argument("--beta_scheduler_end_val", type=float, default=2.0)
     p.add_argument("--beta_scheduler_step_size", type=int, default=5000)
     p.add_argument("--beta_scheduler_logit", type=float, default=2.0)
+    p.add_argument("--backend", default=None, help="torch.distributed backend when started with WORLD_SIZE > 1 (nccl = RCCL)")
+    p.add_argument("--share_device", action="store_true", help="TEST ONLY: every rank on cuda:0 (1-GPU box, --backend gloo)")
     return p.parse_args(argv)
 
 
@@ -91,38 +99,56 @@ def batches(dataset, batch_size, device, drop_last):
 
 
 @torch.no_grad()
-def evaluate(model, prior, dataset, device, batch_size, max_graphs=None):
-    """(bits per node, validity of sampled colourings) on `dataset`."""
-    model.eval()
-    total, count, seen, sample_on = 0.0, 0, 0, []
-    for nodes, adjacency, length in batches(dataset, batch_size, device, drop_last=False):
-        nll, _ = flow_nll(model, prior, nodes, adjacency, length)
-        total += float(nll.double().sum())
-        count += nodes.shape[0]
-        sample_on.append((nodes, adjacency, length))
-        seen += nodes.shape[0]
+def evaluate(model, prior, dataset, device, batch_size, max_graphs=None, rank=0, world=1):
+    """(bits per node, validity of sampled colourings) on `dataset`; with several ranks the batches are dealt out
+    round-robin and the three sums are all-reduced once."""
+    inner = model.module if hasattr(model, "module") else model
+    inner.eval()
+    sums = torch.zeros(3, dtype=torch.float64, device=device)          # sum of nll, graphs, valid colourings
+    seen = 0
+    state = np.random.get_state()
+    np.random.seed(1234)                     # every rank must see the SAME batch order to take its share of it
+    order = list(dataset.get_sampler(batch_size, drop_last=False))
+    np.random.set_state(state)
+    for b, idx in enumerate(order):
         if max_graphs is not None and seen >= max_graphs:
             break
-    validity = generation_validity(model, prior, sample_on, type(dataset))
-    model.train()
-    return total / max(count, 1) * LOG2E, validity["valid_ratio"]
+        seen += len(idx)
+        if b % world != rank:
+            continue
+        nodes, adjacency, length = collate(dataset, idx, device)
+        nll, _ = flow_nll(inner, prior, nodes, adjacency, length)
+        validity = generation_validity(inner, prior, [(nodes, adjacency, length)], type(dataset))
+        sums[0] += nll.double().sum()
+        sums[1] += nodes.shape[0]
+        sums[2] += validity["valid_ratio"] * nodes.shape[0]
+    if world > 1:
+        torch.distributed.all_reduce(sums)
+    inner.train()
+    total, count, valid = (float(v) for v in sums)
+    return total / max(count, 1.0) * LOG2E, valid / max(count, 1.0)
 
 
 def main(argv=None):
     args = parse(argv)
-    device = torch.device("cuda", 0)
+    rank, local_rank, world = init_process_group("gloo" if args.share_device else args.backend)
+    device = torch.device("cuda", local_rank if (world > 1 and not args.share_device) else 0)
+    torch.cuda.set_device(device)
+    say = (lambda *a: print(*a, flush=True)) if rank == 0 else (lambda *a: None)
     torch.manual_seed(args.seed)
     np.random.seed(args.seed)
     size, colours = args.dataset.split("_")[0], int(args.dataset.split("_")[1])
     GraphColoringDataset.set_dataset(prefix="_" + size, num_colors=colours)
     GraphColoringDataset.DATASET_NODES = GraphColoringDataset.DATASET_VAL_IDX = None          # a new data set selection
     data_file = os.path.join(args.data_root, GraphColoringDataset.DATA_FILENAME)
-    if args.generate_data and not os.path.isfile(data_file):
+    if args.generate_data and not os.path.isfile(data_file) and rank == 0:
         lo, hi = SIZES.get(size, (10, 20))
-        print("generating %d synthetic graphs with %d..%d nodes (planted %d-colourings) under %s"
-              % (args.num_graphs, lo, hi, colours, args.data_root), flush=True)
+        say("generating %d synthetic graphs with %d..%d nodes (planted %d-colourings) under %s"
+            % (args.num_graphs, lo, hi, colours, args.data_root))
         generate_planted_dataset(args.data_root, prefix="_" + size, num_colors=colours, num_graphs=args.num_graphs,
                                  n_min=lo, n_max=hi, seed=args.seed)
+    if world > 1:
+        torch.distributed.barrier()                  # the files are there before anyone reads them
     train_set = GraphColoringDataset(num_colors=colours, train=True, data_root=args.data_root)
     val_set = GraphColoringDataset(num_colors=colours, val=True, data_root=args.data_root)
     test_set = GraphColoringDataset(num_colors=colours, test=True, data_root=args.data_root)
@@ -136,9 +162,11 @@ def main(argv=None):
     if args.checkpoint_path and os.path.exists(args.checkpoint_path):
         state.update(load_checkpoint(args.checkpoint_path, model, optimizer, scheduler, device=device))
 
+    per_rank = max(1, args.batch_size // world)
+
     def stream():
         while True:
-            yield from batches(train_set, args.batch_size, device, drop_last=True)
+            yield from batches(train_set, per_rank, device, drop_last=True)
     feed = stream()
     if state["iteration"] == 0 and not args.only_eval:
         # data-dependent ActNorm initialisation on 16 batches (task.py:144-157), full-width graphs
@@ -155,49 +183,53 @@ def main(argv=None):
         nodes, adjacency, length = next(feed)
         assert model.test_permutation(nodes, adjacency, length), "[!] ERROR: Permutation test failed."
         assert model.test_reversibility(nodes, adjacency, length), "[!] ERROR: Reversibility test failed."
-    if not args.only_eval and args.checkpoint_path:
+    np.random.seed(args.seed + 1000 * rank + 1)          # from here on every rank draws its own order of training graphs
+    ddp = wrap_ddp(model, device)
+    if not args.only_eval and args.checkpoint_path and rank == 0:
         save_args(args.checkpoint_path, args)
     if args.only_eval:
-        val_bpd, val_valid = evaluate(model, prior, val_set, device, args.eval_batch_size)
-        print("validation %.4f bits per node, %.2f %% valid colourings" % (val_bpd, 100 * val_valid), flush=True)
+        val_bpd, val_valid = evaluate(ddp, prior, val_set, device, args.eval_batch_size, rank=rank, world=world)
+        say("validation %.4f bits per node, %.2f %% valid colourings" % (val_bpd, 100 * val_valid))
         return {"val_bpd": val_bpd, "val_valid_ratio": val_valid}
 
-    model.train()
+    ddp.train()
     best = state["best_save_dict"]
     t0, run_loss, seen = time.time(), torch.zeros((), device=device), 0
     for it in range(state["iteration"], args.max_iterations):
         nodes, adjacency, length = next(feed)
-        nll, _ = flow_nll(model, prior, nodes, adjacency, length, beta=beta_at(args, it))
+        nll, _ = flow_nll(ddp, prior, nodes, adjacency, length, beta=beta_at(args, it))
         loss = nll.mean()
         optimizer.zero_grad(set_to_none=True)
         loss.backward()
-        torch.nn.utils.clip_grad_norm_(model.parameters(), args.max_gradient_norm)
+        torch.nn.utils.clip_grad_norm_(ddp.parameters(), args.max_gradient_norm)
         optimizer.step()
         scheduler.step()
         run_loss += loss.detach()
         seen += 1
         step = it + 1
         if step % args.print_freq == 0:
-            print("iteration %7d | train %.4f bits per node (beta %.2f) | %.1f it/s"
-                  % (step, float(run_loss) / seen * LOG2E, beta_at(args, it), seen / (time.time() - t0)), flush=True)
+            say("iteration %7d | train %.4f bits per node (beta %.2f) | %.1f it/s"
+                % (step, float(run_loss) / seen * LOG2E, beta_at(args, it), seen / (time.time() - t0)))
             t0, seen = time.time(), 0
             run_loss.zero_()
         if step % args.eval_freq == 0 or step == args.max_iterations:
-            val_bpd, val_valid = evaluate(model, prior, val_set, device, args.eval_batch_size, max_graphs=8192)
+            val_bpd, val_valid = evaluate(ddp, prior, val_set, device, args.eval_batch_size, max_graphs=8192, rank=rank,
+                                          world=world)
             state["evaluation_dict"][step] = val_bpd
-            print("iteration %7d | validation %.4f bits per node, %.2f %% valid colourings" % (step, val_bpd, 100 * val_valid),
-                  flush=True)
-            if val_bpd < best["metric"] and args.checkpoint_path:
+            say("iteration %7d | validation %.4f bits per node, %.2f %% valid colourings" % (step, val_bpd, 100 * val_valid))
+            if val_bpd < best["metric"] and args.checkpoint_path and rank == 0:
                 if best["file"] and os.path.isfile(best["file"]):
                     os.remove(best["file"])
                 best.update(file=checkpoint_file(args.checkpoint_path, step), metric=val_bpd,
                             detailed_metrics={"val_bpd": val_bpd, "valid_ratio": val_valid})
-                save_checkpoint(args.checkpoint_path, step, model, optimizer, scheduler, best_save_dict=best,
+                save_checkpoint(args.checkpoint_path, step, ddp, optimizer, scheduler, best_save_dict=best,
                                 evaluation_dict=state["evaluation_dict"])
-    val_bpd, val_valid = evaluate(model, prior, val_set, device, args.eval_batch_size)
-    test_bpd, test_valid = evaluate(model, prior, test_set, device, args.eval_batch_size)
-    print("final: validation %.4f bits per node / %.2f %% valid, test %.4f / %.2f %%"
-          % (val_bpd, 100 * val_valid, test_bpd, 100 * test_valid), flush=True)
+    val_bpd, val_valid = evaluate(ddp, prior, val_set, device, args.eval_batch_size, rank=rank, world=world)
+    test_bpd, test_valid = evaluate(ddp, prior, test_set, device, args.eval_batch_size, rank=rank, world=world)
+    say("final: validation %.4f bits per node / %.2f %% valid, test %.4f / %.2f %%"
+        % (val_bpd, 100 * val_valid, test_bpd, 100 * test_valid))
+    if world > 1:
+        torch.distributed.barrier()
     return {"val_bpd": val_bpd, "val_valid_ratio": val_valid, "test_bpd": test_bpd, "test_valid_ratio": test_valid,
             "best_file": best["file"]}
 

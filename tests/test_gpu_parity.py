@@ -1540,3 +1540,23 @@ def test_set_modelling_driver_flat_optimizer_matches_per_tensor_training(tmp_pat
     assert abs(c["val_bpd"] - b["val_bpd"]) < 0.02, (b, c)
     blob = torch.load(sorted((tmp_path / "flat").glob("*.tar"))[-1], weights_only=False)
     assert "optimizer_state_dict" not in blob and "scheduler_state_dict" in blob
+
+
+def test_graph_colouring_driver_two_ranks(tmp_path):
+    """§8e on the second host loop: 2 ranks (sharing cuda:0 over gloo here) train under DDP on their own bucketed batches,
+    deal the evaluation batches out between them and all-reduce (sum of NLL, graphs, valid colourings) once."""
+    import re, socket, subprocess, sys
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), "-m", "categoricalnf_amd.experiments.run_graph_coloring",
+                        "--share_device", "--dataset", "tiny_3", "--data_root", str(tmp_path / "data"), "--generate_data",
+                        "--num_graphs", "2000", "--coupling_hidden_size", "32", "--coupling_hidden_layers", "2",
+                        "--coupling_num_flows", "2", "--checkpoint_path", str(tmp_path / "ck"), "--print_freq", "40",
+                        "--eval_batch_size", "128", "--max_iterations", "80", "--eval_freq", "80", "--batch_size", "128",
+                        "--learning_rate", "2e-3"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    finals = re.findall(r"final: validation ([0-9.]+) bits per node / ([0-9.]+) % valid, test ([0-9.]+)", r.stdout)
+    assert len(finals) == 1 and 0.3 < float(finals[0][0]) < 1.7 and 0.0 <= float(finals[0][1]) <= 100.0, r.stdout[-1500:]
+    assert any(f.endswith(".tar") for f in os.listdir(tmp_path / "ck"))
