@@ -98,6 +98,24 @@ def batches(dataset, batch_size, device, drop_last):
         yield collate(dataset, idx, device)
 
 
+def evaluation_share(dataset, batch_size, rank=0, world=1, max_graphs=None):
+    """The evaluation batches (lists of dataset indices) `rank` of `world` is responsible for: the bucketed batch order is
+    drawn under a fixed seed — every rank must see the SAME order to take every `world`-th batch of it — the first batches
+    covering `max_graphs` graphs are kept, and the caller's numpy random state is left as it was."""
+    state = np.random.get_state()
+    np.random.seed(1234)
+    order = list(dataset.get_sampler(batch_size, drop_last=False))
+    np.random.set_state(state)
+    mine, seen = [], 0
+    for b, idx in enumerate(order):
+        if max_graphs is not None and seen >= max_graphs:
+            break
+        seen += len(idx)
+        if b % world == rank:
+            mine.append(list(idx))
+    return mine
+
+
 @torch.no_grad()
 def evaluate(model, prior, dataset, device, batch_size, max_graphs=None, rank=0, world=1):
     """(bits per node, validity of sampled colourings) on `dataset`; with several ranks the batches are dealt out
@@ -105,17 +123,7 @@ def evaluate(model, prior, dataset, device, batch_size, max_graphs=None, rank=0,
     inner = model.module if hasattr(model, "module") else model
     inner.eval()
     sums = torch.zeros(3, dtype=torch.float64, device=device)          # sum of nll, graphs, valid colourings
-    seen = 0
-    state = np.random.get_state()
-    np.random.seed(1234)                     # every rank must see the SAME batch order to take its share of it
-    order = list(dataset.get_sampler(batch_size, drop_last=False))
-    np.random.set_state(state)
-    for b, idx in enumerate(order):
-        if max_graphs is not None and seen >= max_graphs:
-            break
-        seen += len(idx)
-        if b % world != rank:
-            continue
+    for idx in evaluation_share(dataset, batch_size, rank, world, max_graphs):
         nodes, adjacency, length = collate(dataset, idx, device)
         nll, _ = flow_nll(inner, prior, nodes, adjacency, length)
         validity = generation_validity(inner, prior, [(nodes, adjacency, length)], type(dataset))

@@ -867,3 +867,27 @@ def test_reference_molecule_cli_reaches_the_kernel_boundary(tmp_path):
     assert "MI355X kernels" in out.stdout and "Preparing data dependent initialization" in out.stdout, out.stdout[-1500:]
     assert "HipOnlyError" in out.stderr and "/root/reference/experiments/molecule_generation/graphCNF.py" in out.stderr
     assert os.path.isfile(tmp_path / "data" / "zinc250k" / "zinc250k_node_prior.npy")      # written by the reference's dataset class
+
+
+def test_graph_colouring_evaluation_batches_are_dealt_out_once(tmp_path):
+    """Sharded evaluation of the graph-colouring driver: the ranks' shares are disjoint, together they are exactly the
+    single-process batch list, a graph budget cuts every rank at the same batch, and the caller's numpy random stream is
+    untouched (training order does not depend on when evaluations happen)."""
+    from categoricalnf_amd.experiments.graph_coloring_data import GraphColoringDataset, generate_planted_dataset
+    from categoricalnf_amd.experiments.run_graph_coloring import evaluation_share
+    generate_planted_dataset(str(tmp_path), num_graphs=500, seed=3)
+    GraphColoringDataset.set_dataset(prefix="_tiny", num_colors=3)
+    GraphColoringDataset.DATASET_NODES = GraphColoringDataset.DATASET_VAL_IDX = None
+    val = GraphColoringDataset(num_colors=3, val=True, data_root=str(tmp_path))
+    np.random.seed(77)
+    before = np.random.get_state()[1].copy()
+    whole = evaluation_share(val, 16)
+    assert np.array_equal(np.random.get_state()[1], before)
+    assert sorted(i for b in whole for i in b) == list(range(len(val)))
+    for world in (2, 3):
+        shares = [evaluation_share(val, 16, r, world) for r in range(world)]
+        dealt = [b for k in range(len(whole)) for b in [shares[k % world][k // world]]]
+        assert dealt == whole
+    budget = [evaluation_share(val, 16, r, 2, max_graphs=20) for r in range(2)]
+    assert sum(len(b) for s in budget for b in s) == len(whole[0]) + len(whole[1]) and budget[0][0] == whole[0]
+    GraphColoringDataset.DATASET_NODES = GraphColoringDataset.DATASET_VAL_IDX = None
