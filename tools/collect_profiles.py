@@ -32,7 +32,9 @@ for src, dst in (("sweep_affine.log", "_sweep_affine.txt"), ("sweep_nll.log", "_
                  ("flow_traffic.json", "_flow_traffic.json"), ("mfma_set/mfma_util.txt", "_mfma_util_set_modelling.txt"),
                  ("mfma_set/mfma_util.json", "_mfma_util_set_modelling.json"),
                  ("train_step_flat.txt", "_train_step_flat_optimizer.txt"), ("host_profile.txt", "_host_profile_train_step.txt"),
-                 ("enc/table.txt", "_pmc_encoder.txt")):
+                 ("enc/table.txt", "_pmc_encoder.txt"), ("train_lm.txt", "_train_language_modelling.txt"),
+                 ("train_lm_ptb.txt", "_train_language_modelling_ptb_shape.txt"),
+                 ("lm_kernel_stats.csv", "_train_language_modelling_kernel_stats.csv")):
     if os.path.exists(os.path.join(G, src)):
         shutil.copy(os.path.join(G, src), os.path.join(P, tag + dst))
 tr = os.path.join(G, "prof_train", "train_kernel_stats.csv")

@@ -48,3 +48,11 @@ timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_t
     python tools/bench_train_step.py 8192 10 > "$OUT/train_prof.log" 2>&1
 rm -f "$OUT"/prof_train/*kernel_trace.csv
 find "$OUT" -name "*counter_collection.csv" -size +4M -delete
+# training logs of the drivers (each stopped by its timeout; the logs are flushed line by line)
+timeout 330 python -m categoricalnf_amd.experiments.run_language_modeling --eval_freq 500 --print_freq 100 > "$OUT/train_lm.txt" 2>&1; grep validation "$OUT/train_lm.txt" | tail -2
+timeout 330 python -m categoricalnf_amd.experiments.run_language_modeling --variable_length --max_seq_len 288 --vocab_size 51 --coupling_num_mixtures 51 --coupling_hidden_layers 1 --coupling_dropout 0.3 --coupling_input_dropout 0.1 --eval_freq 500 --print_freq 100 > "$OUT/train_lm_ptb.txt" 2>&1; grep validation "$OUT/train_lm_ptb.txt" | tail -2
+rm -rf "$OUT/prof_lm"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_lm" -o lm -- \
+    python -m categoricalnf_amd.experiments.run_language_modeling --max_iterations 40 --print_freq 20 --eval_freq 100000 --num_val 128 > "$OUT/prof_lm.log" 2>&1
+python tools/summarize_kernel_stats.py "$OUT/prof_lm/lm_kernel_stats.csv" "$OUT/lm_kernel_stats.csv" "40 training steps of the language-modelling flow (text8 recipe, batch 128 x 256 characters) + data-dependent init + one evaluation of 128 sentences" 40 | head -3
+rm -f "$OUT"/prof_lm/*kernel_trace.csv
