@@ -1501,7 +1501,7 @@ def test_language_modelling_driver_trains_towards_the_source_entropy(tmp_path):
     assert out["entropy_rate"] < out["val_bpc"] < out["unigram_entropy"], out
     assert out["best_file"] and os.path.isfile(out["best_file"])
     again = R.main(common + ["--only_eval"])
-    assert abs(again["val_bpc"] - out["val_bpc"]) < 0.05, (again, out)
+    assert abs(again["val_bpc"] - out["val_bpc"]) < 0.08, (again, out)
 
 
 def test_language_modelling_driver_two_ranks(tmp_path):
