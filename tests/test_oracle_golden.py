@@ -3,6 +3,8 @@
 Integer / index outputs must be identical; floating-point outputs are expected bit-equal because the
 oracle uses the same torch CPU ops in the same order — asserted with a 1e-6 guard band to stay
 robust against thread-count dependent reduction order."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -156,3 +158,18 @@ def test_encoder_large_vocab(c):
     close(z, c.z); close(ldj, c.ldj, atol=5e-6)
     assert torch.equal(O.encoder_decode(c.z, c.table, c.category_prior)[0], c.decoded)
     assert torch.equal(O.encoder_decode(c.z_probe, c.table, c.category_prior)[0], c.decoded_probe)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/layers"), reason="reference checkout only exists in the build container")
+@pytest.mark.parametrize("seed", [0, 1])
+def test_oracle_equals_the_live_reference_on_random_cases(seed):
+    """oracle/fuzz_vs_reference.py: the reference's own layer objects (imported from the checkout, sub-networks replaced by
+    injected outputs) against the oracle on seeded random shapes, masks, mixture counts, paddings, regulariser settings and
+    train / eval modes — the pin beyond the fixed golden cases.  Runs in a subprocess: the reference's `layers` package
+    must not meet this package's aliases."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "oracle", "fuzz_vs_reference.py"), "100", str(seed)],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd="/tmp", timeout=600,
+                         env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1", MPLBACKEND="Agg"))
+    assert out.returncode == 0 and "FUZZ OK 500" in out.stdout, (out.stdout[-800:], out.stderr[-1500:])
