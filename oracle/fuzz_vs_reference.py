@@ -115,9 +115,9 @@ def main(cases=60, seed=0):
             lay.scaling_factor.data, lay.mixture_scaling_factor.data = sfm.clone(), msf.clone()
             lay.nn.value = nn_m
             lay.train(training)
-            kw = dict(channel_padding_mask=pad) if padded else {}
-            zf, lf, det = lay(zt, reverse=False, **kw)
-            zr, lr, _ = lay(zf, reverse=True, **kw)
+            kw_m = dict(channel_padding_mask=pad) if padded else {}
+            zf, lf, det = lay(zt, reverse=False, **kw_m)
+            zr, lr, _ = lay(zf, reverse=True, **kw_m)
             okw = dict(channel_padding_mask=pad, reg_max=reg_max, reg_factor=reg_factor, is_training=training)
             of, olf, oreg = O.mixture_coupling(zt, nn_m, mk, K, sfm, msf, reverse=False, **okw)
             orr, olr, _ = O.mixture_coupling(zf, nn_m, mk, K, sfm, msf, reverse=True, **okw)
@@ -160,6 +160,37 @@ def main(cases=60, seed=0):
         x = float(rng.choice([1.0, 5.0, 30.0])) * torch.randn(B, N, D, generator=g)
         close(O.logistic_log_prob(x), prior.log_prob(x), what="logistic log-prob")
         counts["logistic prior"] = counts.get("logistic prior", 0) + 1
+        # ---- gradients: the reference's autograd through its own layers vs autograd through the oracle (what the GPU
+        #      suite differentiates when it checks the HIP backward kernels on seeded inputs) ----
+        wz, wl = torch.randn(B, N, D, generator=g), torch.randn(B, generator=g)
+        nn_g = nn_out.clone().requires_grad_()
+        layer.nn.value = nn_g
+        layer.scaling_factor.grad = None
+        zf, lf = layer(z, ldj=None, reverse=False)
+        ((zf * wz).sum() + (lf * wl).sum()).backward()
+        nn_o, sf_o = nn_out.clone().requires_grad_(), sf.clone().requires_grad_()
+        of, olf = O.affine_coupling(z, nn_o, mask, sf_o, reverse=False)
+        ((of * wz).sum() + (olf * wl).sum()).backward()
+        close(nn_o.grad, nn_g.grad, tol=2e-6, what="affine d/d nn_out")
+        close(sf_o.grad, layer.scaling_factor.grad, tol=1e-5, what="affine d/d scaling_factor")
+        layer.nn.value = nn_out
+        if type(lay) is MixtureCDFCoupling:
+            wzm, wlm = torch.randn(Bm, Nm, Dm, generator=g), torch.randn(Bm, generator=g)
+            nn_g = nn_m.clone().requires_grad_()
+            lay.nn.value = nn_g
+            lay.scaling_factor.grad = lay.mixture_scaling_factor.grad = None
+            zf, lf, _ = lay(zt, reverse=False, **kw_m)
+            ((zf * wzm).sum() + (lf * wlm).sum()).backward()
+            nn_o = nn_m.clone().requires_grad_()
+            sf_o, msf_o = sfm.clone().requires_grad_(), msf.clone().requires_grad_()
+            of, olf, _ = O.mixture_coupling(zt, nn_o, mk, K, sf_o, msf_o, reverse=False, **okw)
+            ((of * wzm).sum() + (olf * wlm).sum()).backward()
+            scale = float(nn_g.grad.abs().max()) + 1e-12
+            close(nn_o.grad / scale, nn_g.grad / scale, tol=1e-5, what="mixture d/d nn_out")
+            close(sf_o.grad, lay.scaling_factor.grad, tol=1e-4, what="mixture d/d scaling_factor")
+            close(msf_o.grad, lay.mixture_scaling_factor.grad, tol=1e-4, what="mixture d/d mixture_scaling_factor")
+            counts["gradients (affine + mixture)"] = counts.get("gradients (affine + mixture)", 0) + 1
+
         # ---- ExtActNorm with an injected predictor output (activation_normalization.py:116-144) ----
         ext = quiet(lambda: ExtActNormFlow(c_in=D, net=Inject()))
         nn_e = 0.7 * torch.randn(B, N, 2 * D, generator=g)
