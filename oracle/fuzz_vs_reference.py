@@ -31,6 +31,7 @@ with contextlib.redirect_stdout(io.StringIO()):
     from layers.flows.distributions import LogisticDistribution                        # noqa: E402
     from general.mutils import create_channel_mask                                     # noqa: E402
     from layers.categorical_encoding.linear_encoding import LinearCategoricalEncoding  # noqa: E402
+    from layers.flows.sigmoid_layer import SigmoidFlow                                 # noqa: E402
 assert CouplingLayer.__module__ == "layers.flows.coupling_layer" and "categoricalnf_amd" not in sys.modules
 
 
@@ -203,6 +204,19 @@ def main(cases=60, seed=0):
         orr, olr = O.ext_actnorm(zf, nn_e, reverse=True, **pkw)
         close(orr, zr, what="ExtActNorm inverse z"); close(olr, lr, tol=2e-6, what="ExtActNorm inverse ldj")
         counts["ExtActNorm"] = counts.get("ExtActNorm", 0) + 1
+
+        # ---- SigmoidFlow in both orientations (sigmoid_layer.py:24-47; the layer XORs its own flag with the call's) ----
+        for own in (False, True):
+            sg = SigmoidFlow(reverse=own)
+            zs = 2.5 * torch.randn(B, N, D, generator=g)
+            a, la = sg(zs, ldj=ldj_in.clone(), reverse=own)                  # net direction: real line -> (0, 1)
+            oa, ola = O.sigmoid_flow(zs, reverse=False, ldj=ldj_in)
+            close(oa, a, what="sigmoid"); close(ola, la, tol=2e-6, what="sigmoid ldj")
+            us = torch.rand(B, N, D, generator=g)
+            b, lb = sg(us, ldj=None, reverse=not own)                        # net direction: (0, 1) -> real line
+            ob, olb = O.sigmoid_flow(us, reverse=True)
+            close(ob, b, tol=2e-6, what="logit"); close(olb, lb, tol=2e-6, what="logit ldj")
+        counts["SigmoidFlow"] = counts.get("SigmoidFlow", 0) + 1
 
         # ---- mixture-model categorical encoder (linear_encoding.py:59-196): forward with the CPU generator's noise,
         #      posterior over all classes, arg-max decode ----

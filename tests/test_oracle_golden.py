@@ -174,5 +174,5 @@ def test_oracle_equals_the_live_reference_on_random_cases(seed):
                          env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1", MPLBACKEND="Agg"))
     import re
     done = re.search(r"FUZZ OK (\d+)", out.stdout)
-    assert out.returncode == 0 and done and int(done.group(1)) >= 700, (out.stdout[-800:], out.stderr[-1500:])
+    assert out.returncode == 0 and done and int(done.group(1)) >= 800, (out.stdout[-800:], out.stderr[-1500:])
     assert "gradients (affine + mixture)" in out.stdout
