@@ -10,6 +10,7 @@
 #include "cnf_common.h"
 
 #include <algorithm>
+#include <type_traits>
 
 namespace cnf {
 
@@ -199,6 +200,342 @@ __global__ __launch_bounds__(kBlock) void encoder_decode_kernel(EncArgs a, long 
         a.categ_out[tok] = (int64_t)arg;
     }
 }
+
+
+// ---- round 3: two tokens per lane ------------------------------------------------------------------------------------
+//
+// Calibration on the device (tools/microbench/enc_micro.hip, profiles/r03_valu_calibration.txt): a plain wave64 VALU
+// instruction occupies its SIMD for 2 cycles, v_exp_f32 / v_log_f32 for 8, and ONE wave issues at most one VALU
+// instruction per ~5.3 cycles.  The class loop is 3 plain + 1 transcendental instruction per (class, channel): 14 cycles
+// per wave, of which the exp2 alone is 8 — the loop's slope per class already sits at that figure, so what a kernel can
+// still save is what is NOT the (class, channel) arithmetic:
+//   * a lane scores TWO consecutive tokens against each class, so the class constants are read once per pair, as 16-byte
+//     LDS vectors ([A0 C0 A1 C1 ... cst2] padded to a multiple of four floats): 4 ds_read_b128 per class and pair instead
+//     of 13 ds_read2_b32 per two classes and ONE token, and two independent product chains per class;
+//   * a pair's latents / noise are 8D contiguous bytes: 16-byte nontemporal loads (D even) instead of D dword loads at a
+//     4D-byte lane stride; the decoded indices of a pair are one 16-byte store;
+//   * the derived table is built with ONE tanhf per (class, channel) (the per-class sum reads the values back from LDS;
+//     round 2 evaluated every tanhf twice, the second time D of them in one serial thread), and a thread's raw table
+//     entries are loaded BEFORE its latents: vmcnt retires in order, so a load issued behind the latents could not be
+//     waited for without them and the build would start only after the whole first burst had arrived.
+// Arithmetic per token is unchanged (same operations in the same order as class_score2 / encoder_forward_kernel), so
+// latents, class posteriors, log-det terms and decoded indices are bit-identical to the round-2 kernels, which stay as
+// the fallback for shapes this layout does not take (block-per-row tilings, odd tile starts, unaligned views, D > 8).
+typedef float vf4 __attribute__((ext_vector_type(4)));
+typedef float vf2 __attribute__((ext_vector_type(2)));
+typedef long long ll2 __attribute__((ext_vector_type(2)));
+
+template <int D>
+struct PairIO {
+    static constexpr bool kWide = (D % 2 == 0);            // 8D bytes per pair: a multiple of 16 iff D is even
+    static constexpr int kN = kWide ? D / 2 : D;           // vectors per pair
+    using V = typename std::conditional<kWide, vf4, vf2>::type;
+    static constexpr int kW = kWide ? 4 : 2;
+    // both tokens of the pair at p (2D floats, aligned to the vector width)
+    static __device__ __forceinline__ void load_nt(const float* p, float (&x)[2][D]) {
+        const V* src = reinterpret_cast<const V*>(p);
+        float buf[2 * D];
+#pragma unroll
+        for (int q = 0; q < kN; ++q) {
+            const V v = __builtin_nontemporal_load(src + q);
+#pragma unroll
+            for (int w = 0; w < kW; ++w) buf[kW * q + w] = v[w];
+        }
+#pragma unroll
+        for (int i = 0; i < 2 * D; ++i) x[i / D][i % D] = buf[i];
+    }
+    static __device__ __forceinline__ void store(float* p, const float (&x)[2][D]) {
+        V* dst = reinterpret_cast<V*>(p);
+        float buf[2 * D];
+#pragma unroll
+        for (int i = 0; i < 2 * D; ++i) buf[i] = x[i / D][i % D];
+#pragma unroll
+        for (int q = 0; q < kN; ++q) {
+            V v;
+#pragma unroll
+            for (int w = 0; w < kW; ++w) v[w] = buf[kW * q + w];
+            dst[q] = v;
+        }
+    }
+};
+
+template <int D>
+struct PairTab {
+    static constexpr int S = (2 * D + 1 + 3) / 4 * 4;      // score constants per class: [A0 C0 ... A(D-1) C(D-1) cst2 pad]
+    static constexpr int F = 3 * D + 2;                    // forward constants per class: [bias D | e^ts D | ts D | sum_ts | prior]
+};
+
+// first half of the table build: this thread's raw entries (issued before the latents' loads)
+template <int D>
+__device__ __forceinline__ void pair_table_load(const EncArgs& a, float& r_b, float& r_s) {
+    r_b = 0.f;
+    r_s = 0.f;
+    const int i = threadIdx.x;
+    if (i < a.C * D) {
+        const int c = i / D, d = i - c * D;
+        r_b = a.table[(size_t)c * 2 * D + d];
+        r_s = a.table[(size_t)c * 2 * D + D + d];
+    }
+}
+// second half.  FWD: the forward constants as well; otherwise `ft` holds the tanh values only (stride D).
+// Same expressions as build_class_table, so every constant has the same bits.
+template <int D, bool FWD>
+__device__ __forceinline__ void pair_table_finish(const EncArgs& a, float* vt, float* ft, float r_b, float r_s) {
+    constexpr int S = PairTab<D>::S, F = FWD ? PairTab<D>::F : D, TS = FWD ? 2 * D : 0;
+    const float k = kLog2e / a.sigma;
+    for (int i = threadIdx.x; i < a.C * D; i += kBlock) {
+        const int c = i / D, d = i - c * D;
+        if (i != (int)threadIdx.x) {
+            r_b = a.table[(size_t)c * 2 * D + d];
+            r_s = a.table[(size_t)c * 2 * D + D + d];
+        }
+        const float ts = tanhf(r_s);
+        const float ems = expf(-ts);
+        vt[c * S + 2 * d] = ems * k;
+        vt[c * S + 2 * d + 1] = r_b * k;
+        ft[c * F + TS + d] = ts;
+        if (FWD) {
+            ft[c * F + d] = r_b;
+            ft[c * F + D + d] = expf(ts);
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < a.C; c += kBlock) {
+        float s = 0.f;
+        for (int d = 0; d < D; ++d) s += ft[c * F + TS + d];
+        const float pr = a.prior[c];
+        vt[c * S + 2 * D] = ((pr - s) - (float)D * a.log_sigma) * kLog2e;
+        if (FWD) {
+            ft[c * F + 3 * D] = s;
+            ft[c * F + 3 * D + 1] = pr;
+        }
+    }
+    __syncthreads();
+}
+
+// scores of class j for both tokens of a pair (class_score2's arithmetic, constants from one row of 16-byte vectors)
+template <int D>
+__device__ __forceinline__ void pair_score(const float4* vt4, int j, const float (&z)[2][D], float (&sc)[2]) {
+    constexpr int S = PairTab<D>::S;
+    float k[S];
+#pragma unroll
+    for (int q = 0; q < S / 4; ++q) {
+        const float4 v = vt4[j * (S / 4) + q];
+        k[4 * q] = v.x; k[4 * q + 1] = v.y; k[4 * q + 2] = v.z; k[4 * q + 3] = v.w;
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        float acc = 0.f, prod = 1.f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const float vs = fabsf(fmaf(z[t][d], k[2 * d], -k[2 * d + 1]));
+            acc += vs;
+            prod = fmaf(prod, __builtin_amdgcn_exp2f(-vs), prod);
+        }
+        sc[t] = k[2 * D] - fmaf(2.f, __builtin_amdgcn_logf(prod), acc);
+    }
+}
+
+// arg-max decode (linear_encoding.py:184-196): one tile of 128 consecutive tokens per wave, lane i owns tokens 2i, 2i+1
+template <int D>
+__global__ __launch_bounds__(kBlock) void encoder_decode_pair_kernel(EncArgs a, long ntok) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int S = PairTab<D>::S;
+    float* vt = reinterpret_cast<float*>(smem);
+    float* ts_sh = vt + a.C * S;
+    const int lane = threadIdx.x & 63;
+    const long base = ((long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * 128 + 2 * lane;
+    float r_b, r_s;
+    pair_table_load<D>(a, r_b, r_s);
+    float z[2][D];
+    const bool full = base + 1 < ntok;
+    if (full) {
+        PairIO<D>::load_nt(a.z_in + base * D, z);
+    } else {
+        const long t0 = min(base, ntok - 1);                 // a lone last token (or a lane past the end): scored twice
+#pragma unroll
+        for (int d = 0; d < D; ++d) z[0][d] = z[1][d] = a.z_in[t0 * D + d];
+    }
+    pair_table_finish<D, false>(a, vt, ts_sh, r_b, r_s);
+    if (base >= ntok) return;
+    const float4* vt4 = reinterpret_cast<const float4*>(smem);
+    float best[2] = {-INFINITY, -INFINITY};
+    int arg[2] = {0, 0};
+    for (int j = 0; j < a.C; ++j) {
+        float sc[2];
+        pair_score<D>(vt4, j, z, sc);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+            if (sc[t] > best[t]) {                          // first maximum wins, like torch.argmax (class 0 holds a tie at -inf)
+                best[t] = sc[t];
+                arg[t] = j;
+            }
+    }
+    if (full) {
+        ll2 v = {(long long)arg[0], (long long)arg[1]};
+        *reinterpret_cast<ll2*>(a.categ_out + base) = v;
+    } else {
+        a.categ_out[base] = (int64_t)arg[0];
+    }
+}
+
+// forward (linear_encoding.py:59-133,153-174) on the row tiling of encoder_forward_kernel (a wave owns tl.rw whole rows;
+// requires !tl.bpr, tl.rw >= 2 and an even number of tokens per tile, so that every pair starts at an even token):
+// lane i owns the tile's tokens 2i, 2i+1, then 2i+128, 2i+129, ...; the next pair's inputs are in flight while the
+// current pair is scored.  Token log-det terms go to the wave's LDS strip and are summed per row exactly as
+// walk_row_tile_split does.
+template <int D>
+__global__ __launch_bounds__(kBlock) void encoder_forward_pair_kernel(EncArgs a, RowTiling tl) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int S = PairTab<D>::S, F = PairTab<D>::F;
+    float* part = reinterpret_cast<float*>(smem) + (threadIdx.x >> 6) * kMaxTileChunks;
+    float* vt = reinterpret_cast<float*>(smem) + kWavesPerBlock * kMaxTileChunks;
+    float* ft = vt + a.C * S;
+    const float4* vt4 = reinterpret_cast<const float4*>(vt);
+    const int lane = threadIdx.x & 63;
+    const long tile = (long)walker_block() * kWavesPerBlock + (threadIdx.x >> 6);
+    const bool live = tile < tl.ntiles;
+    const int row0 = live ? (int)(tile * tl.rw) : 0;
+    const int nrows = live ? min(tl.rw, tl.B - row0) : 0;
+    const int nch = nrows * a.N;                            // tokens of this tile
+    const long tok0 = (long)row0 * a.N;
+
+    struct In {
+        float e[2][D];
+        long long c[2];
+        float pv[2];
+    };
+    auto load = [&](int pc, In& in) {
+        const long tok = tok0 + pc;
+        if (pc + 1 < nch) {
+            PairIO<D>::load_nt(a.eps + tok * D, in.e);
+            const ll2 cc = *reinterpret_cast<const ll2*>(a.categ + tok);
+            in.c[0] = cc[0];
+            in.c[1] = cc[1];
+            if (a.pad) {
+                const vf2 p = *reinterpret_cast<const vf2*>(a.pad + tok);
+                in.pv[0] = p[0];
+                in.pv[1] = p[1];
+            } else {
+                in.pv[0] = in.pv[1] = 1.f;
+            }
+        } else {                                            // lone last token of the tile: its partner is a copy
+#pragma unroll
+            for (int d = 0; d < D; ++d) in.e[0][d] = in.e[1][d] = a.eps[tok * D + d];
+            in.c[0] = in.c[1] = a.categ[tok];
+            in.pv[0] = in.pv[1] = a.pad ? a.pad[tok] : 1.f;
+        }
+    };
+    float r_b, r_s;
+    pair_table_load<D>(a, r_b, r_s);
+    In nxt;
+    if (2 * lane < nch) load(2 * lane, nxt);
+    pair_table_finish<D, true>(a, vt, ft, r_b, r_s);
+    bool bad = false;
+    const float kn = kLog2e / a.sigma;
+    for (int pc = 2 * lane; pc < nch; pc += 128) {
+        const In cur = nxt;
+        if (pc + 128 < nch) load(pc + 128, nxt);
+        const bool two = pc + 1 < nch;
+        float z[2][D], init_lp[2], ldj_f[2], lp2[2];
+        int c[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            // an index outside [0, C) would read past the class table: clamp it and report it (general/mutils.py:264)
+            const long long craw = cur.c[t];
+            if (craw < 0 || craw >= a.C) raise_flag(a.flags, CNF_FLAG_CATEGORY);
+            c[t] = (int)(craw < 0 ? 0 : (craw >= a.C ? a.C - 1 : craw));
+            const float* tc = ft + c[t] * F;
+            float nacc = 0.f, nprod = 1.f;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const float e = cur.e[t][d];
+                const float vs = fabsf(e) * kn;
+                nacc += vs;
+                nprod = fmaf(nprod, __builtin_amdgcn_exp2f(-vs), nprod);
+                z[t][d] = (e + tc[d]) * tc[D + d];
+            }
+            init_lp[t] = -(kLn2 * fmaf(2.f, __builtin_amdgcn_logf(nprod), nacc) + (float)D * a.log_sigma);
+            ldj_f[t] = tc[3 * D];
+            const float log_point = (init_lp[t] - ldj_f[t]) + tc[3 * D + 1];
+            lp2[t] = log_point * kLog2e;
+        }
+        // streamed base-2 log-sum-exp over the classes in blocks of four, as in encoder_forward_kernel
+        float m[2] = {-3e38f, -3e38f}, s[2] = {0.f, 0.f};
+        int j = 0;
+        for (; j + 4 <= a.C; j += 4) {
+            float v[4][2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                pair_score<D>(vt4, j + i, z, v[i]);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) v[i][t] = (j + i) == c[t] ? lp2[t] : v[i][t];
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const float mn = fmaxf(m[t], fmaxf(fmaxf(v[0][t], v[1][t]), fmaxf(v[2][t], v[3][t])));
+                const float blk = (__builtin_amdgcn_exp2f(v[0][t] - mn) + __builtin_amdgcn_exp2f(v[1][t] - mn)) +
+                                  (__builtin_amdgcn_exp2f(v[2][t] - mn) + __builtin_amdgcn_exp2f(v[3][t] - mn));
+                s[t] = fmaf(s[t], __builtin_amdgcn_exp2f(m[t] - mn), blk);
+                m[t] = mn;
+            }
+        }
+        for (; j < a.C; ++j) {
+            float sc[2];
+            pair_score<D>(vt4, j, z, sc);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const float v = j == c[t] ? lp2[t] : sc[t];
+                const float mn = fmaxf(m[t], v);
+                s[t] = fmaf(s[t], __builtin_amdgcn_exp2f(m[t] - mn), __builtin_amdgcn_exp2f(v - mn));
+                m[t] = mn;
+            }
+        }
+        float cpl[2], zo[2][D];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            cpl[t] = (lp2[t] - (m[t] + __builtin_amdgcn_logf(s[t]))) * kLn2;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                zo[t][d] = z[t][d] * cur.pv[t];
+                bad |= isnan(zo[t][d]);
+            }
+            if (t == 0 || two) part[pc + t] = (a.beta * cpl[t] - (init_lp[t] - ldj_f[t])) * cur.pv[t];
+        }
+        const long tok = tok0 + pc;
+        if (two) {
+            PairIO<D>::store(a.z_out + tok * D, zo);
+            if (a.cpl) {
+                vf2 cv = {cpl[0], cpl[1]};
+                *reinterpret_cast<vf2*>(a.cpl + tok) = cv;
+            }
+        } else {
+#pragma unroll
+            for (int d = 0; d < D; ++d) a.z_out[tok * D + d] = zo[0][d];
+            if (a.cpl) a.cpl[tok] = cpl[0];
+        }
+    }
+    if (bad) raise_flag(a.flags, CNF_FLAG_NAN_Z);
+    if (!live) return;
+    // per-row sums: the reduction of walk_row_tile_split (rw > 1), chunk = token
+    wave_lds_sync();
+    const int g = kWave / tl.p2;
+    const int sub = lane & (g - 1);
+    for (int r0 = 0; r0 < nrows; r0 += tl.p2) {
+        const int r = r0 + lane / g;
+        float acc = 0.f;
+        if (r < nrows)
+            for (int i = sub; i < tl.cpr; i += g) acc += part[r * tl.cpr + i];
+        acc = group_sum(acc, g);
+        if (sub == 0 && r < nrows) {
+            const float v = (a.ldj_in ? a.ldj_in[row0 + r] : 0.f) + acc;
+            a.ldj_out[row0 + r] = v;
+            if (isnan(v)) raise_flag(a.flags, CNF_FLAG_NAN_LDJ);
+        }
+    }
+}
+
+static int g_encoder_kernel = 0;     // cnf_set_encoder_kernel: 0 = by measurement (below), 1 = round-2 kernels, 2 = pair kernels wherever eligible
 
 
 // ---- large vocabularies: the class table does not fit LDS, so it is walked in chunks ---------------------------------
@@ -660,7 +997,29 @@ static size_t table_bytes(int C, int D) { return (size_t)C * (6 * D + 3) * sizeo
         default: { constexpr int DT = 0; CALL; } break;   \
     }
 
+// ---- round-3 pair kernels: eligibility ---------------------------------------------------------------------------------
+static bool pair_has_d(int D) { return D == 1 || D == 2 || D == 3 || D == 4 || D == 6 || D == 8; }
+static size_t pair_table_bytes(int C, int D, bool fwd) {
+    const int S = (2 * D + 1 + 3) / 4 * 4;
+    return (size_t)C * (S + (fwd ? 3 * D + 2 : D)) * sizeof(float);
+}
+static bool aligned_to(const void* p, size_t mask) { return ((uintptr_t)p & mask) == 0; }   // null passes
+#define DISPATCH_PAIR_D(D, CALL)                          \
+    switch (D) {                                          \
+        case 1: { constexpr int DT = 1; CALL; } break;    \
+        case 2: { constexpr int DT = 2; CALL; } break;    \
+        case 3: { constexpr int DT = 3; CALL; } break;    \
+        case 4: { constexpr int DT = 4; CALL; } break;    \
+        case 6: { constexpr int DT = 6; CALL; } break;    \
+        case 8: { constexpr int DT = 8; CALL; } break;    \
+        default: break;                                   \
+    }
+
 extern "C" {
+
+static int64_t g_pair_launches = 0;
+void cnf_set_encoder_kernel(int which) { g_encoder_kernel = which; }
+int64_t cnf_encoder_pair_launches(void) { return g_pair_launches; }
 
 int cnf_encoder_forward(const int64_t* categ, const float* eps, const float* table,
                         const float* category_prior, const float* pad, float beta,
@@ -679,8 +1038,24 @@ int cnf_encoder_forward(const int64_t* categ, const float* eps, const float* tab
     a.ldj_in = ldj_in; a.z_out = z_out; a.ldj_out = ldj_out; a.cpl = class_prob_log; a.flags = flags;
     a.B = B; a.N = N; a.D = D; a.C = C; a.beta = beta; a.sigma = sigma; a.log_sigma = log_sigma;
     const RowTiling tl = make_row_tiling(B, N, /*force_vec=*/1);
-    DISPATCH_D(D, CNF_LAUNCH((encoder_forward_kernel<DT>), tiling_grid(tl), dim3(kBlock), smem,
-                                     (hipStream_t)stream, a, tl));
+    // two tokens per lane (round 3) when every pair of a tile starts at an even token and the views are aligned
+    const size_t va = (D % 2 == 0) ? 15 : 7;
+    const size_t smem_pair = (size_t)kWavesPerBlock * kMaxTileChunks * sizeof(float) + pair_table_bytes(C, D, true);
+    // Interleaved A/B on one MI355X (profiles/r03_encoder_ab.txt, B=16384, N=64, D=6): 72.0 -> 68.0 us at 51 classes, 48.2 -> 46.8
+    // at 32, 29.8 -> 29.4 at 16, but 20.7 -> 22.0 at 9 and 14.1 -> 16.0 at 3 (the pair kernel's 127 VGPRs leave 4 waves per
+    // SIMD, which only pays once the class loop dominates): automatic selection from 24 classes on.
+    const bool want_pair = g_encoder_kernel == 2 || (g_encoder_kernel == 0 && C >= 24);
+    const bool pair = want_pair && pair_has_d(D) && !tl.bpr && tl.rw >= 2 && ((long)tl.rw * N) % 2 == 0 &&
+                      smem_pair <= 64 * 1024 && aligned_to(eps, va) && aligned_to(z_out, va) && aligned_to(categ, 15) &&
+                      aligned_to(pad, 7) && aligned_to(class_prob_log, 7);
+    if (pair) {
+        ++g_pair_launches;
+        DISPATCH_PAIR_D(D, CNF_LAUNCH((encoder_forward_pair_kernel<DT>), tiling_grid(tl), dim3(kBlock), smem_pair,
+                                      (hipStream_t)stream, a, tl));
+    } else {
+        DISPATCH_D(D, CNF_LAUNCH((encoder_forward_kernel<DT>), tiling_grid(tl), dim3(kBlock), smem,
+                                 (hipStream_t)stream, a, tl));
+    }
     return launch_status("cnf_encoder_forward");
 }
 
@@ -697,9 +1072,21 @@ int cnf_encoder_decode(const float* z, const float* table, const float* category
     a.z_in = z; a.table = table; a.prior = category_prior; a.categ_out = categ_out;
     a.B = B; a.N = N; a.D = D; a.C = C; a.sigma = sigma; a.log_sigma = log_sigma;
     const long ntok = (long)B * N;
-    const int grid = (int)std::min<long>((ntok + kBlock - 1) / kBlock, 256 * 8);
-    DISPATCH_D(D, CNF_LAUNCH((encoder_decode_kernel<DT>), dim3(grid), dim3(kBlock), smem,
-                                     (hipStream_t)stream, a, ntok));
+    const size_t smem_pair = pair_table_bytes(C, D, false);
+    const long pair_grid = ((ntok + 127) / 128 + kWavesPerBlock - 1) / kWavesPerBlock;   // one tile of 128 tokens per wave
+    // the pair decode is within +-5 % of the round-2 kernel at every vocabulary size measured (20.3 vs 21.2 us at 16 classes,
+    // 53.7 vs 55.1 at 51, 9.9 vs 9.7 at 3; profiles/r03_encoder_ab.txt): not selected automatically, kept for the A/B
+    const bool pair = g_encoder_kernel == 2 && pair_has_d(D) && smem_pair <= 64 * 1024 && pair_grid < (1L << 31) &&
+                      aligned_to(z, (D % 2 == 0) ? 15 : 7) && aligned_to(categ_out, 15);
+    if (pair) {
+        ++g_pair_launches;
+        DISPATCH_PAIR_D(D, CNF_LAUNCH((encoder_decode_pair_kernel<DT>), dim3((unsigned)pair_grid), dim3(kBlock), smem_pair,
+                                      (hipStream_t)stream, a, ntok));
+    } else {
+        const int grid = (int)std::min<long>((ntok + kBlock - 1) / kBlock, 256 * 8);
+        DISPATCH_D(D, CNF_LAUNCH((encoder_decode_kernel<DT>), dim3(grid), dim3(kBlock), smem,
+                                 (hipStream_t)stream, a, ntok));
+    }
     return launch_status("cnf_encoder_decode");
 }
 

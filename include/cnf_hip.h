@@ -325,6 +325,15 @@ int cnf_encoder_decode(const float* z, const float* table, const float* category
                        int64_t* categ_out, int B, int N, int D, int C, float sigma, float log_sigma,
                        cnf_stream_t stream);
 
+/* A-B knob of the LDS-resident encoder kernels: 2 = two tokens per lane with 16-byte LDS constants wherever the shape
+ * allows it (whole-row wave tiles of an even number of tokens, 16-byte aligned views, D in {1,2,3,4,6,8}), 1 = the
+ * one-token-per-lane kernels of round 2 (the fallback for every other shape), 0 (default) = by measurement: the
+ * two-token forward from 24 classes on, the round-2 decode.  Same arithmetic per token: both give bit-identical latents,
+ * log-det and decoded indices (linear_encoding.py:59-133,153-196). */
+void cnf_set_encoder_kernel(int which);
+/* number of cnf_encoder_forward / cnf_encoder_decode calls this process served with the two-token kernels (tests) */
+int64_t cnf_encoder_pair_launches(void);
+
 /* The same two for vocabularies whose class table does not fit LDS (wikitext: 10^4 classes): the classes are walked
  * in chunks whose score constants a workgroup rebuilds in LDS, the streamed log-sum-exp / arg-max runs across chunks,
  * and nothing of size [T*C, ...] is materialised (linear_encoding.py:155-160 expands to [T*C, 1, D]).  Same results as

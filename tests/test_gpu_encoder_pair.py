@@ -1,0 +1,131 @@
+"""Round-3 encoder kernels (two tokens per lane, 16-byte LDS constants) against the round-2 kernels they replace
+(cnf_set_encoder_kernel(2) vs (1)): same arithmetic per token, so latents, class posteriors, log-det and decoded indices must be
+BIT-identical (linear_encoding.py:59-133,153-196); the goldens and the oracle comparisons of test_gpu_parity.py run on
+whichever kernel the shape selects."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup():
+    from categoricalnf_amd import _lib, ops
+    return _lib.load(), ops
+
+
+def _inputs(B, N, D, C, seed, pad_mode, dev):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    categ = torch.randint(0, C, (B, N), generator=g, device=dev)
+    table = 0.7 * torch.randn(C, 2 * D, generator=g, device=dev)
+    prior = torch.log_softmax(torch.randn(C, generator=g, device=dev), 0)
+    u = torch.rand(B * N, D, generator=g, device=dev) * (1 - 1e-4) + 5e-5
+    eps = (torch.log(u.double()) - torch.log1p(-u.double())).float() / 1.81
+    pad = None
+    if pad_mode:
+        length = torch.randint(max(1, N // 2), N + 1, (B,), generator=g, device=dev)
+        pad = (torch.arange(N, device=dev)[None, :] < length[:, None]).float().unsqueeze(-1)
+    ldj = torch.randn(B, generator=g, device=dev)
+    return categ, eps, table, prior, pad, ldj
+
+
+# (B, N, D, C, pair expected): tilings with whole rows per wave and an even number of tokens per tile take the new kernel
+SHAPES = [
+    (4096, 64, 6, 16, True), (4096, 16, 4, 16, True), (2049, 16, 2, 2, True), (3000, 20, 2, 3, True), (2500, 38, 6, 9, True),
+    (2200, 50, 6, 3, True), (2100, 7, 3, 5, True), (4099, 3, 1, 4, True), (2048, 64, 8, 51, True), (2304, 36, 6, 51, True),
+    (128, 288, 3, 51, False),           # block-per-row tiling: round-2 kernel
+    (2100, 5, 5, 7, False),             # D = 5 has no pair instantiation
+    (7, 16, 4, 16, True),               # tiny batch, partial tile
+]
+
+
+@pytest.mark.parametrize("B,N,D,C,expect_pair", SHAPES)
+@pytest.mark.parametrize("pad_mode", [0, 1])
+def test_pair_forward_is_bit_identical_to_round2_kernel(B, N, D, C, expect_pair, pad_mode):
+    lib, ops = _setup()
+    dev = torch.device("cuda:0")
+    categ, eps, table, prior, pad, ldj = _inputs(B, N, D, C, 100 + B + N, pad_mode, dev)
+    out = {}
+    for which in (1, 2):
+        lib.cnf_set_encoder_kernel(which)
+        try:
+            n0 = lib.cnf_encoder_pair_launches()
+            z, l, cpl = ops.encoder_forward(categ, eps, table, prior, beta=1.7, channel_padding_mask=pad, ldj=ldj,
+                                            want_class_prob=True, tiled=False)
+            torch.cuda.synchronize()
+            out[which] = (z, l, cpl, lib.cnf_encoder_pair_launches() - n0)
+        finally:
+            lib.cnf_set_encoder_kernel(0)
+    assert out[1][3] == 0
+    assert out[2][3] == (1 if expect_pair else 0)
+    assert torch.equal(out[2][0], out[1][0])
+    assert torch.equal(out[2][2], out[1][2])
+    assert torch.equal(out[2][1], out[1][1])
+    assert torch.isfinite(out[2][1]).all()
+
+
+@pytest.mark.parametrize("B,N,D,C", [(4096, 64, 6, 16), (4096, 16, 4, 16), (1, 1, 6, 16), (3, 43, 6, 9), (1000, 127, 2, 3), (129, 1, 1, 2),
+                                     (2048, 64, 8, 51), (37, 5, 3, 5), (1, 129, 4, 300), (64, 64, 5, 7)])
+def test_pair_decode_is_bit_identical_to_round2_kernel(B, N, D, C):
+    lib, ops = _setup()
+    dev = torch.device("cuda:0")
+    categ, eps, table, prior, _, _ = _inputs(B, N, D, C, 7 + B, 0, dev)
+    z, _, _ = ops.encoder_forward(categ, eps, table, prior, tiled=False)
+    z = z + 0.3 * torch.randn_like(z)                       # perturbed probes: not only the clean forward outputs
+    out = {}
+    for which in (1, 2):
+        lib.cnf_set_encoder_kernel(which)
+        try:
+            n0 = lib.cnf_encoder_pair_launches()
+            out[which] = (ops.encoder_decode(z, table, prior, tiled=False), lib.cnf_encoder_pair_launches() - n0)
+        finally:
+            lib.cnf_set_encoder_kernel(0)
+    assert out[2][1] == (1 if D != 5 else 0) and out[1][1] == 0
+    assert torch.equal(out[2][0], out[1][0])
+
+
+def test_pair_kernels_decline_unaligned_views():
+    """A view that starts at an odd token (8 bytes off a 16-byte boundary at D = 6) falls back to the round-2 kernel."""
+    lib, ops = _setup()
+    dev = torch.device("cuda:0")
+    B, N, D, C = 64, 64, 6, 16
+    categ, eps, table, prior, _, _ = _inputs(B, N, D, C, 5, 0, dev)
+    z, _, _ = ops.encoder_forward(categ, eps, table, prior, tiled=False)
+    flat = torch.empty(B * N * D + D, device=dev)
+    view = flat[D:].view(B, N, D)
+    view.copy_(z)
+    assert view.data_ptr() % 16 != 0
+    lib.cnf_set_encoder_kernel(2)
+    try:
+        n0 = lib.cnf_encoder_pair_launches()
+        dec = ops.encoder_decode(view, table, prior, tiled=False)
+        assert lib.cnf_encoder_pair_launches() == n0
+        assert torch.equal(dec, ops.encoder_decode(z, table, prior, tiled=False))
+        assert lib.cnf_encoder_pair_launches() == n0 + 1
+    finally:
+        lib.cnf_set_encoder_kernel(0)
+
+
+def test_pair_forward_reports_out_of_range_categories():
+    lib, ops = _setup()
+    dev = torch.device("cuda:0")
+    B, N, D, C = 2048, 16, 4, 5
+    categ, eps, table, prior, _, _ = _inputs(B, N, D, C, 9, 0, dev)
+    categ[3, 2] = C + 4
+    lib.cnf_set_encoder_kernel(2)
+    try:
+        with pytest.raises(AssertionError):
+            ops.encoder_forward(categ, eps, table, prior, tiled=False)
+            ops.check_flags(dev)
+    finally:
+        lib.cnf_set_encoder_kernel(0)
+
+
+def test_automatic_selection_takes_the_pair_forward_from_24_classes_on():
+    lib, ops = _setup()
+    dev = torch.device("cuda:0")
+    for C, expect in ((16, 0), (24, 1), (51, 1)):
+        categ, eps, table, prior, _, _ = _inputs(4096, 64, 6, C, 11, 0, dev)
+        n0 = lib.cnf_encoder_pair_launches()
+        z, _, _ = ops.encoder_forward(categ, eps, table, prior, tiled=False)
+        ops.encoder_decode(z, table, prior, tiled=False)
+        assert lib.cnf_encoder_pair_launches() - n0 == expect
