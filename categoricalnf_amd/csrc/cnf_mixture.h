@@ -61,6 +61,7 @@ struct MixArgs {
 // cnf_mixture_tok.hip
 bool launch_mixture_tok(MixArgs& a, hipStream_t st, int force_g);
 void set_mixture_split_waves(int w);
+void set_mixture_whole_tokens(int on);
 // cnf_mixture_tok_bwd.hip
 bool launch_mixture_tok_bwd(MixArgs& a, const float* g_zout, const float* g_ldj, float* g_z, float* g_nn,
                             float* g_sf, float* g_msf, float* workspace, hipStream_t st, int force_g);
@@ -111,5 +112,33 @@ __device__ __forceinline__ float gmin(float v) {
     return v;
 }
 
+// The same reductions for groups of G consecutive lanes that start on a multiple of G (the token-pass kernels: lane =
+// token * DA * G + channel * G + share): quad-permute DPP moves instead of ds_bpermute, i.e. no LDS round trip (the
+// Newton iterations of the inverse reduce three sums per evaluation).  All lanes of a group are active together.
+template <int CTRL>
+__device__ __forceinline__ float quad_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+constexpr int kQuadXor1 = 0xB1;     // quad_perm [1,0,3,2]
+constexpr int kQuadXor2 = 0x4E;     // quad_perm [2,3,0,1]
+template <int G>
+__device__ __forceinline__ float qsum(float v) {
+    static_assert(G == 1 || G == 2 || G == 4, "quad-permute reductions cover groups of 1, 2 or 4 lanes");
+    if (G >= 2) v += quad_dpp<kQuadXor1>(v);
+    if (G >= 4) v += quad_dpp<kQuadXor2>(v);
+    return v;
+}
+template <int G>
+__device__ __forceinline__ float qmax(float v) {
+    if (G >= 2) v = fmaxf(v, quad_dpp<kQuadXor1>(v));
+    if (G >= 4) v = fmaxf(v, quad_dpp<kQuadXor2>(v));
+    return v;
+}
+template <int G>
+__device__ __forceinline__ float qmin(float v) {
+    if (G >= 2) v = fminf(v, quad_dpp<kQuadXor1>(v));
+    if (G >= 4) v = fminf(v, quad_dpp<kQuadXor2>(v));
+    return v;
+}
 
 }  // namespace cnf

@@ -1071,6 +1071,8 @@ void cnf_set_mixture_lanes(int lanes_per_item) {
     if (lanes_per_item == 0 || lanes_per_item == 1 || lanes_per_item == 2 || lanes_per_item == 4) g_mix_lanes = lanes_per_item;
 }
 
+void cnf_set_mixture_whole_tokens(int on) { set_mixture_whole_tokens(on); }
+
 void cnf_set_mixture_split(int waves) {
     if (waves >= 256 && waves <= 65536) set_mixture_split_waves(waves);
 }

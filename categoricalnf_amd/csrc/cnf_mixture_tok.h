@@ -18,6 +18,7 @@ constexpr int kMaxDmaInstr = 24;       // 1 KiB DMA instructions per pass
 
 struct TokGeom {
     int d0;             // first transformed channel
+    int sd0;            // first STAGED channel: d0, or 0 when whole tokens are staged (forward / inverse only)
     int DA;             // transformed channels per token
     int lpt;            // lanes per token = DA * G
     int TPP;            // tokens per pass
@@ -72,6 +73,7 @@ __device__ __forceinline__ int stage_pass(const TokGeom& gm, char* stage_b, cons
 }
 
 // host: pass geometry and work decomposition for `a`; false = shape outside what the token-pass kernels are built for
-bool make_tok_geom(const MixArgs& a, int kt, int force_g, TokGeom& gm, int& G, size_t& lds);
+bool make_tok_geom(const MixArgs& a, int kt, int force_g, TokGeom& gm, int& G, size_t& lds, int slot_g = 0,
+                   bool whole_tokens = false, long max_wgs = 0);
 
 }  // namespace cnf

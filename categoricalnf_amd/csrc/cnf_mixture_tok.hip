@@ -25,20 +25,37 @@
 #include "cnf_mixture_tok.h"
 
 #include <algorithm>
+#include <climits>
+#include <map>
+#include <mutex>
+#include <utility>
 
 namespace cnf {
 
 // ED > 0: the ActNorm + 1x1 convolution of the next flow step (D = ED channels) are applied to the coupling's output
 // while it is on chip (forward only): the [B,N,D] round trip between the two kernels (8 B/elem) disappears.  Same
 // arithmetic, in the same order, as actnorm_invconv_kernel (cnf_linear.hip): results are bit-identical to the chain.
-template <int KT, bool REVERSE, int G, bool NLL, int ED = 0>
-__global__ __launch_bounds__(kBlock) void mixture_tok_kernel(MixArgs a, TokGeom gm) {
-    static_assert(G == 1 || KT == 0, "several lanes per item only with a run-time K");
+//
+// Mixtures per lane.  KT > 0: a lane keeps KT mixtures in registers and every loop over them is unrolled — with PR ==
+// false these are exactly the K = KT mixtures of the item (G == 1); with PR == true ("predicated slots") the K <= KT * G
+// run-time mixtures of an item are dealt to its G lanes, lane `sub` holding k = sub + G * i in slot i, and a slot past
+// K repeats mixture K - 1 with weight zero (so minima / maxima over the slots are those over the mixtures and nothing
+// outside the row is read).  KT == 0: the general fallback, a rolled loop over the LDS row.  Round 2 ran every K other
+// than 4 / 8 / 16 on the rolled loop: three dependent LDS reads and an `s_waitcnt lgkmcnt(0)` per mixture and Newton
+// evaluation, one serial chain per wave (PTB shape, K = 51: inverse 45 us against a 25 us forward).
+// Register budget: the K = 8 inverse (configs[1]) needs 97 VGPRs as compiled freely, one more than five waves per SIMD
+// allow; asking for five costs nothing in the loop (no spills) and buys the fifth wave.
+constexpr int tok_min_waves(int kt, bool reverse, int g, bool pr) { return (kt == 8 && reverse && g == 1 && !pr) ? 5 : 1; }
+
+template <int KT, bool REVERSE, int G, bool NLL, int ED = 0, bool PR = false>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(tok_min_waves(KT, REVERSE, G, PR))))
+void mixture_tok_kernel(MixArgs a, TokGeom gm) {
+    static_assert(G == 1 || KT == 0 || PR, "several lanes per item: run-time K (rolled loop) or predicated slots");
     static_assert(!(NLL && REVERSE), "the NLL epilogue belongs to the forward pass");
     static_assert(ED == 0 || (!REVERSE && !NLL), "the ActNorm + convolution epilogue belongs to a forward pass inside a flow");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    const int K = KT > 0 ? KT : a.K;
+    const int K = (KT > 0 && !PR) ? KT : a.K;
     const int P = a.P;
     char* stage_b = smem + (size_t)wave * gm.stage_bytes;
     BoundTab* sf_tab = reinterpret_cast<BoundTab*>(smem + gm.tab_off);
@@ -49,33 +66,12 @@ __global__ __launch_bounds__(kBlock) void mixture_tok_kernel(MixArgs a, TokGeom 
     // epilogue: constants [bias D | e^scales D | W D*D | sum scales] and this wave's strip of one pass of tokens
     float* etab = reinterpret_cast<float*>(smem + gm.epi_off);
     float* ep = etab + (2 * ED + ED * ED + 4) + (size_t)wave * gm.TPP * ED;
-    if (ED > 0) {
-        for (int i = threadIdx.x; i < ED; i += blockDim.x) {
-            etab[i] = a.e_bias[i];
-            etab[ED + i] = expf(a.e_scales[i]);
-        }
-        for (int i = threadIdx.x; i < ED * ED; i += blockDim.x) etab[2 * ED + i] = a.e_w[i];
-        if (threadIdx.x == 0) {
-            float ssum = 0.f;
-            for (int i = 0; i < ED; ++i) ssum += a.e_scales[i];
-            etab[2 * ED + ED * ED] = ssum;
-        }
-    }
-    for (int i = threadIdx.x; i < a.D; i += blockDim.x)
-        if (a.sf) sf_tab[i] = make_bound(a.sf[i]);
-    for (int i = threadIdx.x; i < a.D * K; i += blockDim.x)
-        if (a.msf) msf_tab[i] = make_bound(a.msf[i]);
-    if (!gm.split)
-        for (int i = lane; i < gm.rw * 2; i += kWave) rowacc[i] = 0;
-    __syncthreads();
-
     // ---- this wave's tile: tokens [0, ntok) counted from (row0, n_first)
     int row0, nrows, n_first, ntok;
     if (!gm.split) {
         const long tile = (long)blockIdx.x * kWavesPerBlock + wave;
-        if (tile >= gm.ntiles) return;            // no barrier follows in this mode
-        row0 = (int)(tile * gm.rw);
-        nrows = min(gm.rw, a.B - row0);
+        row0 = (int)min(tile * gm.rw, (long)a.B);
+        nrows = min(gm.rw, a.B - row0);         // 0: a wave past the last tile (it still meets the barrier below)
         n_first = 0;
         ntok = nrows * a.N;
     } else {
@@ -102,15 +98,44 @@ __global__ __launch_bounds__(kBlock) void mixture_tok_kernel(MixArgs a, TokGeom 
     const float* pad_tile = a.pad ? a.pad + tok_g0 : nullptr;
     const char* nn_lo = reinterpret_cast<const char*>(a.nn);
     const char* nn_last = nn_lo + ((size_t)a.B * a.N * a.D * P - 4) * sizeof(float);      // last aligned 16-byte chunk
-    const char* span0 = nn_lo + (tok_g0 * a.D + gm.d0) * (size_t)P * sizeof(float);        // first token's span
+    const char* span0 = nn_lo + (tok_g0 * a.D + gm.sd0) * (size_t)P * sizeof(float);       // first token's staged span
 
     // lane -> (token in pass, channel, share of the mixtures)
     const int tli = (int)fdiv((uint32_t)lane, gm.div_lpt);
     const int rem = lane - tli * gm.lpt;
     const int j = rem / G, sub = rem - j * G;
     const int d = gm.d0 + j;
+    // the first pass's DMA goes out BEFORE the workgroup builds its tables: the table inputs are global loads too, and a
+    // wave that first waited for them and the barrier started its DMA one memory round trip late (split rows: every
+    // workgroup, on the critical path of launches that are a single round of workgroups)
+    int my_pos = 0;
+    if (ntok > 0)
+        my_pos = stage_pass(gm, stage_b, span0, nn_last, min(gm.TPP, ntok), lane, tli, j + (gm.d0 - gm.sd0), P);
+    if (ED > 0) {
+        for (int i = threadIdx.x; i < ED; i += blockDim.x) {
+            etab[i] = a.e_bias[i];
+            etab[ED + i] = expf(a.e_scales[i]);
+        }
+        for (int i = threadIdx.x; i < ED * ED; i += blockDim.x) etab[2 * ED + i] = a.e_w[i];
+        if (threadIdx.x == 0) {
+            float ssum = 0.f;
+            for (int i = 0; i < ED; ++i) ssum += a.e_scales[i];
+            etab[2 * ED + ED * ED] = ssum;
+        }
+    }
+    for (int i = threadIdx.x; i < a.D; i += blockDim.x)
+        if (a.sf) sf_tab[i] = make_bound(a.sf[i]);
+    for (int i = threadIdx.x; i < a.D * K; i += blockDim.x)
+        if (a.msf) msf_tab[i] = make_bound(a.msf[i]);
+    if (!gm.split)
+        for (int i = lane; i < gm.rw * 2; i += kWave) rowacc[i] = 0;
+    __syncthreads();
+    if (!gm.split && nrows <= 0) return;            // no barrier follows in this mode
     const BoundTab* mt = msf_tab + d * K;
     const PriorConst prior = a.prior;
+    // slot i of this lane -> mixture index, and whether the slot holds a mixture of its own
+    auto kidx = [&](int i) { return PR ? min(sub + G * i, K - 1) : i; };
+    auto kown = [&](int i) { return !PR || sub + G * i < K; };
     bool bad = false, range = false, badl = false;
     double acc_ldj = 0.0, acc_nlp = 0.0;          // split mode: this lane's running sums
 
@@ -151,33 +176,40 @@ __global__ __launch_bounds__(kBlock) void mixture_tok_kernel(MixArgs a, TokGeom 
             const float u = upper ? ubig : usmall, uc = upper ? usmall : ubig;
             if (!(u > 0.f && u < 1.f)) range = true;
             const float logit_u = (__builtin_amdgcn_logf(u) - __builtin_amdgcn_logf(uc)) * kLn2F;
+            // Only the side that is solved for is accumulated in the iterations: with the standardised argument's sign
+            // flipped for u > 1/2, `side` below is cdf (u <= 1/2) or ccdf (u > 1/2) from the same instructions, and
+            // log2(e) rides in the reciprocal scales, so that an evaluation is 10 plain + 2 transcendental
+            // instructions per mixture (round 2: 13 + 2).
+            const float sgn = upper ? -1.f : 1.f;
             constexpr int KK = KT > 0 ? KT : 1;
             float wr[KK], isr[KK], mur[KK];
             float mx = -INFINITY;
             if (KT > 0) {
 #pragma unroll
-                for (int k = 0; k < KK; ++k) mx = fmaxf(mx, my[2 + k]);
+                for (int i = 0; i < KK; ++i) mx = fmaxf(mx, my[2 + kidx(i)]);
+                mx = qmax<G>(mx);
             } else {
                 for (int k = sub; k < K; k += G) mx = fmaxf(mx, my[2 + k]);
-                mx = gmax<G>(mx);
+                mx = qmax<G>(mx);
             }
-            float se = 0.f, spread = 0.f, lb = INFINITY, ub = -INFINITY, qsum = 0.f;
-            auto setup = [&](int k) {
+            float se = 0.f, spread = 0.f, lb = INFINITY, ub = -INFINITY, qws = 0.f;
+            auto setup = [&](int k, int slot, bool own) {
                 const float lsk = my[2 + 2 * K + k];
                 const float ls = a.msf ? apply_bound(lsk, mt[k]) : lsk;
-                const float w = __builtin_amdgcn_exp2f((my[2 + k] - mx) * kLog2eF);
+                float w = __builtin_amdgcn_exp2f((my[2 + k] - mx) * kLog2eF);
+                if (PR && !own) w = 0.f;
                 const float sk = __builtin_amdgcn_exp2f(ls * kLog2eF);
-                const float ik = __builtin_amdgcn_rcpf(sk);
+                const float ik = __builtin_amdgcn_rcpf(sk) * (sgn * kLog2eF);      // signed, in log2 units
                 const float mk = my[2 + K + k];
                 // every component's own u-quantile: the mixture quantile lies between their min and max
                 const float qk = fmaf(sk, logit_u, mk);
                 se += w;
-                spread += sk;
+                spread += (PR && !own) ? 0.f : sk;
                 lb = fminf(lb, qk);
                 ub = fmaxf(ub, qk);
-                qsum = fmaf(w, qk, qsum);
+                qws = fmaf(w, qk, qws);
                 if (KT > 0) {
-                    wr[k < KK ? k : 0] = w; isr[k < KK ? k : 0] = ik; mur[k < KK ? k : 0] = mk;
+                    wr[slot < KK ? slot : 0] = w; isr[slot < KK ? slot : 0] = ik; mur[slot < KK ? slot : 0] = mk;
                 } else {
                     my[2 + k] = w;              // run-time K: the constants replace the raw row in LDS
                     my[2 + 2 * K + k] = ik;
@@ -185,37 +217,39 @@ __global__ __launch_bounds__(kBlock) void mixture_tok_kernel(MixArgs a, TokGeom 
             };
             if (KT > 0) {
 #pragma unroll
-                for (int k = 0; k < KK; ++k) setup(k);
+                for (int i = 0; i < KK; ++i) setup(kidx(i), i, kown(i));
             } else {
-                for (int k = sub; k < K; k += G) setup(k);
-                se = gsum<G>(se); spread = gsum<G>(spread); qsum = gsum<G>(qsum);
-                lb = gmin<G>(lb); ub = gmax<G>(ub);
+                for (int k = sub; k < K; k += G) setup(k, 0, true);
+            }
+            if (G > 1) {
+                se = qsum<G>(se); spread = qsum<G>(spread); qws = qsum<G>(qws);
+                lb = qmin<G>(lb); ub = qmax<G>(ub);
             }
             const float target = (upper ? uc : u) * se;
             const float tol_scale = 1e-7f * spread;
-            float xb = fminf(fmaxf(qsum * __builtin_amdgcn_rcpf(se), lb), ub);
+            float xb = fminf(fmaxf(qws * __builtin_amdgcn_rcpf(se), lb), ub);
             float dx_prev = ub - lb, dens = 0.f, diff = INFINITY;
             auto eval = [&](float xq, float& f_out, float& dens_out) {
-                float cdf = 0.f, ccdf = 0.f, dn = 0.f;
+                float side = 0.f, dn = 0.f;
                 auto one = [&](float wk, float ik, float mk) {
                     const float zk = (xq - mk) * ik;
-                    const float e = __builtin_amdgcn_exp2f(-fabsf(zk) * kLog2eF);
+                    const float e = __builtin_amdgcn_exp2f(-fabsf(zk));
                     const float rr = __builtin_amdgcn_rcpf(1.f + e);
                     const float er = e * rr;
-                    const bool pos = zk >= 0.f;
-                    cdf = fmaf(wk, pos ? rr : er, cdf);
-                    ccdf = fmaf(wk, pos ? er : rr, ccdf);
-                    dn = fmaf(wk * ik, er * rr, dn);
+                    side = fmaf(wk, zk >= 0.f ? rr : er, side);
+                    dn = fmaf(wk * fabsf(ik), er * rr, dn);
                 };
                 if (KT > 0) {
 #pragma unroll
                     for (int k = 0; k < KK; ++k) one(wr[k], isr[k], mur[k]);
                 } else {
                     for (int k = sub; k < K; k += G) one(my[2 + k], my[2 + 2 * K + k], my[2 + K + k]);
-                    cdf = gsum<G>(cdf); ccdf = gsum<G>(ccdf); dn = gsum<G>(dn);
                 }
-                f_out = upper ? target - ccdf : cdf - target;       // increasing in x either way
-                dens_out = dn;
+                if (G > 1) {
+                    side = qsum<G>(side); dn = qsum<G>(dn);
+                }
+                f_out = sgn * (side - target);                      // increasing in x either way
+                dens_out = dn * kLn2F;
             };
             for (int iter = 0; iter < 64; ++iter) {
                 float f;
@@ -256,22 +290,25 @@ __global__ __launch_bounds__(kBlock) void mixture_tok_kernel(MixArgs a, TokGeom 
             float mx = -INFINITY;
             if (KT > 0) {
 #pragma unroll
-                for (int k = 0; k < KK; ++k) {
-                    lp[k] = my[2 + k];
-                    mu[k] = my[2 + KK + k];
-                    lsr[k] = my[2 + 2 * KK + k];
+                for (int i = 0; i < KK; ++i) {
+                    const int k = kidx(i);
+                    lp[i] = my[2 + k];
+                    mu[i] = my[2 + K + k];
+                    lsr[i] = my[2 + 2 * K + k];
                 }
 #pragma unroll
-                for (int k = 0; k < KK; ++k) mx = fmaxf(mx, lp[k]);
+                for (int i = 0; i < KK; ++i) mx = fmaxf(mx, lp[i]);
+                mx = qmax<G>(mx);
             } else {
                 for (int k = sub; k < K; k += G) mx = fmaxf(mx, my[2 + k]);
-                mx = gmax<G>(mx);
+                mx = qmax<G>(mx);
             }
             float se = 0.f, cdf = 0.f, ccdf = 0.f, pdf = 0.f;
-            auto one = [&](float lpk, float muk, float lsk, int k) {
+            auto one = [&](float lpk, float muk, float lsk, int k, bool own) {
                 const float ls = a.msf ? apply_bound(lsk, mt[k]) : lsk;
                 const float inv_s = __builtin_amdgcn_exp2f(-ls * kLog2eF);
-                const float w = __builtin_amdgcn_exp2f((lpk - mx) * kLog2eF);
+                float w = __builtin_amdgcn_exp2f((lpk - mx) * kLog2eF);
+                if (PR && !own) w = 0.f;
                 const float zk = (x - muk) * inv_s;
                 const float e = __builtin_amdgcn_exp2f(-fabsf(zk) * kLog2eF);
                 const float rr = __builtin_amdgcn_rcpf(1.f + e);
@@ -284,10 +321,12 @@ __global__ __launch_bounds__(kBlock) void mixture_tok_kernel(MixArgs a, TokGeom 
             };
             if (KT > 0) {
 #pragma unroll
-                for (int k = 0; k < KK; ++k) one(lp[k], mu[k], lsr[k], k);
+                for (int i = 0; i < KK; ++i) one(lp[i], mu[i], lsr[i], kidx(i), kown(i));
             } else {
-                for (int k = sub; k < K; k += G) one(my[2 + k], my[2 + K + k], my[2 + 2 * K + k], k);
-                se = gsum<G>(se); cdf = gsum<G>(cdf); ccdf = gsum<G>(ccdf); pdf = gsum<G>(pdf);
+                for (int k = sub; k < K; k += G) one(my[2 + k], my[2 + K + k], my[2 + 2 * K + k], k, true);
+            }
+            if (G > 1) {
+                se = qsum<G>(se); cdf = qsum<G>(cdf); ccdf = qsum<G>(ccdf); pdf = qsum<G>(pdf);
             }
             double reg = 0.0;
             const float inv_se = __builtin_amdgcn_rcpf(se);
@@ -437,11 +476,12 @@ __global__ __launch_bounds__(kBlock) void mixture_tok_kernel(MixArgs a, TokGeom 
     // doubled stages halve the resident waves)
     for (int tp = 0; tp < ntok; tp += gm.TPP) {                               // wave-uniform
         const int npt = min(gm.TPP, ntok - tp);
-        const char* pass_addr = span0 + (size_t)tp * gm.tokstride;
-        const int my_pos = stage_pass(gm, stage_b, pass_addr, nn_last, npt, lane, tli, j, P);
         wave_lds_sync();
         pass_body(tp, npt, stage_b, my_pos, [&](size_t i) { return z_tile[i]; }, [&](int t) { return pad_tile[t]; });
         wave_lds_sync();      // the stage is overwritten by the next pass
+        if (tp + gm.TPP < ntok)
+            my_pos = stage_pass(gm, stage_b, span0 + (size_t)(tp + gm.TPP) * gm.tokstride, nn_last, min(gm.TPP, ntok - tp - gm.TPP),
+                                lane, tli, j + (gm.d0 - gm.sd0), P);
     }
 
     // ---- per-sample results
@@ -521,11 +561,27 @@ __global__ __launch_bounds__(kBlock) void mixture_tok_kernel(MixArgs a, TokGeom 
 }
 
 // ---- host side: geometry ------------------------------------------------------------------------------------
-static int g_split_waves = 2048;      // waves a split launch aims at (cnf_set_mixture_split)
+static int g_split_waves = 4096;      // waves a split launch aims at (cnf_set_mixture_split)
 void set_mixture_split_waves(int w) { g_split_waves = w; }
+static int g_whole_tokens = 1;        // cnf_set_mixture_whole_tokens: A/B switch of the whole-token staging
+void set_mixture_whole_tokens(int on) { g_whole_tokens = on ? 1 : 0; }
+static bool whole_tokens_enabled() { return g_whole_tokens != 0; }
 
 // Returns false when the shape is outside what this kernel is built for (the caller falls back to the fp64 kernel).
-bool make_tok_geom(const MixArgs& a, int kt, int force_g, TokGeom& gm, int& G, size_t& lds) {
+// slot_g > 0: the caller fixes the lanes per item (predicated-slot kernels); otherwise kt > 0 means one lane per item
+// and kt == 0 picks G for the rolled-loop kernel from the stage size (or takes force_g).
+//
+// whole_tokens: the caller can stage ALL D parameter blocks of a token (forward / inverse; the backward writes its
+// stage back and cannot).  Taken when skipping the untransformed blocks skips no 128-byte lines anyway — a span of
+// DA * P * 4 bytes at a D * P * 4 stride touches ~(span + 128) / stride of the lines — because then a pass is ONE
+// contiguous, fully coalesced range instead of 16-byte-aligned pieces of two lines each (Zinc edges / graph colouring
+// tiny, D = 2, K = 8: 104-byte spans at a 208-byte stride; profiles/r03_sweep_mixture.txt).
+//
+// max_wgs > 0: workgroups of this kernel the device holds at once (launch_mixture_tok asks the runtime).  A split
+// launch never exceeds it: its workgroups are equal, so a launch of 1.3 rounds takes two (PTB shape, 43 KB of LDS per
+// workgroup -> 768 resident: 1024 workgroups 23.7 us, 512 workgroups 20.6 us; Zinc edges 1024 vs 512: 22.3 vs 16.5 us).
+bool make_tok_geom(const MixArgs& a, int kt, int force_g, TokGeom& gm, int& G, size_t& lds, int slot_g, bool whole_tokens,
+                   long max_wgs) {
     const int P = a.P;
     // transformed channels must be one contiguous range
     int d0 = 0, DA = a.D;
@@ -540,7 +596,8 @@ bool make_tok_geom(const MixArgs& a, int kt, int force_g, TokGeom& gm, int& G, s
     if (((size_t)a.B * a.N * a.D * P) % 4 != 0) return false;
     const int span = DA * P * 4;
     const int tokstride = a.D * P * 4;
-    const bool contig = DA == a.D;
+    const bool whole = whole_tokens && DA < a.D && (span + 128) * 20 >= tokstride * 19 && whole_tokens_enabled();
+    const bool contig = DA == a.D || whole;
     const bool phase0 = tokstride % 16 == 0 && (d0 * P * 4) % 16 == 0;       // every span starts on a 16-byte boundary
     const int slot = contig ? tokstride : ((span + (phase0 ? 0 : 12) + 15) & ~15);
     if (slot >= 32768) return false;
@@ -550,9 +607,9 @@ bool make_tok_geom(const MixArgs& a, int kt, int force_g, TokGeom& gm, int& G, s
         const int bytes = contig ? tpp * tokstride + 12 : tpp * slot;
         return ((bytes + 1023) >> 10) << 10;
     };
-    G = 1;
-    int tpp = 0, stage = stage_of(1, tpp);
-    if (kt == 0) {
+    G = slot_g > 0 ? slot_g : 1;
+    int tpp = 0, stage = stage_of(G, tpp);
+    if (kt == 0 && slot_g <= 0) {
         const int cands[3] = {1, 2, 4};
         for (int c = 0; c < 3; ++c) {
             int tp2 = 0;
@@ -563,6 +620,7 @@ bool make_tok_geom(const MixArgs& a, int kt, int force_g, TokGeom& gm, int& G, s
         }
     }
     if (stage < 0 || stage > kMaxDmaInstr * 1024) return false;
+    gm.sd0 = whole ? 0 : d0;
     gm.d0 = d0; gm.DA = DA; gm.lpt = DA * G; gm.TPP = tpp; gm.ncopy = a.D - DA; gm.contig = contig ? 1 : 0;
     gm.tokstride = tokstride; gm.slot = slot; gm.stage_bytes = stage;
     gm.div_slot = make_fastdiv((uint32_t)slot);
@@ -596,9 +654,20 @@ bool make_tok_geom(const MixArgs& a, int kt, int force_g, TokGeom& gm, int& G, s
     gm.ppr = ppr;
     if (tiles0 < 2048 && ppr >= 2 && (long)ppr * kWavesPerBlock * 64 < 0x7fffffffL) {
         // few long rows: S workgroups x 4 waves per row, each wave a run of whole passes
-        int S = (int)std::max<long>(1, (g_split_waves + 4L * a.B - 1) / (4L * a.B));
-        S = std::min(S, std::max(1, ppr / kWavesPerBlock));
-        if (S > 1 && !(a.ws_acc && a.ws_cnt)) S = 1;      // no workspace: the four waves of ONE workgroup share a row
+        int s_hi = (int)std::max<long>(1, (g_split_waves + 4L * a.B - 1) / (4L * a.B));
+        s_hi = std::min(s_hi, std::max(1, ppr / kWavesPerBlock));
+        if (max_wgs > 0) s_hi = (int)std::max<long>(1, std::min<long>(s_hi, max_wgs / a.B));
+        if (s_hi > 1 && !(a.ws_acc && a.ws_cnt)) s_hi = 1;      // no workspace: the four waves of ONE workgroup share a row
+        // the fewest workgroups per row that reach the smallest number of passes per wave (a wave walks its passes one
+        // after the other; every further workgroup costs its table build and its arrival at the row's ticket)
+        int S = 1, best_pp = INT_MAX;
+        for (int c = 1; c <= s_hi; ++c) {
+            const int pp = (ppr + c * kWavesPerBlock - 1) / (c * kWavesPerBlock);
+            if (pp < best_pp) {
+                best_pp = pp;
+                S = c;
+            }
+        }
         if ((long)a.B * S * kWavesPerBlock > tiles0) {
             gm.split = 1; gm.S = S; gm.rw = 1;
         }
@@ -618,39 +687,122 @@ bool make_tok_geom(const MixArgs& a, int kt, int force_g, TokGeom& gm, int& G, s
     return lds <= 65536;
 }
 
+// Mixtures per lane (KT) and lanes per item (G) for a run-time K that has no exact instantiation, from the
+// instantiated pairs with KT * G >= K.  A launch that fills the chip costs ~ KT * G per item (slots past K are executed
+// with weight zero), one that does not costs ~ KT (the length of a lane's chain): `items` transformed elements on
+// `G * items / 64` waves against the ~4096 waves the chip holds at the 4 waves per SIMD these kernels reach.
+// (B = 1024, N = 64, D = 4, K = 10: 13 slots on one lane 15.7 / 23.1 us forward / inverse, the rolled loop on 4 lanes
+// 11.6 / 19.3.)  kt = 0: none (rolled loop).
+static void slots_for(int K, long items, int& kt, int& g) {
+    static const int pairs[9][2] = {{7, 1}, {13, 1}, {16, 1}, {7, 2}, {13, 2}, {16, 2}, {7, 4}, {13, 4}, {16, 4}};
+    kt = 0; g = 0;
+    double best = 1e300;
+    for (const auto& pr : pairs) {
+        if (pr[0] * pr[1] < K) continue;
+        const double waves = (double)items * pr[1] / 64.0;
+        const double cost = pr[0] * std::max(1.0, waves / 4096.0) * (1.0 + 1e-3 * pr[0] * pr[1]);     // ties: less waste
+        if (cost < best) {
+            best = cost; kt = pr[0]; g = pr[1];
+        }
+    }
+}
+
+using TokKernel = void (*)(MixArgs, TokGeom);
+
+template <int KT, int G, bool PR>
+static TokKernel tok_variant(const MixArgs& a, bool nll) {
+    if (a.reverse) return mixture_tok_kernel<KT, true, G, false, 0, PR>;
+    if (nll) return mixture_tok_kernel<KT, false, G, true, 0, PR>;
+    if (a.e_w) {
+        if constexpr (G == 1 && !PR) {
+            switch (a.D) {
+                case 2: return mixture_tok_kernel<KT, false, 1, false, 2>;
+                case 3: return mixture_tok_kernel<KT, false, 1, false, 3>;
+                case 4: return mixture_tok_kernel<KT, false, 1, false, 4>;
+                case 6: return mixture_tok_kernel<KT, false, 1, false, 6>;
+                default: return nullptr;
+            }
+        }
+        return nullptr;
+    }
+    return mixture_tok_kernel<KT, false, G, false, 0, PR>;
+}
+
+static TokKernel tok_kernel_for(const MixArgs& a, int kt, int slot_g, int G, bool nll) {
+    if (slot_g > 0) {
+        switch (kt * 8 + slot_g) {
+            case 7 * 8 + 1: return tok_variant<7, 1, true>(a, nll);
+            case 13 * 8 + 1: return tok_variant<13, 1, true>(a, nll);
+            case 16 * 8 + 1: return tok_variant<16, 1, true>(a, nll);
+            case 7 * 8 + 2: return tok_variant<7, 2, true>(a, nll);
+            case 13 * 8 + 2: return tok_variant<13, 2, true>(a, nll);
+            case 16 * 8 + 2: return tok_variant<16, 2, true>(a, nll);
+            case 7 * 8 + 4: return tok_variant<7, 4, true>(a, nll);
+            case 13 * 8 + 4: return tok_variant<13, 4, true>(a, nll);
+            case 16 * 8 + 4: return tok_variant<16, 4, true>(a, nll);
+            default: return nullptr;
+        }
+    }
+    if (kt == 4) return tok_variant<4, 1, false>(a, nll);
+    if (kt == 8) return tok_variant<8, 1, false>(a, nll);
+    if (kt == 16) return tok_variant<16, 1, false>(a, nll);
+    if (G == 1) return tok_variant<0, 1, false>(a, nll);
+    if (G == 2) return tok_variant<0, 2, false>(a, nll);
+    return tok_variant<0, 4, false>(a, nll);
+}
+
+// workgroups of `kern` (with `lds` bytes of dynamic LDS) that are resident on the device at once: registers, LDS and
+// the wave slots as the runtime's occupancy calculator sees them, times the number of CUs; cached per (kernel, LDS size)
+static long resident_workgroups(TokKernel kern, size_t lds) {
+    static std::mutex mu;
+    static std::map<std::pair<const void*, size_t>, long> cache;
+    static int cus = 0;
+    std::lock_guard<std::mutex> lock(mu);
+    const auto key = std::make_pair(reinterpret_cast<const void*>(kern), lds);
+    const auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    if (cus == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+    }
+    int per_cu = 0;
+    long n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), kBlock, lds) == hipSuccess &&
+        per_cu > 0)
+        n = (long)per_cu * cus;
+    (void)hipGetLastError();
+    cache[key] = n;
+    return n;
+}
+
 // forward (optionally with the NLL epilogue) or Newton inverse on the token-pass kernel; false = not handled
 bool launch_mixture_tok(MixArgs& a, hipStream_t st, int force_g) {
-    const int kt = (a.K == 4 || a.K == 8 || a.K == 16) ? a.K : 0;
+    int kt = (a.K == 4 || a.K == 8 || a.K == 16) ? a.K : 0;
+    // every other K: predicated register slots (force_g > 0, the sweep / test knob, keeps the rolled-loop kernel and
+    // its lanes per item; the epilogue kernels exist for one lane per item only)
+    int slot_g = 0;
+    if (kt == 0 && force_g == 0 && !a.e_w) slots_for(a.K, (long)a.B * a.N * a.DA, kt, slot_g);
     TokGeom gm;
     int G = 1;
     size_t lds = 0;
-    if (!make_tok_geom(a, kt, force_g, gm, G, lds)) return false;
+    if (!make_tok_geom(a, kt, force_g, gm, G, lds, slot_g, true, 0)) {
+        if (slot_g == 0) return false;
+        kt = 0; slot_g = 0;                     // the slot geometry does not fit: rolled loop
+        if (!make_tok_geom(a, kt, force_g, gm, G, lds, 0, true, 0)) return false;
+    }
     const bool nll = a.nll_out != nullptr;
+    if (a.e_w && (G != 1 || !(a.D == 2 || a.D == 3 || a.D == 4 || a.D == 6))) return false;
+    const TokKernel kern = tok_kernel_for(a, kt, slot_g, G, nll);
+    if (!kern) return false;
+    if (gm.split && gm.S > 1) {
+        const long cap = resident_workgroups(kern, lds);
+        if (cap > 0 && (long)a.B * gm.S > cap && !make_tok_geom(a, kt, force_g, gm, G, lds, slot_g, true, cap)) return false;
+    }
     const dim3 block(kBlock);
     const dim3 grid(gm.split ? (unsigned)((long)a.B * gm.S) : (unsigned)((gm.ntiles + kWavesPerBlock - 1) / kWavesPerBlock));
-#define CNF_TOK(KT_, G_)                                                                                            \
-    do {                                                                                                            \
-        if (a.reverse) CNF_LAUNCH((mixture_tok_kernel<KT_, true, G_, false>), grid, block, lds, st, a, gm);         \
-        else if (nll) CNF_LAUNCH((mixture_tok_kernel<KT_, false, G_, true>), grid, block, lds, st, a, gm);          \
-        else if (a.e_w && G_ == 1) {                                                                                \
-            switch (a.D) {                                                                                          \
-                case 2: CNF_LAUNCH((mixture_tok_kernel<KT_, false, 1, false, 2>), grid, block, lds, st, a, gm); break; \
-                case 3: CNF_LAUNCH((mixture_tok_kernel<KT_, false, 1, false, 3>), grid, block, lds, st, a, gm); break; \
-                case 4: CNF_LAUNCH((mixture_tok_kernel<KT_, false, 1, false, 4>), grid, block, lds, st, a, gm); break; \
-                case 6: CNF_LAUNCH((mixture_tok_kernel<KT_, false, 1, false, 6>), grid, block, lds, st, a, gm); break; \
-                default: return false;                                                                              \
-            }                                                                                                       \
-        } else if (a.e_w) return false;                                                                             \
-        else CNF_LAUNCH((mixture_tok_kernel<KT_, false, G_, false>), grid, block, lds, st, a, gm);                  \
-    } while (0)
-    if (a.e_w && (G != 1 || !(a.D == 2 || a.D == 3 || a.D == 4 || a.D == 6))) return false;
-    if (kt == 4) CNF_TOK(4, 1);
-    else if (kt == 8) CNF_TOK(8, 1);
-    else if (kt == 16) CNF_TOK(16, 1);
-    else if (G == 1) CNF_TOK(0, 1);
-    else if (G == 2) CNF_TOK(0, 2);
-    else CNF_TOK(0, 4);
-#undef CNF_TOK
+    CNF_LAUNCH(kern, grid, block, lds, st, a, gm);
     return true;
 }
 

@@ -228,11 +228,15 @@ int cnf_mixture_coupling_actconv(const float* z, const float* nn_out,
                                  int* flags, cnf_stream_t stream);
 
 /* Tuning / A-B knobs of the fp32 mixture kernels: which kernel serves math mode 1 (0 = token-pass kernel on
- * DMA-staged rows, default; 1 = the round-1 kernel), lanes per item for a run-time K (0 = automatic, 1, 2, 4),
- * and the number of waves a split-row launch aims at (default 4096). */
+ * DMA-staged rows, default; 1 = the round-1 kernel); lanes per item for a run-time K (0 = automatic: K = 4 / 8 / 16
+ * exactly, every other K <= 64 on predicated register slots, larger K on the rolled LDS loop; 1, 2, 4 = the rolled
+ * loop with that many lanes per item, the A/B partner of the register slots); the number of waves a split-row launch
+ * aims at (default 4096; never more workgroups than the device holds at once); and whether forward / inverse may stage whole tokens when skipping the untransformed
+ * parameter blocks would skip no 128-byte lines anyway (default 1).  No counterpart in the reference (pure tuning). */
 void cnf_set_mixture_kernel(int which);
 void cnf_set_mixture_lanes(int lanes_per_item);
 void cnf_set_mixture_split(int waves);
+void cnf_set_mixture_whole_tokens(int on);
 
 /* MixtureCDFCoupling.get_mixt_params (mixture_cdf_layer.py:145-180): split + bound + mask in
  * fp32, results cast to fp64: t, log_s [B,N,D]; log_pi, mixt_t, mixt_log_s [B,N,D,K]. */

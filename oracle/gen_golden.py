@@ -9,6 +9,7 @@ coupling subnets are replaced by a stub that returns a pre-drawn ``nn_out`` so t
 arithmetic is captured in isolation.  Each .npz holds, per case, the inputs, the parameters and the
 reference outputs plus a JSON ``meta`` entry describing the cases.  The fixtures are data only.
 """
+import copy
 import io
 import json
 import os
@@ -590,6 +591,14 @@ def gen_grads():
     def leaf(t):
         return t.clone().requires_grad_(True)
 
+    def leaf64(t):
+        return t.detach().double().clone().requires_grad_(True)
+
+    # Every case also carries the SAME gradients from a float64 run of the reference (`g64_*`: the module converted
+    # with .double(), double inputs): |g - g64| is the rounding noise of the reference's own fp32 autograd, the unit in
+    # which the GPU tests state their gradient tolerance (tests/test_gpu_parity.py, grad_close).  The float64 runs
+    # consume no random numbers, so the float32 arrays are the ones round 1 wrote.
+
     # affine coupling, both directions, channel and chess masks
     for (B, N, D, kind, reverse) in [(4, 6, 4, "channel", False), (3, 5, 6, "channel", True), (4, 7, 1, "chess", False),
                                      (5, 3, 3, "channel", True), (2, 64, 6, "channel", False)]:
@@ -602,9 +611,15 @@ def gen_grads():
         wz, wl = torch.randn(B, N, D, generator=g), torch.randn(B, generator=g)
         zo, lo = layer(z, ldj=ldj, reverse=reverse)
         ((zo * wz).sum() + (lo * wl).sum()).backward()
+        l64 = copy.deepcopy(layer).double()
+        z64, nn64, ldj64 = leaf64(z), leaf64(nn_out), leaf64(ldj)
+        l64.nn.value = nn64
+        zo64, lo64 = l64(z64, ldj=ldj64, reverse=reverse)
+        ((zo64 * wz.double()).sum() + (lo64 * wl.double()).sum()).backward()
         cases.append(dict(meta=dict(layer="affine", B=B, N=N, D=D, mask_kind=kind, reverse=reverse), z=z.detach(), nn_out=nn_out.detach(),
                           ldj=ldj.detach(), mask=mask, scaling_factor=layer.scaling_factor.data, wz=wz, wl=wl,
-                          g_z=z.grad, g_nn=nn_out.grad, g_ldj=ldj.grad, g_sf=layer.scaling_factor.grad))
+                          g_z=z.grad, g_nn=nn_out.grad, g_ldj=ldj.grad, g_sf=layer.scaling_factor.grad,
+                          g64_z=z64.grad, g64_nn=nn64.grad, g64_ldj=ldj64.grad, g64_sf=l64.scaling_factor.grad))
 
     # ActNorm
     for (B, N, D, mode, reverse) in [(4, 6, 3, "length_mask", False), (3, 5, 4, "none", True), (5, 4, 6, "mask", False), (3, 7, 2, "length", True)]:
@@ -621,9 +636,14 @@ def gen_grads():
         wz, wl = torch.randn(B, N, D, generator=g), torch.randn(B, generator=g)
         zo, lo = layer(z, ldj=ldj * 1.0, reverse=reverse, **kw)
         ((zo * wz).sum() + (lo * wl).sum()).backward()
+        l64 = copy.deepcopy(layer).double()
+        z64, ldj64 = leaf64(z), leaf64(ldj)
+        zo64, lo64 = l64(z64, ldj=ldj64 * 1.0, reverse=reverse, **{k: (v.double() if v.is_floating_point() else v) for k, v in kw.items()})
+        ((zo64 * wz.double()).sum() + (lo64 * wl.double()).sum()).backward()
         cases.append(dict(meta=dict(layer="actnorm", B=B, N=N, D=D, mode=mode, reverse=reverse), z=z.detach(), ldj=ldj.detach(),
                           bias=layer.bias.data, scales=layer.scales.data, length=ln, pad=pad, wz=wz, wl=wl,
-                          g_z=z.grad, g_ldj=ldj.grad, g_bias=layer.bias.grad, g_scales=layer.scales.grad))
+                          g_z=z.grad, g_ldj=ldj.grad, g_bias=layer.bias.grad, g_scales=layer.scales.grad,
+                          g64_z=z64.grad, g64_ldj=ldj64.grad, g64_bias=l64.bias.grad, g64_scales=l64.scales.grad))
 
     # ExtActNorm
     for (B, N, D, padded, reverse) in [(6, 1, 3, False, False), (4, 5, 4, True, False), (5, 1, 2, False, True)]:
@@ -636,8 +656,15 @@ def gen_grads():
         wz, wl = torch.randn(B, N, D, generator=g), torch.randn(B, generator=g)
         zo, lo = layer(z, ldj * 1.0, ext_input=z, reverse=reverse, **(dict(channel_padding_mask=pad) if padded else {}))
         ((zo * wz).sum() + (lo * wl).sum()).backward()
+        net64 = Inject()
+        l64 = ExtActNormFlow(D, net=net64).double()
+        z64, nn64, ldj64 = leaf64(z), leaf64(nn_out), leaf64(ldj)
+        net64.value = nn64
+        zo64, lo64 = l64(z64, ldj64 * 1.0, ext_input=z64, reverse=reverse, **(dict(channel_padding_mask=pad.double()) if padded else {}))
+        ((zo64 * wz.double()).sum() + (lo64 * wl.double()).sum()).backward()
         cases.append(dict(meta=dict(layer="ext_actnorm", B=B, N=N, D=D, padded=padded, reverse=reverse), z=z.detach(), nn_out=nn_out.detach(),
-                          ldj=ldj.detach(), pad=pad, wz=wz, wl=wl, g_z=z.grad, g_nn=nn_out.grad, g_ldj=ldj.grad))
+                          ldj=ldj.detach(), pad=pad, wz=wz, wl=wl, g_z=z.grad, g_nn=nn_out.grad, g_ldj=ldj.grad,
+                          g64_z=z64.grad, g64_nn=nn64.grad, g64_ldj=ldj64.grad))
 
     # invertible 1x1 convolution (LU parameters and dense weight)
     np.random.seed(61)
@@ -662,6 +689,15 @@ def gen_grads():
             c["sd_" + k] = v
         for k, v in layer.named_parameters():
             c["gp_" + k] = v.grad
+        if not reverse:      # the reference's inverse casts its weight to float (permutation_layers.py:86): no float64 run of it exists
+            l64 = copy.deepcopy(layer).double()
+            l64.zero_grad()
+            x64, ldj64 = leaf64(x), leaf64(ldj)
+            zo64, lo64 = l64(x64, ldj=ldj64, reverse=reverse, **{k: (v.double() if v.is_floating_point() else v) for k, v in kw.items()})
+            ((zo64 * wz.double()).sum() + (lo64 * wl.double()).sum()).backward()
+            c["g64_x"], c["g64_ldj"] = x64.grad, ldj64.grad
+            for k, v in l64.named_parameters():
+                c["gp64_" + k] = v.grad
         cases.append(c)
 
     # logistic prior log-prob, NLL assembly, sigmoid flows
@@ -669,7 +705,9 @@ def gen_grads():
     x = leaf(2 * torch.randn(5, 6, 3, generator=g))
     w = torch.randn(5, 6, 3, generator=g)
     (prior.log_prob(x) * w).sum().backward()
-    cases.append(dict(meta=dict(layer="log_prob"), x=x.detach(), w=w, g_x=x.grad))
+    x64 = leaf64(x)
+    (prior.log_prob(x64) * w.double()).sum().backward()
+    cases.append(dict(meta=dict(layer="log_prob"), x=x.detach(), w=w, g_x=x.grad, g64_x=x64.grad))
     B, N, D = 5, 6, 4
     z, ldj = leaf(1.5 * torch.randn(B, N, D, generator=g)), leaf(torch.randn(B, generator=g))
     ln = lengths(B, N, g)
@@ -677,8 +715,11 @@ def gen_grads():
     wl = torch.randn(B, generator=g)
     nll = (-ldj) / ln.float() + (-(prior.log_prob(z) * pad).sum(dim=[1, 2])) / ln.float()
     (nll * wl).sum().backward()
+    z64, ldj64 = leaf64(z), leaf64(ldj)
+    nll64 = (-ldj64) / ln.double() + (-(prior.log_prob(z64) * pad.double()).sum(dim=[1, 2])) / ln.double()
+    (nll64 * wl.double()).sum().backward()
     cases.append(dict(meta=dict(layer="nll", B=B, N=N, D=D), z=z.detach(), ldj=ldj.detach(), length=ln, pad=pad, wl=wl,
-                      g_z=z.grad, g_ldj=ldj.grad))
+                      g_z=z.grad, g_ldj=ldj.grad, g64_z=z64.grad, g64_ldj=ldj64.grad))
     for reverse in (False, True):
         layer = SigmoidFlow()
         zi = leaf(2 * torch.randn(4, 6, 1, generator=g)) if not reverse else leaf(torch.rand(4, 6, 1, generator=g))
@@ -686,7 +727,11 @@ def gen_grads():
         wz, wl = torch.randn(4, 6, 1, generator=g), torch.randn(4, generator=g)
         zo, lo = layer(zi, ldj=ldj, reverse=reverse)
         ((zo * wz).sum() + (lo * wl).sum()).backward()
-        cases.append(dict(meta=dict(layer="sigmoid", reverse=reverse), z=zi.detach(), ldj=ldj.detach(), wz=wz, wl=wl, g_z=zi.grad, g_ldj=ldj.grad))
+        z64, ldj64 = leaf64(zi), leaf64(ldj)
+        zo64, lo64 = SigmoidFlow()(z64, ldj=ldj64, reverse=reverse)
+        ((zo64 * wz.double()).sum() + (lo64 * wl.double()).sum()).backward()
+        cases.append(dict(meta=dict(layer="sigmoid", reverse=reverse), z=zi.detach(), ldj=ldj.detach(), wz=wz, wl=wl, g_z=zi.grad, g_ldj=ldj.grad,
+                          g64_z=z64.grad, g64_ldj=ldj64.grad))
 
     # mixture-CDF coupling forward (the inverse is never differentiated by the reference)
     for (B, N, D, K, kind, reg_max, training, padded) in [(3, 6, 4, 8, "channel", -1, True, False), (3, 5, 6, 16, "channel", 3.5, True, True),
@@ -719,6 +764,13 @@ def gen_grads():
                  g_z=z.grad, g_nn=nn_out.grad, g_sf=layer.scaling_factor.grad, g_msf=layer.mixture_scaling_factor.grad)
         if mask is not None:
             c["mask"] = mask
+        l64 = copy.deepcopy(layer).double()
+        l64.zero_grad()
+        z64, nn64 = leaf64(z), leaf64(nn_out)
+        l64.nn.value = nn64
+        res64 = l64(z64, reverse=False, **(dict(channel_padding_mask=pad.double()) if padded else {}))
+        ((res64[0] * wz.double()).sum() + (res64[1] * wl.double()).sum()).backward()
+        c.update(g64_z=z64.grad, g64_nn=nn64.grad, g64_sf=l64.scaling_factor.grad, g64_msf=l64.mixture_scaling_factor.grad)
         cases.append(c)
 
     # mixture-model encoder: gradients reach the embedding and the predictor through the class table
@@ -744,6 +796,13 @@ def gen_grads():
             c["sd_" + k] = v
         for k, v in enc.named_parameters():
             c["gp_" + k] = v.grad
+        e64 = copy.deepcopy(enc).double()
+        e64.zero_grad()
+        torch.manual_seed(900 + i)
+        zo64, lo64, _ = e64(cat, reverse=False, beta=beta, **(dict(channel_padding_mask=pad.double()) if padded else {}))
+        ((zo64 * wz.double()).sum() + (lo64 * wl.double()).sum()).backward()
+        for k, v in e64.named_parameters():
+            c["gp64_" + k] = v.grad
         cases.append(c)
     save("grads", cases)
 

@@ -19,7 +19,6 @@ from categoricalnf_amd import _lib
 pytestmark = pytest.mark.gpu
 
 ELEM = dict(rtol=2e-5, atol=2e-5)
-LDJ = dict(rtol=1e-4, atol=1e-4)
 
 
 def ops():
@@ -38,6 +37,9 @@ def close(a, b, **kw):
 def loglik_close(actual, ref, rel=1e-4, floor=1.0):
     """BASELINE north_star bar on per-sample log-likelihood terms: max |actual - ref| <= rel * max(|ref|, floor)."""
     a, r = actual.detach().double().cpu(), ref.detach().double().cpu()
+    assert a.shape == r.shape, (a.shape, r.shape)
+    if a.numel() == 0:
+        return
     worst = ((a - r).abs() / r.abs().clamp(min=floor)).max().item()
     assert worst <= rel, "relative deviation %.3g exceeds %.1g" % (worst, rel)
 
@@ -54,15 +56,15 @@ def test_library_loaded_is_hip():
 @pytest.mark.parametrize("c", load_cases("affine_coupling"))
 def test_affine_golden(c):
     zf, lf = ops().affine_coupling(g(c.z), g(c.nn_out), g(c.scaling_factor), g(c.mask), reverse=False, ldj=g(c.ldj_in))
-    close(zf, c.z_fwd, **ELEM); close(lf, c.ldj_fwd, **LDJ)
+    close(zf, c.z_fwd, **ELEM); loglik_close(lf, c.ldj_fwd)
     zr, lr = ops().affine_coupling(g(c.z_fwd), g(c.nn_out), g(c.scaling_factor), g(c.mask), reverse=True)
-    close(zr, c.z_rev, **ELEM); close(lr, c.ldj_rev, **LDJ)
+    close(zr, c.z_rev, **ELEM); loglik_close(lr, c.ldj_rev)
     s, t = ops().affine_params(g(c.nn_out), g(c.mask), g(c.scaling_factor))
     close(s, c.s, **ELEM); close(t, c.t, **ELEM)
     s, t = ops().affine_params(g(c.nn_out), g(c.mask), None)
     close(s, c.s_nofac, **ELEM); close(t, c.t_nofac, **ELEM)
     z2, l2 = ops().affine_transform(g(c.z), g(c.s), g(c.t), reverse=False)
-    close(z2, c.z_fwd, **ELEM); close(l2, c.ldj_fwd - c.ldj_in, **LDJ)
+    close(z2, c.z_fwd, **ELEM); loglik_close(l2, c.ldj_fwd - c.ldj_in)
 
 
 @pytest.mark.parametrize("B,N,D,chess", [(37, 64, 6, False), (130, 16, 4, False), (9, 703, 2, False), (50, 21, 2, False),
@@ -78,10 +80,10 @@ def test_affine_vs_oracle(B, N, D, chess):
     for use_sf in (True, False):
         zf_o, lf_o = O.affine_coupling(z, nn_out, mask, sf if use_sf else None, reverse=False, ldj=ldj0)
         zf, lf = ops().affine_coupling(g(z), g(nn_out), g(sf) if use_sf else None, g(mask), reverse=False, ldj=g(ldj0))
-        close(zf, zf_o, **ELEM); close(lf, lf_o, **LDJ)
+        close(zf, zf_o, **ELEM); loglik_close(lf, lf_o)
         zr_o, lr_o = O.affine_coupling(zf_o, nn_out, mask, sf if use_sf else None, reverse=True)
         zr, lr = ops().affine_coupling(g(zf_o), g(nn_out), g(sf) if use_sf else None, g(mask), reverse=True)
-        close(zr, zr_o, **ELEM); close(lr, lr_o, **LDJ)
+        close(zr, zr_o, **ELEM); loglik_close(lr, lr_o)
 
 
 def test_affine_tiling_knobs_do_not_change_results():
@@ -100,7 +102,7 @@ def test_affine_tiling_knobs_do_not_change_results():
                 if ref is None:
                     ref = out
                     zo, lo = O.affine_coupling(z, nn_out, mask, sf)
-                    close(out[0], zo, **ELEM); close(out[1], lo, **LDJ)
+                    close(out[0], zo, **ELEM); loglik_close(out[1], lo)
                 assert torch.equal(out[0], ref[0])            # element math independent of the tiling
                 close(out[1], ref[1], rtol=1e-6, atol=1e-5)    # sums may associate differently
         # hardware-transcendental math mode: same results to ~1e-6
@@ -126,7 +128,7 @@ def test_affine_full_size_properties():
     assert torch.equal(zf[..., :3], z[..., :3])                   # masked channels untouched bit-for-bit
     # a slice against the oracle + linearity of the log-det in the batch (checksum of checksums)
     zo, lo = O.affine_coupling(z[:64].cpu(), nn_out[:64].cpu(), mask.cpu(), sf.cpu())
-    close(zf[:64], zo, **ELEM); close(lf[:64], lo, **LDJ)
+    close(zf[:64], zo, **ELEM); loglik_close(lf[:64], lo)
     _, l_half = ops().affine_coupling(z[:8192].contiguous(), nn_out[:8192].contiguous(), sf, mask)
     assert torch.equal(l_half, lf[:8192])
 
@@ -142,12 +144,12 @@ def test_mixture_golden(c):
     zf, lf, reg = ops().mixture_coupling(g(c.z), g(c.nn_out), g(mask), reverse=False, **kw)
     tail = m.get("tail", 1.0) > 1.0
     etol = dict(rtol=1e-4, atol=1e-4) if tail else ELEM
-    close(zf, c.z_fwd, **etol); close(lf, c.ldj_fwd, **LDJ)
+    close(zf, c.z_fwd, **etol); loglik_close(lf, c.ldj_fwd)
     if "reg_ldj" in c:
-        close(reg, c.reg_ldj, **LDJ)
+        loglik_close(reg, c.reg_ldj)
     if "z_rev" in c:
         zr, lr, _ = ops().mixture_coupling(g(c.z_fwd), g(c.get("nn_out_rev", c.nn_out)), g(mask), reverse=True, **kw)
-        close(zr, c.z_rev, rtol=1e-4, atol=1e-4); close(lr, c.ldj_rev, **LDJ)
+        close(zr, c.z_rev, rtol=1e-4, atol=1e-4); loglik_close(lr, c.ldj_rev)
     if "p_t" in c:
         p = ops().mixture_params(g(c.nn_out), g(mask), m["K"], g(c.scaling_factor), g(c.mixture_scaling_factor))
         for got, key in zip(p, ["p_t", "p_log_s", "p_log_pi", "p_mixt_t", "p_mixt_log_s"]):
@@ -179,13 +181,13 @@ def test_mixture_vs_oracle(B, N, D, K, kind):
     zo, lo, ro = O.mixture_coupling(z, nn_out, mask, scaling_factor=sf, mixture_scaling_factor=msf, channel_padding_mask=pad, **kw)
     zf, lf, rf = ops().mixture_coupling(g(z), g(nn_out), g(mask), scaling_factor=g(sf), mixture_scaling_factor=g(msf),
                                         channel_padding_mask=g(pad), **kw)
-    close(zf, zo, **ELEM); close(lf, lo, **LDJ); close(rf, ro, **LDJ)
+    close(zf, zo, **ELEM); loglik_close(lf, lo); loglik_close(rf, ro)
     # inverse (K = 51 exceeds the LDS constant table: exercises the recompute path)
     zo2, lo2, _ = O.mixture_coupling(zo, nn_out, mask, scaling_factor=sf, mixture_scaling_factor=msf,
                                      channel_padding_mask=pad, reverse=True, **kw)
     zr, lr, _ = ops().mixture_coupling(g(zo), g(nn_out), g(mask), scaling_factor=g(sf), mixture_scaling_factor=g(msf),
                                        channel_padding_mask=g(pad), reverse=True, **kw)
-    close(zr, zo2, rtol=1e-4, atol=1e-4); close(lr, lo2, **LDJ)
+    close(zr, zo2, rtol=1e-4, atol=1e-4); loglik_close(lr, lo2)
     # round trip on the transformed, un-padded entries
     keep = (pad if pad is not None else torch.ones(B, N, 1)).expand(-1, -1, D) > 0
     assert ((zr.cpu() - z)[keep]).abs().max() < 5e-4
@@ -215,7 +217,7 @@ def test_mixture_exact_mode_vs_oracle(exact_math, B, N, D, K, kind):
     zo, lo, ro = O.mixture_coupling(z, nn_out, mask, scaling_factor=sf, mixture_scaling_factor=msf, channel_padding_mask=pad, **kw)
     zf, lf, rf = ops().mixture_coupling(g(z), g(nn_out), g(mask), scaling_factor=g(sf), mixture_scaling_factor=g(msf),
                                         channel_padding_mask=g(pad), **kw)
-    close(zf, zo, **ELEM); close(lf, lo, **LDJ); close(rf, ro, **LDJ)
+    close(zf, zo, **ELEM); loglik_close(lf, lo); loglik_close(rf, ro)
     # fp64 inverse (safeguarded Newton and the reference's bisection)
     zo2, lo2, _ = O.mixture_coupling(zo, nn_out, mask, scaling_factor=sf, mixture_scaling_factor=msf,
                                      channel_padding_mask=pad, reverse=True, **kw)
@@ -226,7 +228,7 @@ def test_mixture_exact_mode_vs_oracle(exact_math, B, N, D, K, kind):
                                                channel_padding_mask=g(pad), reverse=True, **kw)
         finally:
             _lib.load().cnf_set_inverse_mode(1)
-        close(zr, zo2, rtol=1e-4, atol=1e-4); close(lr, lo2, **LDJ)
+        close(zr, zo2, rtol=1e-4, atol=1e-4); loglik_close(lr, lo2)
 
 
 @pytest.mark.parametrize("scale", [1.0, 4.0, 12.0, 40.0])
@@ -259,7 +261,7 @@ def test_mixture_fast_vs_exact(scale):
         zo, lo, _ = O.mixture_coupling(z, nn_out, mask, num_mixtures=K, scaling_factor=sf, mixture_scaling_factor=msf,
                                        reg_max=3.5, reg_factor=2.0, is_training=True)
         fo = torch.isfinite(zo)
-        close(zf.cpu()[fo], zo[fo], rtol=1e-4, atol=1e-4); close(lf, lo, **LDJ)
+        close(zf.cpu()[fo], zo[fo], rtol=1e-4, atol=1e-4); loglik_close(lf, lo)
 
 
 def test_mixture_underflow_fallback_matches_logspace():
@@ -275,7 +277,7 @@ def test_mixture_underflow_fallback_matches_logspace():
     zo, lo, _ = O.mixture_coupling(z, nn_out, mask, K, None, None)
     zf, lf, _ = ops().mixture_coupling(g(z), g(nn_out), g(mask), K)
     assert torch.isfinite(lf).all()
-    close(lf, lo, **LDJ)
+    loglik_close(lf, lo)
     fin = torch.isfinite(zo)
     close(zf.cpu()[fin], zo[fin], **ELEM)
 
@@ -293,7 +295,7 @@ def test_mixture_full_size_properties():
     assert ((lf + lr).abs() / lf.abs().clamp(min=1.0)).max().item() < 1e-4
     assert torch.equal(zf[..., :2], z[..., :2])
     zo, lo, _ = O.mixture_coupling(z[:32].cpu(), nn_out[:32].cpu(), mask.cpu(), K, None, None)
-    close(zf[:32], zo, **ELEM); close(lf[:32], lo, **LDJ)
+    close(zf[:32], zo, **ELEM); loglik_close(lf[:32], lo)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -308,9 +310,9 @@ def test_actnorm_golden(c):
     ldj = g(c.ldj_in.clone())
     zf, lf = ops().actnorm(g(c.z), g(c.bias), g(c.scales), reverse=False, ldj=ldj, **kw)
     assert lf.data_ptr() == ldj.data_ptr()           # in-place `ldj +=` like the reference
-    close(zf, c.z_fwd, **ELEM); close(lf, c.ldj_fwd, **LDJ)
+    close(zf, c.z_fwd, **ELEM); loglik_close(lf, c.ldj_fwd)
     zr, lr = ops().actnorm(g(c.z_fwd), g(c.bias), g(c.scales), reverse=True, **kw)
-    close(zr, c.z_rev, **ELEM); close(lr, c.ldj_rev, **LDJ)
+    close(zr, c.z_rev, **ELEM); loglik_close(lr, c.ldj_rev)
     b, s = ops().actnorm_data_init(g(c.z), g(c.pad) if "mask" in mode else None)
     close(b, c.init_bias, rtol=1e-5, atol=1e-5); close(s, c.init_scales, rtol=1e-5, atol=1e-5)
 
@@ -319,9 +321,9 @@ def test_actnorm_golden(c):
 def test_ext_actnorm_golden(c):
     pad = g(c.pad) if c.meta["padded"] else None
     zf, lf = ops().ext_actnorm(g(c.z), g(c.nn_out), reverse=False, channel_padding_mask=pad, ldj=g(c.ldj_in.clone()))
-    close(zf, c.z_fwd, **ELEM); close(lf, c.ldj_fwd, **LDJ)
+    close(zf, c.z_fwd, **ELEM); loglik_close(lf, c.ldj_fwd)
     zr, lr = ops().ext_actnorm(g(c.z_fwd), g(c.nn_out), reverse=True, channel_padding_mask=pad)
-    close(zr, c.z_rev, **ELEM); close(lr, c.ldj_rev, **LDJ)
+    close(zr, c.z_rev, **ELEM); loglik_close(lr, c.ldj_rev)
 
 
 @pytest.mark.parametrize("c", load_cases("invconv"))
@@ -341,9 +343,9 @@ def test_invconv_golden(c):
         for train in (True, False):
             layer.train(train)
             zf, lf = layer(g(c.z), ldj=g(c.ldj_in.clone()), reverse=False, **kw)
-            close(zf, c.z_fwd, **ELEM); close(lf, c.ldj_fwd, **LDJ)
+            close(zf, c.z_fwd, **ELEM); loglik_close(lf, c.ldj_fwd)
             zr, lr = layer(g(c.z_fwd), reverse=True, **kw)
-            close(zr, c.z_rev, **ELEM); close(lr, c.ldj_rev, **LDJ)
+            close(zr, c.z_rev, **ELEM); loglik_close(lr, c.ldj_rev)
         assert str(torch.device("cuda:0")) in layer.eval_dict or "cuda:0" in layer.eval_dict
 
 
@@ -358,11 +360,11 @@ def test_actnorm_invconv_vs_oracle(D):
     pad = O.length_mask(ln, N)
     zo, lo = O.invconv(z, w, sldj, length=ln, channel_padding_mask=pad)
     zf, lf = ops().invconv(g(z), g(w), g(sldj), length=g(ln), channel_padding_mask=g(pad))
-    close(zf, zo, **ELEM); close(lf, lo, **LDJ)
+    close(zf, zo, **ELEM); loglik_close(lf, lo)
     bias, sc = torch.randn(1, 1, D, generator=gen), 0.3 * torch.randn(1, 1, D, generator=gen)
     zo, lo = O.actnorm(z, bias, sc, channel_padding_mask=pad)           # length from the mask row-sum
     zf, lf = ops().actnorm(g(z), g(bias), g(sc), channel_padding_mask=g(pad))
-    close(zf, zo, **ELEM); close(lf, lo, **LDJ)
+    close(zf, zo, **ELEM); loglik_close(lf, lo)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -377,7 +379,7 @@ def test_prior_golden():
         else:
             sums = torch.zeros(2, dtype=torch.float64, device="cuda")
             neglog, nll = ops().prior_nll(g(c.z), g(c.ldj), g(c.length), g(c.pad), sums=sums)
-            close(neglog, c.neglog, **LDJ); close(nll, c.nll, **LDJ)
+            loglik_close(neglog, c.neglog); loglik_close(nll, c.nll)
             assert abs(sums[0].item() / sums[1].item() - float(c.nll_mean)) < 1e-5
             assert sums[1].item() == c.z.size(0)
 
@@ -401,7 +403,7 @@ def test_affine_coupling_nll_fused_vs_oracle_and_split(B, N, D, kind, has_sf):
     sums = torch.zeros(2, dtype=torch.float64, device="cuda")
     zf, lf, neglog, nll = ops().affine_coupling_nll(g(z), g(nn_out), g(sf), g(mask), ldj=g(ldj0), length=g(ln),
                                                     channel_padding_mask=g(pad), sums=sums)
-    close(zf, zo, **ELEM); close(lf, lo, **LDJ); close(nll, nll_o, **LDJ)
+    close(zf, zo, **ELEM); loglik_close(lf, lo); loglik_close(nll, nll_o)
     z2, l2 = ops().affine_coupling(g(z), g(nn_out), g(sf), g(mask), ldj=g(ldj0))
     neglog2, nll2 = ops().prior_nll(z2, l2, g(ln), g(pad))
     assert torch.equal(zf, z2) and torch.equal(lf, l2)
@@ -420,7 +422,7 @@ def test_affine_coupling_nll_fused_vs_oracle_and_split(B, N, D, kind, has_sf):
     # without padding / length (defaults: every token counts, length = N)
     zf, lf, neglog, nll = ops().affine_coupling_nll(g(z), g(nn_out), g(sf), g(mask))
     zo, lo = O.affine_coupling(z, nn_out, mask, scaling_factor=sf)
-    close(nll, O.nll_per_sample(zo, lo, torch.full((B,), float(N)), None), **LDJ)
+    loglik_close(nll, O.nll_per_sample(zo, lo, torch.full((B,), float(N)), None))
 
 
 def test_encoder_full_size_properties():
@@ -440,7 +442,7 @@ def test_encoder_full_size_properties():
     zs, ls, _ = ops().encoder_forward(g(categ[:8192]), eps[:8192 * N], g(table), g(prior))
     assert torch.equal(zs, z[:8192]) and torch.equal(ls, ldj[:8192])
     zo, lo, _ = O.encoder_forward(categ[:64], O.logistic_from_uniform(u[:64 * N]), table, prior)
-    close(z[:64], zo, **ELEM); close(ldj[:64], lo, **LDJ)
+    close(z[:64], zo, **ELEM); loglik_close(ldj[:64], lo)
     assert torch.equal(dec[:64].cpu(), O.encoder_decode(zo, table, prior)[0])
 
 
@@ -451,7 +453,7 @@ def test_encoder_golden(c):
     pad = g(c.pad) if m["padded"] else None
     z, ldj, cpl = ops().encoder_forward(g(c.categ), eps, g(c.table), g(c.category_prior), beta=m["beta"],
                                         channel_padding_mask=pad, want_class_prob=True)
-    close(z, c.z, **ELEM); close(ldj, c.ldj, **LDJ)
+    close(z, c.z, **ELEM); loglik_close(ldj, c.ldj)
     dec = ops().encoder_decode(g(c.z), g(c.table), g(c.category_prior))
     assert torch.equal(dec.cpu(), c.decoded)                       # integer indices: bit-exact
     dec = ops().encoder_decode(g(c.z_probe), g(c.table), g(c.category_prior))
@@ -470,7 +472,7 @@ def test_encoder_module_golden(c):
     with torch.no_grad():
         z, ldj, det = enc(g(c.categ), reverse=False, beta=m["beta"], noise=g(c.u), **kw)
         dec, ldj_r, _ = enc(g(c.z), reverse=True)
-    close(z, c.z, **ELEM); close(ldj, c.ldj, **LDJ)
+    close(z, c.z, **ELEM); loglik_close(ldj, c.ldj)
     assert torch.equal(dec.cpu(), c.decoded) and float(ldj_r.abs().sum()) == 0.0
     if m["training"]:
         assert set(det) == {"avg_token_prob", "avg_token_bpd", "z_min", "z_max", "z_std"}
@@ -492,7 +494,7 @@ def test_encoder_cpu_generator_matches_reference_seed():
     torch.manual_seed(500 + 0)
     with torch.no_grad():
         z, ldj, _ = enc(g(c.categ), reverse=False, beta=m["beta"])
-    close(z, c.z, **ELEM); close(ldj, c.ldj, **LDJ)
+    close(z, c.z, **ELEM); loglik_close(ldj, c.ldj)
 
 
 def test_sigmoid_and_dequant_golden():
@@ -503,7 +505,7 @@ def test_sigmoid_and_dequant_golden():
         else:
             a, la = ops().sigmoid_flow(g(c.u), reverse=True)
             b, lb = ops().sigmoid_flow(g(c.z), reverse=False)
-        close(a, c.out_fwd, **ELEM); close(la, c.ldj_fwd, **LDJ); close(b, c.out_rev, **ELEM); close(lb, c.ldj_rev, **LDJ)
+        close(a, c.out_fwd, **ELEM); loglik_close(la, c.ldj_fwd); close(b, c.out_rev, **ELEM); loglik_close(lb, c.ldj_rev)
 
     from categoricalnf_amd.layers.categorical_encoding.variational_dequantization import VariationalDequantization
     c = load_cases("dequant")[0]
@@ -557,8 +559,8 @@ def test_flow_stack_config0(c):
         neglog, nll = ops().prior_nll(z, ldj, ln)
         dec, _ = model(g(c.z), reverse=True, length=ln)
     close(z, c.z, rtol=1e-4, atol=1e-4)
-    close(ldj, c.ldj, **LDJ)
-    close(nll, c.nll, **LDJ)
+    loglik_close(ldj, c.ldj)
+    loglik_close(nll, c.nll)
     bpd = float(np.log2(np.exp(1)) * nll.mean().item())
     assert abs(bpd - float(c.bpd)) < 0.01
     assert torch.equal(dec.cpu(), c.decoded)
@@ -569,7 +571,7 @@ def test_flow_stack_config0(c):
     sums = torch.zeros(2, dtype=torch.float64, device="cuda")
     z2, ldj2, nll2 = model.nll(g(c.categ), length=ln, noise=g(c.u), sums=sums)
     assert torch.equal(z2, z) and torch.equal(ldj2, ldj)
-    close(nll2, nll, rtol=2e-6, atol=2e-5); close(nll2, c.nll, **LDJ)
+    close(nll2, nll, rtol=2e-6, atol=2e-5); loglik_close(nll2, c.nll)
     assert sums[1].item() == m["B"] and abs(sums[0].item() - nll2.double().sum().item()) < 1e-6 * abs(sums[0].item()) + 1e-9
 
 
@@ -702,10 +704,10 @@ def test_node_edge_coupling_golden(c):
     with torch.no_grad():
         zn, ze, ldj, det = layer(g(c.z_nodes), g(c.z_edges), reverse=False, **kw)
         zn_r, ze_r, ldj_r, det_r = layer(g(c.z_nodes_fwd), g(c.z_edges_fwd), reverse=True, **kw)
-    close(zn, c.z_nodes_fwd, **ELEM); close(ze, c.z_edges_fwd, **ELEM); close(ldj, c.ldj_fwd, **LDJ)
-    close(det["regularizer_nodes_ldj"], c.reg_nodes, **LDJ); close(det["regularizer_edges_ldj"], c.reg_edges, **LDJ)
+    close(zn, c.z_nodes_fwd, **ELEM); close(ze, c.z_edges_fwd, **ELEM); loglik_close(ldj, c.ldj_fwd)
+    loglik_close(det["regularizer_nodes_ldj"], c.reg_nodes); loglik_close(det["regularizer_edges_ldj"], c.reg_edges)
     close(zn_r, c.z_nodes_rev, rtol=1e-4, atol=1e-4); close(ze_r, c.z_edges_rev, rtol=1e-4, atol=1e-4)
-    close(ldj_r, c.ldj_rev, **LDJ)
+    loglik_close(ldj_r, c.ldj_rev)
     assert "regularizer_nodes_ldj" not in det_r
     # the reference's two-call static path (get_mixt_params + run_with_params) gives the same nodes result
     from categoricalnf_amd.layers.flows.mixture_cdf_layer import MixtureCDFCoupling
@@ -721,7 +723,7 @@ def test_node_edge_coupling_golden(c):
     wrap.cuda()
     with torch.no_grad():
         wn, we, wl = wrap(g(c.z_nodes), g(c.z_edges), ldj=g(c.wrap_ldj_in.clone()), reverse=False, **kw)
-    close(wn, c.wrap_nodes, **ELEM); close(we, c.wrap_edges, **ELEM); close(wl, c.wrap_ldj, **LDJ)
+    close(wn, c.wrap_nodes, **ELEM); close(we, c.wrap_edges, **ELEM); loglik_close(wl, c.wrap_ldj)
 
 
 def test_data_dependent_init_driver_golden():
@@ -754,7 +756,7 @@ def test_autoregressive_module_golden():
     ldj0 = torch.randn(m["B"], device="cuda")
     with torch.no_grad():
         z, ldj = layer(g(c.z), ldj=ldj0)
-    close(z, c.z_fwd, **ELEM); close(ldj - ldj0, c.ldj_fwd, **LDJ)
+    close(z, c.z_fwd, **ELEM); loglik_close(ldj - ldj0, c.ldj_fwd)
     with pytest.raises(NotImplementedError):
         layer(g(c.z), reverse=True)
 
@@ -762,6 +764,37 @@ def test_autoregressive_module_golden():
 # ------------------------------------------------------------------------------------------------
 # Backward kernels against the reference's autograd (tests/golden/grads.npz)
 GRAD = dict(rtol=2e-4, atol=2e-4)
+
+
+# Error budget of the gradient checks.  grads.npz carries every gradient twice: from the reference's own fp32 autograd
+# (`g_*`, `gp_*`) and from a float64 run of the same reference modules (`g64_*`, `gp64_*`; oracle/gen_golden.py:gen_grads).
+# Their difference is the rounding noise of the REFERENCE's fp32 gradients (1e-7 ... 5e-6 absolute on gradients of size
+# 1 ... 30).  A HIP gradient must lie within GRAD_K times that noise of the float64 gradient, plus GRAD_FLOOR of the
+# gradient's scale for entries whose reference noise happens to be zero (hardware exp / log / rcp are good to ~1e-7
+# relative, sums run in another order).  Measured on an MI355X the worst ratio over all cases is below GRAD_K / 2
+# (CNF_GRAD_REPORT=1 prints them).  Where the reference has no float64 run (the 1x1 convolution's inverse casts its
+# weight to float) the flat tolerance stays.
+GRAD_K = 32.0
+GRAD_FLOOR = 2e-6
+
+
+def grad_close(actual, c, key, flat=None):
+    import os
+    k64 = key.replace("gp_", "gp64_", 1) if key.startswith("gp_") else key.replace("g_", "g64_", 1)
+    a = actual.detach().double().cpu()
+    if k64 not in c:
+        close(actual, c[key], **(flat or GRAD))
+        return
+    g32, g64 = c[key].double(), c[k64].double()
+    assert a.shape == g64.shape, (a.shape, g64.shape)
+    noise, scale = (g32 - g64).abs().max().item(), max(g64.abs().max().item(), 1e-30)
+    bound = GRAD_K * noise + GRAD_FLOOR * scale
+    dev = (a - g64).abs().max().item()
+    if os.environ.get("CNF_GRAD_REPORT"):
+        print("grad %-44s dev %.2e  ref noise %.2e  scale %.2e  dev/bound %.3f  dev/noise %.1f" % (
+            c.meta["layer"] + ":" + key, dev, noise, scale, dev / bound, dev / max(noise, 1e-30)))
+    assert dev <= bound, "%s: |g - g64| = %.3g exceeds %.0f x reference fp32 noise (%.3g) + %.0e x scale (%.3g)" % (
+        key, dev, GRAD_K, noise, GRAD_FLOOR, scale)
 
 
 def _leaf(t):
@@ -782,8 +815,8 @@ def test_affine_backward(c):
     layer.nn.out = nn_out
     zo, lo = layer(z, ldj=ldj, reverse=m["reverse"])
     ((zo * g(c.wz)).sum() + (lo * g(c.wl)).sum()).backward()
-    close(z.grad, c.g_z, **GRAD); close(nn_out.grad, c.g_nn, **GRAD); close(ldj.grad, c.g_ldj, **GRAD)
-    close(layer.scaling_factor.grad, c.g_sf, rtol=5e-4, atol=5e-4)
+    grad_close(z.grad, c, "g_z"); grad_close(nn_out.grad, c, "g_nn"); grad_close(ldj.grad, c, "g_ldj")
+    grad_close(layer.scaling_factor.grad, c, "g_sf")
 
 
 @pytest.mark.parametrize("c", _grad_cases("actnorm"))
@@ -800,8 +833,8 @@ def test_actnorm_backward(c):
         kw["channel_padding_mask"] = g(c.pad)
     zo, lo = layer(z, ldj=ldj * 1.0, reverse=m["reverse"], **kw)
     ((zo * g(c.wz)).sum() + (lo * g(c.wl)).sum()).backward()
-    close(z.grad, c.g_z, **GRAD); close(ldj.grad, c.g_ldj, **GRAD)
-    close(layer.bias.grad, c.g_bias, rtol=5e-4, atol=5e-4); close(layer.scales.grad, c.g_scales, rtol=5e-4, atol=5e-4)
+    grad_close(z.grad, c, "g_z"); grad_close(ldj.grad, c, "g_ldj")
+    grad_close(layer.bias.grad, c, "g_bias"); grad_close(layer.scales.grad, c, "g_scales")
 
 
 @pytest.mark.parametrize("c", _grad_cases("ext_actnorm"))
@@ -815,7 +848,7 @@ def test_ext_actnorm_backward(c):
     kw = dict(channel_padding_mask=g(c.pad)) if m["padded"] else {}
     zo, lo = layer(z, ldj * 1.0, ext_input=z, reverse=m["reverse"], **kw)
     ((zo * g(c.wz)).sum() + (lo * g(c.wl)).sum()).backward()
-    close(z.grad, c.g_z, **GRAD); close(nn_out.grad, c.g_nn, **GRAD); close(ldj.grad, c.g_ldj, **GRAD)
+    grad_close(z.grad, c, "g_z"); grad_close(nn_out.grad, c, "g_nn"); grad_close(ldj.grad, c, "g_ldj")
 
 
 @pytest.mark.parametrize("c", _grad_cases("invconv"))
@@ -833,9 +866,9 @@ def test_invconv_backward(c):
         kw["channel_padding_mask"] = g(c.pad)
     zo, lo = layer(x, ldj=ldj, reverse=m["reverse"], **kw)
     ((zo * g(c.wz)).sum() + (lo * g(c.wl)).sum()).backward()
-    close(x.grad, c.g_x, **GRAD); close(ldj.grad, c.g_ldj, **GRAD)
+    grad_close(x.grad, c, "g_x"); grad_close(ldj.grad, c, "g_ldj")
     for name, p in layer.named_parameters():
-        close(p.grad, c["gp_" + name], rtol=1e-3, atol=1e-3)
+        grad_close(p.grad, c, "gp_" + name, flat=dict(rtol=1e-3, atol=1e-3))
 
 
 def test_prior_and_sigmoid_backward():
@@ -845,17 +878,17 @@ def test_prior_and_sigmoid_backward():
     c = _grad_cases("log_prob")[0]
     x = _leaf(c.x)
     (LogisticDistribution().log_prob(x) * g(c.w)).sum().backward()
-    close(x.grad, c.g_x, **GRAD)
+    grad_close(x.grad, c, "g_x")
     c = _grad_cases("nll")[0]
     z, ldj = _leaf(c.z), _leaf(c.ldj)
     nll = Fn.PriorNllFn.apply(z, ldj, g(c.length), g(c.pad))
     (nll * g(c.wl)).sum().backward()
-    close(z.grad, c.g_z, **GRAD); close(ldj.grad, c.g_ldj, **GRAD)
+    grad_close(z.grad, c, "g_z"); grad_close(ldj.grad, c, "g_ldj")
     for c in _grad_cases("sigmoid"):
         z, ldj = _leaf(c.z), _leaf(c.ldj)
         zo, lo = SigmoidFlow()(z, ldj=ldj, reverse=c.meta["reverse"])
         ((zo * g(c.wz)).sum() + (lo * g(c.wl)).sum()).backward()
-        close(z.grad, c.g_z, rtol=1e-3, atol=1e-3); close(ldj.grad, c.g_ldj, **GRAD)
+        grad_close(z.grad, c, "g_z"); grad_close(ldj.grad, c, "g_ldj")
 
 
 @pytest.mark.parametrize("c", _grad_cases("mixture"))
@@ -874,10 +907,8 @@ def test_mixture_backward(c):
     layer.nn.out = nn_out
     res = layer(z, reverse=False, **(dict(channel_padding_mask=g(c.pad)) if m["padded"] else {}))
     ((res[0] * g(c.wz)).sum() + (res[1] * g(c.wl)).sum()).backward()
-    close(z.grad, c.g_z, rtol=5e-4, atol=5e-4)
-    close(nn_out.grad, c.g_nn, rtol=5e-4, atol=5e-4)
-    close(layer.scaling_factor.grad, c.g_sf, rtol=1e-3, atol=1e-3)
-    close(layer.mixture_scaling_factor.grad, c.g_msf, rtol=1e-3, atol=1e-3)
+    grad_close(z.grad, c, "g_z"); grad_close(nn_out.grad, c, "g_nn")
+    grad_close(layer.scaling_factor.grad, c, "g_sf"); grad_close(layer.mixture_scaling_factor.grad, c, "g_msf")
     with pytest.raises(NotImplementedError):
         layer(z, reverse=True)
 
@@ -893,7 +924,7 @@ def test_encoder_backward(c):
     zo, lo, _ = enc(g(c.categ), reverse=False, beta=m["beta"], noise=g(c.u), **kw)
     ((zo * g(c.wz)).sum() + (lo * g(c.wl)).sum()).backward()
     for name, p in enc.named_parameters():
-        close(p.grad, c["gp_" + name], rtol=2e-3, atol=2e-3)
+        grad_close(p.grad, c, "gp_" + name)
 
 
 def test_training_steps_reduce_nll_on_set_shuffling():
@@ -939,8 +970,8 @@ def test_mixture_static_api_backward(c):
                                                      is_training=m["training"], return_reg_ldj=True)
     zo = z64.float() * (pad if pad is not None else 1.0)
     ((zo * g(c.wz)).sum() + (l64.float() * g(c.wl)).sum()).backward()
-    close(z.grad, c.g_z, rtol=5e-4, atol=5e-4); close(nn_out.grad, c.g_nn, rtol=5e-4, atol=5e-4)
-    close(sf.grad, c.g_sf, rtol=1e-3, atol=1e-3); close(msf.grad, c.g_msf, rtol=1e-3, atol=1e-3)
+    grad_close(z.grad, c, "g_z"); grad_close(nn_out.grad, c, "g_nn")
+    grad_close(sf.grad, c, "g_sf"); grad_close(msf.grad, c, "g_msf")
 
 
 @pytest.mark.parametrize("c", _grad_cases("affine"))
@@ -952,7 +983,7 @@ def test_affine_static_api_backward(c):
     s, t = CouplingLayer.get_coup_params(nn_out, mask, scaling_factor=sf)
     zo, lo = CouplingLayer.run_with_params(z, s, t, reverse=m["reverse"])
     ((zo * g(c.wz)).sum() + ((g(c.ldj) + lo) * g(c.wl)).sum()).backward()
-    close(z.grad, c.g_z, **GRAD); close(nn_out.grad, c.g_nn, **GRAD); close(sf.grad, c.g_sf, rtol=5e-4, atol=5e-4)
+    grad_close(z.grad, c, "g_z"); grad_close(nn_out.grad, c, "g_nn"); grad_close(sf.grad, c, "g_sf")
 
 
 @pytest.mark.parametrize("D", [1, 2, 3, 4, 5, 6, 8])
@@ -1026,12 +1057,12 @@ def test_empty_and_single_element_batches():
         mask = O.channel_mask(D) if D > 1 else O.chess_mask()
         zo, lo = O.affine_coupling(z, nn_out, mask, None)
         zf, lf = ops().affine_coupling(g(z), g(nn_out), None, g(mask))
-        close(zf, zo, **ELEM); close(lf, lo, **LDJ)
+        close(zf, zo, **ELEM); loglik_close(lf, lo)
         K = 4
         nn_m = 0.5 * torch.randn(B, N, D * (2 + 3 * K), generator=gen)
         zo, lo, _ = O.mixture_coupling(z, nn_m, mask, K, None, None)
         zf, lf, _ = ops().mixture_coupling(g(z), g(nn_m), g(mask), K)
-        close(zf, zo, **ELEM); close(lf, lo, **LDJ)
+        close(zf, zo, **ELEM); loglik_close(lf, lo)
 
 
 def test_hip_graph_replay_matches_eager():
