@@ -771,11 +771,12 @@ GRAD = dict(rtol=2e-4, atol=2e-4)
 # Their difference is the rounding noise of the REFERENCE's fp32 gradients (1e-7 ... 5e-6 absolute on gradients of size
 # 1 ... 30).  A HIP gradient must lie within GRAD_K times that noise of the float64 gradient, plus GRAD_FLOOR of the
 # gradient's scale for entries whose reference noise happens to be zero (hardware exp / log / rcp are good to ~1e-7
-# relative, sums run in another order).  Measured on an MI355X the worst ratio over all cases is below GRAD_K / 2
-# (CNF_GRAD_REPORT=1 prints them).  Where the reference has no float64 run (the 1x1 convolution's inverse casts its
+# relative, sums run in another order).  Measured on an MI355X: the HIP gradients deviate from the float64 ones by 0.2 ... 5.6
+# times the reference's own noise (25 x where that noise happens to be 1e-8), at most 0.3 of this bound
+# (profiles/r03_grad_budget.txt; CNF_GRAD_REPORT=1 prints the table).  Where the reference has no float64 run (the 1x1 convolution's inverse casts its
 # weight to float) the flat tolerance stays.
-GRAD_K = 32.0
-GRAD_FLOOR = 2e-6
+GRAD_K = 8.0
+GRAD_FLOOR = 5e-7
 
 
 def grad_close(actual, c, key, flat=None):
