@@ -13,9 +13,10 @@ into this package):
        model = GraphCNF(params, dataset, edge_subnet=lambda stage, c_out_nodes, c_out_edges: gl.EdgeGNN(...))
 
 2. `fall_through(module_globals, name)` is the module-level `__getattr__` of the drop-in modules whose reference
-   counterparts also hold host-side helpers that are none of this package's business (argparse flag builders, the
-   Gaussian prior): after `categoricalnf_amd.install()`, `from layers.flows.distributions import
-   add_prior_distribution_parameters` still works — it is served by the reference's own file."""
+   counterparts also hold host-side helpers that are none of this package's business (the argparse flag builders of the
+   reference's training template, an explicit list of names per module): after `categoricalnf_amd.install()`, `from
+   layers.flows.distributions import add_prior_distribution_parameters` still works — it is served by the reference's
+   own file when the checkout is on sys.path, and is a clear AttributeError otherwise."""
 import importlib.util
 import os
 import sys
@@ -55,6 +56,19 @@ def find_reference_file(name):
     return None
 
 
+def apply_patches(name, source, path="<reference>"):
+    """The torch >= 2 fixes of `name` applied to its source text.  A fix whose target line is missing AND whose result
+    is not there either means another revision of the reference: stop with the file and the line looked for, instead of
+    an obscure runtime error inside the reference's code later (used by reference_module and by run_reference's loader)."""
+    for old, new in PATCHES.get(name, []):
+        if old in source:
+            source = source.replace(old, new)
+        elif new not in source:
+            raise ImportError("%s: cannot apply the torch >= 2 fix for %s — neither %r nor its replacement is in the file "
+                              "(another revision of the reference?)" % (path, name, old))
+    return source
+
+
 def reference_module(name):
     """Import the reference's `name` from its checkout on sys.path as `_cnf_reference.<name>`, torch >= 2 fixes applied."""
     if name in _loaded:
@@ -63,9 +77,7 @@ def reference_module(name):
     if path is None:
         raise ImportError("the reference's %s.py is not on sys.path: add the checkout of phlippe/CategoricalNF to sys.path"
                           % name.replace(".", "/"))
-    source = open(path).read()
-    for old, new in PATCHES.get(name, []):
-        source = source.replace(old, new)
+    source = apply_patches(name, open(path).read(), path)
     module = types.ModuleType("_cnf_reference." + name)
     module.__file__ = path
     sys.modules[module.__name__] = module

@@ -1191,7 +1191,12 @@ int cnf_encoder_forward_bwd_tiled(const int64_t* categ, const float* eps, const 
                                   const float* g_zout, const float* g_ldj, float* g_table, float* workspace,
                                   int B, int N, int D, int C, float sigma, float log_sigma, cnf_stream_t stream) {
     CNF_REQUIRE(categ && eps && table && category_prior && g_table && workspace, "cnf_encoder_forward_bwd_tiled: null tensor");
-    CNF_REQUIRE(B > 0 && N > 0 && D > 0 && C > 0 && D <= kEncMaxD, "cnf_encoder_forward_bwd_tiled: bad shape");
+    CNF_REQUIRE(B >= 0 && N > 0 && D > 0 && C > 0 && D <= kEncMaxD, "cnf_encoder_forward_bwd_tiled: bad shape");
+    if (B == 0) {       // the forward accepts an empty batch; its gradient is a zero table
+        if (hipMemsetAsync(g_table, 0, (size_t)C * 2 * D * sizeof(float), (hipStream_t)stream) != hipSuccess)
+            return launch_status("cnf_encoder_forward_bwd_tiled");
+        return CNF_OK;
+    }
     EncBwdTiledArgs b = {};
     b.categ = categ; b.eps = eps; b.table = table; b.prior = category_prior; b.pad = pad;
     b.g_zout = g_zout; b.g_ldj = g_ldj; b.g_table = g_table;

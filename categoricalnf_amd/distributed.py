@@ -49,6 +49,30 @@ def allreduce_nll(sums):
     return mean, float(np.log2(np.exp(1)) * mean)
 
 
+_SYNC_DATA_INIT = False
+
+
+def sync_data_init(enable=True):
+    """Opt in to (or out of) cross-rank statistics in ActNorm's data-dependent initialisation (SURVEY.md section 8e;
+    layers/flows/activation_normalization.py:55-73).  The reference initialises from ONE batch on ONE process; under one
+    process per GPU every rank must end up with the same bias / scales.  This package's drivers get that by feeding
+    every rank the same initialisation batches; a caller whose ranks hold DIFFERENT shards of the initialisation data
+    switches this on, and every ActNorm / ExtActNorm layer then all-reduces its per-channel sums — (sum x, count), then
+    sum (x - mean)^2, two collectives of D + 1 fp64 per layer — so that all ranks compute the statistics of the union.
+    Returns the previous setting."""
+    global _SYNC_DATA_INIT
+    prev, _SYNC_DATA_INIT = _SYNC_DATA_INIT, bool(enable)
+    return prev
+
+
+def allreduce_init_stats(acc):
+    """Sum the fp64 statistics vector `acc` over the ranks, in place, when sync_data_init() is on and a process group
+    with more than one rank exists; otherwise a no-op.  Called by ops.actnorm_data_init after each of its two passes."""
+    if _SYNC_DATA_INIT and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+    return acc
+
+
 def wrap_ddp(model, device, bucket_cap_mb=25):
     """Data-parallel training wrapper replacing the reference's nn.DataParallel (general/mutils.py:243-249):
     one process per GPU, gradients all-reduced by RCCL in buckets that overlap with the HIP backward kernels.

@@ -21,6 +21,7 @@ import argparse
 import contextlib
 import io
 import os
+import random
 import time
 
 import numpy as np
@@ -192,6 +193,8 @@ def main(argv=None):
         assert model.test_permutation(nodes, adjacency, length), "[!] ERROR: Permutation test failed."
         assert model.test_reversibility(nodes, adjacency, length), "[!] ERROR: Reversibility test failed."
     np.random.seed(args.seed + 1000 * rank + 1)          # from here on every rank draws its own order of training graphs
+    random.seed(args.seed + 1000 * rank + 1)             # the dataset's colour permutations / random node orders (general/mutils.py:29-36 seeds it too)
+    torch.manual_seed(args.seed + 1000 * rank + 1)       # dropout masks differ between the ranks; the replicas are initialised
     ddp = wrap_ddp(model, device)
     if not args.only_eval and args.checkpoint_path and rank == 0:
         save_args(args.checkpoint_path, args)

@@ -202,6 +202,7 @@ def main(argv=None):
             init.append((x, {"length": length}))
         with contextlib.redirect_stdout(io.StringIO()):
             model.initialize_data_dependent(init)
+    torch.manual_seed(args.seed + 1000 * rank + 1)        # dropout masks differ between the ranks (the replicas are initialised)
     ddp = wrap_ddp(model, device)
     if not args.only_eval and args.checkpoint_path and rank == 0:
         save_args(args.checkpoint_path, args)

@@ -255,6 +255,7 @@ def main(argv=None):
         advance_schedule(scheduler, state["iteration"])
     ddp.train()
     best = state["best_save_dict"]
+    periodic = set()          # full-state checkpoints written at save_freq steps (kept when a better validation file appears)
     t0, run_loss, seen = time.time(), torch.zeros((), device=device), 0       # the loss stays on the device between prints
     for it in range(state["iteration"], args.max_iterations):
         x, ln = batch()
@@ -280,7 +281,9 @@ def main(argv=None):
             state["evaluation_dict"][step] = val_nll
             say("iteration %7d | validation %.4f bpd (optimum %.4f)" % (step, val_bpd, optimum))
             if val_nll < best["metric"] and args.checkpoint_path and rank == 0:
-                if best["file"] and os.path.isfile(best["file"]):
+                # the previous best file goes, unless it is also a periodic full-state checkpoint (optimizer and scheduler
+                # included; the isfile guard of general/train.py:215 kept those too): a resume needs the newest of them
+                if best["file"] and os.path.isfile(best["file"]) and best["file"] not in periodic:
                     os.remove(best["file"])
                 best.update(file=checkpoint_file(args.checkpoint_path, step), metric=val_nll,
                             detailed_metrics={"val_bpd": val_bpd})
@@ -289,6 +292,7 @@ def main(argv=None):
             # always the full state (a best-validation file of the same step is a subset of it and is replaced)
             save_checkpoint(args.checkpoint_path, step, ddp, optimizer if flat is None else None, scheduler,
                             best_save_dict=best, evaluation_dict=state["evaluation_dict"])
+            periodic.add(checkpoint_file(args.checkpoint_path, step))
     _, val_bpd = evaluate(ddp, val_sets, device, rank, world, args.eval_batch_size)
     _, test_bpd = evaluate(ddp, test_sets, device, rank, world, args.eval_batch_size)
     say("final: validation %.4f bpd, test %.4f bpd (optimum %.4f)" % (val_bpd, test_bpd, optimum))

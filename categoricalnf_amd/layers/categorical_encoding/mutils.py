@@ -3,11 +3,16 @@ from .linear_encoding import LinearCategoricalEncoding
 from .variational_dequantization import VariationalDequantization
 
 
+# the CLI flag builders (:14-48) are host-side code of the reference's training template: served from the user's checkout
+# when it is on sys.path, by NAME — any other missing attribute is a plain AttributeError
+_FROM_REFERENCE = ("add_encoding_parameters", "encoding_args_to_params")
+
+
 def __getattr__(name):
-    # the CLI flag builders (add_encoding_parameters, encoding_args_to_params :14-48) are host-side code of the
-    # reference: served from its checkout, not re-typed here
-    from ... import compat
-    return compat.fall_through("layers.categorical_encoding.mutils", name)
+    if name in _FROM_REFERENCE:
+        from ... import compat
+        return compat.fall_through("layers.categorical_encoding.mutils", name)
+    raise AttributeError("module %r has no attribute %r" % (__name__, name))
 
 
 def create_encoding(encoding_params, dataset_class, vocab=None, vocab_size=-1, category_prior=None):

@@ -57,6 +57,31 @@ class PriorDistribution(nn.Module):
         return "%i - Gaussian, %i - Logistic" % (PriorDistribution.GAUSSIAN, PriorDistribution.LOGISTIC)
 
 
+class GaussianDistribution(PriorDistribution):
+    """Normal prior (distributions.py:74-88): plain torch.distributions host code, off the HIP path (no experiment of the
+    reference selects it; the logistic prior is the default everywhere).  `sample` takes the keyword arguments this
+    package's callers pass to a prior (device, temp, return_ldj) so that it can stand in for the logistic one."""
+
+    def __init__(self, mu=0.0, sigma=1.0, **kwargs):
+        super().__init__(mu=mu, sigma=sigma)
+        self.mu = mu
+        self.sigma = sigma
+
+    def _create_distribution(self, mu=0.0, sigma=1.0, **kwargs):
+        return torch.distributions.normal.Normal(loc=mu, scale=sigma)
+
+    def sample(self, shape=None, return_ldj=False, temp=1.0, device=None, **kwargs):
+        x = super().sample(shape=shape)
+        if temp != 1.0:
+            x = self.mu + (x - self.mu) * temp
+        if device is not None:
+            x = x.to(device)
+        return (x, -self.log_prob(x)) if return_ldj else x
+
+    def info(self):
+        return "Gaussian distribution with mu=%f and sigma=%f" % (self.mu, self.sigma)
+
+
 class LogisticDistribution(PriorDistribution):
 
     def __init__(self, mu=0.0, sigma=1.0, eps=1e-4, **kwargs):
@@ -130,18 +155,23 @@ class LogisticDistribution(PriorDistribution):
 
 def create_prior_distribution(distribution_params):
     """distributions.py:190-200.  The logistic prior (the default of every experiment) runs on the HIP kernels; the
-    optional Gaussian prior is plain torch.distributions host code and is served by the reference's own class."""
+    optional Gaussian prior is plain torch.distributions host code."""
     kind = get_param_val(distribution_params, "distribution_type", PriorDistribution.LOGISTIC)
     params = {k: v for k, v in distribution_params.items() if v is not None}
     if kind == PriorDistribution.GAUSSIAN:
-        return compat.fall_through("layers.flows.distributions", "GaussianDistribution")(**params)
+        return GaussianDistribution(**params)
     if kind == PriorDistribution.LOGISTIC:
         return LogisticDistribution(**params)
     print("[!] ERROR: Unknown distribution type %s" % str(kind))
     sys.exit(1)
 
 
+# the reference's command-line flag builders (distributions.py:203-222) are host-side code of its training template:
+# served from the user's checkout when it is on sys.path, by NAME — any other missing attribute is a plain AttributeError
+_FROM_REFERENCE = ("add_prior_distribution_parameters", "prior_distribution_args_to_params")
+
+
 def __getattr__(name):
-    # GaussianDistribution and the argparse helpers (add_prior_distribution_parameters, prior_distribution_args_to_params)
-    # are host-side code of the reference: served from its checkout, not re-typed here
-    return compat.fall_through("layers.flows.distributions", name)
+    if name in _FROM_REFERENCE:
+        return compat.fall_through("layers.flows.distributions", name)
+    raise AttributeError("module %r has no attribute %r" % (__name__, name))

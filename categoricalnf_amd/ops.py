@@ -74,6 +74,9 @@ def _launch(dev, name, *args):
     else:
         status = fn(*args)
     if status != _lib.CNF_OK:
+        # a failed launch may have left a split-row workspace (tickets, fixed-point sums) half-written: the next
+        # launch must not inherit it
+        _mix_ws.clear()
         _lib.check(status, name)
 
 
@@ -273,11 +276,14 @@ def actnorm_data_init(x, channel_padding_mask=None):
     pad = _pad2d(channel_padding_mask, B, N, dev)
     acc = torch.zeros(D + 1, dtype=torch.float64, device=dev)
     _launch(dev, "cnf_actnorm_stats", _ptr(x), _ptr(pad), None, _ptr(acc), B, N, D, 0, _stream(dev))
+    from .distributed import allreduce_init_stats          # no-op unless distributed.sync_data_init() was switched on
+    allreduce_init_stats(acc)
     mean = acc[:D] / acc[D]
     acc2 = torch.zeros(D + 1, dtype=torch.float64, device=dev)
     mean_c = mean.contiguous()
     _launch(dev, "cnf_actnorm_stats", _ptr(x), _ptr(pad), _ptr(mean_c), _ptr(acc2), B, N, D, 1,
                                      _stream(dev))
+    allreduce_init_stats(acc2)
     var = acc2[:D] / acc[D]
     bias = (-mean).float().view(1, 1, D)
     scales = (-0.5 * var.log()).float().view(1, 1, D)
@@ -374,6 +380,10 @@ def _mixture_workspace(dev, B):
     (device, stream); the kernels leave it zeroed, so it is filled once."""
     key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream)
     need = int(_lib.load().cnf_mixture_workspace_bytes(int(B)))
+    if torch.cuda.is_current_stream_capturing():
+        # a buffer allocated during a capture belongs to the graph's private pool: the graph keeps it (its replays
+        # leave it zeroed like every launch), the cache must not hand it to eager launches
+        return torch.zeros(max(need, 1 << 16), dtype=torch.uint8, device=dev)
     w = _mix_ws.get(key)
     if w is None or w.numel() < need:
         w = torch.zeros(max(need, 1 << 16), dtype=torch.uint8, device=dev)

@@ -49,13 +49,7 @@ class _PatchedSourceLoader(importlib.abc.Loader):
         return None
 
     def get_source(self, fullname=None):
-        source = open(self.path).read()
-        for old, new in compat.PATCHES.get(self.name, []):
-            if old not in source and new not in source:
-                raise ImportError("%s: the line the torch >= 2 fix applies to was not found (%r); the checkout differs "
-                                  "from the revision categoricalnf_amd.compat.PATCHES was written for" % (self.path, old))
-            source = source.replace(old, new)
-        return source
+        return compat.apply_patches(self.name, open(self.path).read(), self.path)
 
     def exec_module(self, module):
         exec(compile(self.get_source(), self.path, "exec"), module.__dict__)

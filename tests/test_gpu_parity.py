@@ -1159,6 +1159,46 @@ def test_bench_self_launches_n_ranks():
     assert out["value"] > 0 and out["roofline"]["kernel_ms"] > 0 and np.isfinite(out["mean_nll"])
 
 
+def test_bench_rehearses_eight_ranks_on_one_device():
+    """The driver's first real 8-GPU run must not be the first 8-rank run: `python bench.py --gpus 8` as 8 processes
+    sharing cuda:0 over gloo — rendezvous, per-rank rates, the all-reduce of the batch sums as the closing barrier —
+    and the refusal paths (a WORLD_SIZE that contradicts --gpus; 8 devices asked for where 1 is visible)."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--share-device", "--backend", "gloo",
+                        "--steps", "5", "--warmup", "2", "--batch", "1024", "--prewarm-seconds", "0.1"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and len(out["per_rank_elems_per_s"]) == 8 and out["allreduce_latency_us"] > 0
+    assert out["scaling"] == "weak" and out["value"] > 0 and np.isfinite(out["mean_nll"])
+    assert abs(out["value"] - 8 * 1024 * 64 * 6 * 5 / (out["ms_per_step"] * 5e-3)) < 1e-6 * out["value"]
+    if torch.cuda.device_count() < 8:
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1"],
+                           capture_output=True, text=True, timeout=300, env=env, cwd=root)
+        assert r.returncode != 0 and "HIP device(s) visible" in (r.stdout + r.stderr)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, cwd=root,
+                       env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and "does not match WORLD_SIZE" in (r.stdout + r.stderr)
+
+
+def test_actnorm_data_init_statistics_meet_across_ranks():
+    """distributed.sync_data_init(): ranks holding different shards of the initialisation batch all-reduce ActNorm's
+    per-channel sums and end up with the whole batch's bias / scales; 2 and 3 ranks on cuda:0."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for world, port in ((2, "29641"), (3, "29642")):
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                            "--master-addr", "127.0.0.1", "--master-port", port, os.path.join(root, "tools", "init_sync_check.py"),
+                            "--backend", "gloo", "--share-device"], capture_output=True, text=True, timeout=600, cwd=root,
+                           env=dict(os.environ, OMP_NUM_THREADS="1"))
+        assert r.returncode == 0 and r.stdout.count("INIT_SYNC OK") == world, (r.stdout[-2000:], r.stderr[-2000:])
+
+
 def test_dispatch_bound_kernel_timing_matches_event_brackets():
     """cnf_prof_arm / cnf_prof_collect (bench.py's roofline clock): the dispatch-bound duration of a big launch is
     positive, below a marker-bracketed measurement of the same launch and within 2x of it."""

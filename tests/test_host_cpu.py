@@ -161,6 +161,21 @@ mean, bpd = allreduce_nll(sums)
 full = O.nll_per_sample(z, ldj, ln).double().mean().item()
 assert abs(mean - full) < 1e-9, (mean, full)
 assert abs(bpd - O.bits_per_dim(full)) < 1e-9
+# opt-in all-reduce of ActNorm's init statistics (distributed.sync_data_init): the two passes of the data-dependent init
+# on row shards — (sum x, count), then sum (x - mean)^2 — against the whole batch (activation_normalization.py:55-67)
+from categoricalnf_amd.distributed import allreduce_init_stats, sync_data_init
+x = z[lo:hi].double().reshape(-1, D)
+acc = torch.cat([x.sum(0), torch.tensor([float(x.shape[0])], dtype=torch.float64)])
+assert torch.equal(allreduce_init_stats(acc.clone()), acc)          # switched off: untouched
+assert sync_data_init(True) is False
+allreduce_init_stats(acc)
+mean_c = acc[:D] / acc[D]
+acc2 = torch.cat([((x - mean_c) ** 2).sum(0), torch.zeros(1, dtype=torch.float64)])
+allreduce_init_stats(acc2)
+sync_data_init(False)
+zz = z.double().reshape(-1, D)
+assert acc[D].item() == B * N and torch.allclose(mean_c, zz.mean(0), atol=1e-12)
+assert torch.allclose(acc2[:D] / acc[D], zz.var(0, unbiased=False), atol=1e-12)
 if rank == 0:
     print("OK", world, mean)
 dist.destroy_process_group()
@@ -470,12 +485,36 @@ def test_graph_cnf_assembly_matches_reference_names_and_edge_list_helpers():
     assert model.edge_virtual_decoder.layers.main_net[-1].bias.dtype == torch.float32
 
 
+def test_gaussian_prior_and_flag_builders_without_a_checkout():
+    """create_prior_distribution(GAUSSIAN) works without the reference on sys.path (in-package class whose
+    sample() takes the keyword arguments this package's callers pass); the flag builders, which ARE served from the
+    checkout, fail with an AttributeError that says so; a misspelled name is a plain AttributeError."""
+    from categoricalnf_amd.layers.flows import distributions as D
+    from categoricalnf_amd.layers.categorical_encoding import mutils as M
+    prior = D.create_prior_distribution({"distribution_type": D.PriorDistribution.GAUSSIAN, "mu": 0.5, "sigma": 2.0})
+    assert isinstance(prior, D.GaussianDistribution) and prior.info() == "Gaussian distribution with mu=0.500000 and sigma=2.000000"
+    torch.manual_seed(0)
+    x, ldj = prior.sample(shape=(4, 3), return_ldj=True, temp=1.0, device=torch.device("cpu"))
+    ref = torch.distributions.normal.Normal(0.5, 2.0)
+    assert x.shape == (4, 3) and torch.allclose(ldj, -ref.log_prob(x)) and torch.allclose(prior.log_prob(x), ref.log_prob(x))
+    saved = list(sys.path)
+    sys.path[:] = [p for p in sys.path if "reference" not in p]
+    try:
+        for mod, name in ((D, "add_prior_distribution_parameters"), (M, "add_encoding_parameters")):
+            with pytest.raises(AttributeError, match="reference checkout is not on sys.path"):
+                getattr(mod, name)
+        with pytest.raises(AttributeError, match="has no attribute"):
+            D.GausianDistribution
+    finally:
+        sys.path[:] = saved
+
+
 @pytest.mark.skipif(not os.path.isdir("/root/reference/experiments"), reason="reference checkout only exists in the build container")
 def test_reference_edge_gnn_runs_on_torch2_through_compat_and_plugs_into_graph_cnf():
     """§8 f-2: the Edge-GNN sub-network is NOT re-typed in this package; categoricalnf_amd.compat imports the reference's
     own graph_layers.py with the integer-division fix applied in memory (its sparse attention stops on torch >= 2
-    otherwise) and the molecule GraphCNF of this package takes it as its stage-2/3 sub-network.  Also: CLI helpers and
-    the Gaussian prior fall through to the reference's files after install()."""
+    otherwise) and the molecule GraphCNF of this package takes it as its stage-2/3 sub-network.  Also: the CLI flag builders
+    (and only they) fall through to the reference's files after install()."""
     code = r'''
 import sys, io, contextlib
 sys.path.insert(0, "%s"); sys.path.insert(1, "/root/reference")
@@ -485,7 +524,14 @@ from categoricalnf_amd import compat
 categoricalnf_amd.install()
 from layers.flows.distributions import add_prior_distribution_parameters, GaussianDistribution, LogisticDistribution
 from layers.categorical_encoding.mutils import add_encoding_parameters, create_encoding
-assert add_prior_distribution_parameters.__module__.startswith("_cnf_reference") and GaussianDistribution.__module__.startswith("_cnf_reference")
+assert add_prior_distribution_parameters.__module__.startswith("_cnf_reference") and add_encoding_parameters.__module__.startswith("_cnf_reference")
+assert GaussianDistribution.__module__.startswith("categoricalnf_amd")          # in the package: needs no checkout (ADVICE r2)
+import layers.flows.distributions as dmod
+try:
+    dmod.no_such_name
+    raise SystemExit("a misspelled attribute must not import the reference's file")
+except AttributeError as e:
+    assert "no attribute" in str(e)
 assert LogisticDistribution.__module__.startswith("categoricalnf_amd") and create_encoding.__module__.startswith("categoricalnf_amd")
 with contextlib.redirect_stdout(io.StringIO()):
     gl = compat.reference_module("layers.networks.graph_layers")
