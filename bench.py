@@ -198,7 +198,19 @@ def mixture_measure(ops, dev, R=4, reps=50):
     assert (zrs[0] - zs[0]).abs().max().item() < 2e-4, "mixture inverse did not recover z"
     elems = B * N * D
     bytes_alg = elems * (16 + 12 * K)
+    # what the kernel must really move: only the parameter blocks of the transformed channels (half of nn_out under the
+    # channel mask), the latents in and out, the log-det — the contract's 16 + 12 K bytes per element also prices the
+    # parameter blocks of the channels that pass through, which the kernel skips
+    DA = D - D // 2
+    bytes_needed = B * N * (DA * (2 + 3 * K) * 4 + 8 * D) + 4 * B
     return {"workload": "mixture_cdf_coupling B=16384 N=16 D=4 K=8 (configs[1])", "dtype": "f32 (fp64 fallback branch for |logit| > 20.7)",
+            "needed_bytes_per_launch": bytes_needed, "fwd_needed_GBps": bytes_needed / (tf * 1e-3) / 1e9,
+            "fwd_needed_hbm_frac": bytes_needed / (tf * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "inv_needed_hbm_frac": bytes_needed / (ti * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "note_on_pricing": "fwd_hbm_frac uses SURVEY 8d's 16 + 12 K bytes per element (all of nn_out); *_needed_* uses the bytes "
+                               "the kernel has to touch (transformed channels' blocks only). The PMC traffic of the forward is "
+                               "~1.45 x the needed bytes: spans of 208 bytes at a 416-byte stride share their first and last "
+                               "64-byte sectors with the skipped blocks (profiles/traffic.json)",
             "fwd_ms": tf, "inv_ms": ti, "fwd_elems_per_s": elems / (tf * 1e-3), "inv_elems_per_s": elems / (ti * 1e-3),
             "fwd_inv_elems_per_s": elems / ((tf + ti) * 1e-3),
             "fwd_algorithmic_GBps": bytes_alg / (tf * 1e-3) / 1e9, "fwd_hbm_frac": bytes_alg / (tf * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -303,6 +315,9 @@ def main():
     # never the first launch after the opening barrier
     EV = max(1, args.event_every if args.event_every > 0 else -(-args.steps // min(32, max(2, args.steps // 8))))
     EV_AT = EV // 2
+    if args.event_every <= 0 and args.steps < 64:
+        EV = EV_AT = args.steps + 1         # a short run: its two or three in-loop pairs prove nothing (the roofline's 120
+                                            # samples are taken right after the timed region) and cost ~4 us each inside it
 
     # outputs and pre-bound launches per buffer set (host cost per launch ~2 us)
     zfs = [torch.empty_like(zs[0]) for _ in range(R)]
@@ -464,7 +479,7 @@ def main():
     # measured ceiling for this traffic mix on this device, same run, same rotating buffers: a streaming kernel that
     # reads 4 + 8 bytes and writes 4 bytes per element and computes nothing (cnf_stream_probe), timed with
     # dispatch-bound pairs (a) where the forward kernel sits — the timed loop again with the probe in the forward's
-    # place, alternating with the inverse, every EV-th probe timed — and (b) in a short burst of its own (spaced launches: no overlap with a neighbour)
+    # place, alternating with the inverse, every 8th probe timed — and (b) in a short burst of its own (spaced launches: no overlap with a neighbour)
     def probe(r, cpl):
         ops._launch(dev, "cnf_stream_probe", zs[r].data_ptr(), nns[r].data_ptr(), zfs[r].data_ptr(), elems, cpl,
                     ops._stream(dev))
@@ -480,13 +495,14 @@ def main():
         burst_ms[cpl] = float(np.median([pb[i] for i in range(n_pb)]))
     best_cpl = min(burst_ms, key=burst_ms.get)
     n_loop = min(args.steps, 1000)
+    n_loop = max(n_loop, 256)
     for i in range(n_loop):
-        if i % EV == EV_AT:
+        if i % 8 == 4:
             lib.cnf_prof_arm(1)
         probe(i % R, best_cpl)
         inv[i % R]()
-    pb = (ctypes.c_float * (n_loop // EV + 1))()
-    n_pb = lib.cnf_prof_collect(pb, n_loop // EV + 1)
+    pb = (ctypes.c_float * (n_loop // 8 + 1))()
+    n_pb = lib.cnf_prof_collect(pb, n_loop // 8 + 1)
     tail = [pb[i] for i in range(n_pb)][n_pb // 4:]            # first quarter dropped: the stream settles
     ceil_ms = float(np.mean(tail)) if tail else burst_ms[best_cpl]
     ceil_gbs = 16.0 * elems / (ceil_ms * 1e-3) / 1e9

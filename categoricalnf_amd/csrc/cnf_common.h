@@ -38,6 +38,17 @@ bool prof_take(hipEvent_t* start, hipEvent_t* stop);
             hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                                   \
     } while (0)
 
+// Zero `bytes` bytes (a multiple of 4) at `p` with a KERNEL.  The library never issues hipMemsetAsync: on this stack a
+// hipGraph memset node of 16 B ... 4 KiB writes garbage from the second launch of the graph on (tools/
+// graph_linear_probe.py, profiles/r03_graph_train_root_cause.txt), and every entry point may be captured.
+__global__ void cnf_zero_fill_kernel(uint32_t* p, size_t words);
+inline void zero_fill_async(void* p, size_t bytes, hipStream_t st) {
+    const size_t words = bytes / 4;
+    if (words == 0) return;
+    const unsigned grid = (unsigned)std::min<size_t>((words + 4 * 256 - 1) / (4 * 256), 4096);
+    hipLaunchKernelGGL(cnf_zero_fill_kernel, dim3(grid), dim3(256), 0, st, reinterpret_cast<uint32_t*>(p), words);
+}
+
 #define CNF_REQUIRE(cond, ...)                \
     do {                                      \
         if (!(cond)) {                        \

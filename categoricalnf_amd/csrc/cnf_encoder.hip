@@ -1193,9 +1193,8 @@ int cnf_encoder_forward_bwd_tiled(const int64_t* categ, const float* eps, const 
     CNF_REQUIRE(categ && eps && table && category_prior && g_table && workspace, "cnf_encoder_forward_bwd_tiled: null tensor");
     CNF_REQUIRE(B >= 0 && N > 0 && D > 0 && C > 0 && D <= kEncMaxD, "cnf_encoder_forward_bwd_tiled: bad shape");
     if (B == 0) {       // the forward accepts an empty batch; its gradient is a zero table
-        if (hipMemsetAsync(g_table, 0, (size_t)C * 2 * D * sizeof(float), (hipStream_t)stream) != hipSuccess)
-            return launch_status("cnf_encoder_forward_bwd_tiled");
-        return CNF_OK;
+        cnf::zero_fill_async(g_table, (size_t)C * 2 * D * sizeof(float), (hipStream_t)stream);
+        return launch_status("cnf_encoder_forward_bwd_tiled");
     }
     EncBwdTiledArgs b = {};
     b.categ = categ; b.eps = eps; b.table = table; b.prior = category_prior; b.pad = pad;

@@ -44,6 +44,10 @@ struct ProfState {
 static thread_local ProfState g_prof;
 constexpr int kMaxProfPairs = 8192;
 
+__global__ void cnf_zero_fill_kernel(uint32_t* p, size_t words) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+
 bool prof_take(hipEvent_t* start, hipEvent_t* stop) {
     ProfState& p = g_prof;
     if (p.armed <= 0) return false;

@@ -27,7 +27,7 @@ struct MixBwdArgs {
     const float* g_zout;
     const float* g_ldj;
     float* g_z;
-    float* g_nn;            // pre-zeroed by the caller side (hipMemsetAsync below)
+    float* g_nn;            // pre-zeroed by the host side (zero_fill_async below)
     float* partials;        // [gridDim.x, D + D*K]
     // split (static API) form: fp64 parameter tensors in, fp64 gradients out
     const double* z64;
@@ -292,7 +292,7 @@ int cnf_mixture_coupling_bwd(const float* z, const float* nn_out,
     a.use_reg = (reg_max > 0 && is_training) ? 1 : 0;
     a.reg_max = reg_max; a.reg_factor = reg_factor;
     // parameters of untransformed elements get no gradient
-    hipMemsetAsync(g_nn, 0, sizeof(float) * (size_t)a.total * a.P, st);
+    zero_fill_async(g_nn, sizeof(float) * (size_t)a.total * a.P, st);
     const int grid = (int)std::min<long>(std::max<long>((a.total + kBlock - 1) / kBlock, 1), kMixBwdGrid);
     CNF_LAUNCH((mixture_fwd_bwd_kernel<false>), dim3(grid), dim3(kBlock), 0, st, a);
     const int PP = D + D * K;
@@ -325,11 +325,11 @@ int cnf_mixture_transform_bwd(const double* z, const double* t, const double* lo
     a.use_reg = (reg_max > 0 && is_training) ? 1 : 0;
     a.reg_max = reg_max; a.reg_factor = reg_factor;
     const size_t n = (size_t)a.total;
-    hipMemsetAsync(g_t, 0, sizeof(double) * n, st);
-    hipMemsetAsync(g_log_s, 0, sizeof(double) * n, st);
-    hipMemsetAsync(g_log_pi, 0, sizeof(double) * n * K, st);
-    hipMemsetAsync(g_mixt_t, 0, sizeof(double) * n * K, st);
-    hipMemsetAsync(g_mixt_log_s, 0, sizeof(double) * n * K, st);
+    zero_fill_async(g_t, sizeof(double) * n, st);
+    zero_fill_async(g_log_s, sizeof(double) * n, st);
+    zero_fill_async(g_log_pi, sizeof(double) * n * K, st);
+    zero_fill_async(g_mixt_t, sizeof(double) * n * K, st);
+    zero_fill_async(g_mixt_log_s, sizeof(double) * n * K, st);
     const int grid = (int)std::min<long>(std::max<long>((a.total + kBlock - 1) / kBlock, 1), kMixBwdGrid);
     CNF_LAUNCH((mixture_fwd_bwd_kernel<true>), dim3(grid), dim3(kBlock), 0, st, a);
     return launch_status("cnf_mixture_transform_bwd");

@@ -36,6 +36,52 @@ from ..layers.flows.permutation_layers import InvertibleConv
 from .graph_node_edge_coupling import NodeEdgeCoupling, NodeEdgeFlowWrapper
 
 
+class PairMessageNet(nn.Module):
+    """A node + edge message-passing sub-network of THIS package's own design for stages 2 / 3 — not the reference's
+    Edge-GNN (layers/networks/graph_layers.py:737-815), whose attention layers, parameter names and checkpoints it does not
+    share.  It exists so that the assembled three-stage flow can train and sample END TO END on the device at
+    configs[4]'s sizes where the user's checkout (which is what INTEGRATION.md plugs in, through
+    compat.reference_module) cannot travel: `GraphCNF(params, dataset, edge_subnet=PairMessageNet.factory(6, 2))`.
+
+    Interface of a NodeEdgeCoupling sub-network: called with z_nodes [B, N, c_in_nodes], z_edges [B, E, c_in_edges],
+    x_indices = (i, j) with the two end points of every node pair, mask_valid [B, E] (1 = the pair takes part), returns
+    (nn_out_nodes [B, N, c_out_nodes], nn_out_edges [B, E, c_out_edges]).  `rounds` times: every pair reads its two end
+    points, every node the mean over its valid pairs; residual updates, layer norm, zero-initialised output layers (the
+    coupling starts as the identity).  Dense GEMMs on PyTorch-ROCm; gathers and index_add for the graph structure."""
+
+    def __init__(self, c_in_nodes, c_in_edges, c_out_nodes, c_out_edges, hidden_nodes=128, hidden_edges=64, rounds=2):
+        super().__init__()
+        self.node_in, self.edge_in = nn.Linear(c_in_nodes, hidden_nodes), nn.Linear(c_in_edges, hidden_edges)
+        self.edge_upd = nn.ModuleList([nn.Sequential(nn.Linear(hidden_edges + 2 * hidden_nodes, hidden_edges), nn.GELU(),
+                                                     nn.Linear(hidden_edges, hidden_edges)) for _ in range(rounds)])
+        self.node_upd = nn.ModuleList([nn.Sequential(nn.Linear(hidden_nodes + hidden_edges, hidden_nodes), nn.GELU(),
+                                                     nn.Linear(hidden_nodes, hidden_nodes)) for _ in range(rounds)])
+        self.edge_norm = nn.ModuleList([nn.LayerNorm(hidden_edges) for _ in range(rounds)])
+        self.node_norm = nn.ModuleList([nn.LayerNorm(hidden_nodes) for _ in range(rounds)])
+        self.node_out, self.edge_out = nn.Linear(hidden_nodes, c_out_nodes), nn.Linear(hidden_edges, c_out_edges)
+        for layer in (self.node_out, self.edge_out):
+            nn.init.zeros_(layer.weight)
+            nn.init.zeros_(layer.bias)
+
+    @staticmethod
+    def factory(c_in_nodes, c_in_edges, **kwargs):
+        """`edge_subnet` argument of GraphCNF: (stage, c_out_nodes, c_out_edges) -> module."""
+        return lambda stage, c_out_nodes, c_out_edges: PairMessageNet(c_in_nodes, c_in_edges, c_out_nodes, c_out_edges, **kwargs)
+
+    def forward(self, z_nodes, z_edges, x_indices=None, mask_valid=None, **kwargs):
+        i, j = x_indices
+        if i.dim() > 1:
+            i, j = i[0], j[0]
+        m = mask_valid.unsqueeze(dim=-1).to(z_edges.dtype) if mask_valid is not None else z_edges.new_ones(z_edges.shape[:-1] + (1,))
+        hn, he = self.node_in(z_nodes), self.edge_in(z_edges) * m
+        degree = z_nodes.new_zeros(z_nodes.shape[:2] + (1,)).index_add_(1, i, m).index_add_(1, j, m).clamp_(min=1.0)
+        for edge_upd, node_upd, edge_norm, node_norm in zip(self.edge_upd, self.node_upd, self.edge_norm, self.node_norm):
+            he = edge_norm(he + edge_upd(torch.cat([he, hn.index_select(1, i), hn.index_select(1, j)], dim=-1))) * m
+            received = hn.new_zeros(hn.shape[:2] + (he.shape[-1],)).index_add_(1, i, he).index_add_(1, j, he) / degree
+            hn = node_norm(hn + node_upd(torch.cat([hn, received], dim=-1)))
+        return self.node_out(hn), self.edge_out(he) * m
+
+
 # ---- edge list <-> adjacency matrix (experiments/molecule_generation/mutils.py:5-36) ---------------------------
 def pair_indices(num_nodes, device):
     """(i, j) of every unordered node pair i < j, row-major: the order of the reference's edge list."""

@@ -12,7 +12,10 @@ graph replays exactly the kernels the eager pass would launch.
 Constraints (as for any HIP graph): static shapes, inputs are copied into the captured buffers, no host
 synchronisation inside the pass — the device-side NaN / range flag word is therefore read AFTER the replay.
 """
+import contextlib
+
 import torch
+import torch.nn.functional as F
 
 from . import ops
 
@@ -53,4 +56,118 @@ class GraphedFlow:
         self.graph.replay()
         if check:
             ops.check_flags(self.device, "GraphedFlow replay")
+        return self.static_out
+
+
+# ---- a captured TRAINING step --------------------------------------------------------------------------------------
+# Round 2 removed its GraphedTrainStep: a 6000-step run stopped improving after ~2000 replays and the cause was not known.
+# Round 3 found it (tools/graph_grad_diag.py, tools/graph_linear_probe.py; profiles/r03_graph_train_root_cause.txt): on this
+# stack (ROCm 7.2 runtime, torch 2.10 + rocm7.0) a hipGraph MEMSET NODE of 16 B ... 4 KiB writes garbage from the second
+# launch of the graph on (a captured hipMemsetAsync followed by `buf += 1` leaves 1 after the first replay and inf after
+# every later one; 4-byte and 1-MiB memsets are fine).  PyTorch's own `sum` reduction zeroes the block semaphores of its
+# two-pass ("global reduce") configuration with cudaMemsetAsync — that is how the BIAS gradient of every nn.Linear is
+# taken — so from the second replay on every Linear bias gradient of a captured step is wrong (forward, weight gradients and
+# every kernel of this library bit-equal to eager; one torch.nn.Linear alone reproduces it, with either BLAS back end).
+# Nothing in this library's default path issues a memset (its zero fills are kernels).  Until the runtime is fixed a
+# captured step must not contain such a reduction: `capture_safe_linear` takes the bias gradient in single-pass stages.
+
+_orig_linear = F.linear
+
+
+def _column_sums(m):
+    """Column sums of a [M, N] matrix by reductions over at most 64 rows at a time.  PyTorch's reduce kernel goes to its
+    two-pass configuration — the one with the memset — only when a thread has >= 256 values to add (ATen/native/cuda/
+    Reduce.cuh, setReduceConfig); over <= 64 rows it is a single pass, in a fixed order: deterministic, and no memset node."""
+    while m.shape[0] > 64:
+        rows = m.shape[0]
+        c = next((c for c in (64, 32, 48, 16, 24, 8, 12, 4, 6, 2, 3) if rows % c == 0), 0)
+        if c == 0:                                   # no small divisor: zero rows up to the next multiple of 32
+            pad = (-rows) % 32
+            m = torch.cat([m, m.new_zeros(pad, m.shape[1])], 0)
+            c = 32
+        m = m.reshape(m.shape[0] // c, c, m.shape[1]).sum(1)
+    return m.sum(0)
+
+
+class _LinearNoReduce(torch.autograd.Function):
+    """F.linear whose backward takes the bias gradient by `_column_sums` instead of dY.sum(0) (PyTorch's two-pass reduce
+    kernel with a memset node in front of it).  Same values up to the order of the additions; deterministic."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return _orig_linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gy2 = gy.reshape(-1, gy.shape[-1])
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = (gy2 @ weight).reshape(x.shape)
+        if ctx.needs_input_grad[1]:
+            gw = gy2.t() @ x.reshape(-1, x.shape[-1])
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = _column_sums(gy2)
+        return gx, gw, gb
+
+
+def _safe_linear(input, weight, bias=None):
+    if torch.is_grad_enabled() and (input.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad)):
+        return _LinearNoReduce.apply(input, weight, bias)
+    return _orig_linear(input, weight, bias)
+
+
+@contextlib.contextmanager
+def capture_safe_linear():
+    """Inside: torch.nn.functional.linear (nn.Linear, nn.MultiheadAttention's projections) differentiates without
+    PyTorch's two-pass sum.  Use it around BOTH the capture and any eager run that is to be compared with the replays."""
+    prev = F.linear
+    F.linear = _safe_linear
+    try:
+        yield
+    finally:
+        F.linear = prev
+
+
+class GraphedTrainStep:
+    """One training step — forward, backward, clipping, optimiser — captured in a HIP graph and replayed.
+
+        step = GraphedTrainStep(lambda: train_step(model, optimizer, static_x, static_noise), device)
+        for batch in data:
+            static_x.copy_(batch); static_noise.uniform_()      # only copies into the static inputs between replays
+            loss = step()                                        # replay; `loss` is the captured step's return value
+
+    `step_fn` must follow the usual rules of a captured step: static input tensors, random numbers drawn OUTSIDE into
+    static buffers, gradients through torch.autograd.grad (or .backward() with grads set to None before the capture), a
+    `capturable` optimiser with its learning rate in a device tensor, no host synchronisation.  The warm-up runs on a
+    side stream; capture and replays run with `capture_safe_linear` (see above for why).  Accepted by the soak
+    (tools/graph_train_soak.py: 3000 replays against an eager twin fed the same data) — the GPU suite runs a short one."""
+
+    def __init__(self, step_fn, device, warmup=3):
+        self.step_fn, self.device = step_fn, torch.device(device)
+        main = torch.cuda.current_stream(self.device)
+        side = torch.cuda.Stream(device=self.device)
+        for _ in range(warmup):
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self._run()
+            main.wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        ops.check_flags(self.device, "GraphedTrainStep warm-up")
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.static_out = self._run()
+
+    def _run(self):
+        ops.CAPTURING = True
+        try:
+            with capture_safe_linear():
+                return self.step_fn()
+        finally:
+            ops.CAPTURING = False
+
+    def __call__(self):
+        self.graph.replay()
         return self.static_out

@@ -1159,6 +1159,20 @@ def test_bench_self_launches_n_ranks():
     assert out["value"] > 0 and out["roofline"]["kernel_ms"] > 0 and np.isfinite(out["mean_nll"])
 
 
+def test_graphed_train_step_tracks_its_eager_twin():
+    """graphs.GraphedTrainStep (back in round 3 with its root cause found): 400 replays of a captured training step of the
+    set-modelling flow — forward, the HIP backward kernels, clipping, RAdam — stay as close to an eagerly trained copy fed
+    the same data as a second eager copy does (tools/graph_train_soak.py; the acceptance run is 3000 replays,
+    profiles/r03_graph_train_soak.txt), and the same run WITHOUT capture_safe_linear leaves it (the memset-node fault)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "tools", "graph_train_soak.py"), "--steps", "400", "--check_every", "100", "--flows", "4", "--hidden", "128"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0 and "SOAK OK" in r.stdout, (r.stdout[-3000:], r.stderr[-2000:])
+    r = subprocess.run(cmd + ["--plain_linear"], capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode != 0 and "SOAK FAILED" in r.stdout, (r.stdout[-3000:], r.stderr[-2000:])
+
+
 def test_bench_rehearses_eight_ranks_on_one_device():
     """The driver's first real 8-GPU run must not be the first 8-rank run: `python bench.py --gpus 8` as 8 processes
     sharing cuda:0 over gloo — rendezvous, per-rank rates, the all-reduce of the batch sums as the closing barrier —
@@ -1296,13 +1310,17 @@ def test_c_abi_without_torch(tmp_path):
     assert run.returncode == 0 and "ABI_C OK" in run.stdout, (run.stdout[-1000:], run.stderr[-1000:])
 
 
-def test_molecule_graph_cnf_three_stage_flow_golden():
+@pytest.mark.parametrize("fixture", ["graph_cnf", "graph_cnf_zinc"])
+def test_molecule_graph_cnf_three_stage_flow_golden(fixture):
     """BASELINE configs[4]: the three-stage GraphCNF (nodes / edge attributes / virtual edges) assembled on the HIP
     layers against the REFERENCE's assembly of its own layers, sub-network outputs injected on both sides
     (oracle/gen_golden.py::gen_graph_cnf): latents after every stage, the log-det of every layer, the final per-sample
-    log-likelihood terms within 1e-4 relative, and the sampling pass's decoded node types and adjacency bit-exact."""
+    log-likelihood terms within 1e-4 relative, and the sampling pass's decoded node types and adjacency bit-exact.
+    `graph_cnf_zinc` is the configuration at its real sizes (experiments/molecule_generation/README.md:19-30,
+    zinc250k.py:150-164): 38 nodes, 703 node pairs, D = 6 / 2, K = 16 / 8, 9 node and 3 edge types, 4 + 6 + 6 coupling
+    layers, graphs of different sizes."""
     from tests.test_host_cpu import _graph_cnf_model
-    c = load_cases("graph_cnf")[0]
+    c = load_cases(fixture)[0]
     model = _graph_cnf_model(c).cuda()
     for layer in list(model.step1_flows) + list(model.step2_flows) + list(model.step3_flows):
         if hasattr(layer, "nn"):
@@ -1333,6 +1351,19 @@ def test_molecule_graph_cnf_three_stage_flow_golden():
         (nodes, adjacency), ldj_rev = model(g(c.z), reverse=True, length=g(c.length), edge_latents=g(c.edge_latents))
     assert torch.equal(nodes.cpu(), c.dec_nodes) and torch.equal(adjacency.cpu(), c.dec_adjacency)
     loglik_close(ldj_rev, c.ldj_rev)
+
+
+def test_molecule_graph_cnf_trains_and_samples_end_to_end_at_zinc_sizes():
+    """configs[4] executed END TO END on the device at its real sizes (38 nodes, 703 pairs, D = 6 / 2, K = 16 / 8, 9 node
+    types): the three-stage GraphCNF on the HIP layers with a stand-in stage-2 / 3 sub-network of this package's own
+    design (PairMessageNet; the reference's Edge-GNN lives in the user's checkout) — data-dependent init, 30 training
+    steps through every backward kernel of the path (loss falls), evaluation, one sampling pass (tools/molecule_train_probe.py)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "molecule_train_probe.py"), "--steps", "30", "--batch", "16",
+                        "--flows", "2,2,2", "--hidden_nodes", "64", "--hidden_edges", "32", "--graphs", "256"],
+                       capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0 and "MOLECULE PROBE OK" in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])
 
 
 @pytest.mark.parametrize("B,N,D,C", [(9, 16, 4, 16), (5, 33, 3, 51), (3, 20, 10, 700), (2, 12, 6, 3000), (4, 7, 1, 2), (70, 5, 2, 1200)])

@@ -5,10 +5,12 @@ transcendental (v_exp / v_log / v_rcp) for 8 (quarter rate); MI355X has 1024 SIM
     valu_frac = ((INSTS_VALU - TRANS) * 2 + TRANS * 8) / (128 * GRBM_GUI_ACTIVE)
 (MI355X_MICROARCH.md: v_fma_f32 wave64 = 2 cycles on a SIMD-32; GRBM_GUI_ACTIVE is summed over the 8 XCDs, each with
 128 SIMDs: for a 136 us launch it reads 2.73e6 = 8 x 2.5 GHz x 136 us).
-That is a MODEL of the issue cost; beside it `valu_busy` is the MEASURED share of SIMD cycles in which the VALU executed,
-    valu_busy = SQ_ACTIVE_INST_VALU * 4 / (128 * GRBM_GUI_ACTIVE)          (SQ cycle counters tick in quad-cycles)
-and `cyc/inst` = SQ_ACTIVE_INST_VALU * 4 / SQ_INSTS_VALU.  Where the two disagree (the encoder kernels: 0.40 by the
-model, 0.60 measured, 4.8 cycles per instruction) the measured one is what the kernel does; `binds` uses the larger.
+Round 3 calibrated both columns on the device (tools/microbench, profiles/r03_valu_calibration.txt): a SIMD saturated with
+independent v_fma_f32 retires one per 2.0 cycles and v_exp / v_log / v_rcp one per 8 — the model above is what the
+hardware does — while SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU is EXACTLY 1 quad-cycle for every plain and 2 for every
+transcendental instruction at every occupancy: it is an instruction count in quantised units, not busy time.  Round 2's
+`valu_busy` = SQ_ACTIVE_INST_VALU * 4 / SIMD cycles therefore over-states plain instructions 2x (1.73 for a saturated
+SIMD).  It is still printed, as `quantised` (for the record), but `binds` is decided by `valu_frac` alone.
 Usage: ceilings.py <pmc dir> [out.json]"""
 import csv, glob, json, os, sys
 from collections import defaultdict
@@ -24,7 +26,7 @@ for path in glob.glob(os.path.join(d, "stats", "**", "*kernel_stats.csv"), recur
     for row in csv.DictReader(open(path)):
         dur[row["Name"]] = float(row["AverageNs"])
 out = []
-print("%-40s %9s %9s %9s %9s %9s %9s %9s %9s  %s" % ("kernel", "us", "alg GB/s", "hbm_frac", "valu_frac", "valu_busy", "cyc/inst", "wait %", "HBM MB", "binds"))
+print("%-40s %9s %9s %9s %9s %9s %9s %9s %9s  %s" % ("kernel", "us", "alg GB/s", "hbm_frac", "valu_frac", "quantised", "cyc/inst", "wait %", "HBM MB", "binds"))
 for frag, info in manifest.items():
     names = [k for k in vals if frag in k]
     if not names:
@@ -44,9 +46,9 @@ for frag, info in manifest.items():
     cyc_inst = act * 4.0 / valu if (act and valu) else None
     wait = 100.0 * c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAVE_CYCLES") else None
     mb = (c.get("FETCH_SIZE", 0) * 2 + c.get("WRITE_SIZE", 0)) * 1024 / 1e6 if "FETCH_SIZE" in c else None
-    binds = "hbm" if hbm >= max(valu_frac or 0.0, valu_busy or 0.0) else "valu"
+    binds = "hbm" if hbm >= (valu_frac or 0.0) else "valu"
     row = {"kernel": frag, "what": info["what"], "avg_us": t_ns / 1e3, "alg_GBps": info["alg_bytes"] / t_ns, "hbm_frac": hbm,
-           "valu_frac": valu_frac, "valu_busy": valu_busy, "cycles_per_valu_inst": cyc_inst, "wave_wait_pct": wait, "hbm_MB_per_launch": mb, "valu_insts": valu, "trans_insts": trans,
+           "valu_frac": valu_frac, "sq_active_inst_valu_x4_over_simd_cycles": valu_busy, "cycles_per_valu_inst": cyc_inst, "wave_wait_pct": wait, "hbm_MB_per_launch": mb, "valu_insts": valu, "trans_insts": trans,
            "clock_GHz_if_unprofiled_duration": gui / 8.0 / t_ns if gui else None, "binds": binds}
     out.append(row)
     print("%-40s %9.1f %9.0f %9.3f %9s %9s %9s %9s %9s  %s" % (info["what"][:40], t_ns / 1e3, info["alg_bytes"] / t_ns, hbm,

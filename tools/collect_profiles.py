@@ -1,10 +1,10 @@
 """Copy the summaries tools/refresh_profiles.sh left under gpurun_out/ into profiles/ (tracked).
-Usage: python tools/collect_profiles.py [round_tag]   (default r02)"""
+Usage: python tools/collect_profiles.py [round_tag]   (default r03)"""
 import csv, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 
 
 def last_json_line(path):
@@ -28,7 +28,7 @@ for src, dst in (("sweep_affine.log", "_sweep_affine.txt"), ("sweep_nll.log", "_
                  ("sweep_mixture_bwd.log", "_sweep_mixture_bwd.txt"), ("bench_kernels.log", "_bench_kernels.txt"),
                  ("flow_graph.txt", "_flow_graph.txt"), ("encoder_probe.txt", "_encoder_probe.txt"), ("sustained_probe.txt", "_sustained_probe.txt"), ("train_step.txt", "_train_step.txt"),
                  ("ceilings/ceilings.txt", "_ceilings.txt"), ("ceilings/ceilings.json", "_ceilings.json"),
-                 ("pmc_small/table.txt", "_pmc_small_mixture.txt"), ("flow_traffic.txt", "_flow_traffic.txt"),
+                 ("pmc_small/table.txt", "_pmc_small_mixture.txt"), ("ab_mixture_inverse.txt", "_ab_mixture_inverse.txt"), ("flow_traffic.txt", "_flow_traffic.txt"),
                  ("flow_traffic.json", "_flow_traffic.json"), ("mfma_set/mfma_util.txt", "_mfma_util_set_modelling.txt"),
                  ("mfma_set/mfma_util.json", "_mfma_util_set_modelling.json"),
                  ("train_step_flat.txt", "_train_step_flat_optimizer.txt"), ("host_profile.txt", "_host_profile_train_step.txt"),

@@ -58,10 +58,10 @@ for tag, (B, N, D, K, masked) in {"configs1": (16384, 16, 4, 8, True), "ptb": (1
     run([ops.mixture_coupling_launch(zs[r], nns[r], mask, K, zo, lf) for r in range(R)])
     run([ops.mixture_coupling_launch(zo, nns[r], mask, K, zr, lr, reverse=True) for r in range(R)])
     e = B * N * D
-    kt = K if K in (4, 8, 16) else 0
-    gl = 1 if kt else 4
-    manifest["mixture_tok_kernel<%d, false, %d, false, 0>" % (kt, gl)] = {"what": "mixture fwd %s" % tag, "alg_bytes": (16 + 12 * K) * e, "elems": e}
-    manifest["mixture_tok_kernel<%d, true, %d, false, 0>" % (kt, gl)] = {"what": "mixture inverse %s" % tag, "alg_bytes": (16 + 12 * K) * e, "elems": e}
+    # K = 8: exact instantiation; K = 51: 13 predicated slots on each of 4 lanes (cnf_mixture_tok.hip, slots_for)
+    kt, gl, pr = (K, 1, "false") if K in (4, 8, 16) else (13, 4, "true")
+    manifest["mixture_tok_kernel<%d, false, %d, false, 0, %s>" % (kt, gl, pr)] = {"what": "mixture fwd %s" % tag, "alg_bytes": (16 + 12 * K) * e, "elems": e}
+    manifest["mixture_tok_kernel<%d, true, %d, false, 0, %s>" % (kt, gl, pr)] = {"what": "mixture inverse %s" % tag, "alg_bytes": (16 + 12 * K) * e, "elems": e}
     del zs, nns
 out = os.environ.get("CNF_MANIFEST")
 if out:

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Re-measure everything profiles/ holds, on the GPU box.  Run from the repo root:
-#   gpurun --timeout 2400 -- 'bash tools/refresh_profiles.sh'
-# then, back in the build container:  python tools/collect_profiles.py r02
+#   gpurun --timeout 2400 -- 'bash tools/refresh_profiles.sh'        (CNF_REFRESH_QUICK=1: the kernel measurements only)
+# then, back in the build container:  python tools/collect_profiles.py r03
 # The --pmc passes are separate rocprofv3 runs with --kernel-trace only (never combined with sys/hip traces).
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -38,6 +38,9 @@ bash tools/pmc_passes.sh pmc_small python tools/pmc_small_mixture.py > "$OUT/pmc
 bash tools/pmc_passes.sh flow_fused python tools/flow_traffic_workload.py fused > /dev/null 2>&1
 bash tools/pmc_passes.sh flow_unfused python tools/flow_traffic_workload.py unfused > /dev/null 2>&1
 python tools/flow_traffic.py "$OUT/flow_fused" "$OUT/flow_unfused" "$OUT/flow_traffic.json" > "$OUT/flow_traffic.txt" 2>&1; head -12 "$OUT/flow_traffic.txt"
+timeout 300 python tools/ab_mixture_inverse.py 2>&1 | grep -v amdgpu.ids > "$OUT/ab_mixture_inverse.txt"; tail -5 "$OUT/ab_mixture_inverse.txt" | cut -c1-200
+# CNF_REFRESH_QUICK=1: kernels only — skip the training-step, host-profile, MFMA and training-log sections below
+if [ -n "${CNF_REFRESH_QUICK:-}" ]; then exit 0; fi
 ( for b in 64 256 1024; do timeout 300 python tools/bench_train_step.py $b 20 2>&1 | grep "^batch"; done ) > "$OUT/train_step.txt"; cat "$OUT/train_step.txt"
 ( for b in 64 1024; do timeout 300 python tools/bench_train_step.py $b 30 2>&1 | grep "^batch"; timeout 300 python tools/bench_train_step.py $b 30 flat 2>&1 | grep "^batch"; done ) > "$OUT/train_step_flat.txt"; cat "$OUT/train_step_flat.txt"
 timeout 200 python tools/host_profile_train_step.py 64 30 > "$OUT/host_profile.txt" 2>&1; head -6 "$OUT/host_profile.txt"
