@@ -1,6 +1,8 @@
 """Training step of the reference's default set-modelling flow (8 flow steps, Transformer sub-network hidden 256 x 2
-layers, D=4, K=8, |S|=16): forward + NLL + backward + Adam.  Run under `rocprofv3 --kernel-trace --stats` to see how
-the step splits between this library's kernels (namespace cnf::) and the PyTorch-ROCm sub-networks."""
+layers, D=4, K=8, |S|=16): forward + NLL + backward + RAdam.  Run under `rocprofv3 --kernel-trace --stats` to see how
+the step splits between this library's kernels (namespace cnf::) and the PyTorch-ROCm sub-networks.
+    python tools/bench_train_step.py <batch> <steps> [flat | graph]
+`graph`: the whole step captured once by categoricalnf_amd.graphs.GraphedTrainStep and replayed (round 3)."""
 import os, sys, time, io, contextlib
 import numpy as np
 import torch
@@ -40,6 +42,31 @@ def step(i):
     opt.step()
     return loss
 
+GRAPH = len(sys.argv) > 3 and sys.argv[3] == "graph"
+if GRAPH:
+    from categoricalnf_amd.graphs import GraphedTrainStep
+    opt = torch.optim.RAdam(model.parameters(), lr=torch.tensor(7.5e-4, device="cuda"), capturable=True)
+    static_x = xs[0].clone()
+    static_noise = torch.rand(B * 16, 1, 4, device="cuda")
+    plist = [p for p in model.parameters() if p.requires_grad]
+
+    def graph_step():
+        z, ldj = model(static_x, reverse=False, length=ln, beta=1, noise=static_noise)
+        loss = Fn.PriorNllFn.apply(z, ldj, ln, None).mean()
+        for p, g in zip(plist, torch.autograd.grad(loss, plist, allow_unused=True)):
+            p.grad = g
+        torch.nn.utils.clip_grad_norm_(plist, 0.25, foreach=True)
+        opt.step()
+        return loss.detach()
+    for p in plist:
+        p.grad = None
+    graphed = GraphedTrainStep(graph_step, torch.device("cuda", 0))
+
+    def step(i):                                   # what a training loop does between replays: new data and noise into the static inputs
+        static_x.copy_(xs[i % 4], non_blocking=True)
+        static_noise.uniform_()
+        return graphed()
+
 for i in range(5):
     step(i)
 torch.cuda.synchronize()
@@ -48,4 +75,4 @@ for i in range(steps):
     loss = step(i)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
-print("batch %d eager%s: %.2f ms / training step (%.0f sets/s), loss %.4f" % (B, " (flat optimiser)" if FLAT else "  ", dt * 1e3, B / dt, float(loss.detach())))
+print("batch %d %s: %.2f ms / training step (%.0f sets/s), loss %.4f" % (B, "HIP graph replay" if GRAPH else ("eager (flat optimiser)" if FLAT else "eager"), dt * 1e3, B / dt, float(loss.detach())))
