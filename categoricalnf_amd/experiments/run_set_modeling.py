@@ -64,6 +64,10 @@ def parse(argv=None):
     p.add_argument("--coupling_mask_ratio", type=float, default=0.5)
     p.add_argument("--coupling_num_mixtures", type=int, default=8)
     p.add_argument("--backend", default=None, help="torch.distributed backend (default: nccl = RCCL)")
+    p.add_argument("--graph_step", action="store_true",
+                   help="single process only: the whole training step (forward, HIP backward kernels, clipping, RAdam) is captured "
+                        "once in a HIP graph and replayed (categoricalnf_amd.graphs.GraphedTrainStep); between replays only the "
+                        "batch, the encoder noise and the learning rate are written into static device buffers")
     p.add_argument("--flat_optimizer", action="store_true",
                    help="single process only: optimiser, clipping and zero_grad on ONE flat parameter buffer "
                         "(host_utils.FlatParameters: 23.0 -> 21.8 ms per step at batch 64); checkpoints "
@@ -253,22 +257,81 @@ def main(argv=None):
         scheduler = torch.optim.lr_scheduler.LambdaLR(
             optimizer, lambda step: max(floor, args.lr_decay_factor ** (step // max(1, args.lr_decay_step))))
         advance_schedule(scheduler, state["iteration"])
+    graphed = None
+    if args.graph_step and (world > 1 or flat is not None):
+        say("[#] --graph_step ignored: it is a single-process mode without --flat_optimizer")
+    elif args.graph_step:
+        from ..graphs import GraphedTrainStep
+        lr_of = lambda step: args.learning_rate * max(floor, args.lr_decay_factor ** (step // max(1, args.lr_decay_step)))
+        lr_t = torch.tensor(lr_of(state["iteration"]), dtype=torch.float32, device=device)      # the schedule lives in a device scalar
+        eager_state = optimizer.state_dict()["state"]
+        optimizer = torch.optim.RAdam(model.parameters(), lr=lr_t, capturable=True)
+        if eager_state:                                   # resumed: carry the moments over (step counters move to the device)
+            sd = optimizer.state_dict()
+            sd["state"] = {k: {n: (v.to(device=device, dtype=torch.float32) if n == "step" else v) for n, v in st.items()}
+                           for k, st in eager_state.items()}
+            optimizer.load_state_dict(sd)
+            for group in optimizer.param_groups:
+                group["lr"], group["capturable"] = lr_t, True
+        model.train()
+        static_x, static_ln = batch()
+        static_noise = torch.rand(static_x.numel(), 1, args.encoding_dim, device=device)
+        plist = [p_ for p_ in model.parameters() if p_.requires_grad]
+
+        def graph_train_step():
+            z_, ldj_ = model(static_x, reverse=False, length=static_ln, beta=1, noise=static_noise)
+            loss_ = Fn.PriorNllFn.apply(z_, ldj_, static_ln, None).mean()
+            for p_, g_ in zip(plist, torch.autograd.grad(loss_, plist, allow_unused=True)):
+                p_.grad = g_
+            torch.nn.utils.clip_grad_norm_(plist, args.max_gradient_norm, foreach=True)
+            optimizer.step()
+            return loss_.detach()
+        for p_ in plist:
+            p_.grad = None
+        snapshot = [p_.detach().clone() for p_ in plist], {k: {n: v.clone() for n, v in st.items() if torch.is_tensor(v)}
+                                                          for k, st in optimizer.state.items()}
+        graphed = GraphedTrainStep(graph_train_step, device)
+        # the three warm-up steps before the capture trained on one batch: undo them (parameters and moments)
+        with torch.no_grad():
+            for p_, old in zip(plist, snapshot[0]):
+                p_.copy_(old)
+            for k, st in optimizer.state.items():
+                for n, v in st.items():
+                    if torch.is_tensor(v):
+                        if k in snapshot[1] and n in snapshot[1][k]:
+                            v.copy_(snapshot[1][k][n])
+                        else:
+                            v.zero_()
+
+        def drop_weight_caches():
+            # replays do not run the modules' Python, so the eval-mode caches of the 1x1 convolutions (W, W^-1, log-det per
+            # device) are not dropped by a training forward any more: drop them before anything runs in eval mode
+            for m_ in model.modules():
+                if hasattr(m_, "_empty_eval_dict"):
+                    m_._empty_eval_dict()
     ddp.train()
     best = state["best_save_dict"]
     periodic = set()          # full-state checkpoints written at save_freq steps (kept when a better validation file appears)
     t0, run_loss, seen = time.time(), torch.zeros((), device=device), 0       # the loss stays on the device between prints
     for it in range(state["iteration"], args.max_iterations):
         x, ln = batch()
-        z, ldj = ddp(x, reverse=False, length=ln, beta=1)
-        loss = Fn.PriorNllFn.apply(z, ldj, ln, None).mean()
-        if flat is not None:
-            flat.zero_grad()
+        if graphed is not None:
+            static_x.copy_(x, non_blocking=True)
+            static_noise.uniform_()
+            lr_t.fill_(lr_of(it))
+            loss = graphed()
+            scheduler.last_epoch, scheduler._last_lr = it + 1, [lr_of(it + 1)]      # what the checkpoint stores of the schedule
         else:
-            optimizer.zero_grad(set_to_none=True)
-        loss.backward()
-        torch.nn.utils.clip_grad_norm_(flat.parameters() if flat is not None else ddp.parameters(), args.max_gradient_norm)
-        optimizer.step()
-        scheduler.step()
+            z, ldj = ddp(x, reverse=False, length=ln, beta=1)
+            loss = Fn.PriorNllFn.apply(z, ldj, ln, None).mean()
+            if flat is not None:
+                flat.zero_grad()
+            else:
+                optimizer.zero_grad(set_to_none=True)
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(flat.parameters() if flat is not None else ddp.parameters(), args.max_gradient_norm)
+            optimizer.step()
+            scheduler.step()
         run_loss += loss.detach()
         seen += 1
         step = it + 1
@@ -277,6 +340,8 @@ def main(argv=None):
             t0, seen = time.time(), 0
             run_loss.zero_()
         if step % args.eval_freq == 0 or step == args.max_iterations:
+            if graphed is not None:
+                drop_weight_caches()
             val_nll, val_bpd = evaluate(ddp, val_sets, device, rank, world, args.eval_batch_size)
             state["evaluation_dict"][step] = val_nll
             say("iteration %7d | validation %.4f bpd (optimum %.4f)" % (step, val_bpd, optimum))
@@ -290,9 +355,17 @@ def main(argv=None):
                 save_checkpoint(args.checkpoint_path, step, ddp, best_save_dict=best, evaluation_dict=state["evaluation_dict"])
         if step % args.save_freq == 0 and args.checkpoint_path and rank == 0:
             # always the full state (a best-validation file of the same step is a subset of it and is replaced)
+            if graphed is not None:                       # the file stores the learning rate as a number, like an eager run's
+                for group in optimizer.param_groups:
+                    group["lr"] = float(lr_t)
             save_checkpoint(args.checkpoint_path, step, ddp, optimizer if flat is None else None, scheduler,
                             best_save_dict=best, evaluation_dict=state["evaluation_dict"])
+            if graphed is not None:
+                for group in optimizer.param_groups:
+                    group["lr"] = lr_t
             periodic.add(checkpoint_file(args.checkpoint_path, step))
+    if graphed is not None:
+        drop_weight_caches()
     _, val_bpd = evaluate(ddp, val_sets, device, rank, world, args.eval_batch_size)
     _, test_bpd = evaluate(ddp, test_sets, device, rank, world, args.eval_batch_size)
     say("final: validation %.4f bpd, test %.4f bpd (optimum %.4f)" % (val_bpd, test_bpd, optimum))

@@ -1262,6 +1262,22 @@ def test_set_modelling_driver_trains_checkpoints_and_reloads(tmp_path):
 
 
 
+def test_set_modelling_driver_with_the_captured_training_step(tmp_path):
+    """run_set_modeling --graph_step (round 3): the training step replayed from a HIP graph learns like the eager loop
+    (validation bits/dim well below the uniform 4 bpd after 400 steps), its checkpoint — written while the weights moved
+    under replays, so the eval-mode caches of the 1x1 convolutions must have been dropped — evaluates to the stored
+    validation NLL in a fresh eager process state, and a resumed run carries on from it."""
+    from categoricalnf_amd.experiments import run_set_modeling as R
+    small = ["--dataset", "summation", "--coupling_hidden_size", "32", "--coupling_hidden_layers", "1", "--coupling_num_flows", "2",
+             "--checkpoint_path", str(tmp_path), "--print_freq", "1000000", "--batch_size", "128", "--learning_rate", "2e-3"]
+    out = R.main(small + ["--max_iterations", "400", "--eval_freq", "200", "--save_freq", "400", "--graph_step"])
+    assert np.isfinite(out["val_bpd"]) and out["val_bpd"] < 3.6, out
+    again = R.main(small + ["--only_eval"])
+    assert abs(again["val_bpd"] - out["val_bpd"]) < 2e-3, (again, out)
+    more = R.main(small + ["--max_iterations", "500", "--eval_freq", "100", "--graph_step"])
+    assert np.isfinite(more["val_bpd"]) and more["val_bpd"] < out["val_bpd"] + 0.05, (more, out)
+
+
 def test_backward_with_non_contiguous_upstream_gradients():
     """Both upstream gradients of a layer arrive non-contiguous (a transposed view and the expanded gradient of a
     mean): each is copied for the kernel and both copies must stay alive until the launch (they once could be handed
