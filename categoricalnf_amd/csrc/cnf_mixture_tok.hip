@@ -787,10 +787,15 @@ bool launch_mixture_tok(MixArgs& a, hipStream_t st, int force_g) {
     TokGeom gm;
     int G = 1;
     size_t lds = 0;
-    if (!make_tok_geom(a, kt, force_g, gm, G, lds, slot_g, true, 0)) {
+    // first choice first: (register slots | exact K) with whole-token staging where it applies, then the same on spans only
+    // (a whole token may not fit the stage where its transformed span does), then the rolled loop likewise
+    bool whole = true;
+    if (!make_tok_geom(a, kt, force_g, gm, G, lds, slot_g, true, 0) && (whole = false, !make_tok_geom(a, kt, force_g, gm, G, lds, slot_g, false, 0))) {
         if (slot_g == 0) return false;
-        kt = 0; slot_g = 0;                     // the slot geometry does not fit: rolled loop
-        if (!make_tok_geom(a, kt, force_g, gm, G, lds, 0, true, 0)) return false;
+        kt = 0; slot_g = 0;
+        whole = true;
+        if (!make_tok_geom(a, kt, force_g, gm, G, lds, 0, true, 0) && (whole = false, !make_tok_geom(a, kt, force_g, gm, G, lds, 0, false, 0)))
+            return false;
     }
     const bool nll = a.nll_out != nullptr;
     if (a.e_w && (G != 1 || !(a.D == 2 || a.D == 3 || a.D == 4 || a.D == 6))) return false;
@@ -798,7 +803,7 @@ bool launch_mixture_tok(MixArgs& a, hipStream_t st, int force_g) {
     if (!kern) return false;
     if (gm.split && gm.S > 1) {
         const long cap = resident_workgroups(kern, lds);
-        if (cap > 0 && (long)a.B * gm.S > cap && !make_tok_geom(a, kt, force_g, gm, G, lds, slot_g, true, cap)) return false;
+        if (cap > 0 && (long)a.B * gm.S > cap && !make_tok_geom(a, kt, force_g, gm, G, lds, slot_g, whole, cap)) return false;
     }
     const dim3 block(kBlock);
     const dim3 grid(gm.split ? (unsigned)((long)a.B * gm.S) : (unsigned)((gm.ntiles + kWavesPerBlock - 1) / kWavesPerBlock));

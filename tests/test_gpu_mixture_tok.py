@@ -175,10 +175,13 @@ def test_every_mixture_count_on_register_slots(K):
 
 
 @pytest.mark.parametrize("B,N,D,K,kind", [(6, 703, 2, 8, "channel"), (33, 20, 2, 8, "channel"), (300, 1, 2, 8, "channel"),
-                                          (9, 50, 2, 8, "channel_inv"), (7, 31, 2, 4, "channel"), (5, 64, 3, 2, "channel")])
+                                          (9, 50, 2, 8, "channel_inv"), (7, 31, 2, 4, "channel"), (5, 64, 3, 2, "channel"),
+                                          (4, 90, 2, 11, "channel"), (4, 90, 2, 10, "channel_inv")])
 def test_whole_token_staging_is_bit_identical_to_span_staging(B, N, D, K, kind):
     """Where a transformed span plus one line covers the token's stride (D = 2: 104-byte spans at a 208-byte stride),
-    forward / inverse stage whole tokens as one contiguous range; the arithmetic is the same, so are the results."""
+    forward / inverse stage whole tokens as one contiguous range; the arithmetic is the same, so are the results.  K = 10 / 11
+    at D = 2: whole tokens (280 bytes x 64) no longer fit four stages in 64 KiB of LDS — the launch falls back to spans, it
+    does not leave the token-pass kernel."""
     z, nn_out, sf, msf, mask, ln, pad = _case(B, N, D, K, kind, 321 + B + N)
     gk = dict(scaling_factor=g(sf), mixture_scaling_factor=g(msf), channel_padding_mask=g(pad))
     lib = _lib.load()
