@@ -62,7 +62,8 @@ class GraphedFlow:
 # ---- a captured TRAINING step --------------------------------------------------------------------------------------
 # Round 2 removed its GraphedTrainStep: a 6000-step run stopped improving after ~2000 replays and the cause was not known.
 # Round 3 found it (tools/graph_grad_diag.py, tools/graph_linear_probe.py; profiles/r03_graph_train_root_cause.txt): on this
-# stack (ROCm 7.2 runtime, torch 2.10 + rocm7.0) a hipGraph MEMSET NODE of 16 B ... 4 KiB writes garbage from the second
+# stack — torch 2.10 + rocm7.0, whose wheel bundles the HIP runtime 7.0.51831 that the whole process runs on (the image's ROCm 7.2
+# runtime does not show the fault: tools/repro/hip_graph_memset_node.cpp) — a hipGraph MEMSET NODE of 16 B ... 4 KiB writes garbage from the second
 # launch of the graph on (a captured hipMemsetAsync followed by `buf += 1` leaves 1 after the first replay and inf after
 # every later one; 4-byte and 1-MiB memsets are fine).  PyTorch's own `sum` reduction zeroes the block semaphores of its
 # two-pass ("global reduce") configuration with cudaMemsetAsync — that is how the BIAS gradient of every nn.Linear is
