@@ -250,6 +250,23 @@ def read_traffic(path=None):
         "rocprofv3 --pmc passes of tools/pmc_workload.py on these kernel sources (sha %s)" % sha
 
 
+def rocprof_cross_check(kern_ms):
+    """The committed rocprofv3 summary of this command (profiles/r03_bench_kernel_stats.csv, `rocprofv3 --kernel-trace --stats
+    -- python bench.py --no-cpu-baseline` on these kernel sources' round): its AverageNs for the dominant kernel next to this
+    run's `kernel_ms`.  A static file, reported for the reader's convenience — None when it is absent."""
+    import csv
+    path = os.path.join(ROOT, "profiles", "r03_bench_kernel_stats.csv")
+    try:
+        for row in csv.DictReader(open(path)):
+            if "affine_coupling_kernel<4, 2, true, false, true, 1>" in row["Name"]:
+                avg_ms = float(row["AverageNs"]) * 1e-6
+                return {"file": "profiles/r03_bench_kernel_stats.csv", "rocprofv3_average_kernel_ms": avg_ms, "calls": int(row["Calls"]),
+                        "this_run_over_rocprofv3": kern_ms / avg_ms}
+    except Exception:
+        pass
+    return None
+
+
 def self_launch(args):
     """`python bench.py --gpus N` without a torchrun environment: start the N ranks ourselves (one process per GPU,
     the same command line the driver would use) and hand their exit code back."""
@@ -374,11 +391,12 @@ def main():
         torch.cuda.synchronize(dev)
 
     ev_loop = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-    barrier()
+    # the accumulators are cleared and the start marker is queued BEFORE the opening barrier, so that nothing but the barrier
+    # + device sync sits between the warm-up and t0 (an untimed burst of 64 more steps in front of it was measured: no change)
     acc_all.zero_()
     steps_counted[0] = args.steps
     ev_loop[0].record()             # GPU-side clock of the job (steps + read-out); its start marker goes in before t0
-    torch.cuda.synchronize(dev)
+    barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         zr, lr = step(i, timed=(i % EV == EV_AT))
@@ -547,6 +565,7 @@ def main():
                                               "std %.2f us" % (len(sp_fwd), float(np.std(sp_fwd)) * 1e3))
                                              if len(sp_fwd) >= 32 else "in-loop pairs / steady-state stream (too few serialised samples)",
                          "inverse_kernel_ms": float(np.mean(sp_inv)) if sp_inv else None,
+                         "rocprofv3_cross_check": rocprof_cross_check(kern_ms),
                          "in_loop_pairs": {"kernel_ms": in_loop_ms, "samples": len(in_step),
                                            "frac": (alg_bytes / (in_loop_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if in_loop_ms else None,
                                            "what": "cross-check: sparse pairs on forward launches INSIDE the timed region (every "
