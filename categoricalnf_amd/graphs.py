@@ -132,6 +132,34 @@ def capture_safe_linear():
         F.linear = prev
 
 
+def graph_node_census(graph):
+    """{node type name: count} of a torch.cuda.CUDAGraph created with keep_graph=True (its raw hipGraph_t is walked with
+    hipGraphGetNodes / hipGraphNodeGetType through the HIP runtime the process already runs on).  What it is for: on the
+    runtime the torch wheel bundles a MEMSET node is replayed wrongly (see above), so a captured step should hold none —
+    GraphedTrainStep refuses one that does.  Returns None when the handle or the runtime entry points are not there."""
+    import ctypes
+    try:
+        raw = int(graph.raw_cuda_graph())
+        hip = ctypes.CDLL("libamdhip64.so")          # the SONAME is loaded already: the same runtime torch captured with
+        count = ctypes.c_size_t(0)
+        if hip.hipGraphGetNodes(ctypes.c_void_p(raw), None, ctypes.byref(count)) != 0:
+            return None
+        nodes = (ctypes.c_void_p * max(count.value, 1))()
+        if hip.hipGraphGetNodes(ctypes.c_void_p(raw), nodes, ctypes.byref(count)) != 0:
+            return None
+        names = {0: "kernel", 1: "memcpy", 2: "memset", 3: "host", 4: "graph", 5: "empty"}
+        census = {}
+        for i in range(count.value):
+            kind = ctypes.c_int(-1)
+            if hip.hipGraphNodeGetType(ctypes.c_void_p(nodes[i]), ctypes.byref(kind)) != 0:
+                return None
+            name = names.get(kind.value, "type%d" % kind.value)
+            census[name] = census.get(name, 0) + 1
+        return census
+    except Exception:
+        return None
+
+
 class GraphedTrainStep:
     """One training step — forward, backward, clipping, optimiser — captured in a HIP graph and replayed.
 
@@ -143,10 +171,11 @@ class GraphedTrainStep:
     `step_fn` must follow the usual rules of a captured step: static input tensors, random numbers drawn OUTSIDE into
     static buffers, gradients through torch.autograd.grad (or .backward() with grads set to None before the capture), a
     `capturable` optimiser with its learning rate in a device tensor, no host synchronisation.  The warm-up runs on a
-    side stream; capture and replays run with `capture_safe_linear` (see above for why).  Accepted by the soak
+    side stream; capture and replays run with `capture_safe_linear` (see above for why), and the captured graph is refused if
+    it still holds a memset node (`.nodes` is the census of its node types).  Accepted by the soak
     (tools/graph_train_soak.py: 3000 replays against an eager twin fed the same data) — the GPU suite runs a short one."""
 
-    def __init__(self, step_fn, device, warmup=3):
+    def __init__(self, step_fn, device, warmup=3, allow_memset_nodes=False):
         self.step_fn, self.device = step_fn, torch.device(device)
         main = torch.cuda.current_stream(self.device)
         side = torch.cuda.Stream(device=self.device)
@@ -157,9 +186,21 @@ class GraphedTrainStep:
             main.wait_stream(side)
         torch.cuda.synchronize(self.device)
         ops.check_flags(self.device, "GraphedTrainStep warm-up")
-        self.graph = torch.cuda.CUDAGraph()
+        try:
+            self.graph = torch.cuda.CUDAGraph(keep_graph=True)        # keeps the hipGraph_t so that its nodes can be counted
+        except TypeError:
+            self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.static_out = self._run()
+        # a step that still contains a memset node would replay wrongly from its second launch on, silently: refuse it
+        self.nodes = graph_node_census(self.graph)
+        if self.nodes and self.nodes.get("memset", 0) and not allow_memset_nodes:
+            raise RuntimeError(
+                "the captured step contains %d memset node(s) (%s): on the HIP runtime bundled with this torch wheel a hipGraph "
+                "memset node is replayed wrongly from the second launch on (profiles/r03_graph_train_root_cause.txt).  They come "
+                "from cudaMemsetAsync inside an op — PyTorch's two-pass sum over a long dimension does it; nn.Linear's bias gradient is "
+                "covered by capture_safe_linear.  Reformulate the reduction in stages of <= 64 rows (graphs._column_sums) or pass "
+                "allow_memset_nodes=True if the runtime at hand is known to be sound." % (self.nodes["memset"], self.nodes))
 
     def _run(self):
         ops.CAPTURING = True

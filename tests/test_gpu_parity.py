@@ -1171,6 +1171,23 @@ def test_graphed_train_step_tracks_its_eager_twin():
     assert r.returncode == 0 and "SOAK OK" in r.stdout, (r.stdout[-3000:], r.stderr[-2000:])
     r = subprocess.run(cmd + ["--plain_linear"], capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode != 0 and "SOAK FAILED" in r.stdout, (r.stdout[-3000:], r.stderr[-2000:])
+    # and GraphedTrainStep refuses a step that still holds a memset node instead of replaying it wrongly
+    from categoricalnf_amd.graphs import GraphedTrainStep
+    lin = torch.nn.Linear(256, 256).cuda()
+    x, w = torch.randn(1024, 256, device="cuda"), torch.randn(1024, 256, device="cuda")
+
+    def with_a_two_pass_sum():                       # dY.sum(0) over 1024 rows: reduce_kernel behind a memset of its semaphores
+        y = torch.tanh(x @ lin.weight.t())
+        return torch.autograd.grad((y * w).sum(), [lin.weight])[0].sum(0) + (y * w).sum(0)
+
+    def staged():
+        from categoricalnf_amd.graphs import _column_sums
+        y = torch.tanh(x @ lin.weight.t())
+        return _column_sums(y * w)
+    ok = GraphedTrainStep(staged, torch.device("cuda", 0))
+    assert ok.nodes is not None and ok.nodes.get("memset", 0) == 0 and ok.nodes.get("kernel", 0) > 0, ok.nodes
+    with pytest.raises(RuntimeError, match="memset node"):
+        GraphedTrainStep(with_a_two_pass_sum, torch.device("cuda", 0))
 
 
 def test_bench_rehearses_eight_ranks_on_one_device():

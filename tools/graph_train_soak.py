@@ -114,7 +114,8 @@ for _ in range(3):
 if args.plain_linear:
     import categoricalnf_amd.graphs as _g
     _g.capture_safe_linear = contextlib.nullcontext          # the failure, for the record: PyTorch's own bias gradient under replay
-graph = GraphedTrainStep(lambda: _train_step(model_b, opt_b, static_x, static_noise), dev, warmup=3)
+graph = GraphedTrainStep(lambda: _train_step(model_b, opt_b, static_x, static_noise), dev, warmup=3, allow_memset_nodes=args.plain_linear)
+print("captured graph: %s" % graph.nodes, flush=True)
 static_loss = graph.static_out
 # the capture executed nothing: the first replay is the step copies A and C take now
 graph()
