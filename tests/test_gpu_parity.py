@@ -1190,6 +1190,32 @@ def test_graphed_train_step_tracks_its_eager_twin():
         GraphedTrainStep(with_a_two_pass_sum, torch.device("cuda", 0))
 
 
+def test_rccl_backend_initialises_and_reduces_on_this_box():
+    """RCCL itself (backend "nccl"), as far as a 1-GPU box allows: a one-rank process group on cuda:0 — communicator
+    set-up, the all-reduce of the (sum NLL, count) pair this library's jobs perform, a barrier — in a process of its own
+    (several ranks need several GPUs: RCCL refuses two ranks on one device; the N-rank paths run over gloo above)."""
+    import subprocess, sys
+    code = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29677", rank=0, world_size=1)
+torch.cuda.set_device(0)
+from categoricalnf_amd.distributed import allreduce_nll
+t = torch.tensor([12.5, 4.0], dtype=torch.float64, device="cuda")
+dist.all_reduce(t)
+dist.barrier()
+mean, bpd = allreduce_nll(t.clone())
+assert t.tolist() == [12.5, 4.0] and abs(mean - 3.125) < 1e-12, (t, mean)
+print("RCCL OK", dist.get_backend(), torch.cuda.nccl.version())
+dist.destroy_process_group()
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "-c", code, root], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "RCCL OK nccl" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
 def test_bench_rehearses_eight_ranks_on_one_device():
     """The driver's first real 8-GPU run must not be the first 8-rank run: `python bench.py --gpus 8` as 8 processes
     sharing cuda:0 over gloo — rendezvous, per-rank rates, the all-reduce of the batch sums as the closing barrier —
