@@ -140,7 +140,12 @@ def graph_node_census(graph):
     import ctypes
     try:
         raw = int(graph.raw_cuda_graph())
-        hip = ctypes.CDLL("libamdhip64.so")          # the SONAME is loaded already: the same runtime torch captured with
+        # the runtime the process ALREADY runs on (the wheel's bundled libamdhip64, not whatever the loader path finds):
+        # the graph handle belongs to it
+        loaded = [line.split()[-1] for line in open("/proc/self/maps") if "libamdhip64" in line]
+        if not loaded:
+            return None
+        hip = ctypes.CDLL(loaded[0])
         count = ctypes.c_size_t(0)
         if hip.hipGraphGetNodes(ctypes.c_void_p(raw), None, ctypes.byref(count)) != 0:
             return None
