@@ -197,6 +197,23 @@ __global__ __launch_bounds__(kBlock) void affine_coupling_kernel(AffineArgs a, R
         if (NLL && a.length) my_len = a.length[myrow];
     }
 
+    // Batch sum (cnf_affine_coupling_nll_acc): the rows of a workgroup meet in ONE LDS word (integer adds of 31.32 fixed
+    // point: order-free), every wave draws an LDS ticket when it is through, and the wave that draws the last one sends the
+    // workgroup's total to the global accumulator with a single device-scope atomic.  Rounds 1-2 sent one global atomic per
+    // ROW: a wave does not retire before its atomic is acknowledged (~2 us away), so every wave slot stayed occupied that
+    // much longer — 18.3-18.5 us per launch against 17.1 us without the sum.  The only barrier is here, at the start, where
+    // all waves are starting anyway (the per-workgroup reduction of round 1, 19.4 us, had two at the END).
+    __shared__ unsigned long long wg_sum;
+    __shared__ unsigned int wg_tickets;
+    const bool wg_acc = NLL && a.acc != nullptr && !tl.bpr;
+    if (wg_acc) {
+        if (threadIdx.x == 0) {
+            wg_sum = 0ull;
+            wg_tickets = 0u;
+        }
+        __syncthreads();
+    }
+
     bool bad = false;
     auto load = [&](int row, int e0) {
         const size_t off = (size_t)row * a.L + e0;
@@ -258,9 +275,11 @@ __global__ __launch_bounds__(kBlock) void affine_coupling_kernel(AffineArgs a, R
             // result does not depend on the order the rows arrive in) into one of 64 words that sit in 64 different
             // cache lines: 256 atomics per line for B = 16384, hidden behind the streaming (64 ADJACENT words, i.e.
             // four lines, serialised them: 55 us per launch)
-            if (a.acc)
-                atomicAdd(reinterpret_cast<unsigned long long*>(a.acc) + (size_t)(row & 63) * kAccStride,
-                          (unsigned long long)__double2ll_rn((double)nll * 4294967296.0));
+            if (a.acc) {
+                const unsigned long long fix = (unsigned long long)__double2ll_rn((double)nll * 4294967296.0);
+                if (wg_acc) __hip_atomic_fetch_add(&wg_sum, fix, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // LDS
+                else atomicAdd(reinterpret_cast<unsigned long long*>(a.acc) + (size_t)(row & 63) * kAccStride, fix);
+            }
         } else {
             ldj_of(row, sum, base);
         }
@@ -271,6 +290,16 @@ __global__ __launch_bounds__(kBlock) void affine_coupling_kernel(AffineArgs a, R
         else emit(row, sum, a.ldj_in ? a.ldj_in[row] : 0.f, (NLL && a.length) ? a.length[row] : (float)a.N);
     };
     walk_row_tile_split<(U == 0 ? 1 : U), Acc, AffineChunk<VEC>, U == 0>(tl, part, load, proc, finish, pre);
+    if (wg_acc) {
+        // every wave comes through here, with or without a tile; its rows' LDS adds precede its ticket in program order
+        wave_lds_sync();
+        if ((threadIdx.x & 63) == 0 &&
+            __hip_atomic_fetch_add(&wg_tickets, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == kWavesPerBlock - 1) {
+            const unsigned long long total = __hip_atomic_load(&wg_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (total != 0ull)
+                atomicAdd(reinterpret_cast<unsigned long long*>(a.acc) + (size_t)(blockIdx.x & 63) * kAccStride, total);
+        }
+    }
     if (bad) raise_flag(a.flags, CNF_FLAG_NAN_Z);
 }
 

@@ -296,8 +296,10 @@ int cnf_affine_coupling_nll(const float* z, const float* nn_out, const float* sc
                             int* flags, cnf_stream_t stream);
 
 /* The same with the batch sum taken INSIDE the kernel: every row adds nll[b] * 2^32 (rounded, signed 64-bit fixed point)
- * with one integer atomic to one of 64 words — integer adds are associative, so the sum is deterministic; the 64
- * words sit 128 bytes apart (one cache line each) so that the atomics hide behind the streaming.  `acc` =
+ * to a word in LDS, and the last wave of a workgroup to finish (LDS ticket) sends the workgroup's total with ONE integer
+ * atomic to one of 64 global words — integer adds are associative, so the sum is deterministic; the 64 words sit 128
+ * bytes apart (one cache line each).  (One global atomic per ROW, rounds 1-2, kept every wave slot occupied until its
+ * atomic was acknowledged: 18.3 -> 17.9 us per launch at B = 16384, N = 64, D = 6.)  `acc` =
  * CNF_NLL_ACC_WORDS int64 (only every 16th is used), zeroed by the caller; it may be accumulated over several calls
  * (|sum| < 2^31).  cnf_nll_acc_read turns n such words into sums = {sum / 2^32, count}. */
 #define CNF_NLL_ACC_WORDS 1024
