@@ -688,21 +688,23 @@ bool make_tok_geom(const MixArgs& a, int kt, int force_g, TokGeom& gm, int& G, s
 }
 
 // Mixtures per lane (KT) and lanes per item (G) for a run-time K that has no exact instantiation, from the
-// instantiated pairs with KT * G >= K.  A launch that fills the chip costs ~ KT * G per item (slots past K are executed
-// with weight zero), one that does not costs ~ KT (the length of a lane's chain): `items` transformed elements on
-// `G * items / 64` waves against the ~4096 waves the chip holds at the 4 waves per SIMD these kernels reach.
-// (B = 1024, N = 64, D = 4, K = 10: 13 slots on one lane 15.7 / 23.1 us forward / inverse, the rolled loop on 4 lanes
-// 11.6 / 19.3.)  kt = 0: none (rolled loop).
-static void slots_for(int K, long items, int& kt, int& g) {
-    static const int pairs[9][2] = {{7, 1}, {13, 1}, {16, 1}, {7, 2}, {13, 2}, {16, 2}, {7, 4}, {13, 4}, {16, 4}};
+// instantiated pairs with KT * G >= K — a function of K ONLY, so that a sample's result does not depend on the batch it
+// sits in (the order in which the G partial sums of an item are combined follows G).  A launch that fills the chip costs
+// ~ KT * G per item (slots past K are executed with weight zero), one that does not costs ~ KT (the length of a lane's
+// chain): the smallest capacity wins, and among the pairs within 15 % of it the one with the most lanes per item
+// (K = 10: 7 x 2 rather than 13 x 1 — at B = 1024, N = 64, D = 4 that is 11.8 / 13.1 us forward / inverse against
+// 15.7 / 23.1).  kt = 0: none (rolled loop).
+static void slots_for(int K, int& kt, int& g) {
+    static const int pairs[7][2] = {{7, 1}, {16, 1}, {7, 2}, {16, 2}, {7, 4}, {13, 4}, {16, 4}};
     kt = 0; g = 0;
-    double best = 1e300;
+    int smallest = 1 << 30;
+    for (const auto& pr : pairs)
+        if (pr[0] * pr[1] >= K) smallest = std::min(smallest, pr[0] * pr[1]);
     for (const auto& pr : pairs) {
-        if (pr[0] * pr[1] < K) continue;
-        const double waves = (double)items * pr[1] / 64.0;
-        const double cost = pr[0] * std::max(1.0, waves / 4096.0) * (1.0 + 1e-3 * pr[0] * pr[1]);     // ties: less waste
-        if (cost < best) {
-            best = cost; kt = pr[0]; g = pr[1];
+        const int cap = pr[0] * pr[1];
+        if (cap < K || cap * 100 > smallest * 115) continue;
+        if (pr[1] > g || (pr[1] == g && cap < kt * g)) {
+            kt = pr[0]; g = pr[1];
         }
     }
 }
@@ -732,10 +734,8 @@ static TokKernel tok_kernel_for(const MixArgs& a, int kt, int slot_g, int G, boo
     if (slot_g > 0) {
         switch (kt * 8 + slot_g) {
             case 7 * 8 + 1: return tok_variant<7, 1, true>(a, nll);
-            case 13 * 8 + 1: return tok_variant<13, 1, true>(a, nll);
             case 16 * 8 + 1: return tok_variant<16, 1, true>(a, nll);
             case 7 * 8 + 2: return tok_variant<7, 2, true>(a, nll);
-            case 13 * 8 + 2: return tok_variant<13, 2, true>(a, nll);
             case 16 * 8 + 2: return tok_variant<16, 2, true>(a, nll);
             case 7 * 8 + 4: return tok_variant<7, 4, true>(a, nll);
             case 13 * 8 + 4: return tok_variant<13, 4, true>(a, nll);
@@ -783,7 +783,7 @@ bool launch_mixture_tok(MixArgs& a, hipStream_t st, int force_g) {
     // every other K: predicated register slots (force_g > 0, the sweep / test knob, keeps the rolled-loop kernel and
     // its lanes per item; the epilogue kernels exist for one lane per item only)
     int slot_g = 0;
-    if (kt == 0 && force_g == 0 && !a.e_w) slots_for(a.K, (long)a.B * a.N * a.DA, kt, slot_g);
+    if (kt == 0 && force_g == 0 && !a.e_w) slots_for(a.K, kt, slot_g);
     TokGeom gm;
     int G = 1;
     size_t lds = 0;

@@ -202,6 +202,27 @@ def test_whole_token_staging_is_bit_identical_to_span_staging(B, N, D, K, kind):
     assert rel_ll(outs[0][1], lo) < 1e-4
 
 
+@pytest.mark.parametrize("N,D,K,kind", [(64, 4, 10, "channel"), (288, 3, 51, "none"), (256, 3, 27, "none"), (38, 6, 16, "channel"),
+                                        (20, 2, 8, "channel")])
+def test_a_samples_result_does_not_depend_on_its_batch(N, D, K, kind):
+    """The lanes-per-item / slots-per-lane choice of a run-time K is a function of K only and split rows meet in integer
+    sums, so the latents of a sample are BIT-identical whether it is transformed alone, in a training-sized batch (rows
+    split over workgroups) or in a large one (whole rows per wave), forward and inverse; its log-det to fp32 rounding of
+    the row sum (the split and whole-row paths add the same terms in different groupings)."""
+    big = 4096 if N * D <= 256 else 600
+    z, nn_out, sf, msf, mask, ln, pad = _case(big, N, D, K, kind, 77 + N + K, padded=False)
+    gk = dict(scaling_factor=g(sf), mixture_scaling_factor=g(msf))
+    zb, lb, _ = ops().mixture_coupling(g(z), g(nn_out), g(mask), K, **gk)
+    zrb, lrb, _ = ops().mixture_coupling(zb, g(nn_out), g(mask), K, reverse=True, **gk)
+    for b in (1, 3, 64):
+        zs, ls, _ = ops().mixture_coupling(g(z[:b]), g(nn_out[:b]), g(mask), K, **gk)
+        assert torch.equal(zs, zb[:b])
+        close(ls, lb[:b], rtol=2e-6, atol=2e-5)
+        zr, lr, _ = ops().mixture_coupling(zb[:b].contiguous(), g(nn_out[:b]), g(mask), K, reverse=True, **gk)
+        assert torch.equal(zr, zrb[:b])
+        close(lr, lrb[:b], rtol=2e-6, atol=2e-5)
+
+
 @pytest.mark.parametrize("B,N,D,K,kind", SHAPES)
 def test_mixture_nll_epilogue_equals_coupling_then_prior_nll(B, N, D, K, kind):
     """cnf_mixture_coupling_nll == cnf_mixture_coupling followed by cnf_prior_nll on its outputs (z', ldj bit-equal;
