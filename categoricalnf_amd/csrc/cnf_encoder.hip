@@ -45,9 +45,10 @@ __device__ __forceinline__ float logistic_logp0(float x, float sigma, float log_
 }
 
 // LDS layout per class (stride 6D+3, odd -> no bank conflicts):
-//   [bias D | ts D | e^ts D | e^-ts D | (A, C) pairs 2D | sum_ts | cst2 | -],
+//   [bias D | ts D | e^ts D | e^-ts D | (A, C) pairs 2D | sum_ts | cst2 | E],
 //   A = e^-ts log2e / sigma,  C = bias log2e / sigma  so that |z_back / sigma| log2e = |z A - C| is one FMA per
-//   (class, channel);  cst2 = (prior - sum_ts - D log_sigma) log2e = the class score's constant in base-2 units.
+//   (class, channel);  cst2 = (prior - sum_ts - D log_sigma) log2e = the class score's constant in base-2 units;
+//   E = 2^cst2 = the same constant as a FACTOR (the forward's posterior sums densities, see class_density).
 __device__ __forceinline__ int class_stride(int D) { return 6 * D + 3; }
 __device__ __forceinline__ void build_class_table(const EncArgs& a, float* tab) {
     const int stride = class_stride(a.D);
@@ -71,7 +72,9 @@ __device__ __forceinline__ void build_class_table(const EncArgs& a, float* tab) 
         float s = 0.f;
         for (int d = 0; d < a.D; ++d) s += t[a.D + d];
         t[6 * a.D] = s;
-        t[6 * a.D + 1] = ((a.prior[c] - s) - (float)a.D * a.log_sigma) * kLog2e;
+        const float cst2 = ((a.prior[c] - s) - (float)a.D * a.log_sigma) * kLog2e;
+        t[6 * a.D + 1] = cst2;
+        t[6 * a.D + 2] = __builtin_amdgcn_exp2f(cst2);
     }
     __syncthreads();
 }
@@ -94,6 +97,45 @@ __device__ __forceinline__ float class_score2(const float* t, const float* z, in
 }
 
 constexpr int kEncMaxD = 16;
+
+// ---- the forward's posterior as a sum of DENSITIES (round 3) -----------------------------------------------------------
+// class_prob_log = log_point - LSE_j(score_j) with the true class's entry replaced by the forward value log_point
+// (linear_encoding.py:163-171), i.e.  -log(1 + sum_{j != c} e^{score_j - log_point}).  With q_jd = 2^-vs_jd the summand is
+//   e^{score_j} = E_j prod_d q_jd / (prod_d (1 + q_jd))^2,      E_j = 2^cst2_j   (a logistic density is q / (sigma (1 + q)^2)),
+// so the per-class work is the D exponentials the score needs anyway, two running products and ONE reciprocal: no
+// logarithm per class and no exponential per class for the log-sum-exp (the streamed LSE spent 8.25 transcendental
+// instructions per class at D = 6, this form 7, and 3 fewer plain ones; calibrated cost 118 -> 102 cycles per class and
+// token).  Range: every summand is >= 0 and the true class contributes exactly 1, so an underflowing product only drops
+// terms below 2^-126 / F of the total; F = 2^-lp2 (or F * sum) overflows only for a token whose own density is below
+// ~2^-100 — the caller checks the total and takes the streamed log-sum-exp (lse2_of_classes) for such a token.
+template <int DT>
+__device__ __forceinline__ float class_density(const float* t, const float* z, int D) {
+    float num = t[6 * D + 2], den = 1.f;
+    const int DD = DT > 0 ? DT : D;
+#pragma unroll
+    for (int d = 0; d < DD; ++d) {
+        const float q = __builtin_amdgcn_exp2f(-fabsf(fmaf(z[d], t[4 * D + 2 * d], -t[4 * D + 2 * d + 1])));
+        num *= q;
+        den = fmaf(den, q, den);
+    }
+    const float r = __builtin_amdgcn_rcpf(den);
+    return (num * r) * r;
+}
+// the cold path: base-2 log-sum-exp over the classes, the true class `c` at the forward value lp2 (the loop every token
+// took in rounds 1-2); rolled, so that it adds no registers to its callers
+template <int DT>
+__device__ __forceinline__ float lse2_of_classes(const float* tab, int stride, const float* z, int D, int C, int c, float lp2) {
+    float m = -3e38f, s = 0.f;
+#pragma clang loop unroll(disable)
+    for (int j = 0; j < C; ++j) {
+        const float sc = class_score2<DT>(tab + j * stride, z, D);
+        const float v = j == c ? lp2 : sc;
+        const float mn = fmaxf(m, v);
+        s = fmaf(s, __builtin_amdgcn_exp2f(m - mn), __builtin_amdgcn_exp2f(v - mn));
+        m = mn;
+    }
+    return m + __builtin_amdgcn_logf(s);
+}
 
 template <int DT>
 __global__ __launch_bounds__(kBlock) void encoder_forward_kernel(EncArgs a, RowTiling tl) {
@@ -128,36 +170,23 @@ __global__ __launch_bounds__(kBlock) void encoder_forward_kernel(EncArgs a, RowT
         const float init_lp = -(kLn2 * fmaf(2.f, __builtin_amdgcn_logf(nprod), nacc) + (float)D * a.log_sigma);
         const float ldj_f = tc[6 * D];
         const float log_point = (init_lp - ldj_f) + a.prior[c];
-        // streamed base-2 log-sum-exp over the classes, branch-free (every lane scores every class, the true
-        // class then takes the forward value, :167-168)
         const float lp2 = log_point * kLog2e;
-        float m = -3e38f, s = 0.f;
-        int j = 0;
-#ifndef CNF_ENC_NO_BLOCK_LSE
-        // four classes per update of the running (max, sum): 5 exp2 per 4 classes instead of 8, and four independent
-        // score chains for the scheduler
-        for (; j + 4 <= a.C; j += 4) {
-            float v[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float sc = class_score2<DT>(tab + (j + i) * stride, z, D);
-                v[i] = (j + i) == c ? lp2 : sc;
-            }
-            const float mn = fmaxf(m, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
-            const float blk = (__builtin_amdgcn_exp2f(v[0] - mn) + __builtin_amdgcn_exp2f(v[1] - mn)) +
-                              (__builtin_amdgcn_exp2f(v[2] - mn) + __builtin_amdgcn_exp2f(v[3] - mn));
-            s = fmaf(s, __builtin_amdgcn_exp2f(m - mn), blk);
-            m = mn;
+#ifdef CNF_ENC_LSE
+        // A/B build: the streamed log-sum-exp of rounds 1-2 for every token
+        const float cpl = (lp2 - lse2_of_classes<DT>(tab, stride, z, D, a.C, c, lp2)) * kLn2;
+#else
+        // densities of the other classes relative to the token's own (class_density above), branch-free: every lane
+        // scores every class and the true class's summand is dropped (it is the 1 of `tot`, :167-168)
+        float dsum = 0.f;
+        for (int j = 0; j < a.C; ++j) {
+            const float dj = class_density<DT>(tab + j * stride, z, D);
+            dsum += j == c ? 0.f : dj;
         }
+        const float tot = fmaf(__builtin_amdgcn_exp2f(-lp2), dsum, 1.f);
+        float cpl;
+        if (tot < 3e38f) cpl = -kLn2 * __builtin_amdgcn_logf(tot);
+        else cpl = (lp2 - lse2_of_classes<DT>(tab, stride, z, D, a.C, c, lp2)) * kLn2;       // overflow / NaN: log domain
 #endif
-        for (; j < a.C; ++j) {
-            const float sc = class_score2<DT>(tab + j * stride, z, D);
-            const float v = j == c ? lp2 : sc;
-            const float mn = fmaxf(m, v);
-            s = fmaf(s, __builtin_amdgcn_exp2f(m - mn), __builtin_amdgcn_exp2f(v - mn));
-            m = mn;
-        }
-        const float cpl = (lp2 - (m + __builtin_amdgcn_logf(s))) * kLn2;
         const float pv = a.pad ? a.pad[tok] : 1.f;
         if (a.cpl) a.cpl[tok] = cpl;
 #pragma unroll
@@ -261,7 +290,7 @@ struct PairIO {
 
 template <int D>
 struct PairTab {
-    static constexpr int S = (2 * D + 1 + 3) / 4 * 4;      // score constants per class: [A0 C0 ... A(D-1) C(D-1) cst2 pad]
+    static constexpr int S = (2 * D + 1 + 3) / 4 * 4;      // score constants per class: [A0 C0 ... A(D-1) C(D-1) cst2 E pad]; E = 2^cst2 (2D + 1 is odd: the slot exists)
     static constexpr int F = 3 * D + 2;                    // forward constants per class: [bias D | e^ts D | ts D | sum_ts | prior]
 };
 
@@ -304,7 +333,9 @@ __device__ __forceinline__ void pair_table_finish(const EncArgs& a, float* vt, f
         float s = 0.f;
         for (int d = 0; d < D; ++d) s += ft[c * F + TS + d];
         const float pr = a.prior[c];
-        vt[c * S + 2 * D] = ((pr - s) - (float)D * a.log_sigma) * kLog2e;
+        const float cst2 = ((pr - s) - (float)D * a.log_sigma) * kLog2e;
+        vt[c * S + 2 * D] = cst2;
+        vt[c * S + 2 * D + 1] = __builtin_amdgcn_exp2f(cst2);
         if (FWD) {
             ft[c * F + 3 * D] = s;
             ft[c * F + 3 * D + 1] = pr;
@@ -334,6 +365,53 @@ __device__ __forceinline__ void pair_score(const float4* vt4, int j, const float
         }
         sc[t] = k[2 * D] - fmaf(2.f, __builtin_amdgcn_logf(prod), acc);
     }
+}
+
+// densities of class j at both tokens of a pair (class_density's arithmetic on the 16-byte rows)
+template <int D>
+__device__ __forceinline__ void pair_density(const float4* vt4, int j, const float (&z)[2][D], float (&dn)[2]) {
+    constexpr int S = PairTab<D>::S;
+    float k[S];
+#pragma unroll
+    for (int q = 0; q < S / 4; ++q) {
+        const float4 v = vt4[j * (S / 4) + q];
+        k[4 * q] = v.x; k[4 * q + 1] = v.y; k[4 * q + 2] = v.z; k[4 * q + 3] = v.w;
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        float num = k[2 * D + 1], den = 1.f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const float q = __builtin_amdgcn_exp2f(-fabsf(fmaf(z[t][d], k[2 * d], -k[2 * d + 1])));
+            num *= q;
+            den = fmaf(den, q, den);
+        }
+        const float r = __builtin_amdgcn_rcpf(den);
+        dn[t] = (num * r) * r;
+    }
+}
+// cold path of the pair forward: streamed base-2 log-sum-exp of ONE token (lse2_of_classes on the 16-byte rows)
+template <int D>
+__device__ __forceinline__ float pair_lse2(const float* vt, const float (&z)[D], int C, int c, float lp2) {
+    constexpr int S = PairTab<D>::S;
+    float m = -3e38f, s = 0.f;
+#pragma clang loop unroll(disable)
+    for (int j = 0; j < C; ++j) {
+        const float* k = vt + j * S;
+        float acc = 0.f, prod = 1.f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const float vs = fabsf(fmaf(z[d], k[2 * d], -k[2 * d + 1]));
+            acc += vs;
+            prod = fmaf(prod, __builtin_amdgcn_exp2f(-vs), prod);
+        }
+        const float sc = k[2 * D] - fmaf(2.f, __builtin_amdgcn_logf(prod), acc);
+        const float v = j == c ? lp2 : sc;
+        const float mn = fmaxf(m, v);
+        s = fmaf(s, __builtin_amdgcn_exp2f(m - mn), __builtin_amdgcn_exp2f(v - mn));
+        m = mn;
+    }
+    return m + __builtin_amdgcn_logf(s);
 }
 
 // arg-max decode (linear_encoding.py:184-196): one tile of 128 consecutive tokens per wave, lane i owns tokens 2i, 2i+1
@@ -460,41 +538,26 @@ __global__ __launch_bounds__(kBlock) void encoder_forward_pair_kernel(EncArgs a,
             const float log_point = (init_lp[t] - ldj_f[t]) + tc[3 * D + 1];
             lp2[t] = log_point * kLog2e;
         }
-        // streamed base-2 log-sum-exp over the classes in blocks of four, as in encoder_forward_kernel
-        float m[2] = {-3e38f, -3e38f}, s[2] = {0.f, 0.f};
-        int j = 0;
-        for (; j + 4 <= a.C; j += 4) {
-            float v[4][2];
+        // the other classes' densities relative to the token's own, as in encoder_forward_kernel
+        float dsum[2] = {0.f, 0.f};
+#ifndef CNF_ENC_LSE
+        for (int j = 0; j < a.C; ++j) {
+            float dn[2];
+            pair_density<D>(vt4, j, z, dn);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                pair_score<D>(vt4, j + i, z, v[i]);
-#pragma unroll
-                for (int t = 0; t < 2; ++t) v[i][t] = (j + i) == c[t] ? lp2[t] : v[i][t];
-            }
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const float mn = fmaxf(m[t], fmaxf(fmaxf(v[0][t], v[1][t]), fmaxf(v[2][t], v[3][t])));
-                const float blk = (__builtin_amdgcn_exp2f(v[0][t] - mn) + __builtin_amdgcn_exp2f(v[1][t] - mn)) +
-                                  (__builtin_amdgcn_exp2f(v[2][t] - mn) + __builtin_amdgcn_exp2f(v[3][t] - mn));
-                s[t] = fmaf(s[t], __builtin_amdgcn_exp2f(m[t] - mn), blk);
-                m[t] = mn;
-            }
+            for (int t = 0; t < 2; ++t) dsum[t] += j == c[t] ? 0.f : dn[t];
         }
-        for (; j < a.C; ++j) {
-            float sc[2];
-            pair_score<D>(vt4, j, z, sc);
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const float v = j == c[t] ? lp2[t] : sc[t];
-                const float mn = fmaxf(m[t], v);
-                s[t] = fmaf(s[t], __builtin_amdgcn_exp2f(m[t] - mn), __builtin_amdgcn_exp2f(v - mn));
-                m[t] = mn;
-            }
-        }
+#endif
         float cpl[2], zo[2][D];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            cpl[t] = (lp2[t] - (m[t] + __builtin_amdgcn_logf(s[t]))) * kLn2;
+#ifdef CNF_ENC_LSE
+            const float tot = INFINITY;
+#else
+            const float tot = fmaf(__builtin_amdgcn_exp2f(-lp2[t]), dsum[t], 1.f);
+#endif
+            if (tot < 3e38f) cpl[t] = -kLn2 * __builtin_amdgcn_logf(tot);
+            else cpl[t] = (lp2[t] - pair_lse2<D>(vt, z[t], a.C, c[t], lp2[t])) * kLn2;      // overflow / NaN: log domain
 #pragma unroll
             for (int d = 0; d < D; ++d) {
                 zo[t][d] = z[t][d] * cur.pv[t];
@@ -547,8 +610,9 @@ static int g_encoder_kernel = 0;     // cnf_set_encoder_kernel: 0 = by measureme
 // materialises [T * C, 1, D] tensors for this (linear_encoding.py:155-160) — 13 GB per tensor at 32 k tokens and 10 k
 // classes; here nothing of that size exists.  Token log-det terms go to a [B * N] buffer; a second small kernel sums
 // the rows in a fixed order.
+__device__ __forceinline__ int chunk_stride(int D) { return 2 * D + 2; }     // [A0 C0 ... A(D-1) C(D-1) | cst2 | E = 2^cst2]
 __device__ __forceinline__ void build_class_chunk(const EncArgs& a, float* tab, int j0, int cc, int D) {
-    const int stride = 2 * D + 1;
+    const int stride = chunk_stride(D);
     const float k = kLog2e / a.sigma;
     for (int i = threadIdx.x; i < cc * D; i += blockDim.x) {
         const int c = i / D, d = i - c * D;
@@ -561,7 +625,9 @@ __device__ __forceinline__ void build_class_chunk(const EncArgs& a, float* tab, 
         const float* row = a.table + (size_t)(j0 + c) * 2 * D;
         float ssum = 0.f;
         for (int d = 0; d < D; ++d) ssum += tanhf(row[D + d]);
-        tab[c * stride + 2 * D] = ((a.prior[j0 + c] - ssum) - (float)D * a.log_sigma) * kLog2e;
+        const float cst2 = ((a.prior[j0 + c] - ssum) - (float)D * a.log_sigma) * kLog2e;
+        tab[c * stride + 2 * D] = cst2;
+        tab[c * stride + 2 * D + 1] = __builtin_amdgcn_exp2f(cst2);
     }
 }
 template <int DT>
@@ -576,18 +642,59 @@ __device__ __forceinline__ float chunk_score2(const float* t, const float* z, in
     }
     return t[2 * D] - fmaf(2.f, __builtin_amdgcn_logf(prod), acc);
 }
+// class_density on a chunk row
+template <int DT>
+__device__ __forceinline__ float chunk_density(const float* t, const float* z, int D) {
+    float num = t[2 * D + 1], den = 1.f;
+    const int DD = DT > 0 ? DT : D;
+#pragma unroll
+    for (int d = 0; d < DD; ++d) {
+        const float q = __builtin_amdgcn_exp2f(-fabsf(fmaf(z[d], t[2 * d], -t[2 * d + 1])));
+        num *= q;
+        den = fmaf(den, q, den);
+    }
+    const float r = __builtin_amdgcn_rcpf(den);
+    return (num * r) * r;
+}
+// Cold path of the tiled forward (a token whose density sum left the fp32 range, see class_density): the streamed base-2
+// log-sum-exp over ALL classes straight from the raw [C, 2D] table — no LDS chunk, no barrier, so a single lane can
+// take it; tanhf / expf per (class, channel) make it ~20x the cost of a chunk sweep, for tokens that essentially do
+// not occur (own density below ~2^-100).
+__device__ __noinline__ float lse2_from_raw_table(const float* table, const float* prior, const float* z, int D, int C, int c,
+                                                  float lp2, float sigma, float log_sigma) {
+    float m = -3e38f, s = 0.f;
+    const float k = kLog2e / sigma;
+    for (int j = 0; j < C; ++j) {
+        const float* row = table + (size_t)j * 2 * D;
+        float acc = 0.f, prod = 1.f, tsum = 0.f;
+        for (int d = 0; d < D; ++d) {
+            const float ts = tanhf(row[D + d]);
+            const float vs = fabsf(fmaf(z[d], expf(-ts) * k, -(row[d] * k)));
+            acc += vs;
+            prod = fmaf(prod, __builtin_amdgcn_exp2f(-vs), prod);
+            tsum += ts;
+        }
+        const float sc = ((prior[j] - tsum) - (float)D * log_sigma) * kLog2e - fmaf(2.f, __builtin_amdgcn_logf(prod), acc);
+        const float v = j == c ? lp2 : sc;
+        const float mn = fmaxf(m, v);
+        s = fmaf(s, __builtin_amdgcn_exp2f(m - mn), __builtin_amdgcn_exp2f(v - mn));
+        m = mn;
+    }
+    return m + __builtin_amdgcn_logf(s);
+}
 
 // PHASE 0: the whole class range and the epilogue in one kernel.  Very large vocabularies with moderate token counts
 // (10^4 classes x 10^4..10^5 tokens: 40-400 token workgroups) would leave most of the chip idle, so the class range is
-// also split over blockIdx.y: PHASE 1 sweeps one split and writes the token's partial (max, sum) / (best, arg-max) to
-// part[split][tok]; PHASE 2 (token lanes again, no class sweep) merges the partials in split order and runs the
-// epilogue.  The number of splits depends on C only, so a sample's result does not depend on the batch it is in.
+// also split over blockIdx.y: PHASE 1 sweeps one split and writes the token's partial (density sum, -) / (best, arg-max)
+// to part[split][tok]; PHASE 2 (token lanes again, no class sweep) merges the partials in split order and runs the
+// epilogue.  The forward sums the other classes' densities (class_density: absolute values, so the partials of the
+// splits simply add up) and scales by 2^-lp2 at the end.  The number of splits depends on C only, so a sample's result does not depend on the batch it is in.
 template <int DT, bool DECODE, int PHASE>
 __global__ __launch_bounds__(kBlock) void encoder_tiled_kernel(EncArgs a, long ntok, int CC, float* tok_ldj, float* part, int KS) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* tab = reinterpret_cast<float*>(smem);
     const int D = DT > 0 ? DT : a.D;
-    const int stride = 2 * D + 1;
+    const int stride = chunk_stride(D);
     bool bad = false;
     const int per = (a.C + KS - 1) / KS;
     const int j_lo = PHASE == 1 ? (int)blockIdx.y * per : 0;
@@ -625,7 +732,7 @@ __global__ __launch_bounds__(kBlock) void encoder_tiled_kernel(EncArgs a, long n
 #pragma unroll
             for (int d = 0; d < D; ++d) z[d] = 0.f;
         }
-        float m = -3e38f, ssum = 0.f, best = -INFINITY;
+        float dsum = 0.f, best = -INFINITY;
         int arg = 0;
         if (PHASE != 2) {
             bool first = true;
@@ -635,18 +742,16 @@ __global__ __launch_bounds__(kBlock) void encoder_tiled_kernel(EncArgs a, long n
                 build_class_chunk(a, tab, j0, cc, D);
                 __syncthreads();
                 for (int jj = 0; jj < cc; ++jj) {
-                    const float sc = chunk_score2<DT>(tab + jj * stride, z, D);
                     if (DECODE) {
+                        const float sc = chunk_score2<DT>(tab + jj * stride, z, D);
                         if (first || sc > best) {               // first maximum wins, like torch.argmax
                             best = sc;
                             arg = j0 + jj;
                             first = false;
                         }
                     } else {
-                        const float v = (j0 + jj) == c ? lp2 : sc;  // the true class takes the forward value (:167-168)
-                        const float mn = fmaxf(m, v);
-                        ssum = fmaf(ssum, __builtin_amdgcn_exp2f(m - mn), __builtin_amdgcn_exp2f(v - mn));
-                        m = mn;
+                        const float dj = chunk_density<DT>(tab + jj * stride, z, D);
+                        dsum += (j0 + jj) == c ? 0.f : dj;      // the true class is the 1 of the total (:167-168)
                     }
                 }
             }
@@ -659,23 +764,30 @@ __global__ __launch_bounds__(kBlock) void encoder_tiled_kernel(EncArgs a, long n
                         arg = __float_as_int(p1);
                     }
                 } else {
-                    const float mn = fmaxf(m, p0);
-                    ssum = fmaf(ssum, __builtin_amdgcn_exp2f(m - mn), p1 * __builtin_amdgcn_exp2f(p0 - mn));
-                    m = mn;
+                    dsum += p0;
                 }
             }
         }
         if (!live) continue;
         if (PHASE == 1) {
             float* o = part + ((size_t)blockIdx.y * ntok + tok) * 2;
-            o[0] = DECODE ? best : m;
-            o[1] = DECODE ? __int_as_float(arg) : ssum;
+            o[0] = DECODE ? best : dsum;
+            o[1] = DECODE ? __int_as_float(arg) : 0.f;
             continue;
         }
         if (DECODE) {
             a.categ_out[tok] = (int64_t)arg;
         } else {
-            const float cpl = (lp2 - (m + __builtin_amdgcn_logf(ssum))) * kLn2;
+            const float tot = fmaf(__builtin_amdgcn_exp2f(-lp2), dsum, 1.f);
+            float cpl;
+            if (tot < 3e38f) cpl = -kLn2 * __builtin_amdgcn_logf(tot);
+            else {
+                // a copy goes to the callee (scratch memory): the latents themselves stay in registers for the sweep
+                float zc[DT > 0 ? DT : kEncMaxD];
+#pragma unroll
+                for (int d = 0; d < (DT > 0 ? DT : kEncMaxD); ++d) zc[d] = z[d];
+                cpl = (lp2 - lse2_from_raw_table(a.table, a.prior, zc, D, a.C, c, lp2, a.sigma, a.log_sigma)) * kLn2;
+            }
             const float pv = a.pad ? a.pad[tok] : 1.f;
             if (a.cpl) a.cpl[tok] = cpl;
 #pragma unroll
@@ -745,7 +857,7 @@ __global__ __launch_bounds__(kBlock) void encoder_bwd_token_kernel(EncBwdTiledAr
     float* tab = reinterpret_cast<float*>(smem);
     const int D = DT > 0 ? DT : b.D;
     constexpr int DM = DT > 0 ? DT : kEncMaxD;
-    const int stride = 2 * D + 1, R = 3 * D + 3;
+    const int stride = chunk_stride(D), R = 3 * D + 3;
     EncArgs a = {};
     a.table = b.table; a.prior = b.prior; a.D = D; a.C = b.C; a.sigma = b.sigma; a.log_sigma = b.log_sigma;
     const int per = (b.C + KS - 1) / KS;
@@ -1090,7 +1202,7 @@ int cnf_encoder_decode(const float* z, const float* table, const float* category
     return launch_status("cnf_encoder_decode");
 }
 
-static int tiled_chunk_classes(int D) { return std::max(1, (int)(32768 / ((2 * D + 1) * sizeof(float)))); }
+static int tiled_chunk_classes(int D) { return std::max(1, (int)(32768 / ((2 * D + 2) * sizeof(float)))); }
 
 // class splits of the token-lane kernels: a function of C only (see encoder_tiled_kernel), no empty split
 static int tiled_class_splits(int C) {
@@ -1121,7 +1233,7 @@ int cnf_encoder_forward_tiled(const int64_t* categ, const float* eps, const floa
     a.B = B; a.N = N; a.D = D; a.C = C; a.beta = beta; a.sigma = sigma; a.log_sigma = log_sigma;
     const long ntok = (long)B * N;
     const int CC = std::min(C, tiled_chunk_classes(D));
-    const size_t smem = (size_t)CC * (2 * D + 1) * sizeof(float);
+    const size_t smem = (size_t)CC * (2 * D + 2) * sizeof(float);
     const int grid = (int)std::min<long>((ntok + kBlock - 1) / kBlock, 256 * 8);
     hipStream_t st = (hipStream_t)stream;
     const int KS = tiled_class_splits(C);
@@ -1152,7 +1264,7 @@ int cnf_encoder_decode_tiled(const float* z, const float* table, const float* ca
     a.B = B; a.N = N; a.D = D; a.C = C; a.sigma = sigma; a.log_sigma = log_sigma;
     const long ntok = (long)B * N;
     const int CC = std::min(C, tiled_chunk_classes(D));
-    const size_t smem = (size_t)CC * (2 * D + 1) * sizeof(float);
+    const size_t smem = (size_t)CC * (2 * D + 2) * sizeof(float);
     const int grid = (int)std::min<long>((ntok + kBlock - 1) / kBlock, 256 * 8);
     hipStream_t st = (hipStream_t)stream;
     const int KS = tiled_class_splits(C);
@@ -1205,7 +1317,7 @@ int cnf_encoder_forward_bwd_tiled(const int64_t* categ, const float* eps, const 
     b.partials = workspace + (size_t)b.ntok * (3 * D + 3);
     hipStream_t st = (hipStream_t)stream;
     const int CC = std::min(C, tiled_chunk_classes(D));
-    const size_t smem_a = (size_t)CC * (2 * D + 1) * sizeof(float);
+    const size_t smem_a = (size_t)CC * (2 * D + 2) * sizeof(float);
     const int grid_a = (int)std::min<long>((b.ntok + kBlock - 1) / kBlock, 256 * 8);
     const int KS = tiled_class_splits(C);
     float* part = b.partials + (size_t)b.S * C * 2 * D;

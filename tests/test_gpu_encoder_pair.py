@@ -129,3 +129,57 @@ def test_automatic_selection_takes_the_pair_forward_from_24_classes_on():
         z, _, _ = ops.encoder_forward(categ, eps, table, prior, tiled=False)
         ops.encoder_decode(z, table, prior, tiled=False)
         assert lib.cnf_encoder_pair_launches() - n0 == expect
+
+
+def _oracle64(categ, eps, table, prior, beta, pad):
+    """the oracle's encoder forward on float64 copies of the inputs (linear_encoding.py:59-133,153-174): the reference
+    value the fp32 kernels are held to in the extreme cases below, where fp32 torch itself is at its limits"""
+    from oracle import cnf_oracle as O
+    B, N = categ.shape
+    D = eps.shape[-1]
+    return O.encoder_forward(categ.cpu(), eps.double().cpu().reshape(B * N, 1, D), table.double().cpu(), prior.double().cpu(),
+                             beta=beta, channel_padding_mask=None if pad is None else pad.double().cpu())
+
+
+@pytest.mark.parametrize("B,N,D,C,which", [(2048, 16, 6, 16, 1), (2048, 16, 6, 16, 2), (2048, 16, 8, 32, 2), (512, 8, 16, 12, 1),
+                                           (512, 8, 12, 7, 1), (2050, 6, 4, 51, 2)])
+def test_forward_density_sum_and_its_log_domain_fallback(B, N, D, C, which):
+    """Round 3's forward sums class DENSITIES relative to the token's own (cnf_encoder.hip: class_density) instead of
+    streaming a log-sum-exp; a token whose own density is so small that 2^-lp2 (or its product with the sum) leaves the
+    fp32 range takes the log-domain loop.  Inputs: ordinary tokens, tokens with every noise channel at the prior's clamp
+    (|eps| = 5.47, the far tail), class tables with far-apart means and a prior with nearly impossible classes
+    (log-prior -120: own density ~2^-170 and below).  class_prob_log, latents and per-sample log-det against the
+    float64 oracle, at the literal 1e-4 bar; both kernels (one / two tokens per lane) must give the same bits."""
+    lib, ops = _setup()
+    dev = torch.device("cuda:0")
+    categ, eps, table, prior, pad, ldj = _inputs(B, N, D, C, 31 + D + C, 1, dev)
+    g = torch.Generator(device=dev).manual_seed(5)
+    eps = eps.reshape(B, N, D).clone()
+    tail = 9.903487 / 1.81
+    eps[: B // 4] = tail * torch.sign(torch.randn(B // 4, N, D, generator=g, device=dev))       # every channel at the clamp
+    table = table.clone()
+    table[:, :D] *= 6.0                                                                           # class means far apart
+    prior = prior.clone()
+    prior[::3] = -120.0                                                                           # nearly impossible classes
+    eps = eps.reshape(B * N, D).contiguous()
+    out = {}
+    for k in (1, which):
+        lib.cnf_set_encoder_kernel(k)
+        try:
+            out[k] = ops.encoder_forward(categ, eps, table, prior, beta=1.3, channel_padding_mask=pad, ldj=ldj,
+                                         want_class_prob=True, tiled=False)
+            torch.cuda.synchronize()
+        finally:
+            lib.cnf_set_encoder_kernel(0)
+    z, l, cpl = out[which]
+    for a, b in zip(out[1], out[which]):
+        assert torch.equal(a, b)
+    zo, lo, co = _oracle64(categ, eps, table, prior, 1.3, pad)
+    assert torch.isfinite(cpl).all() and torch.isfinite(l).all()
+    worst = ((cpl.double().cpu() - co).abs() / co.abs().clamp(min=1.0)).max().item()
+    assert worst <= 1e-4, worst
+    assert torch.allclose(z.double().cpu(), zo, rtol=2e-5, atol=2e-5)
+    ref = lo + ldj.double().cpu()
+    assert ((l.double().cpu() - ref).abs() / ref.abs().clamp(min=1.0)).max().item() <= 1e-4
+    # the extreme tokens did reach the fallback's territory: own log2-density below -127
+    assert float(co.min()) < -50.0
