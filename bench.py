@@ -220,15 +220,26 @@ def mixture_measure(ops, dev, R=4, reps=50):
 
 
 def kernel_sources_sha():
-    """sha256 over the kernel sources; profiles/traffic.json carries the same stamp (tools/pmc_summarize.py) and its
-    numbers are only reported while the sources they were measured on are the ones that are built."""
+    """sha256 over the sources the DOMINANT kernel is compiled from — cnf_affine.hip and the closure of its quoted
+    #includes (cnf_common.h, include/cnf_hip.h); profiles/traffic.json carries the same stamp (tools/pmc_summarize.py) and
+    its numbers are only reported while the sources they were measured on are the ones that are built.  (Until late
+    round 3 the stamp covered every file under csrc/, so an edit to the encoder or mixture kernels withdrew the affine
+    kernel's traffic figure although it cannot change it.)"""
     import hashlib
-    h = hashlib.sha256()
+    import re
     d = os.path.join(ROOT, "categoricalnf_amd", "csrc")
-    for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".h")):
-            h.update(name.encode())
-            h.update(open(os.path.join(d, name), "rb").read())
+    todo, seen = [os.path.join(d, "cnf_affine.hip")], []
+    while todo:
+        f = os.path.normpath(todo.pop())
+        if f in seen or not os.path.exists(f):
+            continue
+        seen.append(f)
+        for inc in re.findall(r'^\s*#include\s+"([^"]+)"', open(f).read(), flags=re.M):
+            todo.append(os.path.join(os.path.dirname(f), inc))
+    h = hashlib.sha256()
+    for f in sorted(seen):
+        h.update(os.path.relpath(f, ROOT).encode())
+        h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
 
 

@@ -598,7 +598,7 @@ __global__ __launch_bounds__(kBlock) void encoder_forward_pair_kernel(EncArgs a,
     }
 }
 
-static int g_encoder_kernel = 0;     // cnf_set_encoder_kernel: 0 = by measurement (below), 1 = round-2 kernels, 2 = pair kernels wherever eligible
+static int g_encoder_kernel = 0;     // cnf_set_encoder_kernel: 0 = by measurement (below: the one-token kernels), 1 = one-token kernels, 2 = pair kernels wherever eligible
 
 
 // ---- large vocabularies: the class table does not fit LDS, so it is walked in chunks ---------------------------------
@@ -1149,14 +1149,22 @@ int cnf_encoder_forward(const int64_t* categ, const float* eps, const float* tab
     a.categ = categ; a.eps = eps; a.table = table; a.prior = category_prior; a.pad = pad;
     a.ldj_in = ldj_in; a.z_out = z_out; a.ldj_out = ldj_out; a.cpl = class_prob_log; a.flags = flags;
     a.B = B; a.N = N; a.D = D; a.C = C; a.beta = beta; a.sigma = sigma; a.log_sigma = log_sigma;
-    const RowTiling tl = make_row_tiling(B, N, /*force_vec=*/1);
+    // Tokens per wave tile.  Interleaved runs on one MI355X after the density-sum loop (B=16384, N=64, D=6; us at tiles of
+    // 64 / 128 / 256 tokens): 3 classes 14.4 / 12.9 / 14.1, 9 classes 19.2 / 18.3 / 19.2, 16 classes 25.1 / 25.1 / 26.4,
+    // 32 classes 37.7 / 39.0 / 41.6, 51 classes 55.0 / 57.0 / 61.3 (rounds 1-3 used 256): one token per lane once the class
+    // loop dominates (16 384 waves: two rounds of eight per SIMD overlap their load and store phases), two below that.
+    // (The forced kernels of cnf_set_encoder_kernel(1 / 2) keep the 256-token tiles both were written for: the row sums'
+    // order follows the tiling, and those two are compared bit for bit.)
+    const RowTiling tl = make_row_tiling(B, N, /*force_vec=*/1, g_encoder_kernel != 0 ? 256 : (C >= 24 ? 64 : 128));
     // two tokens per lane (round 3) when every pair of a tile starts at an even token and the views are aligned
     const size_t va = (D % 2 == 0) ? 15 : 7;
     const size_t smem_pair = (size_t)kWavesPerBlock * kMaxTileChunks * sizeof(float) + pair_table_bytes(C, D, true);
-    // Interleaved A/B on one MI355X (profiles/r03_encoder_ab.txt, B=16384, N=64, D=6): 72.0 -> 68.0 us at 51 classes, 48.2 -> 46.8
-    // at 32, 29.8 -> 29.4 at 16, but 20.7 -> 22.0 at 9 and 14.1 -> 16.0 at 3 (the pair kernel's 127 VGPRs leave 4 waves per
-    // SIMD, which only pays once the class loop dominates): automatic selection from 24 classes on.
-    const bool want_pair = g_encoder_kernel == 2 || (g_encoder_kernel == 0 && C >= 24);
+    // The pair kernel won from 24 classes on while every token streamed a log-sum-exp (72.0 -> 68.0 us at 51 classes);
+    // with the density sum and the tiles above the one-token kernel is as fast or faster at every size measured (51 classes
+    // 55.0 vs 55.0, 32: 37.7 vs 37.8, 16: 25.1 vs 26.3, 9: 18.3 vs 20.7; D = 8, 16 classes: 29.3 vs 29.3), so the pair kernel
+    // is no longer selected automatically: it stays as the independent second implementation the bit-identity tests run
+    // against (cnf_set_encoder_kernel(2)).
+    const bool want_pair = g_encoder_kernel == 2;
     const bool pair = want_pair && pair_has_d(D) && !tl.bpr && tl.rw >= 2 && ((long)tl.rw * N) % 2 == 0 &&
                       smem_pair <= 64 * 1024 && aligned_to(eps, va) && aligned_to(z_out, va) && aligned_to(categ, 15) &&
                       aligned_to(pad, 7) && aligned_to(class_prob_log, 7);

@@ -596,11 +596,18 @@ def encoder_fused_supported(C, D):
     return D <= 16 and 4 * 512 * 4 + C * (6 * D + 3) * 4 <= 64 * 1024
 
 
-def encoder_prefers_tiled_forward(C, D):
-    """Forward pass: the class-tiled kernel when the LDS-resident table would not fit or would exceed ~9 KB (64 classes
-    at D = 6) — from there on the tiled kernel is faster (32.9 vs 36.2 us at 64 classes, 40.7 vs 77.9 at 160;
-    profiles/r02_encoder_probe.txt).  Decode keeps the LDS table whenever it fits (equal or slightly faster)."""
-    return not encoder_fused_supported(C, D) or C * (6 * D + 3) * 4 >= 9000
+def encoder_prefers_tiled_forward(C, D, B=None, N=None):
+    """Forward pass: the class-tiled kernel when the class table does not fit LDS, or — for a small batch of long rows
+    (fewer than 256 rows of at least 64 tokens: the LDS-resident kernel then runs one workgroup per row) — from ~9 KB of
+    table on.  Measured after round 3's density-sum loop and tile sizes (profiles/r03_encoder_lds_vs_tiled.txt; LDS-resident
+    vs tiled, us): 2048 x 64 tokens, D = 6: 30.6 vs 33.3 at 160 classes, 42.4 vs 47.1 at 256, 57.0 vs 62.2 at 350;
+    16384 x 16, D = 4: 36.5 vs 41.7 at 160, 73.4 vs 79.8 at 350; 128 x 288, D = 3: 17.0 vs 18.6 at 100 classes but 24.8
+    vs 20.9 at 160 and 70.4 vs 50.5 at 500; 64 x 703, D = 2: 27.7 vs 22.7 at 160.  (Round 2 switched at 9 KB for every
+    shape: its LDS-resident kernel streamed a log-sum-exp on 256-token tiles and lost from 64 classes on.)  Decode keeps
+    the LDS table whenever it fits (equal or slightly faster)."""
+    if not encoder_fused_supported(C, D):
+        return True
+    return B is not None and N is not None and B < 256 and N >= 64 and C * (6 * D + 3) * 4 >= 9000
 
 
 def encoder_forward(categ, eps, table, category_prior, beta=1.0, channel_padding_mask=None, ldj=None,
@@ -622,7 +629,7 @@ def encoder_forward(categ, eps, table, category_prior, beta=1.0, channel_padding
     z = torch.empty(B, N, D, dtype=torch.float32, device=dev)
     cpl = torch.empty(B * N, dtype=torch.float32, device=dev) if want_class_prob else None
     if tiled is None:
-        tiled = encoder_prefers_tiled_forward(C, D)
+        tiled = encoder_prefers_tiled_forward(C, D, B, N)
     if not tiled:
         _launch(dev, "cnf_encoder_forward", _ptr(categ), _ptr(eps), _ptr(table), _ptr(prior), _ptr(pad), float(beta),
                                            _ptr(ldj_in), _ptr(z), _ptr(ldj_out), _ptr(cpl), B, N, D, C, float(sigma),

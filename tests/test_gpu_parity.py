@@ -1608,11 +1608,13 @@ def test_class_split_encoder_results_do_not_depend_on_the_batch():
 @pytest.mark.parametrize("c", load_cases("encoder_large_vocab"))
 def test_encoder_large_vocab_golden(c):
     """The REFERENCE's encoder at 300 / 1100 / 1300 classes (tests/golden/encoder_large_vocab.npz): the drop-in module on
-    the class-tiled kernels (class splits above 1024) — latents, log-det (1e-4 relative), decoded classes bit-exact, and
-    the parameter gradients of the reference's autograd."""
+    the kernels its vocabulary selects — 300 classes at D = 6 still fit the LDS-resident forward (47 KB of class table,
+    the faster kernel there since round 3), 1100 / 1300 run on the class-tiled kernels with class splits — latents,
+    log-det (1e-4 relative), decoded classes bit-exact, and the parameter gradients of the reference's autograd (the
+    class-tiled backward at every size)."""
     from categoricalnf_amd.layers.categorical_encoding.linear_encoding import LinearCategoricalEncoding
     m = c.meta
-    assert ops().encoder_prefers_tiled_forward(m["C"], m["D"])
+    assert ops().encoder_prefers_tiled_forward(m["C"], m["D"]) == (m["C"] > 1000)
     enc = LinearCategoricalEncoding(num_dimensions=m["D"], flow_config={"num_flows": 0}, vocab_size=m["C"], default_embed_layer_dims=8)
     enc.load_state_dict({k[3:]: v for k, v in c.items() if k.startswith("sd_")})
     enc.cuda().eval()

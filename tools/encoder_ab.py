@@ -22,7 +22,7 @@ def steady(fn, reps=30, blocks=5):
     return float(np.median([m[b].elapsed_time(m[b + 1]) / reps * 1e3 for b in range(1, blocks)]))
 
 
-print("shape                      C | forward r2 -> r3 (us) | decode r2 -> r3 (us) | forward with class_prob_log r3")
+print("shape                      C | forward r2 -> r3 (us) | decode r2 -> r3 (us) | forward with class_prob_log r3 | forward, two tokens per lane forced")
 for (B, N, D), Cs in (((16384, 64, 6), (16, 3, 9, 32, 51)), ((16384, 16, 4), (16,)), ((16384, 64, 2), (2, 3)), ((16384, 64, 8), (16,))):
     for C in Cs:
         g = torch.Generator(device=dev).manual_seed(0)
@@ -40,6 +40,9 @@ for (B, N, D), Cs in (((16384, 64, 6), (16, 3, 9, 32, 51)), ((16384, 16, 4), (16
                 res.setdefault(which, []).append((f, d))
         lib.cnf_set_encoder_kernel(0)
         fc = steady(lambda: ops.encoder_forward(categ, eps, table, prior, want_class_prob=True, tiled=False))
+        lib.cnf_set_encoder_kernel(2)
+        fp = min(steady(lambda: ops.encoder_forward(categ, eps, table, prior, tiled=False)) for _ in range(2))
+        lib.cnf_set_encoder_kernel(0)
         r2 = np.min(np.array(res[1]), 0)
         r3 = np.min(np.array(res[0]), 0)
-        print("B=%5d N=%3d D=%d  C=%3d | %7.2f -> %7.2f | %7.2f -> %7.2f | %7.2f" % (B, N, D, C, r2[0], r3[0], r2[1], r3[1], fc), flush=True)
+        print("B=%5d N=%3d D=%d  C=%3d | %7.2f -> %7.2f | %7.2f -> %7.2f | %7.2f | %7.2f" % (B, N, D, C, r2[0], r3[0], r2[1], r3[1], fc, fp), flush=True)
