@@ -1,0 +1,76 @@
+// Shared by the encoder's translation units: cnf_encoder.hip (forward / decode, LDS-resident and class-tiled) and
+// cnf_encoder_bwd_tiled.hip (the class-tiled backward).  They are separate files because they are compiled with
+// different flags (Makefile: the forward / decode loops lose 3 of 26.5 plain instructions per class without the SLP
+// vectoriser, the backward kernels lose time without it).
+#pragma once
+#include "cnf_common.h"
+
+#include <algorithm>
+
+namespace cnf {
+
+struct EncArgs {
+    const int64_t* categ;
+    const float* eps;
+    const float* z_in;       // decode
+    const float* table;      // [C, 2D]
+    const float* prior;      // [C]
+    const float* pad;        // [B*N] or null
+    const float* ldj_in;
+    float* z_out;
+    float* ldj_out;
+    float* cpl;              // class_prob_log [B*N] or null
+    int64_t* categ_out;
+    int* flags;
+    int B, N, D, C;
+    float beta, sigma, log_sigma;
+};
+
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+constexpr int kEncMaxD = 16;
+
+// ---- class chunks of the tiled kernels (see cnf_encoder.hip: "large vocabularies") ----------------------------------
+__device__ __forceinline__ int chunk_stride(int D) { return 2 * D + 2; }     // [A0 C0 ... A(D-1) C(D-1) | cst2 | E = 2^cst2]
+__device__ __forceinline__ void build_class_chunk(const EncArgs& a, float* tab, int j0, int cc, int D) {
+    const int stride = chunk_stride(D);
+    const float k = kLog2e / a.sigma;
+    for (int i = threadIdx.x; i < cc * D; i += blockDim.x) {
+        const int c = i / D, d = i - c * D;
+        const float* row = a.table + (size_t)(j0 + c) * 2 * D;
+        const float ts = tanhf(row[D + d]);
+        tab[c * stride + 2 * d] = expf(-ts) * k;
+        tab[c * stride + 2 * d + 1] = row[d] * k;
+    }
+    for (int c = threadIdx.x; c < cc; c += blockDim.x) {
+        const float* row = a.table + (size_t)(j0 + c) * 2 * D;
+        float ssum = 0.f;
+        for (int d = 0; d < D; ++d) ssum += tanhf(row[D + d]);
+        const float cst2 = ((a.prior[j0 + c] - ssum) - (float)D * a.log_sigma) * kLog2e;
+        tab[c * stride + 2 * D] = cst2;
+        tab[c * stride + 2 * D + 1] = __builtin_amdgcn_exp2f(cst2);
+    }
+}
+
+}  // namespace cnf
+
+#define DISPATCH_D(D, CALL)                               \
+    switch (D) {                                          \
+        case 1: { constexpr int DT = 1; CALL; } break;    \
+        case 2: { constexpr int DT = 2; CALL; } break;    \
+        case 3: { constexpr int DT = 3; CALL; } break;    \
+        case 4: { constexpr int DT = 4; CALL; } break;    \
+        case 6: { constexpr int DT = 6; CALL; } break;    \
+        case 8: { constexpr int DT = 8; CALL; } break;    \
+        default: { constexpr int DT = 0; CALL; } break;   \
+    }
+
+static inline int tiled_chunk_classes(int D) { return std::max(1, (int)(32768 / ((2 * D + 2) * sizeof(float)))); }
+
+// class splits of the token-lane kernels: a function of C only (see encoder_tiled_kernel), no empty split
+static inline int tiled_class_splits(int C) {
+    if (C <= 1024) return 1;
+    const int ks = std::min(32, (C + 511) / 512);
+    const int per = (C + ks - 1) / ks;
+    return (C + per - 1) / per;
+}

@@ -7,32 +7,13 @@
 //   bias[c][d], ts = tanh(scale_raw), e^{ts}, e^{-ts}, sum_d ts.
 // The reference materialises [T*C, 1, D] tensors and runs an embedding + Linear for every class
 // (:155-160); here the C x D loop runs in registers and the log-sum-exp is streamed.
-#include "cnf_common.h"
+#include "cnf_encoder.h"
 
-#include <algorithm>
 #include <type_traits>
 
 namespace cnf {
 
-struct EncArgs {
-    const int64_t* categ;
-    const float* eps;
-    const float* z_in;       // decode
-    const float* table;      // [C, 2D]
-    const float* prior;      // [C]
-    const float* pad;        // [B*N] or null
-    const float* ldj_in;
-    float* z_out;
-    float* ldj_out;
-    float* cpl;              // class_prob_log [B*N] or null
-    int64_t* categ_out;
-    int* flags;
-    int B, N, D, C;
-    float beta, sigma, log_sigma;
-};
 
-constexpr float kLog2e = 1.4426950408889634f;
-constexpr float kLn2 = 0.6931471805599453f;
 
 // logistic log-density pieces in base-2 units so that the hardware exp2 / log2 are used directly:
 //   softplus(v) + softplus(-v) = |v| + 2 ln(1 + e^{-|v|}) = ln2 * (vs + 2 log2(1 + 2^{-vs})),  vs = |v| log2(e)
@@ -96,7 +77,6 @@ __device__ __forceinline__ float class_score2(const float* t, const float* z, in
     return t[6 * D + 1] - fmaf(2.f, __builtin_amdgcn_logf(prod), acc);
 }
 
-constexpr int kEncMaxD = 16;
 
 // ---- the forward's posterior as a sum of DENSITIES (round 3) -----------------------------------------------------------
 // class_prob_log = log_point - LSE_j(score_j) with the true class's entry replaced by the forward value log_point
@@ -610,26 +590,6 @@ static int g_encoder_kernel = 0;     // cnf_set_encoder_kernel: 0 = by measureme
 // materialises [T * C, 1, D] tensors for this (linear_encoding.py:155-160) — 13 GB per tensor at 32 k tokens and 10 k
 // classes; here nothing of that size exists.  Token log-det terms go to a [B * N] buffer; a second small kernel sums
 // the rows in a fixed order.
-__device__ __forceinline__ int chunk_stride(int D) { return 2 * D + 2; }     // [A0 C0 ... A(D-1) C(D-1) | cst2 | E = 2^cst2]
-__device__ __forceinline__ void build_class_chunk(const EncArgs& a, float* tab, int j0, int cc, int D) {
-    const int stride = chunk_stride(D);
-    const float k = kLog2e / a.sigma;
-    for (int i = threadIdx.x; i < cc * D; i += blockDim.x) {
-        const int c = i / D, d = i - c * D;
-        const float* row = a.table + (size_t)(j0 + c) * 2 * D;
-        const float ts = tanhf(row[D + d]);
-        tab[c * stride + 2 * d] = expf(-ts) * k;
-        tab[c * stride + 2 * d + 1] = row[d] * k;
-    }
-    for (int c = threadIdx.x; c < cc; c += blockDim.x) {
-        const float* row = a.table + (size_t)(j0 + c) * 2 * D;
-        float ssum = 0.f;
-        for (int d = 0; d < D; ++d) ssum += tanhf(row[D + d]);
-        const float cst2 = ((a.prior[j0 + c] - ssum) - (float)D * a.log_sigma) * kLog2e;
-        tab[c * stride + 2 * D] = cst2;
-        tab[c * stride + 2 * D + 1] = __builtin_amdgcn_exp2f(cst2);
-    }
-}
 template <int DT>
 __device__ __forceinline__ float chunk_score2(const float* t, const float* z, int D) {
     float acc = 0.f, prod = 1.f;
@@ -819,295 +779,12 @@ __global__ __launch_bounds__(kBlock) void encoder_row_sum_kernel(const float* to
 }
 
 
-// ---- backward for large vocabularies --------------------------------------------------------------------------------
-//
-// d loss / d table [C, 2D] of the forward above for tables beyond the LDS-resident backward kernel (2 C D > 2048).
-// The work is T x C x D in both directions, but the two reductions run across different axes, so there are two
-// kernels and neither needs a cross-lane reduction or a floating-point atomic:
-//   (1) token lanes (encoder_bwd_token_kernel): a lane owns a token and walks the class chunks ONCE, keeping the
-//       streamed log-sum-exp together with D accumulators sum_j w_j tanh(x_jd / 2 sigma) A_jd that are rescaled
-//       with it whenever the running maximum moves (w_j = 2^(v_j - max)); this gives the token's log-denominator and
-//       d loss / d z (the sum over all OTHER classes' reverse flows) in one sweep.  It writes one record per token:
-//       [z (D) | own-class gradient w.r.t. bias and tanh(scale) (2D) | log2 denominator | beta G | class].
-//   (2) class lanes (encoder_bwd_class_kernel): a lane owns a class (its 2D + 1 constants in registers) and walks a
-//       range of token records broadcast from LDS, accumulating its class's 2D gradient entries in registers; the
-//       lane whose class IS the token's class adds the record's own-class gradient instead.  Token ranges ("splits")
-//       give the launch enough workgroups; their partial tables are summed in split order by a third tiny kernel, so
-//       the result is bit-reproducible.
-// Notation as in cnf_encoder_bwd.hip: G = d loss / d ldj_tok (x pad), v_j the class scores, q = softmax(v).
-struct EncBwdTiledArgs {
-    const int64_t* categ;
-    const float* eps;
-    const float* table;
-    const float* prior;
-    const float* pad;
-    const float* g_zout;
-    const float* g_ldj;
-    float* rec;              // [T, 3D + 3]
-    float* partials;         // [S, C, 2D]
-    float* g_table;          // [C, 2D]
-    long ntok;
-    int N, D, C, S;
-    float beta, sigma, log_sigma;
-};
-
-template <int DT, int PHASE>      // PHASE as in encoder_tiled_kernel; a partial is (max, sum, D accumulators)
-__global__ __launch_bounds__(kBlock) void encoder_bwd_token_kernel(EncBwdTiledArgs b, int CC, float* part, int KS) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* tab = reinterpret_cast<float*>(smem);
-    const int D = DT > 0 ? DT : b.D;
-    constexpr int DM = DT > 0 ? DT : kEncMaxD;
-    const int stride = chunk_stride(D), R = 3 * D + 3;
-    EncArgs a = {};
-    a.table = b.table; a.prior = b.prior; a.D = D; a.C = b.C; a.sigma = b.sigma; a.log_sigma = b.log_sigma;
-    const int per = (b.C + KS - 1) / KS;
-    const int j_lo = PHASE == 1 ? (int)blockIdx.y * per : 0;
-    const int j_hi = PHASE == 1 ? min(b.C, j_lo + per) : b.C;
-    const int PS = 2 + D;
-    const long rounds = (b.ntok + kBlock - 1) / kBlock;
-    for (long r = blockIdx.x; r < rounds; r += gridDim.x) {
-        const long tok = r * kBlock + threadIdx.x;
-        const bool live = tok < b.ntok;
-        float z[DM], acc_g[DM], ets[DM];
-        int c = -1;
-        float lp2 = 0.f, G = 0.f, pv = 0.f;
-#pragma unroll
-        for (int d = 0; d < D; ++d) { z[d] = 0.f; acc_g[d] = 0.f; ets[d] = 1.f; }
-        if (live) {
-            const long long craw = b.categ[tok];        // range-checked (and reported) by the forward kernel
-            c = (int)(craw < 0 ? 0 : (craw >= b.C ? b.C - 1 : craw));
-            const float* row = b.table + (size_t)c * 2 * D;
-            float nacc = 0.f, nprod = 1.f, ldj_f = 0.f;
-            const float kn = kLog2e / b.sigma;
-#pragma unroll
-            for (int d = 0; d < D; ++d) {
-                const float e = b.eps[tok * D + d];
-                const float vs = fabsf(e) * kn;
-                nacc += vs;
-                nprod = fmaf(nprod, __builtin_amdgcn_exp2f(-vs), nprod);
-                const float ts = tanhf(row[D + d]);
-                ets[d] = expf(ts);
-                z[d] = (e + row[d]) * ets[d];
-                ldj_f += ts;
-            }
-            const float init_lp = -(kLn2 * fmaf(2.f, __builtin_amdgcn_logf(nprod), nacc) + (float)D * b.log_sigma);
-            lp2 = ((init_lp - ldj_f) + b.prior[c]) * kLog2e;
-            pv = b.pad ? b.pad[tok] : 1.f;
-            G = (b.g_ldj ? b.g_ldj[tok / b.N] : 0.f) * pv;
-        }
-        float m = -3e38f, ssum = 0.f;
-        if (PHASE != 2) {
-            for (int j0 = j_lo; j0 < j_hi; j0 += CC) {
-                const int cc = min(CC, j_hi - j0);
-                __syncthreads();
-                build_class_chunk(a, tab, j0, cc, D);
-                __syncthreads();
-                for (int jj = 0; jj < cc; ++jj) {
-                    const float* t = tab + jj * stride;
-                    float acc = 0.f, prod = 1.f, ta[DM];
-#pragma unroll
-                    for (int d = 0; d < D; ++d) {
-                        const float xk = fmaf(z[d], t[2 * d], -t[2 * d + 1]);
-                        const float vs = fabsf(xk);
-                        const float e = __builtin_amdgcn_exp2f(-vs);
-                        acc += vs;
-                        prod = fmaf(prod, e, prod);
-                        // tanh(x / 2 sigma) A = sign(x) (1 - e) / (1 + e) A
-                        ta[d] = copysignf((1.f - e) * __builtin_amdgcn_rcpf(1.f + e), xk) * t[2 * d];
-                    }
-                    const bool own = (j0 + jj) == c;
-                    const float v = own ? lp2 : t[2 * D] - fmaf(2.f, __builtin_amdgcn_logf(prod), acc);
-                    const float mn = fmaxf(m, v);
-                    const float scale = __builtin_amdgcn_exp2f(m - mn), w = __builtin_amdgcn_exp2f(v - mn);
-                    ssum = fmaf(ssum, scale, w);
-                    const float wg = own ? 0.f : w;
-#pragma unroll
-                    for (int d = 0; d < D; ++d) acc_g[d] = fmaf(acc_g[d], scale, wg * ta[d]);
-                    m = mn;
-                }
-            }
-        } else if (live) {
-            for (int k = 0; k < KS; ++k) {
-                const float* pk = part + ((size_t)k * b.ntok + tok) * PS;
-                const float mn = fmaxf(m, pk[0]);
-                const float scale = __builtin_amdgcn_exp2f(m - mn), w = __builtin_amdgcn_exp2f(pk[0] - mn);
-                ssum = fmaf(ssum, scale, pk[1] * w);
-#pragma unroll
-                for (int d = 0; d < D; ++d) acc_g[d] = fmaf(acc_g[d], scale, pk[2 + d] * w);
-                m = mn;
-            }
-        }
-        if (live && PHASE == 1) {
-            float* o = part + ((size_t)blockIdx.y * b.ntok + tok) * PS;
-            o[0] = m;
-            o[1] = ssum;
-#pragma unroll
-            for (int d = 0; d < D; ++d) o[2 + d] = acc_g[d];
-        }
-        if (PHASE == 1) continue;
-        if (!live) continue;
-        const float lse2 = m + __builtin_amdgcn_logf(ssum);
-        const float Gb = G * b.beta;
-        const float q_c = __builtin_amdgcn_exp2f(lp2 - lse2);
-        const float g_ldjf = G - Gb * (1.f - q_c);
-        const float norm = Gb * kLn2 / ssum;
-        float* rec = b.rec + (size_t)tok * R;
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const float gz = fmaf(norm, acc_g[d], (b.g_zout ? b.g_zout[tok * D + d] : 0.f) * pv);
-            rec[d] = z[d];
-            rec[D + d] = gz * ets[d];
-            rec[2 * D + d] = fmaf(gz, z[d], g_ldjf);
-        }
-        rec[3 * D] = lse2;
-        rec[3 * D + 1] = Gb;
-        rec[3 * D + 2] = __int_as_float(c);
-    }
-}
-
-constexpr int kEncBwdStage = 64;     // token records staged per barrier pair
-
-template <int DT>
-__global__ __launch_bounds__(kBlock) void encoder_bwd_class_kernel(EncBwdTiledArgs b, int cl_shift) {
-    // 256 lanes = CL class lanes x TL token lanes (CL = 2^cl_shift >= min(C, 256)): small vocabularies keep the whole
-    // workgroup busy by giving every class TL lanes that take every TL-th token record of a stage
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* stage = reinterpret_cast<float*>(smem);
-    const int D = DT > 0 ? DT : b.D;
-    constexpr int DM = DT > 0 ? DT : kEncMaxD;
-    const int R = 3 * D + 3;
-    const int CL = 1 << cl_shift, TL = kBlock >> cl_shift;
-    const int jl = threadIdx.x & (CL - 1), tl = threadIdx.x >> cl_shift;
-    const int j = blockIdx.x * CL + jl;
-    const bool live = j < b.C;
-    float A[DM], Cb[DM], gb[DM], gt[DM], dts[DM];
-    float cst2 = 0.f;
-    {
-        const float k = kLog2e / b.sigma;
-        float ssum = 0.f;
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const float* row = b.table + (size_t)(live ? j : 0) * 2 * D;
-            const float ts = tanhf(row[D + d]);
-            A[d] = expf(-ts) * k;
-            Cb[d] = row[d] * k;
-            dts[d] = 1.f - ts * ts;
-            ssum += ts;
-            gb[d] = 0.f;
-            gt[d] = 0.f;
-        }
-        cst2 = ((b.prior[live ? j : 0] - ssum) - (float)D * b.log_sigma) * kLog2e;
-    }
-    // token range of this split, in whole stages
-    const long per = ((b.ntok + b.S - 1) / b.S + kEncBwdStage - 1) / kEncBwdStage * kEncBwdStage;
-    const long t0 = (long)blockIdx.y * per, t1 = min(t0 + per, b.ntok);
-    const float inv_sigma = 1.f / b.sigma;
-    for (long ts0 = t0; ts0 < t1; ts0 += kEncBwdStage) {
-        const int nt = (int)min<long>(kEncBwdStage, t1 - ts0);
-        __syncthreads();
-        for (int i = threadIdx.x; i < nt * R; i += kBlock) stage[i] = b.rec[(size_t)ts0 * R + i];
-        __syncthreads();
-        if (!live) continue;
-        for (int t = tl; t < nt; t += TL) {
-            const float* rec = stage + t * R;            // one address per token lane: LDS broadcast within it
-            const int c = __float_as_int(rec[3 * D + 2]);
-            if (c == j) {                                // exactly one lane of the whole grid per token
-#pragma unroll
-                for (int d = 0; d < D; ++d) { gb[d] += rec[D + d]; gt[d] += rec[2 * D + d]; }
-                continue;
-            }
-            float acc = 0.f, prod = 1.f, th[DM];
-#pragma unroll
-            for (int d = 0; d < D; ++d) {
-                const float xk = fmaf(rec[d], A[d], -Cb[d]);
-                const float vs = fabsf(xk);
-                const float e = __builtin_amdgcn_exp2f(-vs);
-                acc += vs;
-                prod = fmaf(prod, e, prod);
-                th[d] = copysignf((1.f - e) * __builtin_amdgcn_rcpf(1.f + e), xk);      // tanh(x / 2 sigma)
-            }
-            const float v = cst2 - fmaf(2.f, __builtin_amdgcn_logf(prod), acc);
-            const float gv = -rec[3 * D + 1] * __builtin_amdgcn_exp2f(v - rec[3 * D]);  // d loss / d v_j = -beta G q_j
-#pragma unroll
-            for (int d = 0; d < D; ++d) {
-                // d v_j / d bias = tanh / sigma;  d v_j / d ts = tanh z e^{-ts} / sigma - 1  (A ln2 = e^{-ts} / sigma)
-                const float tg = th[d] * gv;
-                gb[d] = fmaf(tg, inv_sigma, gb[d]);
-                gt[d] += fmaf(tg * kLn2, rec[d] * A[d], -gv);
-            }
-        }
-    }
-    // combine the token lanes of a class in lane order, then through tanh to the raw scale
-    if (TL > 1) {
-        __syncthreads();
-        float* red = stage;                              // [TL][CL][2D]
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            red[((size_t)tl * CL + jl) * 2 * D + d] = gb[d];
-            red[((size_t)tl * CL + jl) * 2 * D + D + d] = gt[d];
-        }
-        __syncthreads();
-        if (tl == 0) {
-            for (int o = 1; o < TL; ++o) {
-#pragma unroll
-                for (int d = 0; d < D; ++d) {
-                    gb[d] += red[((size_t)o * CL + jl) * 2 * D + d];
-                    gt[d] += red[((size_t)o * CL + jl) * 2 * D + D + d];
-                }
-            }
-        }
-    }
-    if (!live || tl != 0) return;
-    float* out = b.partials + ((size_t)blockIdx.y * b.C + j) * 2 * D;
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-        out[d] = gb[d];
-        out[D + d] = gt[d] * dts[d];
-    }
-}
-
-// g_table[p] = sum over the splits, fixed order: a workgroup owns 16 table entries, 16 lanes per entry each add every
-// 16th split (fp64), then the 16 lane sums are combined in lane order.  (One lane per entry walking all S splits was
-// a chain of S dependent-latency loads: 380 us of the 430 us backward at S = 1024.)
-__global__ __launch_bounds__(kBlock) void encoder_bwd_splits_kernel(const float* partials, int S, long P, float* out) {
-    __shared__ double red[16][17];
-    const int pl = threadIdx.x & 15, sl = threadIdx.x >> 4;
-    const long p = (long)blockIdx.x * 16 + pl;
-    double acc = 0.0;
-    if (p < P) {
-        int s = sl;
-        for (; s + 48 < S; s += 64) {                   // four independent loads in flight per lane
-            const float v0 = partials[(size_t)s * P + p], v1 = partials[(size_t)(s + 16) * P + p];
-            const float v2 = partials[(size_t)(s + 32) * P + p], v3 = partials[(size_t)(s + 48) * P + p];
-            acc += (double)v0; acc += (double)v1; acc += (double)v2; acc += (double)v3;
-        }
-        for (; s < S; s += 16) acc += (double)partials[(size_t)s * P + p];
-    }
-    red[sl][pl] = acc;
-    __syncthreads();
-    if (sl == 0 && p < P) {
-        double t = 0.0;
-        for (int k = 0; k < 16; ++k) t += red[k][pl];
-        out[p] = (float)t;
-    }
-}
-
 }  // namespace cnf
 
 using namespace cnf;
 
 static size_t table_bytes(int C, int D) { return (size_t)C * (6 * D + 3) * sizeof(float); }
 
-#define DISPATCH_D(D, CALL)                               \
-    switch (D) {                                          \
-        case 1: { constexpr int DT = 1; CALL; } break;    \
-        case 2: { constexpr int DT = 2; CALL; } break;    \
-        case 3: { constexpr int DT = 3; CALL; } break;    \
-        case 4: { constexpr int DT = 4; CALL; } break;    \
-        case 6: { constexpr int DT = 6; CALL; } break;    \
-        case 8: { constexpr int DT = 8; CALL; } break;    \
-        default: { constexpr int DT = 0; CALL; } break;   \
-    }
 
 // ---- round-3 pair kernels: eligibility ---------------------------------------------------------------------------------
 static bool pair_has_d(int D) { return D == 1 || D == 2 || D == 3 || D == 4 || D == 6 || D == 8; }
@@ -1210,15 +887,7 @@ int cnf_encoder_decode(const float* z, const float* table, const float* category
     return launch_status("cnf_encoder_decode");
 }
 
-static int tiled_chunk_classes(int D) { return std::max(1, (int)(32768 / ((2 * D + 2) * sizeof(float)))); }
 
-// class splits of the token-lane kernels: a function of C only (see encoder_tiled_kernel), no empty split
-static int tiled_class_splits(int C) {
-    if (C <= 1024) return 1;
-    const int ks = std::min(32, (C + 511) / 512);
-    const int per = (C + ks - 1) / ks;
-    return (C + per - 1) / per;
-}
 
 int64_t cnf_encoder_workspace_floats(int B, int N, int D, int C) {
     (void)D;
@@ -1287,62 +956,6 @@ int cnf_encoder_decode_tiled(const float* z, const float* table, const float* ca
                                  (float*)nullptr, part, KS));
     }
     return launch_status("cnf_encoder_decode_tiled");
-}
-
-static int bwd_class_shift(int C) {
-    int sh = 0;
-    while ((1 << sh) < std::min(C, kBlock)) ++sh;
-    return sh;
-}
-static int bwd_tiled_splits(long ntok, int C) {
-    const int groups = (C + kBlock - 1) / kBlock;
-    const long by_tokens = std::max<long>(1, ntok / 256);           // at least 256 tokens per split
-    return (int)std::max<long>(1, std::min<long>(by_tokens, (1024 + groups - 1) / groups));
-}
-
-int64_t cnf_encoder_bwd_tiled_workspace_floats(int B, int N, int D, int C) {
-    const long ntok = (long)B * N;
-    const int ks = tiled_class_splits(C);
-    return (int64_t)ntok * (3 * D + 3) + (int64_t)bwd_tiled_splits(ntok, C) * C * 2 * D + (ks > 1 ? (int64_t)ks * ntok * (2 + D) : 0);
-}
-
-int cnf_encoder_forward_bwd_tiled(const int64_t* categ, const float* eps, const float* table,
-                                  const float* category_prior, const float* pad, float beta,
-                                  const float* g_zout, const float* g_ldj, float* g_table, float* workspace,
-                                  int B, int N, int D, int C, float sigma, float log_sigma, cnf_stream_t stream) {
-    CNF_REQUIRE(categ && eps && table && category_prior && g_table && workspace, "cnf_encoder_forward_bwd_tiled: null tensor");
-    CNF_REQUIRE(B >= 0 && N > 0 && D > 0 && C > 0 && D <= kEncMaxD, "cnf_encoder_forward_bwd_tiled: bad shape");
-    if (B == 0) {       // the forward accepts an empty batch; its gradient is a zero table
-        cnf::zero_fill_async(g_table, (size_t)C * 2 * D * sizeof(float), (hipStream_t)stream);
-        return launch_status("cnf_encoder_forward_bwd_tiled");
-    }
-    EncBwdTiledArgs b = {};
-    b.categ = categ; b.eps = eps; b.table = table; b.prior = category_prior; b.pad = pad;
-    b.g_zout = g_zout; b.g_ldj = g_ldj; b.g_table = g_table;
-    b.ntok = (long)B * N; b.N = N; b.D = D; b.C = C; b.beta = beta; b.sigma = sigma; b.log_sigma = log_sigma;
-    b.S = bwd_tiled_splits(b.ntok, C);
-    b.rec = workspace;
-    b.partials = workspace + (size_t)b.ntok * (3 * D + 3);
-    hipStream_t st = (hipStream_t)stream;
-    const int CC = std::min(C, tiled_chunk_classes(D));
-    const size_t smem_a = (size_t)CC * (2 * D + 2) * sizeof(float);
-    const int grid_a = (int)std::min<long>((b.ntok + kBlock - 1) / kBlock, 256 * 8);
-    const int KS = tiled_class_splits(C);
-    float* part = b.partials + (size_t)b.S * C * 2 * D;
-    if (KS == 1) {
-        DISPATCH_D(D, CNF_LAUNCH((encoder_bwd_token_kernel<DT, 0>), dim3(grid_a), dim3(kBlock), smem_a, st, b, CC, (float*)nullptr, 1));
-    } else {
-        DISPATCH_D(D, CNF_LAUNCH((encoder_bwd_token_kernel<DT, 1>), dim3(grid_a, KS), dim3(kBlock), smem_a, st, b, CC, part, KS));
-        DISPATCH_D(D, CNF_LAUNCH((encoder_bwd_token_kernel<DT, 2>), dim3(grid_a), dim3(kBlock), 0, st, b, CC, part, KS));
-    }
-    const int sh = bwd_class_shift(C);
-    const size_t smem_b = std::max((size_t)kEncBwdStage * (3 * D + 3), (size_t)(sh < 8 ? kBlock * 2 * D : 0)) * sizeof(float);
-    const dim3 grid_b((C + (1 << sh) - 1) >> sh, b.S);
-    DISPATCH_D(D, CNF_LAUNCH((encoder_bwd_class_kernel<DT>), grid_b, dim3(kBlock), smem_b, st, b, sh));
-    const long P = (long)C * 2 * D;
-    CNF_LAUNCH(encoder_bwd_splits_kernel, dim3((unsigned)((P + 15) / 16)), dim3(kBlock), 0, st,
-               (const float*)b.partials, b.S, P, g_table);
-    return launch_status("cnf_encoder_forward_bwd_tiled");
 }
 
 }  // extern "C"
