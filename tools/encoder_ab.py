@@ -1,6 +1,8 @@
-"""Round-3 (two tokens per lane) vs round-2 encoder kernels, interleaved A/B on one box: steady-state us per launch of
-cnf_encoder_forward / cnf_encoder_decode at the benchmark shape (B=16384, N=64, D=6) for several vocabulary sizes, and at
-configs[1]'s shape (B=16384, N=16, D=4, C=16)."""
+"""Encoder kernels, interleaved A/B on one box: steady-state us per launch of cnf_encoder_forward / cnf_encoder_decode at the
+benchmark shape (B=16384, N=64, D=6) for several vocabulary sizes, and at configs[1]'s shape (B=16384, N=16, D=4, C=16).
+Columns: the one-token kernel forced (cnf_set_encoder_kernel(1): 256-token tiles) -> the automatic choice (one-token kernel
+on 64- / 128-token tiles); the automatic forward with class_prob_log written; the two-tokens-per-lane kernel forced
+(256-token tiles).  CNF_LIB_OVERRIDE=<other build> runs the same table on another build of the library."""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -22,7 +24,7 @@ def steady(fn, reps=30, blocks=5):
     return float(np.median([m[b].elapsed_time(m[b + 1]) / reps * 1e3 for b in range(1, blocks)]))
 
 
-print("shape                      C | forward r2 -> r3 (us) | decode r2 -> r3 (us) | forward with class_prob_log r3 | forward, two tokens per lane forced")
+print("shape                      C | forward forced(1) -> automatic (us) | decode forced(1) -> automatic (us) | forward + class_prob_log | forward, two tokens per lane forced")
 for (B, N, D), Cs in (((16384, 64, 6), (16, 3, 9, 32, 51)), ((16384, 16, 4), (16,)), ((16384, 64, 2), (2, 3)), ((16384, 64, 8), (16,))):
     for C in Cs:
         g = torch.Generator(device=dev).manual_seed(0)

@@ -32,6 +32,8 @@ timeout 300 python tools/sweep_mixture_bwd.py > "$OUT/sweep_mixture_bwd.log" 2>&
 timeout 300 python tools/bench_kernels.py > "$OUT/bench_kernels.log" 2>&1; tail -14 "$OUT/bench_kernels.log"
 timeout 300 python tools/bench_flow_graph.py > "$OUT/flow_graph.txt" 2>&1; tail -6 "$OUT/flow_graph.txt"
 timeout 400 python tools/encoder_probe.py > "$OUT/encoder_probe.txt" 2>&1; tail -7 "$OUT/encoder_probe.txt"
+timeout 300 python tools/encoder_ab.py 2>/dev/null > "$OUT/encoder_ab.txt"; tail -9 "$OUT/encoder_ab.txt" | cut -c1-160
+timeout 200 python tools/encoder_lds_vs_tiled.py 2>/dev/null > "$OUT/encoder_lds_vs_tiled.txt"; tail -3 "$OUT/encoder_lds_vs_tiled.txt"
 timeout 200 python tools/sustained_probe.py > "$OUT/sustained_probe.txt" 2>&1; tail -6 "$OUT/sustained_probe.txt"
 bash tools/pmc_ceilings.sh ceilings > "$OUT/ceilings.log" 2>&1; tail -10 "$OUT/ceilings.log"
 bash tools/pmc_passes.sh pmc_small python tools/pmc_small_mixture.py > "$OUT/pmc_small.log" 2>&1
