@@ -220,18 +220,19 @@ def mixture_measure(ops, dev, R=4, reps=50):
 
 
 def kernel_sources_sha():
-    """sha256 over the sources the DOMINANT kernel is compiled from — cnf_affine.hip and the closure of its quoted
-    #includes (cnf_common.h, include/cnf_hip.h); profiles/traffic.json carries the same stamp (tools/pmc_summarize.py) and
-    its numbers are only reported while the sources they were measured on are the ones that are built.  (Until late
-    round 3 the stamp covered every file under csrc/, so an edit to the encoder or mixture kernels withdrew the affine
-    kernel's traffic figure although it cannot change it.)"""
+    """sha256 over the kernel sources the DOMINANT kernel is compiled from — cnf_affine.hip and the closure of its quoted
+    #includes under csrc/ (cnf_common.h; the public header include/cnf_hip.h holds declarations only and is left out);
+    profiles/traffic.json carries the same stamp (tools/pmc_summarize.py) and its numbers are only reported while the
+    sources they were measured on are the ones that are built.  (Until late round 3 the stamp covered every file under
+    csrc/, so an edit to the encoder or mixture kernels withdrew the affine kernel's traffic figure although it cannot
+    change it.)"""
     import hashlib
     import re
     d = os.path.join(ROOT, "categoricalnf_amd", "csrc")
     todo, seen = [os.path.join(d, "cnf_affine.hip")], []
     while todo:
         f = os.path.normpath(todo.pop())
-        if f in seen or not os.path.exists(f):
+        if f in seen or not os.path.exists(f) or os.path.dirname(f) != os.path.normpath(d):
             continue
         seen.append(f)
         for inc in re.findall(r'^\s*#include\s+"([^"]+)"', open(f).read(), flags=re.M):

@@ -333,9 +333,10 @@ int cnf_encoder_decode(const float* z, const float* table, const float* category
 
 /* A-B knob of the LDS-resident encoder kernels: 2 = two tokens per lane with 16-byte LDS constants wherever the shape
  * allows it (whole-row wave tiles of an even number of tokens, 16-byte aligned views, D in {1,2,3,4,6,8}), 1 = the
- * one-token-per-lane kernels of round 2 (the fallback for every other shape), 0 (default) = by measurement: the
- * two-token forward from 24 classes on, the round-2 decode.  Same arithmetic per token: both give bit-identical latents,
- * log-det and decoded indices (linear_encoding.py:59-133,153-196). */
+ * one-token-per-lane kernels (the fallback for every other shape), both on 256-token wave tiles; 0 (default) = by
+ * measurement: since the forward sums class densities instead of streaming a log-sum-exp that is the one-token kernels
+ * at every size, on 64- / 128-token tiles.  Same arithmetic per token: 1 and 2 give bit-identical latents, log-det and
+ * decoded indices (linear_encoding.py:59-133,153-196); 0 differs from them only in the order of the per-row sums. */
 void cnf_set_encoder_kernel(int which);
 /* number of cnf_encoder_forward / cnf_encoder_decode calls this process served with the two-token kernels (tests) */
 int64_t cnf_encoder_pair_launches(void);
