@@ -6,7 +6,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from categoricalnf_amd import ops, functional as Fn
 dev = torch.device("cuda:0")
 D = 6
-for B, N, C in ((16384, 64, 16), (128, 288, 10000)):
+SHAPES = ((16384, 64, 16), (128, 288, 10000))
+if len(sys.argv) > 1:          # e.g. 16384,64,16  16384,64,51
+    SHAPES = tuple(tuple(int(v) for v in a.split(",")) for a in sys.argv[1:])
+for B, N, C in SHAPES:
     g = torch.Generator(device=dev).manual_seed(1)
     categ = torch.randint(0, C, (B, N), generator=g, device=dev)
     table = (0.5 * torch.randn(C, 2 * D, generator=g, device=dev)).requires_grad_()
