@@ -186,3 +186,38 @@ def test_forward_density_sum_and_its_log_domain_fallback(B, N, D, C, which):
     assert ((l.double().cpu() - ref).abs() / ref.abs().clamp(min=1.0)).max().item() <= 1e-4
     # the extreme tokens did reach the fallback's territory: own log2-density below -127
     assert float(co.min()) < -50.0
+
+
+@pytest.mark.parametrize("B,N,D,C", [(64, 16, 6, 16), (40, 8, 16, 12), (6, 30, 4, 1500), (33, 8, 8, 51)])
+def test_backward_density_sum_and_its_log_domain_fallback(B, N, D, C):
+    """The class-tiled backward's token lanes sum class densities like the forward (cnf_encoder_bwd_tiled.hip) and take a
+    log-domain sweep straight from the raw table for a token outside the fp32 range.  Same extreme inputs as the forward's
+    test (noise at the prior's clamp in every channel, far-apart class means, log-priors of -120); d loss / d class table
+    against float64 autograd through the oracle."""
+    from categoricalnf_amd import functional as Fn
+    from oracle import cnf_oracle as O
+    lib, ops = _setup()
+    dev = torch.device("cuda:0")
+    categ, eps, table, prior, pad, _ = _inputs(B, N, D, C, 77 + D + C, 1, dev)
+    g = torch.Generator(device=dev).manual_seed(6)
+    eps = eps.reshape(B, N, D).clone()
+    eps[: B // 4] = (9.903487 / 1.81) * torch.sign(torch.randn(B // 4, N, D, generator=g, device=dev))
+    eps = eps.reshape(B * N, D).contiguous()
+    table = table.clone()
+    table[:, :D] *= 6.0
+    prior = prior.clone()
+    prior[::3] = -120.0
+    wz = torch.randn(B, N, D, generator=g, device=dev)
+    wl = torch.randn(B, generator=g, device=dev)
+    tg = table.clone().requires_grad_()
+    z, ldj, _ = Fn.EncoderForwardFn.apply(tg, categ, eps, prior, pad, 1.3, False, True)
+    ((z * wz).sum() + (ldj * wl).sum()).backward()
+    tc = table.double().cpu().requires_grad_()
+    zo, lo, co = O.encoder_forward(categ.cpu(), eps.double().cpu().reshape(B * N, 1, D), tc, prior.double().cpu(), beta=1.3,
+                                   channel_padding_mask=pad.double().cpu())
+    ((zo * wz.double().cpu()).sum() + (lo * wl.double().cpu()).sum()).backward()
+    assert float(co.min()) < -50.0                      # tokens in the fallback's territory are present
+    assert torch.isfinite(tg.grad).all()
+    scale = float(tc.grad.abs().max())
+    err = (tg.grad.double().cpu() - tc.grad).abs()
+    assert float((err / (2e-3 * tc.grad.abs() + 2e-4 * max(scale, 1.0))).max()) <= 1.0, float(err.max())
