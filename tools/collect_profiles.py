@@ -25,7 +25,7 @@ for r in rows[1:8]:
 shutil.copy(os.path.join(G, "traffic.json"), os.path.join(P, "traffic.json"))
 shutil.copy(os.path.join(G, "traffic.txt"), os.path.join(P, tag + "_pmc_traffic.txt"))
 for src, dst in (("sweep_affine.log", "_sweep_affine.txt"), ("sweep_nll.log", "_sweep_nll.txt"), ("sweep_mixture.log", "_sweep_mixture.txt"),
-                 ("sweep_mixture_bwd.log", "_sweep_mixture_bwd.txt"), ("bench_kernels.log", "_bench_kernels.txt"),
+                 ("sweep_mixture_bwd.log", "_sweep_mixture_bwd.txt"), ("bench_kernels.log", "_bench_kernels.txt"), ("layer_kernel_stats.csv", "_layer_kernel_stats.csv"),
                  ("flow_graph.txt", "_flow_graph.txt"), ("encoder_probe.txt", "_encoder_probe.txt"), ("encoder_ab.txt", "_encoder_ab.txt"), ("sustained_probe.txt", "_sustained_probe.txt"), ("train_step.txt", "_train_step.txt"),
                  ("ceilings/ceilings.txt", "_ceilings.txt"), ("ceilings/ceilings.json", "_ceilings.json"),
                  ("pmc_small/table.txt", "_pmc_small_mixture.txt"), ("ab_mixture_inverse.txt", "_ab_mixture_inverse.txt"), ("flow_traffic.txt", "_flow_traffic.txt"),

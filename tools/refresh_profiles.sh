@@ -30,6 +30,12 @@ timeout 300 python tools/sweep_nll.py > "$OUT/sweep_nll.log" 2>&1; tail -4 "$OUT
 timeout 300 python tools/sweep_mixture.py > "$OUT/sweep_mixture.log" 2>&1; tail -6 "$OUT/sweep_mixture.log" | cut -c1-200
 timeout 300 python tools/sweep_mixture_bwd.py > "$OUT/sweep_mixture_bwd.log" 2>&1; tail -7 "$OUT/sweep_mixture_bwd.log" | cut -c1-200
 timeout 300 python tools/bench_kernels.py > "$OUT/bench_kernels.log" 2>&1; tail -14 "$OUT/bench_kernels.log"
+# the same table's kernels by themselves (the table's microseconds include ~15 us of host time per op call, which paces every
+# kernel shorter than that): rocprofv3 durations per kernel
+rm -rf "$OUT/prof_layers"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_layers" -o layers -- python tools/bench_kernels.py > /dev/null 2>&1
+python tools/summarize_kernel_stats.py "$OUT/prof_layers/layers_kernel_stats.csv" "$OUT/layer_kernel_stats.csv" "tools/bench_kernels.py (every forward layer kernel at B=16384, N=64, D=6 on four rotating input sets = 100 MB: inputs are re-read from the 256 MB memory-side cache, so these are kernel durations, not HBM figures)" 20 | head -3
+rm -f "$OUT"/prof_layers/*kernel_trace.csv
 timeout 300 python tools/bench_flow_graph.py > "$OUT/flow_graph.txt" 2>&1; tail -6 "$OUT/flow_graph.txt"
 timeout 400 python tools/encoder_probe.py > "$OUT/encoder_probe.txt" 2>&1; tail -7 "$OUT/encoder_probe.txt"
 timeout 300 python tools/encoder_ab.py 2>/dev/null > "$OUT/encoder_ab.txt"; tail -9 "$OUT/encoder_ab.txt" | cut -c1-160
