@@ -342,11 +342,11 @@ void cnf_set_encoder_kernel(int which);
 int64_t cnf_encoder_pair_launches(void);
 
 /* The same two for vocabularies whose class table does not fit LDS (wikitext: 10^4 classes): the classes are walked
- * in chunks whose score constants a workgroup rebuilds in LDS, the streamed log-sum-exp / arg-max runs across chunks,
- * and nothing of size [T*C, ...] is materialised (linear_encoding.py:155-160 expands to [T*C, 1, D]).  Same results as
- * cnf_encoder_forward / cnf_encoder_decode.  Beyond 1024 classes the class range is also split over workgroups (up to 32
- * splits, a function of C only, so a sample's result does not depend on its batch): a second launch merges the per-split
- * (max, sum) / (best, arg-max) pairs in split order.  workspace: cnf_encoder_workspace_floats(B, N, D, C) floats (token
+ * in chunks whose score constants a workgroup rebuilds in LDS, the sum of class densities (forward) / the arg-max
+ * (decode) runs across chunks, and nothing of size [T*C, ...] is materialised (linear_encoding.py:155-160 expands to
+ * [T*C, 1, D]).  Same results as cnf_encoder_forward / cnf_encoder_decode.  Beyond 1024 classes the class range is also
+ * split over workgroups (up to 32 splits, a function of C only, so a sample's result does not depend on its batch): a
+ * second launch merges the per-split density sums / (best, arg-max) pairs in split order.  workspace: cnf_encoder_workspace_floats(B, N, D, C) floats (token
  * log-det terms, which a small kernel sums per row in a fixed order, and the split partials); decode needs it only
  * above 1024 classes (else it may be null). */
 int64_t cnf_encoder_workspace_floats(int B, int N, int D, int C);
