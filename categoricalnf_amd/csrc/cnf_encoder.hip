@@ -832,7 +832,20 @@ int cnf_encoder_forward(const int64_t* categ, const float* eps, const float* tab
     // loop dominates (16 384 waves: two rounds of eight per SIMD overlap their load and store phases), two below that.
     // (The forced kernels of cnf_set_encoder_kernel(1 / 2) keep the 256-token tiles both were written for: the row sums'
     // order follows the tiling, and those two are compared bit for bit.)
-    const RowTiling tl = make_row_tiling(B, N, /*force_vec=*/1, g_encoder_kernel != 0 ? 256 : (C >= 24 ? 64 : 128));
+    // A row length that fills a small tile badly (N = 38: one row = 38 of 64 lanes) moves on to the next larger tile.
+    auto tiling_for = [&](int target) { return make_row_tiling(B, N, /*force_vec=*/1, target); };
+    auto lane_use = [&](const RowTiling& t) {
+        const long tok = (long)t.rw * N;
+        return t.bpr ? 1.0 : (double)tok / (double)(((tok + kWave - 1) / kWave) * kWave);
+    };
+    RowTiling tl = tiling_for(256);
+    if (g_encoder_kernel == 0) {
+        const int first = C >= 24 ? 64 : 128;
+        for (int target = first; target <= 256; target *= 2) {
+            tl = tiling_for(target);
+            if (lane_use(tl) >= 0.85) break;
+        }
+    }
     // two tokens per lane (round 3) when every pair of a tile starts at an even token and the views are aligned
     const size_t va = (D % 2 == 0) ? 15 : 7;
     const size_t smem_pair = (size_t)kWavesPerBlock * kMaxTileChunks * sizeof(float) + pair_table_bytes(C, D, true);
