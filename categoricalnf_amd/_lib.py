@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libcnf_hip.so")
 
 CNF_OK = 0
+CNF_ERR_UNSUPPORTED = 3
 FLAG_NAN_Z, FLAG_NAN_LDJ, FLAG_RANGE, FLAG_CATEGORY = 1, 2, 4, 8
 
 _p = ctypes.c_void_p
@@ -51,8 +52,10 @@ SIGNATURES = {
     "cnf_nll_acc_read": [_p, _i64, _d, _p, _p],
     "cnf_prior_nll": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _p],
     "cnf_encoder_forward": [_p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p, _p],
+    "cnf_encoder_forward_sampled": [_p, _p, _f, _p, _p, _p, _f, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p, _p],
     "cnf_encoder_decode": [_p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
     "cnf_encoder_forward_tiled": [_p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p, _p],
+    "cnf_encoder_forward_tiled_sampled": [_p, _p, _f, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p, _p],
     "cnf_encoder_decode_tiled": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
     "cnf_sigmoid_flow": [_p, _p, _p, _p, _i, _i, _i, _f, _p, _p],
     "cnf_affine_coupling_bwd": [_p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],

@@ -24,11 +24,45 @@ struct EncArgs {
     int* flags;
     int B, N, D, C;
     float beta, sigma, log_sigma;
+    // sampler fusion (cnf_encoder_forward_sampled): `eps` holds the UNIFORM draw, the kernel turns it into logistic noise
+    // itself (and writes the noise to eps_out if that is set, for the backward)
+    int eps_is_u;
+    float u_squeeze;
+    float* eps_out;
 };
 
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
 constexpr int kEncMaxD = 16;
+
+// LogisticDistribution.sample given the uniform draw (distributions.py:139-145,117-127) in math mode 1: the expression of
+// logistic_icdf<true> in cnf_affine.hip (cnf_logistic_from_uniform), mu = 0 — kept literally the same so that the fused
+// sampler gives the bits of the two-kernel path (tests/test_gpu_encoder_pair.py pins that).
+__device__ __forceinline__ float enc_noise_from_uniform(float u, float sigma, float squeeze) {
+    const float uf = (u * (1.f - squeeze)) + squeeze / 2.f;
+    const float v = (__builtin_amdgcn_logf(uf) - __builtin_amdgcn_logf(1.f - uf)) * 0.6931471805599453f;
+    return v * sigma + 0.f;
+}
+// a token's D noise values from token-major [T, D] storage, whichever form the caller handed over: the D loads go out back
+// to back, THEN one wave-uniform branch samples (a branch per value would put a memory round trip between the loads)
+// MODE: 0 = the caller's noise as it is (no branch at all: the hot LDS-resident kernel is instantiated both ways — with the
+// run-time test in it, even untaken, its forward ran 1.5 us slower at the benchmark shape), 1 = sample, 2 = run-time test
+template <int MODE, int DM>
+__device__ __forceinline__ void enc_token_noise(const EncArgs& a, size_t tok, int D, float (&e)[DM]) {
+#pragma unroll
+    for (int d = 0; d < DM; ++d)
+        if (d < D) e[d] = a.eps[tok * D + d];
+    if (MODE == 1 || (MODE == 2 && a.eps_is_u)) {
+#pragma unroll
+        for (int d = 0; d < DM; ++d)
+            if (d < D) e[d] = enc_noise_from_uniform(e[d], a.sigma, a.u_squeeze);
+        if (a.eps_out) {
+#pragma unroll
+            for (int d = 0; d < DM; ++d)
+                if (d < D) a.eps_out[tok * D + d] = e[d];
+        }
+    }
+}
 
 // ---- class chunks of the tiled kernels (see cnf_encoder.hip: "large vocabularies") ----------------------------------
 __device__ __forceinline__ int chunk_stride(int D) { return 2 * D + 2; }     // [A0 C0 ... A(D-1) C(D-1) | cst2 | E = 2^cst2]

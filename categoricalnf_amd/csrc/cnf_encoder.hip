@@ -117,7 +117,7 @@ __device__ __forceinline__ float lse2_of_classes(const float* tab, int stride, c
     return m + __builtin_amdgcn_logf(s);
 }
 
-template <int DT>
+template <int DT, bool SAMPLE>
 __global__ __launch_bounds__(kBlock) void encoder_forward_kernel(EncArgs a, RowTiling tl) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* part_all = reinterpret_cast<float*>(smem);
@@ -139,9 +139,11 @@ __global__ __launch_bounds__(kBlock) void encoder_forward_kernel(EncArgs a, RowT
         // log-prob of the noise under the logistic prior: same product form as class_score
         float nacc = 0.f, nprod = 1.f;
         const float kn = kLog2e / a.sigma;
+        float ev[DT > 0 ? DT : kEncMaxD];
+        enc_token_noise<SAMPLE ? 1 : 0>(a, tok, D, ev);
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            const float e = a.eps[tok * D + d];
+            const float e = ev[d];
             const float vs = fabsf(e) * kn;
             nacc += vs;
             nprod = fmaf(nprod, __builtin_amdgcn_exp2f(-vs), nprod);
@@ -467,6 +469,13 @@ __global__ __launch_bounds__(kBlock) void encoder_forward_pair_kernel(EncArgs a,
         const long tok = tok0 + pc;
         if (pc + 1 < nch) {
             PairIO<D>::load_nt(a.eps + tok * D, in.e);
+            if (a.eps_is_u) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int d = 0; d < D; ++d) in.e[t][d] = enc_noise_from_uniform(in.e[t][d], a.sigma, a.u_squeeze);
+                if (a.eps_out) PairIO<D>::store(a.eps_out + tok * D, in.e);
+            }
             const ll2 cc = *reinterpret_cast<const ll2*>(a.categ + tok);
             in.c[0] = cc[0];
             in.c[1] = cc[1];
@@ -478,8 +487,9 @@ __global__ __launch_bounds__(kBlock) void encoder_forward_pair_kernel(EncArgs a,
                 in.pv[0] = in.pv[1] = 1.f;
             }
         } else {                                            // lone last token of the tile: its partner is a copy
+            enc_token_noise<2>(a, (size_t)tok, D, in.e[0]);
 #pragma unroll
-            for (int d = 0; d < D; ++d) in.e[0][d] = in.e[1][d] = a.eps[tok * D + d];
+            for (int d = 0; d < D; ++d) in.e[1][d] = in.e[0][d];
             in.c[0] = in.c[1] = a.categ[tok];
             in.pv[0] = in.pv[1] = a.pad ? a.pad[tok] : 1.f;
         }
@@ -676,9 +686,11 @@ __global__ __launch_bounds__(kBlock) void encoder_tiled_kernel(EncArgs a, long n
             const float* row = a.table + (size_t)c * 2 * D;
             float nacc = 0.f, nprod = 1.f;
             const float kn = kLog2e / a.sigma;
+            float ev[DT > 0 ? DT : kEncMaxD];
+            enc_token_noise<2>(a, (size_t)tok, D, ev);
 #pragma unroll
             for (int d = 0; d < D; ++d) {
-                const float e = a.eps[tok * D + d];
+                const float e = ev[d];
                 const float vs = fabsf(e) * kn;
                 nacc += vs;
                 nprod = fmaf(nprod, __builtin_amdgcn_exp2f(-vs), nprod);
@@ -810,11 +822,11 @@ static int64_t g_pair_launches = 0;
 void cnf_set_encoder_kernel(int which) { g_encoder_kernel = which; }
 int64_t cnf_encoder_pair_launches(void) { return g_pair_launches; }
 
-int cnf_encoder_forward(const int64_t* categ, const float* eps, const float* table,
-                        const float* category_prior, const float* pad, float beta,
-                        const float* ldj_in, float* z_out, float* ldj_out, float* class_prob_log,
-                        int B, int N, int D, int C, float sigma, float log_sigma,
-                        int* flags, cnf_stream_t stream) {
+static int encoder_forward_impl(const int64_t* categ, const float* eps, const float* table,
+                                const float* category_prior, const float* pad, float beta,
+                                const float* ldj_in, float* z_out, float* ldj_out, float* class_prob_log,
+                                int B, int N, int D, int C, float sigma, float log_sigma,
+                                int* flags, cnf_stream_t stream, int eps_is_u, float u_squeeze, float* eps_out) {
     CNF_REQUIRE(categ && eps && table && category_prior && z_out && ldj_out, "cnf_encoder_forward: null tensor");
     CNF_REQUIRE(B >= 0 && N > 0 && D > 0 && C > 0, "cnf_encoder_forward: bad shape");
     if (B == 0) return CNF_OK;
@@ -826,6 +838,7 @@ int cnf_encoder_forward(const int64_t* categ, const float* eps, const float* tab
     a.categ = categ; a.eps = eps; a.table = table; a.prior = category_prior; a.pad = pad;
     a.ldj_in = ldj_in; a.z_out = z_out; a.ldj_out = ldj_out; a.cpl = class_prob_log; a.flags = flags;
     a.B = B; a.N = N; a.D = D; a.C = C; a.beta = beta; a.sigma = sigma; a.log_sigma = log_sigma;
+    a.eps_is_u = eps_is_u; a.u_squeeze = u_squeeze; a.eps_out = eps_out;
     // Tokens per wave tile.  Interleaved runs on one MI355X after the density-sum loop (B=16384, N=64, D=6; us at tiles of
     // 64 / 128 / 256 tokens): 3 classes 14.4 / 12.9 / 14.1, 9 classes 19.2 / 18.3 / 19.2, 16 classes 25.1 / 25.1 / 26.4,
     // 32 classes 37.7 / 39.0 / 41.6, 51 classes 55.0 / 57.0 / 61.3 (rounds 1-3 used 256): one token per lane once the class
@@ -856,17 +869,44 @@ int cnf_encoder_forward(const int64_t* categ, const float* eps, const float* tab
     // against (cnf_set_encoder_kernel(2)).
     const bool want_pair = g_encoder_kernel == 2;
     const bool pair = want_pair && pair_has_d(D) && !tl.bpr && tl.rw >= 2 && ((long)tl.rw * N) % 2 == 0 &&
-                      smem_pair <= 64 * 1024 && aligned_to(eps, va) && aligned_to(z_out, va) && aligned_to(categ, 15) &&
+                      smem_pair <= 64 * 1024 && aligned_to(eps, va) && aligned_to(eps_out, va) && aligned_to(z_out, va) && aligned_to(categ, 15) &&
                       aligned_to(pad, 7) && aligned_to(class_prob_log, 7);
     if (pair) {
         ++g_pair_launches;
         DISPATCH_PAIR_D(D, CNF_LAUNCH((encoder_forward_pair_kernel<DT>), tiling_grid(tl), dim3(kBlock), smem_pair,
                                       (hipStream_t)stream, a, tl));
     } else {
-        DISPATCH_D(D, CNF_LAUNCH((encoder_forward_kernel<DT>), tiling_grid(tl), dim3(kBlock), smem,
-                                 (hipStream_t)stream, a, tl));
+        if (eps_is_u) {
+            DISPATCH_D(D, CNF_LAUNCH((encoder_forward_kernel<DT, true>), tiling_grid(tl), dim3(kBlock), smem,
+                                     (hipStream_t)stream, a, tl));
+        } else {
+            DISPATCH_D(D, CNF_LAUNCH((encoder_forward_kernel<DT, false>), tiling_grid(tl), dim3(kBlock), smem,
+                                     (hipStream_t)stream, a, tl));
+        }
     }
     return launch_status("cnf_encoder_forward");
+}
+
+int cnf_encoder_forward(const int64_t* categ, const float* eps, const float* table,
+                        const float* category_prior, const float* pad, float beta,
+                        const float* ldj_in, float* z_out, float* ldj_out, float* class_prob_log,
+                        int B, int N, int D, int C, float sigma, float log_sigma,
+                        int* flags, cnf_stream_t stream) {
+    return encoder_forward_impl(categ, eps, table, category_prior, pad, beta, ldj_in, z_out, ldj_out, class_prob_log,
+                                B, N, D, C, sigma, log_sigma, flags, stream, 0, 0.f, nullptr);
+}
+
+int cnf_encoder_forward_sampled(const int64_t* categ, const float* u, float squeeze_eps, const float* table,
+                                const float* category_prior, const float* pad, float beta,
+                                const float* ldj_in, float* z_out, float* ldj_out, float* class_prob_log, float* eps_out,
+                                int B, int N, int D, int C, float sigma, float log_sigma,
+                                int* flags, cnf_stream_t stream) {
+    if (math_mode() != 1) {
+        set_error("cnf_encoder_forward_sampled: the fused sampler is the fp32 one of math mode 1; run cnf_logistic_from_uniform + cnf_encoder_forward");
+        return CNF_ERR_UNSUPPORTED;
+    }
+    return encoder_forward_impl(categ, u, table, category_prior, pad, beta, ldj_in, z_out, ldj_out, class_prob_log,
+                                B, N, D, C, sigma, log_sigma, flags, stream, 1, squeeze_eps, eps_out);
 }
 
 int cnf_encoder_decode(const float* z, const float* table, const float* category_prior,
@@ -908,12 +948,12 @@ int64_t cnf_encoder_workspace_floats(int B, int N, int D, int C) {
     return (int64_t)B * N * (1 + (ks > 1 ? 2 * ks : 0));
 }
 
-int cnf_encoder_forward_tiled(const int64_t* categ, const float* eps, const float* table,
-                              const float* category_prior, const float* pad, float beta,
-                              const float* ldj_in, float* z_out, float* ldj_out, float* class_prob_log,
-                              float* workspace,
-                              int B, int N, int D, int C, float sigma, float log_sigma,
-                              int* flags, cnf_stream_t stream) {
+static int encoder_forward_tiled_impl(const int64_t* categ, const float* eps, const float* table,
+                                      const float* category_prior, const float* pad, float beta,
+                                      const float* ldj_in, float* z_out, float* ldj_out, float* class_prob_log,
+                                      float* workspace,
+                                      int B, int N, int D, int C, float sigma, float log_sigma,
+                                      int* flags, cnf_stream_t stream, int eps_is_u, float u_squeeze, float* eps_out) {
     CNF_REQUIRE(categ && eps && table && category_prior && z_out && ldj_out && workspace, "cnf_encoder_forward_tiled: null tensor");
     CNF_REQUIRE(B >= 0 && N > 0 && D > 0 && C > 0 && D <= kEncMaxD, "cnf_encoder_forward_tiled: bad shape");
     if (B == 0) return CNF_OK;
@@ -921,6 +961,7 @@ int cnf_encoder_forward_tiled(const int64_t* categ, const float* eps, const floa
     a.categ = categ; a.eps = eps; a.table = table; a.prior = category_prior; a.pad = pad;
     a.z_out = z_out; a.cpl = class_prob_log; a.flags = flags;
     a.B = B; a.N = N; a.D = D; a.C = C; a.beta = beta; a.sigma = sigma; a.log_sigma = log_sigma;
+    a.eps_is_u = eps_is_u; a.u_squeeze = u_squeeze; a.eps_out = eps_out;
     const long ntok = (long)B * N;
     const int CC = std::min(C, tiled_chunk_classes(D));
     const size_t smem = (size_t)CC * (2 * D + 2) * sizeof(float);
@@ -940,6 +981,30 @@ int cnf_encoder_forward_tiled(const int64_t* categ, const float* eps, const floa
     CNF_LAUNCH(encoder_row_sum_kernel, dim3((B + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kBlock), 0, st,
                (const float*)workspace, ldj_in, ldj_out, B, N, flags);
     return launch_status("cnf_encoder_forward_tiled");
+}
+
+int cnf_encoder_forward_tiled(const int64_t* categ, const float* eps, const float* table,
+                              const float* category_prior, const float* pad, float beta,
+                              const float* ldj_in, float* z_out, float* ldj_out, float* class_prob_log,
+                              float* workspace,
+                              int B, int N, int D, int C, float sigma, float log_sigma,
+                              int* flags, cnf_stream_t stream) {
+    return encoder_forward_tiled_impl(categ, eps, table, category_prior, pad, beta, ldj_in, z_out, ldj_out, class_prob_log,
+                                      workspace, B, N, D, C, sigma, log_sigma, flags, stream, 0, 0.f, nullptr);
+}
+
+int cnf_encoder_forward_tiled_sampled(const int64_t* categ, const float* u, float squeeze_eps, const float* table,
+                                      const float* category_prior, const float* pad, float beta,
+                                      const float* ldj_in, float* z_out, float* ldj_out, float* class_prob_log,
+                                      float* eps_out, float* workspace,
+                                      int B, int N, int D, int C, float sigma, float log_sigma,
+                                      int* flags, cnf_stream_t stream) {
+    if (math_mode() != 1) {
+        set_error("cnf_encoder_forward_tiled_sampled: the fused sampler is the fp32 one of math mode 1; run cnf_logistic_from_uniform + cnf_encoder_forward_tiled");
+        return CNF_ERR_UNSUPPORTED;
+    }
+    return encoder_forward_tiled_impl(categ, u, table, category_prior, pad, beta, ldj_in, z_out, ldj_out, class_prob_log,
+                                      workspace, B, N, D, C, sigma, log_sigma, flags, stream, 1, squeeze_eps, eps_out);
 }
 
 int cnf_encoder_decode_tiled(const float* z, const float* table, const float* category_prior,

@@ -264,9 +264,16 @@ class EncoderForwardFn(torch.autograd.Function):
     """class table [C,2D] -> (z, ldj, class_prob_log); categories, noise, prior and padding are constants."""
 
     @staticmethod
-    def forward(ctx, table, categ, eps, prior, pad, beta, want_class_prob, tiled=None):
-        z, ldj, cpl = ops.encoder_forward(categ, eps, table, prior, beta=beta, channel_padding_mask=pad,
-                                          want_class_prob=want_class_prob, tiled=tiled)
+    def forward(ctx, table, categ, eps, prior, pad, beta, want_class_prob, tiled=None, uniform_squeeze=None):
+        # uniform_squeeze: `eps` is the uniform draw and the forward kernel samples the noise itself (and hands it back for
+        # the backward kernels), see ops.encoder_forward
+        if uniform_squeeze is not None:
+            z, ldj, cpl, eps = ops.encoder_forward(categ, eps, table, prior, beta=beta, channel_padding_mask=pad,
+                                                   want_class_prob=want_class_prob, tiled=tiled,
+                                                   uniform_squeeze=uniform_squeeze, want_noise=True)
+        else:
+            z, ldj, cpl = ops.encoder_forward(categ, eps, table, prior, beta=beta, channel_padding_mask=pad,
+                                              want_class_prob=want_class_prob, tiled=tiled)
         ctx.tiled = tiled
         ctx.save_for_backward(table, categ, eps, prior, pad if isinstance(pad, torch.Tensor) else z.new_empty(0))
         ctx.has_pad, ctx.beta = isinstance(pad, torch.Tensor), float(beta)
@@ -297,7 +304,7 @@ class EncoderForwardFn(torch.autograd.Function):
         _launch(dev, name, _ptr(categ_c), _ptr(ec), _ptr(tc), _ptr(pc), _ptr(p2), ctx.beta,
                                                hold(g_zout), hold(g_ldj), _ptr(g_table), _ptr(ws), B, N, D, C,
                                                float(ops.LOGISTIC_SIGMA), float(ops.LOGISTIC_LOG_SIGMA), _stream(dev))
-        return g_table, None, None, None, None, None, None, None
+        return g_table, None, None, None, None, None, None, None, None
 
 
 class AffineParamsFn(torch.autograd.Function):

@@ -4,8 +4,9 @@ Interface of layers/categorical_encoding/linear_encoding.py (LinearCategoricalEn
 _create_flows :214-250).  Mixture-model encoding (num_flows == 0 — the default of every
 experiment) runs as ONE kernel per direction (cnf_encoder_forward / cnf_encoder_decode): the
 class-conditional flow is a single ExtActNorm whose predictor sees only the class embedding, so it
-is a [C, 2D] table; the kernel samples nothing itself (noise is an input), computes the forward
-push, the per-category log-prob over all C classes, the posterior and the token log-det.
+is a [C, 2D] table; the kernel takes the uniform draw, turns it into logistic noise itself
+(LogisticDistribution.sample fused in: cnf_encoder_forward_sampled), computes the forward push, the
+per-category log-prob over all C classes, the posterior and the token log-det.
 Linear-flow encoding (num_flows > 0) composes the ExtActNorm / InvertibleConv / CouplingLayer
 kernels over the expanded [T*C, 1, D] tensor like the reference."""
 import os
@@ -76,6 +77,18 @@ class LinearCategoricalEncoding(FlowLayer):
             return self.prior_distribution.sample(shape=shape, device=device, uniform=noise.reshape(shape))
         return self.prior_distribution.sample(shape=shape, device=device, generator=self.noise_generator)
 
+    def _uniform_draw(self, tokens, device, noise=None):
+        """The U[0,1) draw behind `_noise`, as [tokens, D] on the device: the one-kernel encoder samples the logistic noise
+        from it itself (the steps of LogisticDistribution.sample :105-122 up to cnf_logistic_from_uniform)."""
+        shape = (tokens, 1, self.D)
+        if noise is not None:                        # injected U[0,1) draw (parity tests)
+            u = noise.reshape(shape)
+        else:
+            u = self.prior_distribution.uniform(shape, generator=self.noise_generator, device=device)
+        if u.dim() == len(shape) + 1:
+            u = u.squeeze(dim=-1)
+        return u.to(device=device, dtype=torch.float32).reshape(tokens, self.D)
+
     # ---- forward -------------------------------------------------------------------------------
     def forward(self, z, ldj=None, reverse=False, beta=1, delta=0.0, channel_padding_mask=None, noise=None, **kwargs):
         batch_size, seq_length = z.size(0), z.size(1)
@@ -83,14 +96,15 @@ class LinearCategoricalEncoding(FlowLayer):
         if not reverse:
             table = self.class_table() if self._is_mixture_model() else None
             if table is not None and self._kernel_path(Fn.needs_grad(table)):
-                eps = self._noise(batch_size * seq_length, z.device, noise)
+                u = self._uniform_draw(batch_size * seq_length, z.device, noise)
+                squeeze = float(self.prior_distribution.eps)
                 if Fn.needs_grad(table):
-                    z_out, ldj_loc, cpl = Fn.EncoderForwardFn.apply(table, z, eps, self.category_prior, channel_padding_mask,
-                                                                    float(beta), self.training)
+                    z_out, ldj_loc, cpl = Fn.EncoderForwardFn.apply(table, z, u, self.category_prior, channel_padding_mask,
+                                                                    float(beta), self.training, None, squeeze)
                 else:
-                    z_out, ldj_loc, cpl = ops.encoder_forward(z, eps, table, self.category_prior, beta=float(beta),
+                    z_out, ldj_loc, cpl = ops.encoder_forward(z, u, table, self.category_prior, beta=float(beta),
                                                               channel_padding_mask=channel_padding_mask,
-                                                              want_class_prob=self.training)
+                                                              want_class_prob=self.training, uniform_squeeze=squeeze)
                 if self.training:
                     detailed_ldj = self._train_stats(z_out, cpl, channel_padding_mask)
             else:

@@ -611,8 +611,14 @@ def encoder_prefers_tiled_forward(C, D, B=None, N=None):
 
 
 def encoder_forward(categ, eps, table, category_prior, beta=1.0, channel_padding_mask=None, ldj=None,
-                    want_class_prob=False, sigma=LOGISTIC_SIGMA, log_sigma=LOGISTIC_LOG_SIGMA, tiled=None):
-    """`tiled`: None = by vocabulary size; True / False force the class-tiled / the LDS-resident kernel (tests)."""
+                    want_class_prob=False, sigma=LOGISTIC_SIGMA, log_sigma=LOGISTIC_LOG_SIGMA, tiled=None,
+                    uniform_squeeze=None, want_noise=False):
+    """`tiled`: None = by vocabulary size; True / False force the class-tiled / the LDS-resident kernel (tests).
+
+    `uniform_squeeze` (the prior's eps, 1e-4 in the reference): `eps` then holds the UNIFORM draw and the kernel samples the
+    logistic noise itself (cnf_encoder_forward_sampled: LogisticDistribution.sample fused in, one launch and a [T, D] round
+    trip less, the same bits); `want_noise` returns that noise as a fourth value (the backward takes it).  In math mode 0
+    the sampler's fp64 logit is not what the kernel holds: the two calls are made instead."""
     dev = _dev(categ)
     if categ.dtype != torch.int64:
         categ = categ.long()
@@ -630,17 +636,48 @@ def encoder_forward(categ, eps, table, category_prior, beta=1.0, channel_padding
     cpl = torch.empty(B * N, dtype=torch.float32, device=dev) if want_class_prob else None
     if tiled is None:
         tiled = encoder_prefers_tiled_forward(C, D, B, N)
+    ws = None
+    if tiled:
+        # token log-det terms (+ the per-split partials above 1024 classes)
+        ws = torch.empty(int(_lib.load().cnf_encoder_workspace_floats(B, N, D, C)), dtype=torch.float32, device=dev)
+    noise = None
+    if uniform_squeeze is not None:
+        noise = torch.empty(B * N, D, dtype=torch.float32, device=dev) if want_noise else None
+        lib = _lib.load()
+        if not tiled:
+            args = (_ptr(categ), _ptr(eps), float(uniform_squeeze), _ptr(table), _ptr(prior), _ptr(pad), float(beta), _ptr(ldj_in),
+                    _ptr(z), _ptr(ldj_out), _ptr(cpl), _ptr(noise), B, N, D, C, float(sigma), float(log_sigma),
+                    _ptr(flag_word(dev)), _stream(dev))
+            name = "cnf_encoder_forward_sampled"
+        else:
+            args = (_ptr(categ), _ptr(eps), float(uniform_squeeze), _ptr(table), _ptr(prior), _ptr(pad), float(beta), _ptr(ldj_in),
+                    _ptr(z), _ptr(ldj_out), _ptr(cpl), _ptr(noise), _ptr(ws), B, N, D, C, float(sigma), float(log_sigma),
+                    _ptr(flag_word(dev)), _stream(dev))
+            name = "cnf_encoder_forward_tiled_sampled"
+        fn = getattr(lib, name)
+        if dev.index is not None and dev.index != torch.cuda.current_device():
+            with torch.cuda.device(dev):
+                status = fn(*args)
+        else:
+            status = fn(*args)
+        if status == _lib.CNF_OK:
+            _after(dev, "categorical encoder")
+            return (z, ldj_out, cpl, noise) if want_noise else (z, ldj_out, cpl)
+        if status != _lib.CNF_ERR_UNSUPPORTED:
+            _lib.check(status, name)
+        eps = logistic_from_uniform(eps, mu=0.0, sigma=sigma, eps=uniform_squeeze)      # math mode 0: the two calls
+        noise = eps
     if not tiled:
         _launch(dev, "cnf_encoder_forward", _ptr(categ), _ptr(eps), _ptr(table), _ptr(prior), _ptr(pad), float(beta),
                                            _ptr(ldj_in), _ptr(z), _ptr(ldj_out), _ptr(cpl), B, N, D, C, float(sigma),
                                            float(log_sigma), _ptr(flag_word(dev)), _stream(dev))
     else:
-        # token log-det terms (+ the per-split partials above 1024 classes)
-        ws = torch.empty(int(_lib.load().cnf_encoder_workspace_floats(B, N, D, C)), dtype=torch.float32, device=dev)
         _launch(dev, "cnf_encoder_forward_tiled", _ptr(categ), _ptr(eps), _ptr(table), _ptr(prior), _ptr(pad), float(beta),
                                                  _ptr(ldj_in), _ptr(z), _ptr(ldj_out), _ptr(cpl), _ptr(ws), B, N, D, C,
                                                  float(sigma), float(log_sigma), _ptr(flag_word(dev)), _stream(dev))
     _after(dev, "categorical encoder")
+    if want_noise:
+        return z, ldj_out, cpl, (noise if noise is not None else eps)
     return z, ldj_out, cpl
 
 

@@ -327,6 +327,17 @@ int cnf_encoder_forward(const int64_t* categ, const float* eps, const float* tab
 
 /* LinearCategoricalEncoding reverse / _posterior_sample (linear_encoding.py:108-118,184-196):
  * argmax_c of (reverse-flow log-prob + category prior) -> int64 [B,N]; first max wins. */
+/* cnf_encoder_forward with LogisticDistribution.sample fused in (distributions.py:139-145,117-127 + linear_encoding.py:59-106):
+ * `u` fp32 [B*N,D] is the UNIFORM draw; the kernel squeezes it (u (1 - squeeze_eps) + squeeze_eps / 2), takes the logit and
+ * scales by sigma — the arithmetic of cnf_logistic_from_uniform in math mode 1, mu = 0 — and goes on as cnf_encoder_forward:
+ * one launch and 8 D bytes per token less than the two calls, the same bits.  eps_out (optional, fp32 [B*N,D]) receives the
+ * logistic noise (the backward kernels take it).  Math mode 0 (fp64 logit): CNF_ERR_UNSUPPORTED — run the two calls. */
+int cnf_encoder_forward_sampled(const int64_t* categ, const float* u, float squeeze_eps, const float* table,
+                                const float* category_prior, const float* pad, float beta,
+                                const float* ldj_in, float* z_out, float* ldj_out, float* class_prob_log, float* eps_out,
+                                int B, int N, int D, int C, float sigma, float log_sigma,
+                                int* flags, cnf_stream_t stream);
+
 int cnf_encoder_decode(const float* z, const float* table, const float* category_prior,
                        int64_t* categ_out, int B, int N, int D, int C, float sigma, float log_sigma,
                        cnf_stream_t stream);
@@ -356,6 +367,13 @@ int cnf_encoder_forward_tiled(const int64_t* categ, const float* eps, const floa
                               float* workspace,
                               int B, int N, int D, int C, float sigma, float log_sigma,
                               int* flags, cnf_stream_t stream);
+/* cnf_encoder_forward_tiled with the sampler fused in (see cnf_encoder_forward_sampled). */
+int cnf_encoder_forward_tiled_sampled(const int64_t* categ, const float* u, float squeeze_eps, const float* table,
+                                      const float* category_prior, const float* pad, float beta,
+                                      const float* ldj_in, float* z_out, float* ldj_out, float* class_prob_log,
+                                      float* eps_out, float* workspace,
+                                      int B, int N, int D, int C, float sigma, float log_sigma,
+                                      int* flags, cnf_stream_t stream);
 int cnf_encoder_decode_tiled(const float* z, const float* table, const float* category_prior,
                              int64_t* categ_out, float* workspace, int B, int N, int D, int C, float sigma, float log_sigma,
                              cnf_stream_t stream);

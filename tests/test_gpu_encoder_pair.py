@@ -221,3 +221,62 @@ def test_backward_density_sum_and_its_log_domain_fallback(B, N, D, C):
     scale = float(tc.grad.abs().max())
     err = (tg.grad.double().cpu() - tc.grad).abs()
     assert float((err / (2e-3 * tc.grad.abs() + 2e-4 * max(scale, 1.0))).max()) <= 1.0, float(err.max())
+
+
+@pytest.mark.parametrize("B,N,D,C,tiled", [(2048, 64, 6, 16, False), (512, 16, 4, 51, False), (7, 33, 3, 5, False), (300, 9, 5, 7, False),
+                                           (64, 20, 6, 700, True), (9, 12, 4, 2500, True), (2048, 64, 8, 40, False)])
+def test_fused_sampler_gives_the_bits_of_the_two_calls(B, N, D, C, tiled):
+    """cnf_encoder_forward[_tiled]_sampled (LogisticDistribution.sample fused into the encoder forward, distributions.py:139-145 +
+    linear_encoding.py:59-106) against cnf_logistic_from_uniform followed by cnf_encoder_forward[_tiled]: latents, log-det,
+    class posterior and the noise it hands to the backward are bit-identical; in math mode 0 the wrapper makes the two calls."""
+    lib, ops = _setup()
+    dev = torch.device("cuda:0")
+    categ, _, table, prior, pad, ldj = _inputs(B, N, D, C, 5 + B + C, 1, dev)
+    g = torch.Generator(device=dev).manual_seed(B)
+    u = torch.rand(B * N, D, generator=g, device=dev)
+    u[0, 0] = 0.0                                         # the interval's closed end (squeezed to 5e-5)
+    eps = ops.logistic_from_uniform(u, mu=0.0, sigma=ops.LOGISTIC_SIGMA, eps=1e-4)
+    for which in ((0,) if tiled else (0, 1, 2)):
+        lib.cnf_set_encoder_kernel(which)
+        try:
+            ref = ops.encoder_forward(categ, eps, table, prior, beta=1.2, channel_padding_mask=pad, ldj=ldj, want_class_prob=True, tiled=tiled)
+            got = ops.encoder_forward(categ, u, table, prior, beta=1.2, channel_padding_mask=pad, ldj=ldj, want_class_prob=True, tiled=tiled,
+                                      uniform_squeeze=1e-4, want_noise=True)
+        finally:
+            lib.cnf_set_encoder_kernel(0)
+        for a, b in zip(ref, got[:3]):
+            assert torch.equal(a, b)
+        assert torch.equal(got[3].reshape(-1), eps.reshape(-1))
+    lib.cnf_set_math_mode(0)
+    try:
+        got0 = ops.encoder_forward(categ, u, table, prior, beta=1.2, channel_padding_mask=pad, ldj=ldj, tiled=tiled, uniform_squeeze=1e-4, want_noise=True)
+        eps0 = ops.logistic_from_uniform(u, mu=0.0, sigma=ops.LOGISTIC_SIGMA, eps=1e-4)
+        ref0 = ops.encoder_forward(categ, eps0, table, prior, beta=1.2, channel_padding_mask=pad, ldj=ldj, tiled=tiled)
+    finally:
+        lib.cnf_set_math_mode(1)
+    assert torch.equal(got0[0], ref0[0]) and torch.equal(got0[1], ref0[1]) and torch.equal(got0[3].reshape(-1), eps0.reshape(-1))
+
+
+def test_encoder_module_trains_through_the_fused_sampler():
+    """The module's forward (uniform draw in, noise sampled in the kernel) and its backward (which takes the noise the forward
+    handed back): parameter gradients equal those of the explicit two-call route."""
+    from categoricalnf_amd import functional as Fn
+    from categoricalnf_amd.layers.categorical_encoding.linear_encoding import LinearCategoricalEncoding
+    lib, ops = _setup()
+    torch.manual_seed(1)
+    enc = LinearCategoricalEncoding(num_dimensions=6, flow_config={"num_flows": 0}, vocab_size=16).cuda().train()
+    for p in enc.parameters():
+        p.data.normal_(0.0, 0.4)
+    x = torch.randint(0, 16, (32, 24), device="cuda")
+    u = torch.rand(32 * 24, 1, 6, device="cuda")
+    z, ldj, _ = enc(x, noise=u)
+    (z.sum() + ldj.sum()).backward()
+    grads = {n: p.grad.clone() for n, p in enc.named_parameters()}
+    enc.zero_grad()
+    table = enc.class_table()
+    eps = ops.logistic_from_uniform(u.reshape(-1, 6), mu=0.0, sigma=ops.LOGISTIC_SIGMA, eps=1e-4)
+    z2, ldj2, _ = Fn.EncoderForwardFn.apply(table, x, eps, enc.category_prior, None, 1.0, True)
+    (z2.sum() + ldj2.sum()).backward()
+    assert torch.equal(z, z2) and torch.equal(ldj, ldj2)
+    for n, p in enc.named_parameters():
+        assert torch.equal(p.grad, grads[n]), n
