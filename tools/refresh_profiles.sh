@@ -40,6 +40,7 @@ timeout 300 python tools/bench_flow_graph.py > "$OUT/flow_graph.txt" 2>&1; tail 
 timeout 400 python tools/encoder_probe.py > "$OUT/encoder_probe.txt" 2>&1; tail -7 "$OUT/encoder_probe.txt"
 timeout 300 python tools/encoder_ab.py 2>/dev/null > "$OUT/encoder_ab.txt"; tail -9 "$OUT/encoder_ab.txt" | cut -c1-160
 timeout 200 python tools/encoder_lds_vs_tiled.py 2>/dev/null > "$OUT/encoder_lds_vs_tiled.txt"; tail -3 "$OUT/encoder_lds_vs_tiled.txt"
+timeout 200 python tools/encoder_fused_sampler.py 2>/dev/null > "$OUT/encoder_fused_sampler.txt"; tail -5 "$OUT/encoder_fused_sampler.txt"
 timeout 200 python tools/sustained_probe.py > "$OUT/sustained_probe.txt" 2>&1; tail -6 "$OUT/sustained_probe.txt"
 bash tools/pmc_ceilings.sh ceilings > "$OUT/ceilings.log" 2>&1; tail -10 "$OUT/ceilings.log"
 bash tools/pmc_passes.sh pmc_small python tools/pmc_small_mixture.py > "$OUT/pmc_small.log" 2>&1
