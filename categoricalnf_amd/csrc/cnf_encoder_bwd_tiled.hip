@@ -284,6 +284,9 @@ __global__ __launch_bounds__(kBlock) void encoder_bwd_class_kernel(EncBwdTiledAr
     const long per = ((b.ntok + b.S - 1) / b.S + STAGE - 1) / STAGE * STAGE;
     const long t0 = (long)blockIdx.y * per, t1 = min(t0 + per, b.ntok);
     const float inv_sigma = 1.f / b.sigma;
+    float s1[DM], s2[DM], sgv = 0.f;               // sum of tanh gv, of tanh gv z, of gv over this lane's (token, class) pairs
+#pragma unroll
+    for (int d = 0; d < DM; ++d) { s1[d] = 0.f; s2[d] = 0.f; }
     float pf[NPF];
     auto fetch = [&](long ts0) {
         const int n = (int)min<long>(STAGE, t1 - ts0) * R;
@@ -333,17 +336,24 @@ __global__ __launch_bounds__(kBlock) void encoder_bwd_class_kernel(EncBwdTiledAr
             }
             const float v = cst2 - fmaf(2.f, __builtin_amdgcn_logf(prod), acc);
             const float gv = -rec[3 * D + 1] * __builtin_amdgcn_exp2f(v - rec[3 * D]);  // d loss / d v_j = -beta G q_j
+            // d v_j / d bias = tanh / sigma;  d v_j / d ts = tanh z e^{-ts} / sigma - 1  (A ln2 = e^{-ts} / sigma): the
+            // per-class constants (1 / sigma, ln2 A_d, the -1) are applied ONCE to the sums, after the token loop
+            sgv += gv;
 #pragma unroll
             for (int d = 0; d < D; ++d) {
-                // d v_j / d bias = tanh / sigma;  d v_j / d ts = tanh z e^{-ts} / sigma - 1  (A ln2 = e^{-ts} / sigma)
                 const float tg = th[d] * gv;
-                gb[d] = fmaf(tg, inv_sigma, gb[d]);
-                gt[d] += fmaf(tg * kLn2, rec[d] * A[d], -gv);
+                s1[d] += tg;
+                s2[d] = fmaf(tg, rec[d], s2[d]);
             }
         }
         }
         if (more) put(stage + (size_t)(sidx ^ 1) * STAGE * R, ts0 + STAGE);
         __syncthreads();                                 // the other buffer is complete; this one may be overwritten next time
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        gb[d] = fmaf(s1[d], inv_sigma, gb[d]);
+        gt[d] += fmaf(s2[d] * kLn2, A[d], -sgv);
     }
     // combine the token lanes of a class in lane order, then through tanh to the raw scale
     if (TL > 1) {
