@@ -29,6 +29,13 @@ struct EncArgs {
     int eps_is_u;
     float u_squeeze;
     float* eps_out;
+    // ActNorm + 1x1 convolution of the first flow step applied to the latents before they are written
+    // (cnf_encoder_forward_actconv); null e_w = no epilogue
+    const float* e_bias;
+    const float* e_scales;
+    const float* e_w;
+    const float* e_sldj;
+    const float* e_length;
 };
 
 constexpr float kLog2e = 1.4426950408889634f;

@@ -117,14 +117,34 @@ __device__ __forceinline__ float lse2_of_classes(const float* tab, int stride, c
     return m + __builtin_amdgcn_logf(s);
 }
 
-template <int DT, bool SAMPLE>
+// EPI: the ActNorm + 1x1 convolution of the flow step that follows the encoder (every flow of the reference starts with
+// that pair) applied to the token's latents while they are in registers — activation_normalization.py:24-48,
+// permutation_layers.py:106-136 in the arithmetic and order of actnorm_invconv_kernel (cnf_linear.hip), so the result is
+// the chain's, bit for bit; the [B,N,D] round trip between the two kernels (8 B/elem) and a launch disappear.  The class
+// posterior is taken at the encoder's own latents, as in the chain.
+template <int DT, bool SAMPLE, bool EPI = false>
 __global__ __launch_bounds__(kBlock) void encoder_forward_kernel(EncArgs a, RowTiling tl) {
+    static_assert(!EPI || DT > 0, "the epilogue is built for the templated dimensions");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* part_all = reinterpret_cast<float*>(smem);
     float* tab = part_all + kWavesPerBlock * kMaxTileChunks;
-    build_class_table(a, tab);
     const int D = DT > 0 ? DT : a.D;
     const int stride = class_stride(D);
+    // epilogue constants behind the class table: [bias D | e^scales D | W D*D | sum of the scales]
+    float* etab = tab + (size_t)a.C * stride;
+    if (EPI) {
+        for (int i = threadIdx.x; i < D; i += kBlock) {
+            etab[i] = a.e_bias[i];
+            etab[D + i] = expf(a.e_scales[i]);
+        }
+        for (int i = threadIdx.x; i < D * D; i += kBlock) etab[2 * D + i] = a.e_w[i];
+        if (threadIdx.x == 0) {
+            float ssum = 0.f;
+            for (int i = 0; i < D; ++i) ssum += a.e_scales[i];
+            etab[2 * D + D * D] = ssum;
+        }
+    }
+    build_class_table(a, tab);          // ends with a barrier: the epilogue constants are visible as well
     bool bad = false;
 
     auto chunk = [&](int row, int n) -> float {
@@ -171,16 +191,51 @@ __global__ __launch_bounds__(kBlock) void encoder_forward_kernel(EncArgs a, RowT
 #endif
         const float pv = a.pad ? a.pad[tok] : 1.f;
         if (a.cpl) a.cpl[tok] = cpl;
+        if (EPI) {
+            float xv[DT > 0 ? DT : 1];
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const float o = z[d] * pv;
-            bad |= isnan(o);
-            a.z_out[tok * D + d] = o;
+            for (int i = 0; i < DT; ++i) {
+                float y = (z[i] * pv + etab[i]) * etab[DT + i];
+                if (a.pad) y = y * pv;
+                xv[i] = y;
+            }
+#pragma unroll
+            for (int j = 0; j < DT; ++j) {
+                float acc = 0.f;
+#pragma unroll
+                for (int i = 0; i < DT; ++i) acc = fmaf(xv[i], etab[2 * DT + i * DT + j], acc);
+                if (a.pad) acc = acc * pv;
+                bad |= isnan(acc);
+                a.z_out[tok * D + j] = acc;
+            }
+        } else {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const float o = z[d] * pv;
+                bad |= isnan(o);
+                a.z_out[tok * D + d] = o;
+            }
         }
         return (a.beta * cpl - (init_lp - ldj_f)) * pv;
     };
     auto finish = [&](int row, float sum) {
-        const float v = (a.ldj_in ? a.ldj_in[row] : 0.f) + sum;
+        float v = (a.ldj_in ? a.ldj_in[row] : 0.f) + sum;
+        if (EPI) {
+            // log-det of the two layers, same association as run in sequence: ActNorm uses length | sum(pad) | N, the
+            // convolution length | N (actnorm_invconv_kernel)
+            float len_a, len_c;
+            if (a.e_length) {
+                len_a = len_c = a.e_length[row];
+            } else {
+                len_c = (float)a.N;
+                len_a = (float)a.N;
+                if (a.pad) {
+                    len_a = 0.f;
+                    for (int n = 0; n < a.N; ++n) len_a += a.pad[(size_t)row * a.N + n];
+                }
+            }
+            v = (v + etab[2 * D + D * D] * len_a) + a.e_sldj[0] * len_c;
+        }
         a.ldj_out[row] = v;
         if (isnan(v)) raise_flag(a.flags, CNF_FLAG_NAN_LDJ);
     };
@@ -826,19 +881,28 @@ static int encoder_forward_impl(const int64_t* categ, const float* eps, const fl
                                 const float* category_prior, const float* pad, float beta,
                                 const float* ldj_in, float* z_out, float* ldj_out, float* class_prob_log,
                                 int B, int N, int D, int C, float sigma, float log_sigma,
-                                int* flags, cnf_stream_t stream, int eps_is_u, float u_squeeze, float* eps_out) {
+                                int* flags, cnf_stream_t stream, int eps_is_u, float u_squeeze, float* eps_out,
+                                const float* e_bias = nullptr, const float* e_scales = nullptr, const float* e_w = nullptr,
+                                const float* e_sldj = nullptr, const float* e_length = nullptr) {
     CNF_REQUIRE(categ && eps && table && category_prior && z_out && ldj_out, "cnf_encoder_forward: null tensor");
     CNF_REQUIRE(B >= 0 && N > 0 && D > 0 && C > 0, "cnf_encoder_forward: bad shape");
     if (B == 0) return CNF_OK;
     CNF_REQUIRE(D <= kEncMaxD, "cnf_encoder_forward: D=%d exceeds %d", D, kEncMaxD);
     CNF_REQUIRE(N < 65536, "cnf_encoder_forward: N=%d exceeds 65535", N);
-    const size_t smem = (size_t)kWavesPerBlock * kMaxTileChunks * sizeof(float) + table_bytes(C, D);
+    const bool epi = e_w != nullptr;
+    const size_t smem = (size_t)kWavesPerBlock * kMaxTileChunks * sizeof(float) + table_bytes(C, D) +
+                        (epi ? (size_t)(2 * D + D * D + 1) * sizeof(float) : 0);
     if (smem > 64 * 1024) { set_error("cnf_encoder_forward: class table for C=%d D=%d exceeds LDS", C, D); return CNF_ERR_UNSUPPORTED; }
+    if (epi && !(eps_is_u && e_bias && e_scales && e_sldj && (D <= 6 || D == 8))) {
+        set_error("cnf_encoder_forward_actconv: the epilogue is built for the sampled forward and D in {1,2,3,4,5,6,8}");
+        return CNF_ERR_UNSUPPORTED;
+    }
     EncArgs a = {};
     a.categ = categ; a.eps = eps; a.table = table; a.prior = category_prior; a.pad = pad;
     a.ldj_in = ldj_in; a.z_out = z_out; a.ldj_out = ldj_out; a.cpl = class_prob_log; a.flags = flags;
     a.B = B; a.N = N; a.D = D; a.C = C; a.beta = beta; a.sigma = sigma; a.log_sigma = log_sigma;
     a.eps_is_u = eps_is_u; a.u_squeeze = u_squeeze; a.eps_out = eps_out;
+    a.e_bias = e_bias; a.e_scales = e_scales; a.e_w = e_w; a.e_sldj = e_sldj; a.e_length = e_length;
     // Tokens per wave tile.  Interleaved runs on one MI355X after the density-sum loop (B=16384, N=64, D=6; us at tiles of
     // 64 / 128 / 256 tokens): 3 classes 14.4 / 12.9 / 14.1, 9 classes 19.2 / 18.3 / 19.2, 16 classes 25.1 / 25.1 / 26.4,
     // 32 classes 37.7 / 39.0 / 41.6, 51 classes 55.0 / 57.0 / 61.3 (rounds 1-3 used 256): one token per lane once the class
@@ -867,7 +931,7 @@ static int encoder_forward_impl(const int64_t* categ, const float* eps, const fl
     // 55.0 vs 55.0, 32: 37.7 vs 37.8, 16: 25.1 vs 26.3, 9: 18.3 vs 20.7; D = 8, 16 classes: 29.3 vs 29.3), so the pair kernel
     // is no longer selected automatically: it stays as the independent second implementation the bit-identity tests run
     // against (cnf_set_encoder_kernel(2)).
-    const bool want_pair = g_encoder_kernel == 2;
+    const bool want_pair = g_encoder_kernel == 2 && !epi;
     const bool pair = want_pair && pair_has_d(D) && !tl.bpr && tl.rw >= 2 && ((long)tl.rw * N) % 2 == 0 &&
                       smem_pair <= 64 * 1024 && aligned_to(eps, va) && aligned_to(eps_out, va) && aligned_to(z_out, va) && aligned_to(categ, 15) &&
                       aligned_to(pad, 7) && aligned_to(class_prob_log, 7);
@@ -876,7 +940,17 @@ static int encoder_forward_impl(const int64_t* categ, const float* eps, const fl
         DISPATCH_PAIR_D(D, CNF_LAUNCH((encoder_forward_pair_kernel<DT>), tiling_grid(tl), dim3(kBlock), smem_pair,
                                       (hipStream_t)stream, a, tl));
     } else {
-        if (eps_is_u) {
+        if (epi) {
+            switch (D) {
+                case 1: CNF_LAUNCH((encoder_forward_kernel<1, true, true>), tiling_grid(tl), dim3(kBlock), smem, (hipStream_t)stream, a, tl); break;
+                case 2: CNF_LAUNCH((encoder_forward_kernel<2, true, true>), tiling_grid(tl), dim3(kBlock), smem, (hipStream_t)stream, a, tl); break;
+                case 3: CNF_LAUNCH((encoder_forward_kernel<3, true, true>), tiling_grid(tl), dim3(kBlock), smem, (hipStream_t)stream, a, tl); break;
+                case 4: CNF_LAUNCH((encoder_forward_kernel<4, true, true>), tiling_grid(tl), dim3(kBlock), smem, (hipStream_t)stream, a, tl); break;
+                case 5: CNF_LAUNCH((encoder_forward_kernel<5, true, true>), tiling_grid(tl), dim3(kBlock), smem, (hipStream_t)stream, a, tl); break;
+                case 6: CNF_LAUNCH((encoder_forward_kernel<6, true, true>), tiling_grid(tl), dim3(kBlock), smem, (hipStream_t)stream, a, tl); break;
+                default: CNF_LAUNCH((encoder_forward_kernel<8, true, true>), tiling_grid(tl), dim3(kBlock), smem, (hipStream_t)stream, a, tl); break;
+            }
+        } else if (eps_is_u) {
             DISPATCH_D(D, CNF_LAUNCH((encoder_forward_kernel<DT, true>), tiling_grid(tl), dim3(kBlock), smem,
                                      (hipStream_t)stream, a, tl));
         } else {
@@ -907,6 +981,23 @@ int cnf_encoder_forward_sampled(const int64_t* categ, const float* u, float sque
     }
     return encoder_forward_impl(categ, u, table, category_prior, pad, beta, ldj_in, z_out, ldj_out, class_prob_log,
                                 B, N, D, C, sigma, log_sigma, flags, stream, 1, squeeze_eps, eps_out);
+}
+
+int cnf_encoder_forward_actconv(const int64_t* categ, const float* u, float squeeze_eps, const float* table,
+                                const float* category_prior, const float* pad, float beta,
+                                const float* act_bias, const float* act_scales, const float* conv_weight, const float* conv_sldj,
+                                const float* length,
+                                const float* ldj_in, float* z_out, float* ldj_out,
+                                int B, int N, int D, int C, float sigma, float log_sigma,
+                                int* flags, cnf_stream_t stream) {
+    CNF_REQUIRE(act_bias && act_scales && conv_weight && conv_sldj, "cnf_encoder_forward_actconv: null tensor");
+    if (math_mode() != 1) {
+        set_error("cnf_encoder_forward_actconv: the fused sampler is the fp32 one of math mode 1; run the layers separately");
+        return CNF_ERR_UNSUPPORTED;
+    }
+    return encoder_forward_impl(categ, u, table, category_prior, pad, beta, ldj_in, z_out, ldj_out, nullptr,
+                                B, N, D, C, sigma, log_sigma, flags, stream, 1, squeeze_eps, nullptr,
+                                act_bias, act_scales, conv_weight, conv_sldj, length);
 }
 
 int cnf_encoder_decode(const float* z, const float* table, const float* category_prior,

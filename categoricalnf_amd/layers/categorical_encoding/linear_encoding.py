@@ -122,6 +122,20 @@ class LinearCategoricalEncoding(FlowLayer):
         ldj = ldj + ldj_loc if ldj is not None else ldj_loc
         return z_out, ldj, detailed_ldj
 
+    def fusable_with_actconv(self):
+        """FlowModel may run this layer together with the ActNorm + 1x1 convolution behind it: the one-kernel mixture-model
+        encoder in evaluation mode (training mode reports statistics of the encoder's own latents, :95-106)."""
+        return self._is_mixture_model() and not self.training
+
+    def forward_with_actconv(self, z, act_bias, act_scales, conv_weight, conv_sldj, ldj=None, beta=1, channel_padding_mask=None,
+                             length=None, noise=None):
+        """forward() followed by ActNormFlow.forward and InvertibleConv.forward of the next flow step, as one kernel
+        (cnf_encoder_forward_actconv); returns (latents after the convolution, running log-det)."""
+        u = self._uniform_draw(z.size(0) * z.size(1), z.device, noise)
+        return ops.encoder_forward_actconv(z, u, self.class_table(), self.category_prior, act_bias, act_scales, conv_weight,
+                                           conv_sldj, beta=float(beta), channel_padding_mask=channel_padding_mask,
+                                           length=length, ldj=ldj, uniform_squeeze=float(self.prior_distribution.eps))
+
     def _train_stats(self, z_out, class_prob_log, channel_padding_mask):
         """Monitoring scalars of the reference's train mode (:95-106); global reductions over the
         batch, not part of the likelihood — plain torch reductions on the device."""

@@ -34,11 +34,15 @@ class FlowModel(nn.Module):
         if reverse:
             order.reverse()
         per_layer = []
-        fuse = self._fusable(z, get_ldj_per_layer)
+        fusable = self._fusable(z, get_ldj_per_layer)
         skip = set()
         for pos, (index, layer) in enumerate(order):
             if index in skip:
                 continue
+            # the fusions of latents-in, latents-out layers need float32 latents AT THIS POINT of the pass (a flow that starts
+            # with the categorical encoder is handed int64 categories: until round 3 that switched every fusion of the
+            # encoding direction off, because the test looked at the pass's input only)
+            fuse = fusable and z.dtype == torch.float32
             if (fuse and not reverse and pos + 2 < len(order) and type(layer).__name__ == "MixtureCDFCoupling"
                     and type(order[pos + 1][1]) is ActNormFlow and type(order[pos + 2][1]) is InvertibleConv
                     and layer.c_in in ops.FUSED_ACTCONV_DIMS):
@@ -54,6 +58,19 @@ class FlowModel(nn.Module):
                     scaling_factor=layer.scaling_factor, mixture_scaling_factor=layer.mixture_scaling_factor,
                     channel_padding_mask=pad, length=kwargs.get("length", None), reg_max=layer.regularizer_max,
                     reg_factor=layer.regularizer_factor, is_training=layer.training, ldj=ldj, want_reg=False)
+                skip.update((order[pos + 1][0], order[pos + 2][0]))
+                continue
+            if (fusable and not reverse and pos + 2 < len(order) and type(layer).__name__ == "LinearCategoricalEncoding"
+                    and not z.is_floating_point()
+                    and type(order[pos + 1][1]) is ActNormFlow and type(order[pos + 2][1]) is InvertibleConv
+                    and layer.fusable_with_actconv() and order[pos + 1][1].c_in in ops.FUSED_ACTCONV_DIMS):
+                # encoder + ActNorm + 1x1 conv of the first flow step in ONE kernel: the latents go to HBM once, already
+                # transformed (same arithmetic as the three layers, bit for bit)
+                act, conv = order[pos + 1][1], order[pos + 2][1]
+                weight, sldj = conv._get_weight(device_name=str(z.device), inverse=False)
+                z, ldj = layer.forward_with_actconv(z, act.bias, act.scales, weight, sldj, ldj=ldj, beta=kwargs.get("beta", 1),
+                                                    channel_padding_mask=kwargs.get("channel_padding_mask", None),
+                                                    length=kwargs.get("length", None), noise=kwargs.get("noise", None))
                 skip.update((order[pos + 1][0], order[pos + 2][0]))
                 continue
             if fuse and pos + 1 < len(order):
@@ -140,7 +157,7 @@ class FlowModel(nn.Module):
     def _fusable(self, z, get_ldj_per_layer):
         """Layer fusion only where it is unobservable: no autograd, no per-layer log-det report, CUDA tensors."""
         return (not get_ldj_per_layer and not torch.is_grad_enabled() and isinstance(z, torch.Tensor) and z.is_cuda
-                and z.dtype == torch.float32 and ops.FUSE_LAYERS)
+                and ops.FUSE_LAYERS)
 
     def reverse(self, z):
         """The inverse pass.  (The reference's one-liner, flow_model.py:56-57, passes an undefined name and can only

@@ -681,6 +681,52 @@ def encoder_forward(categ, eps, table, category_prior, beta=1.0, channel_padding
     return z, ldj_out, cpl
 
 
+def encoder_forward_actconv(categ, uniform, table, category_prior, act_bias, act_scales, conv_weight, conv_sldj,
+                            beta=1.0, channel_padding_mask=None, length=None, ldj=None, uniform_squeeze=1e-4,
+                            sigma=LOGISTIC_SIGMA, log_sigma=LOGISTIC_LOG_SIGMA):
+    """The sampled encoder forward + the ActNorm and 1x1 convolution of the flow step behind it in ONE kernel
+    (cnf_encoder_forward_actconv); where that kernel does not apply (class table beyond LDS, D outside
+    FUSED_ACTCONV_DIMS, math mode 0) the same layers run one after the other — same bits either way.
+    Returns (z after the convolution, running log-det)."""
+    dev = _dev(categ)
+    if categ.dtype != torch.int64:
+        categ = categ.long()
+    categ = categ.contiguous()
+    B, N = categ.shape
+    table = _f32(table, "table")
+    C, D = table.shape[0], table.shape[1] // 2
+    if D in FUSED_ACTCONV_DIMS and not encoder_prefers_tiled_forward(C, D, B, N):
+        u = _f32(uniform, "uniform")
+        if u.numel() != B * N * D:
+            raise ValueError("noise must have B*N*D entries")
+        prior = _f32(category_prior, "category_prior")
+        pad = _pad2d(channel_padding_mask, B, N, dev)
+        b, s = _f32(act_bias.reshape(-1), "bias"), _f32(act_scales.reshape(-1), "scales")
+        w, sl = _f32(conv_weight, "weight"), _f32(conv_sldj.reshape(1), "sldj")
+        ln = _length(length, B, dev) if isinstance(length, torch.Tensor) else None
+        ldj_in, ldj_out = _ldj_io(ldj, B, dev, inplace=False)
+        z = torch.empty(B, N, D, dtype=torch.float32, device=dev)
+        fn = _lib.load().cnf_encoder_forward_actconv
+        args = (_ptr(categ), _ptr(u), float(uniform_squeeze), _ptr(table), _ptr(prior), _ptr(pad), float(beta),
+                _ptr(b), _ptr(s), _ptr(w), _ptr(sl), _ptr(ln), _ptr(ldj_in), _ptr(z), _ptr(ldj_out), B, N, D, C,
+                float(sigma), float(log_sigma), _ptr(flag_word(dev)), _stream(dev))
+        if dev.index is not None and dev.index != torch.cuda.current_device():
+            with torch.cuda.device(dev):
+                status = fn(*args)
+        else:
+            status = fn(*args)
+        if status == _lib.CNF_OK:
+            _after(dev, "categorical encoder + ActNorm + InvertibleConv")
+            return z, ldj_out
+        if status != _lib.CNF_ERR_UNSUPPORTED:
+            _lib.check(status, "cnf_encoder_forward_actconv")
+    z, ldj_enc, _ = encoder_forward(categ, uniform, table, category_prior, beta=beta, channel_padding_mask=channel_padding_mask,
+                                    sigma=sigma, log_sigma=log_sigma, uniform_squeeze=uniform_squeeze)
+    ldj_run = ldj_enc if ldj is None else ldj + ldj_enc
+    return actnorm_invconv(z, act_bias, act_scales, conv_weight, conv_sldj, length=length,
+                           channel_padding_mask=channel_padding_mask, ldj=ldj_run)
+
+
 def encoder_decode(z, table, category_prior, sigma=LOGISTIC_SIGMA, log_sigma=LOGISTIC_LOG_SIGMA, tiled=None):
     z = _f32(z, "z")
     dev = z.device

@@ -338,6 +338,20 @@ int cnf_encoder_forward_sampled(const int64_t* categ, const float* u, float sque
                                 int B, int N, int D, int C, float sigma, float log_sigma,
                                 int* flags, cnf_stream_t stream);
 
+/* The sampled encoder forward with the ActNorm + 1x1 convolution of the flow step that follows it applied to the latents
+ * before they are written (activation_normalization.py:24-48, permutation_layers.py:106-136; every flow of the reference
+ * starts with that pair): the results of cnf_encoder_forward_sampled followed by cnf_actnorm_invconv (forward), bit for bit,
+ * in one launch and without the [B,N,D] round trip between them.  ldj_out = ldj_in + encoder log-det + both layers' log-det
+ * (ActNorm over `length` | sum(pad) | N, the convolution over `length` | N).  D in {1,2,3,4,5,6,8} and a class table that
+ * fits LDS, math mode 1; otherwise CNF_ERR_UNSUPPORTED (run the layers separately). */
+int cnf_encoder_forward_actconv(const int64_t* categ, const float* u, float squeeze_eps, const float* table,
+                                const float* category_prior, const float* pad, float beta,
+                                const float* act_bias, const float* act_scales, const float* conv_weight, const float* conv_sldj,
+                                const float* length,
+                                const float* ldj_in, float* z_out, float* ldj_out,
+                                int B, int N, int D, int C, float sigma, float log_sigma,
+                                int* flags, cnf_stream_t stream);
+
 int cnf_encoder_decode(const float* z, const float* table, const float* category_prior,
                        int64_t* categ_out, int B, int N, int D, int C, float sigma, float log_sigma,
                        cnf_stream_t stream);

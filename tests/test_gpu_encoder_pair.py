@@ -280,3 +280,56 @@ def test_encoder_module_trains_through_the_fused_sampler():
     assert torch.equal(z, z2) and torch.equal(ldj, ldj2)
     for n, p in enc.named_parameters():
         assert torch.equal(p.grad, grads[n]), n
+
+
+@pytest.mark.parametrize("B,N,D,C,padded,use_len", [(2048, 64, 6, 16, 0, 0), (300, 16, 4, 16, 1, 1), (77, 20, 2, 3, 1, 0), (9, 5, 5, 7, 0, 1),
+                                                    (2048, 16, 8, 51, 1, 1), (4, 7, 3, 9, 0, 0), (6, 12, 6, 700, 1, 1)])
+def test_encoder_actconv_kernel_gives_the_bits_of_the_three_layers(B, N, D, C, padded, use_len):
+    """cnf_encoder_forward_actconv (sampled encoder forward + ActNorm + 1x1 convolution in one launch) against the chain
+    cnf_encoder_forward_sampled -> cnf_actnorm_invconv: latents and running log-det bit-identical, with and without a padding
+    mask / a length vector; a vocabulary beyond the LDS-resident table takes the chain inside the wrapper."""
+    lib, ops = _setup()
+    dev = torch.device("cuda:0")
+    categ, _, table, prior, pad, ldj = _inputs(B, N, D, C, 3 + B + C, padded, dev)
+    g = torch.Generator(device=dev).manual_seed(B + 1)
+    u = torch.rand(B * N, D, generator=g, device=dev)
+    bias, scales = torch.randn(1, 1, D, generator=g, device=dev), 0.2 * torch.randn(1, 1, D, generator=g, device=dev)
+    w = torch.linalg.qr(torch.randn(D, D))[0].to(dev) + 0.05 * torch.randn(D, D, generator=g, device=dev)
+    sldj = torch.randn((), generator=g, device=dev)
+    length = torch.randint(max(1, N // 2), N + 1, (B,), generator=g, device=dev).float() if use_len else None
+    z1, l1, _ = ops.encoder_forward(categ, u, table, prior, beta=1.1, channel_padding_mask=pad, uniform_squeeze=1e-4)
+    zc, lc = ops.actnorm_invconv(z1, bias, scales, w, sldj, length=length, channel_padding_mask=pad, ldj=ldj + l1)
+    zf, lf = ops.encoder_forward_actconv(categ, u, table, prior, bias, scales, w, sldj, beta=1.1, channel_padding_mask=pad,
+                                         length=length, ldj=ldj, uniform_squeeze=1e-4)
+    assert torch.equal(zf, zc) and torch.equal(lf, lc)
+    ops.check_flags(dev, "encoder + actconv")
+
+
+def test_flow_model_fuses_the_encoding_direction_of_a_real_model(monkeypatch):
+    """A set-modelling flow (encoder, then ActNorm / 1x1 conv / mixture coupling steps) evaluated from int64 categories: the
+    fused kernels run in the ENCODING direction too (until round 3 the fusion test looked at the dtype of the pass's input
+    and switched them all off there) and give the bits of the layer-by-layer pass."""
+    from categoricalnf_amd import ops as O
+    from categoricalnf_amd.experiments.set_modeling import FlowSetModeling, SetShufflingDataset
+    torch.manual_seed(0)
+    params = {"set_size": 16, "coupling_hidden_layers": 1, "coupling_hidden_size": 32, "coupling_num_flows": 3, "coupling_mask_ratio": 0.5,
+              "coupling_num_mixtures": 8,
+              "categ_encoding": {"use_dequantization": False, "use_variational": False, "use_decoder": False, "num_dimensions": 4,
+                                 "flow_config": {"num_flows": 0, "hidden_layers": 2, "hidden_size": 64},
+                                 "decoder_config": {"num_layers": 1, "hidden_size": 64}}}
+    model = FlowSetModeling(params, SetShufflingDataset).cuda().eval()
+    for p in model.parameters():
+        p.data.normal_(0.0, 0.1)
+    x = torch.randint(0, model.vocab_size, (64, 16), device="cuda")
+    ln = torch.full((64,), 16, dtype=torch.long, device="cuda")
+    u = torch.rand(64 * 16, 1, 4, device="cuda")
+    calls = {"enc": 0, "three": 0}
+    real_enc, real_three = O.encoder_forward_actconv, O.mixture_coupling_actconv
+    monkeypatch.setattr(O, "encoder_forward_actconv", lambda *a, **k: (calls.__setitem__("enc", calls["enc"] + 1), real_enc(*a, **k))[1])
+    monkeypatch.setattr(O, "mixture_coupling_actconv", lambda *a, **k: (calls.__setitem__("three", calls["three"] + 1), real_three(*a, **k))[1])
+    with torch.no_grad():
+        z, ldj = model(x, reverse=False, length=ln, noise=u)
+        monkeypatch.setattr(O, "FUSE_LAYERS", False)
+        z0, ldj0 = model(x, reverse=False, length=ln, noise=u)
+    assert calls["enc"] == 1 and calls["three"] >= 1, calls
+    assert torch.equal(z, z0) and torch.equal(ldj, ldj0)
