@@ -53,6 +53,7 @@ SIGNATURES = {
     "cnf_prior_nll": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _p],
     "cnf_encoder_forward": [_p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p, _p],
     "cnf_encoder_forward_sampled": [_p, _p, _f, _p, _p, _p, _f, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p, _p],
+    "cnf_encoder_decode_actconv": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p, _p],
     "cnf_encoder_forward_actconv": [_p, _p, _f, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p, _p],
     "cnf_encoder_decode": [_p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
     "cnf_encoder_forward_tiled": [_p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p, _p],

@@ -243,17 +243,53 @@ __global__ __launch_bounds__(kBlock) void encoder_forward_kernel(EncArgs a, RowT
     if (bad) raise_flag(a.flags, CNF_FLAG_NAN_Z);
 }
 
-template <int DT>
+// EPI: the sampling direction's last three layers in one launch — the inverse 1x1 convolution and the inverse ActNorm of
+// the first flow step (permutation_layers.py:106-136, activation_normalization.py:24-48 with reverse = True) applied to the
+// token's latents as they are loaded, arithmetic and order of actnorm_invconv_kernel (cnf_linear.hip, reverse), then the
+// arg-max decode; the running log-det gets the two layers' terms (the decode itself adds zero, linear_encoding.py:108-118).
+template <int DT, bool EPI = false>
 __global__ __launch_bounds__(kBlock) void encoder_decode_kernel(EncArgs a, long ntok) {
+    static_assert(!EPI || DT > 0, "the prologue is built for the templated dimensions");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* tab = reinterpret_cast<float*>(smem);
-    build_class_table(a, tab);
     const int D = DT > 0 ? DT : a.D;
     const int stride = class_stride(D);
+    float* etab = tab + (size_t)a.C * stride;          // [bias D | e^-scales D | W^-1 D*D | sum of the scales]
+    if (EPI) {
+        for (int i = threadIdx.x; i < D; i += kBlock) {
+            etab[i] = a.e_bias[i];
+            etab[D + i] = expf(-a.e_scales[i]);
+        }
+        for (int i = threadIdx.x; i < D * D; i += kBlock) etab[2 * D + i] = a.e_w[i];
+        if (threadIdx.x == 0) {
+            float ssum = 0.f;
+            for (int i = 0; i < D; ++i) ssum += a.e_scales[i];
+            etab[2 * D + D * D] = ssum;
+        }
+    }
+    build_class_table(a, tab);          // ends with a barrier
+    bool bad = false;
     for (long tok = (long)blockIdx.x * kBlock + threadIdx.x; tok < ntok; tok += (long)gridDim.x * kBlock) {
         float z[DT > 0 ? DT : kEncMaxD];
 #pragma unroll
         for (int d = 0; d < D; ++d) z[d] = a.z_in[tok * D + d];
+        if (EPI) {
+            const float p = a.pad ? a.pad[tok] : 1.f;
+            float xv[DT > 0 ? DT : 1];
+#pragma unroll
+            for (int i = 0; i < DT; ++i) xv[i] = z[i];
+#pragma unroll
+            for (int j = 0; j < DT; ++j) {
+                float acc = 0.f;
+#pragma unroll
+                for (int i = 0; i < DT; ++i) acc = fmaf(xv[i], etab[2 * DT + i * DT + j], acc);
+                if (a.pad) acc = acc * p;
+                acc = acc * etab[DT + j] - etab[j];
+                if (a.pad) acc = acc * p;
+                bad |= isnan(acc);
+                z[j] = acc;
+            }
+        }
         float best = -INFINITY;
         int arg = 0;
         for (int j = 0; j < a.C; ++j) {
@@ -264,6 +300,27 @@ __global__ __launch_bounds__(kBlock) void encoder_decode_kernel(EncArgs a, long 
             }
         }
         a.categ_out[tok] = (int64_t)arg;
+    }
+    if (EPI) {
+        if (bad) raise_flag(a.flags, CNF_FLAG_NAN_Z);
+        const float ssum = etab[2 * D + D * D], sl = a.e_sldj[0];
+        for (long b = (long)blockIdx.x * kBlock + threadIdx.x; b < a.B; b += (long)gridDim.x * kBlock) {
+            float len_a, len_c;
+            if (a.e_length) {
+                len_a = len_c = a.e_length[b];
+            } else {
+                len_c = (float)a.N;
+                if (a.pad) {
+                    len_a = 0.f;
+                    for (int n = 0; n < a.N; ++n) len_a += a.pad[b * a.N + n];
+                } else len_a = (float)a.N;
+            }
+            const float base = a.ldj_in ? a.ldj_in[b] : 0.f;
+            // the two layers in reverse, same association as actnorm_invconv_kernel; + 0: the decode's own (zero) term
+            const float v = ((base - sl * len_c) + (-ssum) * len_a) + 0.f;
+            a.ldj_out[b] = v;
+            if (isnan(v)) raise_flag(a.flags, CNF_FLAG_NAN_LDJ);
+        }
     }
 }
 
@@ -1032,6 +1089,40 @@ int cnf_encoder_decode(const float* z, const float* table, const float* category
 }
 
 
+
+int cnf_encoder_decode_actconv(const float* z, const float* act_bias, const float* act_scales, const float* conv_weight_inv,
+                               const float* conv_sldj, const float* pad, const float* length,
+                               const float* table, const float* category_prior,
+                               const float* ldj_in, int64_t* categ_out, float* ldj_out,
+                               int B, int N, int D, int C, float sigma, float log_sigma, int* flags, cnf_stream_t stream) {
+    CNF_REQUIRE(z && act_bias && act_scales && conv_weight_inv && conv_sldj && table && category_prior && categ_out && ldj_out,
+                "cnf_encoder_decode_actconv: null tensor");
+    CNF_REQUIRE(B >= 0 && N > 0 && D > 0 && C > 0, "cnf_encoder_decode_actconv: bad shape");
+    if (B == 0) return CNF_OK;
+    const size_t smem = table_bytes(C, D) + (size_t)(2 * D + D * D + 1) * sizeof(float);
+    if (!(D <= 6 || D == 8) || smem > 64 * 1024) {
+        set_error("cnf_encoder_decode_actconv: built for D in {1,2,3,4,5,6,8} and a class table that fits LDS (C=%d D=%d)", C, D);
+        return CNF_ERR_UNSUPPORTED;
+    }
+    EncArgs a = {};
+    a.z_in = z; a.table = table; a.prior = category_prior; a.categ_out = categ_out; a.pad = pad;
+    a.ldj_in = ldj_in; a.ldj_out = ldj_out; a.flags = flags;
+    a.e_bias = act_bias; a.e_scales = act_scales; a.e_w = conv_weight_inv; a.e_sldj = conv_sldj; a.e_length = length;
+    a.B = B; a.N = N; a.D = D; a.C = C; a.sigma = sigma; a.log_sigma = log_sigma;
+    const long ntok = (long)B * N;
+    const dim3 grid((unsigned)std::min<long>(std::max<long>((ntok + kBlock - 1) / kBlock, 1), 256 * 8)), block(kBlock);
+    hipStream_t st = (hipStream_t)stream;
+    switch (D) {
+        case 1: CNF_LAUNCH((encoder_decode_kernel<1, true>), grid, block, smem, st, a, ntok); break;
+        case 2: CNF_LAUNCH((encoder_decode_kernel<2, true>), grid, block, smem, st, a, ntok); break;
+        case 3: CNF_LAUNCH((encoder_decode_kernel<3, true>), grid, block, smem, st, a, ntok); break;
+        case 4: CNF_LAUNCH((encoder_decode_kernel<4, true>), grid, block, smem, st, a, ntok); break;
+        case 5: CNF_LAUNCH((encoder_decode_kernel<5, true>), grid, block, smem, st, a, ntok); break;
+        case 6: CNF_LAUNCH((encoder_decode_kernel<6, true>), grid, block, smem, st, a, ntok); break;
+        default: CNF_LAUNCH((encoder_decode_kernel<8, true>), grid, block, smem, st, a, ntok); break;
+    }
+    return launch_status("cnf_encoder_decode_actconv");
+}
 
 int64_t cnf_encoder_workspace_floats(int B, int N, int D, int C) {
     (void)D;

@@ -136,6 +136,16 @@ class LinearCategoricalEncoding(FlowLayer):
                                            conv_sldj, beta=float(beta), channel_padding_mask=channel_padding_mask,
                                            length=length, ldj=ldj, uniform_squeeze=float(self.prior_distribution.eps))
 
+    def decode_with_actconv(self, z, act_bias, act_scales, conv_weight_inv, conv_sldj, ldj=None, channel_padding_mask=None,
+                            length=None):
+        """InvertibleConv.forward(reverse=True) and ActNormFlow.forward(reverse=True) of the first flow step followed by
+        this layer's reverse pass (arg-max decode), as one kernel (cnf_encoder_decode_actconv); returns (categories,
+        running log-det)."""
+        assert z.size(-1) == self.D, \
+            "[!] ERROR in categorical decoding: Input must have %i latent dimensions but got %i" % (self.D, z.shape[-1])
+        return ops.encoder_decode_actconv(z, act_bias, act_scales, conv_weight_inv, conv_sldj, self.class_table().detach(),
+                                          self.category_prior, channel_padding_mask=channel_padding_mask, length=length, ldj=ldj)
+
     def _train_stats(self, z_out, class_prob_log, channel_padding_mask):
         """Monitoring scalars of the reference's train mode (:95-106); global reductions over the
         batch, not part of the likelihood — plain torch reductions on the device."""

@@ -73,6 +73,18 @@ class FlowModel(nn.Module):
                                                     length=kwargs.get("length", None), noise=kwargs.get("noise", None))
                 skip.update((order[pos + 1][0], order[pos + 2][0]))
                 continue
+            if (fuse and reverse and pos + 2 < len(order) and type(layer) is InvertibleConv and type(order[pos + 1][1]) is ActNormFlow
+                    and type(order[pos + 2][1]).__name__ == "LinearCategoricalEncoding" and order[pos + 2][1]._is_mixture_model()
+                    and order[pos + 1][1].c_in in ops.FUSED_ACTCONV_DIMS):
+                # sampling direction: inverse 1x1 conv + inverse ActNorm of the first flow step + the arg-max decode in ONE
+                # kernel (same arithmetic as the three layers, bit for bit)
+                act, enc = order[pos + 1][1], order[pos + 2][1]
+                weight, sldj = layer._get_weight(device_name=str(z.device), inverse=True)
+                z, ldj = enc.decode_with_actconv(z, act.bias, act.scales, weight, sldj, ldj=ldj,
+                                                 channel_padding_mask=kwargs.get("channel_padding_mask", None),
+                                                 length=kwargs.get("length", None))
+                skip.update((order[pos + 1][0], order[pos + 2][0]))
+                continue
             if fuse and pos + 1 < len(order):
                 pair = (layer, order[pos + 1][1]) if not reverse else (order[pos + 1][1], layer)
                 if type(pair[0]) is ActNormFlow and type(pair[1]) is InvertibleConv and pair[0].c_in in ops.FUSED_ACTCONV_DIMS:

@@ -745,6 +745,42 @@ def encoder_decode(z, table, category_prior, sigma=LOGISTIC_SIGMA, log_sigma=LOG
     return out
 
 
+def encoder_decode_actconv(z, act_bias, act_scales, conv_weight_inv, conv_sldj, table, category_prior,
+                           channel_padding_mask=None, length=None, ldj=None, sigma=LOGISTIC_SIGMA, log_sigma=LOGISTIC_LOG_SIGMA):
+    """The sampling direction's last three layers — inverse 1x1 convolution, inverse ActNorm, arg-max decode — in ONE
+    kernel (cnf_encoder_decode_actconv); where it does not apply the layers run one after the other, same bits.
+    Returns (int64 categories [B,N], running log-det)."""
+    z = _f32(z, "z")
+    dev = z.device
+    B, N, D = z.shape
+    table = _f32(table, "table")
+    C = table.shape[0]
+    if D in FUSED_ACTCONV_DIMS and encoder_fused_supported(C, D):
+        prior = _f32(category_prior, "category_prior")
+        pad = _pad2d(channel_padding_mask, B, N, dev)
+        b, s = _f32(act_bias.reshape(-1), "bias"), _f32(act_scales.reshape(-1), "scales")
+        w, sl = _f32(conv_weight_inv, "weight"), _f32(conv_sldj.reshape(1), "sldj")
+        ln = _length(length, B, dev) if isinstance(length, torch.Tensor) else None
+        ldj_in, ldj_out = _ldj_io(ldj, B, dev, inplace=False)
+        out = torch.empty(B, N, dtype=torch.int64, device=dev)
+        fn = _lib.load().cnf_encoder_decode_actconv
+        args = (_ptr(z), _ptr(b), _ptr(s), _ptr(w), _ptr(sl), _ptr(pad), _ptr(ln), _ptr(table), _ptr(prior), _ptr(ldj_in),
+                _ptr(out), _ptr(ldj_out), B, N, D, C, float(sigma), float(log_sigma), _ptr(flag_word(dev)), _stream(dev))
+        if dev.index is not None and dev.index != torch.cuda.current_device():
+            with torch.cuda.device(dev):
+                status = fn(*args)
+        else:
+            status = fn(*args)
+        if status == _lib.CNF_OK:
+            _after(dev, "InvertibleConv + ActNorm (reverse) + categorical decoding")
+            return out, ldj_out
+        if status != _lib.CNF_ERR_UNSUPPORTED:
+            _lib.check(status, "cnf_encoder_decode_actconv")
+    zz, ldj_run = actnorm_invconv(z, act_bias, act_scales, conv_weight_inv, conv_sldj, reverse=True, length=length,
+                                  channel_padding_mask=channel_padding_mask, ldj=ldj)
+    return encoder_decode(zz, table, category_prior, sigma=sigma, log_sigma=log_sigma), ldj_run + torch.zeros_like(ldj_run)
+
+
 def sigmoid_flow(z, reverse=False, ldj=None, alpha=1e-5):
     z = _f32(z, "z")
     dev = z.device

@@ -356,6 +356,17 @@ int cnf_encoder_decode(const float* z, const float* table, const float* category
                        int64_t* categ_out, int B, int N, int D, int C, float sigma, float log_sigma,
                        cnf_stream_t stream);
 
+/* The sampling direction's last three layers in one launch: InvertibleConv.forward(reverse=True) with the inverse weight
+ * (permutation_layers.py:106-136), ActNormFlow.forward(reverse=True) (activation_normalization.py:24-48) and the arg-max decode
+ * (linear_encoding.py:108-118,184-196): the results of cnf_actnorm_invconv(reverse = 1) followed by cnf_encoder_decode, bit for
+ * bit.  ldj_out = ldj_in - both layers' log-det (the decode adds zero).  D in {1,2,3,4,5,6,8} and a class table that fits
+ * LDS; otherwise CNF_ERR_UNSUPPORTED (run the layers separately). */
+int cnf_encoder_decode_actconv(const float* z, const float* act_bias, const float* act_scales, const float* conv_weight_inv,
+                               const float* conv_sldj, const float* pad, const float* length,
+                               const float* table, const float* category_prior,
+                               const float* ldj_in, int64_t* categ_out, float* ldj_out,
+                               int B, int N, int D, int C, float sigma, float log_sigma, int* flags, cnf_stream_t stream);
+
 /* A-B knob of the LDS-resident encoder kernels: 2 = two tokens per lane with 16-byte LDS constants wherever the shape
  * allows it (whole-row wave tiles of an even number of tokens, 16-byte aligned views, D in {1,2,3,4,6,8}), 1 = the
  * one-token-per-lane kernels (the fallback for every other shape), both on 256-token wave tiles; 0 (default) = by

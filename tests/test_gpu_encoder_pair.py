@@ -323,13 +323,43 @@ def test_flow_model_fuses_the_encoding_direction_of_a_real_model(monkeypatch):
     x = torch.randint(0, model.vocab_size, (64, 16), device="cuda")
     ln = torch.full((64,), 16, dtype=torch.long, device="cuda")
     u = torch.rand(64 * 16, 1, 4, device="cuda")
-    calls = {"enc": 0, "three": 0}
-    real_enc, real_three = O.encoder_forward_actconv, O.mixture_coupling_actconv
+    calls = {"enc": 0, "three": 0, "dec": 0}
+    real_enc, real_three, real_dec = O.encoder_forward_actconv, O.mixture_coupling_actconv, O.encoder_decode_actconv
+    monkeypatch.setattr(O, "encoder_decode_actconv", lambda *a, **k: (calls.__setitem__("dec", calls["dec"] + 1), real_dec(*a, **k))[1])
     monkeypatch.setattr(O, "encoder_forward_actconv", lambda *a, **k: (calls.__setitem__("enc", calls["enc"] + 1), real_enc(*a, **k))[1])
     monkeypatch.setattr(O, "mixture_coupling_actconv", lambda *a, **k: (calls.__setitem__("three", calls["three"] + 1), real_three(*a, **k))[1])
     with torch.no_grad():
         z, ldj = model(x, reverse=False, length=ln, noise=u)
+        zs = z + 0.1 * torch.randn_like(z)
+        xr, ldjr = model(zs, reverse=True, length=ln)
         monkeypatch.setattr(O, "FUSE_LAYERS", False)
         z0, ldj0 = model(x, reverse=False, length=ln, noise=u)
-    assert calls["enc"] == 1 and calls["three"] >= 1, calls
+        xr0, ldjr0 = model(zs, reverse=True, length=ln)
+    assert calls["enc"] == 1 and calls["three"] >= 1 and calls["dec"] == 1, calls
     assert torch.equal(z, z0) and torch.equal(ldj, ldj0)
+    assert torch.equal(xr, xr0) and torch.equal(ldjr, ldjr0)
+
+
+@pytest.mark.parametrize("B,N,D,C,padded,use_len", [(2048, 64, 6, 16, 0, 0), (300, 16, 4, 16, 1, 1), (77, 20, 2, 3, 1, 0), (9, 5, 5, 7, 0, 1),
+                                                    (2048, 16, 8, 51, 1, 1), (4, 7, 3, 9, 0, 0), (6, 12, 6, 700, 1, 1)])
+def test_decode_actconv_kernel_gives_the_bits_of_the_three_layers(B, N, D, C, padded, use_len):
+    """cnf_encoder_decode_actconv (inverse 1x1 conv + inverse ActNorm + arg-max decode in one launch) against the chain
+    cnf_actnorm_invconv(reverse) -> cnf_encoder_decode: decoded categories and running log-det bit-identical."""
+    lib, ops = _setup()
+    dev = torch.device("cuda:0")
+    categ, eps, table, prior, pad, ldj = _inputs(B, N, D, C, 13 + B + C, padded, dev)
+    g = torch.Generator(device=dev).manual_seed(B + 2)
+    zenc, _, _ = ops.encoder_forward(categ, eps, table, prior, tiled=False if ops.encoder_fused_supported(C, D) else True)
+    bias, scales = torch.randn(1, 1, D, generator=g, device=dev), 0.2 * torch.randn(1, 1, D, generator=g, device=dev)
+    w = torch.linalg.qr(torch.randn(D, D))[0].to(dev) + 0.05 * torch.randn(D, D, generator=g, device=dev)
+    sldj = torch.randn((), generator=g, device=dev)
+    length = torch.randint(max(1, N // 2), N + 1, (B,), generator=g, device=dev).float() if use_len else None
+    # latents a sampling pass would hand over: the forward pair applied to the encoder's output, plus noise
+    z, _ = ops.actnorm_invconv(zenc, bias, scales, w, sldj, channel_padding_mask=pad)
+    z = z + 0.2 * torch.randn(B, N, D, generator=g, device=dev)
+    w_inv = torch.inverse(w.double()).float()
+    zc, lc = ops.actnorm_invconv(z, bias, scales, w_inv, sldj, reverse=True, length=length, channel_padding_mask=pad, ldj=ldj)
+    dc = ops.encoder_decode(zc, table, prior)
+    df, lf = ops.encoder_decode_actconv(z, bias, scales, w_inv, sldj, table, prior, channel_padding_mask=pad, length=length, ldj=ldj)
+    assert torch.equal(df, dc) and torch.equal(lf, lc + torch.zeros_like(lc))
+    ops.check_flags(dev, "decode + actconv")
