@@ -44,7 +44,7 @@ constexpr int kEncMaxD = 16;
 
 // LogisticDistribution.sample given the uniform draw (distributions.py:139-145,117-127) in math mode 1: the expression of
 // logistic_icdf<true> in cnf_affine.hip (cnf_logistic_from_uniform), mu = 0 — kept literally the same so that the fused
-// sampler gives the bits of the two-kernel path (tests/test_gpu_encoder_pair.py pins that).
+// sampler gives the bits of the two-kernel path (tests/test_gpu_encoder_kernels.py pins that).
 __device__ __forceinline__ float enc_noise_from_uniform(float u, float sigma, float squeeze) {
     const float uf = (u * (1.f - squeeze)) + squeeze / 2.f;
     const float v = (__builtin_amdgcn_logf(uf) - __builtin_amdgcn_logf(1.f - uf)) * 0.6931471805599453f;

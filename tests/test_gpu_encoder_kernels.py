@@ -1,7 +1,11 @@
-"""Round-3 encoder kernels (two tokens per lane, 16-byte LDS constants) against the round-2 kernels they replace
-(cnf_set_encoder_kernel(2) vs (1)): same arithmetic per token, so latents, class posteriors, log-det and decoded indices must be
-BIT-identical (linear_encoding.py:59-133,153-196); the goldens and the oracle comparisons of test_gpu_parity.py run on
-whichever kernel the shape selects."""
+"""The mixture-model encoder's kernels against each other and against the oracle (linear_encoding.py:59-133,153-196):
+* two independent implementations of the LDS-resident kernels (one / two tokens per lane, cnf_set_encoder_kernel(1 / 2)) must agree
+  bit for bit — latents, class posteriors, log-det, decoded indices;
+* the forward's density sum and the class-tiled backward's, with their log-domain fallbacks, against the float64 oracle on
+  extreme inputs;
+* the fused entry points (sampler, ActNorm + 1x1 convolution behind the encoder / in front of the decode) against the chains of
+  calls they replace, bit for bit, and inside a real flow model.
+The goldens and the oracle comparisons of test_gpu_parity.py run on whichever kernel a shape selects."""
 import pytest
 import torch
 
