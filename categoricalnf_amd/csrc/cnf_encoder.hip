@@ -1113,7 +1113,7 @@ int cnf_encoder_decode_actconv(const float* z, const float* act_bias, const floa
     a.e_bias = act_bias; a.e_scales = act_scales; a.e_w = conv_weight_inv; a.e_sldj = conv_sldj; a.e_length = length;
     a.B = B; a.N = N; a.D = D; a.C = C; a.sigma = sigma; a.log_sigma = log_sigma;
     const long ntok = (long)B * N;
-    const dim3 grid((unsigned)std::min<long>(std::max<long>((ntok + kBlock - 1) / kBlock, 1), 256 * 8)), block(kBlock);
+    const dim3 grid((unsigned)std::min<long>(std::max<long>((ntok + kBlock - 1) / kBlock, 1), C >= 24 ? (1L << 22) : 256 * 8)), block(kBlock);
     hipStream_t st = (hipStream_t)stream;
     switch (D) {
         case 1: CNF_LAUNCH((encoder_decode_kernel<1, true>), grid, block, smem, st, a, ntok); break;
