@@ -68,6 +68,11 @@ void cnf_set_math_mode(int mode);
 void cnf_set_inverse_mode(int mode);
 /* Items (transformed elements) one wave of the fp32 mixture forward kernel owns, 64..512 (default 128). */
 void cnf_set_mixture_tile(int items);
+/* Flat tiles of the streaming backward kernels (csrc/cnf_backward.hip): 16-byte chunks a lane keeps in flight (1..3) and
+ * chunk groups one wave walks (1..64); 0 = every kernel's own default (2 chunks; 1 group, 2 for ActNorm / the 1x1 conv).  A tuning knob like the ones above: the reference has no
+ * counterpart (its backward is autograd, general/train.py:144-155).  All tuning knobs are process-wide atomics — set them
+ * before use; they are not per device or per thread. */
+void cnf_set_bwd_tile(int chunks_in_flight, int groups_per_tile);
 
 /* Kernel timing bound to the dispatch (bench.py's `roofline`; a timed launch costs ~4 us of queue time; the reference has no counterpart — its
  * only clock is the host-side time_per_step tracker, general/train.py:147-157).  cnf_prof_arm(n): the next n
@@ -83,6 +88,11 @@ int cnf_prof_collect(float* ms_out_host, int capacity);
  * element on this device ("a measured stream-copy ceiling from the same run").  No reference
  * counterpart. */
 int cnf_stream_probe(const float* a, const float* b, float* out, long n, int chunks_per_lane, cnf_stream_t stream);
+/* The same for the affine coupling's BACKWARD mix (tools/bwd_probe.py, bench.py's extra.kernels): a [n], b [2n], c [n]
+ * read, o1 [n], o2 [2n] written — 16 B read + 12 B written per element; chunks_per_lane in {1,2}; hint bit 0 / 1 / 2 =
+ * nontemporal loads of (a, b) / of c / nontemporal stores.  No reference counterpart. */
+int cnf_stream_probe_bwd(const float* a, const float* b, const float* c, float* o1, float* o2, long n,
+                         int chunks_per_lane, int hint, cnf_stream_t stream);
 
 /* ---- affine coupling -------------------------------------------------------------------- */
 
