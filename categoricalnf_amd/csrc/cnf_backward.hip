@@ -1206,9 +1206,11 @@ extern "C" {
 
 /* floats the caller must provide as `workspace` to the backward entry points that return parameter gradients: rows of
  * `param_count` (+ 1) partial sums — one per wave of the streaming kernels of this file (their rows are at most
- * kBwdMaxRowP wide), one per workgroup (at most 1024) for the mixture / encoder kernels — + one reduced row */
+ * kBwdMaxRowP wide), one per workgroup (at most 1024, twice for the mixture kernel and its fix-up launch) for the
+ * mixture / encoder kernels — + one reduced row + the fix-up launch's flag words */
 int64_t cnf_bwd_workspace_floats(int param_count) {
-    return (int64_t)((param_count <= kBwdMaxRowP ? kBwdMaxRows : 1024) + 1) * (param_count + 1);
+    // wide rows: 1024 partial rows + 1024 rows of the mixture fix-up launch + its 5 x 1024 flag words
+    return (int64_t)((param_count <= kBwdMaxRowP ? kBwdMaxRows : 2048) + 1) * (param_count + 1) + 8192;
 }
 
 void cnf_set_bwd_tile(int chunks_in_flight, int groups_per_tile) {

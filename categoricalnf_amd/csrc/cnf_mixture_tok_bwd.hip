@@ -20,10 +20,13 @@
 #include "cnf_mixture_tok.h"
 
 #include <algorithm>
+#include <atomic>
 
 namespace cnf {
 
 constexpr int kTokBwdGrid = 1024;       // rows of the partials buffer (cnf_bwd_workspace_floats)
+static std::atomic<int> g_tok_bwd_w4{-1};
+static inline int tok_bwd_w4() { return g_tok_bwd_w4.load(std::memory_order_relaxed); }
 
 struct TokBwdArgs {
     const float* g_zout;      // [B,N,D] or null
@@ -35,6 +38,9 @@ struct TokBwdArgs {
     int nacc;                 // run-time K: lane-private accumulator slots = 1 + ceil(K / G)
     int lacc_off;             // byte offset of the lane-private accumulators / the reduction scratch in dynamic LDS
     int wrow_off;             // byte offset of the per-wave parameter-gradient rows [4][PP]
+    float* fix_partials;      // [gridDim.x, D + D*K] rows of the fix-up launch (read for flagged workgroups only)
+    int* wave_flags;          // [gridDim.x * 4] 1 = the wave met a tail element
+    int* block_flags;         // [gridDim.x]
     long nunits;              // wave work units: tiles (whole rows) or (row, wave-of-row) pairs
     FastDiv div_ncp, div_span;   // by the zero-fill units per token ((D - DA) * P * 4 / wb_align); by DA * P * 4 bytes (one span)
 };
@@ -50,8 +56,192 @@ __device__ __forceinline__ void bound_grads_f(float raw, const BoundTab& b, floa
     d_sf = b.f >= 1.f ? b.f * (th - uu * sech2) : b.f * th;
 }
 
+// g_z of an element the streaming kernel left to the fix-up launch: a quiet NaN with this payload
+constexpr uint32_t kTailSentinel = 0x7fc0a11eu;
+
+// One tail element (token `tok`, channel d) redone by a whole wave in fp64 — the arithmetic of the fp64 kernel
+// (cnf_mixture_bwd.hip): lane k owns mixture k (k, k + 64, ... for K > 64), the four mixture sums are formed in mixture
+// order, every lane writes its mixture's three gradients to g_nn, lane 0 the element's g_z and the t / log_s slots.
+// Scaling-factor gradients are added to the wave's parameter row prow [D + D K] (one writer per word).
+__device__ __forceinline__ void tail_fixup(const MixArgs& a, const TokBwdArgs& w, const BoundTab* mt, const BoundTab* sf_tab,
+                                           size_t tok, int d, int K, int P, int lane, float* prow) {
+    const size_t e = tok * a.D + d;
+    const float* prm = a.nn + e * (size_t)P;
+    float* gprm = w.g_nn + e * (size_t)P;
+    const float pv = a.pad ? a.pad[tok] : 1.f;
+    const float outscale = a.pad_output ? pv : 1.f;
+    const double xd = (double)a.z[e];
+    const double gzd = w.g_zout ? (double)(w.g_zout[e] * outscale) : 0.0;
+    const double gld = w.g_ldj ? (double)w.g_ldj[tok / a.N] : 0.0;
+    const float t = prm[0], raw_ls = prm[1];
+    const float log_s = a.sf ? apply_bound(raw_ls, sf_tab[d]) : raw_ls;
+    float mx = -INFINITY;
+    for (int k = lane; k < K; k += kWave) mx = fmaxf(mx, prm[2 + k]);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m, kWave));
+    // the four mixture sums in the fp64 kernel's own order (k = 0, 1, 2, ...): beyond |logit| ~ 36 the value of 1 - u is
+    // rounding noise of these sums, and only the same order reproduces the fp64 kernel there
+    double sed = 0.0, cdfd = 0.0, pdfd = 0.0, dpdfd = 0.0;
+    for (int k0 = 0; k0 < K; k0 += kWave) {
+        const int k = k0 + lane;
+        double wd = 0.0, t_cdf = 0.0, t_pdf = 0.0, t_dpdf = 0.0;
+        if (k < K) {
+            const float lsf = a.msf ? apply_bound(prm[2 + 2 * K + k], mt[k]) : prm[2 + 2 * K + k];
+            wd = exp((double)prm[2 + k] - (double)mx);
+            const double isd = exp(-(double)lsf);
+            const double zd = (xd - (double)prm[2 + K + k]) * isd;
+            const double ed = exp(-fabs(zd));
+            const double rd = 1.0 / (1.0 + ed);
+            const double sg = zd >= 0.0 ? rd : ed * rd;
+            const double pk = ed * rd * rd * isd;
+            t_cdf = wd * sg;
+            t_pdf = wd * pk;
+            t_dpdf = wd * pk * (1.0 - 2.0 * sg) * isd;
+        }
+        const int nk = min(kWave, K - k0);
+        for (int l = 0; l < nk; ++l) {
+            sed += __shfl(wd, l, kWave);
+            cdfd += __shfl(t_cdf, l, kWave);
+            pdfd += __shfl(t_pdf, l, kWave);
+            dpdfd += __shfl(t_dpdf, l, kWave);
+        }
+    }
+    const double ud = cdfd / sed, pdf_n = pdfd / sed;
+    const double a_s = exp((double)log_s);
+    const double ucl = fmax(ud, 1e-22), u1cl = fmax(1.0 - ud, 1e-22);
+    const double lud = log(ucl), l1ud = log(u1cl);
+    const double dlu = ud > 1e-22 ? 1.0 / ud : 0.0;
+    const double dl1u = (1.0 - ud) > 1e-22 ? -1.0 / (1.0 - ud) : 0.0;
+    const double zt = ((lud - l1ud) + (double)t) * a_s;
+    double g_ud = gzd * a_s * (dlu - dl1u) + gld * (-dlu - dl1u);
+    if (a.use_reg) {
+        double dreg = 0.0;
+        if (lud / kLn10 <= -a.reg_max) dreg += dlu / kLn10;
+        if (l1ud / kLn10 <= -a.reg_max) dreg += dl1u / kLn10;
+        g_ud += gld * a.reg_factor * dreg;
+    }
+    const double inv_pdf = pdf_n > 1e-290 ? 1.0 / pdf_n : 0.0;
+    const float g_logs = (float)(gzd * zt + gld);
+    float d_raw0 = 1.f, d_sf0 = 0.f;
+    if (a.sf) bound_grads_f(raw_ls, sf_tab[d], d_raw0, d_sf0);
+    if (lane == 0) {
+        w.g_z[e] = (float)(g_ud * pdf_n + gld * (dpdfd / sed) * inv_pdf);
+        gprm[0] = (float)(gzd * a_s);
+        gprm[1] = g_logs * d_raw0;
+        prow[d] += g_logs * d_sf0;
+    }
+    for (int k = lane; k < K; k += kWave) {
+        const float raw = prm[2 + 2 * K + k];
+        float lsf = raw, d_raw = 1.f, d_sf = 0.f;
+        if (a.msf) {
+            lsf = apply_bound(raw, mt[k]);
+            bound_grads_f(raw, mt[k], d_raw, d_sf);
+        }
+        const double pi = exp((double)prm[2 + k] - (double)mx) / sed;
+        const double isd = exp(-(double)lsf);
+        const double zd = (xd - (double)prm[2 + K + k]) * isd;
+        const double ed = exp(-fabs(zd));
+        const double rd = 1.0 / (1.0 + ed);
+        const double sg = zd >= 0.0 ? rd : ed * rd;
+        const double s1s = ed * rd * rd;
+        const double pk = s1s * isd;
+        const double resp = pi * pk * inv_pdf;
+        const double g_lp = g_ud * pi * (sg - ud) + gld * (resp - pi);
+        const double g_mu = g_ud * (-pi * pk) + gld * (-resp * (1.0 - 2.0 * sg) * isd);
+        const double g_ls = g_ud * (-pi * zd * s1s) + gld * (resp * (-1.0 - zd * (1.0 - 2.0 * sg)));
+        gprm[2 + k] = (float)g_lp;
+        gprm[2 + K + k] = (float)g_mu;
+        gprm[2 + 2 * K + k] = (float)(g_ls * (double)d_raw);
+        prow[a.D + d * K + k] += (float)g_ls * d_sf;
+    }
+}
+
+// The fix-up launch: same grid and the same wave -> unit mapping as the streaming kernel.  A workgroup none of whose waves
+// met a tail returns at once (one load); a flagged wave walks its units again, finds its tail elements by their sentinel
+// g_z and redoes them one by one with tail_fixup.  Its parameter-gradient sums go to the workgroup's row of a second
+// partials region that the reduction adds for flagged workgroups only.
+__global__ __launch_bounds__(kBlock) void mixture_tok_bwd_fixup_kernel(MixArgs a, TokGeom gm, TokBwdArgs w) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (w.block_flags[blockIdx.x] == 0) return;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int K = a.K, P = a.P, PP = a.D + a.D * K;
+    BoundTab* sf_tab = reinterpret_cast<BoundTab*>(smem);
+    BoundTab* msf_tab = sf_tab + a.D;
+    float* rows = reinterpret_cast<float*>(msf_tab + a.D * K);
+    float* prow = rows + (size_t)wave * PP;
+    for (int i = threadIdx.x; i < a.D; i += blockDim.x) sf_tab[i] = make_bound(a.sf ? a.sf[i] : 0.f);
+    for (int i = threadIdx.x; i < a.D * K; i += blockDim.x) msf_tab[i] = make_bound(a.msf ? a.msf[i] : 0.f);
+    for (int i = lane; i < PP; i += kWave) prow[i] = 0.f;
+    __syncthreads();
+    if (w.wave_flags[blockIdx.x * kWavesPerBlock + wave]) {
+        for (long unit = (long)blockIdx.x * kWavesPerBlock + wave; unit < w.nunits; unit += (long)gridDim.x * kWavesPerBlock) {
+            int row0, n_first, ntok;
+            if (!gm.split) {
+                row0 = (int)(unit * gm.rw);
+                n_first = 0;
+                ntok = min(gm.rw, a.B - row0) * a.N;
+            } else {
+                const int nw = gm.S * kWavesPerBlock;
+                row0 = (int)(unit / nw);
+                const int wv = (int)(unit - (long)row0 * nw);
+                const int p_lo = (wv * gm.ppr) / nw, p_hi = ((wv + 1) * gm.ppr) / nw;
+                n_first = p_lo * gm.TPP;
+                ntok = max(0, min(a.N, p_hi * gm.TPP) - n_first);
+            }
+            const size_t tok_g0 = (size_t)row0 * a.N + n_first;
+            const int items = ntok * gm.DA;
+            for (int it0 = 0; it0 < items; it0 += kWave) {
+                const int it = it0 + lane;
+                const bool valid = it < items;
+                const int tokl = valid ? it / gm.DA : 0;
+                const int d = gm.d0 + (valid ? it - tokl * gm.DA : 0);
+                const bool is_tail = valid && __float_as_uint(w.g_z[(tok_g0 + tokl) * a.D + d]) == kTailSentinel;
+                unsigned long long todo = __ballot(is_tail);
+                while (todo) {
+                    const int src = __builtin_ctzll(todo);
+                    todo &= todo - 1;
+                    const int s_tokl = __builtin_amdgcn_readlane(tokl, src), s_d = __builtin_amdgcn_readlane(d, src);
+                    tail_fixup(a, w, msf_tab + s_d * K, sf_tab, tok_g0 + s_tokl, s_d, K, P, lane, prow);
+                    wave_lds_sync();
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < PP; i += blockDim.x) {
+        float t = 0.f;
+        for (int wv = 0; wv < kWavesPerBlock; ++wv) t += rows[wv * PP + i];
+        w.fix_partials[(size_t)blockIdx.x * PP + i] = t;
+    }
+}
+
+// partials [nrows, P] and, for workgroups whose flag is set, fix_partials [nrows, P] -> column sums in fp64, fixed order
+__global__ __launch_bounds__(kBlock) void mix_reduce_partials_fix_kernel(const float* partials, const float* fix_partials,
+                                                                         const int* block_flags, int nrows, int P,
+                                                                         float* out_a, float* out_b, int split) {
+    const int p = blockIdx.x;
+    double accd = 0.0;
+    for (int r = threadIdx.x; r < nrows; r += kBlock) {
+        accd += (double)partials[(size_t)r * P + p];
+        if (block_flags[r]) accd += (double)fix_partials[(size_t)r * P + p];
+    }
+    __shared__ double sh[kWavesPerBlock];
+    accd = wave_sum(accd);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = accd;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w2 = 0; w2 < kWavesPerBlock; ++w2) t += sh[w2];
+        if (p < split) {
+            if (out_a) out_a[p] = (float)t;
+        } else if (out_b) {
+            out_b[p - split] = (float)t;
+        }
+    }
+}
+
 template <int KT, int G>
-__global__ __launch_bounds__(kBlock) void mixture_tok_bwd_kernel(MixArgs a, TokGeom gm, TokBwdArgs w) {
+__device__ __forceinline__ void mixture_tok_bwd_body(const MixArgs& a, const TokGeom& gm, const TokBwdArgs& w) {
     static_assert(G == 1 || KT == 0, "several lanes per item only with a run-time K");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
@@ -87,6 +277,7 @@ __global__ __launch_bounds__(kBlock) void mixture_tok_bwd_kernel(MixArgs a, TokG
 #pragma unroll
     for (int k = 0; k < KK; ++k) acc_m[k] = 0.f;
     float* my_acc = lacc + lane * w.nacc;       // run-time K: slot 0 = scaling_factor, slot 1 + i = mixture k = sub + i G
+    bool any_tail = false;
 
     for (long unit = (long)blockIdx.x * kWavesPerBlock + wave; unit < w.nunits; unit += (long)gridDim.x * kWavesPerBlock) {
         int row0, n_first, ntok;
@@ -135,6 +326,7 @@ __global__ __launch_bounds__(kBlock) void mixture_tok_bwd_kernel(MixArgs a, TokG
             wave_lds_sync();
 
             float g_x = gzo;                       // an element that is not transformed passes its gradient through
+            bool tail = false;
             if (active) {
                 const float t = my[0];
                 const float raw_ls = my[1];
@@ -182,7 +374,7 @@ __global__ __launch_bounds__(kBlock) void mixture_tok_bwd_kernel(MixArgs a, TokG
                 }
                 const float inv_se = __builtin_amdgcn_rcpf(se);
                 const float u = cdf * inv_se, uc = ccdf * inv_se;
-                float g_t, g_ls_raw_main, g_logs;
+                float g_t, g_logs;
                 if (u > 1e-9f && uc > 1e-9f && pdf > 1e-30f) {
                     const float a_s = __builtin_amdgcn_exp2f(log_s * kLog2eF);
                     const float dlu = se * __builtin_amdgcn_rcpf(cdf);             // 1 / u
@@ -241,77 +433,18 @@ __global__ __launch_bounds__(kBlock) void mixture_tok_bwd_kernel(MixArgs a, TokG
                         for (int k = sub; k < K; k += G, ++slot) grads(my[2 + k], my[2 + K + k], my[2 + 2 * K + k], k, my_acc[slot]);
                     }
                 } else {
-                    // rare: a tail or an underflow — the fp64 kernel's arithmetic (cnf_mixture_bwd.hip) on the staged row;
-                    // with several lanes per item every lane walks all mixtures and keeps its own
-                    const double xd = (double)x, gzd = (double)gzo, gld = (double)gl;
-                    double sed = 0.0, cdfd = 0.0, pdfd = 0.0, dpdfd = 0.0;
-#pragma clang loop unroll(disable)
-                    for (int k = 0; k < K; ++k) {
-                        const float lsf = a.msf ? apply_bound(my[2 + 2 * K + k], mt[k]) : my[2 + 2 * K + k];
-                        const double wd = exp((double)my[2 + k] - (double)mx);
-                        const double isd = exp(-(double)lsf);
-                        const double zd = (xd - (double)my[2 + K + k]) * isd;
-                        const double ed = exp(-fabs(zd));
-                        const double rd = 1.0 / (1.0 + ed);
-                        const double sg = zd >= 0.0 ? rd : ed * rd;
-                        const double pk = ed * rd * rd * isd;
-                        sed += wd;
-                        cdfd += wd * sg;
-                        pdfd += wd * pk;
-                        dpdfd += wd * pk * (1.0 - 2.0 * sg) * isd;
-                    }
-                    const double ud = cdfd / sed, pdf_n = pdfd / sed;
-                    const double a_s = exp((double)log_s);
-                    const double ucl = fmax(ud, 1e-22), u1cl = fmax(1.0 - ud, 1e-22);
-                    const double lud = log(ucl), l1ud = log(u1cl);
-                    const double dlu = ud > 1e-22 ? 1.0 / ud : 0.0;
-                    const double dl1u = (1.0 - ud) > 1e-22 ? -1.0 / (1.0 - ud) : 0.0;
-                    const double zt = ((lud - l1ud) + (double)t) * a_s;
-                    double g_ud = gzd * a_s * (dlu - dl1u) + gld * (-dlu - dl1u);
-                    if (a.use_reg) {
-                        double dreg = 0.0;
-                        if (lud / kLn10 <= -a.reg_max) dreg += dlu / kLn10;
-                        if (l1ud / kLn10 <= -a.reg_max) dreg += dl1u / kLn10;
-                        g_ud += gld * a.reg_factor * dreg;
-                    }
-                    const double inv_pdf = pdf_n > 1e-290 ? 1.0 / pdf_n : 0.0;
-                    g_x = (float)(g_ud * pdf_n + gld * (dpdfd / sed) * inv_pdf);
-                    g_logs = (float)(gzd * zt + gld);
-                    g_t = (float)(gzd * a_s);
-                    // per-mixture gradients.  All lanes of the item (G of them) walk all mixtures in lockstep: iteration k
-                    // reads slots k, then the lane that owns mixture k overwrites them; later iterations read other slots
-#pragma clang loop unroll(disable)
-                    for (int k = 0; k < K; ++k) {
-                        const float raw = my[2 + 2 * K + k];
-                        float lsf = raw, d_raw = 1.f, d_sf = 0.f;
-                        if (a.msf) {
-                            lsf = apply_bound(raw, mt[k]);
-                            bound_grads_f(raw, mt[k], d_raw, d_sf);
-                        }
-                        const double pi = exp((double)my[2 + k] - (double)mx) / sed;
-                        const double isd = exp(-(double)lsf);
-                        const double zd = (xd - (double)my[2 + K + k]) * isd;
-                        const double ed = exp(-fabs(zd));
-                        const double rd = 1.0 / (1.0 + ed);
-                        const double sg = zd >= 0.0 ? rd : ed * rd;
-                        const double s1s = ed * rd * rd;
-                        const double pk = s1s * isd;
-                        const double resp = pi * pk * inv_pdf;
-                        const double g_lp = g_ud * pi * (sg - ud) + gld * (resp - pi);
-                        const double g_mu = g_ud * (-pi * pk) + gld * (-resp * (1.0 - 2.0 * sg) * isd);
-                        const double g_ls = g_ud * (-pi * zd * s1s) + gld * (resp * (-1.0 - zd * (1.0 - 2.0 * sg)));
-                        if (G == 1 || (k % G) == sub) {
-                            const float add = (float)g_ls * d_sf;
-                            if (KT > 0) {
-#pragma unroll
-                                for (int kk = 0; kk < KK; ++kk) acc_m[kk] += kk == k ? add : 0.f;      // no dynamic register index
-                            } else {
-                                my_acc[1 + (k - sub) / G] += add;
-                            }
-                            my[2 + k] = (float)g_lp;
-                            my[2 + K + k] = (float)g_mu;
-                            my[2 + 2 * K + k] = (float)(g_ls * (double)d_raw);
-                        }
+                    // rare: a tail or an underflow.  The element is redone in fp64 by the whole wave at the END of the pass
+                    // (tail_fixup), where none of the unrolled mixture state is live: inside this branch the fp64 code cost
+                    // the streaming path 21-36 VGPRs.  Zeros go to the stage meanwhile.
+                    tail = true;
+                    any_tail = true;
+                    g_x = __uint_as_float(kTailSentinel);
+                    g_t = 0.f;
+                    g_logs = 0.f;
+                    for (int k = sub; k < K; k += G) {
+                        my[2 + k] = 0.f;
+                        my[2 + K + k] = 0.f;
+                        my[2 + 2 * K + k] = 0.f;
                     }
                 }
                 // t and log_s (the shared first two slots: one lane of the item writes)
@@ -420,7 +553,11 @@ __global__ __launch_bounds__(kBlock) void mixture_tok_bwd_kernel(MixArgs a, TokG
             }
         }
     }
-    __syncthreads();
+    // which waves / workgroups the fix-up launch has to visit (always written: the workspace is not initialised)
+    const int wave_tail = __ballot(any_tail) != 0ull;
+    if (lane == 0) w.wave_flags[blockIdx.x * kWavesPerBlock + wave] = wave_tail;
+    const int block_tail = __syncthreads_or(wave_tail);
+    if (threadIdx.x == 0) w.block_flags[blockIdx.x] = block_tail;
     const float* rows = reinterpret_cast<const float*>(smem + w.wrow_off);
     for (int i = threadIdx.x; i < PP; i += blockDim.x) {
         float t = 0.f;
@@ -429,13 +566,26 @@ __global__ __launch_bounds__(kBlock) void mixture_tok_bwd_kernel(MixArgs a, TokG
     }
 }
 
+template <int KT, int G>
+__global__ __launch_bounds__(kBlock) void mixture_tok_bwd_kernel(MixArgs a, TokGeom gm, TokBwdArgs w) {
+    mixture_tok_bwd_body<KT, G>(a, gm, w);
+}
+// the same kernel held to 128 VGPRs (4 waves per SIMD): a few registers of scratch buy twice the resident waves, which is
+// what large launches are short of (selected by size in launch_mixture_tok_bwd; measured in profiles/r04_sweep_mixture_bwd.txt)
+template <int KT, int G>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void mixture_tok_bwd_kernel_w4(MixArgs a, TokGeom gm, TokBwdArgs w) {
+    mixture_tok_bwd_body<KT, G>(a, gm, w);
+}
+
 }  // namespace cnf
 
 using namespace cnf;
 
+extern "C" void cnf_set_mixture_bwd_waves(int mode) {
+    if (mode >= -1 && mode <= 1) cnf::g_tok_bwd_w4.store(mode, std::memory_order_relaxed);
+}
+
 namespace cnf {
-// cnf_mixture_bwd.hip
-__global__ void mix_reduce_partials_kernel(const float* partials, int nrows, int P, float* out_a, float* out_b, int split);
 
 // false = shape outside what the token-pass backward is built for (the caller runs the fp64 kernel)
 bool launch_mixture_tok_bwd(MixArgs& a, const float* g_zout, const float* g_ldj, float* g_z, float* g_nn,
@@ -469,14 +619,32 @@ bool launch_mixture_tok_bwd(MixArgs& a, const float* g_zout, const float* g_ldj,
     w.div_span = make_fastdiv((uint32_t)span_b);
     if (span_b >= 65536 || gm.TPP * span_b >= 65536 || gm.ncopy * P * gm.TPP >= 65536) return false;
     const int grid = (int)std::min<long>((w.nunits + kWavesPerBlock - 1) / kWavesPerBlock, kTokBwdGrid);
+    // workspace (cnf_bwd_workspace_floats(PP) floats): [kTokBwdGrid rows] partials | [kTokBwdGrid rows] fix-up partials |
+    // wave flags [4 kTokBwdGrid] | workgroup flags [kTokBwdGrid]
+    w.fix_partials = workspace + (size_t)kTokBwdGrid * PP;
+    w.wave_flags = reinterpret_cast<int*>(workspace + (size_t)2 * kTokBwdGrid * PP);
+    w.block_flags = w.wave_flags + kWavesPerBlock * kTokBwdGrid;
     const dim3 g(grid), b(kBlock);
-    if (kt == 4) CNF_LAUNCH((mixture_tok_bwd_kernel<4, 1>), g, b, lds, st, a, gm, w);
-    else if (kt == 8) CNF_LAUNCH((mixture_tok_bwd_kernel<8, 1>), g, b, lds, st, a, gm, w);
-    else if (kt == 16) CNF_LAUNCH((mixture_tok_bwd_kernel<16, 1>), g, b, lds, st, a, gm, w);
-    else if (G == 1) CNF_LAUNCH((mixture_tok_bwd_kernel<0, 1>), g, b, lds, st, a, gm, w);
-    else if (G == 2) CNF_LAUNCH((mixture_tok_bwd_kernel<0, 2>), g, b, lds, st, a, gm, w);
-    else CNF_LAUNCH((mixture_tok_bwd_kernel<0, 4>), g, b, lds, st, a, gm, w);
-    CNF_LAUNCH(mix_reduce_partials_kernel, dim3(PP), dim3(kBlock), 0, st, workspace, grid, PP,
+    // The build held to 4 waves per SIMD (K = 8: 160 -> 128 VGPRs, 34 of them spilled) pays where few long rows are
+    // split over workgroups (Zinc edges 99.5 -> 80 us); with many short rows the spills cost more than the fourth wave
+    // returns (configs[1] 62 -> 77 us, S* 386 -> 399).  tok_bwd_w4(): -1 = this rule, 0 / 1 force (A/B)
+    const int w4_knob = tok_bwd_w4();
+    const bool w4 = w4_knob >= 0 ? w4_knob != 0 : (gm.split && kt == 8);
+#define TOK_BWD(KT_, G_)                                                                        \
+    do {                                                                                        \
+        if (w4) CNF_LAUNCH((mixture_tok_bwd_kernel_w4<KT_, G_>), g, b, lds, st, a, gm, w);      \
+        else CNF_LAUNCH((mixture_tok_bwd_kernel<KT_, G_>), g, b, lds, st, a, gm, w);            \
+    } while (0)
+    if (kt == 4) TOK_BWD(4, 1);
+    else if (kt == 8) TOK_BWD(8, 1);
+    else if (kt == 16) TOK_BWD(16, 1);
+    else if (G == 1) TOK_BWD(0, 1);
+    else if (G == 2) TOK_BWD(0, 2);
+    else TOK_BWD(0, 4);
+#undef TOK_BWD
+    const size_t lds_fix = tabs + (size_t)kWavesPerBlock * PP * sizeof(float);
+    CNF_LAUNCH(mixture_tok_bwd_fixup_kernel, g, b, lds_fix, st, a, gm, w);
+    CNF_LAUNCH(mix_reduce_partials_fix_kernel, dim3(PP), dim3(kBlock), 0, st, workspace, w.fix_partials, w.block_flags, grid, PP,
                a.sf ? g_sf : nullptr, a.msf ? g_msf : nullptr, a.D);
     return true;
 }

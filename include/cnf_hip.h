@@ -73,6 +73,9 @@ void cnf_set_mixture_tile(int items);
  * counterpart (its backward is autograd, general/train.py:144-155).  All tuning knobs are process-wide atomics — set them
  * before use; they are not per device or per thread. */
 void cnf_set_bwd_tile(int chunks_in_flight, int groups_per_tile);
+/* fp32 mixture-coupling backward (cnf_mixture_coupling_bwd_f32): -1 (default) = the build held to 4 waves per SIMD for
+ * large launches, the natural register allocation for small ones; 0 / 1 force one of them (A/B).  No reference counterpart. */
+void cnf_set_mixture_bwd_waves(int mode);
 
 /* Kernel timing bound to the dispatch (bench.py's `roofline`; a timed launch costs ~4 us of queue time; the reference has no counterpart — its
  * only clock is the host-side time_per_step tracker, general/train.py:147-157).  cnf_prof_arm(n): the next n

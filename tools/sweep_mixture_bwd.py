@@ -45,15 +45,21 @@ for name, B, N, D, K, masked in shapes:
                 fn()
             b.record(); torch.cuda.synchronize()
             ts.append(a.elapsed_time(b) / reps * 1e3)
-        lib.cnf_prof_arm(2 * 5)
+        lib.cnf_prof_arm(3 * 5)
         for _ in range(5):
             fn()
         buf = (ctypes.c_float * 16)()
         n = lib.cnf_prof_collect(buf, 16)
         kern = sum(buf[i] for i in range(n)) / 5 * 1e3
         return min(ts), kern
+    per_mode = []
+    for mode in (0, 1):             # natural register allocation / held to 4 waves per SIMD
+        lib.cnf_set_mixture_bwd_waves(mode)
+        per_mode.append(timeit(f32))
+    lib.cnf_set_mixture_bwd_waves(-1)
     (t32, k32), (t64, k64) = timeit(f32), timeit(f64, reps=3)
     e = B * N * D
     byts = e * (16 + 24 * K) + 8 * e          # read z, g_zout, nn_out; write g_z, g_nn (all blocks)
     print("%-26s B=%5d N=%3d D=%d K=%2d | fp32 token-pass %8.1f us per call, kernels %7.1f us (%.0f GB/s incl. the g_nn zeros) | fp64 kernel %8.1f us per call "
-          "(with its memset), kernels %7.1f us | %.1fx per call, %.1fx kernels" % (name, B, N, D, K, t32, k32, byts / k32 / 1e3, t64, k64, t64 / t32, k64 / k32), flush=True)
+          "(with its memset), kernels %7.1f us | %.1fx per call, %.1fx kernels | natural regs %.1f / %.1f us, 4 waves per SIMD %.1f / %.1f us"
+          % (name, B, N, D, K, t32, k32, byts / k32 / 1e3, t64, k64, t64 / t32, k64 / k32, per_mode[0][0], per_mode[0][1], per_mode[1][0], per_mode[1][1]), flush=True)
