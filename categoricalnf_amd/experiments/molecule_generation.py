@@ -14,10 +14,10 @@ edge_virtual_encoding, edge_virtual_decoder, step1_flows, step2_flows, step3_flo
 
 and the whole thing backwards for sampling (:255-273).  Every layer call goes through the HIP kernels of this
 package (ActNorm, 1x1 conv, mixture-CDF coupling, encoders); the coupling sub-networks are PyTorch modules the caller
-provides: `node_subnet(c_out)` for stage 1 and `edge_subnet(stage, c_out_nodes, c_out_edges)` for stages 2 / 3.  The
-default stage-1 sub-network is this package's RGCNNet; the reference's EdgeGNN (layers/networks/graph_layers.py:737-815)
-is not re-typed here — pass it from the reference checkout (INTEGRATION.md shows the two-line torch >= 2 patch its
-sparse attention needs)."""
+may provide: `node_subnet(c_out)` for stage 1 and `edge_subnet(stage, c_out_nodes, c_out_edges)` for stages 2 / 3.  The
+defaults are this package's RGCNNet and Edge-GNN (layers/networks/edge_gnn.py: the reference's architecture and parameter
+names — graphCNF.py:125-160 — as dense masked attention), built with the reference's hyper-parameters
+(coupling_hidden_size_nodes 256, coupling_hidden_size_edges 128, coupling_hidden_layers 4: graphCNF.py:80-91)."""
 import numpy as np
 import torch
 import torch.nn as nn
@@ -36,53 +36,6 @@ from ..layers.flows.permutation_layers import InvertibleConv
 from .graph_node_edge_coupling import NodeEdgeCoupling, NodeEdgeFlowWrapper
 
 
-class PairMessageNet(nn.Module):
-    """A node + edge message-passing sub-network of THIS package's own design for stages 2 / 3 — not the reference's
-    Edge-GNN (layers/networks/graph_layers.py:737-815), whose attention layers, parameter names and checkpoints it does not
-    share.  It exists so that the assembled three-stage flow can train and sample END TO END on the device at
-    configs[4]'s sizes where the user's checkout (which is what INTEGRATION.md plugs in, through
-    compat.reference_module) cannot travel: `GraphCNF(params, dataset, edge_subnet=PairMessageNet.factory(6, 2))`.
-
-    Interface of a NodeEdgeCoupling sub-network: called with z_nodes [B, N, c_in_nodes], z_edges [B, E, c_in_edges],
-    x_indices = (i, j) with the two end points of every node pair, mask_valid [B, E] (1 = the pair takes part), returns
-    (nn_out_nodes [B, N, c_out_nodes], nn_out_edges [B, E, c_out_edges]).  `rounds` times: every pair reads its two end
-    points, every node the mean over its valid pairs; residual updates, layer norm, zero-initialised output layers (the
-    coupling starts as the identity).  Dense GEMMs on PyTorch-ROCm; gathers and index_add for the graph structure."""
-
-    def __init__(self, c_in_nodes, c_in_edges, c_out_nodes, c_out_edges, hidden_nodes=128, hidden_edges=64, rounds=2):
-        super().__init__()
-        self.node_in, self.edge_in = nn.Linear(c_in_nodes, hidden_nodes), nn.Linear(c_in_edges, hidden_edges)
-        self.edge_upd = nn.ModuleList([nn.Sequential(nn.Linear(hidden_edges + 2 * hidden_nodes, hidden_edges), nn.GELU(),
-                                                     nn.Linear(hidden_edges, hidden_edges)) for _ in range(rounds)])
-        self.node_upd = nn.ModuleList([nn.Sequential(nn.Linear(hidden_nodes + hidden_edges, hidden_nodes), nn.GELU(),
-                                                     nn.Linear(hidden_nodes, hidden_nodes)) for _ in range(rounds)])
-        self.edge_norm = nn.ModuleList([nn.LayerNorm(hidden_edges) for _ in range(rounds)])
-        self.node_norm = nn.ModuleList([nn.LayerNorm(hidden_nodes) for _ in range(rounds)])
-        self.node_out, self.edge_out = nn.Linear(hidden_nodes, c_out_nodes), nn.Linear(hidden_edges, c_out_edges)
-        for layer in (self.node_out, self.edge_out):
-            nn.init.zeros_(layer.weight)
-            nn.init.zeros_(layer.bias)
-
-    @staticmethod
-    def factory(c_in_nodes, c_in_edges, **kwargs):
-        """`edge_subnet` argument of GraphCNF: (stage, c_out_nodes, c_out_edges) -> module."""
-        return lambda stage, c_out_nodes, c_out_edges: PairMessageNet(c_in_nodes, c_in_edges, c_out_nodes, c_out_edges, **kwargs)
-
-    def forward(self, z_nodes, z_edges, x_indices=None, mask_valid=None, **kwargs):
-        i, j = x_indices
-        if i.dim() > 1:
-            i, j = i[0], j[0]
-        m = mask_valid.unsqueeze(dim=-1).to(z_edges.dtype) if mask_valid is not None else z_edges.new_ones(z_edges.shape[:-1] + (1,))
-        hn, he = self.node_in(z_nodes), self.edge_in(z_edges) * m
-        degree = z_nodes.new_zeros(z_nodes.shape[:2] + (1,)).index_add_(1, i, m).index_add_(1, j, m).clamp_(min=1.0)
-        for edge_upd, node_upd, edge_norm, node_norm in zip(self.edge_upd, self.node_upd, self.edge_norm, self.node_norm):
-            he = edge_norm(he + edge_upd(torch.cat([he, hn.index_select(1, i), hn.index_select(1, j)], dim=-1))) * m
-            received = hn.new_zeros(hn.shape[:2] + (he.shape[-1],)).index_add_(1, i, he).index_add_(1, j, he) / degree
-            hn = node_norm(hn + node_upd(torch.cat([hn, received], dim=-1)))
-        return self.node_out(hn), self.edge_out(he) * m
-
-
-# ---- edge list <-> adjacency matrix (experiments/molecule_generation/mutils.py:5-36) ---------------------------
 def pair_indices(num_nodes, device):
     """(i, j) of every unordered node pair i < j, row-major: the order of the reference's edge list."""
     idx = torch.triu_indices(num_nodes, num_nodes, offset=1, device=device)
@@ -166,10 +119,19 @@ class GraphCNF(FlowModel):
                 return RGCNNet(c_in=dn, c_out=c_out, num_edges=self.num_edge_types, num_layers=layers[0], hidden_size=hidden_nodes,
                                max_neighbours=self.num_max_neighbours, dp_rate=dropout, rgc_layer_fun=RelationGraphConv)
         if edge_subnet is None:
+            from ..layers.networks.edge_gnn import (EdgeGNN, EdgeGNNLayer, Edge2NodeAttnLayer, Edge2NodeQKVAttnLayer,
+                                                     Node2EdgePlainLayer)
+            hidden_edges = get_param_val(p, "coupling_hidden_size_edges", default_val=128, **quiet)
+
             def edge_subnet(stage, c_out_nodes, c_out_edges):
-                raise NotImplementedError(
-                    "GraphCNF stages 2/3 need an Edge-GNN sub-network: pass edge_subnet=lambda stage, c_out_nodes, c_out_edges: "
-                    "EdgeGNN(...) built from the reference's layers/networks/graph_layers.py (see INTEGRATION.md)")
+                # graphCNF.py:132-155: the edge-attribute stage attends with pair-only (sigmoid) weights, the virtual-edge
+                # stage with query-key-value attention; highway skips everywhere
+                node_update = Edge2NodeAttnLayer if stage == 1 else Edge2NodeQKVAttnLayer
+                return EdgeGNN(c_in_nodes=dn, c_in_edges=de, c_out_nodes=c_out_nodes, c_out_edges=c_out_edges,
+                               edge_gnn_layer_func=lambda: EdgeGNNLayer(
+                                   edge2node_layer_func=lambda: node_update(hidden_size_nodes=hidden_nodes, hidden_size_edges=hidden_edges, skip_config=2),
+                                   node2edge_layer_func=lambda: Node2EdgePlainLayer(hidden_size_nodes=hidden_nodes, hidden_size_edges=hidden_edges, skip_config=2)),
+                               max_neighbours=self.num_max_neighbours, num_layers=layers[stage])
 
         def node_step():
             return [ActNormFlow(dn), InvertibleConv(dn),

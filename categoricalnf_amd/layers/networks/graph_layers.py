@@ -141,3 +141,15 @@ class RGCNNet(nn.Module):
         if channel_padding_mask is not None:       # the adjacency is already zero for padded nodes
             x = x * channel_padding_mask
         return x
+
+
+_EDGE_GNN_NAMES = ("EdgeGNN", "EdgeGNNLayer", "Node2EdgePlainLayer", "Edge2NodeQKVAttnLayer", "Edge2NodeAttnLayer")
+
+
+def __getattr__(name):
+    """The molecule flow's Edge-GNN lives in edge_gnn.py (which imports GNNSkipConnection from here); the reference keeps all
+    of these classes in this one file, so `layers.networks.graph_layers.EdgeGNN` resolves too."""
+    if name in _EDGE_GNN_NAMES:
+        from . import edge_gnn
+        return getattr(edge_gnn, name)
+    raise AttributeError("module %r has no attribute %r" % (__name__, name))

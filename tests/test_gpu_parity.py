@@ -1414,13 +1414,13 @@ def test_molecule_graph_cnf_three_stage_flow_golden(fixture):
 
 def test_molecule_graph_cnf_trains_and_samples_end_to_end_at_zinc_sizes():
     """configs[4] executed END TO END on the device at its real sizes (38 nodes, 703 pairs, D = 6 / 2, K = 16 / 8, 9 node
-    types): the three-stage GraphCNF on the HIP layers with a stand-in stage-2 / 3 sub-network of this package's own
-    design (PairMessageNet; the reference's Edge-GNN lives in the user's checkout) — data-dependent init, 30 training
+    types): the three-stage GraphCNF on the HIP layers with the reference's own sub-network architectures (RGCN, Edge-GNN:
+    layers/networks/edge_gnn.py, pinned by tests/golden/edge_gnn.npz) — data-dependent init, 30 training
     steps through every backward kernel of the path (loss falls), evaluation, one sampling pass (tools/molecule_train_probe.py)."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "molecule_train_probe.py"), "--steps", "30", "--batch", "16",
-                        "--flows", "2,2,2", "--hidden_nodes", "64", "--hidden_edges", "32", "--graphs", "256"],
+                        "--flows", "2,2,2", "--hidden_nodes", "64", "--hidden_edges", "32", "--layers", "2", "--graphs", "256"],
                        capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0 and "MOLECULE PROBE OK" in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])
 
@@ -1724,3 +1724,15 @@ def test_graph_colouring_driver_two_ranks(tmp_path):
     finals = re.findall(r"final: validation ([0-9.]+) bits per node / ([0-9.]+) % valid, test ([0-9.]+)", r.stdout)
     assert len(finals) == 1 and 0.3 < float(finals[0][0]) < 1.7 and 0.0 <= float(finals[0][1]) <= 100.0, r.stdout[-1500:]
     assert any(f.endswith(".tar") for f in os.listdir(tmp_path / "ck"))
+
+
+def test_edge_gnn_golden_on_the_device():
+    """The in-package Edge-GNN (configs[4]'s stage-2 / 3 sub-network; dense masked attention on PyTorch-ROCm) on the GPU against the
+    reference's outputs at the Zinc250k graph sizes (tests/golden/edge_gnn.npz)."""
+    from tests.test_host_cpu import edge_gnn_from_golden, run_edge_gnn_case
+    cases = load_cases("edge_gnn")
+    for c in cases:
+        on, oe = run_edge_gnn_case(edge_gnn_from_golden(cases, c, "cuda"), c, "cuda")
+        scale_n, scale_e = c.out_nodes.abs().max().item(), c.out_edges.abs().max().item()
+        assert (on.cpu() - c.out_nodes).abs().max().item() <= 5e-5 * max(scale_n, 1.0), c.meta
+        assert (oe.cpu() - c.out_edges).abs().max().item() <= 5e-5 * max(scale_e, 1.0), c.meta

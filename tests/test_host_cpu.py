@@ -1006,3 +1006,99 @@ def test_language_modelling_batches():
     for b in range(9):
         assert (xv[b, lv[b]:] == 0).all() and torch.equal(xv[b, :lv[b]], x[b, :lv[b]])
     assert abs(L.beta_at(args, 5000) - 1.5) < 1e-12 and L.beta_at(args, 0) == 1.0
+
+
+# ---- the in-package Edge-GNN (sub-network of the molecule flow's edge stages; plain PyTorch, runs on any device) -----------
+def _build_edge_gnn(mod, m, c_in_nodes=6, c_in_edges=2):
+    hn, he = m["hidden_nodes"], m["hidden_edges"]
+    if m["step"] == 1:
+        e2n = lambda: mod.Edge2NodeAttnLayer(hidden_size_nodes=hn, hidden_size_edges=he, skip_config=2)          # noqa: E731
+    else:
+        e2n = lambda: mod.Edge2NodeQKVAttnLayer(hidden_size_nodes=hn, hidden_size_edges=he, skip_config=2)       # noqa: E731
+    n2e = lambda: mod.Node2EdgePlainLayer(hidden_size_nodes=hn, hidden_size_edges=he, skip_config=2)             # noqa: E731
+    return mod.EdgeGNN(c_in_nodes=c_in_nodes, c_in_edges=c_in_edges, c_out_nodes=m["c_out_nodes"], c_out_edges=m["c_out_edges"],
+                       edge_gnn_layer_func=lambda: mod.EdgeGNNLayer(edge2node_layer_func=e2n, node2edge_layer_func=n2e),
+                       num_layers=m["layers"], max_neighbours=m["max_neighbours"])
+
+
+def edge_gnn_from_golden(cases, c, device="cpu"):
+    from categoricalnf_amd.layers.networks import edge_gnn
+    net = _build_edge_gnn(edge_gnn, c.meta).to(device).eval()
+    w = cases[c.meta["weights_case"]]
+    net.load_state_dict({k[3:]: v for k, v in w.items() if k.startswith("sd_")}, strict=True)       # the reference's own keys
+    return net
+
+
+def run_edge_gnn_case(net, c, device="cpu"):
+    d = lambda t: t.to(device)
+    with torch.no_grad():
+        return net(d(c.z_nodes), d(c.z_edges), length=d(c.length), x_indices=(d(c.x1), d(c.x2)), mask_valid=d(c.mask_valid),
+                   channel_padding_mask=d(c.pad), binary_adjacency=d(c.adjacency) if c.meta["use_adjacency"] else None)
+
+
+def test_edge_gnn_golden_cpu():
+    """layers/networks/edge_gnn.py against the REFERENCE's EdgeGNN outputs at the Zinc250k graph sizes (tests/golden/
+    edge_gnn.npz: both node-update layers, with and without binary_adjacency, padded graphs); the reference's state_dict
+    loads strictly."""
+    from tests.golden_util import load_cases
+    cases = load_cases("edge_gnn")
+    assert {(c.meta["step"], c.meta["use_adjacency"]) for c in cases} == {(1, True), (1, False), (2, True), (2, False)}
+    for c in cases:
+        on, oe = run_edge_gnn_case(edge_gnn_from_golden(cases, c), c)
+        scale_n, scale_e = c.out_nodes.abs().max().item(), c.out_edges.abs().max().item()
+        assert (on - c.out_nodes).abs().max().item() <= 2e-5 * max(scale_n, 1.0), c.meta
+        assert (oe - c.out_edges).abs().max().item() <= 2e-5 * max(scale_e, 1.0), c.meta
+        # padded nodes and invalid pairs are exactly zero
+        assert float((on * (1 - c.pad)).abs().max()) == 0.0 and float((oe * (1 - c.mask_valid.unsqueeze(-1))).abs().max()) == 0.0
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/layers"), reason="needs the reference checkout")
+def test_edge_gnn_matches_the_live_reference_on_random_graphs():
+    """Seeded random graphs, sizes, degrees and weights: this package's Edge-GNN and the reference's (imported through
+    compat with its torch >= 2 fix) on the same state_dict — forward outputs AND parameter gradients."""
+    import subprocess, sys
+    code = r"""
+import sys, torch
+sys.path.insert(0, %r); sys.path.insert(0, "/root/reference")
+from categoricalnf_amd import compat
+from categoricalnf_amd.layers.networks import edge_gnn as mine
+from tests.test_host_cpu import _build_edge_gnn
+gl = compat.reference_module("layers.networks.graph_layers")
+worst = 0.0
+for seed in range(6):
+    g = torch.Generator().manual_seed(seed)
+    V = int(torch.randint(3, 14, (1,), generator=g)); B = int(torch.randint(1, 5, (1,), generator=g))
+    m = dict(step=1 + seed %% 2, hidden_nodes=16 * (1 + seed %% 3), hidden_edges=8 * (1 + seed %% 2), layers=1 + seed %% 3, max_neighbours=4,
+             c_out_nodes=10, c_out_edges=6)
+    torch.manual_seed(seed)
+    ref = _build_edge_gnn(gl, m, 3, 2)
+    for p in ref.parameters():
+        p.data.normal_(0, 0.4)
+    net = _build_edge_gnn(mine, m, 3, 2)
+    net.load_state_dict(ref.state_dict(), strict=True)
+    x1, x2 = torch.triu_indices(V, V, offset=1)
+    length = torch.randint(1, V + 1, (B,), generator=g); length[0] = V
+    pad = (torch.arange(V)[None] < length[:, None]).float().unsqueeze(-1)
+    adj = torch.triu((torch.rand(B, V, V, generator=g) < 0.35).long(), 1)
+    adj = (adj + adj.transpose(1, 2)) * (pad * pad.transpose(1, 2)).long()
+    use_adj = seed %% 3 != 0
+    mask_valid = adj[:, x1, x2].float() if use_adj else pad[:, x1, 0] * pad[:, x2, 0] * (torch.rand(B, x1.numel(), generator=g) > 0.4).float()
+    zn = torch.randn(B, V, 3, generator=g) * pad; ze = torch.randn(B, x1.numel(), 2, generator=g) * mask_valid.unsqueeze(-1)
+    wn, we = torch.randn(B, V, 10, generator=g), torch.randn(B, x1.numel(), 6, generator=g)
+    outs = []
+    for mod in (ref, net):
+        mod.zero_grad()
+        on, oe = mod(zn, ze, length=length, x_indices=(x1, x2), mask_valid=mask_valid, channel_padding_mask=pad, binary_adjacency=adj if use_adj else None)
+        ((on * wn).sum() + (oe * we).sum()).backward()
+        outs.append((on.detach(), oe.detach(), {k: p.grad.clone() for k, p in mod.named_parameters() if p.grad is not None}))
+    (rn, re, rg), (mn, me, mg) = outs
+    worst = max(worst, float((rn - mn).abs().max() / rn.abs().max().clamp(min=1)), float((re - me).abs().max() / re.abs().max().clamp(min=1)))
+    assert set(rg) == set(mg)
+    for k in rg:
+        worst = max(worst, float((rg[k] - mg[k]).abs().max() / rg[k].abs().max().clamp(min=1)))
+assert worst <= 5e-5, worst
+print("EDGE GNN LIVE OK", worst)
+""" % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT,
+                       env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1", MPLBACKEND="Agg"))
+    assert r.returncode == 0 and "EDGE GNN LIVE OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])

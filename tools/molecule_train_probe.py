@@ -1,7 +1,7 @@
 """configs[4] end to end on the device at its real sizes: the three-stage molecule GraphCNF (38 nodes, 703 node pairs,
-D = 6 / 2, K = 16 / 8, 9 node types, flows 4,6,6) on this package's HIP layers, its stage-1 sub-network the RGCN mirror and
-its stage-2 / 3 sub-network PairMessageNet (this package's own stand-in: the reference's Edge-GNN comes from the user's
-checkout, which cannot travel to the GPU box), on the synthetic molecule-like graphs of experiments/molecule_data.py:
+D = 6 / 2, K = 16 / 8, 9 node types, flows 4,6,6) on this package's HIP layers, its stage-1 sub-network the RGCN and its
+stage-2 / 3 sub-network the Edge-GNN (layers/networks/edge_gnn.py: the reference's architecture, graphCNF.py:125-160, hidden
+sizes 256 / 128, 4 layers), on the synthetic molecule-like graphs of experiments/molecule_data.py:
 data-dependent init, `--steps` training steps (Adam, gradient clipping), the per-node NLL curve, steps per second, and one
 sampling pass whose graphs are checked for shape / symmetry / padding.
 
@@ -12,15 +12,16 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from categoricalnf_amd import functional as Fn
 from categoricalnf_amd.experiments.molecule_data import MAX_NODES, NUM_NODE_TYPES, TYPE_PROBS, random_molecule_like_graph
-from categoricalnf_amd.experiments.molecule_generation import GraphCNF, PairMessageNet
+from categoricalnf_amd.experiments.molecule_generation import GraphCNF
 from categoricalnf_amd.host_utils import create_channel_mask
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=60)
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--flows", default="4,6,6")
-ap.add_argument("--hidden_nodes", type=int, default=384)
-ap.add_argument("--hidden_edges", type=int, default=192)
+ap.add_argument("--hidden_nodes", type=int, default=256)
+ap.add_argument("--hidden_edges", type=int, default=128)
+ap.add_argument("--layers", type=int, default=4)
 ap.add_argument("--graphs", type=int, default=4096)
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
@@ -49,10 +50,10 @@ enc = lambda d: {"use_dequantization": False, "use_variational": False, "use_dec
                  "flow_config": {"num_flows": 0, "hidden_layers": 2, "hidden_size": 128}, "decoder_config": {"num_layers": 1, "hidden_size": 64}}
 params = {"categ_encoding_nodes": enc(6), "categ_encoding_edges": enc(2), "encoding_virtual_num_flows": 0,
           "coupling_hidden_size_nodes": args.hidden_nodes, "coupling_hidden_size_edges": args.hidden_edges, "coupling_num_flows": args.flows,
-          "coupling_hidden_layers": 4, "coupling_num_mixtures_nodes": 16, "coupling_num_mixtures_edges": 8,
+          "coupling_hidden_layers": args.layers, "coupling_num_mixtures_nodes": 16, "coupling_num_mixtures_edges": 8,
           "coupling_mask_ratio": 0.5, "coupling_dropout": 0.0}
 with contextlib.redirect_stdout(io.StringIO()):
-    model = GraphCNF(params, Molecules, edge_subnet=PairMessageNet.factory(6, 2, hidden_nodes=args.hidden_nodes, hidden_edges=args.hidden_edges)).to(dev)
+    model = GraphCNF(params, Molecules).to(dev)
 n_par = sum(p.numel() for p in model.parameters())
 
 
