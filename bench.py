@@ -51,6 +51,7 @@ def parse():
     p.add_argument("--dim", type=int, default=6)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-mixture", action="store_true", help="skip the secondary mixture-CDF measurement")
+    p.add_argument("--no-kernel-table", action="store_true", help="skip extra.kernels (the per-kernel table of the rest of the path)")
     p.add_argument("--tile-chunks", type=int, default=0)
     p.add_argument("--unroll", type=int, default=-1)
     p.add_argument("--math-mode", type=int, default=-1)
@@ -217,6 +218,167 @@ def mixture_measure(ops, dev, R=4, reps=50):
             "fwd_algorithmic_GBps": bytes_alg / (tf * 1e-3) / 1e9, "fwd_hbm_frac": bytes_alg / (tf * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "fwd_bound": "hbm", "inv_bound": "valu (fp32 Newton iterations over the staged rows) on top of the same HBM stream",
             "inv_hbm_frac": bytes_alg / (ti * 1e-3) / 1e9 / HBM_PEAK_GBS}
+
+
+def kernel_table(lib, ops, dev, budget_ms=6.0):
+    """`extra.kernels`: every other kernel of the path the north star / SURVEY 8(d, f) name, timed in THIS run with the
+    roofline's clock (start-to-start over blocks of back-to-back launches on rotating buffers, first block discarded)
+    through the C ABI on pre-bound arguments (a few microseconds of host time per launch).  One row per entry point:
+    algorithmic bytes (the tensors it must read and write once), microseconds, GB/s, fraction of the 8 TB/s
+    HBM peak, and for the VALU-bound encoder kernels the share of the calibrated issue ceiling
+    (profiles/r03_valu_calibration.txt: one plain VALU instruction per 2 cycles, one transcendental per 8, per SIMD;
+    forward 103 / decode 100.5 cycles per class and token at D = 6; 1.88 GHz under such load).  Entry points that launch a
+    reduction behind their kernel (parameter gradients) are timed as a whole."""
+    import functools
+    from categoricalnf_amd.layers.flows.coupling_layer import CouplingLayer
+    P, st = ops._ptr, ops._stream(dev)
+    flags = P(ops.flag_word(dev))
+    g = torch.Generator(device=dev).manual_seed(7)
+    rn = lambda *shape, k=1.0: k * torch.randn(*shape, generator=g, device=dev)
+    rows = []
+
+    def call(name, *args):
+        fn = getattr(lib, name)
+
+        def run():
+            rc = fn(*args)
+            if rc != 0:
+                raise RuntimeError("%s -> %d: %s" % (name, rc, lib.cnf_last_error().decode()))
+        return run
+
+    def timed(calls):
+        for c in calls:
+            c()
+        torch.cuda.synchronize(dev)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for i in range(4):
+            calls[i % len(calls)]()
+        b.record()
+        torch.cuda.synchronize(dev)
+        est = max(a.elapsed_time(b) / 4, 1e-3)
+        reps = int(min(200, max(8, budget_ms / est)))
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        marks[0].record()
+        for k in range(3):
+            for i in range(reps):
+                calls[i % len(calls)]()
+            marks[k + 1].record()
+        torch.cuda.synchronize(dev)
+        return float(np.median([marks[k].elapsed_time(marks[k + 1]) / reps for k in range(1, 3)])), 2 * reps
+
+    def row(name, shape, nbytes, calls, **extra):
+        ms, n = timed(calls)
+        r = {"kernel": name, "shape": shape, "algorithmic_bytes": float(nbytes), "us": ms * 1e3, "GBps": nbytes / (ms * 1e-3) / 1e9,
+             "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "launches_timed": n}
+        r.update(extra)
+        rows.append(r)
+        return ms
+
+    # ---- S* = (16384, 64, 6): the single-layer kernels --------------------------------------------------------------------
+    B, N, D, R = 16384, 64, 6, 4
+    e = B * N * D
+    zs = [rn(B, N, D) for _ in range(R)]
+    nn2 = [rn(B, N, 2 * D, k=0.5) for _ in range(R)]
+    gz = [rn(B, N, D) for _ in range(R)]
+    o1 = [torch.empty(B, N, D, device=dev) for _ in range(R)]
+    o2 = [torch.empty(B, N, 2 * D, device=dev) for _ in range(R)]
+    ldj, lo, gl = torch.zeros(B, device=dev), torch.empty(B, device=dev), rn(B)
+    ln = torch.full((B,), float(N), device=dev)
+    mask = CouplingLayer.create_channel_mask(D).to(dev).contiguous()
+    sf, bias, scales = rn(D, k=0.1), rn(D), rn(D, k=0.1)
+    w = torch.linalg.qr(torch.randn(D, D))[0].to(dev).contiguous()
+    sldj = torch.zeros(1, device=dev)
+    S = "B=%d N=%d D=%d" % (B, N, D)
+    row("actnorm_invconv (fused pair, forward)", S, 8 * e,
+        [call("cnf_actnorm_invconv", P(zs[r]), P(bias), P(scales), P(w), P(sldj), None, None, P(ldj), P(o1[r]), P(lo), B, N, D, 0, flags, st) for r in range(R)])
+    neglog, nll = torch.empty(B, device=dev), torch.empty(B, device=dev)
+    row("prior_nll", S, 4 * e,
+        [call("cnf_prior_nll", P(zs[r]), None, P(ldj), P(ln), P(neglog), P(nll), None, B, N, D, float(ops.LOGISTIC_SIGMA), float(ops.LOGISTIC_LOG_SIGMA), st) for r in range(R)])
+    ws = torch.empty(int(lib.cnf_bwd_workspace_floats(D * D + 1)), device=dev)
+    g_sf, g_b, g_s, g_w, g_sl = (torch.empty(n, device=dev) for n in (D, D, D, D * D, 1))
+    for rev, what in ((0, "forward direction"), (1, "inverse direction")):
+        row("affine_coupling_bwd (%s, + reduction launch)" % what, S, 28 * e,
+            [call("cnf_affine_coupling_bwd", P(zs[r]), P(nn2[r]), P(sf), P(mask), 1, D, P(gz[r]), P(gl), P(o1[r]), P(o2[r]), P(g_sf), P(ws), B, N, D, rev, st)
+             for r in range(R)])
+    row("actnorm_bwd (+ reduction launch)", S, 12 * e,
+        [call("cnf_actnorm_bwd", P(zs[r]), P(bias), P(scales), None, P(ln), P(gz[r]), P(gl), P(o1[r]), P(g_b), P(g_s), P(ws), B, N, D, 0, st) for r in range(R)])
+    row("invconv_bwd (+ reduction launch)", S, 12 * e,
+        [call("cnf_invconv_bwd", P(zs[r]), P(w), None, P(ln), P(gz[r]), P(gl), P(o1[r]), P(g_w), P(g_sl), P(ws), B, N, D, 0, st) for r in range(R)])
+    row("ext_actnorm_bwd", S, 28 * e,
+        [call("cnf_ext_actnorm_bwd", P(zs[r]), P(nn2[r]), None, P(gz[r]), P(gl), P(o1[r]), P(o2[r]), B, N, D, 0, st) for r in range(R)])
+    gldj = torch.empty(B, device=dev)
+    row("prior_nll_bwd", S, 8 * e,
+        [call("cnf_prior_nll_bwd", P(zs[r]), None, P(ln), P(gl), P(o1[r]), P(gldj), B, N, D, float(ops.LOGISTIC_SIGMA), st) for r in range(R)])
+
+    # ---- the mixture-model encoder at the same token count, 16 and 51 classes ----------------------------------------------
+    T = B * N
+    us_ = [torch.rand(T, D, generator=g, device=dev) for _ in range(R)]
+    cat_out = torch.empty(B, N, dtype=torch.int64, device=dev)
+    clock, simds = 1.88e9, 1024
+    for C in (16, 51):
+        cats = [torch.randint(0, C, (B, N), generator=g, device=dev) for _ in range(R)]
+        table = rn(C, 2 * D)
+        prior = torch.log_softmax(torch.zeros(C, device=dev), 0)
+        SC = "%d tokens, D=%d, C=%d" % (T, D, C)
+        ms = row("encoder_forward_sampled (LogisticDistribution.sample + encoder forward)", SC, T * (8 + 8 * D),
+                 [call("cnf_encoder_forward_sampled", P(cats[r]), P(us_[r]), 1e-4, P(table), P(prior), None, 1.0, None, P(o1[r]), P(lo), None, None,
+                       B, N, D, C, float(ops.LOGISTIC_SIGMA), float(ops.LOGISTIC_LOG_SIGMA), flags, st) for r in range(R)], bound="valu")
+        rows[-1]["valu_frac"] = (T / 64.0) * C * 103.0 / simds / clock / (ms * 1e-3)
+        ms = row("encoder_decode", SC, T * (8 + 4 * D),
+                 [call("cnf_encoder_decode", P(zs[r]), P(table), P(prior), P(cat_out), B, N, D, C, float(ops.LOGISTIC_SIGMA), float(ops.LOGISTIC_LOG_SIGMA), st)
+                  for r in range(R)], bound="valu")
+        rows[-1]["valu_frac"] = (T / 64.0) * C * 100.5 / simds / clock / (ms * 1e-3)
+        wsb = torch.empty(int(lib.cnf_encoder_bwd_tiled_workspace_floats(B, N, D, C)), device=dev)
+        g_table = torch.empty(C, 2 * D, device=dev)
+        row("encoder_forward_bwd_tiled (token-lane + class-lane + split-sum launches)", SC, T * (8 + 8 * D),
+            [call("cnf_encoder_forward_bwd_tiled", P(cats[r]), P(zs[r]), P(table), P(prior), None, 1.0, P(gz[r]), P(gl), P(g_table), P(wsb), B, N, D, C,
+                  float(ops.LOGISTIC_SIGMA), float(ops.LOGISTIC_LOG_SIGMA), st) for r in range(R)], bound="valu")
+    del zs, nn2, gz, o1, o2, us_
+
+    # ---- mixture-CDF coupling: configs[1] and S*, fp32 default and the reference's fp64 (math mode 0) ----------------------
+    for (B, N, D, K, R, tag) in ((16384, 16, 4, 8, 4, "configs[1]"), (16384, 64, 6, 8, 2, "S*")):
+        e = B * N * D
+        zs = [rn(B, N, D) for _ in range(R)]
+        nns = [rn(B, N, D * (2 + 3 * K), k=0.5) for _ in range(R)]
+        zf = [torch.empty(B, N, D, device=dev) for _ in range(R)]
+        lf = torch.empty(B, device=dev)
+        mask = CouplingLayer.create_channel_mask(D).to(dev)
+        S = "%s B=%d N=%d D=%d K=%d" % (tag, B, N, D, K)
+        alg = e * (16 + 12 * K)
+        fwd = [ops.mixture_coupling_launch(zs[r], nns[r], mask, K, zf[r], lf) for r in range(R)]
+        for c in fwd:
+            c()
+        inv = [ops.mixture_coupling_launch(zf[r], nns[r], mask, K, zs[r], lf, reverse=True) for r in range(R)]
+        for mode, what in ((1, "fp32 (default)"), (0, "fp64 (the reference's precision)")):
+            lib.cnf_set_math_mode(mode)
+            row("mixture_coupling forward, %s" % what, S, alg, fwd, math_mode=mode)
+            for c in fwd:
+                c()
+            row("mixture_coupling inverse (Newton), %s" % what, S, alg, inv, math_mode=mode)
+        lib.cnf_set_math_mode(1)
+        for c in fwd:
+            c()
+        bias, scales = rn(D), rn(D, k=0.1)
+        w = torch.linalg.qr(torch.randn(D, D))[0].to(dev).contiguous()
+        sldj, ln = torch.zeros(1, device=dev), torch.full((B,), float(N), device=dev)
+        m, mr, mc = ops._mask_desc(mask, D, dev)
+        act, n_act = ops._act_list(mask, m, mr, mc, D)
+        wsm = ops._mixture_workspace(dev, B)
+        row("mixture_coupling + ActNorm + 1x1 conv of the next step (three-way fusion)", S, alg,
+            [call("cnf_mixture_coupling_actconv", P(zs[r]), P(nns[r]), None, None, P(m), mr, mc, act, n_act, None, None, P(zf[r]), P(lf), None,
+                  P(bias), P(scales), P(w), P(sldj), None, B, N, D, K, -1.0, 1.0, 1, P(wsm), int(wsm.numel()), flags, st) for r in range(R)])
+        g_z, g_nn = torch.empty(B, N, D, device=dev), torch.empty_like(nns[0])
+        gzu, gl = rn(B, N, D), rn(B)
+        sf0, msf0 = torch.zeros(D, device=dev), torch.zeros(D, K, device=dev)
+        g_sf, g_msf = torch.empty_like(sf0), torch.empty_like(msf0)
+        wsb = torch.empty(int(lib.cnf_bwd_workspace_floats(D + D * K)), device=dev)
+        row("mixture_coupling_bwd_f32 (+ fix-up and reduction launches)", S, e * (16 + 24 * K) + 8 * e,
+            [call("cnf_mixture_coupling_bwd_f32", P(zs[r]), P(nns[r]), P(sf0), P(msf0), P(m), mr, mc, act, n_act, None, 0, 0, P(gzu), P(gl), P(g_z), P(g_nn),
+                  P(g_sf), P(g_msf), P(wsb), B, N, D, K, -1.0, 1.0, 1, st) for r in range(R)])
+        del zs, nns, zf, g_nn
+    ops.check_flags(dev, "bench kernel table")
+    return rows
 
 
 def kernel_sources_sha():
@@ -454,7 +616,8 @@ def main():
     #      went out through hipExtLaunchKernelGGL with an event pair bound to ITS dispatch packet (cnf_prof_arm), so
     #      the pair's elapsed time is the kernel's own start-to-end time on the launch stream — the quantity
     #      rocprofv3 --kernel-trace reports; a timed launch still costs ~4 us of queue time, hence only ~32 of them per run;
-    #  (2) `steady_ms`, THE FIGURE THE ROOFLINE USES: start-to-start time of back-to-back forward launches right after the
+    #  (2) `kern_ms` (the MEAN of the block means below; `steady_ms` is their median, reported beside it), THE FIGURE THE
+    #      ROOFLINE USES: start-to-start time of back-to-back forward launches right after the
     #      timed region — HIP events around blocks of 200 launches, 6 blocks, the first discarded, i.e. the mean over 1000
     #      launches whatever --steps is.  It contains the inter-kernel boundary, so it never flatters, and it is the figure
     #      rocprofv3's AverageNs agrees with (r03: 18.22 us here, 18.27 us in profiles/r03_bench_kernel_stats.csv; under the
@@ -608,6 +771,10 @@ def main():
             out["cpu_baseline"] = cpu_baseline(B, N, D)
         if world == 1 and not args.no_mixture:
             out["extra"] = {"mixture": mixture_measure(ops, dev), "affine_padded": padded_measure(ops, dev, B, N, D)}
+            if not args.no_kernel_table:
+                t_k = time.perf_counter()
+                out["extra"]["kernels"] = kernel_table(lib, ops, dev)
+                out["extra"]["kernels_wall_s"] = time.perf_counter() - t_k
             if not args.no_cpu_baseline:
                 out["extra"]["mixture"].update(mixture_cpu_baseline())
         print(json.dumps(out))
