@@ -475,6 +475,10 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no CUDA(HIP) device visible")
+    env_world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    if env_world_size > 1 and not args.share_device and torch.cuda.device_count() < env_world_size:
+        # before the process group: with RCCL every rank makes cuda:LOCAL_RANK current first, which must exist
+        raise SystemExit("--gpus %d but only %d HIP device(s) visible" % (env_world_size, torch.cuda.device_count()))
     rank, local_rank, world = init_process_group(args.backend if not args.share_device else "gloo")
     if world != args.gpus:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
@@ -704,6 +708,12 @@ def main():
     alg_bytes = 16.0 * elems + 4.0 * B            # z 4 + (s,t) 8 + z' 4 per elem, + ldj per sample
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
     traffic, traffic_note = read_traffic()
+    per_rank_kernel_ms = [kern_ms]
+    if world > 1:
+        t = torch.tensor([kern_ms], dtype=torch.float64, device=dev)
+        gathered = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(gathered, t)
+        per_rank_kernel_ms = [float(x.item()) for x in gathered]
 
     if rank == 0:
         out = {
@@ -735,6 +745,7 @@ def main():
                                                      "burst_kernel_ms_by_chunks_per_lane": burst_ms,
                                                      "burst_GBps": 16.0 * elems / (burst_ms[best_cpl] * 1e-3) / 1e9},
                          "kernel": "affine_coupling_kernel<VEC=4,fwd,NLL>", "kernel_ms": kern_ms,
+                         "per_rank_kernel_ms": per_rank_kernel_ms,
                          "kernel_ms_samples": reps * (blocks - 1),
                          "kernel_ms_source": "start-to-start over %d back-to-back forward launches right after the timed region (HIP events "
                                              "around %d blocks of %d; block means %.2f ... %.2f us); includes the inter-kernel boundary"

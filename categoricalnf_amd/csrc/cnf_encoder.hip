@@ -9,6 +9,8 @@
 // (:155-160); here the C x D loop runs in registers and the log-sum-exp is streamed.
 #include "cnf_encoder.h"
 
+#include <atomic>
+
 #include <type_traits>
 
 namespace cnf {
@@ -700,7 +702,7 @@ __global__ __launch_bounds__(kBlock) void encoder_forward_pair_kernel(EncArgs a,
     }
 }
 
-static int g_encoder_kernel = 0;     // cnf_set_encoder_kernel: 0 = by measurement (below: the one-token kernels), 1 = one-token kernels, 2 = pair kernels wherever eligible
+static std::atomic<int> g_encoder_kernel{0};     // cnf_set_encoder_kernel: 0 = by measurement (below: the one-token kernels), 1 = one-token kernels, 2 = pair kernels wherever eligible
 
 
 // ---- large vocabularies: the class table does not fit LDS, so it is walked in chunks ---------------------------------
@@ -930,7 +932,7 @@ static bool aligned_to(const void* p, size_t mask) { return ((uintptr_t)p & mask
 
 extern "C" {
 
-static int64_t g_pair_launches = 0;
+static std::atomic<int64_t> g_pair_launches{0};
 void cnf_set_encoder_kernel(int which) { g_encoder_kernel = which; }
 int64_t cnf_encoder_pair_launches(void) { return g_pair_launches; }
 

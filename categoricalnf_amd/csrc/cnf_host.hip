@@ -2,18 +2,22 @@
 #include "cnf_common.h"
 
 #include <algorithm>
+#include <atomic>
 #include <string.h>
 #include <vector>
 
 namespace cnf {
 
 static thread_local char g_err[512] = "";
-// defaults from the interleaved A/B sweep on MI355X (tools/sweep_affine.py, profiles/r01_sweep_affine.txt)
-static int g_tile_chunks = 128;
-static int g_unroll = 2;
-static int g_math = 1;
-static int g_inverse = 1;
-static int g_mix_tile = 128;
+// defaults from the interleaved A/B sweep on MI355X (tools/sweep_affine.py, profiles/r01_sweep_affine.txt).
+// Process-wide knobs, relaxed atomics: a host thread per device (nn.DataParallel replicas) may launch while another thread
+// sets one — it then sees the old or the new value, never a torn one.  They are NOT per device or per thread: set them
+// before use.
+static std::atomic<int> g_tile_chunks{128};
+static std::atomic<int> g_unroll{2};
+static std::atomic<int> g_math{1};
+static std::atomic<int> g_inverse{1};
+static std::atomic<int> g_mix_tile{128};
 
 void set_error(const char* fmt, ...) {
     va_list ap;
@@ -29,11 +33,11 @@ int launch_status(const char* what) {
     return CNF_ERR_LAUNCH;
 }
 
-int tile_chunks_target() { return g_tile_chunks; }
-int unroll_target() { return g_unroll; }
-int math_mode() { return g_math; }
-int inverse_mode() { return g_inverse; }
-int mixture_tile_items() { return g_mix_tile; }
+int tile_chunks_target() { return g_tile_chunks.load(std::memory_order_relaxed); }
+int unroll_target() { return g_unroll.load(std::memory_order_relaxed); }
+int math_mode() { return g_math.load(std::memory_order_relaxed); }
+int inverse_mode() { return g_inverse.load(std::memory_order_relaxed); }
+int mixture_tile_items() { return g_mix_tile.load(std::memory_order_relaxed); }
 
 // ---- kernel timing: event pairs bound to the dispatch packets of armed launches (host thread local) ----------
 struct ProfState {
@@ -116,23 +120,23 @@ int cnf_abi_version(void) { return 1; }
 const char* cnf_last_error(void) { return cnf::g_err; }
 
 void cnf_set_tile_chunks(int chunks) {
-    if (chunks >= 64 && chunks <= cnf::kMaxTileChunks) cnf::g_tile_chunks = chunks;
+    if (chunks >= 64 && chunks <= cnf::kMaxTileChunks) cnf::g_tile_chunks.store(chunks, std::memory_order_relaxed);
 }
 
 void cnf_set_unroll(int u) {
-    if (u == 0 || u == 1 || u == 2 || u == 3 || u == 4) cnf::g_unroll = u;
+    if (u == 0 || u == 1 || u == 2 || u == 3 || u == 4) cnf::g_unroll.store(u, std::memory_order_relaxed);
 }
 
 void cnf_set_math_mode(int mode) {
-    if (mode == 0 || mode == 1) cnf::g_math = mode;
+    if (mode == 0 || mode == 1) cnf::g_math.store(mode, std::memory_order_relaxed);
 }
 
 void cnf_set_mixture_tile(int items) {
-    if (items >= 64 && items <= cnf::kMaxTileChunks) cnf::g_mix_tile = items;
+    if (items >= 64 && items <= cnf::kMaxTileChunks) cnf::g_mix_tile.store(items, std::memory_order_relaxed);
 }
 
 void cnf_set_inverse_mode(int mode) {
-    if (mode == 0 || mode == 1) cnf::g_inverse = mode;
+    if (mode == 0 || mode == 1) cnf::g_inverse.store(mode, std::memory_order_relaxed);
 }
 
 int cnf_prof_arm(int launches) {

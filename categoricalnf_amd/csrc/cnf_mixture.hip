@@ -15,6 +15,7 @@
 #include "cnf_mixture.h"
 
 #include <algorithm>
+#include <atomic>
 
 namespace cnf {
 
@@ -882,8 +883,8 @@ __global__ void nll_to_acc_kernel(const float* nll, long long* acc, int B) {
                   (unsigned long long)__double2ll_rn((double)nll[row] * 4294967296.0));
 }
 
-static int g_mix_kernel = 0;     // 0: token-pass kernel first; 1: round-1 fp32 kernel (A/B and tests)
-static int g_mix_lanes = 0;      // lanes per item of the token-pass kernel with a run-time K: 0 = automatic, 1 / 2 / 4
+static std::atomic<int> g_mix_kernel{0};     // 0: token-pass kernel first; 1: round-1 fp32 kernel (A/B and tests)
+static std::atomic<int> g_mix_lanes{0};      // lanes per item of the token-pass kernel with a run-time K: 0 = automatic, 1 / 2 / 4
 
 // Which channels are transformed.  The caller knows the (tiny, constant) coupling mask on the host
 // and passes the list of transformed channels; without it every item tests the mask itself.

@@ -25,6 +25,7 @@
 #include "cnf_mixture_tok.h"
 
 #include <algorithm>
+#include <atomic>
 #include <climits>
 #include <map>
 #include <mutex>
@@ -561,9 +562,9 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
 }
 
 // ---- host side: geometry ------------------------------------------------------------------------------------
-static int g_split_waves = 4096;      // waves a split launch aims at (cnf_set_mixture_split)
+static std::atomic<int> g_split_waves{4096};      // waves a split launch aims at (cnf_set_mixture_split)
 void set_mixture_split_waves(int w) { g_split_waves = w; }
-static int g_whole_tokens = 1;        // cnf_set_mixture_whole_tokens: A/B switch of the whole-token staging
+static std::atomic<int> g_whole_tokens{1};        // cnf_set_mixture_whole_tokens: A/B switch of the whole-token staging
 void set_mixture_whole_tokens(int on) { g_whole_tokens = on ? 1 : 0; }
 static bool whole_tokens_enabled() { return g_whole_tokens != 0; }
 

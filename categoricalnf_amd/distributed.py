@@ -26,9 +26,18 @@ def init_process_group(backend=None):
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kw = {}
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)        # one process per GPU; RCCL picks the xGMI links
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            # one process per GPU.  The device is made current BEFORE the group exists (nothing is ever allocated on
+            # cuda:0 by a rank that owns another device), and the group is bound to it (`device_id`): RCCL then creates its
+            # communicator eagerly on that device instead of at the first collective on whatever device is current, and a
+            # barrier needs no device guess.
+            torch.cuda.set_device(local_rank)
+            kw["device_id"] = torch.device("cuda", local_rank)
+        try:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+        except TypeError:                            # a torch without the device_id keyword
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
 
 

@@ -1243,6 +1243,26 @@ def test_bench_rehearses_eight_ranks_on_one_device():
     assert r.returncode != 0 and "does not match WORLD_SIZE" in (r.stdout + r.stderr)
 
 
+def test_scale_sweep_script_rehearses_the_drivers_scaling_run():
+    """tools/scale_sweep.sh — bench.py at N = 1, 2, 8 ranks back to back, one JSON line each, the efficiency table — with all
+    ranks on cuda:0 over gloo: the N-rank code path of the driver's SCALE run (rank start-up, per-rank kernel times and
+    rates gathered to rank 0, the all-reduce as the closing barrier), not the interconnect."""
+    import json, subprocess, tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    with tempfile.TemporaryDirectory() as out:
+        r = subprocess.run(["bash", os.path.join(root, "tools", "scale_sweep.sh"), out, "1", "2", "8"], capture_output=True, text=True, timeout=1500, cwd=root,
+                           env=dict(env, SHARE_DEVICE="1", BENCH_FLAGS="--steps 5 --warmup 2 --batch 1024 --prewarm-seconds 0.1 --no-cpu-baseline --no-mixture"))
+        assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+        rows = [json.loads(l) for l in open(os.path.join(out, "scale.jsonl"))]
+    assert [x["n_gpus"] for x in rows] == [1, 2, 8], r.stdout[-2000:]
+    for x in rows:
+        assert len(x["per_rank_elems_per_s"]) == x["n_gpus"] == len(x["roofline"]["per_rank_kernel_ms"])
+        assert all(k > 0 for k in x["roofline"]["per_rank_kernel_ms"])
+        assert (x["allreduce_latency_us"] is None) == (x["n_gpus"] == 1)
+    assert "efficiency" in r.stdout and len([l for l in r.stdout.splitlines() if l.strip() and l.split()[0] in ("1", "2", "8")]) == 3, r.stdout
+
+
 def test_actnorm_data_init_statistics_meet_across_ranks():
     """distributed.sync_data_init(): ranks holding different shards of the initialisation batch all-reduce ActNorm's
     per-channel sums and end up with the whole batch's bias / scales; 2 and 3 ranks on cuda:0."""
@@ -1736,3 +1756,49 @@ def test_edge_gnn_golden_on_the_device():
         scale_n, scale_e = c.out_nodes.abs().max().item(), c.out_edges.abs().max().item()
         assert (on.cpu() - c.out_nodes).abs().max().item() <= 5e-5 * max(scale_n, 1.0), c.meta
         assert (oe.cpu() - c.out_edges).abs().max().item() <= 5e-5 * max(scale_e, 1.0), c.meta
+
+
+@pytest.mark.parametrize("c", load_cases("encoder"))
+def test_fused_encoder_entry_points_against_the_oracle_on_the_golden_cases(c):
+    """The three fused entry points of round 3 directly against the oracle on the reference's golden encoder cases (they are
+    also tested bit for bit against the chains of kernels they replace, tests/test_gpu_encoder_kernels.py):
+    cnf_encoder_forward_sampled (sampler + encoder) against the golden latents / log-det; cnf_encoder_forward_actconv against
+    O.encoder_forward -> O.actnorm -> O.invconv; cnf_encoder_decode_actconv against O.invconv / O.actnorm reversed ->
+    O.encoder_decode (linear_encoding.py:59-133, 184-196; activation_normalization.py:24-48; permutation_layers.py:106-136)."""
+    m = c.meta
+    B, N = c.categ.shape
+    D, C = c.table.shape[1] // 2, c.table.shape[0]
+    pad = c.pad if m["padded"] else None
+    # (1) the sampler fused into the forward
+    z, ldj, _ = ops().encoder_forward(g(c.categ), g(c.u), g(c.table), g(c.category_prior), beta=m["beta"],
+                                      channel_padding_mask=g(pad) if pad is not None else None, uniform_squeeze=1e-4)
+    close(z, c.z, **ELEM); loglik_close(ldj, c.ldj)
+    # (2) + ActNorm + 1x1 convolution behind it
+    gen = torch.Generator().manual_seed(17 + C + D)
+    bias, scales = torch.randn(1, 1, D, generator=gen), 0.2 * torch.randn(1, 1, D, generator=gen)
+    w = torch.linalg.qr(torch.randn(D, D, generator=gen))[0].contiguous() + 0.05 * torch.randn(D, D, generator=gen)
+    sldj = torch.slogdet(w)[1]
+    ldj0 = torch.randn(B, generator=gen)
+    length = pad.reshape(B, N).sum(1) if pad is not None else None
+    eps = O.logistic_from_uniform(c.u.reshape(B * N, 1, D))
+    zo, lo, _ = O.encoder_forward(c.categ, eps, c.table, c.category_prior, beta=m["beta"], channel_padding_mask=pad)
+    za, la = O.actnorm(zo, bias, scales, length=length, channel_padding_mask=pad, ldj=ldj0 + lo)
+    zc, lc = O.invconv(za, w, sldj, length=length, channel_padding_mask=pad, ldj=la)
+    zf, lf = ops().encoder_forward_actconv(g(c.categ), g(c.u), g(c.table), g(c.category_prior), g(bias), g(scales), g(w), g(sldj), beta=m["beta"],
+                                           channel_padding_mask=g(pad) if pad is not None else None, length=g(length) if length is not None else None,
+                                           ldj=g(ldj0), uniform_squeeze=1e-4)
+    close(zf, zc, rtol=5e-5, atol=5e-5); loglik_close(lf, lc)
+    # (3) the sampling direction: inverse convolution, inverse ActNorm, arg-max decode
+    w_inv = torch.inverse(w.double()).float()
+    probe = zc + 0.3 * torch.randn(B, N, D, generator=gen) * (pad if pad is not None else 1.0)
+    xi, li = O.invconv(probe, w, sldj, reverse=True, length=length, channel_padding_mask=pad, ldj=ldj0.clone())     # inverts w itself
+    xa, la2 = O.actnorm(xi, bias, scales, reverse=True, length=length, channel_padding_mask=pad, ldj=li)
+    dec_o, score = O.encoder_decode(xa, c.table, c.category_prior)
+    dec, ld = ops().encoder_decode_actconv(g(probe), g(bias), g(scales), g(w_inv), g(sldj), g(c.table), g(c.category_prior),
+                                           channel_padding_mask=g(pad) if pad is not None else None, length=g(length) if length is not None else None, ldj=g(ldj0))
+    loglik_close(ld, la2)
+    differ = dec.cpu() != dec_o
+    if differ.any():        # only where the oracle's two best classes are a rounding error apart
+        top2 = score.topk(min(2, C), dim=-1).values
+        gap = (top2[:, 0] - top2[:, -1]).reshape(B, N)
+        assert C > 1 and float(gap[differ].max()) < 1e-4, "decoded classes differ where the scores are %g apart" % float(gap[differ].max())
