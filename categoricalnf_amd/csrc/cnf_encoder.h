@@ -54,7 +54,8 @@ __device__ __forceinline__ float enc_noise_from_uniform(float u, float sigma, fl
 // to back, THEN one wave-uniform branch samples (a branch per value would put a memory round trip between the loads)
 // MODE: 0 = the caller's noise as it is (no branch at all: the hot LDS-resident kernel is instantiated both ways — with the
 // run-time test in it, even untaken, its forward ran 1.5 us slower at the benchmark shape), 1 = sample, 2 = run-time test
-template <int MODE, int DM>
+// WRITE: false where another launch of the same forward stores the noise (the class-split sweeps: the merge phase does it once)
+template <int MODE, int DM, bool WRITE = true>
 __device__ __forceinline__ void enc_token_noise(const EncArgs& a, size_t tok, int D, float (&e)[DM]) {
 #pragma unroll
     for (int d = 0; d < DM; ++d)
@@ -63,7 +64,7 @@ __device__ __forceinline__ void enc_token_noise(const EncArgs& a, size_t tok, in
 #pragma unroll
         for (int d = 0; d < DM; ++d)
             if (d < D) e[d] = enc_noise_from_uniform(e[d], a.sigma, a.u_squeeze);
-        if (a.eps_out) {
+        if (WRITE && a.eps_out) {
 #pragma unroll
             for (int d = 0; d < DM; ++d)
                 if (d < D) a.eps_out[tok * D + d] = e[d];
@@ -92,6 +93,11 @@ __device__ __forceinline__ void build_class_chunk(const EncArgs& a, float* tab, 
         tab[c * stride + 2 * D + 1] = __builtin_amdgcn_exp2f(cst2);
     }
 }
+
+// The density-sum posterior (cnf_encoder.hip: class_density) is taken when its total is finite AND the token's own density
+// 2^lp2 is above 2^-90: below that, densities of other classes of the same size may have been flushed to zero in the
+// products, which would bias the posterior without overflowing anything.  Otherwise: the log-domain sweep.
+__device__ __forceinline__ bool density_sum_ok(float tot, float lp2) { return tot < 3e38f && lp2 > -90.f; }
 
 }  // namespace cnf
 

@@ -88,8 +88,10 @@ __device__ __forceinline__ float class_score2(const float* t, const float* z, in
 // logarithm per class and no exponential per class for the log-sum-exp (the streamed LSE spent 8.25 transcendental
 // instructions per class at D = 6, this form 7, and 3 fewer plain ones; calibrated cost 118 -> 102 cycles per class and
 // token).  Range: every summand is >= 0 and the true class contributes exactly 1, so an underflowing product only drops
-// terms below 2^-126 / F of the total; F = 2^-lp2 (or F * sum) overflows only for a token whose own density is below
-// ~2^-100 — the caller checks the total and takes the streamed log-sum-exp (lse2_of_classes) for such a token.
+// terms below 2^-126 (absolute) of the sum; relative to the total that is negligible while the token's own density 2^lp2 is
+// well inside the fp32 range.  For a token whose own density is itself below ~2^-90 the other classes' densities — which may
+// be comparable to it — can flush to zero in the products, and F = 2^-lp2 (or F * sum) eventually overflows: such a token
+// takes the streamed log-sum-exp (lse2_of_classes), decided by density_sum_ok below (a wave-rare compare).
 template <int DT>
 __device__ __forceinline__ float class_density(const float* t, const float* z, int D) {
     float num = t[6 * D + 2], den = 1.f;
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(kBlock) void encoder_forward_kernel(EncArgs a, RowT
         }
         const float tot = fmaf(__builtin_amdgcn_exp2f(-lp2), dsum, 1.f);
         float cpl;
-        if (tot < 3e38f) cpl = -kLn2 * __builtin_amdgcn_logf(tot);
+        if (density_sum_ok(tot, lp2)) cpl = -kLn2 * __builtin_amdgcn_logf(tot);
         else cpl = (lp2 - lse2_of_classes<DT>(tab, stride, z, D, a.C, c, lp2)) * kLn2;       // overflow / NaN: log domain
 #endif
         const float pv = a.pad ? a.pad[tok] : 1.f;
@@ -660,7 +662,7 @@ __global__ __launch_bounds__(kBlock) void encoder_forward_pair_kernel(EncArgs a,
 #else
             const float tot = fmaf(__builtin_amdgcn_exp2f(-lp2[t]), dsum[t], 1.f);
 #endif
-            if (tot < 3e38f) cpl[t] = -kLn2 * __builtin_amdgcn_logf(tot);
+            if (density_sum_ok(tot, lp2[t])) cpl[t] = -kLn2 * __builtin_amdgcn_logf(tot);
             else cpl[t] = (lp2[t] - pair_lse2<D>(vt, z[t], a.C, c[t], lp2[t])) * kLn2;      // overflow / NaN: log domain
 #pragma unroll
             for (int d = 0; d < D; ++d) {
@@ -801,7 +803,7 @@ __global__ __launch_bounds__(kBlock) void encoder_tiled_kernel(EncArgs a, long n
             float nacc = 0.f, nprod = 1.f;
             const float kn = kLog2e / a.sigma;
             float ev[DT > 0 ? DT : kEncMaxD];
-            enc_token_noise<2>(a, (size_t)tok, D, ev);
+            enc_token_noise<2, (DT > 0 ? DT : kEncMaxD), PHASE != 1>(a, (size_t)tok, D, ev);
 #pragma unroll
             for (int d = 0; d < D; ++d) {
                 const float e = ev[d];
@@ -866,7 +868,7 @@ __global__ __launch_bounds__(kBlock) void encoder_tiled_kernel(EncArgs a, long n
         } else {
             const float tot = fmaf(__builtin_amdgcn_exp2f(-lp2), dsum, 1.f);
             float cpl;
-            if (tot < 3e38f) cpl = -kLn2 * __builtin_amdgcn_logf(tot);
+            if (density_sum_ok(tot, lp2)) cpl = -kLn2 * __builtin_amdgcn_logf(tot);
             else {
                 // a copy goes to the callee (scratch memory): the latents themselves stay in registers for the sweep
                 float zc[DT > 0 ? DT : kEncMaxD];

@@ -192,7 +192,7 @@ __global__ __launch_bounds__(kBlock) void encoder_bwd_token_kernel(EncBwdTiledAr
             const float F = __builtin_amdgcn_exp2f(-lp2);
             const float tot = fmaf(F, dsum, 1.f);
             float lse2, q_c;
-            if (tot < 3e38f) {
+            if (density_sum_ok(tot, lp2)) {
                 const float inv_tot = __builtin_amdgcn_rcpf(tot);
                 lse2 = lp2 + __builtin_amdgcn_logf(tot);
                 q_c = inv_tot;

@@ -312,6 +312,16 @@ def main(argv=None):
     ddp.train()
     best = state["best_save_dict"]
     periodic = set()          # full-state checkpoints written at save_freq steps (kept when a better validation file appears)
+    if args.checkpoint_path and rank == 0 and os.path.isdir(args.checkpoint_path):
+        # resumed: the full-state files already in the directory stay protected (a pre-resume periodic file that is also the best
+        # one must not be removed when a better validation file appears)
+        import glob
+        for f in glob.glob(os.path.join(args.checkpoint_path, "checkpoint_*.tar")):
+            try:
+                if "optimizer_state_dict" in torch.load(f, map_location="cpu", weights_only=False):
+                    periodic.add(f)
+            except Exception:
+                pass
     t0, run_loss, seen = time.time(), torch.zeros((), device=device), 0       # the loss stays on the device between prints
     for it in range(state["iteration"], args.max_iterations):
         x, ln = batch()
@@ -355,14 +365,16 @@ def main(argv=None):
                 save_checkpoint(args.checkpoint_path, step, ddp, best_save_dict=best, evaluation_dict=state["evaluation_dict"])
         if step % args.save_freq == 0 and args.checkpoint_path and rank == 0:
             # always the full state (a best-validation file of the same step is a subset of it and is replaced)
-            if graphed is not None:                       # the file stores the learning rate as a number, like an eager run's
+            if graphed is not None:
+                # the file stores what an eager run stores after scheduler.step(): the NEXT step's learning rate as a number,
+                # and no capturable flag (an eager resume must not inherit device-side step counters' mode)
                 for group in optimizer.param_groups:
-                    group["lr"] = float(lr_t)
+                    group["lr"], group["capturable"] = lr_of(step), False
             save_checkpoint(args.checkpoint_path, step, ddp, optimizer if flat is None else None, scheduler,
                             best_save_dict=best, evaluation_dict=state["evaluation_dict"])
             if graphed is not None:
                 for group in optimizer.param_groups:
-                    group["lr"] = lr_t
+                    group["lr"], group["capturable"] = lr_t, True
             periodic.add(checkpoint_file(args.checkpoint_path, step))
     if graphed is not None:
         drop_weight_caches()

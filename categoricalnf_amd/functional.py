@@ -11,9 +11,28 @@ from . import _lib, ops
 from .ops import _f32, _launch, _mask_desc, _opt_f32, _pad2d, _length, _ptr, _stream
 
 
+_ws_cache = {}
+
+
 def _ws(param_count, device):
-    n = int(_lib.load().cnf_bwd_workspace_floats(int(param_count)))
-    return torch.empty(n, dtype=torch.float32, device=device)
+    """Workspace of a backward entry point that reduces parameter gradients (cnf_bwd_workspace_floats): one buffer per
+    (device, stream, size), reused — launches on one stream are ordered, so the next launch's kernels overwrite it only after
+    this launch's reduction has read it.  Not under stream capture, where the buffer must belong to the graph's pool."""
+    n = _ws_sizes.get(param_count)
+    if n is None:
+        n = _ws_sizes[param_count] = int(_lib.load().cnf_bwd_workspace_floats(int(param_count)))
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty(n, dtype=torch.float32, device=device)
+    key = (device, _stream(device).value, n)
+    buf = _ws_cache.get(key)
+    if buf is None:
+        if len(_ws_cache) > 64:
+            _ws_cache.clear()
+        buf = _ws_cache[key] = torch.empty(n, dtype=torch.float32, device=device)
+    return buf
+
+
+_ws_sizes = {}
 
 
 def _g(t, like=None):

@@ -199,7 +199,19 @@ class GraphedTrainStep:
             self.static_out = self._run()
         # a step that still contains a memset node would replay wrongly from its second launch on, silently: refuse it
         self.nodes = graph_node_census(self.graph)
-        if self.nodes and self.nodes.get("memset", 0) and not allow_memset_nodes:
+        if self.nodes is None:
+            # the one guard against the silent wrong-gradient fault could not run (a torch without keep_graph, libamdhip64 not
+            # found in the process map, a HIP error): an UNVERIFIED step is not accepted silently
+            self.nodes = "unverified"
+            if not allow_memset_nodes:
+                raise RuntimeError(
+                    "the captured step's hipGraph could not be inspected (torch.cuda.CUDAGraph(keep_graph=True) / hipGraphGetNodes "
+                    "unavailable), so it cannot be shown to be free of memset nodes, which this HIP runtime replays wrongly from the "
+                    "second launch on (profiles/r03_graph_train_root_cause.txt).  Pass allow_memset_nodes=True to accept the step "
+                    "unverified (nodes == 'unverified').")
+            import warnings
+            warnings.warn("GraphedTrainStep: captured graph accepted WITHOUT a node census (allow_memset_nodes=True)")
+        elif self.nodes.get("memset", 0) and not allow_memset_nodes:
             raise RuntimeError(
                 "the captured step contains %d memset node(s) (%s): on the HIP runtime bundled with this torch wheel a hipGraph "
                 "memset node is replayed wrongly from the second launch on (profiles/r03_graph_train_root_cause.txt).  They come "

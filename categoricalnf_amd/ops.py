@@ -34,6 +34,9 @@ def _dev(t):
 
 
 def _f32(t, name):
+    # the common case first (a contiguous fp32 device tensor): these helpers are most of a small launch's host time
+    if type(t) is torch.Tensor and t.dtype is torch.float32 and t.is_cuda and t.is_contiguous():
+        return t
     _dev(t)
     if t.dtype != torch.float32:
         raise TypeError("%s must be float32, got %s" % (name, t.dtype))
@@ -45,6 +48,8 @@ def _opt_f32(t, name, device):
         return None
     if not isinstance(t, torch.Tensor):
         raise TypeError("%s must be a tensor" % name)
+    if t.dtype is torch.float32 and t.device == device and t.is_contiguous():
+        return t
     if t.device != device:
         t = t.to(device)
     if t.dtype != torch.float32:
@@ -60,24 +65,42 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr() if t.numel() > 0 else 8)
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream(device):
+    """The current HIP stream of `device` as a void*: the raw handle straight from torch's C side (0.3 us) where this torch has
+    that entry point, else through the Stream object (3 us)."""
+    if _raw_stream is not None:
+        idx = device.index
+        return ctypes.c_void_p(_raw_stream(idx if idx is not None else torch.cuda.current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-def _launch(dev, name, *args):
+_fn_cache = {}
+
+
+def _launch(dev, name, *args, allow_unsupported=False):
     """Call one C-ABI entry point with `dev` as the current HIP device (a stream can only be launched into
-    from its own device; multi-GPU-per-process callers such as nn.DataParallel threads rely on this)."""
-    fn = getattr(_lib.load(), name)
+    from its own device; multi-GPU-per-process callers such as nn.DataParallel threads rely on this).
+    `allow_unsupported`: CNF_ERR_UNSUPPORTED (nothing was launched) is returned to the caller, which then takes the
+    unfused route; every other failure raises as usual.  Returns the status."""
+    fn = _fn_cache.get(name)
+    if fn is None:
+        fn = _fn_cache[name] = getattr(_lib.load(), name)
     if dev.index is not None and dev.index != torch.cuda.current_device():
         with torch.cuda.device(dev):
             status = fn(*args)
     else:
         status = fn(*args)
     if status != _lib.CNF_OK:
+        if allow_unsupported and status == _lib.CNF_ERR_UNSUPPORTED:
+            return status
         # a failed launch may have left a split-row workspace (tickets, fixed-point sums) half-written: the next
         # launch must not inherit it
         _mix_ws.clear()
         _lib.check(status, name)
+    return status
 
 
 def flag_word(device):
@@ -126,6 +149,18 @@ def _mask_desc(mask, D, device):
     """(ptr-holder tensor, rows, cols) of a coupling mask buffer shaped [1,D], [rows,1], [1,1,D], [1,rows,1]..."""
     if mask is None:
         return None, 0, 0
+    cached = getattr(mask, "_cnf_mask_desc", None)
+    if cached is not None and cached[0] == (mask._version, D, device):
+        return cached[1]
+    desc = _mask_desc_uncached(mask, D, device)
+    try:
+        mask._cnf_mask_desc = ((mask._version, D, device), desc)       # masks are module buffers: described once
+    except Exception:
+        pass
+    return desc
+
+
+def _mask_desc_uncached(mask, D, device):
     m = mask
     while m.dim() > 2:
         if m.size(0) != 1:
@@ -636,35 +671,21 @@ def encoder_forward(categ, eps, table, category_prior, beta=1.0, channel_padding
     cpl = torch.empty(B * N, dtype=torch.float32, device=dev) if want_class_prob else None
     if tiled is None:
         tiled = encoder_prefers_tiled_forward(C, D, B, N)
-    ws = None
-    if tiled:
-        # token log-det terms (+ the per-split partials above 1024 classes)
-        ws = torch.empty(int(_lib.load().cnf_encoder_workspace_floats(B, N, D, C)), dtype=torch.float32, device=dev)
+    # token log-det terms (+ the per-split partials above 1024 classes): only the class-tiled kernels take a workspace
+    ws = torch.empty(int(_lib.load().cnf_encoder_workspace_floats(B, N, D, C)), dtype=torch.float32, device=dev) if tiled else None
     noise = None
     if uniform_squeeze is not None:
         noise = torch.empty(B * N, D, dtype=torch.float32, device=dev) if want_noise else None
-        lib = _lib.load()
+        head = (_ptr(categ), _ptr(eps), float(uniform_squeeze), _ptr(table), _ptr(prior), _ptr(pad), float(beta), _ptr(ldj_in),
+                _ptr(z), _ptr(ldj_out), _ptr(cpl), _ptr(noise))
+        tail = (B, N, D, C, float(sigma), float(log_sigma), _ptr(flag_word(dev)), _stream(dev))
         if not tiled:
-            args = (_ptr(categ), _ptr(eps), float(uniform_squeeze), _ptr(table), _ptr(prior), _ptr(pad), float(beta), _ptr(ldj_in),
-                    _ptr(z), _ptr(ldj_out), _ptr(cpl), _ptr(noise), B, N, D, C, float(sigma), float(log_sigma),
-                    _ptr(flag_word(dev)), _stream(dev))
-            name = "cnf_encoder_forward_sampled"
+            status = _launch(dev, "cnf_encoder_forward_sampled", *head, *tail, allow_unsupported=True)
         else:
-            args = (_ptr(categ), _ptr(eps), float(uniform_squeeze), _ptr(table), _ptr(prior), _ptr(pad), float(beta), _ptr(ldj_in),
-                    _ptr(z), _ptr(ldj_out), _ptr(cpl), _ptr(noise), _ptr(ws), B, N, D, C, float(sigma), float(log_sigma),
-                    _ptr(flag_word(dev)), _stream(dev))
-            name = "cnf_encoder_forward_tiled_sampled"
-        fn = getattr(lib, name)
-        if dev.index is not None and dev.index != torch.cuda.current_device():
-            with torch.cuda.device(dev):
-                status = fn(*args)
-        else:
-            status = fn(*args)
+            status = _launch(dev, "cnf_encoder_forward_tiled_sampled", *head, _ptr(ws), *tail, allow_unsupported=True)
         if status == _lib.CNF_OK:
             _after(dev, "categorical encoder")
             return (z, ldj_out, cpl, noise) if want_noise else (z, ldj_out, cpl)
-        if status != _lib.CNF_ERR_UNSUPPORTED:
-            _lib.check(status, name)
         eps = logistic_from_uniform(eps, mu=0.0, sigma=sigma, eps=uniform_squeeze)      # math mode 0: the two calls
         noise = eps
     if not tiled:
@@ -706,20 +727,13 @@ def encoder_forward_actconv(categ, uniform, table, category_prior, act_bias, act
         ln = _length(length, B, dev) if isinstance(length, torch.Tensor) else None
         ldj_in, ldj_out = _ldj_io(ldj, B, dev, inplace=False)
         z = torch.empty(B, N, D, dtype=torch.float32, device=dev)
-        fn = _lib.load().cnf_encoder_forward_actconv
-        args = (_ptr(categ), _ptr(u), float(uniform_squeeze), _ptr(table), _ptr(prior), _ptr(pad), float(beta),
-                _ptr(b), _ptr(s), _ptr(w), _ptr(sl), _ptr(ln), _ptr(ldj_in), _ptr(z), _ptr(ldj_out), B, N, D, C,
-                float(sigma), float(log_sigma), _ptr(flag_word(dev)), _stream(dev))
-        if dev.index is not None and dev.index != torch.cuda.current_device():
-            with torch.cuda.device(dev):
-                status = fn(*args)
-        else:
-            status = fn(*args)
+        status = _launch(dev, "cnf_encoder_forward_actconv",
+                         _ptr(categ), _ptr(u), float(uniform_squeeze), _ptr(table), _ptr(prior), _ptr(pad), float(beta),
+                         _ptr(b), _ptr(s), _ptr(w), _ptr(sl), _ptr(ln), _ptr(ldj_in), _ptr(z), _ptr(ldj_out), B, N, D, C,
+                         float(sigma), float(log_sigma), _ptr(flag_word(dev)), _stream(dev), allow_unsupported=True)
         if status == _lib.CNF_OK:
             _after(dev, "categorical encoder + ActNorm + InvertibleConv")
             return z, ldj_out
-        if status != _lib.CNF_ERR_UNSUPPORTED:
-            _lib.check(status, "cnf_encoder_forward_actconv")
     z, ldj_enc, _ = encoder_forward(categ, uniform, table, category_prior, beta=beta, channel_padding_mask=channel_padding_mask,
                                     sigma=sigma, log_sigma=log_sigma, uniform_squeeze=uniform_squeeze)
     ldj_run = ldj_enc if ldj is None else ldj + ldj_enc
@@ -763,19 +777,13 @@ def encoder_decode_actconv(z, act_bias, act_scales, conv_weight_inv, conv_sldj, 
         ln = _length(length, B, dev) if isinstance(length, torch.Tensor) else None
         ldj_in, ldj_out = _ldj_io(ldj, B, dev, inplace=False)
         out = torch.empty(B, N, dtype=torch.int64, device=dev)
-        fn = _lib.load().cnf_encoder_decode_actconv
-        args = (_ptr(z), _ptr(b), _ptr(s), _ptr(w), _ptr(sl), _ptr(pad), _ptr(ln), _ptr(table), _ptr(prior), _ptr(ldj_in),
-                _ptr(out), _ptr(ldj_out), B, N, D, C, float(sigma), float(log_sigma), _ptr(flag_word(dev)), _stream(dev))
-        if dev.index is not None and dev.index != torch.cuda.current_device():
-            with torch.cuda.device(dev):
-                status = fn(*args)
-        else:
-            status = fn(*args)
+        status = _launch(dev, "cnf_encoder_decode_actconv",
+                         _ptr(z), _ptr(b), _ptr(s), _ptr(w), _ptr(sl), _ptr(pad), _ptr(ln), _ptr(table), _ptr(prior), _ptr(ldj_in),
+                         _ptr(out), _ptr(ldj_out), B, N, D, C, float(sigma), float(log_sigma), _ptr(flag_word(dev)), _stream(dev),
+                         allow_unsupported=True)
         if status == _lib.CNF_OK:
             _after(dev, "InvertibleConv + ActNorm (reverse) + categorical decoding")
             return out, ldj_out
-        if status != _lib.CNF_ERR_UNSUPPORTED:
-            _lib.check(status, "cnf_encoder_decode_actconv")
     zz, ldj_run = actnorm_invconv(z, act_bias, act_scales, conv_weight_inv, conv_sldj, reverse=True, length=length,
                                   channel_padding_mask=channel_padding_mask, ldj=ldj)
     return encoder_decode(zz, table, category_prior, sigma=sigma, log_sigma=log_sigma), ldj_run + torch.zeros_like(ldj_run)

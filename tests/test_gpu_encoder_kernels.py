@@ -192,6 +192,30 @@ def test_forward_density_sum_and_its_log_domain_fallback(B, N, D, C, which):
     assert float(co.min()) < -50.0
 
 
+@pytest.mark.parametrize("tiled", [False, True])
+def test_forward_with_own_density_near_the_denormal_range_and_comparable_rivals(tiled):
+    """a token whose OWN density is ~2^-120 keeps 2^-lp2 finite, but rival classes of about the same density
+    could flush to zero in the density products and bias the posterior without any overflow.  Every class here has a
+    log-prior of about -83 (own density ~2^-120 ... 2^-135 with the noise term), so the rivals are comparable to the token's own
+    class for every token; such tokens take the log-domain sweep (density_sum_ok) and match the float64 oracle at 1e-4."""
+    lib, ops = _setup()
+    dev = torch.device("cuda:0")
+    B, N, D, C = 96, 16, 6, 7
+    categ, eps, table, prior, pad, ldj = _inputs(B, N, D, C, 77, 1, dev)
+    g = torch.Generator(device=dev).manual_seed(3)
+    prior = -83.0 + 0.7 * torch.randn(C, generator=g, device=dev)        # not normalised: the kernels take log-priors as given
+    table = table.clone()
+    table[:, :D] *= 0.5                                                   # overlapping classes: several rivals matter
+    z, l, cpl = ops.encoder_forward(categ, eps, table, prior, beta=1.0, channel_padding_mask=pad, ldj=ldj, want_class_prob=True, tiled=tiled)
+    zo, lo, co = _oracle64(categ, eps, table, prior, 1.0, pad)
+    assert torch.isfinite(cpl).all()
+    worst = ((cpl.double().cpu() - co).abs() / co.abs().clamp(min=1.0)).max().item()
+    assert worst <= 1e-4, worst
+    ref = lo + ldj.double().cpu()
+    assert ((l.double().cpu() - ref).abs() / ref.abs().clamp(min=1.0)).max().item() <= 1e-4
+    assert float((co < -0.05).double().mean()) > 0.5          # the rivals do carry weight for most tokens
+
+
 @pytest.mark.parametrize("B,N,D,C", [(64, 16, 6, 16), (40, 8, 16, 12), (6, 30, 4, 1500), (33, 8, 8, 51)])
 def test_backward_density_sum_and_its_log_domain_fallback(B, N, D, C):
     """The class-tiled backward's token lanes sum class densities like the forward (cnf_encoder_bwd_tiled.hip) and take a

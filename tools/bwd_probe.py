@@ -15,6 +15,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--B", type=int, default=16384); ap.add_argument("--N", type=int, default=64); ap.add_argument("--D", type=int, default=6)
 ap.add_argument("--sweep", action="store_true"); ap.add_argument("--reps", type=int, default=100)
 ap.add_argument("--only", default=""); ap.add_argument("--U", type=int, default=0); ap.add_argument("--G", type=int, default=0)
+ap.add_argument("--pmc", action="store_true", help="counter workload: 12 launches of each kernel and the manifest $CNF_MANIFEST for tools/ceilings.py")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 lib = _lib.load()
@@ -120,6 +121,25 @@ rows = [
 ]
 if args.only:
     rows = [r for r in rows if any(k in r[0] for k in args.only.split(","))]
+if args.pmc:
+    import json
+    frag = {"affine_bwd fwd-dir (sf)": "affine_bwd_kernel<4, 2, true, false", "affine_bwd inv-dir (sf)": "affine_bwd_kernel<4, 2, true, true",
+            "affine_bwd fwd-dir (no sf)": "affine_bwd_kernel<4, 2, false, false", "actnorm_bwd": "::actnorm_bwd_kernel<",
+            "invconv_bwd": "invconv_bwd_kernel<6>", "ext_actnorm_bwd": "ext_actnorm_bwd_group_kernel<6", "prior_nll_bwd": "prior_nll_bwd_kernel",
+            "logistic_log_prob_bwd": "logistic_log_prob_bwd_kernel", "sigmoid_flow_bwd": "sigmoid_flow_bwd_kernel",
+            "affine_params_bwd": "affine_params_bwd_kernel<4, 2, true", "affine_transform_bwd": "affine_transform_bwd_kernel<4, 2"}
+    manifest = {}
+    for name, bpe, fn in rows:
+        if name not in frag:
+            continue
+        for i in range(12):
+            fn(i % R)
+        torch.cuda.synchronize()
+        manifest[frag[name]] = {"what": name + ", S*", "alg_bytes": bpe * elems, "elems": elems}
+    if os.environ.get("CNF_MANIFEST"):
+        json.dump(manifest, open(os.environ["CNF_MANIFEST"], "w"), indent=1)
+    print("done")
+    sys.exit(0)
 print("shape B=%d N=%d D=%d (%.2f M elems); start-to-start over blocks of %d launches incl. the partials reduction launch where there is one"
       % (B, N, D, elems / 1e6, args.reps))
 print("%-30s %6s %9s %9s %10s %8s" % ("kernel", "B/elem", "us (med)", "us (min)", "alg GB/s", "of 8TB/s"))
