@@ -45,11 +45,11 @@ static std::atomic<int> g_bwd_u{0}, g_bwd_g{0};
 // column; a thread's (up to 16) loads are all issued before the first add — the launch is one memory round trip long.
 constexpr int kReduceBlock = 1024;
 __global__ __launch_bounds__(kReduceBlock) void bwd_reduce_partials_kernel(const float* partials, int nrows, int P, float* out_a,
-                                                                          float* out_b, int split, int extra) {
-    // extra >= 0: column `extra` is added to every out_b entry (ActNorm's log-det term belongs to every d scales[d])
+                                                                          float* out_b, int split, int extra, int extra_from) {
+    // extra >= 0: column `extra` is added to every column >= extra_from (ActNorm's log-det term belongs to every d scales[d])
     constexpr int K = kBwdMaxRows / kReduceBlock;
     const int p = blockIdx.x;
-    const bool with_extra = extra >= 0 && p >= split;
+    const bool with_extra = extra >= 0 && p >= extra_from;
     float v[K], w[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -1022,6 +1022,213 @@ __global__ __launch_bounds__(kBlock) void invconv_bwd_generic_kernel(ConvBwdArgs
     wave_lane_private_reduce(acc, P, wave_partials_row(a.partials));
 }
 
+// ---- ActNorm + 1x1 convolution of one flow step, ONE backward kernel (forward direction; the forward is actnorm_invconv_kernel,
+// cnf_linear.hip).  The layer pair's intermediate y = (z + b) e^s never went to HBM in the forward and does not here: it is
+// recomputed per token — from the pair's INPUT z (FROM_OUT = false: the forward's own arithmetic, the same bits) or, where
+// only the pair's OUTPUT exists (the pair was fused behind a coupling layer or the encoder, whose output stayed in
+// registers), from out @ W^-1 (FROM_OUT = true).  12 bytes per element (saved tensor, upstream gradient, gradient out) against
+// the 24 of the two layers' kernels run one after the other.  activation_normalization.py:24-48, permutation_layers.py:106-136.
+struct ActConvBwdArgs {
+    const float* saved;     // FROM_OUT ? the pair's output : the pair's input
+    const float* bias;
+    const float* scales;
+    const float* w;         // [D,D]
+    const float* w_inv;     // [D,D], FROM_OUT only
+    const float* pad;
+    const float* length;
+    const float* g_zout;
+    const float* g_ldj;
+    float* g_z;
+    float* partials;        // rows of [dW (D*D) | d sldj | d bias (D) | d scales (D) | ActNorm's log-det term]
+    long ntok;
+    int B, N, D;
+};
+// W^-1 in fp64 (Gauss-Jordan, partial pivoting) by one wave: lane (r, c) owns entry [r][c] of W and of the inverse being built.
+// The reference inverts in double as well (permutation_layers.py:76: torch.inverse(weight.double()).float()).
+__global__ __launch_bounds__(kWave) void small_inverse_kernel(const float* w, float* w_inv, int D) {
+    __shared__ double A[8][17];
+    const int r = threadIdx.x >> 3, c = threadIdx.x & 7;
+    const bool live = r < D && c < D;
+    if (live) {
+        A[r][c] = (double)w[r * D + c];
+        A[r][8 + c] = r == c ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    for (int k = 0; k < D; ++k) {
+        int piv = k;
+        double best = fabs(A[k][k]);
+        for (int row = k + 1; row < D; ++row) {
+            const double v = fabs(A[row][k]);
+            if (v > best) {
+                best = v;
+                piv = row;
+            }
+        }
+        const double k0 = live ? A[k][c] : 0.0, k1 = live ? A[k][8 + c] : 0.0;
+        const double p0 = live ? A[piv][c] : 0.0, p1 = live ? A[piv][8 + c] : 0.0;
+        __syncthreads();
+        if (r == 0 && c < D && piv != k) {
+            A[k][c] = p0; A[k][8 + c] = p1;
+            A[piv][c] = k0; A[piv][8 + c] = k1;
+        }
+        __syncthreads();
+        double n0 = 0.0, n1 = 0.0;
+        if (live) {
+            const double pv = A[k][k];
+            const double q0 = A[k][c] / pv, q1 = A[k][8 + c] / pv, f = A[r][k];
+            n0 = r == k ? q0 : A[r][c] - f * q0;
+            n1 = r == k ? q1 : A[r][8 + c] - f * q1;
+        }
+        __syncthreads();
+        if (live) {
+            A[r][c] = n0;
+            A[r][8 + c] = n1;
+        }
+        __syncthreads();
+    }
+    if (live) w_inv[r * D + c] = (float)A[r][8 + c];
+}
+template <int D, bool FROM_OUT>
+__global__ __launch_bounds__(kBlock) void actconv_bwd_kernel(ActConvBwdArgs a) {
+    constexpr int TP = (D % 4 == 0) ? 1 : (D % 2 == 0 ? 2 : 4);
+    constexpr int NV = TP * D / 4;
+    constexpr int R = D * D + 2 * D + 2;
+    constexpr int kSl = D * D, kB0 = D * D + 1, kS0 = D * D + 1 + D, kLa = D * D + 1 + 2 * D;
+    __shared__ bw_f4 strip_all[kWavesPerBlock][2][kWave * NV];
+    __shared__ float comb[kWavesPerBlock][4 * R];
+    bw_f4* sx = strip_all[threadIdx.x >> 6][0];
+    bw_f4* sg = strip_all[threadIdx.x >> 6][1];
+    const int lane = threadIdx.x & 63;
+    float wk[D * D], wi[FROM_OUT ? D * D : 1], bk[D], ek[D], acc[R];
+#pragma unroll
+    for (int i = 0; i < D * D; ++i) {
+        wk[i] = a.w[i];
+        if (FROM_OUT) wi[i] = a.w_inv[i];
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        bk[i] = a.bias[i];
+        ek[i] = expf(a.scales[i]);              // the forward's expf (actnorm_invconv_kernel): the recomputed y has its bits
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i) acc[i] = 0.f;
+    auto token = [&](const float* sv, const float* gin, float p, float* gz) {
+        float u[D], y[D], g[D];                  // u = (z + b) e^s, y = u pad: what the convolution was given
+        if (!FROM_OUT) {
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                u[i] = (sv[i] + bk[i]) * ek[i];
+                y[i] = a.pad ? u[i] * p : u[i];
+            }
+        } else {
+            // out = (y @ W) pad: y = (out / pad) @ W^-1 where pad != 0 (elsewhere y = 0 and no gradient passes)
+            const float ip = a.pad ? (p != 0.f ? 1.f / p : 0.f) : 1.f;
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                float t = 0.f;
+#pragma unroll
+                for (int j = 0; j < D; ++j) t = fmaf(a.pad ? sv[j] * ip : sv[j], wi[j * D + i], t);
+                y[i] = t;
+                u[i] = a.pad ? t * ip : t;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < D; ++j) g[j] = a.pad ? gin[j] * p : gin[j];         // out = (y @ W) pad
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            float gy = 0.f;
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                gy = fmaf(g[j], wk[i * D + j], gy);                              // g_y[i] = sum_j g[j] W[i,j]
+                acc[i * D + j] = fmaf(y[i], g[j], acc[i * D + j]);               // dW[i,j] += y[i] g[j]
+            }
+            const float gu = a.pad ? gy * p : gy;                                // y = u pad
+            const float gzv = gu * ek[i];
+            gz[i] = gzv;
+            acc[kB0 + i] += gzv;                                                 // d bias
+            acc[kS0 + i] = fmaf(gu, u[i], acc[kS0 + i]);                         // d scales
+        }
+    };
+    const bool aligned = a.g_zout && ((reinterpret_cast<uintptr_t>(a.saved) | reinterpret_cast<uintptr_t>(a.g_zout) |
+                                       reinterpret_cast<uintptr_t>(a.g_z)) & 15) == 0;
+    const long ngroups = aligned ? a.ntok / TP : 0;
+    const long ntiles = ngroups / kWave;
+    const long wave_id = (long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const long nwaves = (long)gridDim.x * kWavesPerBlock;
+    for (long tile = wave_id; tile < ntiles; tile += nwaves) {
+        const bw_f4* srcx = reinterpret_cast<const bw_f4*>(a.saved + tile * (kWave * TP * D));
+        const bw_f4* srcg = reinterpret_cast<const bw_f4*>(a.g_zout + tile * (kWave * TP * D));
+        bw_f4 qx[NV], qg[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) qx[v] = __builtin_nontemporal_load(srcx + v * kWave + lane);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) qg[v] = srcg[v * kWave + lane];
+        const long g = tile * kWave + lane;
+        float pv[TP];
+#pragma unroll
+        for (int k = 0; k < TP; ++k) pv[k] = a.pad ? a.pad[g * TP + k] : 1.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            sx[v * kWave + lane] = qx[v];
+            sg[v * kWave + lane] = qg[v];
+        }
+        wave_lds_order();
+        float xin[TP * D], gin[TP * D], gx[TP * D];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const bw_f4 r = sx[lane * NV + v];
+            xin[4 * v] = r.x; xin[4 * v + 1] = r.y; xin[4 * v + 2] = r.z; xin[4 * v + 3] = r.w;
+            const bw_f4 q = sg[lane * NV + v];
+            gin[4 * v] = q.x; gin[4 * v + 1] = q.y; gin[4 * v + 2] = q.z; gin[4 * v + 3] = q.w;
+        }
+#pragma unroll
+        for (int k = 0; k < TP; ++k) token(xin + k * D, gin + k * D, pv[k], gx + k * D);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const bw_f4 r = {gx[4 * v], gx[4 * v + 1], gx[4 * v + 2], gx[4 * v + 3]};
+            sx[lane * NV + v] = r;                  // the lane's own group: nobody else reads these words
+        }
+        wave_lds_order();
+        bw_f4* dst = reinterpret_cast<bw_f4*>(a.g_z + tile * (kWave * TP * D));
+#pragma unroll
+        for (int v = 0; v < NV; ++v) st_chunk<4, kNtOut>(reinterpret_cast<float*>(dst + v * kWave + lane), reinterpret_cast<const float*>(&sx[v * kWave + lane]));
+        wave_lds_order();                            // the strips are refilled by the next tile
+    }
+    // tokens that do not fill a wave tile (or everything, for unaligned tensors / a missing upstream gradient)
+    for (long t = ntiles * kWave * TP + (long)blockIdx.x * kBlock + threadIdx.x; t < a.ntok; t += (long)gridDim.x * kBlock) {
+        float xin[D], gin[D], gx[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            xin[i] = a.saved[t * D + i];
+            gin[i] = a.g_zout ? a.g_zout[t * D + i] : 0.f;
+        }
+        token(xin, gin, a.pad ? a.pad[t] : 1.f, gx);
+#pragma unroll
+        for (int i = 0; i < D; ++i) a.g_z[t * D + i] = gx[i];
+    }
+    // log-det terms: ldj += (sum_d scales) len_a + sldj len_c with the forward's two lengths (ActNorm: length | sum(pad) | N,
+    // convolution: length | N): this thread's share of the samples
+    if (a.g_ldj) {
+        float pa = 0.f, pc = 0.f;
+        for (long b = (long)blockIdx.x * kBlock + threadIdx.x; b < a.B; b += (long)gridDim.x * kBlock) {
+            float len_a, len_c;
+            if (a.length) len_a = len_c = a.length[b];
+            else {
+                len_c = (float)a.N;
+                if (a.pad) {
+                    len_a = 0.f;
+                    for (int n = 0; n < a.N; ++n) len_a += a.pad[b * a.N + n];
+                } else len_a = (float)a.N;
+            }
+            pa = fmaf(a.g_ldj[b], len_a, pa);
+            pc = fmaf(a.g_ldj[b], len_c, pc);
+        }
+        acc[kSl] = pc;
+        acc[kLa] = pa;
+    }
+    wave_register_reduce<R>(acc, comb[threadIdx.x >> 6], wave_partials_row(a.partials));
+}
+
 // ---- logistic log-prob / NLL (distributions.py:129-163; set_modeling/task.py:96-118) ------------------------
 // d/dx [-(softplus(v) + softplus(-v) + log sigma)] = -tanh(v/2) / sigma,  v = (x - mu)/sigma;  tanh(v/2) = 1 - 2/(e^v + 1)
 template <bool FAST>
@@ -1145,7 +1352,7 @@ __global__ __launch_bounds__(kBlock) void sigmoid_flow_bwd_kernel(SigBwdArgs a, 
 
 // rows = waves of the launch that wrote the partials
 static int reduce_partials(const float* partials, int rows, int P, float* out, hipStream_t st) {
-    CNF_LAUNCH(bwd_reduce_partials_kernel, dim3(P), dim3(kReduceBlock), 0, st, partials, rows, P, out, (float*)nullptr, P, -1);
+    CNF_LAUNCH(bwd_reduce_partials_kernel, dim3(P), dim3(kReduceBlock), 0, st, partials, rows, P, out, (float*)nullptr, P, -1, 0);
     return CNF_OK;
 }
 // chunks in flight per lane / chunk groups per wave: the knob (cnf_set_bwd_tile) when set, else the kernel's own default
@@ -1365,7 +1572,7 @@ int cnf_actnorm_bwd(const float* z_out, const float* bias, const float* scales,
     });
     // partial rows are [d bias (D) | d scales (D) | log-det term]: summed straight into the two gradient tensors
     CNF_LAUNCH(bwd_reduce_partials_kernel, dim3(2 * D), dim3(kReduceBlock), 0, st, workspace, (int)grid.x * kWavesPerBlock, 2 * D + 1,
-               g_bias, g_scales, D, g_ldj ? 2 * D : -1);
+               g_bias, g_scales, D, g_ldj ? 2 * D : -1, D);
     return launch_status("cnf_actnorm_bwd");
 }
 
@@ -1400,8 +1607,47 @@ int cnf_invconv_bwd(const float* x, const float* weight, const float* pad, const
             grid = dim3((unsigned)std::min<long>(std::max<long>((a.ntok * D + kBlock - 1) / kBlock, 1), kBwdMaxBlocks));
             CNF_LAUNCH(invconv_bwd_generic_kernel, grid, block, (size_t)P * kBlock * sizeof(float), st, a);
     }
-    CNF_LAUNCH(bwd_reduce_partials_kernel, dim3(P), dim3(kReduceBlock), 0, st, workspace, (int)grid.x * kWavesPerBlock, P, g_weight, g_sldj, D * D, -1);
+    CNF_LAUNCH(bwd_reduce_partials_kernel, dim3(P), dim3(kReduceBlock), 0, st, workspace, (int)grid.x * kWavesPerBlock, P, g_weight, g_sldj, D * D, -1, 0);
     return launch_status("cnf_invconv_bwd");
+}
+
+int cnf_actnorm_invconv_bwd(const float* saved, int saved_is_output, const float* bias, const float* scales, const float* weight,
+                            const float* weight_inv, const float* pad, const float* length,
+                            const float* g_zout, const float* g_ldj, float* g_z, float* g_params, float* workspace,
+                            int B, int N, int D, cnf_stream_t stream) {
+    CNF_REQUIRE(saved && bias && scales && weight && g_z && g_params && workspace, "cnf_actnorm_invconv_bwd: null tensor");
+    CNF_REQUIRE(B > 0 && N > 0 && D > 0, "cnf_actnorm_invconv_bwd: bad shape");
+    if (!(D <= 6 || D == 8)) {
+        set_error("cnf_actnorm_invconv_bwd: built for D in {1..6, 8} (got %d): run the two layers' backward kernels", D);
+        return CNF_ERR_UNSUPPORTED;
+    }
+    const int P = D * D + 2 * D + 2;
+    hipStream_t st = (hipStream_t)stream;
+    if (saved_is_output && !weight_inv) {
+        // behind the partial rows (cnf_bwd_workspace_floats(P) holds kBwdMaxRows + 1 rows of P + 1)
+        float* inv = workspace + (size_t)kBwdMaxRows * P;
+        CNF_LAUNCH(small_inverse_kernel, dim3(1), dim3(kWave), 0, st, weight, inv, D);
+        weight_inv = inv;
+    }
+    ActConvBwdArgs a{saved, bias, scales, weight, weight_inv, pad, length, g_zout, g_ldj, g_z, workspace, (long)B * N, B, N, D};
+    const dim3 block(kBlock);
+    const int tp = (D % 4 == 0) ? 1 : (D % 2 == 0 ? 2 : 4);
+    const long tiles = std::max<long>(a.ntok / ((long)kWave * tp), 1);
+    const int G = bwd_g(2);
+    const dim3 grid((unsigned)std::min<long>(std::max<long>((tiles + (long)kWavesPerBlock * G - 1) / ((long)kWavesPerBlock * G), 1), kBwdMaxBlocks));
+#define ACB(DD) \
+    case DD: \
+        if (saved_is_output) CNF_LAUNCH((actconv_bwd_kernel<DD, true>), grid, block, 0, st, a); \
+        else CNF_LAUNCH((actconv_bwd_kernel<DD, false>), grid, block, 0, st, a); \
+        break;
+    switch (D) {
+        ACB(1) ACB(2) ACB(3) ACB(4) ACB(5) ACB(6) ACB(8)
+    }
+#undef ACB
+    // rows [dW | d sldj | d bias | d scales | ActNorm's log-det term] -> g_params [dW | d sldj | d bias | d scales]
+    CNF_LAUNCH(bwd_reduce_partials_kernel, dim3(P - 1), dim3(kReduceBlock), 0, st, workspace, (int)grid.x * kWavesPerBlock, P, g_params,
+               (float*)nullptr, P - 1, g_ldj ? P - 1 : -1, D * D + 1 + D);
+    return launch_status("cnf_actnorm_invconv_bwd");
 }
 
 int cnf_logistic_log_prob_bwd(const float* x, const float* g_logp, float* g_x, int64_t n, float mu, float sigma,

@@ -145,10 +145,9 @@ def draw_batch(corpus, args, num, rng, device):
 def sentence_nll(model, prior, x, length, beta=1.0):
     """[B] negative log-likelihood per character, task.py:75-119 (`_train_batch_flow`, `_calc_loss`)."""
     x = x[:, :int(length.max())]                          # the batch is as wide as its longest sentence (task.py:123)
-    z, ldj = model(x, reverse=False, beta=beta, length=length)
-    pad = create_channel_mask(length, max_len=x.size(1))
-    neglog = -(prior.log_prob(z) * pad).sum(dim=[1, 2])
-    return (neglog - ldj) / length.float()
+    inner = model.module if hasattr(model, "module") else model
+    # (-sum_{n,d} log p(z) pad - ldj) / length, assembled by the flow pass itself: one kernel forward, one backward
+    return model(x, reverse=False, beta=beta, length=length, _nll=inner.nll_request(length=length, prior=prior))[2]
 
 
 @torch.no_grad()

@@ -279,8 +279,9 @@ def main(argv=None):
         plist = [p_ for p_ in model.parameters() if p_.requires_grad]
 
         def graph_train_step():
-            z_, ldj_ = model(static_x, reverse=False, length=static_ln, beta=1, noise=static_noise)
-            loss_ = Fn.PriorNllFn.apply(z_, ldj_, static_ln, None).mean()
+            # the NLL assembly rides in the last coupling layer's kernel
+            loss_ = model(static_x, reverse=False, length=static_ln, beta=1, noise=static_noise,
+                          _nll=model.nll_request(length=static_ln))[2].mean()
             for p_, g_ in zip(plist, torch.autograd.grad(loss_, plist, allow_unused=True)):
                 p_.grad = g_
             torch.nn.utils.clip_grad_norm_(plist, args.max_gradient_norm, foreach=True)
@@ -332,8 +333,8 @@ def main(argv=None):
             loss = graphed()
             scheduler.last_epoch, scheduler._last_lr = it + 1, [lr_of(it + 1)]      # what the checkpoint stores of the schedule
         else:
-            z, ldj = ddp(x, reverse=False, length=ln, beta=1)
-            loss = Fn.PriorNllFn.apply(z, ldj, ln, None).mean()
+            # the NLL assembly rides in the last coupling layer's kernel
+            loss = ddp(x, reverse=False, length=ln, beta=1, _nll=model.nll_request(length=ln))[2].mean()
             if flat is not None:
                 flat.zero_grad()
             else:

@@ -83,6 +83,42 @@ class AffineCouplingFn(torch.autograd.Function):
         return g_z, g_nn.view_as(nn_out), (g_sf.view_as(sf) if sf is not None else None), (g_ldj if ctx.has_ldj else None), None, None
 
 
+class AffineCouplingNllFn(torch.autograd.Function):
+    """The LAST affine coupling of a flow + the NLL assembly in ONE forward kernel (cnf_affine_coupling_nll); the backward is the
+    NLL assembly's and the coupling's backward kernels in one Function.  (z, nn_out, sf, ldj) -> (nll [B], z', ldj')."""
+
+    @staticmethod
+    def forward(ctx, z, nn_out, scaling_factor, ldj, mask, pad, length, sigma, log_sigma):
+        z_out, ldj_out, _, nll = ops.affine_coupling_nll(z, nn_out, scaling_factor, mask, ldj=ldj, length=length,
+                                                         channel_padding_mask=pad, sigma=sigma, log_sigma=log_sigma)
+        empty = z_out.new_empty(0)
+        ctx.save_for_backward(z_out, nn_out, scaling_factor if scaling_factor is not None else empty, mask if mask is not None else empty,
+                              pad if isinstance(pad, torch.Tensor) else empty, length if isinstance(length, torch.Tensor) else empty)
+        ctx.flags = (scaling_factor is not None, mask is not None, isinstance(pad, torch.Tensor), isinstance(length, torch.Tensor), ldj is not None)
+        ctx.mark_non_differentiable(z_out, ldj_out)
+        return nll, z_out, ldj_out
+
+    @staticmethod
+    def backward(ctx, g_nll, _g_z, _g_l):
+        hold = _Hold()
+        z_out, nn_out, sf, mask, pad, length = ctx.saved_tensors
+        has_sf, has_mask, has_pad, has_len, has_ldj = ctx.flags
+        g_zo, g_ldj = _prior_nll_bwd(z_out, length if has_len else None, pad if has_pad else None, g_nll, hold)
+        sf = sf if has_sf else None
+        dev = z_out.device
+        B, N, D = z_out.shape
+        nn_c = _f32(nn_out, "nn_out")
+        sfc = _opt_f32(sf, "scaling_factor", dev)
+        m, mr, mc = _mask_desc(mask if has_mask else None, D, dev)
+        g_z, g_nn = torch.empty_like(z_out), torch.empty_like(nn_c)
+        g_sf = torch.empty(D, dtype=torch.float32, device=dev) if sf is not None else None
+        ws = _ws(D, dev) if sf is not None else None
+        _launch(dev, "cnf_affine_coupling_bwd", _ptr(z_out), _ptr(nn_c), _ptr(sfc), _ptr(m), mr, mc, _ptr(g_zo), _ptr(g_ldj), _ptr(g_z),
+                _ptr(g_nn), _ptr(g_sf), _ptr(ws), B, N, D, 0, _stream(dev))
+        return (g_z, g_nn.view_as(nn_out), (g_sf.view_as(sf) if sf is not None else None), (g_ldj if has_ldj else None),
+                None, None, None, None, None)
+
+
 class ExtActNormFn(torch.autograd.Function):
     """(z, nn_out [B,N,2D], ldj) -> (z', ldj +- sum tanh(scales) pad)."""
 
@@ -169,6 +205,124 @@ class InvConvFn(torch.autograd.Function):
         return g_x, g_w, g_s.view_as(sldj), (g_ldj if ctx.has_ldj else None), None, None, None
 
 
+def _actconv_bwd(saved, saved_is_output, bias, scales, weight, length, pad, g_zout, g_ldj, hold):
+    """One launch of cnf_actnorm_invconv_bwd: (g_z, g_bias, g_scales, g_weight, g_sldj [1])."""
+    dev = saved.device
+    B, N, D = saved.shape
+    sv, wc = _f32(saved, "z"), _f32(weight, "weight")
+    bias_c, scales_c = _f32(bias.reshape(-1), "bias"), _f32(scales.reshape(-1), "scales")
+    p2 = _pad2d(pad, B, N, dev) if isinstance(pad, torch.Tensor) else None
+    ln = _length(length, B, dev) if isinstance(length, torch.Tensor) else None
+    g_z = torch.empty_like(sv)
+    g_p = torch.empty(D * D + 1 + 2 * D, dtype=torch.float32, device=dev)
+    ws = _ws(D * D + 2 * D + 2, dev)
+    status = _launch(dev, "cnf_actnorm_invconv_bwd", _ptr(sv), int(bool(saved_is_output)), _ptr(bias_c), _ptr(scales_c), _ptr(wc), None,
+                     _ptr(p2), _ptr(ln), hold(g_zout), hold(g_ldj), _ptr(g_z), _ptr(g_p), _ptr(ws), B, N, D, _stream(dev),
+                     allow_unsupported=True)
+    if status != _lib.CNF_OK:              # D outside {1..6, 8}: the fused forward kernels do not exist there either
+        raise ops.HipOnlyError("cnf_actnorm_invconv_bwd: " + _lib.load().cnf_last_error().decode())
+    dd = D * D
+    return g_z, g_p[dd + 1:dd + 1 + D].view_as(bias), g_p[dd + 1 + D:].view_as(scales), g_p[:dd].view(D, D), g_p[dd:dd + 1]
+
+
+class ActConvFn(torch.autograd.Function):
+    """ActNormFlow.forward -> InvertibleConv.forward of one flow step (forward direction): ONE forward kernel
+    (cnf_actnorm_invconv) and ONE backward kernel (cnf_actnorm_invconv_bwd) that recomputes the pair's intermediate from the
+    saved input.  (z, bias, scales, weight, sldj, ldj) -> (z', ldj'); the same numbers as ActNormFn then InvConvFn."""
+
+    @staticmethod
+    def forward(ctx, z, bias, scales, weight, sldj, ldj, length, pad):
+        z_out, ldj_out = ops.actnorm_invconv(z, bias, scales, weight, sldj, length=length, channel_padding_mask=pad, ldj=ldj)
+        empty = z_out.new_empty(0)
+        ctx.save_for_backward(z, bias, scales, weight, length if isinstance(length, torch.Tensor) else empty,
+                              pad if isinstance(pad, torch.Tensor) else empty)
+        ctx.has_len, ctx.has_pad, ctx.has_ldj = isinstance(length, torch.Tensor), isinstance(pad, torch.Tensor), ldj is not None
+        ctx.sldj_shape = sldj.shape
+        return z_out, ldj_out
+
+    @staticmethod
+    def backward(ctx, g_zout, g_ldj):
+        hold = _Hold()
+        z, bias, scales, weight, length, pad = ctx.saved_tensors
+        length, pad = (length if ctx.has_len else None), (pad if ctx.has_pad else None)
+        g_z, g_b, g_s, g_w, g_sl = _actconv_bwd(z, False, bias, scales, weight, length, pad, g_zout, g_ldj, hold)
+        return g_z, g_b, g_s, g_w, g_sl.view(ctx.sldj_shape), (g_ldj if ctx.has_ldj else None), None, None
+
+
+class MixtureActConvFn(torch.autograd.Function):
+    """Mixture-CDF coupling of one flow step + ActNorm + 1x1 convolution of the next: ONE forward kernel
+    (cnf_mixture_coupling_actconv: the coupling's output stays in registers).  The backward recomputes what that output
+    was from the saved result (cnf_actnorm_invconv_bwd, saved_is_output = 1), then runs the coupling's own backward kernel
+    on the saved input.  (z, nn_out, sf, msf, bias, scales, weight, sldj, ldj) -> (z', ldj')."""
+
+    @staticmethod
+    def forward(ctx, z, nn_out, sf, msf, bias, scales, weight, sldj, ldj, mask, pad, length, K, reg_max, reg_factor, is_training):
+        z_out, ldj_out, _ = ops.mixture_coupling_actconv(z, nn_out, mask, K, bias, scales, weight, sldj, scaling_factor=sf,
+                                                         mixture_scaling_factor=msf, channel_padding_mask=pad, length=length,
+                                                         reg_max=reg_max, reg_factor=reg_factor, is_training=is_training, ldj=ldj,
+                                                         want_reg=False)
+        empty = z_out.new_empty(0)
+        ctx.save_for_backward(z, nn_out, sf if sf is not None else empty, msf if msf is not None else empty,
+                              mask if mask is not None else empty, pad if isinstance(pad, torch.Tensor) else empty,
+                              length if isinstance(length, torch.Tensor) else empty, z_out, bias, scales, weight)
+        ctx.flags = (sf is not None, msf is not None, mask is not None, isinstance(pad, torch.Tensor), ldj is not None,
+                     isinstance(length, torch.Tensor))
+        ctx.cfg = (int(K), float(reg_max), float(reg_factor), bool(is_training))
+        ctx.sldj_shape = sldj.shape
+        return z_out, ldj_out
+
+    @staticmethod
+    def backward(ctx, g_zout, g_ldj):
+        hold = _Hold()
+        z, nn_out, sf, msf, mask, pad, length, z_out, bias, scales, weight = ctx.saved_tensors
+        has_sf, has_msf, has_mask, has_pad, has_ldj, has_len = ctx.flags
+        K, reg_max, reg_factor, is_training = ctx.cfg
+        pad_t, len_t = (pad if has_pad else None), (length if has_len else None)
+        g_zc, g_b, g_s, g_w, g_sl = _actconv_bwd(z_out, True, bias, scales, weight, len_t, pad_t, g_zout, g_ldj, hold)
+        g_z, g_nn, g_sf, g_msf = _mixture_bwd(z, nn_out, sf if has_sf else None, msf if has_msf else None, mask if has_mask else None,
+                                              pad_t, g_zc, g_ldj, K, reg_max, reg_factor, is_training, True, True, hold)
+        return (g_z, g_nn, g_sf, g_msf, g_b, g_s, g_w, g_sl.view(ctx.sldj_shape), (g_ldj if has_ldj else None),
+                None, None, None, None, None, None, None)
+
+
+class EncoderActConvFn(torch.autograd.Function):
+    """Categorical encoder (sampling its own logistic noise from the uniform draw) + ActNorm + 1x1 convolution of the first
+    flow step: ONE forward kernel (cnf_encoder_forward_actconv).  The backward recovers the encoder's latents' gradient
+    through cnf_actnorm_invconv_bwd (saved_is_output = 1) and re-samples the noise from the saved uniform draw for the
+    encoder's own backward kernels.  (table, bias, scales, weight, sldj, ldj) -> (z', ldj')."""
+
+    @staticmethod
+    def forward(ctx, table, bias, scales, weight, sldj, ldj, categ, uniform, prior, pad, length, beta, squeeze):
+        z_out, ldj_out = ops.encoder_forward_actconv(categ, uniform, table, prior, bias, scales, weight, sldj, beta=beta,
+                                                     channel_padding_mask=pad, length=length, ldj=ldj, uniform_squeeze=squeeze)
+        empty = z_out.new_empty(0)
+        ctx.save_for_backward(table, categ, uniform, prior, pad if isinstance(pad, torch.Tensor) else empty,
+                              length if isinstance(length, torch.Tensor) else empty, z_out, bias, scales, weight)
+        ctx.has_pad, ctx.has_len, ctx.has_ldj = isinstance(pad, torch.Tensor), isinstance(length, torch.Tensor), ldj is not None
+        ctx.beta, ctx.squeeze, ctx.sldj_shape = float(beta), float(squeeze), sldj.shape
+        return z_out, ldj_out
+
+    @staticmethod
+    def backward(ctx, g_zout, g_ldj):
+        hold = _Hold()
+        table, categ, uniform, prior, pad, length, z_out, bias, scales, weight = ctx.saved_tensors
+        pad_t, len_t = (pad if ctx.has_pad else None), (length if ctx.has_len else None)
+        g_ze, g_b, g_s, g_w, g_sl = _actconv_bwd(z_out, True, bias, scales, weight, len_t, pad_t, g_zout, g_ldj, hold)
+        dev = table.device
+        B, N = categ.shape
+        C, D = table.shape[0], table.shape[1] // 2
+        eps = ops.logistic_from_uniform(uniform, mu=0.0, sigma=ops.LOGISTIC_SIGMA, eps=ctx.squeeze)
+        tc, pc = _f32(table, "table"), _f32(prior, "category_prior")
+        p2 = _pad2d(pad, B, N, dev) if ctx.has_pad else None
+        g_table = torch.empty_like(tc)
+        ws = torch.empty(int(_lib.load().cnf_encoder_bwd_tiled_workspace_floats(B, N, D, C)), dtype=torch.float32, device=dev)
+        _launch(dev, "cnf_encoder_forward_bwd_tiled", _ptr(categ.contiguous()), _ptr(_f32(eps, "eps")), _ptr(tc), _ptr(pc), _ptr(p2), ctx.beta,
+                _ptr(g_ze), hold(g_ldj), _ptr(g_table), _ptr(ws), B, N, D, C,
+                float(ops.LOGISTIC_SIGMA), float(ops.LOGISTIC_LOG_SIGMA), _stream(dev))
+        return (g_table, g_b, g_s, g_w, g_sl.view(ctx.sldj_shape), (g_ldj if ctx.has_ldj else None),
+                None, None, None, None, None, None, None)
+
+
 class LogisticLogProbFn(torch.autograd.Function):
 
     @staticmethod
@@ -201,17 +355,8 @@ class PriorNllFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_nll):
-        hold = _Hold()
         z, length, pad = ctx.saved_tensors
-        dev = z.device
-        B, N, D = z.shape
-        zc = _f32(z, "z")
-        p2 = _pad2d(pad, B, N, dev) if ctx.has_pad else None
-        ln = _length(length, B, dev) if ctx.has_len else None
-        g_z = torch.empty_like(zc)
-        g_ldj = torch.empty(B, dtype=torch.float32, device=dev)
-        _launch(dev, "cnf_prior_nll_bwd", _ptr(zc), _ptr(p2), _ptr(ln), hold(g_nll), _ptr(g_z), _ptr(g_ldj), B, N, D,
-                                         float(ops.LOGISTIC_SIGMA), _stream(dev))
+        g_z, g_ldj = _prior_nll_bwd(z, length if ctx.has_len else None, pad if ctx.has_pad else None, g_nll, _Hold())
         return g_z, g_ldj, None, None
 
 
@@ -237,6 +382,43 @@ class SigmoidFlowFn(torch.autograd.Function):
         return g_z, (g_ldj if ctx.has_ldj else None), None, None
 
 
+def _mixture_bwd(z, nn_out, sf, msf, mask, pad, g_zout, g_ldj, K, reg_max, reg_factor, is_training, pit, pout, hold):
+    """One launch of cnf_mixture_coupling_bwd_f32 (+ its reductions): (g_z, g_nn, g_sf or None, g_msf or None); sf / msf / mask /
+    pad are tensors or None."""
+    dev = z.device
+    B, N, D = z.shape
+    zc, nn_c = _f32(z, "z"), _f32(nn_out, "nn_out")
+    sfc = _opt_f32(sf, "scaling_factor", dev) if sf is not None else None
+    msfc = _opt_f32(msf, "mixture_scaling_factor", dev) if msf is not None else None
+    m, mr, mc = _mask_desc(mask, D, dev)
+    p2 = _pad2d(pad, B, N, dev) if pad is not None else None
+    g_z, g_nn = torch.empty_like(zc), torch.empty_like(nn_c)
+    g_sf = torch.empty(D, dtype=torch.float32, device=dev) if sf is not None else None
+    g_msf = torch.empty(D, K, dtype=torch.float32, device=dev) if msf is not None else None
+    ws = _ws(D + D * K, dev)
+    act, n_act = ops._act_list(mask, m, mr, mc, D)
+    _launch(dev, "cnf_mixture_coupling_bwd_f32", _ptr(zc), _ptr(nn_c), _ptr(sfc), _ptr(msfc), _ptr(m), mr, mc, act, n_act,
+                                                _ptr(p2), int(pit), int(pout),
+                                                hold(g_zout), hold(g_ldj), _ptr(g_z), _ptr(g_nn), _ptr(g_sf), _ptr(g_msf), _ptr(ws),
+                                                B, N, D, K, reg_max, reg_factor, int(is_training), _stream(dev))
+    return (g_z, g_nn.view_as(nn_out), (g_sf.view_as(sf) if sf is not None else None),
+            (g_msf.view_as(msf) if msf is not None else None))
+
+
+def _prior_nll_bwd(z, length, pad, g_nll, hold):
+    """cnf_prior_nll_bwd: (g_z, g_ldj) of the NLL assembly."""
+    dev = z.device
+    B, N, D = z.shape
+    zc = _f32(z, "z")
+    p2 = _pad2d(pad, B, N, dev) if pad is not None else None
+    ln = _length(length, B, dev) if length is not None else None
+    g_z = torch.empty_like(zc)
+    g_ldj = torch.empty(B, dtype=torch.float32, device=dev)
+    _launch(dev, "cnf_prior_nll_bwd", _ptr(zc), _ptr(p2), _ptr(ln), hold(g_nll), _ptr(g_z), _ptr(g_ldj), B, N, D,
+                                     float(ops.LOGISTIC_SIGMA), _stream(dev))
+    return g_z, g_ldj
+
+
 class MixtureCouplingFn(torch.autograd.Function):
     """(z, nn_out, scaling_factor, mixture_scaling_factor, ldj) -> (z', ldj + layer_ldj, reg_sum); forward direction only."""
 
@@ -259,24 +441,42 @@ class MixtureCouplingFn(torch.autograd.Function):
         z, nn_out, sf, msf, mask, pad = ctx.saved_tensors
         has_sf, has_msf, has_mask, has_pad, has_ldj = ctx.flags
         K, reg_max, reg_factor, is_training, pit, pout = ctx.cfg
-        dev = z.device
-        B, N, D = z.shape
-        zc, nn_c = _f32(z, "z"), _f32(nn_out, "nn_out")
-        sfc = _opt_f32(sf, "scaling_factor", dev) if has_sf else None
-        msfc = _opt_f32(msf, "mixture_scaling_factor", dev) if has_msf else None
-        m, mr, mc = _mask_desc(mask if has_mask else None, D, dev)
-        p2 = _pad2d(pad, B, N, dev) if has_pad else None
-        g_z, g_nn = torch.empty_like(zc), torch.empty_like(nn_c)
-        g_sf = torch.empty(D, dtype=torch.float32, device=dev) if has_sf else None
-        g_msf = torch.empty(D, K, dtype=torch.float32, device=dev) if has_msf else None
-        ws = _ws(D + D * K, dev)
-        act, n_act = ops._act_list(mask if has_mask else None, m, mr, mc, D)
-        _launch(dev, "cnf_mixture_coupling_bwd_f32", _ptr(zc), _ptr(nn_c), _ptr(sfc), _ptr(msfc), _ptr(m), mr, mc, act, n_act,
-                                                    _ptr(p2), int(pit), int(pout),
-                                                    hold(g_zout), hold(g_ldj), _ptr(g_z), _ptr(g_nn), _ptr(g_sf), _ptr(g_msf), _ptr(ws),
-                                                    B, N, D, K, reg_max, reg_factor, int(is_training), _stream(dev))
-        return (g_z, g_nn.view_as(nn_out), (g_sf.view_as(sf) if has_sf else None), (g_msf.view_as(msf) if has_msf else None),
-                (g_ldj if has_ldj else None), None, None, None, None, None, None, None, None)
+        g_z, g_nn, g_sf, g_msf = _mixture_bwd(z, nn_out, sf if has_sf else None, msf if has_msf else None, mask if has_mask else None,
+                                              pad if has_pad else None, g_zout, g_ldj, K, reg_max, reg_factor, is_training, pit, pout, hold)
+        return (g_z, g_nn, g_sf, g_msf, (g_ldj if has_ldj else None), None, None, None, None, None, None, None, None)
+
+
+class MixtureCouplingNllFn(torch.autograd.Function):
+    """The LAST mixture coupling of a flow + the NLL assembly (set_modeling/task.py:96-118) in ONE forward kernel
+    (cnf_mixture_coupling_nll); the backward is the NLL assembly's and the coupling's backward kernels in one Function.
+    (z, nn_out, sf, msf, ldj) -> (nll [B], z', ldj'); z' and ldj' are for reports only (not differentiable)."""
+
+    @staticmethod
+    def forward(ctx, z, nn_out, sf, msf, ldj, mask, pad, length, K, reg_max, reg_factor, is_training, sigma, log_sigma):
+        z_out, ldj_out, _, _, nll = ops.mixture_coupling_nll(z, nn_out, mask, K, sf, msf, channel_padding_mask=pad, reg_max=reg_max,
+                                                             reg_factor=reg_factor, is_training=is_training, ldj=ldj, length=length,
+                                                             want_reg=False, sigma=sigma, log_sigma=log_sigma)
+        empty = z_out.new_empty(0)
+        ctx.save_for_backward(z, nn_out, sf if sf is not None else empty, msf if msf is not None else empty,
+                              mask if mask is not None else empty, pad if isinstance(pad, torch.Tensor) else empty,
+                              length if isinstance(length, torch.Tensor) else empty, z_out)
+        ctx.flags = (sf is not None, msf is not None, mask is not None, isinstance(pad, torch.Tensor), ldj is not None,
+                     isinstance(length, torch.Tensor))
+        ctx.cfg = (int(K), float(reg_max), float(reg_factor), bool(is_training))
+        ctx.mark_non_differentiable(z_out, ldj_out)
+        return nll, z_out, ldj_out
+
+    @staticmethod
+    def backward(ctx, g_nll, _g_z, _g_l):
+        hold = _Hold()
+        z, nn_out, sf, msf, mask, pad, length, z_out = ctx.saved_tensors
+        has_sf, has_msf, has_mask, has_pad, has_ldj, has_len = ctx.flags
+        K, reg_max, reg_factor, is_training = ctx.cfg
+        pad_t = pad if has_pad else None
+        g_zo, g_ldj = _prior_nll_bwd(z_out, length if has_len else None, pad_t, g_nll, hold)
+        g_z, g_nn, g_sf, g_msf = _mixture_bwd(z, nn_out, sf if has_sf else None, msf if has_msf else None, mask if has_mask else None,
+                                              pad_t, g_zo, g_ldj, K, reg_max, reg_factor, is_training, True, True, hold)
+        return (g_z, g_nn, g_sf, g_msf, (g_ldj if has_ldj else None), None, None, None, None, None, None, None, None, None)
 
 
 class EncoderForwardFn(torch.autograd.Function):

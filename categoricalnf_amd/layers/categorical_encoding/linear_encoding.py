@@ -122,16 +122,22 @@ class LinearCategoricalEncoding(FlowLayer):
         ldj = ldj + ldj_loc if ldj is not None else ldj_loc
         return z_out, ldj, detailed_ldj
 
-    def fusable_with_actconv(self):
+    def fusable_with_actconv(self, differentiable=False):
         """FlowModel may run this layer together with the ActNorm + 1x1 convolution behind it: the one-kernel mixture-model
-        encoder in evaluation mode (training mode reports statistics of the encoder's own latents, :95-106)."""
-        return self._is_mixture_model() and not self.training
+        encoder in evaluation mode (training mode reports statistics of the encoder's own latents, :95-106) — or, with
+        `differentiable`, on a training pass whose per-layer report nobody asked for (the statistics would be dropped)."""
+        return self._is_mixture_model() and (differentiable or not self.training)
 
     def forward_with_actconv(self, z, act_bias, act_scales, conv_weight, conv_sldj, ldj=None, beta=1, channel_padding_mask=None,
-                             length=None, noise=None):
+                             length=None, noise=None, differentiable=False):
         """forward() followed by ActNormFlow.forward and InvertibleConv.forward of the next flow step, as one kernel
-        (cnf_encoder_forward_actconv); returns (latents after the convolution, running log-det)."""
+        (cnf_encoder_forward_actconv); returns (latents after the convolution, running log-det).  `differentiable`: through
+        functional.EncoderActConvFn (one backward for the three layers)."""
         u = self._uniform_draw(z.size(0) * z.size(1), z.device, noise)
+        if differentiable:
+            return Fn.EncoderActConvFn.apply(self.class_table(), act_bias, act_scales, conv_weight, conv_sldj, ldj, z, u,
+                                             self.category_prior, channel_padding_mask, length, float(beta),
+                                             float(self.prior_distribution.eps))
         return ops.encoder_forward_actconv(z, u, self.class_table(), self.category_prior, act_bias, act_scales, conv_weight,
                                            conv_sldj, beta=float(beta), channel_padding_mask=channel_padding_mask,
                                            length=length, ldj=ldj, uniform_squeeze=float(self.prior_distribution.eps))

@@ -7,6 +7,7 @@ by device-side flag bits that the kernels raise and that are checked ONCE at the
 import torch
 import torch.nn as nn
 
+from ... import functional as Fn
 from ... import ops
 from .activation_normalization import ActNormFlow
 from .permutation_layers import InvertibleConv
@@ -35,6 +36,10 @@ class FlowModel(nn.Module):
             order.reverse()
         per_layer = []
         fusable = self._fusable(z, get_ldj_per_layer)
+        # the same fusions on the TRAINING path (forward direction, autograd on): one autograd.Function per fused group whose
+        # backward recomputes the intermediate the forward kept in registers (functional.ActConvFn / MixtureActConvFn /
+        # EncoderActConvFn)
+        trainable = self._fusable_training(z, get_ldj_per_layer, reverse)
         skip = set()
         for pos, (index, layer) in enumerate(order):
             if index in skip:
@@ -43,7 +48,8 @@ class FlowModel(nn.Module):
             # with the categorical encoder is handed int64 categories: until round 3 that switched every fusion of the
             # encoding direction off, because the test looked at the pass's input only)
             fuse = fusable and z.dtype == torch.float32
-            if (fuse and not reverse and pos + 2 < len(order) and type(layer).__name__ == "MixtureCDFCoupling"
+            fuse_train = trainable and z.dtype == torch.float32
+            if ((fuse or fuse_train) and not reverse and pos + 2 < len(order) and type(layer).__name__ == "MixtureCDFCoupling"
                     and type(order[pos + 1][1]) is ActNormFlow and type(order[pos + 2][1]) is InvertibleConv
                     and layer.c_in in ops.FUSED_ACTCONV_DIMS):
                 # mixture coupling of this flow step + ActNorm + 1x1 conv of the next one in ONE kernel: the coupling's
@@ -53,6 +59,13 @@ class FlowModel(nn.Module):
                 net_kwargs = {k: v for k, v in kwargs.items() if k != "channel_padding_mask"}
                 nn_out = layer.run_network(x=z * layer._prepare_mask(layer.mask, z), **net_kwargs)
                 weight, sldj = conv._get_weight(device_name=str(z.device), inverse=False)
+                if fuse_train:
+                    z, ldj = Fn.MixtureActConvFn.apply(
+                        z, nn_out, layer.scaling_factor, layer.mixture_scaling_factor, act.bias, act.scales, weight, sldj, ldj,
+                        layer.mask, pad, kwargs.get("length", None), layer.num_mixtures, layer.regularizer_max,
+                        layer.regularizer_factor, layer.training)
+                    skip.update((order[pos + 1][0], order[pos + 2][0]))
+                    continue
                 z, ldj, _ = ops.mixture_coupling_actconv(
                     z, nn_out, layer.mask, layer.num_mixtures, act.bias, act.scales, weight, sldj,
                     scaling_factor=layer.scaling_factor, mixture_scaling_factor=layer.mixture_scaling_factor,
@@ -60,17 +73,18 @@ class FlowModel(nn.Module):
                     reg_factor=layer.regularizer_factor, is_training=layer.training, ldj=ldj, want_reg=False)
                 skip.update((order[pos + 1][0], order[pos + 2][0]))
                 continue
-            if (fusable and not reverse and pos + 2 < len(order) and type(layer).__name__ == "LinearCategoricalEncoding"
+            if ((fusable or trainable) and not reverse and pos + 2 < len(order) and type(layer).__name__ == "LinearCategoricalEncoding"
                     and not z.is_floating_point()
                     and type(order[pos + 1][1]) is ActNormFlow and type(order[pos + 2][1]) is InvertibleConv
-                    and layer.fusable_with_actconv() and order[pos + 1][1].c_in in ops.FUSED_ACTCONV_DIMS):
+                    and layer.fusable_with_actconv(differentiable=trainable) and order[pos + 1][1].c_in in ops.FUSED_ACTCONV_DIMS):
                 # encoder + ActNorm + 1x1 conv of the first flow step in ONE kernel: the latents go to HBM once, already
                 # transformed (same arithmetic as the three layers, bit for bit)
                 act, conv = order[pos + 1][1], order[pos + 2][1]
                 weight, sldj = conv._get_weight(device_name=str(z.device), inverse=False)
                 z, ldj = layer.forward_with_actconv(z, act.bias, act.scales, weight, sldj, ldj=ldj, beta=kwargs.get("beta", 1),
                                                     channel_padding_mask=kwargs.get("channel_padding_mask", None),
-                                                    length=kwargs.get("length", None), noise=kwargs.get("noise", None))
+                                                    length=kwargs.get("length", None), noise=kwargs.get("noise", None),
+                                                    differentiable=trainable)
                 skip.update((order[pos + 1][0], order[pos + 2][0]))
                 continue
             if (fuse and reverse and pos + 2 < len(order) and type(layer) is InvertibleConv and type(order[pos + 1][1]) is ActNormFlow
@@ -85,40 +99,59 @@ class FlowModel(nn.Module):
                                                  length=kwargs.get("length", None))
                 skip.update((order[pos + 1][0], order[pos + 2][0]))
                 continue
-            if fuse and pos + 1 < len(order):
+            if (fuse or fuse_train) and pos + 1 < len(order):
                 pair = (layer, order[pos + 1][1]) if not reverse else (order[pos + 1][1], layer)
                 if type(pair[0]) is ActNormFlow and type(pair[1]) is InvertibleConv and pair[0].c_in in ops.FUSED_ACTCONV_DIMS:
                     # ActNorm -> 1x1 conv (or the pair backwards) in one kernel; same arithmetic as the two layers
                     weight, sldj = pair[1]._get_weight(device_name=str(z.device), inverse=reverse)
+                    if fuse_train:
+                        z, ldj = Fn.ActConvFn.apply(z, pair[0].bias, pair[0].scales, weight, sldj, ldj, kwargs.get("length", None),
+                                                    kwargs.get("channel_padding_mask", None))
+                        skip.add(order[pos + 1][0])
+                        continue
                     z, ldj = ops.actnorm_invconv(z, pair[0].bias, pair[0].scales, weight, sldj, reverse=reverse,
                                                  length=kwargs.get("length", None),
                                                  channel_padding_mask=kwargs.get("channel_padding_mask", None), ldj=ldj)
                     skip.add(order[pos + 1][0])
                     continue
-            if (nll_request is not None and pos == len(order) - 1 and type(layer).__name__ == "CouplingLayer"
-                    and not reverse and not torch.is_grad_enabled()):
+            last_with_nll = (nll_request is not None and pos == len(order) - 1 and not reverse and z.is_cuda and z.dtype == torch.float32
+                             and (not torch.is_grad_enabled() or trainable))
+            if last_with_nll and type(layer).__name__ == "CouplingLayer":
                 # last layer = affine coupling: transform + prior log-prob + NLL in one kernel
+                pad = kwargs.get("channel_padding_mask", None)
                 net_kwargs = {k: v for k, v in kwargs.items() if k != "channel_padding_mask"}
                 nn_out = layer.run_network(x=z * layer._prepare_mask(layer.mask, z), **net_kwargs)
+                if torch.is_grad_enabled():
+                    nll_request["nll"], z, ldj = Fn.AffineCouplingNllFn.apply(
+                        z, nn_out, layer.scaling_factor, ldj, layer.mask, pad, nll_request["length"],
+                        nll_request["sigma"], nll_request["log_sigma"])
+                    if nll_request["sums"] is not None:
+                        ops.nll_sum(nll_request["nll"].detach(), nll_request["sums"])
+                    continue
                 z, ldj, _, nll_request["nll"] = ops.affine_coupling_nll(
                     z, nn_out, layer.scaling_factor, layer.mask, ldj=ldj, length=nll_request["length"],
-                    channel_padding_mask=kwargs.get("channel_padding_mask", None), sums=nll_request["sums"],
+                    channel_padding_mask=pad, sums=nll_request["sums"],
                     sigma=nll_request["sigma"], log_sigma=nll_request["log_sigma"])
                 continue
-            if (nll_request is not None and pos == len(order) - 1 and type(layer).__name__ == "MixtureCDFCoupling"
-                    and not reverse and not torch.is_grad_enabled() and z.is_cuda):
+            if last_with_nll and type(layer).__name__ == "MixtureCDFCoupling":
                 # last layer = mixture-CDF coupling (every flow of the four experiments ends in one, e.g.
                 # experiments/set_modeling/flow_model.py:58-62): transform + prior log-prob + NLL in one kernel
                 pad = kwargs.get("channel_padding_mask", None)
                 net_kwargs = {k: v for k, v in kwargs.items() if k != "channel_padding_mask"}
                 nn_out = layer.run_network(x=z * layer._prepare_mask(layer.mask, z), **net_kwargs)
-                z, ldj, reg, _, nll_request["nll"] = ops.mixture_coupling_nll(
-                    z, nn_out, layer.mask, layer.num_mixtures, layer.scaling_factor, layer.mixture_scaling_factor,
-                    channel_padding_mask=pad, reg_max=layer.regularizer_max, reg_factor=layer.regularizer_factor,
-                    is_training=layer.training, ldj=ldj, length=nll_request["length"],
-                    sigma=nll_request["sigma"], log_sigma=nll_request["log_sigma"])
+                if torch.is_grad_enabled():
+                    nll_request["nll"], z, ldj = Fn.MixtureCouplingNllFn.apply(
+                        z, nn_out, layer.scaling_factor, layer.mixture_scaling_factor, ldj, layer.mask, pad, nll_request["length"],
+                        layer.num_mixtures, layer.regularizer_max, layer.regularizer_factor, layer.training,
+                        nll_request["sigma"], nll_request["log_sigma"])
+                else:
+                    z, ldj, reg, _, nll_request["nll"] = ops.mixture_coupling_nll(
+                        z, nn_out, layer.mask, layer.num_mixtures, layer.scaling_factor, layer.mixture_scaling_factor,
+                        channel_padding_mask=pad, reg_max=layer.regularizer_max, reg_factor=layer.regularizer_factor,
+                        is_training=layer.training, ldj=ldj, length=nll_request["length"],
+                        sigma=nll_request["sigma"], log_sigma=nll_request["log_sigma"])
                 if nll_request["sums"] is not None:
-                    ops.nll_sum(nll_request["nll"], nll_request["sums"])
+                    ops.nll_sum(nll_request["nll"].detach(), nll_request["sums"])
                 continue
             res = layer(z, reverse=reverse, get_ldj_per_layer=get_ldj_per_layer, **kwargs)
             if len(res) == 2:
@@ -136,14 +169,37 @@ class FlowModel(nn.Module):
             else:
                 per_layer.append(detail)
         if nll_request is not None and "nll" not in nll_request:
-            _, nll_request["nll"] = ops.prior_nll(z, ldj, nll_request["length"], kwargs.get("channel_padding_mask", None),
-                                                  sums=nll_request["sums"], sigma=nll_request["sigma"],
-                                                  log_sigma=nll_request["log_sigma"])
+            if torch.is_grad_enabled() and (z.requires_grad or ldj.requires_grad):
+                nll_request["nll"] = Fn.PriorNllFn.apply(z, ldj, nll_request["length"], kwargs.get("channel_padding_mask", None))
+                if nll_request["sums"] is not None:
+                    ops.nll_sum(nll_request["nll"].detach(), nll_request["sums"])
+            else:
+                _, nll_request["nll"] = ops.prior_nll(z, ldj, nll_request["length"], kwargs.get("channel_padding_mask", None),
+                                                      sums=nll_request["sums"], sigma=nll_request["sigma"],
+                                                      log_sigma=nll_request["log_sigma"])
         if z.is_cuda:
             ops.check_flags(z.device, "Flow: %s" % self.name)
+        if nll_request is not None:
+            # the NLL is RETURNED as well (a wrapper such as DistributedDataParallel hands the module a copy of its keyword
+            # containers: the caller's dict would stay empty)
+            return (z, ldj, nll_request["nll"], per_layer) if get_ldj_per_layer else (z, ldj, nll_request["nll"])
         if get_ldj_per_layer:
             return z, ldj, per_layer
         return z, ldj
+
+    def nll_request(self, length=None, prior=None, sums=None):
+        """The `_nll` keyword of `forward`: ask the pass to assemble the per-sample NLL under a zero-mean logistic prior as well —
+        fused into the last coupling layer where there is one — and leave it in the returned dict's "nll".  With autograd on
+        the result is differentiable (functional.MixtureCouplingNllFn / AffineCouplingNllFn / PriorNllFn), so a training loop
+        can go through a wrapper module's forward (DistributedDataParallel); a pass given `_nll` returns (z, ldj, nll):
+            z, ldj, nll = ddp(x, length=ln, _nll=flow.nll_request(length=ln)); loss = nll.mean()"""
+        from .distributions import LogisticDistribution
+        prior = prior if prior is not None else LogisticDistribution()
+        if type(prior) is not LogisticDistribution or float(prior.mu) != 0.0:
+            raise NotImplementedError("FlowModel.nll: zero-mean LogisticDistribution prior only")
+        if float(prior.sigma) != ops.LOGISTIC_SIGMA and torch.is_grad_enabled():
+            raise NotImplementedError("the differentiable NLL assembly is built for the unit logistic prior")
+        return {"sigma": float(prior.sigma), "log_sigma": float(prior.log_sigma), "sums": sums, "length": length}
 
     @torch.no_grad()
     def nll(self, z, length=None, prior=None, sums=None, **kwargs):
@@ -155,21 +211,29 @@ class FlowModel(nn.Module):
         When the last flow layer is an affine `CouplingLayer` or a `MixtureCDFCoupling`, that layer and the NLL
         assembly run as ONE kernel (cnf_affine_coupling_nll / cnf_mixture_coupling_nll: the prior term is accumulated
         while z is still in registers); otherwise the separate prior kernel is used.  Same numbers either way (tests).  Goes through `self.forward`, so the masks a
-        subclass builds from `length` reach the layers as usual."""
-        from .distributions import LogisticDistribution
-        prior = prior if prior is not None else LogisticDistribution()
-        if type(prior) is not LogisticDistribution or float(prior.mu) != 0.0:
-            raise NotImplementedError("FlowModel.nll: zero-mean LogisticDistribution prior only")
-        request = {"sigma": float(prior.sigma), "log_sigma": float(prior.log_sigma), "sums": sums, "length": length}
+        subclass builds from `length` reach the layers as usual.  `nll_loss` is the differentiable twin."""
+        request = self.nll_request(length, prior, sums)
         if length is not None:
             kwargs["length"] = length
-        z, ldj = self.forward(z, reverse=False, _nll=request, **kwargs)
-        return z, ldj, request["nll"]
+        return self.forward(z, reverse=False, _nll=request, **kwargs)
+
+    def nll_loss(self, z, length=None, prior=None, **kwargs):
+        """`nll` with autograd on: (z, ldj, nll [B]) with a differentiable nll (training loops: `nll.mean().backward()`)."""
+        request = self.nll_request(length, prior, None)
+        if length is not None:
+            kwargs["length"] = length
+        return self.forward(z, reverse=False, _nll=request, **kwargs)
 
     def _fusable(self, z, get_ldj_per_layer):
         """Layer fusion only where it is unobservable: no autograd, no per-layer log-det report, CUDA tensors."""
         return (not get_ldj_per_layer and not torch.is_grad_enabled() and isinstance(z, torch.Tensor) and z.is_cuda
                 and ops.FUSE_LAYERS)
+
+    def _fusable_training(self, z, get_ldj_per_layer, reverse):
+        """Layer fusion with autograd on: forward direction, no per-layer report (the fused groups have no per-layer log-det and
+        the encoder's monitoring scalars are not computed), CUDA tensors; ops.FUSE_TRAINING = False restores one Function per layer."""
+        return (not reverse and not get_ldj_per_layer and torch.is_grad_enabled() and isinstance(z, torch.Tensor) and z.is_cuda
+                and ops.FUSE_LAYERS and ops.FUSE_TRAINING)
 
     def reverse(self, z):
         """The inverse pass.  (The reference's one-liner, flow_model.py:56-57, passes an undefined name and can only

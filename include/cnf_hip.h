@@ -466,6 +466,18 @@ int cnf_invconv_bwd(const float* x, const float* weight, const float* pad, const
                     float* g_x, float* g_weight, float* g_sldj, float* workspace,
                     int B, int N, int D, int reverse, cnf_stream_t stream);
 
+/* d(ActNormFlow.forward -> InvertibleConv.forward) of one flow step in ONE kernel (activation_normalization.py:35-43 then
+ * permutation_layers.py:112-121, forward direction; the forward is cnf_actnorm_invconv).  The pair's intermediate is
+ * recomputed per token: from the pair's input (saved_is_output = 0: the forward's arithmetic, the same bits) or from the
+ * pair's output through W^-1 (saved_is_output = 1: the pair ran fused behind a coupling layer / the encoder, whose own
+ * output never reached HBM); weight_inv may then be NULL — the inverse is computed on the device in fp64, as the reference
+ * inverts (permutation_layers.py:76).  g_params [D*D + 1 + 2D] = d weight | d sldj | d bias | d scales, summed in a fixed
+ * order (bit-reproducible); workspace: cnf_bwd_workspace_floats(D*D + 2D + 2).  D in {1..6, 8}, else CNF_ERR_UNSUPPORTED. */
+int cnf_actnorm_invconv_bwd(const float* saved, int saved_is_output, const float* bias, const float* scales, const float* weight,
+                            const float* weight_inv, const float* pad, const float* length,
+                            const float* g_zout, const float* g_ldj, float* g_z, float* g_params, float* workspace,
+                            int B, int N, int D, cnf_stream_t stream);
+
 /* d(LogisticDistribution.log_prob) and d(NLL assembly) w.r.t. z (and ldj). */
 int cnf_logistic_log_prob_bwd(const float* x, const float* g_logp, float* g_x, int64_t n, float mu, float sigma,
                               cnf_stream_t stream);

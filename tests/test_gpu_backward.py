@@ -266,3 +266,229 @@ def test_missing_upstream_gradients_are_zeros():
             torch.cuda.synchronize()
             for x, y in zip(got, want):
                 assert torch.equal(x, y), fn.__name__
+
+
+# ---- fused training groups (functional.ActConvFn / MixtureActConvFn / EncoderActConvFn) ---------------------------------------
+def _actconv_params(D, gen):
+    bias, scales = torch.randn(1, 1, D, generator=gen), 0.3 * torch.randn(1, 1, D, generator=gen)
+    w = torch.linalg.qr(torch.randn(D, D, generator=gen))[0].contiguous() + 0.05 * torch.randn(D, D, generator=gen)
+    return bias, scales, w, torch.slogdet(w)[1].detach()
+
+
+def _pad_len(B, N, seed, gen):
+    ln = torch.randint(1, N + 1, (B,), generator=gen)
+    ln[0] = N
+    pad = O.length_mask(ln, N) if seed % 3 else None
+    length = ln.float() if seed % 2 else None
+    return pad, length
+
+
+@pytest.mark.parametrize("B,N,D,seed", _shapes(21, 30, dims=(1, 2, 3, 4, 5, 6, 8)) + [(512, 64, 6, 5), (300, 38, 6, 7), (256, 16, 4, 6)])
+def test_actconv_fn_vs_oracle_autograd(B, N, D, seed):
+    """ActNorm -> 1x1 convolution as one Function (one forward, ONE backward kernel that recomputes the intermediate from the
+    saved input) against autograd through O.actnorm -> O.invconv; and its output against the two layers' kernels (equal bits)."""
+    from categoricalnf_amd import functional as Fn
+    gen = torch.Generator().manual_seed(seed)
+    z = torch.randn(B, N, D, generator=gen)
+    bias, scales, w, sldj = _actconv_params(D, gen)
+    pad, length = _pad_len(B, N, seed, gen)
+    ldj0, wz, wl = torch.randn(B, generator=gen), torch.randn(B, N, D, generator=gen), torch.randn(B, generator=gen)
+    zc, bc, sc, wc, slc, lc = _leaf(z), _leaf(bias), _leaf(scales), _leaf(w), _leaf(sldj), _leaf(ldj0)
+    za, la = O.actnorm(zc, bc, sc, length=length, channel_padding_mask=pad, ldj=lc * 1.0)
+    zo, lo = O.invconv(za, wc, slc, length=length, channel_padding_mask=pad, ldj=la)
+    ((zo * wz).sum() + (lo * wl).sum()).backward()
+    zg, bg, sg, wg, slg, lg = _leaf(z, True), _leaf(bias, True), _leaf(scales, True), _leaf(w, True), _leaf(sldj, True), _leaf(ldj0, True)
+    zh, lh = Fn.ActConvFn.apply(zg, bg, sg, wg, slg, lg, g(length), g(pad))
+    ((zh * g(wz)).sum() + (lh * g(wl)).sum()).backward()
+    grad_close(zh, zo, "z_out", rel=2e-5); grad_close(lh, lo, "ldj_out", rel=2e-5)
+    grad_close(zg.grad, zc.grad, "g_z"); grad_close(lg.grad, lc.grad, "g_ldj")
+    grad_close(bg.grad, bc.grad, "g_bias", rel=5e-4); grad_close(sg.grad, sc.grad, "g_scales", rel=5e-4)
+    grad_close(wg.grad, wc.grad, "g_weight", rel=5e-4); grad_close(slg.grad, slc.grad, "g_sldj", rel=5e-4)
+    # the two layers' Functions: same forward bits; gradients to the rounding of another summation order
+    z2, b2, s2, w2, sl2, l2 = _leaf(z, True), _leaf(bias, True), _leaf(scales, True), _leaf(w, True), _leaf(sldj, True), _leaf(ldj0, True)
+    ya, la2 = Fn.ActNormFn.apply(z2, b2, s2, l2, g(length), g(pad), False)
+    yo, lo2 = Fn.InvConvFn.apply(ya, w2, sl2, la2, g(length), g(pad), False)
+    ((yo * g(wz)).sum() + (lo2 * g(wl)).sum()).backward()
+    assert torch.equal(yo, zh) and torch.equal(lo2, lh)
+    grad_close(zg.grad, z2.grad, "g_z vs chain", rel=1e-5); grad_close(wg.grad, w2.grad, "g_weight vs chain", rel=2e-5)
+    grad_close(bg.grad, b2.grad, "g_bias vs chain", rel=2e-5); grad_close(sg.grad, s2.grad, "g_scales vs chain", rel=2e-5)
+
+
+@pytest.mark.parametrize("B,N,D,K,seed", [(64, 16, 4, 8, 1), (33, 17, 6, 4, 2), (128, 8, 2, 8, 3), (20, 38, 6, 5, 4), (8, 5, 5, 3, 5), (256, 16, 4, 8, 6),
+                                         (5, 64, 3, 16, 7), (64, 64, 6, 8, 9)])
+def test_mixture_actconv_fn_vs_oracle_autograd(B, N, D, K, seed):
+    """Mixture coupling + ActNorm + 1x1 convolution as one Function: the backward recovers the coupling's output from the
+    group's output (W^-1 on the device) — against autograd through O.mixture_coupling -> O.actnorm -> O.invconv."""
+    from categoricalnf_amd import functional as Fn
+    gen = torch.Generator().manual_seed(seed)
+    z = torch.randn(B, N, D, generator=gen)
+    nn_out = 0.5 * torch.randn(B, N, D * (2 + 3 * K), generator=gen)
+    sf, msf = 0.2 * torch.randn(D, generator=gen), 0.2 * torch.randn(D, K, generator=gen)
+    mask = _mask("channel", D)
+    bias, scales, w, sldj = _actconv_params(D, gen)
+    pad, length = _pad_len(B, N, seed, gen)
+    ldj0, wz, wl = torch.randn(B, generator=gen), torch.randn(B, N, D, generator=gen), torch.randn(B, generator=gen)
+    leaves = [_leaf(t) for t in (z, nn_out, sf, msf, bias, scales, w, sldj, ldj0)]
+    zc, nc, sfc, msfc, bc, sc, wc, slc, lc = leaves
+    z1, l1, _ = O.mixture_coupling(zc, nc, mask, K, sfc, msfc, channel_padding_mask=pad)
+    za, la = O.actnorm(z1, bc, sc, length=length, channel_padding_mask=pad, ldj=lc + l1)
+    zo, lo = O.invconv(za, wc, slc, length=length, channel_padding_mask=pad, ldj=la)
+    ((zo * wz).sum() + (lo * wl).sum()).backward()
+    dl = [_leaf(t, True) for t in (z, nn_out, sf, msf, bias, scales, w, sldj, ldj0)]
+    zg, ng, sfg, msfg, bg, sg, wg, slg, lg = dl
+    zh, lh = Fn.MixtureActConvFn.apply(zg, ng, sfg, msfg, bg, sg, wg, slg, lg, g(mask), g(pad), g(length), K, -1.0, 1.0, True)
+    ((zh * g(wz)).sum() + (lh * g(wl)).sum()).backward()
+    grad_close(zh, zo, "z_out", rel=5e-5); grad_close(lh, lo, "ldj_out", rel=5e-5)
+    for name, a, b in zip(("g_z", "g_nn", "g_sf", "g_msf", "g_bias", "g_scales", "g_weight", "g_sldj", "g_ldj"), dl, leaves):
+        grad_close(a.grad, b.grad, name, rel=5e-4)
+    # twice: the same bits
+    first = [t.grad.clone() for t in dl]
+    for t in dl:
+        t.grad = None
+    zh, lh = Fn.MixtureActConvFn.apply(zg, ng, sfg, msfg, bg, sg, wg, slg, lg, g(mask), g(pad), g(length), K, -1.0, 1.0, True)
+    ((zh * g(wz)).sum() + (lh * g(wl)).sum()).backward()
+    assert all(torch.equal(a, t.grad) for a, t in zip(first, dl))
+
+
+@pytest.mark.parametrize("B,N,D,C,seed", [(64, 16, 6, 16, 1), (33, 17, 4, 7, 2), (16, 38, 6, 51, 3), (128, 8, 2, 5, 4), (9, 30, 8, 300, 5), (7, 5, 3, 12, 6)])
+def test_encoder_actconv_fn_vs_oracle_autograd(B, N, D, C, seed):
+    """Encoder (sampling its noise from the uniform draw) + ActNorm + 1x1 convolution as one Function against autograd through
+    O.encoder_forward -> O.actnorm -> O.invconv (class-table gradient, the pair's parameter gradients, the log-det's)."""
+    from categoricalnf_amd import functional as Fn
+    gen = torch.Generator().manual_seed(seed)
+    categ = torch.randint(0, C, (B, N), generator=gen)
+    u = torch.rand(B * N, D, generator=gen)
+    table = torch.randn(C, 2 * D, generator=gen)
+    prior = torch.log_softmax(torch.randn(C, generator=gen), 0)
+    bias, scales, w, sldj = _actconv_params(D, gen)
+    pad, length = _pad_len(B, N, seed, gen)
+    beta = 1.0 + 0.5 * (seed % 2)
+    ldj0, wz, wl = torch.randn(B, generator=gen), torch.randn(B, N, D, generator=gen), torch.randn(B, generator=gen)
+    leaves = [_leaf(t) for t in (table, bias, scales, w, sldj, ldj0)]
+    tc, bc, sc, wc, slc, lc = leaves
+    eps = O.logistic_from_uniform(u.reshape(B * N, 1, D))
+    z1, l1, _ = O.encoder_forward(categ, eps, tc, prior, beta=beta, channel_padding_mask=pad)
+    za, la = O.actnorm(z1, bc, sc, length=length, channel_padding_mask=pad, ldj=lc + l1)
+    zo, lo = O.invconv(za, wc, slc, length=length, channel_padding_mask=pad, ldj=la)
+    ((zo * wz).sum() + (lo * wl).sum()).backward()
+    dl = [_leaf(t, True) for t in (table, bias, scales, w, sldj, ldj0)]
+    tg, bg, sg, wg, slg, lg = dl
+    zh, lh = Fn.EncoderActConvFn.apply(tg, bg, sg, wg, slg, lg, g(categ), g(u), g(prior), g(pad), g(length), beta, 1e-4)
+    ((zh * g(wz)).sum() + (lh * g(wl)).sum()).backward()
+    grad_close(zh, zo, "z_out", rel=5e-5); grad_close(lh, lo, "ldj_out", rel=5e-5)
+    for name, a, b in zip(("g_table", "g_bias", "g_scales", "g_weight", "g_sldj", "g_ldj"), dl, leaves):
+        grad_close(a.grad, b.grad, name, rel=5e-4)
+
+
+def test_actconv_backward_is_bit_reproducible_and_inverts_on_the_device():
+    """cnf_actnorm_invconv_bwd through the C ABI at a large shape: both forms (intermediate from the input / from the output through
+    the device-side fp64 inverse) give the same gradients to rounding, each the same bits over repeated runs."""
+    from categoricalnf_amd import functional as Fn, ops
+    gen = torch.Generator().manual_seed(3)
+    B, N, D = 2048, 64, 6
+    z = g(torch.randn(B, N, D, generator=gen))
+    bias, scales, w, sldj = (g(t) for t in _actconv_params(D, gen))
+    gz, gl = g(torch.randn(B, N, D, generator=gen)), g(torch.randn(B, generator=gen))
+    out, _ = ops.actnorm_invconv(z, bias, scales, w, sldj)
+    runs = []
+    for saved, is_out in ((z, False), (out, True)):
+        res = [tuple(t.clone() for t in Fn._actconv_bwd(saved, is_out, bias, scales, w, None, None, gz, gl, Fn._Hold())) for _ in range(3)]
+        assert all(torch.equal(a, b) for r in res[1:] for a, b in zip(res[0], r))
+        runs.append(res[0])
+    for name, a, b in zip(("g_z", "g_bias", "g_scales", "g_weight", "g_sldj"), *runs):
+        grad_close(a, b, name + " from the output vs from the input", rel=2e-5)
+
+
+def test_flow_training_pass_with_and_without_the_fused_groups():
+    """FlowModel with autograd on: the fused groups (encoder + ActNorm + conv, coupling + ActNorm + conv — one Function and one
+    backward each, ops.FUSE_TRAINING) against one Function per layer on the set-modelling flow, same noise: the loss to
+    rounding, every parameter gradient within 1e-4 of its scale; and far fewer autograd nodes."""
+    import contextlib, io
+    from categoricalnf_amd import functional as Fn, ops
+    from categoricalnf_amd.experiments.set_modeling import FlowSetModeling, SetShufflingDataset
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    params = {"set_size": 16, "coupling_hidden_layers": 2, "coupling_hidden_size": 64, "coupling_num_flows": 4,
+              "coupling_mask_ratio": 0.5, "coupling_num_mixtures": 8,
+              "categ_encoding": {"use_dequantization": False, "use_variational": False, "use_decoder": False, "num_dimensions": 4,
+                                 "flow_config": {"num_flows": 0}, "decoder_config": {}}}
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = FlowSetModeling(params, SetShufflingDataset).to(dev).train()
+    rng = np.random.RandomState(1)
+    B, S, D = 96, 16, 4
+    draw = lambda: torch.from_numpy(np.stack([rng.permutation(S) for _ in range(B)])).long().to(dev)
+    ln = torch.full((B,), S, dtype=torch.long, device=dev)
+    with contextlib.redirect_stdout(io.StringIO()):
+        model.initialize_data_dependent([(draw(), {"length": ln}) for _ in range(4)])
+    x, noise = draw(), torch.rand(B * S, 1, D, device=dev)
+    plist = [p for p in model.parameters() if p.requires_grad]
+
+    def count_nodes(t):
+        seen, stack = set(), [t.grad_fn]
+        while stack:
+            n = stack.pop()
+            if n is None or n in seen:
+                continue
+            seen.add(n)
+            stack.extend(f for f, _ in n.next_functions)
+        return len(seen), sum(type(n).__name__.endswith("FnBackward") for n in seen)
+
+    out = {}
+    for fused in (True, False):
+        ops.FUSE_TRAINING = fused
+        try:
+            if fused:                    # + the NLL assembly inside the last coupling layer's Function
+                loss = model.nll_loss(x, length=ln, beta=1, noise=noise)[2].mean()
+            else:
+                z, ldj = model(x, reverse=False, length=ln, beta=1, noise=noise)
+                loss = Fn.PriorNllFn.apply(z, ldj, ln, None).mean()
+            out[fused] = (loss.detach().clone(), torch.autograd.grad(loss, plist, allow_unused=True), count_nodes(loss))
+        finally:
+            ops.FUSE_TRAINING = True
+    (la, ga, na), (lb, gb, nb) = out[True], out[False]
+    assert abs(float(la) - float(lb)) <= 2e-6 * max(1.0, abs(float(lb))), (float(la), float(lb))
+    for p, a, b in zip(plist, ga, gb):
+        assert (a is None) == (b is None)
+        if a is not None:
+            grad_close(a, b, "parameter of shape %s" % (tuple(p.shape),), rel=1e-4)
+    # per flow step: ActNormFn + InvConvFn + MixtureCouplingFn + the log-det add -> one Function
+    assert na[1] < nb[1] and na[0] < nb[0], (na, nb)
+
+
+@pytest.mark.parametrize("B,N,D,K,seed", [(64, 16, 4, 8, 1), (33, 17, 6, 4, 2), (20, 38, 6, 5, 4), (5, 64, 3, 16, 7), (16, 9, 7, 3, 8)])
+def test_last_coupling_nll_fns_vs_oracle_autograd(B, N, D, K, seed):
+    """The last coupling layer + the NLL assembly as one Function (mixture and affine) against autograd through the oracle's
+    coupling -> O.nll_per_sample (set_modeling/task.py:96-118)."""
+    from categoricalnf_amd import functional as Fn, ops
+    gen = torch.Generator().manual_seed(seed)
+    z = torch.randn(B, N, D, generator=gen)
+    pad, length = _pad_len(B, N, seed | 1, gen)                   # a length always: the NLL divides by it
+    mask = _mask("channel", D)
+    ldj0, wn = torch.randn(B, generator=gen), torch.randn(B, generator=gen)
+    # mixture
+    nn_out = 0.5 * torch.randn(B, N, D * (2 + 3 * K), generator=gen)
+    sf, msf = 0.2 * torch.randn(D, generator=gen), 0.2 * torch.randn(D, K, generator=gen)
+    leaves = [_leaf(t) for t in (z, nn_out, sf, msf, ldj0)]
+    zc, nc, sfc, msfc, lc = leaves
+    z1, l1, _ = O.mixture_coupling(zc, nc, mask, K, sfc, msfc, channel_padding_mask=pad)
+    nll_o = O.nll_per_sample(z1, lc + l1, length, pad)
+    (nll_o * wn).sum().backward()
+    dl = [_leaf(t, True) for t in (z, nn_out, sf, msf, ldj0)]
+    nll, zo, lo = Fn.MixtureCouplingNllFn.apply(*dl, g(mask), g(pad), g(length), K, -1.0, 1.0, True, ops.LOGISTIC_SIGMA, ops.LOGISTIC_LOG_SIGMA)
+    (nll * g(wn)).sum().backward()
+    grad_close(nll, nll_o, "nll", rel=5e-5); grad_close(zo, z1, "z_out", rel=5e-5)
+    for name, a, b in zip(("g_z", "g_nn", "g_sf", "g_msf", "g_ldj"), dl, leaves):
+        grad_close(a.grad, b.grad, "mixture " + name, rel=5e-4)
+    # affine
+    nn2 = 0.5 * torch.randn(B, N, 2 * D, generator=gen)
+    leaves = [_leaf(t) for t in (z, nn2, sf, ldj0)]
+    zc, nc, sfc, lc = leaves
+    z1, l1 = O.affine_coupling(zc, nc, mask, sfc, ldj=lc * 1.0)
+    nll_o = O.nll_per_sample(z1, l1, length, pad)
+    (nll_o * wn).sum().backward()
+    dl = [_leaf(t, True) for t in (z, nn2, sf, ldj0)]
+    nll, zo, lo = Fn.AffineCouplingNllFn.apply(*dl, g(mask), g(pad), g(length), ops.LOGISTIC_SIGMA, ops.LOGISTIC_LOG_SIGMA)
+    (nll * g(wn)).sum().backward()
+    grad_close(nll, nll_o, "nll", rel=5e-5); grad_close(lo, l1, "ldj_out", rel=5e-5)
+    for name, a, b in zip(("g_z", "g_nn", "g_sf", "g_ldj"), dl, leaves):
+        grad_close(a.grad, b.grad, "affine " + name, rel=5e-4)

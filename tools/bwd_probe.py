@@ -37,7 +37,7 @@ bias, scales = torch.randn(D, generator=g, device=dev), 0.1 * torch.randn(D, gen
 w = torch.linalg.qr(torch.randn(D, D))[0].to(dev).contiguous()
 ln = torch.full((B,), float(N), device=dev)
 pad = (torch.rand(B, N, generator=g, device=dev) > 0.1).float()
-ws = torch.empty(int(lib.cnf_bwd_workspace_floats(D * D + 1 + 2 * D)), device=dev)
+ws = torch.empty(int(lib.cnf_bwd_workspace_floats(D * D + 2 + 2 * D)), device=dev)
 g_sf, g_b, g_s, g_w, g_sl = (torch.empty(n, device=dev) for n in (D, D, D, D * D, 1))
 gldj = torch.empty(B, device=dev)
 st = lambda: _stream(dev)
@@ -62,6 +62,19 @@ def actnorm(i, rev=0, padded=False):
 def invconv(i, rev=0, padded=False):
     call("cnf_invconv_bwd", _ptr(zo[i]), _ptr(w), _ptr(pad) if padded else None, _ptr(ln), _ptr(gzo[i]), _ptr(gl),
          _ptr(gz[i]), _ptr(g_w), _ptr(g_sl), _ptr(ws), B, N, D, rev, st())
+
+
+g_par = torch.empty(D * D + 1 + 2 * D, device=dev)
+sldj_t = torch.slogdet(w)[1].reshape(1).contiguous()
+outs = None
+
+
+def actconv(i, from_out=0):
+    global outs
+    if from_out and outs is None:
+        outs = [ops.actnorm_invconv(zo[r], bias, scales, w, sldj_t)[0] for r in range(R)]
+    call("cnf_actnorm_invconv_bwd", _ptr(outs[i] if from_out else zo[i]), from_out, _ptr(bias), _ptr(scales), _ptr(w), None, None, _ptr(ln),
+         _ptr(gzo[i]), _ptr(gl), _ptr(gz[i]), _ptr(g_par), _ptr(ws), B, N, D, st())
 
 
 def ext(i, rev=0):
@@ -112,6 +125,8 @@ rows = [
     ("actnorm_bwd padded", 12, lambda i: actnorm(i, 0, True)),
     ("invconv_bwd", 12, lambda i: invconv(i, 0)),
     ("invconv_bwd padded", 12, lambda i: invconv(i, 0, True)),
+    ("actnorm+invconv_bwd fused (from input)", 12, lambda i: actconv(i, 0)),
+    ("actnorm+invconv_bwd fused (from output)", 12, lambda i: actconv(i, 1)),
     ("ext_actnorm_bwd", 28, lambda i: ext(i, 0)),
     ("prior_nll_bwd", 8, nll),
     ("logistic_log_prob_bwd", 12, logp),
@@ -125,7 +140,8 @@ if args.pmc:
     import json
     frag = {"affine_bwd fwd-dir (sf)": "affine_bwd_kernel<4, 2, true, false", "affine_bwd inv-dir (sf)": "affine_bwd_kernel<4, 2, true, true",
             "affine_bwd fwd-dir (no sf)": "affine_bwd_kernel<4, 2, false, false", "actnorm_bwd": "::actnorm_bwd_kernel<",
-            "invconv_bwd": "invconv_bwd_kernel<6>", "ext_actnorm_bwd": "ext_actnorm_bwd_group_kernel<6", "prior_nll_bwd": "prior_nll_bwd_kernel",
+            "invconv_bwd": "::invconv_bwd_kernel<6>", "actnorm+invconv_bwd fused (from input)": "actconv_bwd_kernel<6, false>",
+            "actnorm+invconv_bwd fused (from output)": "actconv_bwd_kernel<6, true>", "ext_actnorm_bwd": "ext_actnorm_bwd_group_kernel<6", "prior_nll_bwd": "prior_nll_bwd_kernel",
             "logistic_log_prob_bwd": "logistic_log_prob_bwd_kernel", "sigmoid_flow_bwd": "sigmoid_flow_bwd_kernel",
             "affine_params_bwd": "affine_params_bwd_kernel<4, 2, true", "affine_transform_bwd": "affine_transform_bwd_kernel<4, 2"}
     manifest = {}
@@ -142,10 +158,10 @@ if args.pmc:
     sys.exit(0)
 print("shape B=%d N=%d D=%d (%.2f M elems); start-to-start over blocks of %d launches incl. the partials reduction launch where there is one"
       % (B, N, D, elems / 1e6, args.reps))
-print("%-30s %6s %9s %9s %10s %8s" % ("kernel", "B/elem", "us (med)", "us (min)", "alg GB/s", "of 8TB/s"))
+print("%-40s %6s %9s %9s %10s %8s" % ("kernel", "B/elem", "us (med)", "us (min)", "alg GB/s", "of 8TB/s"))
 for name, bpe, fn in rows:
     med, mn = timeit(fn)
-    print("%-30s %6d %9.2f %9.2f %10.0f %8.3f" % (name, bpe, med, mn, bpe * elems / med / 1e3, bpe * elems / med / 1e3 / 8000), flush=True)
+    print("%-40s %6d %9.2f %9.2f %10.0f %8.3f" % (name, bpe, med, mn, bpe * elems / med / 1e3, bpe * elems / med / 1e3 / 8000), flush=True)
 
 if hasattr(lib, "cnf_stream_probe_bwd") and not args.only:
     print("\nstream ceiling for the affine backward's mix (16 B read + 12 B written per element, no arithmetic), us / TB/s")
