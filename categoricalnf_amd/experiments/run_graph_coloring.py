@@ -65,6 +65,9 @@ def parse(argv=None):
     p.add_argument("--beta_scheduler_end_val", type=float, default=2.0)
     p.add_argument("--beta_scheduler_step_size", type=int, default=5000)
     p.add_argument("--beta_scheduler_logit", type=float, default=2.0)
+    p.add_argument("--graph_step", action="store_true",
+                   help="capture the training step (forward, HIP backward kernels, clipping, RAdam) in a HIP graph and replay it; "
+                        "single process; batches keep the data set's full width, beta and the learning rate live in device scalars")
     p.add_argument("--backend", default=None, help="torch.distributed backend when started with WORLD_SIZE > 1 (nccl = RCCL)")
     p.add_argument("--share_device", action="store_true", help="TEST ONLY: every rank on cuda:0 (1-GPU box, --backend gloo)")
     return p.parse_args(argv)
@@ -84,19 +87,20 @@ def beta_at(args, iteration):
     return a + (b - a) * (1.0 - args.beta_scheduler_logit ** (-iteration * 1.0 / args.beta_scheduler_step_size))
 
 
-def collate(dataset, indices, device):
-    """(nodes, adjacency, length) of a batch, clipped to its longest graph (task.py:133-141)."""
+def collate(dataset, indices, device, clip=True):
+    """(nodes, adjacency, length) of a batch, clipped to its longest graph (task.py:133-141); `clip=False` keeps the data set's
+    full width (one shape for every batch: a captured training step)."""
     items = [dataset[i] for i in indices]
     length = torch.from_numpy(np.array([it[2] for it in items], dtype=np.int64))
-    n = int(length.max())
+    n = int(length.max()) if clip else int(items[0][0].shape[0])
     nodes = torch.from_numpy(np.stack([it[0][:n] for it in items]))
     adjacency = torch.from_numpy(np.stack([it[1][:n, :n] for it in items]))
     return nodes.to(device), adjacency.to(device), length.to(device)
 
 
-def batches(dataset, batch_size, device, drop_last):
+def batches(dataset, batch_size, device, drop_last, clip=True):
     for idx in dataset.get_sampler(batch_size, drop_last=drop_last):
-        yield collate(dataset, idx, device)
+        yield collate(dataset, idx, device, clip=clip)
 
 
 def evaluation_share(dataset, batch_size, rank=0, world=1, max_graphs=None):
@@ -173,9 +177,13 @@ def main(argv=None):
 
     per_rank = max(1, args.batch_size // world)
 
+    graph_mode = args.graph_step and world == 1
+    if args.graph_step and not graph_mode:
+        say("[#] --graph_step ignored: it is a single-process mode")
+
     def stream():
         while True:
-            yield from batches(train_set, per_rank, device, drop_last=True)
+            yield from batches(train_set, per_rank, device, drop_last=True, clip=not graph_mode)
     feed = stream()
     if state["iteration"] == 0 and not args.only_eval:
         # data-dependent ActNorm initialisation on 16 batches (task.py:144-157), full-width graphs
@@ -203,18 +211,38 @@ def main(argv=None):
         say("validation %.4f bits per node, %.2f %% valid colourings" % (val_bpd, 100 * val_valid))
         return {"val_bpd": val_bpd, "val_valid_ratio": val_valid}
 
+    graphed = None
+    if graph_mode:
+        from ..graphs import GraphedTraining
+        lr_of = lambda step: args.learning_rate * args.lr_decay_factor ** step
+        model.train()
+        s_nodes, s_adj, s_len = (t.clone() for t in next(feed))
+        s_noise = torch.rand(s_nodes.numel(), 1, model.embed_dim, device=device)
+        beta_t = torch.tensor(beta_at(args, state["iteration"]), dtype=torch.float32, device=device)      # the beta schedule lives in a device scalar
+        graphed = GraphedTraining(model, lambda: model(s_nodes, s_adj, reverse=False, beta=beta_t, length=s_len, noise=s_noise,
+                                                       _nll=model.nll_request(length=s_len, prior=prior))[2].mean(),
+                                  device, args.max_gradient_norm, lr=lr_of(state["iteration"]), eager_optimizer=optimizer)
+        optimizer = graphed.optimizer
+        say("[#] --graph_step: captured training step, hipGraph nodes %s" % (graphed.nodes,))
     ddp.train()
     best = state["best_save_dict"]
     t0, run_loss, seen = time.time(), torch.zeros((), device=device), 0
     for it in range(state["iteration"], args.max_iterations):
         nodes, adjacency, length = next(feed)
-        nll, _ = flow_nll(ddp, prior, nodes, adjacency, length, beta=beta_at(args, it))
-        loss = nll.mean()
-        optimizer.zero_grad(set_to_none=True)
-        loss.backward()
-        torch.nn.utils.clip_grad_norm_(ddp.parameters(), args.max_gradient_norm)
-        optimizer.step()
-        scheduler.step()
+        if graphed is not None:
+            s_nodes.copy_(nodes, non_blocking=True); s_adj.copy_(adjacency, non_blocking=True); s_len.copy_(length, non_blocking=True)
+            s_noise.uniform_()
+            beta_t.fill_(beta_at(args, it))
+            loss = graphed(lr_of(it))
+            scheduler.last_epoch, scheduler._last_lr = it + 1, [lr_of(it + 1)]      # what the checkpoint stores of the schedule
+        else:
+            nll, _ = flow_nll(ddp, prior, nodes, adjacency, length, beta=beta_at(args, it))
+            loss = nll.mean()
+            optimizer.zero_grad(set_to_none=True)
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(ddp.parameters(), args.max_gradient_norm)
+            optimizer.step()
+            scheduler.step()
         run_loss += loss.detach()
         seen += 1
         step = it + 1
@@ -224,6 +252,8 @@ def main(argv=None):
             t0, seen = time.time(), 0
             run_loss.zero_()
         if step % args.eval_freq == 0 or step == args.max_iterations:
+            if graphed is not None:
+                graphed.drop_weight_caches()
             val_bpd, val_valid = evaluate(ddp, prior, val_set, device, args.eval_batch_size, max_graphs=8192, rank=rank,
                                           world=world)
             state["evaluation_dict"][step] = val_bpd
@@ -233,8 +263,11 @@ def main(argv=None):
                     os.remove(best["file"])
                 best.update(file=checkpoint_file(args.checkpoint_path, step), metric=val_bpd,
                             detailed_metrics={"val_bpd": val_bpd, "valid_ratio": val_valid})
-                save_checkpoint(args.checkpoint_path, step, ddp, optimizer, scheduler, best_save_dict=best,
-                                evaluation_dict=state["evaluation_dict"])
+                with (graphed.checkpoint_groups(lr_of(step)) if graphed is not None else contextlib.nullcontext()):
+                    save_checkpoint(args.checkpoint_path, step, ddp, optimizer, scheduler, best_save_dict=best,
+                                    evaluation_dict=state["evaluation_dict"])
+    if graphed is not None:
+        graphed.drop_weight_caches()
     val_bpd, val_valid = evaluate(ddp, prior, val_set, device, args.eval_batch_size, rank=rank, world=world)
     test_bpd, test_valid = evaluate(ddp, prior, test_set, device, args.eval_batch_size, rank=rank, world=world)
     say("final: validation %.4f bits per node / %.2f %% valid, test %.4f / %.2f %%"

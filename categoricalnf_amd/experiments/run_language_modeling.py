@@ -110,6 +110,10 @@ def parse(argv=None):
     p.add_argument("--beta_scheduler_end_val", type=float, default=2.0)
     p.add_argument("--beta_scheduler_step_size", type=int, default=5000)
     p.add_argument("--beta_scheduler_logit", type=float, default=2.0)
+    p.add_argument("--graph_step", action="store_true",
+                   help="capture the training step (forward, HIP backward kernels, clipping, RAdam) in a HIP graph and replay it; "
+                        "single process; beta and the learning rate live in device scalars; the LSTM runs on PyTorch's native "
+                        "path (MIOpen's RNN calls are refused inside a stream capture)")
     p.add_argument("--backend", default=None, help="torch.distributed backend when started with WORLD_SIZE > 1 (nccl = RCCL)")
     p.add_argument("--share_device", action="store_true", help="TEST ONLY: every rank on cuda:0 (1-GPU box, --backend gloo)")
     return p.parse_args(argv)
@@ -210,17 +214,42 @@ def main(argv=None):
         say("validation %.4f bits per character (source %.4f)" % (bpc, corpus.entropy_rate()))
         return {"val_bpc": bpc, "entropy_rate": corpus.entropy_rate()}
 
+    graphed = None
+    if args.graph_step and world > 1:
+        say("[#] --graph_step ignored: it is a single-process mode")
+    elif args.graph_step:
+        from ..graphs import GraphedTraining
+        # MIOpen's RNN (hipBLASLt inside it) aborts under a stream capture; nn.LSTM's native per-time-step path is captured
+        # instead — a few thousand small kernels, which is exactly what a graph replay is good at
+        torch.backends.cudnn.enabled = False
+        lr_of = lambda step: args.learning_rate * args.lr_decay_factor ** step
+        model.train()
+        s_x, s_len = (t.clone() for t in draw_batch(corpus, args, per_rank, rng, device))      # training batches keep one shape
+        s_noise = torch.rand(s_x.numel(), 1, args.encoding_dim, device=device)
+        beta_t = torch.tensor(beta_at(args, state["iteration"]), dtype=torch.float32, device=device)      # the beta schedule lives in a device scalar
+        graphed = GraphedTraining(model, lambda: model(s_x, reverse=False, beta=beta_t, length=s_len, noise=s_noise,
+                                                       _nll=model.nll_request(length=s_len, prior=prior))[2].mean(),
+                                  device, args.max_gradient_norm, lr=lr_of(state["iteration"]), eager_optimizer=optimizer)
+        optimizer = graphed.optimizer
+        say("[#] --graph_step: captured training step, hipGraph nodes %s" % (graphed.nodes,))
     ddp.train()
     best = state["best_save_dict"]
     t0, run_loss, seen = time.time(), torch.zeros((), device=device), 0
     for it in range(state["iteration"], args.max_iterations):
         x, length = draw_batch(corpus, args, per_rank, rng, device)
-        loss = sentence_nll(ddp, prior, x, length, beta=beta_at(args, it)).mean()
-        optimizer.zero_grad(set_to_none=True)
-        loss.backward()
-        torch.nn.utils.clip_grad_norm_(ddp.parameters(), args.max_gradient_norm)
-        optimizer.step()
-        scheduler.step()
+        if graphed is not None:
+            s_x.copy_(x, non_blocking=True); s_len.copy_(length, non_blocking=True)
+            s_noise.uniform_()
+            beta_t.fill_(beta_at(args, it))
+            loss = graphed(lr_of(it))
+            scheduler.last_epoch, scheduler._last_lr = it + 1, [lr_of(it + 1)]      # what the checkpoint stores of the schedule
+        else:
+            loss = sentence_nll(ddp, prior, x, length, beta=beta_at(args, it)).mean()
+            optimizer.zero_grad(set_to_none=True)
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(ddp.parameters(), args.max_gradient_norm)
+            optimizer.step()
+            scheduler.step()
         run_loss += loss.detach()
         seen += 1
         step = it + 1
@@ -230,6 +259,8 @@ def main(argv=None):
             t0, seen = time.time(), 0
             run_loss.zero_()
         if step % args.eval_freq == 0 or step == args.max_iterations:
+            if graphed is not None:
+                graphed.drop_weight_caches()
             bpc = evaluate(ddp, prior, val, args.batch_size, rank, world)
             state["evaluation_dict"][step] = bpc
             say("iteration %7d | validation %.4f bits per character (source %.4f, context-free %.4f)"
@@ -238,8 +269,11 @@ def main(argv=None):
                 if best["file"] and os.path.isfile(best["file"]):
                     os.remove(best["file"])
                 best.update(file=checkpoint_file(args.checkpoint_path, step), metric=bpc, detailed_metrics={"val_bpc": bpc})
-                save_checkpoint(args.checkpoint_path, step, ddp, optimizer, scheduler, best_save_dict=best,
-                                evaluation_dict=state["evaluation_dict"])
+                with (graphed.checkpoint_groups(lr_of(step)) if graphed is not None else contextlib.nullcontext()):
+                    save_checkpoint(args.checkpoint_path, step, ddp, optimizer, scheduler, best_save_dict=best,
+                                    evaluation_dict=state["evaluation_dict"])
+    if graphed is not None:
+        graphed.drop_weight_caches()
     bpc = evaluate(ddp, prior, val, args.batch_size, rank, world)
     say("final: validation %.4f bits per character; source entropy rate %.4f, context-free optimum %.4f"
         % (bpc, corpus.entropy_rate(), corpus.unigram_entropy()))

@@ -261,55 +261,17 @@ def main(argv=None):
     if args.graph_step and (world > 1 or flat is not None):
         say("[#] --graph_step ignored: it is a single-process mode without --flat_optimizer")
     elif args.graph_step:
-        from ..graphs import GraphedTrainStep
+        from ..graphs import GraphedTraining
         lr_of = lambda step: args.learning_rate * max(floor, args.lr_decay_factor ** (step // max(1, args.lr_decay_step)))
-        lr_t = torch.tensor(lr_of(state["iteration"]), dtype=torch.float32, device=device)      # the schedule lives in a device scalar
-        eager_state = optimizer.state_dict()["state"]
-        optimizer = torch.optim.RAdam(model.parameters(), lr=lr_t, capturable=True)
-        if eager_state:                                   # resumed: carry the moments over (step counters move to the device)
-            sd = optimizer.state_dict()
-            sd["state"] = {k: {n: (v.to(device=device, dtype=torch.float32) if n == "step" else v) for n, v in st.items()}
-                           for k, st in eager_state.items()}
-            optimizer.load_state_dict(sd)
-            for group in optimizer.param_groups:
-                group["lr"], group["capturable"] = lr_t, True
         model.train()
         static_x, static_ln = batch()
         static_noise = torch.rand(static_x.numel(), 1, args.encoding_dim, device=device)
-        plist = [p_ for p_ in model.parameters() if p_.requires_grad]
-
-        def graph_train_step():
-            # the NLL assembly rides in the last coupling layer's kernel
-            loss_ = model(static_x, reverse=False, length=static_ln, beta=1, noise=static_noise,
-                          _nll=model.nll_request(length=static_ln))[2].mean()
-            for p_, g_ in zip(plist, torch.autograd.grad(loss_, plist, allow_unused=True)):
-                p_.grad = g_
-            torch.nn.utils.clip_grad_norm_(plist, args.max_gradient_norm, foreach=True)
-            optimizer.step()
-            return loss_.detach()
-        for p_ in plist:
-            p_.grad = None
-        snapshot = [p_.detach().clone() for p_ in plist], {k: {n: v.clone() for n, v in st.items() if torch.is_tensor(v)}
-                                                          for k, st in optimizer.state.items()}
-        graphed = GraphedTrainStep(graph_train_step, device)
-        # the three warm-up steps before the capture trained on one batch: undo them (parameters and moments)
-        with torch.no_grad():
-            for p_, old in zip(plist, snapshot[0]):
-                p_.copy_(old)
-            for k, st in optimizer.state.items():
-                for n, v in st.items():
-                    if torch.is_tensor(v):
-                        if k in snapshot[1] and n in snapshot[1][k]:
-                            v.copy_(snapshot[1][k][n])
-                        else:
-                            v.zero_()
-
-        def drop_weight_caches():
-            # replays do not run the modules' Python, so the eval-mode caches of the 1x1 convolutions (W, W^-1, log-det per
-            # device) are not dropped by a training forward any more: drop them before anything runs in eval mode
-            for m_ in model.modules():
-                if hasattr(m_, "_empty_eval_dict"):
-                    m_._empty_eval_dict()
+        # the NLL assembly rides in the last coupling layer's kernel
+        graphed = GraphedTraining(model, lambda: model(static_x, reverse=False, length=static_ln, beta=1, noise=static_noise,
+                                                       _nll=model.nll_request(length=static_ln))[2].mean(),
+                                  device, args.max_gradient_norm, lr=lr_of(state["iteration"]), eager_optimizer=optimizer)
+        optimizer = graphed.optimizer
+        say("[#] --graph_step: captured training step, hipGraph nodes %s" % (graphed.nodes,))
     ddp.train()
     best = state["best_save_dict"]
     periodic = set()          # full-state checkpoints written at save_freq steps (kept when a better validation file appears)
@@ -329,8 +291,7 @@ def main(argv=None):
         if graphed is not None:
             static_x.copy_(x, non_blocking=True)
             static_noise.uniform_()
-            lr_t.fill_(lr_of(it))
-            loss = graphed()
+            loss = graphed(lr_of(it))
             scheduler.last_epoch, scheduler._last_lr = it + 1, [lr_of(it + 1)]      # what the checkpoint stores of the schedule
         else:
             # the NLL assembly rides in the last coupling layer's kernel
@@ -352,7 +313,7 @@ def main(argv=None):
             run_loss.zero_()
         if step % args.eval_freq == 0 or step == args.max_iterations:
             if graphed is not None:
-                drop_weight_caches()
+                graphed.drop_weight_caches()
             val_nll, val_bpd = evaluate(ddp, val_sets, device, rank, world, args.eval_batch_size)
             state["evaluation_dict"][step] = val_nll
             say("iteration %7d | validation %.4f bpd (optimum %.4f)" % (step, val_bpd, optimum))
@@ -366,19 +327,14 @@ def main(argv=None):
                 save_checkpoint(args.checkpoint_path, step, ddp, best_save_dict=best, evaluation_dict=state["evaluation_dict"])
         if step % args.save_freq == 0 and args.checkpoint_path and rank == 0:
             # always the full state (a best-validation file of the same step is a subset of it and is replaced)
-            if graphed is not None:
-                # the file stores what an eager run stores after scheduler.step(): the NEXT step's learning rate as a number,
-                # and no capturable flag (an eager resume must not inherit device-side step counters' mode)
-                for group in optimizer.param_groups:
-                    group["lr"], group["capturable"] = lr_of(step), False
-            save_checkpoint(args.checkpoint_path, step, ddp, optimizer if flat is None else None, scheduler,
-                            best_save_dict=best, evaluation_dict=state["evaluation_dict"])
-            if graphed is not None:
-                for group in optimizer.param_groups:
-                    group["lr"], group["capturable"] = lr_t, True
+            # (a graphed run's file stores what an eager run stores after scheduler.step(): the NEXT step's learning rate as a
+            # number, and no capturable flag)
+            with (graphed.checkpoint_groups(lr_of(step)) if graphed is not None else contextlib.nullcontext()):
+                save_checkpoint(args.checkpoint_path, step, ddp, optimizer if flat is None else None, scheduler,
+                                best_save_dict=best, evaluation_dict=state["evaluation_dict"])
             periodic.add(checkpoint_file(args.checkpoint_path, step))
     if graphed is not None:
-        drop_weight_caches()
+        graphed.drop_weight_caches()
     _, val_bpd = evaluate(ddp, val_sets, device, rank, world, args.eval_batch_size)
     _, test_bpd = evaluate(ddp, test_sets, device, rank, world, args.eval_batch_size)
     say("final: validation %.4f bpd, test %.4f bpd (optimum %.4f)" % (val_bpd, test_bpd, optimum))

@@ -526,6 +526,50 @@ class EncoderForwardFn(torch.autograd.Function):
         return g_table, None, None, None, None, None, None, None, None
 
 
+class EncoderForwardDevBetaFn(torch.autograd.Function):
+    """EncoderForwardFn with the posterior weight beta in a DEVICE scalar (a captured training step follows the beta schedule by
+    writing that scalar between replays; the C ABI takes beta by value).  The token log-det is affine in beta —
+    ldj_tok = (beta * class_prob_log - (log p(eps) - ldj_flow)) * pad (linear_encoding.py:120-133) — so the forward runs the
+    kernel at beta = 1 and adds (beta - 1) * sum_n class_prob_log * pad, and the backward combines the kernel's table gradients
+    at beta = 0 and beta = 1: g(beta) = g(0) + beta * (g(1) - g(0)).  Exact up to rounding; twice the encoder backward."""
+
+    @staticmethod
+    def forward(ctx, table, categ, uniform, prior, pad, beta_t, squeeze):
+        z, ldj1, cpl, eps = ops.encoder_forward(categ, uniform, table, prior, beta=1.0, channel_padding_mask=pad,
+                                                want_class_prob=True, uniform_squeeze=squeeze, want_noise=True)
+        B, N = categ.shape
+        w = cpl.view(B, N)
+        if isinstance(pad, torch.Tensor):
+            w = w * pad.reshape(B, N)
+        ldj = ldj1 + (beta_t.reshape(()).to(torch.float32) - 1.0) * w.sum(dim=1)
+        ctx.save_for_backward(table, categ, eps, prior, pad if isinstance(pad, torch.Tensor) else z.new_empty(0), beta_t)
+        ctx.has_pad = isinstance(pad, torch.Tensor)
+        ctx.mark_non_differentiable(cpl)
+        return z, ldj, cpl
+
+    @staticmethod
+    def backward(ctx, g_zout, g_ldj, _g_cpl):
+        hold = _Hold()
+        table, categ, eps, prior, pad, beta_t = ctx.saved_tensors
+        dev = table.device
+        B, N = categ.shape
+        C, D = table.shape[0], table.shape[1] // 2
+        tc, ec, pc = _f32(table, "table"), _f32(eps, "eps"), _f32(prior, "category_prior")
+        p2 = _pad2d(pad, B, N, dev) if ctx.has_pad else None
+        categ_c = categ.contiguous()
+        n_ws = int(_lib.load().cnf_encoder_bwd_tiled_workspace_floats(B, N, D, C))
+        grads = []
+        for beta in (0.0, 1.0):
+            g_table = torch.empty_like(tc)
+            ws = torch.empty(n_ws, dtype=torch.float32, device=dev)
+            _launch(dev, "cnf_encoder_forward_bwd_tiled", _ptr(categ_c), _ptr(ec), _ptr(tc), _ptr(pc), _ptr(p2), beta,
+                    hold(g_zout), hold(g_ldj), _ptr(g_table), _ptr(ws), B, N, D, C,
+                    float(ops.LOGISTIC_SIGMA), float(ops.LOGISTIC_LOG_SIGMA), _stream(dev))
+            grads.append(g_table)
+        g = grads[0] + beta_t.reshape(()).to(torch.float32) * (grads[1] - grads[0])
+        return g, None, None, None, None, None, None
+
+
 class AffineParamsFn(torch.autograd.Function):
     """CouplingLayer.get_coup_params: (nn_out, scaling_factor) -> (s, t)."""
 

@@ -230,3 +230,83 @@ class GraphedTrainStep:
     def __call__(self):
         self.graph.replay()
         return self.static_out
+
+
+class GraphedTraining:
+    """What a training driver needs around a captured step (`--graph_step` of the three experiment drivers): the model's
+    training step — `loss_fn()` on static inputs, gradients, clipping, RAdam — captured once by GraphedTrainStep and replayed,
+    with the learning rate in a device scalar (`.lr`, written before every replay), the moments of the driver's eager optimiser
+    carried over (a resumed run), and the warm-up steps the capture needs undone afterwards (parameters and moments).
+
+        run = GraphedTraining(model, lambda: model(static_x, ..., _nll=model.nll_request(length=static_ln))[2].mean(),
+                              device, max_grad_norm, eager_optimizer=optimizer)
+        for it in ...:
+            static_x.copy_(x); static_noise.uniform_()
+            loss = run(lr_of(it))
+
+    `.optimizer` is the capturable optimiser (for checkpoints: `checkpoint_groups(lr)` switches its param_groups to what an
+    eager run stores and back); `drop_weight_caches()` must be called before the model runs in eval mode (replays do not run
+    the modules' Python, so the eval-mode caches of the 1x1 convolutions are not dropped by a training forward any more)."""
+
+    def __init__(self, model, loss_fn, device, max_grad_norm, lr=7.5e-4, eager_optimizer=None, optimizer_cls=torch.optim.RAdam):
+        self.model, self.device = model, torch.device(device)
+        self.lr = torch.tensor(float(lr), dtype=torch.float32, device=self.device)       # the schedule lives in a device scalar
+        eager_state = eager_optimizer.state_dict()["state"] if eager_optimizer is not None else {}
+        self.optimizer = optimizer_cls(model.parameters(), lr=self.lr, capturable=True)
+        if eager_state:                                   # resumed: carry the moments over (step counters move to the device)
+            sd = self.optimizer.state_dict()
+            sd["state"] = {k: {n: (v.to(device=self.device, dtype=torch.float32) if n == "step" else v) for n, v in st.items()}
+                           for k, st in eager_state.items()}
+            self.optimizer.load_state_dict(sd)
+            for group in self.optimizer.param_groups:
+                group["lr"], group["capturable"] = self.lr, True
+        model.train()
+        plist = [p for p in model.parameters() if p.requires_grad]
+        optimizer = self.optimizer
+
+        def train_step():
+            loss = loss_fn()
+            for p, g in zip(plist, torch.autograd.grad(loss, plist, allow_unused=True)):
+                p.grad = g
+            torch.nn.utils.clip_grad_norm_(plist, max_grad_norm, foreach=True)
+            optimizer.step()
+            return loss.detach()
+        for p in plist:
+            p.grad = None
+        snapshot = [p.detach().clone() for p in plist], {k: {n: v.clone() for n, v in st.items() if torch.is_tensor(v)}
+                                                         for k, st in optimizer.state.items()}
+        self.step = GraphedTrainStep(train_step, self.device)
+        self.nodes = self.step.nodes
+        # the warm-up steps before the capture trained on one batch: undo them (parameters and moments)
+        with torch.no_grad():
+            for p, old in zip(plist, snapshot[0]):
+                p.copy_(old)
+            for k, st in optimizer.state.items():
+                for n, v in st.items():
+                    if torch.is_tensor(v):
+                        if k in snapshot[1] and n in snapshot[1][k]:
+                            v.copy_(snapshot[1][k][n])
+                        else:
+                            v.zero_()
+
+    def __call__(self, lr=None):
+        if lr is not None:
+            self.lr.fill_(float(lr))
+        return self.step()
+
+    def drop_weight_caches(self):
+        for m in self.model.modules():
+            if hasattr(m, "_empty_eval_dict"):
+                m._empty_eval_dict()
+
+    @contextlib.contextmanager
+    def checkpoint_groups(self, lr):
+        """Inside: the optimiser's param_groups read as an eager run stores them — the learning rate as a number, no capturable
+        flag (an eager resume must not inherit the device-side step counters' mode)."""
+        for group in self.optimizer.param_groups:
+            group["lr"], group["capturable"] = float(lr), False
+        try:
+            yield self.optimizer
+        finally:
+            for group in self.optimizer.param_groups:
+                group["lr"], group["capturable"] = self.lr, True

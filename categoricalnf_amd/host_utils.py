@@ -15,14 +15,19 @@ def get_param_val(param_dict, key, default_val=None, allow_default=True, error_l
     return default_val
 
 
+def _capturing():
+    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
+
 def one_hot(x, num_classes, dtype=torch.float32):
     """general/mutils.py:259-270."""
     if isinstance(x, np.ndarray):
         out = np.zeros(x.shape + (num_classes,), dtype=np.float32)
         out[np.arange(x.shape[0]), x] = 1.0
         return out
-    assert torch.max(x) < num_classes, "[!] ERROR: One-hot input has larger entries (%s) than classes (%i)" % (
-        str(torch.max(x)), num_classes)
+    if not _capturing():                                  # the check reads the device: not inside a HIP-graph capture
+        assert torch.max(x) < num_classes, "[!] ERROR: One-hot input has larger entries (%s) than classes (%i)" % (
+            str(torch.max(x)), num_classes)
     out = x.new_zeros(x.shape + (num_classes,), dtype=dtype)
     out.scatter_(-1, x.unsqueeze(dim=-1), 1)
     return out
@@ -45,12 +50,14 @@ def create_channel_mask(length, max_len=None, dtype=torch.float32):
     return _create_length_mask(length=length, max_len=max_len, dtype=dtype).unsqueeze(dim=-1)
 
 
-def create_T_one_hot(length, dataset_max_len, dtype=torch.float32):
+def create_T_one_hot(length, dataset_max_len, dtype=torch.float32, max_len=None):
     """general/mutils.py:290-304 — per position the one-hot of its index from the start and of its distance to the
     end of its sequence, zero beyond the end: [B, max(length), 2*dataset_max_len].  (The reference clamps the long
     distance with a float bound, which torch >= 2 promotes to float and then refuses as a scatter index; the
     integer arithmetic here is what it computed on torch 1.x.)"""
-    max_batch_len = int(length.max())
+    # max_len: the padded width of the batch where the caller knows it (== length.max() for every batch the reference can
+    # process) — no host read of `length`, so the pass stays capturable in a HIP graph
+    max_batch_len = int(length.max()) if max_len is None else int(max_len)
     assert max_batch_len <= dataset_max_len, \
         "[!] ERROR - T_one_hot: Max batch size (%s) was larger than given dataset max length (%s)" % (
             str(max_batch_len), str(dataset_max_len))

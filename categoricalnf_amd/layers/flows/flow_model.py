@@ -76,7 +76,8 @@ class FlowModel(nn.Module):
             if ((fusable or trainable) and not reverse and pos + 2 < len(order) and type(layer).__name__ == "LinearCategoricalEncoding"
                     and not z.is_floating_point()
                     and type(order[pos + 1][1]) is ActNormFlow and type(order[pos + 2][1]) is InvertibleConv
-                    and layer.fusable_with_actconv(differentiable=trainable) and order[pos + 1][1].c_in in ops.FUSED_ACTCONV_DIMS):
+                    and layer.fusable_with_actconv(differentiable=trainable) and order[pos + 1][1].c_in in ops.FUSED_ACTCONV_DIMS
+                    and not isinstance(kwargs.get("beta", 1), torch.Tensor)):
                 # encoder + ActNorm + 1x1 conv of the first flow step in ONE kernel: the latents go to HBM once, already
                 # transformed (same arithmetic as the three layers, bit for bit)
                 act, conv = order[pos + 1][1], order[pos + 2][1]

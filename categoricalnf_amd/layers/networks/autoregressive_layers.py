@@ -44,7 +44,7 @@ class TimeConcat(nn.Module):
     def forward(self, x, time_embed=None, length_one_hot=None, length=None):
         if time_embed is None:
             if length_one_hot is None and length is not None:
-                length_one_hot = create_T_one_hot(length, dataset_max_len=int(self.time_embed_layer.weight.shape[1] // 2))
+                length_one_hot = create_T_one_hot(length, dataset_max_len=int(self.time_embed_layer.weight.shape[1] // 2), max_len=x.size(1))
             time_embed = self.time_embed_layer(length_one_hot)
         return torch.cat([self.input_dropout(x), time_embed], dim=-1)
 

@@ -56,8 +56,10 @@ class RelationGraphAttention(nn.Module):
         x = self.norm_layer(x)
         hs = self.linear_hs(x).reshape(B, N, H, C)
         hr_all = self.linear_hr(x).reshape(B, N, E1, H, C)
-        hs_attn = (hs * self.attn_weight[:, 0].view(1, 1, H, C)).sum(dim=-1)                 # [B,N,H]   (query side)
-        hr_attn = (hr_all * self.attn_weight[:, 1].view(1, 1, 1, H, C)).sum(dim=-1)          # [B,N,E1,H] (key side)
+        # contractions, not broadcast-multiply-and-sum: the gradient of attn_weight is then a batched GEMM instead of a sum over
+        # B*N rows (PyTorch's two-pass reduction, whose memset node a captured training step must not contain: graphs.py)
+        hs_attn = torch.einsum("bnhc,hc->bnh", hs, self.attn_weight[:, 0])                   # [B,N,H]   (query side)
+        hr_attn = torch.einsum("bnehc,hc->bneh", hr_all, self.attn_weight[:, 1])             # [B,N,E1,H] (key side)
         with torch.no_grad():
             eye = torch.eye(N, device=x.device, dtype=adjacency.dtype).view(1, N, N, 1).expand(B, -1, -1, -1)
             adj = torch.cat([adjacency, eye], dim=-1)                                         # self connection = last type

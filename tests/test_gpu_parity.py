@@ -1673,6 +1673,68 @@ def test_graph_colouring_driver_trains_and_samples(tmp_path):
     assert abs(again["val_bpd"] - out["val_bpd"]) < 0.06, (again, out)
 
 
+def test_graph_colouring_driver_with_the_captured_training_step(tmp_path):
+    """run_graph_coloring --graph_step (round 4): full-width batches, beta and the learning rate in device scalars, the step
+    replayed from a HIP graph without a memset node (RelationGraphAttention takes its attention logits by contraction) — it
+    learns like the eager loop and its checkpoint evaluates to the same figure in eager mode."""
+    from categoricalnf_amd.experiments import run_graph_coloring as R
+    common = ["--dataset", "tiny_3", "--data_root", str(tmp_path / "data"), "--generate_data", "--num_graphs", "3000",
+              "--coupling_hidden_size", "32", "--coupling_hidden_layers", "2", "--coupling_num_flows", "2",
+              "--checkpoint_path", str(tmp_path / "ck"), "--print_freq", "1000000", "--eval_batch_size", "256"]
+    out = R.main(common + ["--max_iterations", "300", "--eval_freq", "300", "--batch_size", "128", "--learning_rate", "2e-3", "--graph_step"])
+    assert np.isfinite(out["val_bpd"]) and out["val_bpd"] < np.log2(3) - 0.05, out
+    again = R.main(common + ["--only_eval"])
+    assert abs(again["val_bpd"] - out["val_bpd"]) < 0.06, (again, out)
+
+
+def test_language_modelling_driver_with_the_captured_training_step(tmp_path):
+    """run_language_modeling --graph_step (round 4): the LSTM on PyTorch's native path (MIOpen's RNN aborts under a stream
+    capture), beta and the learning rate in device scalars; the replayed step beats the context-free optimum like the eager
+    loop does, and the checkpoint reproduces the figure in eager mode."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--vocab_size", "9", "--source_alpha", "0.3", "--max_seq_len", "32", "--batch_size", "64", "--num_val", "256",
+              "--coupling_hidden_size", "128", "--coupling_hidden_layers", "1", "--coupling_num_mixtures", "9",
+              "--encoding_dim", "3", "--variable_length", "--checkpoint_path", str(tmp_path / "lm")]
+    # in a process of its own: the mode switches torch.backends.cudnn off for the process
+    code = ("import sys, json; sys.path.insert(0, %r); from categoricalnf_amd.experiments import run_language_modeling as R; "
+            "out = R.main(sys.argv[1:]); print('RESULT ' + json.dumps({k: v for k, v in out.items() if isinstance(v, (int, float, str))}))" % root)
+    r = subprocess.run([sys.executable, "-c", code] + common + ["--max_iterations", "1500", "--eval_freq", "500", "--print_freq", "500",
+                                                                 "--learning_rate", "2e-3", "--graph_step"],
+                       capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0 and "RESULT " in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])
+    assert "hipGraph nodes" in r.stdout and "'memset'" not in r.stdout.split("hipGraph nodes")[1].split("\n")[0], r.stdout[-2000:]
+    import json
+    out = json.loads(r.stdout.split("RESULT ")[1].splitlines()[0])
+    assert out["entropy_rate"] < out["val_bpc"] < out["unigram_entropy"], out
+    from categoricalnf_amd.experiments import run_language_modeling as R
+    again = R.main(common + ["--only_eval"])
+    assert abs(again["val_bpc"] - out["val_bpc"]) < 0.08, (again, out)
+
+
+@pytest.mark.parametrize("c", [c for c in load_cases("encoder")][:4])
+def test_encoder_with_beta_in_a_device_scalar(c):
+    """functional.EncoderForwardDevBetaFn (a captured step's beta schedule): the same latents, log-det and class-table gradient as
+    EncoderForwardFn given the number, for a beta other than the one the kernels run at."""
+    from categoricalnf_amd import functional as Fn
+    m = c.meta
+    pad = g(c.pad) if m["padded"] else None
+    B, N = c.categ.shape
+    gen = torch.Generator().manual_seed(5)
+    wz, wl = g(torch.randn(B, N, c.table.shape[1] // 2, generator=gen)), g(torch.randn(B, generator=gen))
+    res = []
+    for beta in (1.0, 1.7):
+        t1, t2 = g(c.table).clone().requires_grad_(True), g(c.table).clone().requires_grad_(True)
+        z1, l1, _ = Fn.EncoderForwardFn.apply(t1, g(c.categ), g(c.u), g(c.category_prior), pad, beta, True, None, 1e-4)
+        z2, l2, _ = Fn.EncoderForwardDevBetaFn.apply(t2, g(c.categ), g(c.u), g(c.category_prior), pad, torch.tensor(beta, device="cuda"), 1e-4)
+        ((z1 * wz).sum() + (l1 * wl).sum()).backward()
+        ((z2 * wz).sum() + (l2 * wl).sum()).backward()
+        assert torch.equal(z1, z2)
+        close(l2, l1, rtol=2e-5, atol=2e-4)
+        scale = max(float(t1.grad.abs().max()), 1.0)
+        assert float((t1.grad - t2.grad).abs().max()) <= 2e-5 * scale, (beta, float((t1.grad - t2.grad).abs().max()), scale)
+
+
 def test_language_modelling_driver_trains_towards_the_source_entropy(tmp_path):
     """§8 f-3/f-4: the language-modelling host loop (autoregressive mixture coupling + LSTM sub-network, configs[3]'s layer
     stack) on the synthetic Markov source: a small flow trained for 1500 iterations on variable-length sentences beats the
