@@ -39,6 +39,8 @@ constexpr int kBwdMaxD = 64;            // channels of the per-workgroup constan
 // chunks in flight per lane (1..3) and chunk groups per wave tile, 0 = every kernel's own default; process-wide, set
 // before use (cnf_set_bwd_tile)
 static std::atomic<int> g_bwd_u{0}, g_bwd_g{0};
+// ActNorm backward: 1 = the token-owner tile kernel where it applies (default), 0 = always the flat-tile kernel (A/B, tests)
+static std::atomic<int> g_act_bwd_tiles{1};
 
 // partials [P, nrows <= kBwdMaxRows] (column-major rows of the waves) -> column sums in fp64 in a fixed order; columns [0, split) go to out_a, the rest to
 // out_b (either may be null): the parameter-gradient tensors are written directly.  One workgroup of 1024 threads per
@@ -756,6 +758,115 @@ __global__ __launch_bounds__(kBlock) void ext_actnorm_bwd_group_kernel(ExtBwdArg
         }
     }
 }
+// Wave-tile form: a wave takes 64 consecutive token groups — one contiguous span of each tensor — with fully coalesced 16-byte
+// loads (lane i takes vectors i, i + 64, ...), transposes them through its LDS strips so that lane i owns group i, and writes
+// the gradients back the same way.  The group kernel above has every lane read its own 16-byte pieces at a 48 / 96-byte stride
+// (D = 6): 39.7 us at the benchmark shape against this form's coalesced spans (profiles/r04_bwd_probe.txt).  The conditioning
+// row of a group (2 NV vectors) lives in two strips of NV vectors per lane: a lane stride of NV vectors is free of bank conflicts
+// for 128-bit reads where 2 NV is not.
+template <int D, bool FAST>
+__global__ __launch_bounds__(kBlock) void ext_actnorm_bwd_tile_kernel(ExtBwdArgs a) {
+    constexpr int TP = (D % 4 == 0) ? 1 : (D % 2 == 0 ? 2 : 4);
+    constexpr int NV = TP * D / 4, NC = 2 * NV;
+    __shared__ bw_f4 strip_all[kWavesPerBlock][4][kWave * NV];
+    bw_f4* sz = strip_all[threadIdx.x >> 6][0];
+    bw_f4* sg = strip_all[threadIdx.x >> 6][1];
+    bw_f4* sc0 = strip_all[threadIdx.x >> 6][2];        // vectors [0, NV) of every group's conditioning row
+    bw_f4* sc1 = strip_all[threadIdx.x >> 6][3];        // vectors [NV, 2 NV)
+    const int lane = threadIdx.x & 63;
+    const long ngroups = a.ntok / TP;
+    const long ntiles = ngroups / kWave;
+    const long wave_id = (long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const long nwaves = (long)gridDim.x * kWavesPerBlock;
+    for (long tile = wave_id; tile < ntiles; tile += nwaves) {
+        const bw_f4* srcz = reinterpret_cast<const bw_f4*>(a.z_out + tile * (kWave * TP * D));
+        const bw_f4* srcg = reinterpret_cast<const bw_f4*>(a.g_zout + tile * (kWave * TP * D));
+        const bw_f4* srcc = reinterpret_cast<const bw_f4*>(a.nn + tile * (kWave * TP * 2 * D));
+        bw_f4 qz[NV], qg[NV], qc[NC];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) qz[v] = __builtin_nontemporal_load(srcz + v * kWave + lane);
+#pragma unroll
+        for (int v = 0; v < NC; ++v) qc[v] = __builtin_nontemporal_load(srcc + v * kWave + lane);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) qg[v] = srcg[v * kWave + lane];
+        const long tok0 = (tile * kWave + lane) * TP;
+        float glp[TP];
+#pragma unroll
+        for (int k = 0; k < TP; ++k) {
+            glp[k] = 0.f;
+            if (a.g_ldj) {
+                const long tok = tok0 + k;
+                const long b = a.fast_rows ? (long)fdiv((uint32_t)tok, a.div_n) : tok / a.N;
+                glp[k] = a.g_ldj[b] * (a.pad ? a.pad[tok] : 1.f);
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            sz[v * kWave + lane] = qz[v];
+            sg[v * kWave + lane] = qg[v];
+        }
+#pragma unroll
+        for (int v = 0; v < NC; ++v) {
+            const int i = v * kWave + lane, grp = i / NC, j = i - grp * NC;       // vector j of group grp's conditioning row
+            (j < NV ? sc0 : sc1)[grp * NV + (j < NV ? j : j - NV)] = qc[v];
+        }
+        wave_lds_order();
+        float zo[TP * D], gzo[TP * D], cv[2 * TP * D], gz[TP * D], gc[2 * TP * D];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const bw_f4 r = sz[lane * NV + v];
+            zo[4 * v] = r.x; zo[4 * v + 1] = r.y; zo[4 * v + 2] = r.z; zo[4 * v + 3] = r.w;
+            const bw_f4 q = sg[lane * NV + v];
+            gzo[4 * v] = q.x; gzo[4 * v + 1] = q.y; gzo[4 * v + 2] = q.z; gzo[4 * v + 3] = q.w;
+            const bw_f4 c0 = sc0[lane * NV + v];
+            cv[4 * v] = c0.x; cv[4 * v + 1] = c0.y; cv[4 * v + 2] = c0.z; cv[4 * v + 3] = c0.w;
+            const bw_f4 c1 = sc1[lane * NV + v];
+            cv[4 * (NV + v)] = c1.x; cv[4 * (NV + v) + 1] = c1.y; cv[4 * (NV + v) + 2] = c1.z; cv[4 * (NV + v) + 3] = c1.w;
+        }
+#pragma unroll
+        for (int k = 0; k < TP; ++k)
+            ext_bwd_token<D, FAST>(zo + k * D, gzo + k * D, cv + k * 2 * D, glp[k], a.reverse != 0, gz + k * D, gc + k * 2 * D);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {              // the lane's own group: nobody else reads these words
+            const bw_f4 r = {gz[4 * v], gz[4 * v + 1], gz[4 * v + 2], gz[4 * v + 3]};
+            sz[lane * NV + v] = r;
+            const bw_f4 c0 = {gc[4 * v], gc[4 * v + 1], gc[4 * v + 2], gc[4 * v + 3]};
+            sc0[lane * NV + v] = c0;
+            const bw_f4 c1 = {gc[4 * (NV + v)], gc[4 * (NV + v) + 1], gc[4 * (NV + v) + 2], gc[4 * (NV + v) + 3]};
+            sc1[lane * NV + v] = c1;
+        }
+        wave_lds_order();
+        bw_f4* dz = reinterpret_cast<bw_f4*>(a.g_z + tile * (kWave * TP * D));
+        bw_f4* dc = reinterpret_cast<bw_f4*>(a.g_nn + tile * (kWave * TP * 2 * D));
+#pragma unroll
+        for (int v = 0; v < NV; ++v) st_chunk<4, kNtOut>(reinterpret_cast<float*>(dz + v * kWave + lane), reinterpret_cast<const float*>(&sz[v * kWave + lane]));
+#pragma unroll
+        for (int v = 0; v < NC; ++v) {
+            const int i = v * kWave + lane, grp = i / NC, j = i - grp * NC;
+            st_chunk<4, kNtOut>(reinterpret_cast<float*>(dc + i), reinterpret_cast<const float*>(&(j < NV ? sc0 : sc1)[grp * NV + (j < NV ? j : j - NV)]));
+        }
+        wave_lds_order();                            // the strips are refilled by the next tile
+    }
+    // tokens that do not fill a wave tile
+    for (long tok = ntiles * kWave * TP + (long)blockIdx.x * kBlock + threadIdx.x; tok < a.ntok; tok += (long)gridDim.x * kBlock) {
+        float zo[D], gzo[D], cv[2 * D], gz[D], gc[2 * D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            zo[d] = a.z_out[tok * D + d];
+            gzo[d] = a.g_zout[tok * D + d];
+            cv[d] = a.nn[tok * 2 * D + d];
+            cv[D + d] = a.nn[tok * 2 * D + D + d];
+        }
+        const float glp = a.g_ldj ? a.g_ldj[tok / a.N] * (a.pad ? a.pad[tok] : 1.f) : 0.f;
+        ext_bwd_token<D, FAST>(zo, gzo, cv, glp, a.reverse != 0, gz, gc);
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            a.g_z[tok * D + d] = gz[d];
+            a.g_nn[tok * 2 * D + d] = gc[d];
+            a.g_nn[tok * 2 * D + D + d] = gc[D + d];
+        }
+    }
+}
 // any D / unaligned tensors: one lane per element
 template <bool FAST>
 __global__ __launch_bounds__(kBlock) void ext_actnorm_bwd_elem_kernel(ExtBwdArgs a) {
@@ -787,6 +898,7 @@ struct ActBwdArgs {
     float* partials;        // [gridDim.x, 2D]: d bias | d scales
     int B, N, D, L, reverse;
     FastDiv div_d;
+    long ntok;
 };
 template <int VEC>
 struct ActBwdChunk {
@@ -880,6 +992,119 @@ __global__ __launch_bounds__(kBlock) void actnorm_bwd_kernel(ActBwdArgs a, FlatT
     // entry 2D of the row: the log-det term, added to every channel's d scales by the reduction launch
     part = rows_total_in_lane63(row16_sum(part));
     if (lane == kWave - 1) out_row[2 * a.D] = part;
+}
+
+// Token-owner form for D in {1..6, 8} (as the 1x1 convolution below): a wave takes spans of 64 token groups with coalesced
+// 16-byte loads, transposes them through its LDS strips so that a lane owns whole tokens, and keeps the 2D parameter-gradient
+// sums in REGISTERS (a lane's register d always belongs to channel d: no LDS read-add-write per element, which is what the
+// flat-tile kernel above pays).  16.5 -> us at the benchmark shape: profiles/r04_bwd_probe.txt.
+template <int D, bool FAST>
+__global__ __launch_bounds__(kBlock) void actnorm_bwd_tile_kernel(ActBwdArgs a) {
+    constexpr int TP = (D % 4 == 0) ? 1 : (D % 2 == 0 ? 2 : 4);
+    constexpr int NV = TP * D / 4;
+    constexpr int R = 2 * D + 1;
+    __shared__ bw_f4 strip_all[kWavesPerBlock][2][kWave * NV];
+    __shared__ float comb[kWavesPerBlock][4 * R];
+    bw_f4* sx = strip_all[threadIdx.x >> 6][0];
+    bw_f4* sg = strip_all[threadIdx.x >> 6][1];
+    const int lane = threadIdx.x & 63;
+    float bk[D], ek[D], acc[R];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        bk[i] = a.bias[i];
+        ek[i] = bexp<FAST>(a.reverse ? -a.scales[i] : a.scales[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i) acc[i] = 0.f;
+    const bool reverse = a.reverse != 0;
+    auto token = [&](const float* zo, const float* gin, float p, float* gz) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            float gzo = gin[i], y = zo[i];
+            if (a.pad) {
+                gzo *= p;                                    // z' = (...) * pad
+                y = p != 0.f ? zo[i] / p : 0.f;              // the pre-padding output (padded positions have gzo = 0 anyway)
+            }
+            gz[i] = gzo * ek[i];
+            if (!reverse) {                                  // y = (z + b) e^sc
+                acc[i] += gz[i];
+                acc[D + i] = fmaf(gzo, y, acc[D + i]);
+            } else {                                         // y = z e^-sc - b
+                acc[i] -= gzo;
+                acc[D + i] = fmaf(-gzo, y + bk[i], acc[D + i]);
+            }
+        }
+    };
+    const long ngroups = a.ntok / TP;
+    const long ntiles = ngroups / kWave;
+    const long wave_id = (long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const long nwaves = (long)gridDim.x * kWavesPerBlock;
+    for (long tile = wave_id; tile < ntiles; tile += nwaves) {
+        const bw_f4* srcx = reinterpret_cast<const bw_f4*>(a.z_out + tile * (kWave * TP * D));
+        const bw_f4* srcg = reinterpret_cast<const bw_f4*>(a.g_zout + tile * (kWave * TP * D));
+        bw_f4 qx[NV], qg[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) qx[v] = __builtin_nontemporal_load(srcx + v * kWave + lane);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) qg[v] = srcg[v * kWave + lane];
+        const long g = tile * kWave + lane;
+        float pv[TP];
+#pragma unroll
+        for (int k = 0; k < TP; ++k) pv[k] = a.pad ? a.pad[g * TP + k] : 1.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            sx[v * kWave + lane] = qx[v];
+            sg[v * kWave + lane] = qg[v];
+        }
+        wave_lds_order();
+        float xin[TP * D], gin[TP * D], gx[TP * D];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const bw_f4 r = sx[lane * NV + v];
+            xin[4 * v] = r.x; xin[4 * v + 1] = r.y; xin[4 * v + 2] = r.z; xin[4 * v + 3] = r.w;
+            const bw_f4 q = sg[lane * NV + v];
+            gin[4 * v] = q.x; gin[4 * v + 1] = q.y; gin[4 * v + 2] = q.z; gin[4 * v + 3] = q.w;
+        }
+#pragma unroll
+        for (int k = 0; k < TP; ++k) token(xin + k * D, gin + k * D, pv[k], gx + k * D);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const bw_f4 r = {gx[4 * v], gx[4 * v + 1], gx[4 * v + 2], gx[4 * v + 3]};
+            sx[lane * NV + v] = r;                  // the lane's own group: nobody else reads these words
+        }
+        wave_lds_order();
+        bw_f4* dst = reinterpret_cast<bw_f4*>(a.g_z + tile * (kWave * TP * D));
+#pragma unroll
+        for (int v = 0; v < NV; ++v) st_chunk<4, kNtOut>(reinterpret_cast<float*>(dst + v * kWave + lane), reinterpret_cast<const float*>(&sx[v * kWave + lane]));
+        wave_lds_order();                            // the strips are refilled by the next tile
+    }
+    // tokens that do not fill a wave tile
+    for (long t = ntiles * kWave * TP + (long)blockIdx.x * kBlock + threadIdx.x; t < a.ntok; t += (long)gridDim.x * kBlock) {
+        float xin[D], gin[D], gx[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            xin[i] = a.z_out[t * D + i];
+            gin[i] = a.g_zout[t * D + i];
+        }
+        token(xin, gin, a.pad ? a.pad[t] : 1.f, gx);
+#pragma unroll
+        for (int i = 0; i < D; ++i) a.g_z[t * D + i] = gx[i];
+    }
+    // log-det term (see the flat-tile kernel): entry 2D of the row
+    if (a.g_ldj) {
+        float part = 0.f;
+        for (long b = (long)blockIdx.x * kBlock + threadIdx.x; b < a.B; b += (long)gridDim.x * kBlock) {
+            float len;
+            if (a.length) len = a.length[b];
+            else if (a.pad) {
+                len = 0.f;
+                for (int n = 0; n < a.N; ++n) len += a.pad[b * a.N + n];
+            } else len = (float)a.N;
+            part = fmaf(a.g_ldj[b], len, part);
+        }
+        acc[2 * D] = reverse ? -part : part;
+    }
+    wave_register_reduce<R>(acc, comb[threadIdx.x >> 6], wave_partials_row(a.partials));
 }
 
 // ---- invertible 1x1 convolution (permutation_layers.py:106-136) -------------------------------------------
@@ -1420,6 +1645,8 @@ int64_t cnf_bwd_workspace_floats(int param_count) {
     return (int64_t)((param_count <= kBwdMaxRowP ? kBwdMaxRows : 2048) + 1) * (param_count + 1) + 8192;
 }
 
+void cnf_set_actnorm_bwd_tiles(int on) { g_act_bwd_tiles.store(on ? 1 : 0, std::memory_order_relaxed); }
+
 void cnf_set_bwd_tile(int chunks_in_flight, int groups_per_tile) {
     if (chunks_in_flight >= 0 && chunks_in_flight <= 3) g_bwd_u.store(chunks_in_flight, std::memory_order_relaxed);
     if (groups_per_tile >= 0 && groups_per_tile <= 64) g_bwd_g.store(groups_per_tile, std::memory_order_relaxed);
@@ -1519,10 +1746,20 @@ int cnf_ext_actnorm_bwd(const float* z_out, const float* nn_out, const float* pa
     const bool fast = math_mode() == 1;
     const bool aligned = aligned_to(16, {z_out, nn_out, g_zout, g_z, g_nn});
     const int tp = (D % 4 == 0) ? 1 : (D % 2 == 0 ? 2 : 4);
-    const dim3 grid(stream_grid((ntok + tp - 1) / tp)), block(kBlock);
+    const dim3 block(kBlock);
+    // wave tiles (coalesced spans, LDS transpose) where there is an upstream gradient and at least one tile per wave of a modest
+    // grid; `G` tiles per wave as for the 1x1 convolution
+    const long tiles = ntok / ((long)kWave * tp);
+    const bool tiled = g_zout != nullptr && tiles >= 1;
+    const int G = bwd_g(2);
+    const dim3 grid = tiled ? dim3((unsigned)std::min<long>(std::max<long>((tiles + (long)kWavesPerBlock * G - 1) / ((long)kWavesPerBlock * G), 1), kBwdMaxBlocks))
+                            : dim3(stream_grid((ntok + tp - 1) / tp));
 #define EXT_BWD(DD)                                                                                                 \
     do {                                                                                                            \
-        if (fast) CNF_LAUNCH((ext_actnorm_bwd_group_kernel<DD, true>), grid, block, 0, st, a);                      \
+        if (tiled) {                                                                                                \
+            if (fast) CNF_LAUNCH((ext_actnorm_bwd_tile_kernel<DD, true>), grid, block, 0, st, a);                   \
+            else CNF_LAUNCH((ext_actnorm_bwd_tile_kernel<DD, false>), grid, block, 0, st, a);                       \
+        } else if (fast) CNF_LAUNCH((ext_actnorm_bwd_group_kernel<DD, true>), grid, block, 0, st, a);               \
         else CNF_LAUNCH((ext_actnorm_bwd_group_kernel<DD, false>), grid, block, 0, st, a);                          \
     } while (0)
     switch (aligned ? D : 0) {
@@ -1550,14 +1787,32 @@ int cnf_actnorm_bwd(const float* z_out, const float* bias, const float* scales,
     const int L = N * D;
     const int vec = vec_for(L, {z_out, g_zout, g_z});
     CNF_REQUIRE(flat_ok(L, vec), "cnf_actnorm_bwd: rows of %d elements are too long", L);
-    ActBwdArgs a{z_out, bias, scales, pad, length, g_zout, g_ldj, g_z, workspace, B, N, D, L, reverse, make_fastdiv((uint32_t)D)};
+    ActBwdArgs a{z_out, bias, scales, pad, length, g_zout, g_ldj, g_z, workspace, B, N, D, L, reverse, make_fastdiv((uint32_t)D), (long)B * N};
     const int U = vec == 4 ? bwd_u(2) : 2;
-    // two groups per wave: the wave's closing reduction of its 2D + 1 sums weighs as much as one group's arithmetic
-    const FlatTiling tl = make_flat_tiling(B, L, U, vec, bwd_g(2));
-    const dim3 grid = flat_grid(tl), block(kBlock);
-    const size_t lds = (size_t)2 * D * kBlock * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     const bool fast = math_mode() == 1;
+    const dim3 block(kBlock);
+    if ((D <= 6 || D == 8) && g_zout && aligned_to(16, {z_out, g_zout, g_z}) && g_act_bwd_tiles.load(std::memory_order_relaxed)) {
+        // token-owner wave tiles with register sums
+        const int tp = (D % 4 == 0) ? 1 : (D % 2 == 0 ? 2 : 4);
+        const long tiles = std::max<long>(a.ntok / ((long)kWave * tp), 1);
+        const int G = bwd_g(2);
+        const dim3 tgrid((unsigned)std::min<long>(std::max<long>((tiles + (long)kWavesPerBlock * G - 1) / ((long)kWavesPerBlock * G), 1), kBwdMaxBlocks));
+#define ACT_T(DD) \
+    case DD: \
+        if (fast) CNF_LAUNCH((actnorm_bwd_tile_kernel<DD, true>), tgrid, block, 0, st, a); \
+        else CNF_LAUNCH((actnorm_bwd_tile_kernel<DD, false>), tgrid, block, 0, st, a); \
+        break;
+        switch (D) { ACT_T(1) ACT_T(2) ACT_T(3) ACT_T(4) ACT_T(5) ACT_T(6) ACT_T(8) }
+#undef ACT_T
+        CNF_LAUNCH(bwd_reduce_partials_kernel, dim3(2 * D), dim3(kReduceBlock), 0, st, workspace, (int)tgrid.x * kWavesPerBlock, 2 * D + 1,
+                   g_bias, g_scales, D, g_ldj ? 2 * D : -1, D);
+        return launch_status("cnf_actnorm_bwd");
+    }
+    // two groups per wave: the wave's closing reduction of its 2D + 1 sums weighs as much as one group's arithmetic
+    const FlatTiling tl = make_flat_tiling(B, L, U, vec, bwd_g(2));
+    const dim3 grid = flat_grid(tl);
+    const size_t lds = (size_t)2 * D * kBlock * sizeof(float);
     dispatch_vec_u(tl.vec, U, [&](auto v_, auto u_) {
         BWD_VU(v_, u_);
 #define ACT_BWD(FA, PD) CNF_LAUNCH((actnorm_bwd_kernel<V, UU, FA, PD>), grid, block, lds, st, a, tl)

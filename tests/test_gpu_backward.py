@@ -492,3 +492,34 @@ def test_last_coupling_nll_fns_vs_oracle_autograd(B, N, D, K, seed):
     grad_close(nll, nll_o, "nll", rel=5e-5); grad_close(lo, l1, "ldj_out", rel=5e-5)
     for name, a, b in zip(("g_z", "g_nn", "g_sf", "g_ldj"), dl, leaves):
         grad_close(a.grad, b.grad, "affine " + name, rel=5e-4)
+
+
+@pytest.mark.parametrize("B,N,D,seed", [(300, 38, 6, 1), (64, 16, 4, 2), (33, 17, 3, 3), (129, 64, 8, 4), (2048, 64, 6, 5), (7, 5, 5, 6), (50, 9, 7, 7)])
+def test_actnorm_backward_token_owner_and_flat_tile_kernels_agree(B, N, D, seed):
+    """cnf_actnorm_bwd has two kernels: token-owner wave tiles with register sums (default for D in {1..6, 8}) and flat tiles with
+    lane-private LDS sums (cnf_set_actnorm_bwd_tiles(0); any D).  Same gradients to the rounding of the summation order, both
+    directions, with padding and lengths; each bit-reproducible."""
+    from categoricalnf_amd import functional as Fn
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(seed)
+    z = g(torch.randn(B, N, D, generator=gen))
+    bias, scales = g(torch.randn(1, 1, D, generator=gen)), g(0.3 * torch.randn(1, 1, D, generator=gen))
+    pad, length = _pad_len(B, N, seed, gen)
+    gz, gl = g(torch.randn(B, N, D, generator=gen)), g(torch.randn(B, generator=gen))
+    for reverse in (False, True):
+        out = {}
+        for tiles in (1, 0):
+            lib.cnf_set_actnorm_bwd_tiles(tiles)
+            try:
+                runs = []
+                for _ in range(2):
+                    zl, bl, sl, ll = (t.clone().requires_grad_(True) for t in (z, bias, scales, gl * 0))
+                    zo, lo = Fn.ActNormFn.apply(zl, bl, sl, ll, g(length), g(pad), reverse)
+                    torch.autograd.backward([zo, lo], [gz, gl])
+                    runs.append((zl.grad, bl.grad, sl.grad))
+                assert all(torch.equal(a, b) for a, b in zip(*runs))
+                out[tiles] = runs[0]
+            finally:
+                lib.cnf_set_actnorm_bwd_tiles(1)
+        for name, a, b in zip(("g_z", "g_bias", "g_scales"), out[1], out[0]):
+            grad_close(a, b, name + (" reverse" if reverse else ""), rel=2e-5)

@@ -123,6 +123,7 @@ rows = [
     ("affine_bwd fwd-dir (no sf)", 28, lambda i: affine(i, 0, False)),
     ("actnorm_bwd", 12, lambda i: actnorm(i, 0)),
     ("actnorm_bwd padded", 12, lambda i: actnorm(i, 0, True)),
+    ("actnorm_bwd (flat-tile kernel)", 12, lambda i: (lib.cnf_set_actnorm_bwd_tiles(0), actnorm(i, 0), lib.cnf_set_actnorm_bwd_tiles(1))),
     ("invconv_bwd", 12, lambda i: invconv(i, 0)),
     ("invconv_bwd padded", 12, lambda i: invconv(i, 0, True)),
     ("actnorm+invconv_bwd fused (from input)", 12, lambda i: actconv(i, 0)),
@@ -139,9 +140,9 @@ if args.only:
 if args.pmc:
     import json
     frag = {"affine_bwd fwd-dir (sf)": "affine_bwd_kernel<4, 2, true, false", "affine_bwd inv-dir (sf)": "affine_bwd_kernel<4, 2, true, true",
-            "affine_bwd fwd-dir (no sf)": "affine_bwd_kernel<4, 2, false, false", "actnorm_bwd": "::actnorm_bwd_kernel<",
+            "affine_bwd fwd-dir (no sf)": "affine_bwd_kernel<4, 2, false, false", "actnorm_bwd": "::actnorm_bwd_tile_kernel<", "actnorm_bwd (flat-tile kernel)": "::actnorm_bwd_kernel<",
             "invconv_bwd": "::invconv_bwd_kernel<6>", "actnorm+invconv_bwd fused (from input)": "actconv_bwd_kernel<6, false>",
-            "actnorm+invconv_bwd fused (from output)": "actconv_bwd_kernel<6, true>", "ext_actnorm_bwd": "ext_actnorm_bwd_group_kernel<6", "prior_nll_bwd": "prior_nll_bwd_kernel",
+            "actnorm+invconv_bwd fused (from output)": "actconv_bwd_kernel<6, true>", "ext_actnorm_bwd": "ext_actnorm_bwd_tile_kernel<6", "prior_nll_bwd": "prior_nll_bwd_kernel",
             "logistic_log_prob_bwd": "logistic_log_prob_bwd_kernel", "sigmoid_flow_bwd": "sigmoid_flow_bwd_kernel",
             "affine_params_bwd": "affine_params_bwd_kernel<4, 2, true", "affine_transform_bwd": "affine_transform_bwd_kernel<4, 2"}
     manifest = {}
