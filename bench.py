@@ -305,6 +305,14 @@ def kernel_table(lib, ops, dev, budget_ms=6.0):
         [call("cnf_actnorm_bwd", P(zs[r]), P(bias), P(scales), None, P(ln), P(gz[r]), P(gl), P(o1[r]), P(g_b), P(g_s), P(ws), B, N, D, 0, st) for r in range(R)])
     row("invconv_bwd (+ reduction launch)", S, 12 * e,
         [call("cnf_invconv_bwd", P(zs[r]), P(w), None, P(ln), P(gz[r]), P(gl), P(o1[r]), P(g_w), P(g_sl), P(ws), B, N, D, 0, st) for r in range(R)])
+    g_par = torch.empty(D * D + 1 + 2 * D, device=dev)
+    wsa = torch.empty(int(lib.cnf_bwd_workspace_floats(D * D + 2 * D + 2)), device=dev)
+    row("actnorm_invconv_bwd (fused pair, intermediate recomputed from the input, + reduction launch)", S, 12 * e,
+        [call("cnf_actnorm_invconv_bwd", P(zs[r]), 0, P(bias), P(scales), P(w), None, None, P(ln), P(gz[r]), P(gl), P(o1[r]), P(g_par), P(wsa), B, N, D, st)
+         for r in range(R)])
+    row("actnorm_invconv_bwd (behind a fused coupling / encoder: from the output through W^-1, + inverse and reduction launches)", S, 12 * e,
+        [call("cnf_actnorm_invconv_bwd", P(zs[r]), 1, P(bias), P(scales), P(w), None, None, P(ln), P(gz[r]), P(gl), P(o1[r]), P(g_par), P(wsa), B, N, D, st)
+         for r in range(R)])
     row("ext_actnorm_bwd", S, 28 * e,
         [call("cnf_ext_actnorm_bwd", P(zs[r]), P(nn2[r]), None, P(gz[r]), P(gl), P(o1[r]), P(o2[r]), B, N, D, 0, st) for r in range(R)])
     gldj = torch.empty(B, device=dev)
@@ -426,16 +434,16 @@ def read_traffic(path=None):
 
 
 def rocprof_cross_check(kern_ms):
-    """The committed rocprofv3 summary of this command (profiles/r03_bench_kernel_stats.csv, `rocprofv3 --kernel-trace --stats
+    """The committed rocprofv3 summary of this command (profiles/r04_bench_kernel_stats.csv — the newest round's file that exists, `rocprofv3 --kernel-trace --stats
     -- python bench.py --no-cpu-baseline` on these kernel sources' round): its AverageNs for the dominant kernel next to this
     run's `kernel_ms`.  A static file, reported for the reader's convenience — None when it is absent."""
     import csv
-    path = os.path.join(ROOT, "profiles", "r03_bench_kernel_stats.csv")
+    path = next((f for f in (os.path.join(ROOT, "profiles", "r%02d_bench_kernel_stats.csv" % r) for r in (4, 3)) if os.path.exists(f)), "")
     try:
         for row in csv.DictReader(open(path)):
             if "affine_coupling_kernel<4, 2, true, false, true, 1>" in row["Name"]:
                 avg_ms = float(row["AverageNs"]) * 1e-6
-                return {"file": "profiles/r03_bench_kernel_stats.csv", "rocprofv3_average_kernel_ms": avg_ms, "calls": int(row["Calls"]),
+                return {"file": os.path.relpath(path, ROOT), "rocprofv3_average_kernel_ms": avg_ms, "calls": int(row["Calls"]),
                         "this_run_over_rocprofv3": kern_ms / avg_ms}
     except Exception:
         pass

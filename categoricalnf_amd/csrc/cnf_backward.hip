@@ -1796,7 +1796,7 @@ int cnf_actnorm_bwd(const float* z_out, const float* bias, const float* scales,
         // token-owner wave tiles with register sums
         const int tp = (D % 4 == 0) ? 1 : (D % 2 == 0 ? 2 : 4);
         const long tiles = std::max<long>(a.ntok / ((long)kWave * tp), 1);
-        const int G = bwd_g(2);
+        const int G = bwd_g(4);
         const dim3 tgrid((unsigned)std::min<long>(std::max<long>((tiles + (long)kWavesPerBlock * G - 1) / ((long)kWavesPerBlock * G), 1), kBwdMaxBlocks));
 #define ACT_T(DD) \
     case DD: \
@@ -1848,7 +1848,7 @@ int cnf_invconv_bwd(const float* x, const float* weight, const float* pad, const
     // one wave tile = 64 token groups; every wave takes `G` tiles so that its register sums are combined once
     const int tp = (D % 4 == 0) ? 1 : (D % 2 == 0 ? 2 : 4);
     const long tiles = std::max<long>(a.ntok / ((long)kWave * tp), 1);
-    const int G = bwd_g(2);
+    const int G = bwd_g(4);
     dim3 grid((unsigned)std::min<long>(std::max<long>((tiles + (long)kWavesPerBlock * G - 1) / ((long)kWavesPerBlock * G), 1), kBwdMaxBlocks));
     switch (D) {
         case 1: CNF_LAUNCH((invconv_bwd_kernel<1>), grid, block, 0, st, a); break;
@@ -1888,7 +1888,7 @@ int cnf_actnorm_invconv_bwd(const float* saved, int saved_is_output, const float
     const dim3 block(kBlock);
     const int tp = (D % 4 == 0) ? 1 : (D % 2 == 0 ? 2 : 4);
     const long tiles = std::max<long>(a.ntok / ((long)kWave * tp), 1);
-    const int G = bwd_g(2);
+    const int G = bwd_g(4);
     const dim3 grid((unsigned)std::min<long>(std::max<long>((tiles + (long)kWavesPerBlock * G - 1) / ((long)kWavesPerBlock * G), 1), kBwdMaxBlocks));
 #define ACB(DD) \
     case DD: \

@@ -69,7 +69,7 @@ void cnf_set_inverse_mode(int mode);
 /* Items (transformed elements) one wave of the fp32 mixture forward kernel owns, 64..512 (default 128). */
 void cnf_set_mixture_tile(int items);
 /* Flat tiles of the streaming backward kernels (csrc/cnf_backward.hip): 16-byte chunks a lane keeps in flight (1..3) and
- * chunk groups one wave walks (1..64); 0 = every kernel's own default (2 chunks; 1 group, 2 for ActNorm / the 1x1 conv).  A tuning knob like the ones above: the reference has no
+ * chunk groups one wave walks (1..64); 0 = every kernel's own default (2 chunks; 1 group for the flat-tile kernels, 2 for ExtActNorm, 4 for the token-owner ActNorm / 1x1 conv / fused-pair kernels).  A tuning knob like the ones above: the reference has no
  * counterpart (its backward is autograd, general/train.py:144-155).  All tuning knobs are process-wide atomics — set them
  * before use; they are not per device or per thread. */
 void cnf_set_bwd_tile(int chunks_in_flight, int groups_per_tile);

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Re-measure everything profiles/ holds, on the GPU box.  Run from the repo root:
 #   gpurun --timeout 2400 -- 'bash tools/refresh_profiles.sh'        (CNF_REFRESH_QUICK=1: the kernel measurements only)
-# then, back in the build container:  python tools/collect_profiles.py r03
+# then, back in the build container:  python tools/collect_profiles.py r04
 # The --pmc passes are separate rocprofv3 runs with --kernel-trace only (never combined with sys/hip traces).
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -43,6 +43,19 @@ timeout 200 python tools/encoder_lds_vs_tiled.py 2>/dev/null > "$OUT/encoder_lds
 timeout 200 python tools/encoder_fused_sampler.py 2>/dev/null > "$OUT/encoder_fused_sampler.txt"; tail -5 "$OUT/encoder_fused_sampler.txt"
 timeout 200 python tools/sustained_probe.py > "$OUT/sustained_probe.txt" 2>&1; tail -6 "$OUT/sustained_probe.txt"
 bash tools/pmc_ceilings.sh ceilings > "$OUT/ceilings.log" 2>&1; tail -10 "$OUT/ceilings.log"
+# round 4: the backward kernels — start-to-start table + stream ceiling, counters / calibrated VALU fraction, rocprofv3 durations
+timeout 300 python tools/bwd_probe.py --sweep > "$OUT/bwd_probe.txt" 2>&1; head -24 "$OUT/bwd_probe.txt"
+bash tools/pmc_ceilings.sh ceilings_bwd python tools/bwd_probe.py --pmc > "$OUT/ceilings_bwd.log" 2>&1; tail -14 "$OUT/ceilings_bwd.log"
+rm -rf "$OUT/prof_bwd"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_bwd" -o bwd -- python tools/bwd_probe.py --reps 30 > /dev/null 2>&1
+python tools/summarize_kernel_stats.py "$OUT/prof_bwd/bwd_kernel_stats.csv" "$OUT/bwd_kernel_stats.csv" "tools/bwd_probe.py --reps 30 (every streaming backward kernel at B=16384, N=64, D=6 on four rotating buffer sets; kernel durations by themselves: the start-to-start table of r04_bwd_probe.txt includes the reduction launch behind a kernel)" 30 | head -3
+rm -f "$OUT"/prof_bwd/*kernel_trace.csv
+# the encoder backward per kernel (token-lane, class-lane and split-sum launches) at the benchmark token count, C = 16 and 51
+rm -rf "$OUT/prof_encbwd"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_encbwd" -o encbwd -- python tools/encoder_bwd_breakdown.py 16384,64,16 16384,64,51 > "$OUT/encoder_bwd_breakdown.txt" 2>&1
+python tools/summarize_kernel_stats.py "$OUT/prof_encbwd/encbwd_kernel_stats.csv" "$OUT/encoder_bwd_kernel_stats.csv" "tools/encoder_bwd_breakdown.py 16384,64,16 16384,64,51 (encoder forward + cnf_encoder_forward_bwd_tiled at 1 048 576 tokens, D = 6, C = 16 and 51, 20 steps each: its launches one by one)" 12 | head -3
+rm -f "$OUT"/prof_encbwd/*kernel_trace.csv
+timeout 200 python tools/autograd_overhead.py > "$OUT/autograd_overhead.txt" 2>&1; tail -3 "$OUT/autograd_overhead.txt"
 bash tools/pmc_passes.sh pmc_small python tools/pmc_small_mixture.py > "$OUT/pmc_small.log" 2>&1
 bash tools/pmc_passes.sh flow_fused python tools/flow_traffic_workload.py fused > /dev/null 2>&1
 bash tools/pmc_passes.sh flow_unfused python tools/flow_traffic_workload.py unfused > /dev/null 2>&1
