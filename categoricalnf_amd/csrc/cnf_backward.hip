@@ -40,7 +40,7 @@ constexpr int kBwdMaxD = 64;            // channels of the per-workgroup constan
 // before use (cnf_set_bwd_tile)
 static std::atomic<int> g_bwd_u{0}, g_bwd_g{0};
 // ActNorm backward: 1 = the token-owner tile kernel where it applies (default), 0 = always the flat-tile kernel (A/B, tests)
-static std::atomic<int> g_act_bwd_tiles{1};
+static std::atomic<int> g_act_bwd_tiles{1}, g_aff_bwd_tiles{1};
 
 // partials [P, nrows <= kBwdMaxRows] (column-major rows of the waves) -> column sums in fp64 in a fixed order; columns [0, split) go to out_a, the rest to
 // out_b (either may be null): the parameter-gradient tensors are written directly.  One workgroup of 1024 threads per
@@ -479,6 +479,182 @@ __global__ __launch_bounds__(kBlock) void affine_bwd_kernel(AffBwdArgs a, FlatTi
     };
     walk_flat_tiles<VEC, U, AffBwdChunk<VEC>>(tl, load, proc, pre);
     if (HAS_SF && !(CNF_BWD_ABLATE & 1)) wave_lane_private_reduce(acc, a.D, wave_partials_row(a.partials));
+}
+
+// ---- affine coupling, token-owner wave tiles (channel masks, D in {2, 3, 4, 6, 8}) -------------------------------------------------
+// The form of ext_actnorm_bwd_tile_kernel / invconv_bwd_kernel below: a wave takes spans of 64 token groups with coalesced
+// 16-byte loads, transposes them through its LDS strips so that a lane owns whole tokens — every per-channel constant (mask,
+// e^sf, clamp flag) and the D scaling-factor sums then live in REGISTERS: no per-element LDS table read, no lane-private LDS
+// read-add-write.  Measured against the flat-tile kernel above at the benchmark shape: profiles/r04_bwd_probe.txt.
+struct AffTileArgs {
+    const float* z_out;
+    const float* nn;        // [B,N,2D] interleaved (s_raw, t) pairs
+    const float* sf;        // nullable
+    const float* mask;      // [D] channel mask or null (nothing kept)
+    const float* g_zout;
+    const float* g_ldj;     // nullable
+    float* g_z;
+    float* g_nn;
+    float* partials;
+    long ntok;
+    int N, D;
+    FastDiv div_n;
+    int fast_rows;
+};
+template <int D, bool HAS_SF, bool REVERSE, bool FAST>
+__global__ __launch_bounds__(kBlock) void affine_bwd_tile_kernel(AffTileArgs a) {
+    constexpr int TP = (D % 4 == 0) ? 1 : (D % 2 == 0 ? 2 : 4);
+    constexpr int NV = TP * D / 4, NC = 2 * NV;
+    __shared__ bw_f4 strip_all[kWavesPerBlock][4][kWave * NV];
+    __shared__ float comb[kWavesPerBlock][4 * D];
+    bw_f4* sz = strip_all[threadIdx.x >> 6][0];
+    bw_f4* sg = strip_all[threadIdx.x >> 6][1];
+    bw_f4* sc0 = strip_all[threadIdx.x >> 6][2];        // vectors [0, NV) of every group's nn row
+    bw_f4* sc1 = strip_all[threadIdx.x >> 6][3];        // vectors [NV, 2 NV)
+    const int lane = threadIdx.x & 63;
+    float keep[D], keepf[D], x3[D], kscale[D], nfl[D], acc[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const float m = a.mask ? a.mask[d] : 0.f;
+        const float f = HAS_SF ? expf(a.sf[d]) : 1.f;
+        const float fc = fmaxf(f, 1.f);
+        keep[d] = 1.f - m;
+        keepf[d] = (1.f - m) * f;
+        x3[d] = FAST ? 2.8853900817779268f / fc : fc;
+        kscale[d] = keepf[d] / fc;
+        nfl[d] = f >= 1.f ? -1.f : 0.f;
+        acc[d] = 0.f;
+    }
+    // a missing upstream gradient is zero: the loads go to a valid address anyway and their result is dropped
+    const bool has_gz = a.g_zout != nullptr;
+    const float* gz_src = has_gz ? a.g_zout : a.z_out;
+    // one token: zo / gzo [D], nv = (s_raw, t) pairs [2D] in; gz [D], gn [2D] out (the arithmetic of affine_bwd_kernel)
+    auto token = [&](const float* zo, const float* gin, const float* nv, float gl, float* gz, float* gn) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const float sr = nv[2 * d], tr = nv[2 * d + 1], gzo = has_gz ? gin[d] : 0.f;
+            float s, sech2 = 0.f;
+            if (!HAS_SF) {
+                s = sr * keep[d];
+            } else if (FAST) {
+                const float r = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(sr * x3[d]) + 1.f);
+                s = fmaf(r, -2.f * keepf[d], keepf[d]);
+                sech2 = 4.f * r * (1.f - r);
+            } else {
+                const float th = tanhf(sr / x3[d]);
+                s = th * keepf[d];
+                sech2 = 1.f - th * th;
+            }
+            float gs, gt;
+            if (!REVERSE) {                         // z' = (z + t) e^s ; ldj += s
+                gz[d] = gzo * bexp<FAST>(s);
+                gt = gz[d];
+                gs = fmaf(gzo, zo[d], gl);
+            } else {                                // z' = z e^-s - t ; ldj -= s
+                gz[d] = gzo * bexp<FAST>(-s);
+                gt = -gzo;
+                gs = -fmaf(gzo, zo[d] + tr * keep[d], gl);
+            }
+            float g_sr;
+            if (HAS_SF) {
+                g_sr = gs * sech2 * kscale[d];
+                acc[d] += fmaf(nfl[d] * sr, g_sr, gs * s);
+            } else {
+                g_sr = gs * keep[d];
+            }
+            gn[2 * d] = g_sr;
+            gn[2 * d + 1] = gt * keep[d];
+        }
+    };
+    auto row_gl = [&](long tok) {
+        if (!a.g_ldj) return 0.f;
+        const long b = a.fast_rows ? (long)fdiv((uint32_t)tok, a.div_n) : tok / a.N;
+        return a.g_ldj[b];
+    };
+    const long ngroups = a.ntok / TP;
+    const long ntiles = ngroups / kWave;
+    const long wave_id = (long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const long nwaves = (long)gridDim.x * kWavesPerBlock;
+    for (long tile = wave_id; tile < ntiles; tile += nwaves) {
+        const bw_f4* srcz = reinterpret_cast<const bw_f4*>(a.z_out + tile * (kWave * TP * D));
+        const bw_f4* srcg = reinterpret_cast<const bw_f4*>(gz_src + tile * (kWave * TP * D));
+        const bw_f4* srcc = reinterpret_cast<const bw_f4*>(a.nn + tile * (kWave * TP * 2 * D));
+        bw_f4 qz[NV], qg[NV], qc[NC];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) qz[v] = __builtin_nontemporal_load(srcz + v * kWave + lane);
+#pragma unroll
+        for (int v = 0; v < NC; ++v) qc[v] = __builtin_nontemporal_load(srcc + v * kWave + lane);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) qg[v] = srcg[v * kWave + lane];
+        const long tok0 = (tile * kWave + lane) * TP;
+        float gl[TP];
+#pragma unroll
+        for (int k = 0; k < TP; ++k) gl[k] = row_gl(tok0 + k);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            sz[v * kWave + lane] = qz[v];
+            sg[v * kWave + lane] = qg[v];
+        }
+#pragma unroll
+        for (int v = 0; v < NC; ++v) {
+            const int i = v * kWave + lane, grp = i / NC, j = i - grp * NC;
+            (j < NV ? sc0 : sc1)[grp * NV + (j < NV ? j : j - NV)] = qc[v];
+        }
+        wave_lds_order();
+        float zo[TP * D], gzo[TP * D], cv[2 * TP * D], gz[TP * D], gc[2 * TP * D];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const bw_f4 r = sz[lane * NV + v];
+            zo[4 * v] = r.x; zo[4 * v + 1] = r.y; zo[4 * v + 2] = r.z; zo[4 * v + 3] = r.w;
+            const bw_f4 q = sg[lane * NV + v];
+            gzo[4 * v] = q.x; gzo[4 * v + 1] = q.y; gzo[4 * v + 2] = q.z; gzo[4 * v + 3] = q.w;
+            const bw_f4 c0 = sc0[lane * NV + v];
+            cv[4 * v] = c0.x; cv[4 * v + 1] = c0.y; cv[4 * v + 2] = c0.z; cv[4 * v + 3] = c0.w;
+            const bw_f4 c1 = sc1[lane * NV + v];
+            cv[4 * (NV + v)] = c1.x; cv[4 * (NV + v) + 1] = c1.y; cv[4 * (NV + v) + 2] = c1.z; cv[4 * (NV + v) + 3] = c1.w;
+        }
+#pragma unroll
+        for (int k = 0; k < TP; ++k) token(zo + k * D, gzo + k * D, cv + k * 2 * D, gl[k], gz + k * D, gc + k * 2 * D);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {              // the lane's own group: nobody else reads these words
+            const bw_f4 r = {gz[4 * v], gz[4 * v + 1], gz[4 * v + 2], gz[4 * v + 3]};
+            sz[lane * NV + v] = r;
+            const bw_f4 c0 = {gc[4 * v], gc[4 * v + 1], gc[4 * v + 2], gc[4 * v + 3]};
+            sc0[lane * NV + v] = c0;
+            const bw_f4 c1 = {gc[4 * (NV + v)], gc[4 * (NV + v) + 1], gc[4 * (NV + v) + 2], gc[4 * (NV + v) + 3]};
+            sc1[lane * NV + v] = c1;
+        }
+        wave_lds_order();
+        bw_f4* dz = reinterpret_cast<bw_f4*>(a.g_z + tile * (kWave * TP * D));
+        bw_f4* dc = reinterpret_cast<bw_f4*>(a.g_nn + tile * (kWave * TP * 2 * D));
+#pragma unroll
+        for (int v = 0; v < NV; ++v) st_chunk<4, kNtOut>(reinterpret_cast<float*>(dz + v * kWave + lane), reinterpret_cast<const float*>(&sz[v * kWave + lane]));
+#pragma unroll
+        for (int v = 0; v < NC; ++v) {
+            const int i = v * kWave + lane, grp = i / NC, j = i - grp * NC;
+            st_chunk<4, kNtOut>(reinterpret_cast<float*>(dc + i), reinterpret_cast<const float*>(&(j < NV ? sc0 : sc1)[grp * NV + (j < NV ? j : j - NV)]));
+        }
+        wave_lds_order();                            // the strips are refilled by the next tile
+    }
+    // tokens that do not fill a wave tile
+    for (long tok = ntiles * kWave * TP + (long)blockIdx.x * kBlock + threadIdx.x; tok < a.ntok; tok += (long)gridDim.x * kBlock) {
+        float zo[D], gzo[D], cv[2 * D], gz[D], gc[2 * D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            zo[d] = a.z_out[tok * D + d];
+            gzo[d] = gz_src[tok * D + d];
+            cv[2 * d] = a.nn[tok * 2 * D + 2 * d];
+            cv[2 * d + 1] = a.nn[tok * 2 * D + 2 * d + 1];
+        }
+        token(zo, gzo, cv, a.g_ldj ? a.g_ldj[tok / a.N] : 0.f, gz, gc);
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            a.g_z[tok * D + d] = gz[d];
+            a.g_nn[tok * 2 * D + 2 * d] = gc[2 * d];
+            a.g_nn[tok * 2 * D + 2 * d + 1] = gc[2 * d + 1];
+        }
+    }
+    if (HAS_SF) wave_register_reduce<D>(acc, comb[threadIdx.x >> 6], wave_partials_row(a.partials));
 }
 
 // ---- static-API split forms of the affine coupling (coupling_layer.py:76-98) ---------------------------------
@@ -1646,6 +1822,7 @@ int64_t cnf_bwd_workspace_floats(int param_count) {
 }
 
 void cnf_set_actnorm_bwd_tiles(int on) { g_act_bwd_tiles.store(on ? 1 : 0, std::memory_order_relaxed); }
+void cnf_set_affine_bwd_tiles(int on) { g_aff_bwd_tiles.store(on ? 1 : 0, std::memory_order_relaxed); }
 
 void cnf_set_bwd_tile(int chunks_in_flight, int groups_per_tile) {
     if (chunks_in_flight >= 0 && chunks_in_flight <= 3) g_bwd_u.store(chunks_in_flight, std::memory_order_relaxed);
@@ -1672,12 +1849,40 @@ int cnf_affine_coupling_bwd(const float* z_out, const float* nn_out, const float
         set_error("cnf_affine_coupling_bwd: mask period %d x D %d too large", mask_rows, D);
         return CNF_ERR_UNSUPPORTED;
     }
+    hipStream_t st = (hipStream_t)stream;
+    if (mask_rows == 1 && mask_cols == D && (D == 2 || D == 3 || D == 4 || D == 6 || D == 8) &&
+        aligned_to(16, {z_out, nn_out, g_zout, g_z, g_nn}) && g_aff_bwd_tiles.load(std::memory_order_relaxed)) {
+        // channel mask: token-owner wave tiles, constants and scaling-factor sums in registers
+        const long ntok = (long)B * N;
+        AffTileArgs t{z_out, nn_out, scaling_factor, mask, g_zout, g_ldj, g_z, g_nn, workspace, ntok, N, D, make_fastdiv((uint32_t)N),
+                      ntok < (1l << 32) / N ? 1 : 0};
+        const int tp = (D % 4 == 0) ? 1 : (D % 2 == 0 ? 2 : 4);
+        const long tiles = std::max<long>(ntok / ((long)kWave * tp), 1);
+        const int G = bwd_g(2);
+        const dim3 grid((unsigned)std::min<long>(std::max<long>((tiles + (long)kWavesPerBlock * G - 1) / ((long)kWavesPerBlock * G), 1), kBwdMaxBlocks));
+        const dim3 block(kBlock);
+        const bool fast = math_mode() == 1, has_sf = scaling_factor != nullptr, rev = reverse != 0;
+#define AFT3(DD, SF, RV) \
+        do { \
+            if (fast) CNF_LAUNCH((affine_bwd_tile_kernel<DD, SF, RV, true>), grid, block, 0, st, t); \
+            else CNF_LAUNCH((affine_bwd_tile_kernel<DD, SF, RV, false>), grid, block, 0, st, t); \
+        } while (0)
+#define AFT(DD) \
+        case DD: \
+            if (has_sf) { if (rev) AFT3(DD, true, true); else AFT3(DD, true, false); } \
+            else { if (rev) AFT3(DD, false, true); else AFT3(DD, false, false); } \
+            break;
+        switch (D) { AFT(2) AFT(3) AFT(4) AFT(6) AFT(8) }
+#undef AFT
+#undef AFT3
+        if (scaling_factor) reduce_partials(workspace, (int)grid.x * kWavesPerBlock, D, g_scaling_factor, st);
+        return launch_status("cnf_affine_coupling_bwd");
+    }
     AffBwdArgs a{z_out, nn_out, scaling_factor, mask, g_zout, g_ldj, g_z, g_nn, workspace,
                  N, D, L, mask_rows, mask_cols, mask_rows * D, make_fastdiv((uint32_t)(mask_rows * D)), make_fastdiv((uint32_t)D)};
     const int vec = vec_for(L, {z_out, nn_out, g_zout, g_z, g_nn});
     const int U = vec == 4 ? bwd_u(2) : 2;
     const FlatTiling tl = make_flat_tiling(B, L, U, vec, bwd_g(1));
-    hipStream_t st = (hipStream_t)stream;
     dispatch_vec_u(tl.vec, U, [&](auto v_, auto u_) {
         BWD_VU(v_, u_);
         launch_affine_bwd<V, UU>(a, tl, scaling_factor != nullptr, reverse != 0, st);

@@ -523,3 +523,38 @@ def test_actnorm_backward_token_owner_and_flat_tile_kernels_agree(B, N, D, seed)
                 lib.cnf_set_actnorm_bwd_tiles(1)
         for name, a, b in zip(("g_z", "g_bias", "g_scales"), out[1], out[0]):
             grad_close(a, b, name + (" reverse" if reverse else ""), rel=2e-5)
+
+
+@pytest.mark.parametrize("B,N,D,seed", [(300, 38, 6, 1), (64, 16, 4, 2), (33, 17, 3, 3), (129, 64, 8, 4), (2048, 64, 6, 5), (50, 9, 2, 6), (1, 5, 6, 7)])
+@pytest.mark.parametrize("mode", [1, 0])
+def test_affine_backward_token_owner_and_flat_tile_kernels_agree(B, N, D, seed, mode):
+    """cnf_affine_coupling_bwd has two kernels for channel masks: token-owner wave tiles (constants and scaling-factor sums in
+    registers; default at D in {2, 3, 4, 6, 8}) and flat tiles (cnf_set_affine_bwd_tiles(0); any mask, any D).  Same gradients to
+    rounding in both directions, both math modes, with and without the scaling factor; each bit-reproducible."""
+    from categoricalnf_amd import functional as Fn
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(seed)
+    z, nn_out = g(torch.randn(B, N, D, generator=gen)), g(0.5 * torch.randn(B, N, 2 * D, generator=gen))
+    sf, mask = g(0.3 * torch.randn(D, generator=gen)), g(_mask("channel", D))
+    gz, gl = g(torch.randn(B, N, D, generator=gen)), g(torch.randn(B, generator=gen))
+    lib.cnf_set_math_mode(mode)
+    try:
+        for reverse in (False, True):
+            for with_sf in (True, False):
+                out = {}
+                for tiles in (1, 0):
+                    lib.cnf_set_affine_bwd_tiles(tiles)
+                    runs = []
+                    for _ in range(2):
+                        zl, nl, ll = (t.clone().requires_grad_(True) for t in (z, nn_out, gl * 0))
+                        sl = sf.clone().requires_grad_(True) if with_sf else None
+                        zo, lo = Fn.AffineCouplingFn.apply(zl, nl, sl, ll, mask, reverse)
+                        torch.autograd.backward([zo, lo], [gz, gl])
+                        runs.append((zl.grad, nl.grad) + ((sl.grad,) if with_sf else ()))
+                    assert all(torch.equal(a, b) for a, b in zip(*runs))
+                    out[tiles] = runs[0]
+                for name, a, b in zip(("g_z", "g_nn", "g_sf"), out[1], out[0]):
+                    grad_close(a, b, "%s reverse=%s sf=%s" % (name, reverse, with_sf), rel=2e-5)
+    finally:
+        lib.cnf_set_affine_bwd_tiles(1)
+        lib.cnf_set_math_mode(1)

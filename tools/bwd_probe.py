@@ -121,6 +121,8 @@ rows = [
     ("affine_bwd fwd-dir (sf)", 28, lambda i: affine(i, 0)),
     ("affine_bwd inv-dir (sf)", 28, lambda i: affine(i, 1)),
     ("affine_bwd fwd-dir (no sf)", 28, lambda i: affine(i, 0, False)),
+    ("affine_bwd fwd-dir (sf, flat-tile kernel)", 28, lambda i: (lib.cnf_set_affine_bwd_tiles(0), affine(i, 0), lib.cnf_set_affine_bwd_tiles(1))),
+    ("affine_bwd inv-dir (sf, flat-tile kernel)", 28, lambda i: (lib.cnf_set_affine_bwd_tiles(0), affine(i, 1), lib.cnf_set_affine_bwd_tiles(1))),
     ("actnorm_bwd", 12, lambda i: actnorm(i, 0)),
     ("actnorm_bwd padded", 12, lambda i: actnorm(i, 0, True)),
     ("actnorm_bwd (flat-tile kernel)", 12, lambda i: (lib.cnf_set_actnorm_bwd_tiles(0), actnorm(i, 0), lib.cnf_set_actnorm_bwd_tiles(1))),
@@ -139,8 +141,9 @@ if args.only:
     rows = [r for r in rows if any(k in r[0] for k in args.only.split(","))]
 if args.pmc:
     import json
-    frag = {"affine_bwd fwd-dir (sf)": "affine_bwd_kernel<4, 2, true, false", "affine_bwd inv-dir (sf)": "affine_bwd_kernel<4, 2, true, true",
-            "affine_bwd fwd-dir (no sf)": "affine_bwd_kernel<4, 2, false, false", "actnorm_bwd": "::actnorm_bwd_tile_kernel<", "actnorm_bwd (flat-tile kernel)": "::actnorm_bwd_kernel<",
+    frag = {"affine_bwd fwd-dir (sf)": "affine_bwd_tile_kernel<6, true, false", "affine_bwd inv-dir (sf)": "affine_bwd_tile_kernel<6, true, true",
+            "affine_bwd fwd-dir (no sf)": "affine_bwd_tile_kernel<6, false, false",
+            "affine_bwd fwd-dir (sf, flat-tile kernel)": "affine_bwd_kernel<4, 2, true, false", "affine_bwd inv-dir (sf, flat-tile kernel)": "affine_bwd_kernel<4, 2, true, true", "actnorm_bwd": "::actnorm_bwd_tile_kernel<", "actnorm_bwd (flat-tile kernel)": "::actnorm_bwd_kernel<",
             "invconv_bwd": "::invconv_bwd_kernel<6>", "actnorm+invconv_bwd fused (from input)": "actconv_bwd_kernel<6, false>",
             "actnorm+invconv_bwd fused (from output)": "actconv_bwd_kernel<6, true>", "ext_actnorm_bwd": "ext_actnorm_bwd_tile_kernel<6", "prior_nll_bwd": "prior_nll_bwd_kernel",
             "logistic_log_prob_bwd": "logistic_log_prob_bwd_kernel", "sigmoid_flow_bwd": "sigmoid_flow_bwd_kernel",
@@ -176,6 +179,7 @@ if hasattr(lib, "cnf_stream_probe_bwd") and not args.only:
 
 if args.sweep:
     print("\nflat-tile knobs (cnf_set_bwd_tile): chunks in flight U x groups per wave G, us (median, start-to-start)")
+    lib.cnf_set_affine_bwd_tiles(0)       # the U knob belongs to the flat-tile kernels
     kernels = (("affine sf", lambda i: affine(i, 0)), ("affine inv sf", lambda i: affine(i, 1)), ("affine no sf", lambda i: affine(i, 0, False)),
                ("actnorm", lambda i: actnorm(i, 0)), ("invconv", lambda i: invconv(i, 0)), ("prior_nll", nll), ("sigmoid", lambda i: sigmoid(i, 0)))
     print("%-6s %s" % ("U G", " ".join("%13s" % k for k, _ in kernels)))
@@ -184,6 +188,7 @@ if args.sweep:
             lib.cnf_set_bwd_tile(u, grp)
             print("%d %-4d %s" % (u, grp, " ".join("%13.2f" % timeit(f, reps=60, blocks=3)[0] for _, f in kernels)), flush=True)
     lib.cnf_set_bwd_tile(0, 0)
+    lib.cnf_set_affine_bwd_tiles(1)
 
 # run-to-run reproducibility of the parameter gradients
 ok = True
