@@ -76,6 +76,84 @@ __global__ __launch_bounds__(256) void stream_mix_bwd_kernel(const float* __rest
     }
 }
 
+// Experiment (round 4): the affine coupling FORWARD in the token-owner wave-tile form of the backward kernels (coalesced spans
+// transposed through LDS, per-channel constants in registers), D = 6, channel mask, scaling factor, hardware transcendentals, rows
+// of 64 tokens (32 lanes per row: the row's log-det is a 32-lane butterfly).  Timing partner of cnf_affine_coupling at S*.
+typedef float pr_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void probe_lds_order() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+template <int NTH>
+__global__ __launch_bounds__(256) void affine_fwd_tile_probe_kernel(const float* z, const float* nn, const float* sf, const float* mask,
+                                                                     const float* ldj_in, float* z_out, float* ldj_out, long ntok, int N) {
+    constexpr int D = 6, TP = 2, NV = 3, NC = 6, kW = 64;
+    __shared__ pr_f4 strip_all[4][3][kW * NV];
+    pr_f4* sz = strip_all[threadIdx.x >> 6][0];
+    pr_f4* sc0 = strip_all[threadIdx.x >> 6][1];
+    pr_f4* sc1 = strip_all[threadIdx.x >> 6][2];
+    const int lane = threadIdx.x & 63;
+    float keep[D], keepf[D], x2[D], x3[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const float m = mask[d], f = expf(sf[d]), fc = fmaxf(f, 1.f);
+        keep[d] = 1.f - m;
+        keepf[d] = (1.f - m) * f;
+        x2[d] = -2.f * keepf[d];
+        x3[d] = 2.8853900817779268f / fc;
+    }
+    const long ntiles = ntok / TP / kW;
+    const long wave_id = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
+    const int lpr = N / TP;      // lanes per row
+    for (long tile = wave_id; tile < ntiles; tile += nwaves) {
+        const pr_f4* srcz = reinterpret_cast<const pr_f4*>(z + tile * (kW * TP * D));
+        const pr_f4* srcc = reinterpret_cast<const pr_f4*>(nn + tile * (kW * TP * 2 * D));
+        pr_f4 qz[NV], qc[NC];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) qz[v] = __builtin_nontemporal_load(srcz + v * kW + lane);
+#pragma unroll
+        for (int v = 0; v < NC; ++v) qc[v] = NTH ? __builtin_nontemporal_load(srcc + v * kW + lane) : srcc[v * kW + lane];
+        const long row = (tile * kW + lane) * TP / N;
+        const float base = ldj_in ? ldj_in[row] : 0.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) sz[v * kW + lane] = qz[v];
+#pragma unroll
+        for (int v = 0; v < NC; ++v) {
+            const int i = v * kW + lane, grp = i / NC, j = i - grp * NC;
+            (j < NV ? sc0 : sc1)[grp * NV + (j < NV ? j : j - NV)] = qc[v];
+        }
+        probe_lds_order();
+        float zi[TP * D], cv[2 * TP * D], out[TP * D];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const pr_f4 r = sz[lane * NV + v];
+            zi[4 * v] = r.x; zi[4 * v + 1] = r.y; zi[4 * v + 2] = r.z; zi[4 * v + 3] = r.w;
+            const pr_f4 c0 = sc0[lane * NV + v];
+            cv[4 * v] = c0.x; cv[4 * v + 1] = c0.y; cv[4 * v + 2] = c0.z; cv[4 * v + 3] = c0.w;
+            const pr_f4 c1 = sc1[lane * NV + v];
+            cv[4 * (NV + v)] = c1.x; cv[4 * (NV + v) + 1] = c1.y; cv[4 * (NV + v) + 2] = c1.z; cv[4 * (NV + v) + 3] = c1.w;
+        }
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < TP; ++k)
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const float sr = cv[k * 2 * D + 2 * d], tr = cv[k * 2 * D + 2 * d + 1];
+                const float s = fmaf(__builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(sr * x3[d]) + 1.f), x2[d], keepf[d]);
+                out[k * D + d] = (zi[k * D + d] + tr * keep[d]) * __builtin_amdgcn_exp2f(s * 1.4426950408889634f);
+                acc += s;
+            }
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const pr_f4 r = {out[4 * v], out[4 * v + 1], out[4 * v + 2], out[4 * v + 3]};
+            sz[lane * NV + v] = r;
+        }
+        for (int m = lpr >> 1; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, kW);
+        if ((lane & (lpr - 1)) == 0) ldj_out[row] = base + acc;
+        probe_lds_order();
+        pr_f4* dz = reinterpret_cast<pr_f4*>(z_out + tile * (kW * TP * D));
+#pragma unroll
+        for (int v = 0; v < NV; ++v) __builtin_nontemporal_store(sz[v * kW + lane], dz + v * kW + lane);
+        probe_lds_order();
+    }
+}
 }  // namespace
 }  // namespace cnf
 
@@ -115,4 +193,18 @@ extern "C" int cnf_stream_probe_bwd(const float* a, const float* b, const float*
 #undef PROBE_BWD_H
 #undef PROBE_BWD
     return launch_status("cnf_stream_probe_bwd");
+}
+
+extern "C" int cnf_probe_affine_fwd_tile(const float* z, const float* nn, const float* sf, const float* mask, const float* ldj_in,
+                                         float* z_out, float* ldj_out, int B, int N, int groups_per_wave, int nt_hint, void* stream) {
+    using namespace cnf;
+    CNF_REQUIRE(z && nn && sf && mask && z_out && ldj_out && B > 0 && (N == 64 || N == 32 || N == 16 || N == 128), "cnf_probe_affine_fwd_tile: D = 6 rows of 16..128 tokens");
+    const long ntok = (long)B * N, tiles = ntok / 128;
+    CNF_REQUIRE(ntok % 128 == 0, "cnf_probe_affine_fwd_tile: whole wave tiles only");
+    const int G = groups_per_wave > 0 ? groups_per_wave : 2;
+    const dim3 grid((unsigned)std::max<long>((tiles + 4L * G - 1) / (4L * G), 1)), block(256);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (nt_hint) CNF_LAUNCH((affine_fwd_tile_probe_kernel<1>), grid, block, 0, st, z, nn, sf, mask, ldj_in, z_out, ldj_out, ntok, N);
+    else CNF_LAUNCH((affine_fwd_tile_probe_kernel<0>), grid, block, 0, st, z, nn, sf, mask, ldj_in, z_out, ldj_out, ntok, N);
+    return launch_status("cnf_probe_affine_fwd_tile");
 }

@@ -102,6 +102,13 @@ int cnf_stream_probe(const float* a, const float* b, float* out, long n, int chu
  * nontemporal loads of (a, b) / of c / nontemporal stores.  No reference counterpart. */
 int cnf_stream_probe_bwd(const float* a, const float* b, const float* c, float* o1, float* o2, long n,
                          int chunks_per_lane, int hint, cnf_stream_t stream);
+/* Experiment kept for the record (tools/affine_fwd_tile_probe.py, profiles/r04_affine_fwd_tile_experiment.txt): the affine
+ * coupling FORWARD (coupling_layer.py:53-63) in the token-owner wave-tile form that won in the backward kernels, D = 6,
+ * channel mask, scaling factor, rows of 16..128 tokens, B*N a multiple of 128.  Same z bits as cnf_affine_coupling; SLOWER
+ * (17.6-18.7 vs 16.7 us at the benchmark shape), so the flat row-tile kernel stays.  No reference counterpart. */
+int cnf_probe_affine_fwd_tile(const float* z, const float* nn_out, const float* scaling_factor, const float* mask, const float* ldj_in,
+                              float* z_out, float* ldj_out, int B, int N, int tiles_per_wave, int nontemporal_nn_loads,
+                              cnf_stream_t stream);
 
 /* ---- affine coupling -------------------------------------------------------------------- */
 
