@@ -1822,7 +1822,7 @@ int64_t cnf_bwd_workspace_floats(int param_count) {
 }
 
 void cnf_set_actnorm_bwd_tiles(int on) { g_act_bwd_tiles.store(on ? 1 : 0, std::memory_order_relaxed); }
-void cnf_set_affine_bwd_tiles(int on) { g_aff_bwd_tiles.store(on ? 1 : 0, std::memory_order_relaxed); }
+void cnf_set_affine_bwd_tiles(int mode) { g_aff_bwd_tiles.store(mode < 0 || mode > 2 ? 1 : mode, std::memory_order_relaxed); }
 
 void cnf_set_bwd_tile(int chunks_in_flight, int groups_per_tile) {
     if (chunks_in_flight >= 0 && chunks_in_flight <= 3) g_bwd_u.store(chunks_in_flight, std::memory_order_relaxed);
@@ -1851,8 +1851,13 @@ int cnf_affine_coupling_bwd(const float* z_out, const float* nn_out, const float
     }
     hipStream_t st = (hipStream_t)stream;
     if (mask_rows == 1 && mask_cols == D && (D == 2 || D == 3 || D == 4 || D == 6 || D == 8) &&
-        aligned_to(16, {z_out, nn_out, g_zout, g_z, g_nn}) && g_aff_bwd_tiles.load(std::memory_order_relaxed)) {
-        // channel mask: token-owner wave tiles, constants and scaling-factor sums in registers
+        aligned_to(16, {z_out, nn_out, g_zout, g_z, g_nn}) &&
+        (g_aff_bwd_tiles.load(std::memory_order_relaxed) == 2 ||
+         (g_aff_bwd_tiles.load(std::memory_order_relaxed) == 1 && (!scaling_factor || !reverse)))) {
+        // channel mask: token-owner wave tiles, constants (and scaling-factor sums) in registers.  Default where it is the faster
+        // kernel at the benchmark shape (profiles/r04_bwd_kernel_stats.csv, rocprofv3): without a scaling factor 29.8 vs 30.8 us,
+        // with one in the forward direction 32.0 vs 32.6 us; in the inverse direction the flat tiles win (31.6 vs 32.0 us: the
+        // kernel needs 152 VGPRs there).  Mode 2 / 0 force either kernel for A/B runs
         const long ntok = (long)B * N;
         AffTileArgs t{z_out, nn_out, scaling_factor, mask, g_zout, g_ldj, g_z, g_nn, workspace, ntok, N, D, make_fastdiv((uint32_t)N),
                       ntok < (1l << 32) / N ? 1 : 0};

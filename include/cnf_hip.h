@@ -76,9 +76,10 @@ void cnf_set_bwd_tile(int chunks_in_flight, int groups_per_tile);
 /* cnf_actnorm_bwd: 1 (default) = the token-owner wave-tile kernel (register sums) for D in {1..6, 8}, 0 = always the flat-tile
  * kernel with lane-private LDS sums (A/B measurements and tests; same results up to the order of the additions). */
 void cnf_set_actnorm_bwd_tiles(int on);
-/* cnf_affine_coupling_bwd: 1 (default) = the token-owner wave-tile kernel for channel masks at D in {2, 3, 4, 6, 8}, 0 = always
- * the flat-tile kernel (A/B measurements and tests; same results up to the order of the additions). */
-void cnf_set_affine_bwd_tiles(int on);
+/* cnf_affine_coupling_bwd, channel masks at D in {2, 3, 4, 6, 8}: 1 (default) = the token-owner wave-tile kernel where it is the
+ * faster one (no scaling factor, or the forward direction), 2 = always, 0 = always the flat-tile kernel (A/B measurements and
+ * tests; same results up to the order of the additions). */
+void cnf_set_affine_bwd_tiles(int mode);
 /* fp32 mixture-coupling backward (cnf_mixture_coupling_bwd_f32): -1 (default) = the build held to 4 waves per SIMD for
  * large launches, the natural register allocation for small ones; 0 / 1 force one of them (A/B).  No reference counterpart. */
 void cnf_set_mixture_bwd_waves(int mode);

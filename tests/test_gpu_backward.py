@@ -529,7 +529,8 @@ def test_actnorm_backward_token_owner_and_flat_tile_kernels_agree(B, N, D, seed)
 @pytest.mark.parametrize("mode", [1, 0])
 def test_affine_backward_token_owner_and_flat_tile_kernels_agree(B, N, D, seed, mode):
     """cnf_affine_coupling_bwd has two kernels for channel masks: token-owner wave tiles (constants and scaling-factor sums in
-    registers; default at D in {2, 3, 4, 6, 8}) and flat tiles (cnf_set_affine_bwd_tiles(0); any mask, any D).  Same gradients to
+    registers; D in {2, 3, 4, 6, 8}, the default without a scaling factor, forced here with mode 2) and flat tiles
+    (cnf_set_affine_bwd_tiles(0); any mask, any D).  Same gradients to
     rounding in both directions, both math modes, with and without the scaling factor; each bit-reproducible."""
     from categoricalnf_amd import functional as Fn
     lib = _lib.load()
@@ -542,7 +543,7 @@ def test_affine_backward_token_owner_and_flat_tile_kernels_agree(B, N, D, seed, 
         for reverse in (False, True):
             for with_sf in (True, False):
                 out = {}
-                for tiles in (1, 0):
+                for tiles in (2, 0):
                     lib.cnf_set_affine_bwd_tiles(tiles)
                     runs = []
                     for _ in range(2):
@@ -553,7 +554,7 @@ def test_affine_backward_token_owner_and_flat_tile_kernels_agree(B, N, D, seed, 
                         runs.append((zl.grad, nl.grad) + ((sl.grad,) if with_sf else ()))
                     assert all(torch.equal(a, b) for a, b in zip(*runs))
                     out[tiles] = runs[0]
-                for name, a, b in zip(("g_z", "g_nn", "g_sf"), out[1], out[0]):
+                for name, a, b in zip(("g_z", "g_nn", "g_sf"), out[2], out[0]):
                     grad_close(a, b, "%s reverse=%s sf=%s" % (name, reverse, with_sf), rel=2e-5)
     finally:
         lib.cnf_set_affine_bwd_tiles(1)

@@ -101,6 +101,12 @@ def aff_transform(i, rev=0):
     call("cnf_affine_transform_bwd", _ptr(zo[i]), _ptr(s_[i]), _ptr(t_[i]), _ptr(gzo[i]), _ptr(gl), _ptr(gz[i]), _ptr(gz2[i]), _ptr(gz3[i]), B, N, D, rev, st())
 
 
+def forced(mode, fn, *a):
+    lib.cnf_set_affine_bwd_tiles(mode)
+    fn(*a)
+    lib.cnf_set_affine_bwd_tiles(1)
+
+
 def timeit(fn, reps=args.reps, blocks=5):
     for i in range(2 * R):
         fn(i % R)
@@ -118,11 +124,12 @@ def timeit(fn, reps=args.reps, blocks=5):
 
 
 rows = [
-    ("affine_bwd fwd-dir (sf)", 28, lambda i: affine(i, 0)),
-    ("affine_bwd inv-dir (sf)", 28, lambda i: affine(i, 1)),
-    ("affine_bwd fwd-dir (no sf)", 28, lambda i: affine(i, 0, False)),
-    ("affine_bwd fwd-dir (sf, flat-tile kernel)", 28, lambda i: (lib.cnf_set_affine_bwd_tiles(0), affine(i, 0), lib.cnf_set_affine_bwd_tiles(1))),
-    ("affine_bwd inv-dir (sf, flat-tile kernel)", 28, lambda i: (lib.cnf_set_affine_bwd_tiles(0), affine(i, 1), lib.cnf_set_affine_bwd_tiles(1))),
+    ("affine_bwd fwd-dir (sf), token-owner kernel (default)", 28, lambda i: forced(2, affine, i, 0)),
+    ("affine_bwd fwd-dir (sf), flat-tile kernel", 28, lambda i: forced(0, affine, i, 0)),
+    ("affine_bwd inv-dir (sf), flat-tile kernel (default)", 28, lambda i: forced(0, affine, i, 1)),
+    ("affine_bwd inv-dir (sf), token-owner kernel", 28, lambda i: forced(2, affine, i, 1)),
+    ("affine_bwd fwd-dir (no sf), token-owner kernel (default)", 28, lambda i: forced(2, affine, i, 0, False)),
+    ("affine_bwd fwd-dir (no sf), flat-tile kernel", 28, lambda i: forced(0, affine, i, 0, False)),
     ("actnorm_bwd", 12, lambda i: actnorm(i, 0)),
     ("actnorm_bwd padded", 12, lambda i: actnorm(i, 0, True)),
     ("actnorm_bwd (flat-tile kernel)", 12, lambda i: (lib.cnf_set_actnorm_bwd_tiles(0), actnorm(i, 0), lib.cnf_set_actnorm_bwd_tiles(1))),
@@ -141,9 +148,10 @@ if args.only:
     rows = [r for r in rows if any(k in r[0] for k in args.only.split(","))]
 if args.pmc:
     import json
-    frag = {"affine_bwd fwd-dir (sf)": "affine_bwd_tile_kernel<6, true, false", "affine_bwd inv-dir (sf)": "affine_bwd_tile_kernel<6, true, true",
-            "affine_bwd fwd-dir (no sf)": "affine_bwd_tile_kernel<6, false, false",
-            "affine_bwd fwd-dir (sf, flat-tile kernel)": "affine_bwd_kernel<4, 2, true, false", "affine_bwd inv-dir (sf, flat-tile kernel)": "affine_bwd_kernel<4, 2, true, true", "actnorm_bwd": "::actnorm_bwd_tile_kernel<", "actnorm_bwd (flat-tile kernel)": "::actnorm_bwd_kernel<",
+    frag = {"affine_bwd fwd-dir (sf), token-owner kernel (default)": "affine_bwd_tile_kernel<6, true, false", "affine_bwd fwd-dir (sf), flat-tile kernel": "affine_bwd_kernel<4, 2, true, false",
+            "affine_bwd inv-dir (sf), flat-tile kernel (default)": "affine_bwd_kernel<4, 2, true, true", "affine_bwd inv-dir (sf), token-owner kernel": "affine_bwd_tile_kernel<6, true, true",
+            "affine_bwd fwd-dir (no sf), token-owner kernel (default)": "affine_bwd_tile_kernel<6, false, false", "affine_bwd fwd-dir (no sf), flat-tile kernel": "affine_bwd_kernel<4, 2, false, false",
+            "actnorm_bwd": "::actnorm_bwd_tile_kernel<", "actnorm_bwd (flat-tile kernel)": "::actnorm_bwd_kernel<",
             "invconv_bwd": "::invconv_bwd_kernel<6>", "actnorm+invconv_bwd fused (from input)": "actconv_bwd_kernel<6, false>",
             "actnorm+invconv_bwd fused (from output)": "actconv_bwd_kernel<6, true>", "ext_actnorm_bwd": "ext_actnorm_bwd_tile_kernel<6", "prior_nll_bwd": "prior_nll_bwd_kernel",
             "logistic_log_prob_bwd": "logistic_log_prob_bwd_kernel", "sigmoid_flow_bwd": "sigmoid_flow_bwd_kernel",
@@ -162,10 +170,10 @@ if args.pmc:
     sys.exit(0)
 print("shape B=%d N=%d D=%d (%.2f M elems); start-to-start over blocks of %d launches incl. the partials reduction launch where there is one"
       % (B, N, D, elems / 1e6, args.reps))
-print("%-40s %6s %9s %9s %10s %8s" % ("kernel", "B/elem", "us (med)", "us (min)", "alg GB/s", "of 8TB/s"))
+print("%-58s %6s %9s %9s %10s %8s" % ("kernel", "B/elem", "us (med)", "us (min)", "alg GB/s", "of 8TB/s"))
 for name, bpe, fn in rows:
     med, mn = timeit(fn)
-    print("%-40s %6d %9.2f %9.2f %10.0f %8.3f" % (name, bpe, med, mn, bpe * elems / med / 1e3, bpe * elems / med / 1e3 / 8000), flush=True)
+    print("%-58s %6d %9.2f %9.2f %10.0f %8.3f" % (name, bpe, med, mn, bpe * elems / med / 1e3, bpe * elems / med / 1e3 / 8000), flush=True)
 
 if hasattr(lib, "cnf_stream_probe_bwd") and not args.only:
     print("\nstream ceiling for the affine backward's mix (16 B read + 12 B written per element, no arithmetic), us / TB/s")

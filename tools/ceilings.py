@@ -26,7 +26,7 @@ for path in glob.glob(os.path.join(d, "stats", "**", "*kernel_stats.csv"), recur
     for row in csv.DictReader(open(path)):
         dur[row["Name"]] = float(row["AverageNs"])
 out = []
-print("%-40s %9s %9s %9s %9s %9s %9s %9s %9s  %s" % ("kernel", "us", "alg GB/s", "hbm_frac", "valu_frac", "quantised", "cyc/inst", "wait %", "HBM MB", "binds"))
+print("%-58s %9s %9s %9s %9s %9s %9s %9s %9s  %s" % ("kernel", "us", "alg GB/s", "hbm_frac", "valu_frac", "quantised", "cyc/inst", "wait %", "HBM MB", "binds"))
 for frag, info in manifest.items():
     names = [k for k in vals if frag in k]
     if not names:
@@ -51,7 +51,7 @@ for frag, info in manifest.items():
            "valu_frac": valu_frac, "sq_active_inst_valu_x4_over_simd_cycles": valu_busy, "cycles_per_valu_inst": cyc_inst, "wave_wait_pct": wait, "hbm_MB_per_launch": mb, "valu_insts": valu, "trans_insts": trans,
            "clock_GHz_if_unprofiled_duration": gui / 8.0 / t_ns if gui else None, "binds": binds}
     out.append(row)
-    print("%-40s %9.1f %9.0f %9.3f %9s %9s %9s %9s %9s  %s" % (info["what"][:40], t_ns / 1e3, info["alg_bytes"] / t_ns, hbm,
+    print("%-58s %9.1f %9.0f %9.3f %9s %9s %9s %9s %9s  %s" % (info["what"][:58], t_ns / 1e3, info["alg_bytes"] / t_ns, hbm,
           "%.3f" % valu_frac if valu_frac is not None else "-", "%.3f" % valu_busy if valu_busy is not None else "-",
           "%.1f" % cyc_inst if cyc_inst is not None else "-", "%.0f" % wait if wait is not None else "-",
           "%.1f" % mb if mb is not None else "-", binds))

@@ -29,6 +29,7 @@ for src, dst in (("sweep_affine.log", "_sweep_affine.txt"), ("sweep_nll.log", "_
                  ("flow_graph.txt", "_flow_graph.txt"), ("encoder_probe.txt", "_encoder_probe.txt"), ("encoder_ab.txt", "_encoder_ab.txt"), ("sustained_probe.txt", "_sustained_probe.txt"), ("train_step.txt", "_train_step.txt"),
                  ("ceilings/ceilings.txt", "_ceilings.txt"), ("ceilings/ceilings.json", "_ceilings.json"),
                  ("ceilings_bwd/ceilings.txt", "_ceilings_backward.txt"), ("ceilings_bwd/ceilings.json", "_ceilings_backward.json"),
+                 ("ceilings_mixbwd/ceilings.txt", "_ceilings_mixture_backward.txt"),
                  ("bwd_probe.txt", "_bwd_probe.txt"), ("bwd_kernel_stats.csv", "_bwd_kernel_stats.csv"),
                  ("encoder_bwd_kernel_stats.csv", "_encoder_bwd_kernel_stats.csv"), ("encoder_bwd_breakdown.txt", "_encoder_bwd_breakdown.txt"),
                  ("autograd_overhead.txt", "_autograd_overhead.txt"),
