@@ -63,6 +63,8 @@ SIGNATURES = {
     "cnf_affine_coupling_bwd": [_p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "cnf_ext_actnorm_bwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "cnf_actnorm_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "cnf_invconv_lu_weight": [_p, _p, _p, _p, _p, _p, _p, _i, _p],
+    "cnf_invconv_lu_weight_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p],
     "cnf_actnorm_invconv_bwd": [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     "cnf_invconv_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "cnf_logistic_log_prob_bwd": [_p, _p, _p, _i64, _f, _f, _p],

@@ -346,6 +346,70 @@ __global__ __launch_bounds__(kBlock) void actnorm_invconv_kernel(ActConvArgs a) 
     }
 }
 
+// ---- the LU-parametrised weight of the 1x1 convolution (permutation_layers.py:61-71) -------------------------------------------
+// W = P (L o tril(-1) + I)(U o triu(1) + diag(sign_s e^log_s)), sldj = sum log_s — D x D parameter preparation that the reference
+// (and rounds 1-3 here) assembles from ~11 tiny torch ops whose autograd adds ~15 more: 26 launches per flow step and training
+// pass, 208 of the 283 launches of an 8-step affine flow's forward + backward at the benchmark shape (4.0 ms of host time for
+// 1.9 ms of kernels, profiles/r04_flow_autograd_overhead.txt).  One workgroup, thread (r, c) owns entry [r][c]; D <= 16.
+constexpr int kLuMax = 16;
+__device__ __forceinline__ void lu_factors(const float* l, const float* u, const float* log_s, const float* sign_s, int D, int r, int c,
+                                           float (*Lo)[kLuMax + 1], float (*Up)[kLuMax + 1]) {
+    if (r < D && c < D) {
+        Lo[r][c] = (c < r ? l[r * D + c] : 0.f) + (r == c ? 1.f : 0.f);
+        Up[r][c] = (c > r ? u[r * D + c] : 0.f) + (r == c ? sign_s[r] * expf(log_s[r]) : 0.f);
+    }
+}
+__global__ __launch_bounds__(kLuMax * kLuMax) void lu_weight_kernel(const float* p, const float* l, const float* u, const float* log_s,
+                                                                    const float* sign_s, float* w_out, float* sldj_out, int D) {
+    __shared__ float Lo[kLuMax][kLuMax + 1], Up[kLuMax][kLuMax + 1], M[kLuMax][kLuMax + 1];
+    const int r = threadIdx.x / kLuMax, c = threadIdx.x % kLuMax;
+    const bool live = r < D && c < D;
+    lu_factors(l, u, log_s, sign_s, D, r, c, Lo, Up);
+    __syncthreads();
+    if (live) {
+        float m = 0.f;
+        for (int k = 0; k < D; ++k) m = fmaf(Lo[r][k], Up[k][c], m);
+        M[r][c] = m;
+    }
+    __syncthreads();
+    if (live) {
+        float w = 0.f;
+        for (int k = 0; k < D; ++k) w = fmaf(p[r * D + k], M[k][c], w);
+        w_out[r * D + c] = w;
+    }
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int i = 0; i < D; ++i) t += log_s[i];
+        sldj_out[0] = t;
+    }
+}
+// g_l = (P^T g_W U^T) o tril(-1), g_u = (L^T P^T g_W) o triu(1), g_log_s[i] = (L^T P^T g_W)[i][i] sign_s[i] e^log_s[i] + g_sldj
+__global__ __launch_bounds__(kLuMax * kLuMax) void lu_weight_bwd_kernel(const float* p, const float* l, const float* u, const float* log_s,
+                                                                        const float* sign_s, const float* g_w, const float* g_sldj,
+                                                                        float* g_l, float* g_u, float* g_log_s, int D) {
+    __shared__ float Lo[kLuMax][kLuMax + 1], Up[kLuMax][kLuMax + 1], G[kLuMax][kLuMax + 1];
+    const int r = threadIdx.x / kLuMax, c = threadIdx.x % kLuMax;
+    const bool live = r < D && c < D;
+    lu_factors(l, u, log_s, sign_s, D, r, c, Lo, Up);
+    if (live) {
+        float g = 0.f;                                    // (P^T g_W)[r][c]
+        if (g_w)
+            for (int k = 0; k < D; ++k) g = fmaf(p[k * D + r], g_w[k * D + c], g);
+        G[r][c] = g;
+    }
+    __syncthreads();
+    if (live) {
+        float gl = 0.f, gu = 0.f;
+        for (int k = 0; k < D; ++k) {
+            gl = fmaf(G[r][k], Up[c][k], gl);             // (G U^T)[r][c]
+            gu = fmaf(Lo[k][r], G[k][c], gu);             // (L^T G)[r][c]
+        }
+        g_l[r * D + c] = c < r ? gl : 0.f;
+        g_u[r * D + c] = c > r ? gu : 0.f;
+        if (r == c) g_log_s[r] = gu * (sign_s[r] * expf(log_s[r])) + (g_sldj ? g_sldj[0] : 0.f);
+    }
+}
+
 // any D: one lane per output element
 __global__ __launch_bounds__(kBlock) void invconv_generic_kernel(ConvArgs a) {
     const int D = a.D;
@@ -432,6 +496,32 @@ int cnf_invconv(const float* x, const float* weight, const float* sldj,
             CNF_LAUNCH(invconv_generic_kernel, dim3(stream_grid(a.ntok * D)), block, 0, st, a);
     }
     return launch_status("cnf_invconv");
+}
+
+int cnf_invconv_lu_weight(const float* p, const float* l, const float* u, const float* log_s, const float* sign_s,
+                          float* weight_out, float* sldj_out, int D, cnf_stream_t stream) {
+    CNF_REQUIRE(p && l && u && log_s && sign_s && weight_out && sldj_out, "cnf_invconv_lu_weight: null tensor");
+    CNF_REQUIRE(D > 0, "cnf_invconv_lu_weight: bad shape");
+    if (D > kLuMax) {
+        set_error("cnf_invconv_lu_weight: built for D <= %d (got %d)", kLuMax, D);
+        return CNF_ERR_UNSUPPORTED;
+    }
+    CNF_LAUNCH(lu_weight_kernel, dim3(1), dim3(kLuMax * kLuMax), 0, (hipStream_t)stream, p, l, u, log_s, sign_s, weight_out, sldj_out, D);
+    return launch_status("cnf_invconv_lu_weight");
+}
+
+int cnf_invconv_lu_weight_bwd(const float* p, const float* l, const float* u, const float* log_s, const float* sign_s,
+                              const float* g_weight, const float* g_sldj, float* g_l, float* g_u, float* g_log_s, int D,
+                              cnf_stream_t stream) {
+    CNF_REQUIRE(p && l && u && log_s && sign_s && g_l && g_u && g_log_s, "cnf_invconv_lu_weight_bwd: null tensor");
+    CNF_REQUIRE(D > 0, "cnf_invconv_lu_weight_bwd: bad shape");
+    if (D > kLuMax) {
+        set_error("cnf_invconv_lu_weight_bwd: built for D <= %d (got %d)", kLuMax, D);
+        return CNF_ERR_UNSUPPORTED;
+    }
+    CNF_LAUNCH(lu_weight_bwd_kernel, dim3(1), dim3(kLuMax * kLuMax), 0, (hipStream_t)stream, p, l, u, log_s, sign_s, g_weight, g_sldj,
+               g_l, g_u, g_log_s, D);
+    return launch_status("cnf_invconv_lu_weight_bwd");
 }
 
 int cnf_actnorm_invconv(const float* z, const float* bias, const float* scales, const float* weight,

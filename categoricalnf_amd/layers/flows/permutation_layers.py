@@ -2,8 +2,10 @@
 
 Interface of layers/flows/permutation_layers.py: LU-parametrised (buffers p, sign_s, l_mask, eye;
 parameters l, log_s, u) or dense (`weight`), eval-mode cache of (W, W^-1, sldj) per device string
-(:56-103).  Building W from (P, L, U) is D x D host-side parameter preparation and stays in torch;
-the [B,N,D] x [D,D] product, the padding mask and the log-det update are the kernel."""
+(:56-103).  The [B,N,D] x [D,D] product, the padding mask and the log-det update are the kernel; building W
+from (P, L, U) is D x D parameter preparation — one launch of its own on the device (cnf_invconv_lu_weight: the
+reference's chain of ~11 tiny ops and their autograd were 26 launches per flow step of a training pass), the
+reference's tensor expression for CPU tensors and D > 16."""
 from collections import defaultdict
 
 import numpy as np
@@ -50,6 +52,9 @@ class InvertibleConv(FlowLayer):
     def _build_weight(self):
         if not self.LU_decomposed:
             return self.weight, torch.slogdet(self.weight)[1]
+        if self.l.is_cuda and self.num_channels <= ops.LU_WEIGHT_MAX_D and ops.FUSE_LU_WEIGHT:
+            # the same matrix and log-det in one launch (and one for the backward): cnf_invconv_lu_weight
+            return Fn.LUWeightFn.apply(self.l, self.u, self.log_s, self.p, self.sign_s)
         lower = self.l * self.l_mask + self.eye
         upper = self.u * self.l_mask.transpose(0, 1).contiguous() + torch.diag(self.sign_s * torch.exp(self.log_s))
         return torch.matmul(self.p, torch.matmul(lower, upper)), self.log_s.sum()

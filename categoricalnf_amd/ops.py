@@ -18,6 +18,8 @@ LOGISTIC_LOG_SIGMA = float(np.log(LOGISTIC_SIGMA))
 _STRICT = os.environ.get("CNF_STRICT_ASSERTS", "0") == "1"
 CAPTURING = False            # set by graphs.GraphedFlow while a pass is recorded into a HIP graph (no host syncs)
 FUSE_LAYERS = os.environ.get("CNF_FUSE_LAYERS", "1") == "1"      # FlowModel: ActNorm + InvertibleConv in one kernel
+FUSE_LU_WEIGHT = os.environ.get("CNF_FUSE_LU_WEIGHT", "1") == "1"  # InvertibleConv: W = P L U and its log-det in one launch (cnf_invconv_lu_weight)
+LU_WEIGHT_MAX_D = 16
 FUSE_TRAINING = os.environ.get("CNF_FUSE_TRAINING", "1") == "1"  # the same groups with autograd on (one Function and one backward per group)
 _flags = {}
 

@@ -166,6 +166,17 @@ int cnf_invconv(const float* x, const float* weight, const float* sldj,
                 const float* ldj_in, float* z_out, float* ldj_out,
                 int B, int N, int D, int reverse, int* flags, cnf_stream_t stream);
 
+/* The LU-parametrised weight of InvertibleConv (permutation_layers.py:61-71, `_get_weight` in training mode):
+ * weight_out [D,D] = P (L o tril(-1) + I)(U o triu(1) + diag(sign_s e^log_s)), sldj_out [1] = sum log_s — one launch
+ * instead of ~11 tiny eager ops (and ~15 more in their autograd); cnf_invconv_lu_weight_bwd gives g_l, g_u [D,D] (zero
+ * outside the strict triangles) and g_log_s [D] from g_weight [D,D] and g_sldj [1] (either may be NULL = zero).  D <= 16,
+ * else CNF_ERR_UNSUPPORTED (the caller assembles the weight from tensor ops as the reference does). */
+int cnf_invconv_lu_weight(const float* p, const float* l, const float* u, const float* log_s, const float* sign_s,
+                          float* weight_out, float* sldj_out, int D, cnf_stream_t stream);
+int cnf_invconv_lu_weight_bwd(const float* p, const float* l, const float* u, const float* log_s, const float* sign_s,
+                              const float* g_weight, const float* g_sldj, float* g_l, float* g_u, float* g_log_s, int D,
+                              cnf_stream_t stream);
+
 /* ActNormFlow followed by InvertibleConv in ONE pass (the first two layers of every flow step in
  * experiments/set_modeling/flow_model.py:55-57, graph_node_flow.py, graphCNF.py): same arithmetic, same order,
  * identical results to cnf_actnorm + cnf_invconv, without the intermediate [B,N,D] round trip.  reverse = 1 runs

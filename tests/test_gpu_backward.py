@@ -559,3 +559,53 @@ def test_affine_backward_token_owner_and_flat_tile_kernels_agree(B, N, D, seed, 
     finally:
         lib.cnf_set_affine_bwd_tiles(1)
         lib.cnf_set_math_mode(1)
+
+
+@pytest.mark.parametrize("D", [1, 2, 3, 4, 6, 8, 13, 16])
+def test_lu_weight_kernel_matches_the_tensor_expression(D):
+    """cnf_invconv_lu_weight / _bwd (InvertibleConv's W = P L U and sum log_s in one launch each way) against the reference's
+    chain of tensor ops (permutation_layers.py:61-71) and its autograd: values to 1e-6, gradients of l, u, log_s to 1e-5 of scale;
+    entries outside the strict triangles get exactly zero gradient."""
+    from categoricalnf_amd import ops
+    from categoricalnf_amd.layers.flows.permutation_layers import InvertibleConv
+    torch.manual_seed(D)
+    np.random.seed(D)
+    layer = InvertibleConv(D).cuda().train()
+    with torch.no_grad():                         # move away from the initialisation (l, u exactly triangular, an orthogonal W)
+        for prm in (layer.l, layer.u, layer.log_s):
+            prm.add_(0.1 * torch.randn_like(prm))
+    gw, gs = torch.randn(D, D, device="cuda"), torch.randn((), device="cuda")
+    res = {}
+    for fused in (True, False):
+        ops.FUSE_LU_WEIGHT = fused
+        try:
+            for prm in layer.parameters():
+                prm.grad = None
+            w, sldj = layer._build_weight()
+            torch.autograd.backward([w, sldj], [gw, gs])
+            res[fused] = (w.detach().clone(), sldj.detach().clone(), layer.l.grad.clone(), layer.u.grad.clone(), layer.log_s.grad.clone())
+        finally:
+            ops.FUSE_LU_WEIGHT = True
+    a, b = res[True], res[False]
+    assert tuple(a[0].shape) == (D, D) and a[1].dim() == 0
+    for name, x, y in zip(("weight", "sldj", "g_l", "g_u", "g_log_s"), a, b):
+        grad_close(x, y, name, rel=1e-5)
+    strict_lower = torch.tril(torch.ones(D, D, device="cuda"), -1).bool()
+    assert float(a[2][~strict_lower].abs().sum()) == 0.0 and float(a[3][~strict_lower.t()].abs().sum()) == 0.0
+    if D > 12:              # the layer's backward kernel is built for D <= 12 (cnf_invconv_bwd)
+        return
+    # and through the layer: same outputs and parameter gradients of a training call
+    x = torch.randn(7, 5, D, device="cuda")
+    outs = {}
+    for fused in (True, False):
+        ops.FUSE_LU_WEIGHT = fused
+        try:
+            for prm in layer.parameters():
+                prm.grad = None
+            z, ldj = layer(x, ldj=torch.zeros(7, device="cuda"))
+            (z.sum() + ldj.sum()).backward()
+            outs[fused] = (z.detach(), ldj.detach(), layer.l.grad.clone(), layer.u.grad.clone(), layer.log_s.grad.clone())
+        finally:
+            ops.FUSE_LU_WEIGHT = True
+    for name, x1, y1 in zip(("z", "ldj", "g_l", "g_u", "g_log_s"), outs[True], outs[False]):
+        grad_close(x1, y1, "layer " + name, rel=2e-5)
