@@ -144,6 +144,9 @@ def evaluate(model, prior, dataset, device, batch_size, max_graphs=None, rank=0,
 
 def main(argv=None):
     args = parse(argv)
+    # one process per GPU: backward() runs on the calling thread instead of being handed to the autograd engine's device
+    # thread and waited for (two thread wake-ups per call; tools/autograd_overhead.py --single_thread)
+    torch.autograd.set_multithreading_enabled(False)
     rank, local_rank, world = init_process_group("gloo" if args.share_device else args.backend)
     device = torch.device("cuda", local_rank if (world > 1 and not args.share_device) else 0)
     torch.cuda.set_device(device)

@@ -192,6 +192,9 @@ MODEL_ARGS = ("dataset", "set_size", "encoding_dim", "coupling_hidden_size", "co
 
 def main(argv=None):
     args = parse(argv)
+    # one process per GPU: backward() runs on the calling thread instead of being handed to the autograd engine's device
+    # thread and waited for (two thread wake-ups per call; tools/autograd_overhead.py --single_thread)
+    torch.autograd.set_multithreading_enabled(False)
     if args.only_eval and args.checkpoint_path and os.path.isfile(
             os.path.join(args.checkpoint_path if os.path.isdir(args.checkpoint_path) else os.path.dirname(args.checkpoint_path),
                          PARAM_CONFIG_FILE)):

@@ -6,7 +6,10 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from categoricalnf_amd import _lib, functional as Fn, ops as ops_
 ap = argparse.ArgumentParser(); ap.add_argument("--profile", action="store_true"); ap.add_argument("--B", type=int, default=16384)
+ap.add_argument("--single_thread", action="store_true", help="torch.autograd.set_multithreading_enabled(False): backward() runs on the calling thread")
 args = ap.parse_args()
+if args.single_thread:
+    torch.autograd.set_multithreading_enabled(False)
 dev = torch.device("cuda:0"); lib = _lib.load()
 B, N, D, R = args.B, 64, 6, 4
 g = torch.Generator(device=dev).manual_seed(0)

@@ -67,6 +67,17 @@ def aff_bwd(i):
 
 
 rows.append(("affine fwd+bwd (autograd)", (16 + 28) * elems, aff_bwd))
+
+
+def aff_bwd_single_thread(i):             # what the drivers set: backward() on the calling thread (one process per GPU)
+    torch.autograd.set_multithreading_enabled(False)
+    try:
+        aff_bwd(i)
+    finally:
+        torch.autograd.set_multithreading_enabled(True)
+
+
+rows.append(("  ... single-threaded engine", (16 + 28) * elems, aff_bwd_single_thread))
 print("shape B=%d N=%d D=%d (%.2f M elems); includes Python op overhead (~30 us host, hidden when GPU-bound)" % (B, N, D, elems / 1e6))
 print("%-28s %10s %12s %8s" % ("kernel", "us", "alg GB/s", "of 8TB/s"))
 for name, nbytes, fn in rows:

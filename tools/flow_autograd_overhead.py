@@ -13,8 +13,11 @@ from categoricalnf_amd.layers.flows.coupling_layer import CouplingLayer
 from categoricalnf_amd.layers.flows.flow_model import FlowModel
 from categoricalnf_amd.layers.flows.permutation_layers import InvertibleConv
 ap = argparse.ArgumentParser()
+ap.add_argument("--single_thread", action="store_true", help="torch.autograd.set_multithreading_enabled(False), as the drivers set it")
 ap.add_argument("--steps", type=int, default=8); ap.add_argument("--passes", type=int, default=60); ap.add_argument("--B", type=int, default=16384)
 args = ap.parse_args()
+if args.single_thread:
+    torch.autograd.set_multithreading_enabled(False)
 dev = torch.device("cuda:0")
 B, N, D = args.B, 64, 6
 g = torch.Generator(device=dev).manual_seed(0)
@@ -61,5 +64,5 @@ torch.cuda.synchronize()
 t2 = time.perf_counter()
 print("flow of %d x [ActNorm, 1x1 conv, affine coupling] at B=%d N=%d D=%d, %s: %.1f us wall per forward + NLL + backward pass "
       "(host enqueue %.1f us), %d timed passes (+ 6 warm-up passes)"
-      % (args.steps, B, N, D, "fused training groups" if ops.FUSE_TRAINING else "one Function per layer", (t2 - t0) / args.passes * 1e6,
+      % (args.steps, B, N, D, ("fused training groups" if ops.FUSE_TRAINING else "one Function per layer") + (", single-threaded autograd engine" if args.single_thread else ""), (t2 - t0) / args.passes * 1e6,
          (t1 - t0) / args.passes * 1e6, args.passes), flush=True)
