@@ -98,20 +98,22 @@ class LinearCategoricalEncoding(FlowLayer):
             if table is not None and self._kernel_path(Fn.needs_grad(table)):
                 u = self._uniform_draw(batch_size * seq_length, z.device, noise)
                 squeeze = float(self.prior_distribution.eps)
+                # FlowModel passes get_ldj_per_layer on: the monitoring scalars (five global reductions over the posterior of every
+                # token) are only computed for a pass whose per-layer report is asked for — a bare call of the layer reports them as
+                # the reference does
+                want_stats = self.training and kwargs.get("get_ldj_per_layer", True)
                 if isinstance(beta, torch.Tensor):
                     # beta in a device scalar (a captured training step: the schedule is written into it between replays)
                     z_out, ldj_loc, cpl = Fn.EncoderForwardDevBetaFn.apply(table, z, u, self.category_prior, channel_padding_mask,
                                                                            beta, squeeze)
                 elif Fn.needs_grad(table):
                     z_out, ldj_loc, cpl = Fn.EncoderForwardFn.apply(table, z, u, self.category_prior, channel_padding_mask,
-                                                                    float(beta), self.training, None, squeeze)
+                                                                    float(beta), want_stats, None, squeeze)
                 else:
                     z_out, ldj_loc, cpl = ops.encoder_forward(z, u, table, self.category_prior, beta=float(beta),
                                                               channel_padding_mask=channel_padding_mask,
-                                                              want_class_prob=self.training, uniform_squeeze=squeeze)
-                # FlowModel passes get_ldj_per_layer on: the monitoring scalars (five global reductions) are only computed for a
-                # pass whose per-layer report is asked for — a bare call of the layer reports them as the reference does
-                if self.training and kwargs.get("get_ldj_per_layer", True):
+                                                              want_class_prob=want_stats, uniform_squeeze=squeeze)
+                if want_stats:
                     detailed_ldj = self._train_stats(z_out, cpl, channel_padding_mask)
             else:
                 z_out, ldj_loc, detailed_ldj = self._forward_composed(z, beta, channel_padding_mask, noise)

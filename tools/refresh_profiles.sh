@@ -49,7 +49,7 @@ bash tools/pmc_ceilings.sh ceilings_bwd python tools/bwd_probe.py --pmc > "$OUT/
 bash tools/pmc_ceilings.sh ceilings_mixbwd python tools/pmc_mixture_bwd_workload.py > "$OUT/ceilings_mixbwd.log" 2>&1; tail -4 "$OUT/ceilings_mixbwd.log"
 rm -rf "$OUT/prof_bwd"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_bwd" -o bwd -- python tools/bwd_probe.py --reps 30 > /dev/null 2>&1
-python tools/summarize_kernel_stats.py "$OUT/prof_bwd/bwd_kernel_stats.csv" "$OUT/bwd_kernel_stats.csv" "tools/bwd_probe.py --reps 30 (every streaming backward kernel at B=16384, N=64, D=6 on four rotating buffer sets; kernel durations by themselves: the start-to-start table of r04_bwd_probe.txt includes the reduction launch behind a kernel)" 30 | head -3
+python tools/summarize_kernel_stats.py "$OUT/prof_bwd/bwd_kernel_stats.csv" "$OUT/bwd_kernel_stats.csv" "tools/bwd_probe.py --reps 30 (every streaming backward kernel at B=16384, N=64, D=6 on four rotating buffer sets; kernel durations by themselves: the start-to-start table of r04_bwd_probe.txt includes the reduction launch behind a kernel)" 40 | head -3
 rm -f "$OUT"/prof_bwd/*kernel_trace.csv
 # the encoder backward per kernel (token-lane, class-lane and split-sum launches) at the benchmark token count, C = 16 and 51
 rm -rf "$OUT/prof_encbwd"
