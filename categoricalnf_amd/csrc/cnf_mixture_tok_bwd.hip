@@ -582,15 +582,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
 using namespace cnf;
 
 extern "C" void cnf_set_mixture_bwd_waves(int mode) {
-    if (mode >= -1 && mode <= 1) cnf::g_tok_bwd_w4.store(mode, std::memory_order_relaxed);
+    if (mode >= -1 && mode <= 7) cnf::g_tok_bwd_w4.store(mode, std::memory_order_relaxed);
 }
 
 namespace cnf {
 
 // false = shape outside what the token-pass backward is built for (the caller runs the fp64 kernel)
-bool launch_mixture_tok_bwd(MixArgs& a, const float* g_zout, const float* g_ldj, float* g_z, float* g_nn,
-                            float* g_sf, float* g_msf, float* workspace, hipStream_t st, int force_g) {
-    const int kt = (a.K == 4 || a.K == 8 || a.K == 16) ? a.K : 0;
+static bool launch_mixture_tok_bwd_with(MixArgs& a, const float* g_zout, const float* g_ldj, float* g_z, float* g_nn,
+                                        float* g_sf, float* g_msf, float* workspace, hipStream_t st, int kt, int force_g) {
     TokGeom gm;
     int G = 1;
     size_t lds_fwd = 0;
@@ -625,11 +624,10 @@ bool launch_mixture_tok_bwd(MixArgs& a, const float* g_zout, const float* g_ldj,
     w.wave_flags = reinterpret_cast<int*>(workspace + (size_t)2 * kTokBwdGrid * PP);
     w.block_flags = w.wave_flags + kWavesPerBlock * kTokBwdGrid;
     const dim3 g(grid), b(kBlock);
-    // The build held to 4 waves per SIMD (K = 8: 160 -> 128 VGPRs, 34 of them spilled) pays where few long rows are
-    // split over workgroups (Zinc edges 99.5 -> 80 us); with many short rows the spills cost more than the fourth wave
-    // returns (configs[1] 62 -> 77 us, S* 386 -> 399).  tok_bwd_w4(): -1 = this rule, 0 / 1 force (A/B)
+    // (modes 1 and 5-7: the builds held to 4 waves per SIMD — K = 8 unrolled: 160 -> 128 VGPRs, 34 of them spilled; no difference for
+    // the rolled kernels, which fit anyway)
     const int w4_knob = tok_bwd_w4();
-    const bool w4 = w4_knob >= 0 ? w4_knob != 0 : (gm.split && kt == 8);
+    const bool w4 = w4_knob == 1 || w4_knob >= 5;
 #define TOK_BWD(KT_, G_)                                                                        \
     do {                                                                                        \
         if (w4) CNF_LAUNCH((mixture_tok_bwd_kernel_w4<KT_, G_>), g, b, lds, st, a, gm, w);      \
@@ -647,5 +645,34 @@ bool launch_mixture_tok_bwd(MixArgs& a, const float* g_zout, const float* g_ldj,
     CNF_LAUNCH(mix_reduce_partials_fix_kernel, dim3(PP), dim3(kBlock), 0, st, workspace, w.fix_partials, w.block_flags, grid, PP,
                a.sf ? g_sf : nullptr, a.msf ? g_msf : nullptr, a.D);
     return true;
+}
+// false = shape outside what the token-pass backward is built for (the caller runs the fp64 kernel)
+bool launch_mixture_tok_bwd(MixArgs& a, const float* g_zout, const float* g_ldj, float* g_z, float* g_nn,
+                            float* g_sf, float* g_msf, float* workspace, hipStream_t st, int force_g) {
+    // Which kernel (cnf_set_mixture_bwd_waves; profiles/r04_sweep_mixture_bwd.txt): since the fp64 tail arithmetic left the streaming
+    // kernel (round 4) the ROLLED run-time-K kernel — ~100 VGPRs, 5 waves per SIMD, lane-private LDS sums — beats the unrolled
+    // register-slot kernels (K = 8: 160 VGPRs) at every measured shape: S* 357 -> 331-340 us, configs[1] 59.4 -> 55, Zinc edges
+    // 79 -> 54, Zinc nodes 35 -> 26, graph colouring (K = 16) 32 -> 23, a 1024-set training batch 23 -> 17-18.  Lanes per item G
+    // by the amount of work: one lane per item from ~2 M transformed elements on, two from ~400 k, four below (more waves for
+    // small launches); K > 32 needs four for its stage to fit.  Modes 0 / 1 keep the unrolled kernels (natural registers / held
+    // to 4 waves per SIMD) for A/B runs, 2-4 force G = 1 / 2 / 4.
+    int kt = 0;
+    const int knob0 = tok_bwd_w4();
+    if (knob0 == 0 || knob0 == 1) {
+        kt = (a.K == 4 || a.K == 8 || a.K == 16) ? a.K : 0;
+    } else if (knob0 >= 2) {
+        force_g = 1 << ((knob0 - 2) % 3);
+    } else if (force_g <= 0) {
+        const int da = a.per_item_mask ? a.D : __builtin_popcountll(a.act_bits);
+        const long items = (long)a.B * a.N * std::max(da, 1);
+        int g = items >= 2000000L ? 1 : (items >= 400000L ? 2 : 4);
+        if (a.K > 32) g = 4;
+        while (g > 1 && g > a.K) g >>= 1;
+        // the rule's G, or the next one whose stage fits LDS
+        for (; g <= 4; g <<= 1)
+            if (launch_mixture_tok_bwd_with(a, g_zout, g_ldj, g_z, g_nn, g_sf, g_msf, workspace, st, 0, g)) return true;
+        return false;
+    }
+    return launch_mixture_tok_bwd_with(a, g_zout, g_ldj, g_z, g_nn, g_sf, g_msf, workspace, st, kt, force_g);
 }
 }  // namespace cnf

@@ -80,8 +80,10 @@ void cnf_set_actnorm_bwd_tiles(int on);
  * faster one (no scaling factor, or the forward direction), 2 = always, 0 = always the flat-tile kernel (A/B measurements and
  * tests; same results up to the order of the additions). */
 void cnf_set_affine_bwd_tiles(int mode);
-/* fp32 mixture-coupling backward (cnf_mixture_coupling_bwd_f32): -1 (default) = the build held to 4 waves per SIMD for
- * large launches, the natural register allocation for small ones; 0 / 1 force one of them (A/B).  No reference counterpart. */
+/* fp32 mixture-coupling backward (cnf_mixture_coupling_bwd_f32), which streaming kernel: -1 (default) = the rolled run-time-K
+ * kernel with 1 / 2 / 4 lanes per item by the amount of work; 2 / 3 / 4 force that kernel with 1 / 2 / 4 lanes (5-7: its build
+ * held to 4 waves per SIMD); 0 / 1 = the unrolled register-slot kernels of K = 4 / 8 / 16 (natural registers / held to 4 waves
+ * per SIMD), the defaults until round 4.  A/B knob; same gradients up to the order of the additions.  No reference counterpart. */
 void cnf_set_mixture_bwd_waves(int mode);
 
 /* Kernel timing bound to the dispatch (bench.py's `roofline`; a timed launch costs ~4 us of queue time; the reference has no counterpart — its

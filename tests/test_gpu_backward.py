@@ -669,3 +669,37 @@ def test_graph_colouring_flow_training_pass_with_and_without_the_fused_groups(tm
     for p, a, b in zip(plist, gt, ga):
         if a is not None:
             grad_close(a, b, "device-scalar beta, parameter of shape %s" % (tuple(p.shape),), rel=2e-4)
+
+
+@pytest.mark.parametrize("B,N,D,K", [(64, 16, 4, 8), (33, 17, 6, 4), (20, 38, 6, 16), (8, 30, 3, 51), (256, 16, 4, 8), (16, 64, 2, 5)])
+def test_mixture_backward_kernel_variants_agree(B, N, D, K):
+    """cnf_mixture_coupling_bwd_f32 has several streaming kernels (cnf_set_mixture_bwd_waves): the rolled run-time-K kernel with
+    1 / 2 / 4 lanes per item (the default picks among them by the amount of work) and the unrolled register-slot kernels of
+    K = 4 / 8 / 16 (modes 0 / 1).  Every one gives the default's gradients to the rounding of the summation order; the default twice the same bits."""
+    from categoricalnf_amd import functional as Fn
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(B + K)
+    z = g(torch.randn(B, N, D, generator=gen))
+    nn_out = g(0.5 * torch.randn(B, N, D * (2 + 3 * K), generator=gen))
+    sf, msf = g(0.2 * torch.randn(D, generator=gen)), g(0.2 * torch.randn(D, K, generator=gen))
+    mask = g(_mask("channel", D))
+    ln = torch.randint(1, N + 1, (B,), generator=gen); ln[0] = N
+    pad = g(O.length_mask(ln, N))
+    gz, gl = g(torch.randn(B, N, D, generator=gen)), g(torch.randn(B, generator=gen))
+
+    def run():
+        leaves = [t.clone().requires_grad_(True) for t in (z, nn_out, sf, msf)]
+        zo, lo, _ = Fn.MixtureCouplingFn.apply(leaves[0], leaves[1], leaves[2], leaves[3], None, mask, pad, K, -1.0, 1.0, True, True, True)
+        torch.autograd.backward([zo, lo], [gz, gl])
+        return [t.grad for t in leaves]
+    ref, again = run(), run()
+    assert all(torch.equal(x, y) for x, y in zip(ref, again))
+    try:
+        for mode in (0, 1, 2, 3, 4, 6):
+            # (a forced variant whose stage does not fit LDS falls through to the fp64 kernel, whose sums are atomics: values only)
+            lib.cnf_set_mixture_bwd_waves(mode)
+            a = run()
+            for name, x, y in zip(("g_z", "g_nn", "g_sf", "g_msf"), a, ref):
+                grad_close(x, y, "%s mode %d" % (name, mode), rel=2e-5)
+    finally:
+        lib.cnf_set_mixture_bwd_waves(-1)

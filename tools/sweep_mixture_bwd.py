@@ -1,6 +1,6 @@
 """Timing of the mixture-coupling backward: fp32 token-pass kernel (cnf_mixture_coupling_bwd_f32) vs the fp64 kernel
 (cnf_mixture_coupling_bwd, which also needs a memset of g_nn), config-shaped workloads.  GPU only."""
-import ctypes, os, sys
+import ctypes, os, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from categoricalnf_amd import _lib, ops
@@ -56,10 +56,21 @@ for name, B, N, D, K, masked in shapes:
     for mode in (0, 1):             # natural register allocation / held to 4 waves per SIMD
         lib.cnf_set_mixture_bwd_waves(mode)
         per_mode.append(timeit(f32))
+    if True:
+        # A/B: the rolled run-time-K kernel with 1 / 2 / 4 lanes per item, natural and 4-wave builds (the default is the rolled kernel
+        # with G by the amount of work; modes 0 / 1 are the unrolled register-slot kernels)
+        extra = []
+        for mode in range(2, 8):
+            lib.cnf_set_mixture_bwd_waves(mode)
+            try:
+                extra.append("%.1f" % timeit(f32)[0])
+            except Exception as e:
+                extra.append("n/a")
+        print("   rolled kernel, lanes per item 1 / 2 / 4: natural %s / %s / %s us, 4 waves per SIMD %s / %s / %s us" % tuple(extra), flush=True)
     lib.cnf_set_mixture_bwd_waves(-1)
     (t32, k32), (t64, k64) = timeit(f32), timeit(f64, reps=3)
     e = B * N * D
     byts = e * (16 + 24 * K) + 8 * e          # read z, g_zout, nn_out; write g_z, g_nn (all blocks)
     print("%-26s B=%5d N=%3d D=%d K=%2d | fp32 token-pass %8.1f us per call, kernels %7.1f us (%.0f GB/s incl. the g_nn zeros) | fp64 kernel %8.1f us per call "
-          "(with its memset), kernels %7.1f us | %.1fx per call, %.1fx kernels | natural regs %.1f / %.1f us, 4 waves per SIMD %.1f / %.1f us"
+          "(with its memset), kernels %7.1f us | %.1fx per call, %.1fx kernels | unrolled kernels: natural regs %.1f / %.1f us, 4 waves per SIMD %.1f / %.1f us"
           % (name, B, N, D, K, t32, k32, byts / k32 / 1e3, t64, k64, t64 / t32, k64 / k32, per_mode[0][0], per_mode[0][1], per_mode[1][0], per_mode[1][1]), flush=True)
