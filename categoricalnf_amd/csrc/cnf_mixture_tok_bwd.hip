@@ -665,6 +665,11 @@ bool launch_mixture_tok_bwd(MixArgs& a, const float* g_zout, const float* g_ldj,
     } else if (force_g <= 0) {
         const int da = a.per_item_mask ? a.D : __builtin_popcountll(a.act_bits);
         const long items = (long)a.B * a.N * std::max(da, 1);
+        // (the one shape family where the unrolled kernel still wins: K = 16 at ~10^6 tokens — 578 us against 638 / 838 with four / two
+        // lanes per item, whose stages leave LDS room for fewer workgroups: tools/mixture_bwd_variants.py)
+        if (a.K == 16 && items >= 2000000L &&
+            launch_mixture_tok_bwd_with(a, g_zout, g_ldj, g_z, g_nn, g_sf, g_msf, workspace, st, 16, 0))
+            return true;
         int g = items >= 2000000L ? 1 : (items >= 400000L ? 2 : 4);
         if (a.K > 32) g = 4;
         while (g > 1 && g > a.K) g >>= 1;
