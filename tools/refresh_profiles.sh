@@ -56,7 +56,7 @@ rm -rf "$OUT/prof_encbwd"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_encbwd" -o encbwd -- python tools/encoder_bwd_breakdown.py 16384,64,16 16384,64,51 > "$OUT/encoder_bwd_breakdown.txt" 2>&1
 python tools/summarize_kernel_stats.py "$OUT/prof_encbwd/encbwd_kernel_stats.csv" "$OUT/encoder_bwd_kernel_stats.csv" "tools/encoder_bwd_breakdown.py 16384,64,16 16384,64,51 (encoder forward + cnf_encoder_forward_bwd_tiled at 1 048 576 tokens, D = 6, C = 16 and 51, 20 steps each: its launches one by one)" 12 | head -3
 rm -f "$OUT"/prof_encbwd/*kernel_trace.csv
-timeout 200 python tools/autograd_overhead.py > "$OUT/autograd_overhead.txt" 2>&1; tail -3 "$OUT/autograd_overhead.txt"
+( timeout 200 python tools/autograd_overhead.py 2>&1 | grep -v amdgpu.ids; echo; echo "== --single_thread (torch.autograd.set_multithreading_enabled(False): backward() on the calling thread, what the three drivers set)"; timeout 200 python tools/autograd_overhead.py --single_thread 2>&1 | grep "wall" ) > "$OUT/autograd_overhead.txt"; tail -3 "$OUT/autograd_overhead.txt"
 bash tools/pmc_passes.sh pmc_small python tools/pmc_small_mixture.py > "$OUT/pmc_small.log" 2>&1
 bash tools/pmc_passes.sh flow_fused python tools/flow_traffic_workload.py fused > /dev/null 2>&1
 bash tools/pmc_passes.sh flow_unfused python tools/flow_traffic_workload.py unfused > /dev/null 2>&1
