@@ -85,6 +85,10 @@ void cnf_set_affine_bwd_tiles(int mode);
  * held to 4 waves per SIMD); 0 / 1 = the unrolled register-slot kernels of K = 4 / 8 / 16 (natural registers / held to 4 waves
  * per SIMD), the defaults until round 4.  A/B knob; same gradients up to the order of the additions.  No reference counterpart. */
 void cnf_set_mixture_bwd_waves(int mode);
+/* the same entry point's run-time-K kernels: a second LDS stage per wave, so that the next pass's parameter rows are DMA-staged
+ * while the current pass computes: 1 = wherever 64 KB of LDS allow, -1 (default) / 0 = never (measured: no gain, profiles/
+ * r04_sweep_mixture_bwd.txt).  A/B knob; bit-identical gradients either way. */
+void cnf_set_mixture_bwd_prefetch(int mode);
 
 /* Kernel timing bound to the dispatch (bench.py's `roofline`; a timed launch costs ~4 us of queue time; the reference has no counterpart — its
  * only clock is the host-side time_per_step tracker, general/train.py:147-157).  cnf_prof_arm(n): the next n
