@@ -2,6 +2,8 @@
 // log-det is analytic (no reduction over elements), plus the data-dependent-init statistics.
 #include "cnf_common.h"
 
+#include <atomic>
+
 #include <algorithm>
 
 namespace cnf {
@@ -215,24 +217,31 @@ struct ActConvArgs {
 // per-channel constants (bias, e^{+-scales}, W) are read ONCE into registers before the loop — inside it the
 // compiler could not keep them, the stores to z_out may alias them.
 typedef float ac_f4 __attribute__((ext_vector_type(4)));
-template <int D>
+// ACT / CONV: round 4 — the same kernel with one of the two layers compiled out IS the stand-alone ActNorm / 1x1 convolution for
+// D in {1..6, 8} (cnf_actnorm, cnf_invconv): their own kernels (a flat float4 stream with a 64-bit division per vector; one token per
+// lane at a D*4-byte stride) took 12.5 / 12.3 us at the benchmark shape, this one 9.7 for both layers together.
+template <int D, bool ACT = true, bool CONV = true>
 __global__ __launch_bounds__(kBlock) void actnorm_invconv_kernel(ActConvArgs a) {
     constexpr int TP = (D % 4 == 0) ? 1 : (D % 2 == 0 ? 2 : 4);
     constexpr int NV = TP * D / 4;
-    float wk[D * D], bk[D], ek[D];
+    float wk[CONV ? D * D : 1], bk[D], ek[D];
+    if (CONV) {
 #pragma unroll
-    for (int i = 0; i < D * D; ++i) wk[i] = a.w[i];
+        for (int i = 0; i < D * D; ++i) wk[i] = a.w[i];
+    }
+    if (ACT) {
 #pragma unroll
-    for (int i = 0; i < D; ++i) {
-        bk[i] = a.bias[i];
-        ek[i] = expf(a.reverse ? -a.scales[i] : a.scales[i]);
+        for (int i = 0; i < D; ++i) {
+            bk[i] = a.bias[i];
+            ek[i] = expf(a.reverse ? -a.scales[i] : a.scales[i]);
+        }
     }
     bool bad = false;
     auto token = [&](const float* xin, float* out, float p) {
         float xv[D];
 #pragma unroll
         for (int i = 0; i < D; ++i) xv[i] = xin[i];
-        if (!a.reverse) {
+        if (ACT && !a.reverse) {
 #pragma unroll
             for (int i = 0; i < D; ++i) {
                 float y = (xv[i] + bk[i]) * ek[i];
@@ -242,11 +251,16 @@ __global__ __launch_bounds__(kBlock) void actnorm_invconv_kernel(ActConvArgs a) 
         }
 #pragma unroll
         for (int j = 0; j < D; ++j) {
-            float acc = 0.f;
+            float acc;
+            if (CONV) {
+                acc = 0.f;
 #pragma unroll
-            for (int i = 0; i < D; ++i) acc = fmaf(xv[i], wk[i * D + j], acc);
-            if (a.pad) acc = acc * p;
-            if (a.reverse) {
+                for (int i = 0; i < D; ++i) acc = fmaf(xv[i], wk[i * D + j], acc);
+                if (a.pad) acc = acc * p;
+            } else {
+                acc = xv[j];
+            }
+            if (ACT && a.reverse) {
                 acc = acc * ek[j] - bk[j];
                 if (a.pad) acc = acc * p;
             }
@@ -324,9 +338,11 @@ __global__ __launch_bounds__(kBlock) void actnorm_invconv_kernel(ActConvArgs a) 
     if (bad) raise_flag(a.flags, CNF_FLAG_NAN_Z);
     // log-det of both layers: ActNorm uses length | sum(pad) | N, the convolution length | N
     float ssum = 0.f;
+    if (ACT) {
 #pragma unroll
-    for (int i = 0; i < D; ++i) ssum += a.scales[i];
-    const float sl = a.sldj[0];
+        for (int i = 0; i < D; ++i) ssum += a.scales[i];
+    }
+    const float sl = CONV ? a.sldj[0] : 0.f;
     for (long b = (long)blockIdx.x * kBlock + threadIdx.x; b < a.B; b += (long)gridDim.x * kBlock) {
         float len_a, len_c;
         if (a.length) {
@@ -340,7 +356,10 @@ __global__ __launch_bounds__(kBlock) void actnorm_invconv_kernel(ActConvArgs a) 
         }
         const float base = a.ldj_in ? a.ldj_in[b] : 0.f;
         // same association as the two layers run in sequence
-        const float v = a.reverse ? (base - sl * len_c) + (-ssum) * len_a : (base + ssum * len_a) + sl * len_c;
+        float v;
+        if (ACT && CONV) v = a.reverse ? (base - sl * len_c) + (-ssum) * len_a : (base + ssum * len_a) + sl * len_c;
+        else if (ACT) v = base + (a.reverse ? -ssum : ssum) * len_a;                   // the stand-alone kernels' expressions
+        else v = a.reverse ? base - sl * len_c : base + sl * len_c;
         a.ldj_out[b] = v;
         if (isnan(v)) raise_flag(a.flags, CNF_FLAG_NAN_LDJ);
     }
@@ -444,7 +463,34 @@ static inline int stream_grid(long n) {
 
 using namespace cnf;
 
+// 1 (default): cnf_actnorm / cnf_invconv take the fused pair's token-owner kernel for D in {1..6, 8}; 0 = their own older kernels (A/B, tests)
+static std::atomic<int> g_standalone_tiles{1};
+
+// launches actnorm_invconv_kernel<D, ACT, CONV> for D in {1..6, 8}; false = another D (the callers keep their generic kernels)
+template <bool ACT, bool CONV>
+static bool launch_act_conv(const ActConvArgs& a, hipStream_t st) {
+    const int D = a.D;
+    // one lane per group of 1, 2 or 4 tokens (16-byte I/O); uncapped grid: every lane makes a single trip
+    const int tp = (D % 4 == 0) ? 1 : (D % 2 == 0 ? 2 : 4);
+    const long lanes = std::max<long>((a.ntok + tp - 1) / tp, 1);      // one group per lane, 64 groups per wave tile
+    const dim3 grid((unsigned)std::min<long>((lanes + kBlock - 1) / kBlock, 1 << 22)), block(kBlock);
+    switch (D) {
+        case 1: CNF_LAUNCH((actnorm_invconv_kernel<1, ACT, CONV>), grid, block, 0, st, a); break;
+        case 2: CNF_LAUNCH((actnorm_invconv_kernel<2, ACT, CONV>), grid, block, 0, st, a); break;
+        case 3: CNF_LAUNCH((actnorm_invconv_kernel<3, ACT, CONV>), grid, block, 0, st, a); break;
+        case 4: CNF_LAUNCH((actnorm_invconv_kernel<4, ACT, CONV>), grid, block, 0, st, a); break;
+        case 5: CNF_LAUNCH((actnorm_invconv_kernel<5, ACT, CONV>), grid, block, 0, st, a); break;
+        case 6: CNF_LAUNCH((actnorm_invconv_kernel<6, ACT, CONV>), grid, block, 0, st, a); break;
+        case 8: CNF_LAUNCH((actnorm_invconv_kernel<8, ACT, CONV>), grid, block, 0, st, a); break;
+        default: return false;
+    }
+    return true;
+}
+
 extern "C" {
+
+void cnf_set_linear_tiles(int on) { g_standalone_tiles.store(on ? 1 : 0, std::memory_order_relaxed); }
+
 
 int cnf_actnorm(const float* z, const float* bias, const float* scales,
                 const float* pad, const float* length,
@@ -453,6 +499,10 @@ int cnf_actnorm(const float* z, const float* bias, const float* scales,
     CNF_REQUIRE(z && bias && scales && z_out && ldj_out, "cnf_actnorm: null tensor");
     CNF_REQUIRE(B >= 0 && N > 0 && D > 0 && D <= kMaxD, "cnf_actnorm: bad shape B=%d N=%d D=%d (D<=%d)", B, N, D, kMaxD);
     if (B == 0) return CNF_OK;
+    {   // D in {1..6, 8}: the token-owner kernel of the fused pair with the convolution compiled out
+        ActConvArgs f{z, bias, scales, nullptr, nullptr, pad, length, ldj_in, z_out, ldj_out, flags, B, N, D, reverse, (long)B * N};
+        if (g_standalone_tiles.load(std::memory_order_relaxed) && launch_act_conv<true, false>(f, (hipStream_t)stream)) return launch_status("cnf_actnorm");
+    }
     ActNormArgs a{z, bias, scales, pad, length, ldj_in, z_out, ldj_out, flags, B, N, D, reverse, (long)B * N * D};
     const long work = std::max<long>(a.total / 4, B);
     if (a.total % 4 == 0)
@@ -481,9 +531,13 @@ int cnf_invconv(const float* x, const float* weight, const float* sldj,
     CNF_REQUIRE(x && weight && sldj && z_out && ldj_out, "cnf_invconv: null tensor");
     CNF_REQUIRE(B >= 0 && N > 0 && D > 0, "cnf_invconv: bad shape");
     if (B == 0) return CNF_OK;
+    hipStream_t st = (hipStream_t)stream;
+    {   // D in {1..6, 8}: the token-owner kernel of the fused pair with ActNorm compiled out
+        ActConvArgs f{x, nullptr, nullptr, weight, sldj, pad, length, ldj_in, z_out, ldj_out, flags, B, N, D, reverse, (long)B * N};
+        if (g_standalone_tiles.load(std::memory_order_relaxed) && launch_act_conv<false, true>(f, st)) return launch_status("cnf_invconv");
+    }
     ConvArgs a{x, weight, sldj, pad, length, ldj_in, z_out, ldj_out, flags, B, N, D, reverse, (long)B * N};
     const dim3 grid(stream_grid(std::max<long>(a.ntok, B))), block(kBlock);
-    hipStream_t st = (hipStream_t)stream;
     switch (D) {
         case 1: CNF_LAUNCH((invconv_kernel<1>), grid, block, 0, st, a); break;
         case 2: CNF_LAUNCH((invconv_kernel<2>), grid, block, 0, st, a); break;
@@ -532,22 +586,9 @@ int cnf_actnorm_invconv(const float* z, const float* bias, const float* scales, 
     CNF_REQUIRE(B >= 0 && N > 0 && D > 0, "cnf_actnorm_invconv: bad shape");
     if (B == 0) return CNF_OK;
     ActConvArgs a{z, bias, scales, weight, sldj, pad, length, ldj_in, z_out, ldj_out, flags, B, N, D, reverse, (long)B * N};
-    // one lane per group of 1, 2 or 4 tokens (16-byte I/O); uncapped grid: every lane makes a single trip
-    const int tp = (D % 4 == 0) ? 1 : (D % 2 == 0 ? 2 : 4);
-    const long lanes = std::max<long>((a.ntok + tp - 1) / tp, 1);      // one group per lane, 64 groups per wave tile
-    const dim3 grid((unsigned)std::min<long>((lanes + kBlock - 1) / kBlock, 1 << 22)), block(kBlock);
-    hipStream_t st = (hipStream_t)stream;
-    switch (D) {
-        case 1: CNF_LAUNCH((actnorm_invconv_kernel<1>), grid, block, 0, st, a); break;
-        case 2: CNF_LAUNCH((actnorm_invconv_kernel<2>), grid, block, 0, st, a); break;
-        case 3: CNF_LAUNCH((actnorm_invconv_kernel<3>), grid, block, 0, st, a); break;
-        case 4: CNF_LAUNCH((actnorm_invconv_kernel<4>), grid, block, 0, st, a); break;
-        case 5: CNF_LAUNCH((actnorm_invconv_kernel<5>), grid, block, 0, st, a); break;
-        case 6: CNF_LAUNCH((actnorm_invconv_kernel<6>), grid, block, 0, st, a); break;
-        case 8: CNF_LAUNCH((actnorm_invconv_kernel<8>), grid, block, 0, st, a); break;
-        default:
-            set_error("cnf_actnorm_invconv: fused kernel is built for D in {1,2,3,4,5,6,8}; run the two layers separately for D=%d", D);
-            return CNF_ERR_UNSUPPORTED;
+    if (!launch_act_conv<true, true>(a, (hipStream_t)stream)) {
+        set_error("cnf_actnorm_invconv: fused kernel is built for D in {1,2,3,4,5,6,8}; run the two layers separately for D=%d", D);
+        return CNF_ERR_UNSUPPORTED;
     }
     return launch_status("cnf_actnorm_invconv");
 }

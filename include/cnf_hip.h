@@ -76,6 +76,9 @@ void cnf_set_bwd_tile(int chunks_in_flight, int groups_per_tile);
 /* cnf_actnorm_bwd: 1 (default) = the token-owner wave-tile kernel (register sums) for D in {1..6, 8}, 0 = always the flat-tile
  * kernel with lane-private LDS sums (A/B measurements and tests; same results up to the order of the additions). */
 void cnf_set_actnorm_bwd_tiles(int on);
+/* cnf_actnorm / cnf_invconv (forward kernels): 1 (default) = the fused pair's token-owner wave-tile kernel with the other layer compiled
+ * out for D in {1..6, 8} (the same bits, 12.5 -> ~9.7 us at the benchmark shape), 0 = their own older kernels (A/B, tests). */
+void cnf_set_linear_tiles(int on);
 /* cnf_affine_coupling_bwd, channel masks at D in {2, 3, 4, 6, 8}: 1 (default) = the token-owner wave-tile kernel where it is the
  * faster one (no scaling factor, or the forward direction), 2 = always, 0 = always the flat-tile kernel (A/B measurements and
  * tests; same results up to the order of the additions). */
