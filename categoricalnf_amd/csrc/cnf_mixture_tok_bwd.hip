@@ -340,7 +340,6 @@ __device__ __forceinline__ void mixture_tok_bwd_body(const MixArgs& a, const Tok
             }
 
             float g_x = gzo;                       // an element that is not transformed passes its gradient through
-            bool tail = false;
             if (active) {
                 const float t = my[0];
                 const float raw_ls = my[1];
@@ -450,7 +449,6 @@ __device__ __forceinline__ void mixture_tok_bwd_body(const MixArgs& a, const Tok
                     // rare: a tail or an underflow.  The element is redone in fp64 by the whole wave at the END of the pass
                     // (tail_fixup), where none of the unrolled mixture state is live: inside this branch the fp64 code cost
                     // the streaming path 21-36 VGPRs.  Zeros go to the stage meanwhile.
-                    tail = true;
                     any_tail = true;
                     g_x = __uint_as_float(kTailSentinel);
                     g_t = 0.f;
