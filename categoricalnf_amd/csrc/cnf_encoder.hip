@@ -1061,6 +1061,23 @@ int cnf_encoder_forward_actconv(const int64_t* categ, const float* u, float sque
                                 act_bias, act_scales, conv_weight, conv_sldj, length);
 }
 
+int cnf_encoder_forward_actconv_cpl(const int64_t* categ, const float* u, float squeeze_eps, const float* table,
+                                    const float* category_prior, const float* pad, float beta,
+                                    const float* act_bias, const float* act_scales, const float* conv_weight, const float* conv_sldj,
+                                    const float* length,
+                                    const float* ldj_in, float* z_out, float* ldj_out, float* class_prob_log,
+                                    int B, int N, int D, int C, float sigma, float log_sigma,
+                                    int* flags, cnf_stream_t stream) {
+    CNF_REQUIRE(act_bias && act_scales && conv_weight && conv_sldj, "cnf_encoder_forward_actconv_cpl: null tensor");
+    if (math_mode() != 1) {
+        set_error("cnf_encoder_forward_actconv_cpl: the fused sampler is the fp32 one of math mode 1; run the layers separately");
+        return CNF_ERR_UNSUPPORTED;
+    }
+    return encoder_forward_impl(categ, u, table, category_prior, pad, beta, ldj_in, z_out, ldj_out, class_prob_log,
+                                B, N, D, C, sigma, log_sigma, flags, stream, 1, squeeze_eps, nullptr,
+                                act_bias, act_scales, conv_weight, conv_sldj, length);
+}
+
 int cnf_encoder_decode(const float* z, const float* table, const float* category_prior,
                        int64_t* categ_out, int B, int N, int D, int C, float sigma, float log_sigma,
                        cnf_stream_t stream) {

@@ -293,11 +293,13 @@ class EncoderActConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, table, bias, scales, weight, sldj, ldj, categ, uniform, prior, pad, length, beta, squeeze):
-        z_out, ldj_out = ops.encoder_forward_actconv(categ, uniform, table, prior, bias, scales, weight, sldj, beta=beta,
-                                                     channel_padding_mask=pad, length=length, ldj=ldj, uniform_squeeze=squeeze)
+        # class_prob_log rides along for the backward's pair kernel (cnf_encoder_forward_bwd_cpl)
+        z_out, ldj_out, cpl = ops.encoder_forward_actconv(categ, uniform, table, prior, bias, scales, weight, sldj, beta=beta,
+                                                          channel_padding_mask=pad, length=length, ldj=ldj, uniform_squeeze=squeeze,
+                                                          want_class_prob=True)
         empty = z_out.new_empty(0)
         ctx.save_for_backward(table, categ, uniform, prior, pad if isinstance(pad, torch.Tensor) else empty,
-                              length if isinstance(length, torch.Tensor) else empty, z_out, bias, scales, weight)
+                              length if isinstance(length, torch.Tensor) else empty, z_out, bias, scales, weight, cpl)
         ctx.has_pad, ctx.has_len, ctx.has_ldj = isinstance(pad, torch.Tensor), isinstance(length, torch.Tensor), ldj is not None
         ctx.beta, ctx.squeeze, ctx.sldj_shape = float(beta), float(squeeze), sldj.shape
         return z_out, ldj_out
@@ -305,7 +307,7 @@ class EncoderActConvFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_zout, g_ldj):
         hold = _Hold()
-        table, categ, uniform, prior, pad, length, z_out, bias, scales, weight = ctx.saved_tensors
+        table, categ, uniform, prior, pad, length, z_out, bias, scales, weight, cpl = ctx.saved_tensors
         pad_t, len_t = (pad if ctx.has_pad else None), (length if ctx.has_len else None)
         g_ze, g_b, g_s, g_w, g_sl = _actconv_bwd(z_out, True, bias, scales, weight, len_t, pad_t, g_zout, g_ldj, hold)
         dev = table.device
@@ -316,8 +318,8 @@ class EncoderActConvFn(torch.autograd.Function):
         p2 = _pad2d(pad, B, N, dev) if ctx.has_pad else None
         g_table = torch.empty_like(tc)
         ws = torch.empty(int(_lib.load().cnf_encoder_bwd_tiled_workspace_floats(B, N, D, C)), dtype=torch.float32, device=dev)
-        _launch(dev, "cnf_encoder_forward_bwd_tiled", _ptr(categ.contiguous()), _ptr(_f32(eps, "eps")), _ptr(tc), _ptr(pc), _ptr(p2), ctx.beta,
-                _ptr(g_ze), hold(g_ldj), _ptr(g_table), _ptr(ws), B, N, D, C,
+        _launch(dev, "cnf_encoder_forward_bwd_cpl", _ptr(categ.contiguous()), _ptr(_f32(eps, "eps")), _ptr(tc), _ptr(pc), _ptr(p2), ctx.beta,
+                _ptr(cpl.contiguous()), _ptr(g_ze), hold(g_ldj), _ptr(g_table), _ptr(ws), B, N, D, C,
                 float(ops.LOGISTIC_SIGMA), float(ops.LOGISTIC_LOG_SIGMA), _stream(dev))
         return (g_table, g_b, g_s, g_w, g_sl.view(ctx.sldj_shape), (g_ldj if ctx.has_ldj else None),
                 None, None, None, None, None, None, None)
@@ -513,25 +515,30 @@ class EncoderForwardFn(torch.autograd.Function):
     def forward(ctx, table, categ, eps, prior, pad, beta, want_class_prob, tiled=None, uniform_squeeze=None):
         # uniform_squeeze: `eps` is the uniform draw and the forward kernel samples the noise itself (and hands it back for
         # the backward kernels), see ops.encoder_forward
+        # the backward's pair kernel takes every token's denominator from the forward's class_prob_log (4 bytes per token
+        # more to write here, a whole sweep over the classes less there): ask for it whenever a gradient can follow
+        keep_cpl = table.requires_grad and tiled is not False
         if uniform_squeeze is not None:
             z, ldj, cpl, eps = ops.encoder_forward(categ, eps, table, prior, beta=beta, channel_padding_mask=pad,
-                                                   want_class_prob=want_class_prob, tiled=tiled,
+                                                   want_class_prob=want_class_prob or keep_cpl, tiled=tiled,
                                                    uniform_squeeze=uniform_squeeze, want_noise=True)
         else:
             z, ldj, cpl = ops.encoder_forward(categ, eps, table, prior, beta=beta, channel_padding_mask=pad,
-                                              want_class_prob=want_class_prob, tiled=tiled)
+                                              want_class_prob=want_class_prob or keep_cpl, tiled=tiled)
         ctx.tiled = tiled
-        ctx.save_for_backward(table, categ, eps, prior, pad if isinstance(pad, torch.Tensor) else z.new_empty(0))
-        ctx.has_pad, ctx.beta = isinstance(pad, torch.Tensor), float(beta)
-        if cpl is None:
-            cpl = z.new_empty(0)
+        empty = z.new_empty(0)
+        ctx.save_for_backward(table, categ, eps, prior, pad if isinstance(pad, torch.Tensor) else empty,
+                              cpl if keep_cpl else empty)
+        ctx.has_pad, ctx.beta, ctx.has_cpl = isinstance(pad, torch.Tensor), float(beta), keep_cpl
+        if cpl is None or not want_class_prob:
+            cpl = empty
         ctx.mark_non_differentiable(cpl)
         return z, ldj, cpl
 
     @staticmethod
     def backward(ctx, g_zout, g_ldj, _g_cpl):
         hold = _Hold()
-        table, categ, eps, prior, pad = ctx.saved_tensors
+        table, categ, eps, prior, pad, cpl = ctx.saved_tensors
         dev = table.device
         B, N = categ.shape
         C, D = table.shape[0], table.shape[1] // 2
@@ -540,16 +547,18 @@ class EncoderForwardFn(torch.autograd.Function):
         g_table = torch.empty_like(tc)
         categ_c = categ.contiguous()
         if ctx.tiled is not False or C * 2 * D > ops.ENCODER_BWD_LDS_ENTRIES:
-            # token-lane + class-lane passes: any vocabulary size, bit-reproducible, 4-12x faster than the LDS-table
-            # kernel at 16-160 classes (profiles/r02_encoder_probe.txt); `tiled=False` keeps the latter for A/B tests
-            name = "cnf_encoder_forward_bwd_tiled"
+            # one pass over the (token, class) pairs with the forward's class_prob_log, or the token-lane + class-lane passes
+            # (the library picks by shape): any vocabulary size, bit-reproducible, 4-12x faster than the LDS-table kernel at
+            # 16-160 classes (profiles/r02_encoder_probe.txt); `tiled=False` keeps the latter for A/B tests
             ws = torch.empty(int(_lib.load().cnf_encoder_bwd_tiled_workspace_floats(B, N, D, C)), dtype=torch.float32, device=dev)
+            _launch(dev, "cnf_encoder_forward_bwd_cpl", _ptr(categ_c), _ptr(ec), _ptr(tc), _ptr(pc), _ptr(p2), ctx.beta,
+                    _ptr(cpl.contiguous()) if ctx.has_cpl else None, hold(g_zout), hold(g_ldj), _ptr(g_table), _ptr(ws), B, N, D, C,
+                    float(ops.LOGISTIC_SIGMA), float(ops.LOGISTIC_LOG_SIGMA), _stream(dev))
         else:
-            name = "cnf_encoder_forward_bwd"              # table gradient accumulated in LDS
-            ws = _ws(C * 2 * D, dev)
-        _launch(dev, name, _ptr(categ_c), _ptr(ec), _ptr(tc), _ptr(pc), _ptr(p2), ctx.beta,
-                                               hold(g_zout), hold(g_ldj), _ptr(g_table), _ptr(ws), B, N, D, C,
-                                               float(ops.LOGISTIC_SIGMA), float(ops.LOGISTIC_LOG_SIGMA), _stream(dev))
+            ws = _ws(C * 2 * D, dev)                      # table gradient accumulated in LDS
+            _launch(dev, "cnf_encoder_forward_bwd", _ptr(categ_c), _ptr(ec), _ptr(tc), _ptr(pc), _ptr(p2), ctx.beta,
+                    hold(g_zout), hold(g_ldj), _ptr(g_table), _ptr(ws), B, N, D, C,
+                    float(ops.LOGISTIC_SIGMA), float(ops.LOGISTIC_LOG_SIGMA), _stream(dev))
         return g_table, None, None, None, None, None, None, None, None
 
 
@@ -569,7 +578,7 @@ class EncoderForwardDevBetaFn(torch.autograd.Function):
         if isinstance(pad, torch.Tensor):
             w = w * pad.reshape(B, N)
         ldj = ldj1 + (beta_t.reshape(()).to(torch.float32) - 1.0) * w.sum(dim=1)
-        ctx.save_for_backward(table, categ, eps, prior, pad if isinstance(pad, torch.Tensor) else z.new_empty(0), beta_t)
+        ctx.save_for_backward(table, categ, eps, prior, pad if isinstance(pad, torch.Tensor) else z.new_empty(0), beta_t, cpl)
         ctx.has_pad = isinstance(pad, torch.Tensor)
         ctx.mark_non_differentiable(cpl)
         return z, ldj, cpl
@@ -577,19 +586,20 @@ class EncoderForwardDevBetaFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_zout, g_ldj, _g_cpl):
         hold = _Hold()
-        table, categ, eps, prior, pad, beta_t = ctx.saved_tensors
+        table, categ, eps, prior, pad, beta_t, cpl = ctx.saved_tensors
         dev = table.device
         B, N = categ.shape
         C, D = table.shape[0], table.shape[1] // 2
         tc, ec, pc = _f32(table, "table"), _f32(eps, "eps"), _f32(prior, "category_prior")
         p2 = _pad2d(pad, B, N, dev) if ctx.has_pad else None
         categ_c = categ.contiguous()
+        cpl_c = cpl.contiguous()                          # log q_c does not depend on beta: one forward serves both launches
         n_ws = int(_lib.load().cnf_encoder_bwd_tiled_workspace_floats(B, N, D, C))
         grads = []
         for beta in (0.0, 1.0):
             g_table = torch.empty_like(tc)
             ws = torch.empty(n_ws, dtype=torch.float32, device=dev)
-            _launch(dev, "cnf_encoder_forward_bwd_tiled", _ptr(categ_c), _ptr(ec), _ptr(tc), _ptr(pc), _ptr(p2), beta,
+            _launch(dev, "cnf_encoder_forward_bwd_cpl", _ptr(categ_c), _ptr(ec), _ptr(tc), _ptr(pc), _ptr(p2), beta, _ptr(cpl_c),
                     hold(g_zout), hold(g_ldj), _ptr(g_table), _ptr(ws), B, N, D, C,
                     float(ops.LOGISTIC_SIGMA), float(ops.LOGISTIC_LOG_SIGMA), _stream(dev))
             grads.append(g_table)

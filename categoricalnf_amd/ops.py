@@ -707,11 +707,11 @@ def encoder_forward(categ, eps, table, category_prior, beta=1.0, channel_padding
 
 def encoder_forward_actconv(categ, uniform, table, category_prior, act_bias, act_scales, conv_weight, conv_sldj,
                             beta=1.0, channel_padding_mask=None, length=None, ldj=None, uniform_squeeze=1e-4,
-                            sigma=LOGISTIC_SIGMA, log_sigma=LOGISTIC_LOG_SIGMA):
+                            sigma=LOGISTIC_SIGMA, log_sigma=LOGISTIC_LOG_SIGMA, want_class_prob=False):
     """The sampled encoder forward + the ActNorm and 1x1 convolution of the flow step behind it in ONE kernel
-    (cnf_encoder_forward_actconv); where that kernel does not apply (class table beyond LDS, D outside
+    (cnf_encoder_forward_actconv[_cpl]); where that kernel does not apply (class table beyond LDS, D outside
     FUSED_ACTCONV_DIMS, math mode 0) the same layers run one after the other — same bits either way.
-    Returns (z after the convolution, running log-det)."""
+    Returns (z after the convolution, running log-det) and, with want_class_prob, class_prob_log [B*N] as a third item."""
     dev = _dev(categ)
     if categ.dtype != torch.int64:
         categ = categ.long()
@@ -730,18 +730,26 @@ def encoder_forward_actconv(categ, uniform, table, category_prior, act_bias, act
         ln = _length(length, B, dev) if isinstance(length, torch.Tensor) else None
         ldj_in, ldj_out = _ldj_io(ldj, B, dev, inplace=False)
         z = torch.empty(B, N, D, dtype=torch.float32, device=dev)
-        status = _launch(dev, "cnf_encoder_forward_actconv",
-                         _ptr(categ), _ptr(u), float(uniform_squeeze), _ptr(table), _ptr(prior), _ptr(pad), float(beta),
-                         _ptr(b), _ptr(s), _ptr(w), _ptr(sl), _ptr(ln), _ptr(ldj_in), _ptr(z), _ptr(ldj_out), B, N, D, C,
-                         float(sigma), float(log_sigma), _ptr(flag_word(dev)), _stream(dev), allow_unsupported=True)
+        if want_class_prob:
+            cpl = torch.empty(B * N, dtype=torch.float32, device=dev)
+            status = _launch(dev, "cnf_encoder_forward_actconv_cpl",
+                             _ptr(categ), _ptr(u), float(uniform_squeeze), _ptr(table), _ptr(prior), _ptr(pad), float(beta),
+                             _ptr(b), _ptr(s), _ptr(w), _ptr(sl), _ptr(ln), _ptr(ldj_in), _ptr(z), _ptr(ldj_out), _ptr(cpl), B, N, D, C,
+                             float(sigma), float(log_sigma), _ptr(flag_word(dev)), _stream(dev), allow_unsupported=True)
+        else:
+            status = _launch(dev, "cnf_encoder_forward_actconv",
+                             _ptr(categ), _ptr(u), float(uniform_squeeze), _ptr(table), _ptr(prior), _ptr(pad), float(beta),
+                             _ptr(b), _ptr(s), _ptr(w), _ptr(sl), _ptr(ln), _ptr(ldj_in), _ptr(z), _ptr(ldj_out), B, N, D, C,
+                             float(sigma), float(log_sigma), _ptr(flag_word(dev)), _stream(dev), allow_unsupported=True)
         if status == _lib.CNF_OK:
             _after(dev, "categorical encoder + ActNorm + InvertibleConv")
-            return z, ldj_out
-    z, ldj_enc, _ = encoder_forward(categ, uniform, table, category_prior, beta=beta, channel_padding_mask=channel_padding_mask,
-                                    sigma=sigma, log_sigma=log_sigma, uniform_squeeze=uniform_squeeze)
+            return (z, ldj_out, cpl) if want_class_prob else (z, ldj_out)
+    z, ldj_enc, cpl = encoder_forward(categ, uniform, table, category_prior, beta=beta, channel_padding_mask=channel_padding_mask,
+                                      sigma=sigma, log_sigma=log_sigma, uniform_squeeze=uniform_squeeze, want_class_prob=want_class_prob)
     ldj_run = ldj_enc if ldj is None else ldj + ldj_enc
-    return actnorm_invconv(z, act_bias, act_scales, conv_weight, conv_sldj, length=length,
-                           channel_padding_mask=channel_padding_mask, ldj=ldj_run)
+    out = actnorm_invconv(z, act_bias, act_scales, conv_weight, conv_sldj, length=length,
+                          channel_padding_mask=channel_padding_mask, ldj=ldj_run)
+    return (out[0], out[1], cpl) if want_class_prob else out
 
 
 def encoder_decode(z, table, category_prior, sigma=LOGISTIC_SIGMA, log_sigma=LOGISTIC_LOG_SIGMA, tiled=None):

@@ -391,3 +391,170 @@ def test_decode_actconv_kernel_gives_the_bits_of_the_three_layers(B, N, D, C, pa
     df, lf = ops.encoder_decode_actconv(z, bias, scales, w_inv, sldj, table, prior, channel_padding_mask=pad, length=length, ldj=ldj)
     assert torch.equal(df, dc) and torch.equal(lf, lc + torch.zeros_like(lc))
     ops.check_flags(dev, "decode + actconv")
+
+
+# ---- round 5: the one-pass (token, class) pair kernel of the backward (cnf_encoder_forward_bwd_cpl) ---------------------------
+
+def _bwd_call(lib, ops, which, use_cpl, categ, eps, table, prior, pad, beta, gz, gl):
+    """g_table through the C ABI with cnf_set_encoder_bwd_kernel(which); use_cpl: hand over the forward's class_prob_log."""
+    from categoricalnf_amd.ops import _ptr, _stream, _launch
+    dev = table.device
+    B, N = categ.shape
+    C, D = table.shape[0], table.shape[1] // 2
+    p2 = pad.reshape(B, N).contiguous() if pad is not None else None
+    cpl = ops.encoder_forward(categ, eps, table, prior, beta=beta, channel_padding_mask=pad, want_class_prob=True)[2] if use_cpl else None
+    ws = torch.empty(int(lib.cnf_encoder_bwd_tiled_workspace_floats(B, N, D, C)), device=dev)
+    out = torch.full_like(table, float("nan"))
+    lib.cnf_set_encoder_bwd_kernel(which)
+    try:
+        if use_cpl:
+            _launch(dev, "cnf_encoder_forward_bwd_cpl", _ptr(categ), _ptr(eps), _ptr(table), _ptr(prior), _ptr(p2), float(beta), _ptr(cpl),
+                    _ptr(gz), _ptr(gl), _ptr(out), _ptr(ws), B, N, D, C, float(ops.LOGISTIC_SIGMA), float(ops.LOGISTIC_LOG_SIGMA), _stream(dev))
+        else:
+            _launch(dev, "cnf_encoder_forward_bwd_tiled", _ptr(categ), _ptr(eps), _ptr(table), _ptr(prior), _ptr(p2), float(beta),
+                    _ptr(gz), _ptr(gl), _ptr(out), _ptr(ws), B, N, D, C, float(ops.LOGISTIC_SIGMA), float(ops.LOGISTIC_LOG_SIGMA), _stream(dev))
+        torch.cuda.synchronize()
+    finally:
+        lib.cnf_set_encoder_bwd_kernel(0)
+    return out
+
+
+def _oracle_table_grad(categ, eps, table, prior, pad, beta, gz, gl):
+    from oracle import cnf_oracle as O
+    B, N = categ.shape
+    D = table.shape[1] // 2
+    tc = table.double().cpu().requires_grad_()
+    zo, lo, _ = O.encoder_forward(categ.cpu(), eps.double().cpu().reshape(B * N, 1, D), tc, prior.double().cpu(), beta=beta,
+                                  channel_padding_mask=pad.double().cpu() if pad is not None else None)
+    loss = 0.0
+    if gz is not None:
+        loss = loss + (zo * gz.double().cpu()).sum()
+    if gl is not None:
+        loss = loss + (lo * gl.double().cpu()).sum()
+    loss.backward()
+    return tc.grad
+
+
+def _within(got, ref, rtol=2e-3, atol_rel=2e-4):
+    scale = max(float(ref.abs().max()), 1.0)
+    err = (got.double().cpu() - ref).abs()
+    return float((err / (rtol * ref.abs() + atol_rel * scale)).max())
+
+
+# (B, N, D, C): one stage and many stages per workgroup, ragged last stage, every templated D, class counts at the limits of the
+# pair lanes (192 = 3 waves), a vocabulary of one class, more tokens per stage than the token wave's 64 lanes (C = 2, 3)
+PAIR_SHAPES = [(64, 16, 6, 16), (33, 8, 8, 51), (6, 30, 4, 64), (5, 7, 3, 5), (4, 5, 1, 2), (2, 300, 2, 120), (7, 33, 6, 192),
+               (300, 64, 6, 16), (129, 17, 6, 9), (3, 11, 4, 1), (40, 50, 6, 3), (512, 64, 6, 27)]
+
+
+@pytest.mark.parametrize("B,N,D,C", PAIR_SHAPES)
+@pytest.mark.parametrize("pad_mode", [0, 1])
+def test_backward_pair_kernel_against_the_oracle(B, N, D, C, pad_mode):
+    """cnf_encoder_forward_bwd_cpl / _tiled on the pair kernel (cnf_set_encoder_bwd_kernel(2)), with the forward's
+    class_prob_log and with the library's own pre-pass: d loss / d class table against float64 autograd through the oracle
+    (linear_encoding.py:59-106,153-174), bit-identical from run to run, and the two-pass kernels' result within the same
+    tolerance; either upstream gradient may be absent."""
+    lib, ops = _setup()
+    dev = torch.device("cuda:0")
+    categ, eps, table, prior, pad, _ = _inputs(B, N, D, C, 31 + B + C, pad_mode, dev)
+    eps = eps.contiguous()
+    g = torch.Generator(device=dev).manual_seed(B + N)
+    gz, gl = torch.randn(B, N, D, generator=g, device=dev), torch.randn(B, generator=g, device=dev)
+    ref = _oracle_table_grad(categ, eps, table, prior, pad, 1.3, gz, gl)
+    for use_cpl in (True, False):
+        got = _bwd_call(lib, ops, 2, use_cpl, categ, eps, table, prior, pad, 1.3, gz, gl)
+        assert torch.isfinite(got).all()
+        assert _within(got, ref) <= 1.0, (use_cpl, _within(got, ref))
+        assert torch.equal(got, _bwd_call(lib, ops, 2, use_cpl, categ, eps, table, prior, pad, 1.3, gz, gl))      # fixed summation order
+    two = _bwd_call(lib, ops, 1, False, categ, eps, table, prior, pad, 1.3, gz, gl)
+    assert _within(two, ref) <= 1.0
+    # the default route (by shape) is one of the two
+    dflt = _bwd_call(lib, ops, 0, True, categ, eps, table, prior, pad, 1.3, gz, gl)
+    assert torch.equal(dflt, _bwd_call(lib, ops, 2, True, categ, eps, table, prior, pad, 1.3, gz, gl)) or torch.equal(dflt, two)
+    # one upstream gradient only
+    for a, b_ in ((gz, None), (None, gl)):
+        r1 = _oracle_table_grad(categ, eps, table, prior, pad, 0.7, a, b_)
+        assert _within(_bwd_call(lib, ops, 2, True, categ, eps, table, prior, pad, 0.7, a, b_), r1) <= 1.0
+
+
+def test_backward_pair_kernel_shape_limits_fall_back_to_the_two_passes():
+    """Beyond 192 classes or at a D without an instantiation the forced pair kernel is the two passes (same bits)."""
+    lib, ops = _setup()
+    dev = torch.device("cuda:0")
+    for B, N, D, C in ((3, 9, 6, 193), (4, 6, 5, 7)):
+        categ, eps, table, prior, pad, _ = _inputs(B, N, D, C, 5, 1, dev)
+        gz, gl = torch.randn(B, N, D, device=dev), torch.randn(B, device=dev)
+        a = _bwd_call(lib, ops, 2, True, categ, eps.contiguous(), table, prior, pad, 1.0, gz, gl)
+        b_ = _bwd_call(lib, ops, 1, False, categ, eps.contiguous(), table, prior, pad, 1.0, gz, gl)
+        assert torch.equal(a, b_)
+
+
+@pytest.mark.parametrize("B,N,D,C", [(64, 16, 6, 16), (33, 8, 8, 51), (96, 16, 6, 7)])
+def test_backward_pair_kernel_log_domain_tokens(B, N, D, C):
+    """The extreme inputs of test_backward_density_sum_and_its_log_domain_fallback (noise at the prior's clamp, far-apart class
+    means, log-priors of -120) and the near-denormal rivals of the forward's test: tokens whose own density is outside the density
+    sum's fp32 range are scored in the log domain by the pair kernel too (record flag from lp2 and the forward's log q_c)."""
+    lib, ops = _setup()
+    dev = torch.device("cuda:0")
+    categ, eps, table, prior, pad, _ = _inputs(B, N, D, C, 77 + D + C, 1, dev)
+    g = torch.Generator(device=dev).manual_seed(6)
+    eps = eps.reshape(B, N, D).clone()
+    eps[: B // 4] = (9.903487 / 1.81) * torch.sign(torch.randn(B // 4, N, D, generator=g, device=dev))
+    eps = eps.reshape(B * N, D).contiguous()
+    gz, gl = torch.randn(B, N, D, generator=g, device=dev), torch.randn(B, generator=g, device=dev)
+    cases = []
+    t1, p1 = table.clone(), prior.clone()
+    t1[:, :D] *= 6.0
+    p1[::3] = -120.0
+    cases.append((t1, p1))
+    t2 = table.clone()
+    t2[:, :D] *= 0.5
+    cases.append((t2, -83.0 + 0.7 * torch.randn(C, generator=g, device=dev)))        # every own density ~2^-120 ... 2^-135
+    for tb, pr in cases:
+        ref = _oracle_table_grad(categ, eps, tb, pr, pad, 1.3, gz, gl)
+        for use_cpl in (True, False):
+            got = _bwd_call(lib, ops, 2, use_cpl, categ, eps, tb, pr, pad, 1.3, gz, gl)
+            assert torch.isfinite(got).all()
+            assert _within(got, ref) <= 1.0, (use_cpl, _within(got, ref))
+
+
+def test_backward_pair_kernel_at_the_benchmark_size():
+    """1 048 576 tokens x 16 classes (22 stages per workgroup, every workgroup slot of the chip taken): the pair kernel and the
+    two passes agree to 2e-4 of the largest entry, both are reproducible, and the autograd Function (which keeps the forward's
+    class_prob_log) takes the pair kernel."""
+    from categoricalnf_amd import functional as Fn
+    lib, ops = _setup()
+    dev = torch.device("cuda:0")
+    B, N, D, C = 16384, 64, 6, 16
+    categ, eps, table, prior, _, _ = _inputs(B, N, D, C, 3, 0, dev)
+    eps = eps.contiguous()
+    g = torch.Generator(device=dev).manual_seed(9)
+    gz, gl = torch.randn(B, N, D, generator=g, device=dev), torch.randn(B, generator=g, device=dev)
+    pair = _bwd_call(lib, ops, 2, True, categ, eps, table, prior, None, 1.0, gz, gl)
+    assert torch.equal(pair, _bwd_call(lib, ops, 2, True, categ, eps, table, prior, None, 1.0, gz, gl))
+    two = _bwd_call(lib, ops, 1, False, categ, eps, table, prior, None, 1.0, gz, gl)
+    scale = float(two.abs().max())
+    assert float((pair - two).abs().max()) <= 2e-4 * scale
+    tg = table.clone().requires_grad_()
+    z, ldj, _ = Fn.EncoderForwardFn.apply(tg, categ, eps, prior, None, 1.0, False, None)
+    ((z * gz).sum() + (ldj * gl).sum()).backward()
+    assert torch.equal(tg.grad, pair)
+
+
+def test_actconv_forward_hands_out_the_class_posterior():
+    """cnf_encoder_forward_actconv_cpl: latents and log-det of cnf_encoder_forward_actconv, class_prob_log of the plain sampled
+    forward — bit for bit."""
+    lib, ops = _setup()
+    dev = torch.device("cuda:0")
+    B, N, D, C = 96, 20, 6, 16
+    categ, _, table, prior, pad, ldj = _inputs(B, N, D, C, 11, 1, dev)
+    g = torch.Generator(device=dev).manual_seed(2)
+    u = torch.rand(B * N, D, generator=g, device=dev)
+    bias, scales = 0.3 * torch.randn(D, generator=g, device=dev), 0.2 * torch.randn(D, generator=g, device=dev)
+    w = torch.linalg.qr(torch.randn(D, D, generator=g, device=dev))[0].contiguous()
+    sldj = torch.slogdet(w)[1].reshape(1)
+    z0, l0 = ops.encoder_forward_actconv(categ, u, table, prior, bias, scales, w, sldj, beta=1.2, channel_padding_mask=pad, ldj=ldj)
+    z1, l1, c1 = ops.encoder_forward_actconv(categ, u, table, prior, bias, scales, w, sldj, beta=1.2, channel_padding_mask=pad, ldj=ldj,
+                                             want_class_prob=True)
+    cref = ops.encoder_forward(categ, u, table, prior, beta=1.2, channel_padding_mask=pad, want_class_prob=True, uniform_squeeze=1e-4)[2]
+    assert torch.equal(z0, z1) and torch.equal(l0, l1) and torch.equal(c1, cref)
