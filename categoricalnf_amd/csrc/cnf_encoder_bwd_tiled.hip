@@ -462,6 +462,8 @@ __device__ __forceinline__ void lds_barrier() {
 //   * 4 pair waves + token wave (320 lanes): two workgroups per CU instead of the three the occupancy query promises: 143 us;
 //   * own-class adds as a separate phase after the class sums: 0.5 us per stage of exposed LDS latency;
 //   * sign-free tanh / density from r = 1 / (1 + e^-y): 92 us but 4e-3 off (see the pair loop);
+//   * a branch-free copy of the pair loop for full stages without log-domain tokens (no per-token tests, four slots in one
+//     basic block): 141 registers -> three workgroups per CU, 105 us; capped at 128 registers (10 spilled): 97 us;
 // this form: 94-99 us (the pair arithmetic alone is 31 us of VALU issue: tools/isa_cost.py, profiles/r05_op_rates.txt).
 struct PairsGeom {
     int TL, ST, rs, RT;
