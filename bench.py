@@ -267,8 +267,10 @@ def kernel_table(lib, ops, dev, budget_ms=6.0):
         torch.cuda.synchronize(dev)
         return float(np.median([marks[k].elapsed_time(marks[k + 1]) / reps for k in range(1, 3)])), 2 * reps
 
-    def row(name, shape, nbytes, calls, **extra):
+    def row(name, shape, nbytes, calls, per=1, **extra):
+        # per > 1: every element of `calls` makes `per` calls of the entry point (a deferred-reduction group)
         ms, n = timed(calls)
+        ms, n = ms / per, n * per
         r = {"kernel": name, "shape": shape, "algorithmic_bytes": float(nbytes), "us": ms * 1e3, "GBps": nbytes / (ms * 1e-3) / 1e9,
              "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "launches_timed": n}
         r.update(extra)
@@ -315,6 +317,38 @@ def kernel_table(lib, ops, dev, budget_ms=6.0):
          for r in range(R)])
     row("ext_actnorm_bwd", S, 28 * e,
         [call("cnf_ext_actnorm_bwd", P(zs[r]), P(nn2[r]), None, P(gz[r]), P(gl), P(o1[r]), P(o2[r]), B, N, D, 0, st) for r in range(R)])
+    # the same entry points with their closing reductions deferred (cnf_bwd_defer_begin / _flush: one reduction launch per R
+    # calls instead of one per call, each call on its own workspace) — what a host that owns the whole backward pass sees
+    wss = [torch.empty(int(lib.cnf_bwd_workspace_floats(D * D + 2 * D + 2)), device=dev) for _ in range(R)]
+    g_sfs, g_bs, g_ss, g_ws, g_sls, g_pars = ([torch.empty(n, device=dev) for _ in range(R)] for n in (D, D, D, D * D, 1, D * D + 1 + 2 * D))
+
+    def deferred(mk):
+        inner = [mk(r) for r in range(R)]
+        flush = call("cnf_bwd_defer_flush", st)
+
+        def run():
+            lib.cnf_bwd_defer_begin()
+            for c in inner:
+                c()
+            flush()
+        return [run]
+    dn = "reduction deferred: one launch per %d calls" % R
+    for rev, what in ((0, "forward direction"), (1, "inverse direction")):
+        row("affine_coupling_bwd (%s, %s)" % (what, dn), S, 28 * e, deferred(lambda r: call(
+            "cnf_affine_coupling_bwd", P(zs[r]), P(nn2[r]), P(sf), P(mask), 1, D, P(gz[r]), P(gl), P(o1[r]), P(o2[r]), P(g_sfs[r]), P(wss[r]), B, N, D, rev, st)), per=R)
+    row("actnorm_bwd (%s)" % dn, S, 12 * e, deferred(lambda r: call(
+        "cnf_actnorm_bwd", P(zs[r]), P(bias), P(scales), None, P(ln), P(gz[r]), P(gl), P(o1[r]), P(g_bs[r]), P(g_ss[r]), P(wss[r]), B, N, D, 0, st)), per=R)
+    row("invconv_bwd (%s)" % dn, S, 12 * e, deferred(lambda r: call(
+        "cnf_invconv_bwd", P(zs[r]), P(w), None, P(ln), P(gz[r]), P(gl), P(o1[r]), P(g_ws[r]), P(g_sls[r]), P(wss[r]), B, N, D, 0, st)), per=R)
+    w_inv = torch.inverse(w.double()).float().contiguous()
+    for sio, wi, what in ((0, None, "from the input"), (1, None, "from the output through W^-1, own inverse launch"),
+                          (1, w_inv, "from the output through W^-1 handed over by cnf_invconv_lu_weight_inv")):
+        row("actnorm_invconv_bwd (fused pair, %s, %s)" % (what, dn), S, 12 * e, deferred(lambda r: call(
+            "cnf_actnorm_invconv_bwd", P(zs[r]), sio, P(bias), P(scales), P(w), P(wi), None, P(ln), P(gz[r]), P(gl), P(o1[r]), P(g_pars[r]), P(wss[r]), B, N, D, st)), per=R)
+    row("actnorm_invconv_bwd (fused pair, from the output through W^-1 handed over by cnf_invconv_lu_weight_inv, + reduction launch)", S, 12 * e,
+        [call("cnf_actnorm_invconv_bwd", P(zs[r]), 1, P(bias), P(scales), P(w), P(w_inv), None, P(ln), P(gz[r]), P(gl), P(o1[r]), P(g_par), P(wsa), B, N, D, st)
+         for r in range(R)])
+    del wss
     gldj = torch.empty(B, device=dev)
     row("prior_nll_bwd", S, 8 * e,
         [call("cnf_prior_nll_bwd", P(zs[r]), None, P(ln), P(gl), P(o1[r]), P(gldj), B, N, D, float(ops.LOGISTIC_SIGMA), st) for r in range(R)])
@@ -339,9 +373,28 @@ def kernel_table(lib, ops, dev, budget_ms=6.0):
         rows[-1]["valu_frac"] = (T / 64.0) * C * 100.5 / simds / clock / (ms * 1e-3)
         wsb = torch.empty(int(lib.cnf_encoder_bwd_tiled_workspace_floats(B, N, D, C)), device=dev)
         g_table = torch.empty(C, 2 * D, device=dev)
-        row("encoder_forward_bwd_tiled (token-lane + class-lane + split-sum launches)", SC, T * (8 + 8 * D),
-            [call("cnf_encoder_forward_bwd_tiled", P(cats[r]), P(zs[r]), P(table), P(prior), None, 1.0, P(gz[r]), P(gl), P(g_table), P(wsb), B, N, D, C,
-                  float(ops.LOGISTIC_SIGMA), float(ops.LOGISTIC_LOG_SIGMA), st) for r in range(R)], bound="valu")
+        # VALU issue ceiling of the backward: issue time per (token, class) pair and wave from the kernels' instruction mix
+        # (tools/isa_cost.py on the class loops, opcode classes of profiles/r05_op_rates.txt: 1.05 / 1.76 / 3.43 ns per 2-cycle /
+        # 4-cycle / transcendental wave-instruction): token-lane pass 119 ns + class-lane pass 143 ns; pair kernel 120 ns
+        slots = (T / 64.0) * C / simds
+        ms = row("encoder_forward_bwd_tiled (token-lane + class-lane + split-sum launches)", SC, T * (8 + 8 * D),
+                 [call("cnf_encoder_forward_bwd_tiled", P(cats[r]), P(zs[r]), P(table), P(prior), None, 1.0, P(gz[r]), P(gl), P(g_table), P(wsb), B, N, D, C,
+                       float(ops.LOGISTIC_SIGMA), float(ops.LOGISTIC_LOG_SIGMA), st) for r in range(R)], bound="valu")
+        rows[-1]["valu_frac"] = slots * 262e-9 / (ms * 1e-3)
+        cpls = []
+        for r in range(R):
+            c_ = torch.empty(T, device=dev)
+            call("cnf_encoder_forward", P(cats[r]), P(zs[r]), P(table), P(prior), None, 1.0, None, P(o1[r]), P(lo), P(c_), B, N, D, C,
+                 float(ops.LOGISTIC_SIGMA), float(ops.LOGISTIC_LOG_SIGMA), flags, st)()
+            cpls.append(c_)
+        ms = row("encoder_forward_bwd_cpl (the forward's class_prob_log handed back: the library picks the pair kernel or the two passes by shape, + split-sum launch)",
+                 SC, T * (12 + 8 * D),
+                 [call("cnf_encoder_forward_bwd_cpl", P(cats[r]), P(zs[r]), P(table), P(prior), None, 1.0, P(cpls[r]), P(gz[r]), P(gl), P(g_table), P(wsb),
+                       B, N, D, C, float(ops.LOGISTIC_SIGMA), float(ops.LOGISTIC_LOG_SIGMA), st) for r in range(R)], bound="valu")
+        pair = 9 <= C <= 64 and ((192 // C) * C * 100 >= 192 * 84 or T <= 131072)      # pair_kernel_preferred, cnf_encoder_bwd_tiled.hip
+        rows[-1]["valu_frac"] = slots * (120e-9 if pair else 262e-9) / (ms * 1e-3)
+        rows[-1]["route"] = "pair kernel" if pair else "two passes"
+        del cpls
     del zs, nn2, gz, o1, o2, us_
 
     # ---- mixture-CDF coupling: configs[1] and S*, fp32 default and the reference's fp64 (math mode 0) ----------------------

@@ -65,6 +65,7 @@ SIGNATURES = {
     "cnf_ext_actnorm_bwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "cnf_actnorm_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "cnf_invconv_lu_weight": [_p, _p, _p, _p, _p, _p, _p, _i, _p],
+    "cnf_invconv_lu_weight_inv": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _p],
     "cnf_invconv_lu_weight_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p],
     "cnf_actnorm_invconv_bwd": [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     "cnf_invconv_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
@@ -76,6 +77,7 @@ SIGNATURES = {
     "cnf_mixture_coupling_bwd_f32": [_p, _p, _p, _p, _p, _i, _i, _p, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p,
                                      _i, _i, _i, _i, _d, _d, _i, _p],
     "cnf_encoder_forward_bwd": [_p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
+    "cnf_bwd_defer_flush": [_p],
     "cnf_encoder_forward_bwd_tiled": [_p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
     "cnf_encoder_forward_bwd_cpl": [_p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
     "cnf_affine_params_bwd": [_p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _i, _i, _i, _p],
@@ -91,7 +93,7 @@ _PLAIN = {"cnf_abi_version": ([], _i), "cnf_last_error": ([], ctypes.c_char_p),
           "cnf_set_tile_chunks": ([_i], None), "cnf_set_unroll": ([_i], None),
           "cnf_set_math_mode": ([_i], None), "cnf_set_inverse_mode": ([_i], None), "cnf_set_mixture_tile": ([_i], None),
           "cnf_set_bwd_tile": ([_i, _i], None), "cnf_set_actnorm_bwd_tiles": ([_i], None), "cnf_set_linear_tiles": ([_i], None), "cnf_set_affine_bwd_tiles": ([_i], None), "cnf_set_mixture_bwd_waves": ([_i], None), "cnf_set_mixture_bwd_prefetch": ([_i], None),
-          "cnf_bwd_workspace_floats": ([_i], _i64),
+          "cnf_bwd_workspace_floats": ([_i], _i64), "cnf_bwd_defer_begin": ([], None),
           "cnf_mixture_workspace_bytes": ([_i], _i64), "cnf_encoder_workspace_floats": ([_i, _i, _i, _i], _i64),
           "cnf_encoder_bwd_tiled_workspace_floats": ([_i, _i, _i, _i], _i64), "cnf_set_mixture_kernel": ([_i], None), "cnf_set_encoder_kernel": ([_i], None), "cnf_set_encoder_bwd_kernel": ([_i], None), "cnf_encoder_pair_launches": ([], _i64),
           "cnf_set_mixture_lanes": ([_i], None), "cnf_set_mixture_split": ([_i], None),

@@ -46,11 +46,11 @@ static std::atomic<int> g_act_bwd_tiles{1}, g_aff_bwd_tiles{1};
 // out_b (either may be null): the parameter-gradient tensors are written directly.  One workgroup of 1024 threads per
 // column; a thread's (up to 16) loads are all issued before the first add — the launch is one memory round trip long.
 constexpr int kReduceBlock = 1024;
-__global__ __launch_bounds__(kReduceBlock) void bwd_reduce_partials_kernel(const float* partials, int nrows, int P, float* out_a,
-                                                                          float* out_b, int split, int extra, int extra_from) {
-    // extra >= 0: column `extra` is added to every column >= extra_from (ActNorm's log-det term belongs to every d scales[d])
+// one output column: extra >= 0: column `extra` is added to every column >= extra_from (ActNorm's log-det term belongs to
+// every d scales[d])
+__device__ __forceinline__ void reduce_column(const float* partials, int nrows, float* out_a, float* out_b, int split, int extra,
+                                              int extra_from, int p) {
     constexpr int K = kBwdMaxRows / kReduceBlock;
-    const int p = blockIdx.x;
     const bool with_extra = extra >= 0 && p >= extra_from;
     float v[K], w[K];
 #pragma unroll
@@ -76,6 +76,66 @@ __global__ __launch_bounds__(kReduceBlock) void bwd_reduce_partials_kernel(const
             out_b[p - split] = (float)t;
         }
     }
+}
+__global__ __launch_bounds__(kReduceBlock) void bwd_reduce_partials_kernel(const float* partials, int nrows, int P, float* out_a,
+                                                                          float* out_b, int split, int extra, int extra_from) {
+    (void)P;
+    reduce_column(partials, nrows, out_a, out_b, split, extra, extra_from, blockIdx.x);
+}
+
+// ---- deferred reductions (cnf_bwd_defer_begin / cnf_bwd_defer_flush) ------------------------------------------------------
+// Every streaming backward entry point ends with the small dependent launch above: ~4.7 us as the caller sees it (two
+// launch gaps and one memory round trip for a few KB of partials), 18.6 instead of 14.8 us for the ActNorm backward.  A host
+// that owns a whole backward pass can collect those reductions and run them as ONE launch: between begin and flush the entry
+// points only write their partial rows (each call needs its OWN workspace, alive until the flush) and queue a job; the flush
+// launches one workgroup per output column of every job.  Same kernel body, same summation order: the gradients are the
+// bits of the immediate reductions.  The job table travels in the kernel arguments.
+struct ReduceJob {
+    const float* partials;
+    float* out_a;
+    float* out_b;
+    int nrows, split, extra, extra_from;
+    int col0, cols;                     // this job's workgroups are [col0, col0 + cols)
+};
+constexpr int kMaxReduceJobs = 24;
+struct ReduceJobs {
+    int n;
+    ReduceJob j[kMaxReduceJobs];
+};
+__global__ __launch_bounds__(kReduceBlock) void bwd_reduce_jobs_kernel(ReduceJobs jobs) {
+    int k = 0;
+    while (k + 1 < jobs.n && (int)blockIdx.x >= jobs.j[k + 1].col0) ++k;
+    const ReduceJob& jb = jobs.j[k];
+    reduce_column(jb.partials, jb.nrows, jb.out_a, jb.out_b, jb.split, jb.extra, jb.extra_from, (int)blockIdx.x - jb.col0);
+}
+struct DeferState {
+    bool on = false;
+    ReduceJobs jobs;
+};
+static thread_local DeferState g_defer;
+static void flush_reduce_jobs(hipStream_t st) {
+    ReduceJobs& q = g_defer.jobs;
+    if (q.n > 0) {
+        const int total = q.j[q.n - 1].col0 + q.j[q.n - 1].cols;
+        CNF_LAUNCH(bwd_reduce_jobs_kernel, dim3(total), dim3(kReduceBlock), 0, st, q);
+        q.n = 0;
+    }
+}
+// the closing reduction of an entry point: now, or queued for cnf_bwd_defer_flush
+static void enqueue_reduce(int cols, const float* partials, int nrows, int P, float* out_a, float* out_b, int split, int extra,
+                           int extra_from, hipStream_t st) {
+    if (!g_defer.on) {
+        CNF_LAUNCH(bwd_reduce_partials_kernel, dim3(cols), dim3(kReduceBlock), 0, st, partials, nrows, P, out_a, out_b, split, extra, extra_from);
+        return;
+    }
+    ReduceJobs& q = g_defer.jobs;
+    if (q.n == kMaxReduceJobs) flush_reduce_jobs(st);
+    ReduceJob& jb = q.j[q.n];
+    jb.partials = partials; jb.out_a = out_a; jb.out_b = out_b;
+    jb.nrows = nrows; jb.split = split; jb.extra = extra; jb.extra_from = extra_from;
+    jb.col0 = q.n ? q.j[q.n - 1].col0 + q.j[q.n - 1].cols : 0;
+    jb.cols = cols;
+    ++q.n;
 }
 
 // ---- fixed-order cross-lane sums on the DPP network (no LDS round trip, no ds_bpermute) --------------------------------
@@ -1444,50 +1504,10 @@ struct ActConvBwdArgs {
     long ntok;
     int B, N, D;
 };
-// W^-1 in fp64 (Gauss-Jordan, partial pivoting) by one wave: lane (r, c) owns entry [r][c] of W and of the inverse being built.
-// The reference inverts in double as well (permutation_layers.py:76: torch.inverse(weight.double()).float()).
+// W^-1 in fp64 by one wave (small_inverse_wg, cnf_common.h)
 __global__ __launch_bounds__(kWave) void small_inverse_kernel(const float* w, float* w_inv, int D) {
     __shared__ double A[8][17];
-    const int r = threadIdx.x >> 3, c = threadIdx.x & 7;
-    const bool live = r < D && c < D;
-    if (live) {
-        A[r][c] = (double)w[r * D + c];
-        A[r][8 + c] = r == c ? 1.0 : 0.0;
-    }
-    __syncthreads();
-    for (int k = 0; k < D; ++k) {
-        int piv = k;
-        double best = fabs(A[k][k]);
-        for (int row = k + 1; row < D; ++row) {
-            const double v = fabs(A[row][k]);
-            if (v > best) {
-                best = v;
-                piv = row;
-            }
-        }
-        const double k0 = live ? A[k][c] : 0.0, k1 = live ? A[k][8 + c] : 0.0;
-        const double p0 = live ? A[piv][c] : 0.0, p1 = live ? A[piv][8 + c] : 0.0;
-        __syncthreads();
-        if (r == 0 && c < D && piv != k) {
-            A[k][c] = p0; A[k][8 + c] = p1;
-            A[piv][c] = k0; A[piv][8 + c] = k1;
-        }
-        __syncthreads();
-        double n0 = 0.0, n1 = 0.0;
-        if (live) {
-            const double pv = A[k][k];
-            const double q0 = A[k][c] / pv, q1 = A[k][8 + c] / pv, f = A[r][k];
-            n0 = r == k ? q0 : A[r][c] - f * q0;
-            n1 = r == k ? q1 : A[r][8 + c] - f * q1;
-        }
-        __syncthreads();
-        if (live) {
-            A[r][c] = n0;
-            A[r][8 + c] = n1;
-        }
-        __syncthreads();
-    }
-    if (live) w_inv[r * D + c] = (float)A[r][8 + c];
+    small_inverse_wg(w, w_inv, D, threadIdx.x, A);
 }
 template <int D, bool FROM_OUT>
 __global__ __launch_bounds__(kBlock) void actconv_bwd_kernel(ActConvBwdArgs a) {
@@ -1753,7 +1773,7 @@ __global__ __launch_bounds__(kBlock) void sigmoid_flow_bwd_kernel(SigBwdArgs a, 
 
 // rows = waves of the launch that wrote the partials
 static int reduce_partials(const float* partials, int rows, int P, float* out, hipStream_t st) {
-    CNF_LAUNCH(bwd_reduce_partials_kernel, dim3(P), dim3(kReduceBlock), 0, st, partials, rows, P, out, (float*)nullptr, P, -1, 0);
+    enqueue_reduce(P, partials, rows, P, out, (float*)nullptr, P, -1, 0, st);
     return CNF_OK;
 }
 // chunks in flight per lane / chunk groups per wave: the knob (cnf_set_bwd_tile) when set, else the kernel's own default
@@ -1816,6 +1836,16 @@ extern "C" {
  * `param_count` (+ 1) partial sums — one per wave of the streaming kernels of this file (their rows are at most
  * kBwdMaxRowP wide), one per workgroup (at most 1024, twice for the mixture kernel and its fix-up launch) for the
  * mixture / encoder kernels — + one reduced row + the fix-up launch's flag words */
+void cnf_bwd_defer_begin(void) {
+    g_defer.on = true;
+    g_defer.jobs.n = 0;
+}
+int cnf_bwd_defer_flush(cnf_stream_t stream) {
+    flush_reduce_jobs((hipStream_t)stream);
+    g_defer.on = false;
+    return launch_status("cnf_bwd_defer_flush");
+}
+
 int64_t cnf_bwd_workspace_floats(int param_count) {
     // wide rows: 1024 partial rows + 1024 rows of the mixture fix-up launch + its 5 x 1024 flag words
     return (int64_t)((param_count <= kBwdMaxRowP ? kBwdMaxRows : 2048) + 1) * (param_count + 1) + 8192;
@@ -2015,8 +2045,7 @@ int cnf_actnorm_bwd(const float* z_out, const float* bias, const float* scales,
         break;
         switch (D) { ACT_T(1) ACT_T(2) ACT_T(3) ACT_T(4) ACT_T(5) ACT_T(6) ACT_T(8) }
 #undef ACT_T
-        CNF_LAUNCH(bwd_reduce_partials_kernel, dim3(2 * D), dim3(kReduceBlock), 0, st, workspace, (int)tgrid.x * kWavesPerBlock, 2 * D + 1,
-                   g_bias, g_scales, D, g_ldj ? 2 * D : -1, D);
+        enqueue_reduce(2 * D, workspace, (int)tgrid.x * kWavesPerBlock, 2 * D + 1, g_bias, g_scales, D, g_ldj ? 2 * D : -1, D, st);
         return launch_status("cnf_actnorm_bwd");
     }
     // two groups per wave: the wave's closing reduction of its 2D + 1 sums weighs as much as one group's arithmetic
@@ -2036,8 +2065,7 @@ int cnf_actnorm_bwd(const float* z_out, const float* bias, const float* scales,
 #undef ACT_BWD
     });
     // partial rows are [d bias (D) | d scales (D) | log-det term]: summed straight into the two gradient tensors
-    CNF_LAUNCH(bwd_reduce_partials_kernel, dim3(2 * D), dim3(kReduceBlock), 0, st, workspace, (int)grid.x * kWavesPerBlock, 2 * D + 1,
-               g_bias, g_scales, D, g_ldj ? 2 * D : -1, D);
+    enqueue_reduce(2 * D, workspace, (int)grid.x * kWavesPerBlock, 2 * D + 1, g_bias, g_scales, D, g_ldj ? 2 * D : -1, D, st);
     return launch_status("cnf_actnorm_bwd");
 }
 
@@ -2072,7 +2100,7 @@ int cnf_invconv_bwd(const float* x, const float* weight, const float* pad, const
             grid = dim3((unsigned)std::min<long>(std::max<long>((a.ntok * D + kBlock - 1) / kBlock, 1), kBwdMaxBlocks));
             CNF_LAUNCH(invconv_bwd_generic_kernel, grid, block, (size_t)P * kBlock * sizeof(float), st, a);
     }
-    CNF_LAUNCH(bwd_reduce_partials_kernel, dim3(P), dim3(kReduceBlock), 0, st, workspace, (int)grid.x * kWavesPerBlock, P, g_weight, g_sldj, D * D, -1, 0);
+    enqueue_reduce(P, workspace, (int)grid.x * kWavesPerBlock, P, g_weight, g_sldj, D * D, -1, 0, st);
     return launch_status("cnf_invconv_bwd");
 }
 
@@ -2110,8 +2138,7 @@ int cnf_actnorm_invconv_bwd(const float* saved, int saved_is_output, const float
     }
 #undef ACB
     // rows [dW | d sldj | d bias | d scales | ActNorm's log-det term] -> g_params [dW | d sldj | d bias | d scales]
-    CNF_LAUNCH(bwd_reduce_partials_kernel, dim3(P - 1), dim3(kReduceBlock), 0, st, workspace, (int)grid.x * kWavesPerBlock, P, g_params,
-               (float*)nullptr, P - 1, g_ldj ? P - 1 : -1, D * D + 1 + D);
+    enqueue_reduce(P - 1, workspace, (int)grid.x * kWavesPerBlock, P, g_params, (float*)nullptr, P - 1, g_ldj ? P - 1 : -1, D * D + 1 + D, st);
     return launch_status("cnf_actnorm_invconv_bwd");
 }
 

@@ -297,6 +297,54 @@ constexpr int kAccStride = 16;  // int64 words between two of the 64 batch-sum a
 // softplus(v) + softplus(-v) = |v| + 2 log(1 + e^{-|v|}), one exp and one log instead of two each,
 // with the constants folded on the host: a = 1/sigma, a2 = log2(e)/sigma; the hardware
 // exp2 / log2 are used directly (no range-scaling code, no fp32 division): 8 VALU instructions per element
+// W^-1 of a D x D matrix, D <= 8, in fp64 (Gauss-Jordan, partial pivoting): threads tid < 64 of the workgroup work — lane
+// (r, c) = (tid >> 3, tid & 7) owns entry [r][c] of W and of the inverse being built — and EVERY thread of the workgroup must
+// call it (barriers inside).  A: [8][17] doubles of LDS.  The reference inverts in double as well (permutation_layers.py:76:
+// torch.inverse(weight.double()).float()).  One body for cnf_actnorm_invconv_bwd's own inverse launch and for the LU weight
+// assembly's by-product (cnf_invconv_lu_weight_inv): the same bits.
+__device__ __forceinline__ void small_inverse_wg(const float* w, float* w_inv, int D, int tid, double (*A)[17]) {
+    const int r = tid >> 3, c = tid & 7;
+    const bool live = tid < 64 && r < D && c < D;
+    if (live) {
+        A[r][c] = (double)w[r * D + c];
+        A[r][8 + c] = r == c ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    for (int k = 0; k < D; ++k) {
+        int piv = k;
+        double best = fabs(A[k][k]);
+        for (int row = k + 1; row < D; ++row) {
+            const double v = fabs(A[row][k]);
+            if (v > best) {
+                best = v;
+                piv = row;
+            }
+        }
+        const double k0 = live ? A[k][c] : 0.0, k1 = live ? A[k][8 + c] : 0.0;
+        const double p0 = live ? A[piv][c] : 0.0, p1 = live ? A[piv][8 + c] : 0.0;
+        __syncthreads();
+        if (tid < 64 && r == 0 && c < D && piv != k) {
+            A[k][c] = p0; A[k][8 + c] = p1;
+            A[piv][c] = k0; A[piv][8 + c] = k1;
+        }
+        __syncthreads();
+        double n0 = 0.0, n1 = 0.0;
+        if (live) {
+            const double pv = A[k][k];
+            const double q0 = A[k][c] / pv, q1 = A[k][8 + c] / pv, f = A[r][k];
+            n0 = r == k ? q0 : A[r][c] - f * q0;
+            n1 = r == k ? q1 : A[r][8 + c] - f * q1;
+        }
+        __syncthreads();
+        if (live) {
+            A[r][c] = n0;
+            A[r][8 + c] = n1;
+        }
+        __syncthreads();
+    }
+    if (live) w_inv[r * D + c] = (float)A[r][8 + c];
+}
+
 struct PriorConst {
     float inv_sigma, inv_sigma_log2e, log_sigma;
 };

@@ -860,13 +860,17 @@ static bool pair_shape_ok(long ntok, int D, int C) {
     return C <= kPairMaxC && ntok < (1l << 31) && (D <= 4 || D == 6 || D == 8);
 }
 // Where the pair kernel wins (profiles/r05_encoder_bwd_sweep.txt, one MI355X): with the forward's class_prob_log at 9 ... 64
-// classes whatever the token count (16 classes: 94 vs 117 us at 10^6 tokens, 14 vs 21 at 4096) and at every class count up to
+// classes (16 classes: 94 vs 117 us at 10^6 tokens, 14 vs 21 at 4096; 42: 239 vs 299) and at every class count up to
 // 16 384 tokens (the two passes cost 17 ... 110 us there whatever the size, the pair kernel 14 ... 42); without it (the pre-pass
 // repeats the forward's density sum) only on small batches of 16 classes or more.  Elsewhere the two passes: beyond 64 classes
 // the pair lanes' workgroup holds too few tokens per stage, below 9 the class sums in the token lanes' registers are cheaper.
 static bool pair_kernel_preferred(long ntok, int C, bool have_cpl) {
-    if (have_cpl) return (C >= 9 && C <= 64) || ntok <= 16384;
-    return ntok <= 16384 && C >= 16;
+    if (ntok <= 16384) return have_cpl || C >= 16;
+    if (!have_cpl || C < 9 || C > 64) return false;
+    // large batches: only where the class count fills the 192 pair lanes (51 classes: 3 x 51 = 153 lanes, 328 vs 320 us at
+    // 10^6 tokens, but 40 vs 44 at 65 536)
+    const int lanes = (kPairMaxC / C) * C;
+    return lanes * 100 >= kPairMaxC * 84 || ntok <= 131072;
 }
 static size_t make_pairs_geom(long ntok, int D, int C, int U, int pair_lanes, PairsGeom& g, int resident_per_cu = 0) {
     int rs = (C + 1) & ~1;

@@ -378,9 +378,13 @@ __device__ __forceinline__ void lu_factors(const float* l, const float* u, const
         Up[r][c] = (c > r ? u[r * D + c] : 0.f) + (r == c ? sign_s[r] * expf(log_s[r]) : 0.f);
     }
 }
+// w_inv_out (optional, D <= 8): W^-1 as cnf_actnorm_invconv_bwd would compute it in a launch of its own (small_inverse_wg:
+// the same bits) — the backward of a fused group that kept only its OUTPUT takes it from here
 __global__ __launch_bounds__(kLuMax * kLuMax) void lu_weight_kernel(const float* p, const float* l, const float* u, const float* log_s,
-                                                                    const float* sign_s, float* w_out, float* sldj_out, int D) {
+                                                                    const float* sign_s, float* w_out, float* sldj_out, float* w_inv_out, int D) {
     __shared__ float Lo[kLuMax][kLuMax + 1], Up[kLuMax][kLuMax + 1], M[kLuMax][kLuMax + 1];
+    __shared__ float Wd[64];
+    __shared__ double Ainv[8][17];
     const int r = threadIdx.x / kLuMax, c = threadIdx.x % kLuMax;
     const bool live = r < D && c < D;
     lu_factors(l, u, log_s, sign_s, D, r, c, Lo, Up);
@@ -395,11 +399,16 @@ __global__ __launch_bounds__(kLuMax * kLuMax) void lu_weight_kernel(const float*
         float w = 0.f;
         for (int k = 0; k < D; ++k) w = fmaf(p[r * D + k], M[k][c], w);
         w_out[r * D + c] = w;
+        if (w_inv_out) Wd[r * D + c] = w;
     }
     if (threadIdx.x == 0) {
         float t = 0.f;
         for (int i = 0; i < D; ++i) t += log_s[i];
         sldj_out[0] = t;
+    }
+    if (w_inv_out) {                        // workgroup-uniform
+        __syncthreads();
+        small_inverse_wg(Wd, w_inv_out, D, threadIdx.x, Ainv);
     }
 }
 // g_l = (P^T g_W U^T) o tril(-1), g_u = (L^T P^T g_W) o triu(1), g_log_s[i] = (L^T P^T g_W)[i][i] sign_s[i] e^log_s[i] + g_sldj
@@ -560,8 +569,20 @@ int cnf_invconv_lu_weight(const float* p, const float* l, const float* u, const 
         set_error("cnf_invconv_lu_weight: built for D <= %d (got %d)", kLuMax, D);
         return CNF_ERR_UNSUPPORTED;
     }
-    CNF_LAUNCH(lu_weight_kernel, dim3(1), dim3(kLuMax * kLuMax), 0, (hipStream_t)stream, p, l, u, log_s, sign_s, weight_out, sldj_out, D);
+    CNF_LAUNCH(lu_weight_kernel, dim3(1), dim3(kLuMax * kLuMax), 0, (hipStream_t)stream, p, l, u, log_s, sign_s, weight_out, sldj_out, (float*)nullptr, D);
     return launch_status("cnf_invconv_lu_weight");
+}
+
+int cnf_invconv_lu_weight_inv(const float* p, const float* l, const float* u, const float* log_s, const float* sign_s,
+                              float* weight_out, float* sldj_out, float* weight_inv_out, int D, cnf_stream_t stream) {
+    CNF_REQUIRE(p && l && u && log_s && sign_s && weight_out && sldj_out && weight_inv_out, "cnf_invconv_lu_weight_inv: null tensor");
+    CNF_REQUIRE(D > 0, "cnf_invconv_lu_weight_inv: bad shape");
+    if (D > 8) {
+        set_error("cnf_invconv_lu_weight_inv: the inverse is built for D <= 8 (got %d)", D);
+        return CNF_ERR_UNSUPPORTED;
+    }
+    CNF_LAUNCH(lu_weight_kernel, dim3(1), dim3(kLuMax * kLuMax), 0, (hipStream_t)stream, p, l, u, log_s, sign_s, weight_out, sldj_out, weight_inv_out, D);
+    return launch_status("cnf_invconv_lu_weight_inv");
 }
 
 int cnf_invconv_lu_weight_bwd(const float* p, const float* l, const float* u, const float* log_s, const float* sign_s,

@@ -205,8 +205,15 @@ class InvConvFn(torch.autograd.Function):
         return g_x, g_w, g_s.view_as(sldj), (g_ldj if ctx.has_ldj else None), None, None, None
 
 
-def _actconv_bwd(saved, saved_is_output, bias, scales, weight, length, pad, g_zout, g_ldj, hold):
-    """One launch of cnf_actnorm_invconv_bwd: (g_z, g_bias, g_scales, g_weight, g_sldj [1])."""
+def _known_inverse(weight):
+    """W^-1 computed next to W by the LU weight assembly (InvertibleConv._build_weight stores it on the tensor), or None."""
+    inv = getattr(weight, "_cnf_inverse", None)
+    return inv if isinstance(inv, torch.Tensor) and inv.shape == weight.shape and inv.device == weight.device else None
+
+
+def _actconv_bwd(saved, saved_is_output, bias, scales, weight, length, pad, g_zout, g_ldj, hold, weight_inv=None):
+    """One launch of cnf_actnorm_invconv_bwd: (g_z, g_bias, g_scales, g_weight, g_sldj [1]).  weight_inv (with
+    saved_is_output): W^-1 from the LU weight assembly; without it the library inverts W in a launch of its own."""
     dev = saved.device
     B, N, D = saved.shape
     sv, wc = _f32(saved, "z"), _f32(weight, "weight")
@@ -216,7 +223,8 @@ def _actconv_bwd(saved, saved_is_output, bias, scales, weight, length, pad, g_zo
     g_z = torch.empty_like(sv)
     g_p = torch.empty(D * D + 1 + 2 * D, dtype=torch.float32, device=dev)
     ws = _ws(D * D + 2 * D + 2, dev)
-    status = _launch(dev, "cnf_actnorm_invconv_bwd", _ptr(sv), int(bool(saved_is_output)), _ptr(bias_c), _ptr(scales_c), _ptr(wc), None,
+    wi = _f32(weight_inv, "weight_inv") if (saved_is_output and weight_inv is not None and weight_inv.numel() == D * D) else None
+    status = _launch(dev, "cnf_actnorm_invconv_bwd", _ptr(sv), int(bool(saved_is_output)), _ptr(bias_c), _ptr(scales_c), _ptr(wc), _ptr(wi),
                      _ptr(p2), _ptr(ln), hold(g_zout), hold(g_ldj), _ptr(g_z), _ptr(g_p), _ptr(ws), B, N, D, _stream(dev),
                      allow_unsupported=True)
     if status != _lib.CNF_OK:              # D outside {1..6, 8}: the fused forward kernels do not exist there either
@@ -262,9 +270,11 @@ class MixtureActConvFn(torch.autograd.Function):
                                                          reg_max=reg_max, reg_factor=reg_factor, is_training=is_training, ldj=ldj,
                                                          want_reg=False)
         empty = z_out.new_empty(0)
+        inv = _known_inverse(weight)
         ctx.save_for_backward(z, nn_out, sf if sf is not None else empty, msf if msf is not None else empty,
                               mask if mask is not None else empty, pad if isinstance(pad, torch.Tensor) else empty,
-                              length if isinstance(length, torch.Tensor) else empty, z_out, bias, scales, weight)
+                              length if isinstance(length, torch.Tensor) else empty, z_out, bias, scales, weight,
+                              inv if inv is not None else empty)
         ctx.flags = (sf is not None, msf is not None, mask is not None, isinstance(pad, torch.Tensor), ldj is not None,
                      isinstance(length, torch.Tensor))
         ctx.cfg = (int(K), float(reg_max), float(reg_factor), bool(is_training))
@@ -274,11 +284,11 @@ class MixtureActConvFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_zout, g_ldj):
         hold = _Hold()
-        z, nn_out, sf, msf, mask, pad, length, z_out, bias, scales, weight = ctx.saved_tensors
+        z, nn_out, sf, msf, mask, pad, length, z_out, bias, scales, weight, inv = ctx.saved_tensors
         has_sf, has_msf, has_mask, has_pad, has_ldj, has_len = ctx.flags
         K, reg_max, reg_factor, is_training = ctx.cfg
         pad_t, len_t = (pad if has_pad else None), (length if has_len else None)
-        g_zc, g_b, g_s, g_w, g_sl = _actconv_bwd(z_out, True, bias, scales, weight, len_t, pad_t, g_zout, g_ldj, hold)
+        g_zc, g_b, g_s, g_w, g_sl = _actconv_bwd(z_out, True, bias, scales, weight, len_t, pad_t, g_zout, g_ldj, hold, weight_inv=inv)
         g_z, g_nn, g_sf, g_msf = _mixture_bwd(z, nn_out, sf if has_sf else None, msf if has_msf else None, mask if has_mask else None,
                                               pad_t, g_zc, g_ldj, K, reg_max, reg_factor, is_training, True, True, hold)
         return (g_z, g_nn, g_sf, g_msf, g_b, g_s, g_w, g_sl.view(ctx.sldj_shape), (g_ldj if has_ldj else None),
@@ -298,8 +308,10 @@ class EncoderActConvFn(torch.autograd.Function):
                                                           channel_padding_mask=pad, length=length, ldj=ldj, uniform_squeeze=squeeze,
                                                           want_class_prob=True)
         empty = z_out.new_empty(0)
+        inv = _known_inverse(weight)
         ctx.save_for_backward(table, categ, uniform, prior, pad if isinstance(pad, torch.Tensor) else empty,
-                              length if isinstance(length, torch.Tensor) else empty, z_out, bias, scales, weight, cpl)
+                              length if isinstance(length, torch.Tensor) else empty, z_out, bias, scales, weight, cpl,
+                              inv if inv is not None else empty)
         ctx.has_pad, ctx.has_len, ctx.has_ldj = isinstance(pad, torch.Tensor), isinstance(length, torch.Tensor), ldj is not None
         ctx.beta, ctx.squeeze, ctx.sldj_shape = float(beta), float(squeeze), sldj.shape
         return z_out, ldj_out
@@ -307,9 +319,9 @@ class EncoderActConvFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_zout, g_ldj):
         hold = _Hold()
-        table, categ, uniform, prior, pad, length, z_out, bias, scales, weight, cpl = ctx.saved_tensors
+        table, categ, uniform, prior, pad, length, z_out, bias, scales, weight, cpl, inv = ctx.saved_tensors
         pad_t, len_t = (pad if ctx.has_pad else None), (length if ctx.has_len else None)
-        g_ze, g_b, g_s, g_w, g_sl = _actconv_bwd(z_out, True, bias, scales, weight, len_t, pad_t, g_zout, g_ldj, hold)
+        g_ze, g_b, g_s, g_w, g_sl = _actconv_bwd(z_out, True, bias, scales, weight, len_t, pad_t, g_zout, g_ldj, hold, weight_inv=inv)
         dev = table.device
         B, N = categ.shape
         C, D = table.shape[0], table.shape[1] // 2
@@ -336,12 +348,21 @@ class LUWeightFn(torch.autograd.Function):
         lc, uc, sc, pc, gc = (_f32(t, n) for t, n in ((l, "l"), (u, "u"), (log_s, "log_s"), (p, "p"), (sign_s, "sign_s")))
         w = torch.empty(D, D, dtype=torch.float32, device=dev)
         sldj = torch.empty(1, dtype=torch.float32, device=dev)
-        _launch(dev, "cnf_invconv_lu_weight", _ptr(pc), _ptr(lc), _ptr(uc), _ptr(sc), _ptr(gc), _ptr(w), _ptr(sldj), D, _stream(dev))
+        if D <= 8:
+            # W^-1 rides along (third output, not differentiable): the backward of a fused group that kept only its output
+            # (cnf_actnorm_invconv_bwd, saved_is_output = 1) needs it and would otherwise spend a launch on it
+            w_inv = torch.empty(D, D, dtype=torch.float32, device=dev)
+            _launch(dev, "cnf_invconv_lu_weight_inv", _ptr(pc), _ptr(lc), _ptr(uc), _ptr(sc), _ptr(gc), _ptr(w), _ptr(sldj), _ptr(w_inv), D,
+                    _stream(dev))
+        else:
+            w_inv = w.new_empty(0)
+            _launch(dev, "cnf_invconv_lu_weight", _ptr(pc), _ptr(lc), _ptr(uc), _ptr(sc), _ptr(gc), _ptr(w), _ptr(sldj), D, _stream(dev))
         ctx.save_for_backward(lc, uc, sc, pc, gc)
-        return w, sldj.reshape(())
+        ctx.mark_non_differentiable(w_inv)
+        return w, sldj.reshape(()), w_inv
 
     @staticmethod
-    def backward(ctx, g_w, g_sldj):
+    def backward(ctx, g_w, g_sldj, _g_inv):
         hold = _Hold()
         l, u, log_s, p, sign_s = ctx.saved_tensors
         dev = l.device

@@ -54,7 +54,10 @@ class InvertibleConv(FlowLayer):
             return self.weight, torch.slogdet(self.weight)[1]
         if self.l.is_cuda and self.num_channels <= ops.LU_WEIGHT_MAX_D and ops.FUSE_LU_WEIGHT:
             # the same matrix and log-det in one launch (and one for the backward): cnf_invconv_lu_weight
-            return Fn.LUWeightFn.apply(self.l, self.u, self.log_s, self.p, self.sign_s)
+            weight, sldj, inverse = Fn.LUWeightFn.apply(self.l, self.u, self.log_s, self.p, self.sign_s)
+            if inverse.numel():
+                weight._cnf_inverse = inverse             # picked up by the fused groups' backward (functional._known_inverse)
+            return weight, sldj
         lower = self.l * self.l_mask + self.eye
         upper = self.u * self.l_mask.transpose(0, 1).contiguous() + torch.diag(self.sign_s * torch.exp(self.log_s))
         return torch.matmul(self.p, torch.matmul(lower, upper)), self.log_s.sum()

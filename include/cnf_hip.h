@@ -182,6 +182,11 @@ int cnf_invconv(const float* x, const float* weight, const float* sldj,
  * else CNF_ERR_UNSUPPORTED (the caller assembles the weight from tensor ops as the reference does). */
 int cnf_invconv_lu_weight(const float* p, const float* l, const float* u, const float* log_s, const float* sign_s,
                           float* weight_out, float* sldj_out, int D, cnf_stream_t stream);
+/* cnf_invconv_lu_weight that also hands out W^-1 [D,D] (fp64 Gauss-Jordan, rounded to fp32: permutation_layers.py:76), D <= 8:
+ * the bits cnf_actnorm_invconv_bwd(saved_is_output = 1, weight_inv = NULL) computes in a launch of its own — pass it there
+ * as weight_inv and that launch disappears. */
+int cnf_invconv_lu_weight_inv(const float* p, const float* l, const float* u, const float* log_s, const float* sign_s,
+                              float* weight_out, float* sldj_out, float* weight_inv_out, int D, cnf_stream_t stream);
 int cnf_invconv_lu_weight_bwd(const float* p, const float* l, const float* u, const float* log_s, const float* sign_s,
                               const float* g_weight, const float* g_sldj, float* g_l, float* g_u, float* g_log_s, int D,
                               cnf_stream_t stream);
@@ -474,6 +479,15 @@ int cnf_sigmoid_flow(const float* z, const float* ldj_in, float* z_out, float* l
  * `workspace` with cnf_bwd_workspace_floats(P) floats (P = number of parameter entries of that call); the
  * sum is formed in fp64 in a fixed order (deterministic). */
 int64_t cnf_bwd_workspace_floats(int param_count);
+/* Deferred reductions, for a host that owns a whole backward pass (general/train.py:144-155 `loss.backward()` as one unit).
+ * Between cnf_bwd_defer_begin() and cnf_bwd_defer_flush(stream) — host-thread local — cnf_affine_coupling_bwd,
+ * cnf_affine_params_bwd, cnf_actnorm_bwd, cnf_invconv_bwd and cnf_actnorm_invconv_bwd only write their partial rows and queue
+ * their closing reduction; the flush runs all of them as ONE launch on `stream` (the stream of the calls).  Every call in
+ * between needs its OWN workspace, alive until the flush, and its parameter-gradient outputs hold nothing before it.  The
+ * gradients are the bits of the immediate reductions.  (PyTorch's autograd consumes a node's parameter gradients before the
+ * next node runs — the LU weight assembly reads d loss / d W at once — so the Python host of this repo does not defer.) */
+void cnf_bwd_defer_begin(void);
+int cnf_bwd_defer_flush(cnf_stream_t stream);
 
 /* d(CouplingLayer.forward) (coupling_layer.py:53-63,88-98).  z_out = the forward OUTPUT of the same
  * direction.  g_scaling_factor [D] only when scaling_factor != NULL (P = D). */

@@ -714,3 +714,41 @@ def test_mixture_backward_kernel_variants_agree(B, N, D, K):
     finally:
         lib.cnf_set_mixture_bwd_waves(-1)
         lib.cnf_set_mixture_bwd_prefetch(-1)
+
+
+@pytest.mark.parametrize("D", [1, 2, 3, 4, 6, 8])
+def test_lu_weight_assembly_hands_out_the_inverse_the_fused_backward_needs(D):
+    """cnf_invconv_lu_weight_inv: W and sum log_s of cnf_invconv_lu_weight bit for bit, and W^-1 = the bits of the inverse launch
+    inside cnf_actnorm_invconv_bwd(saved_is_output = 1, weight_inv = NULL) — so the fused pair's backward gives torch.equal
+    gradients whether it inverts W itself or takes the inverse from the weight assembly (permutation_layers.py:61-76)."""
+    from categoricalnf_amd import _lib, functional as Fn
+    from categoricalnf_amd.ops import _ptr as P, _stream
+    from categoricalnf_amd.layers.flows.permutation_layers import InvertibleConv
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    st = _stream(dev)
+    torch.manual_seed(D)
+    np.random.seed(D)
+    layer = InvertibleConv(D).cuda().train()
+    with torch.no_grad():
+        for prm in (layer.l, layer.u, layer.log_s):
+            prm.add_(0.2 * torch.randn_like(prm))
+    w, sldj = layer._build_weight()
+    inv = Fn._known_inverse(w)
+    assert inv is not None and tuple(inv.shape) == (D, D)
+    w0, s0 = torch.empty(D, D, device=dev), torch.empty(1, device=dev)
+    assert lib.cnf_invconv_lu_weight(P(layer.p), P(layer.l), P(layer.u), P(layer.log_s), P(layer.sign_s), P(w0), P(s0), D, st) == 0
+    assert torch.equal(w0, w.detach()) and torch.equal(s0.reshape(()), sldj.detach())
+    ref = torch.inverse(w.detach().double())
+    assert float((inv.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    # the fused pair's backward from the saved OUTPUT: own inverse launch vs the handed-over inverse
+    B, N = 33, 20
+    z_out, gz, gl = torch.randn(B, N, D, device=dev), torch.randn(B, N, D, device=dev), torch.randn(B, device=dev)
+    bias, scales = torch.randn(D, device=dev), 0.1 * torch.randn(D, device=dev)
+    outs = []
+    for wi in (None, inv):
+        hold = Fn._Hold()
+        outs.append(Fn._actconv_bwd(z_out, True, bias, scales, w.detach(), None, None, gz, gl, hold, weight_inv=wi))
+    torch.cuda.synchronize()
+    for a, b in zip(*outs):
+        assert torch.isfinite(a).all() and torch.equal(a, b)

@@ -1901,3 +1901,48 @@ def test_standalone_actnorm_and_invconv_forward_kernels_agree_bit_for_bit(B, N, 
     zo, lo = O.invconv(z, w, sldj, channel_padding_mask=pad, ldj=ldj0.clone())
     zc, lc = ops().invconv(g(z), g(w), g(sldj), channel_padding_mask=g(pad), ldj=g(ldj0).clone())
     close(zc, zo, **ELEM); loglik_close(lc, lo)
+
+
+def test_deferred_reductions_give_the_bits_of_the_immediate_ones():
+    """cnf_bwd_defer_begin / cnf_bwd_defer_flush: the streaming backward entry points queue their closing parameter-gradient
+    reductions, the flush runs them as one launch — same kernel body, same order: torch.equal with the immediate reductions,
+    for every entry point that takes part (general/train.py:144-155: one backward pass, many layers)."""
+    from categoricalnf_amd import _lib
+    from categoricalnf_amd.ops import _ptr as P, _stream
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    st = _stream(dev)
+    B, N, D = 512, 40, 6
+    gen = torch.Generator(device=dev).manual_seed(5)
+    rn = lambda *s, k=1.0: k * torch.randn(*s, generator=gen, device=dev)
+    z, nn, gz, gl = rn(B, N, D), rn(B, N, 2 * D, k=0.5), rn(B, N, D), rn(B)
+    sf, bias, scales = rn(D, k=0.1), rn(D), rn(D, k=0.1)
+    w = torch.linalg.qr(torch.randn(D, D))[0].to(dev).contiguous()
+    ln = torch.randint(N // 2, N + 1, (B,), generator=gen, device=dev).float()
+    from categoricalnf_amd.layers.flows.coupling_layer import CouplingLayer
+    mask = CouplingLayer.create_channel_mask(D).to(dev).contiguous()
+    nws = int(lib.cnf_bwd_workspace_floats(D * D + 2 * D + 2))
+
+    def run(deferred):
+        outs = {k: torch.full((n,), float("nan"), device=dev) for k, n in (("sf", D), ("b", D), ("s", D), ("w", D * D), ("sl", 1), ("par", D * D + 1 + 2 * D), ("par2", D * D + 1 + 2 * D))}
+        o1, o2 = torch.empty(B, N, D, device=dev), torch.empty(B, N, 2 * D, device=dev)
+        ws = [torch.empty(nws, device=dev) for _ in range(5)]
+        if deferred:
+            lib.cnf_bwd_defer_begin()
+        rcs = [lib.cnf_affine_coupling_bwd(P(z), P(nn), P(sf), P(mask), 1, D, P(gz), P(gl), P(o1), P(o2), P(outs["sf"]), P(ws[0]), B, N, D, 0, st),
+               lib.cnf_actnorm_bwd(P(z), P(bias), P(scales), None, P(ln), P(gz), P(gl), P(o1), P(outs["b"]), P(outs["s"]), P(ws[1]), B, N, D, 0, st),
+               lib.cnf_invconv_bwd(P(z), P(w), None, P(ln), P(gz), P(gl), P(o1), P(outs["w"]), P(outs["sl"]), P(ws[2]), B, N, D, 0, st),
+               lib.cnf_actnorm_invconv_bwd(P(z), 0, P(bias), P(scales), P(w), None, None, P(ln), P(gz), P(gl), P(o1), P(outs["par"]), P(ws[3]), B, N, D, st),
+               lib.cnf_actnorm_invconv_bwd(P(z), 1, P(bias), P(scales), P(w), None, None, P(ln), P(gz), P(gl), P(o1), P(outs["par2"]), P(ws[4]), B, N, D, st)]
+        if deferred:
+            rcs.append(lib.cnf_bwd_defer_flush(st))
+        torch.cuda.synchronize()
+        assert all(rc == 0 for rc in rcs), lib.cnf_last_error()
+        return outs
+    now, later = run(False), run(True)
+    for k in now:
+        assert torch.isfinite(later[k]).all(), k
+        assert torch.equal(now[k], later[k]), k
+    # after the flush the library is back to immediate reductions
+    again = run(False)
+    assert all(torch.equal(now[k], again[k]) for k in now)
