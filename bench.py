@@ -837,6 +837,8 @@ def main():
             "gpu_ms_per_step": gpu_loop_ms / args.steps,
             "per_rank_elems_per_s": [elems * args.steps / t for t in per_rank],
             "allreduce_latency_us": allreduce_us,
+            "backend": (("gloo" if args.share_device else args.backend) if world > 1 else None),
+            "share_device": bool(args.share_device),
             "mean_nll": mean_nll,
         }
         if world == 1 and not args.no_cpu_baseline:

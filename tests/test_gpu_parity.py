@@ -608,7 +608,7 @@ def _set_model(meta):
 
 @pytest.mark.parametrize("golden", ["set_shuffling_model.npz", "set_shuffling_trained.npz"])
 def test_set_shuffling_trained_model_bits_per_dim(golden):
-    """A FlowSetModeling trained WITH THE REFERENCE for 4000 CPU iterations (3.59 bpd; oracle/gen_set_shuffling_golden.py)
+    """A FlowSetModeling trained WITH THE REFERENCE for 6000 CPU iterations (CNF_TRAIN_ITERS=6000, 3.59 bpd; oracle/gen_set_shuffling_golden.py)
     and one trained by this package's driver on an MI355X for 50000 iterations (2.94 bpd, sharp mixtures) and evaluated
     by the REFERENCE on the CPU (oracle/gen_set_shuffling_trained_golden.py): same weights on the HIP path must give
     the reference's per-sample log-likelihood (1e-4 relative), decoded indices (bit-exact) and validation bits/dim
@@ -1255,7 +1255,10 @@ def test_scale_sweep_script_rehearses_the_drivers_scaling_run():
                            env=dict(env, SHARE_DEVICE="1", BENCH_FLAGS="--steps 5 --warmup 2 --batch 1024 --prewarm-seconds 0.1 --no-cpu-baseline --no-mixture"))
         assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
         rows = [json.loads(l) for l in open(os.path.join(out, "scale.jsonl"))]
+        table = json.load(open(os.path.join(out, "scale.json")))          # the table for programs
     assert [x["n_gpus"] for x in rows] == [1, 2, 8], r.stdout[-2000:]
+    assert [x["n_gpus"] for x in table["rows"]] == [1, 2, 8] and table["scaling"] == "weak"
+    assert all(x["share_device"] for x in table["rows"]) and table["rows"][1]["backend"] == "gloo" and table["rows"][0]["efficiency"] == 1.0
     for x in rows:
         assert len(x["per_rank_elems_per_s"]) == x["n_gpus"] == len(x["roofline"]["per_rank_kernel_ms"])
         assert all(k > 0 for k in x["roofline"]["per_rank_kernel_ms"])

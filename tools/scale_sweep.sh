@@ -29,9 +29,16 @@ if not rows:
     raise SystemExit("no bench line was produced")
 base = next((r for r in rows if r["n_gpus"] == 1), rows[0])
 print("%4s %14s %10s %10s %12s %14s %s" % ("N", "elems/s", "ms/step", "efficiency", "allreduce us", "kernel us min", "kernel us max"))
+table = []
 for r in rows:
     k = r["roofline"].get("per_rank_kernel_ms") or [r["roofline"]["kernel_ms"]]
     eff = r["value"] / (r["n_gpus"] * base["value"] / base["n_gpus"])
     print("%4d %14.4g %10.4f %10.3f %12s %14.2f %.2f" % (r["n_gpus"], r["value"], r["ms_per_step"], eff,
           "-" if r.get("allreduce_latency_us") is None else "%.1f" % r["allreduce_latency_us"], min(k) * 1e3, max(k) * 1e3))
+    table.append({"n_gpus": r["n_gpus"], "value": r["value"], "unit": r.get("unit"), "ms_per_step": r["ms_per_step"], "efficiency": eff,
+                  "allreduce_latency_us": r.get("allreduce_latency_us"), "kernel_us_min": min(k) * 1e3, "kernel_us_max": max(k) * 1e3,
+                  "backend": r.get("backend"), "share_device": bool(r.get("share_device"))})
+# the same table for programs (weak scaling: per-GPU work fixed; efficiency = value(N) / (N x value(1)))
+import os
+json.dump({"metric": base.get("metric"), "scaling": "weak", "rows": table}, open(os.path.join(os.path.dirname(sys.argv[1]), "scale.json"), "w"), indent=1)
 PY
