@@ -76,7 +76,6 @@ SIGNATURES = {
                                  _i, _i, _i, _i, _d, _d, _i, _p],
     "cnf_mixture_coupling_bwd_f32": [_p, _p, _p, _p, _p, _i, _i, _p, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p,
                                      _i, _i, _i, _i, _d, _d, _i, _p],
-    "cnf_encoder_forward_bwd": [_p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
     "cnf_bwd_defer_flush": [_p],
     "cnf_encoder_forward_bwd_tiled": [_p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
     "cnf_encoder_forward_bwd_cpl": [_p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],

@@ -24,7 +24,7 @@ namespace cnf {
 //       lane whose class IS the token's class adds the record's own-class gradient instead.  Token ranges ("splits")
 //       give the launch enough workgroups; their partial tables are summed in split order by a third tiny kernel, so
 //       the result is bit-reproducible.
-// Notation as in cnf_encoder_bwd.hip: G = d loss / d ldj_tok (x pad), v_j the class scores, q = softmax(v).
+// Notation: G = d loss / d ldj_tok (x pad), v_j the class scores, q = softmax(v).
 struct EncBwdTiledArgs {
     const int64_t* categ;
     const float* eps;

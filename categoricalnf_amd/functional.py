@@ -538,7 +538,7 @@ class EncoderForwardFn(torch.autograd.Function):
         # the backward kernels), see ops.encoder_forward
         # the backward's pair kernel takes every token's denominator from the forward's class_prob_log (4 bytes per token
         # more to write here, a whole sweep over the classes less there): ask for it whenever a gradient can follow
-        keep_cpl = table.requires_grad and tiled is not False
+        keep_cpl = table.requires_grad
         if uniform_squeeze is not None:
             z, ldj, cpl, eps = ops.encoder_forward(categ, eps, table, prior, beta=beta, channel_padding_mask=pad,
                                                    want_class_prob=want_class_prob or keep_cpl, tiled=tiled,
@@ -567,19 +567,13 @@ class EncoderForwardFn(torch.autograd.Function):
         p2 = _pad2d(pad, B, N, dev) if ctx.has_pad else None
         g_table = torch.empty_like(tc)
         categ_c = categ.contiguous()
-        if ctx.tiled is not False or C * 2 * D > ops.ENCODER_BWD_LDS_ENTRIES:
-            # one pass over the (token, class) pairs with the forward's class_prob_log, or the token-lane + class-lane passes
-            # (the library picks by shape): any vocabulary size, bit-reproducible, 4-12x faster than the LDS-table kernel at
-            # 16-160 classes (profiles/r02_encoder_probe.txt); `tiled=False` keeps the latter for A/B tests
-            ws = torch.empty(int(_lib.load().cnf_encoder_bwd_tiled_workspace_floats(B, N, D, C)), dtype=torch.float32, device=dev)
-            _launch(dev, "cnf_encoder_forward_bwd_cpl", _ptr(categ_c), _ptr(ec), _ptr(tc), _ptr(pc), _ptr(p2), ctx.beta,
-                    _ptr(cpl.contiguous()) if ctx.has_cpl else None, hold(g_zout), hold(g_ldj), _ptr(g_table), _ptr(ws), B, N, D, C,
-                    float(ops.LOGISTIC_SIGMA), float(ops.LOGISTIC_LOG_SIGMA), _stream(dev))
-        else:
-            ws = _ws(C * 2 * D, dev)                      # table gradient accumulated in LDS
-            _launch(dev, "cnf_encoder_forward_bwd", _ptr(categ_c), _ptr(ec), _ptr(tc), _ptr(pc), _ptr(p2), ctx.beta,
-                    hold(g_zout), hold(g_ldj), _ptr(g_table), _ptr(ws), B, N, D, C,
-                    float(ops.LOGISTIC_SIGMA), float(ops.LOGISTIC_LOG_SIGMA), _stream(dev))
+        # one pass over the (token, class) pairs with the forward's class_prob_log, or the token-lane + class-lane passes (the
+        # library picks by shape): any vocabulary size, bit-reproducible.  (Round 1's LDS-table kernel with floating-point
+        # atomics — 13x slower at 16 classes, not reproducible — is gone since round 5; `tiled` selects the forward kernel only.)
+        ws = torch.empty(int(_lib.load().cnf_encoder_bwd_tiled_workspace_floats(B, N, D, C)), dtype=torch.float32, device=dev)
+        _launch(dev, "cnf_encoder_forward_bwd_cpl", _ptr(categ_c), _ptr(ec), _ptr(tc), _ptr(pc), _ptr(p2), ctx.beta,
+                _ptr(cpl.contiguous()) if ctx.has_cpl else None, hold(g_zout), hold(g_ldj), _ptr(g_table), _ptr(ws), B, N, D, C,
+                float(ops.LOGISTIC_SIGMA), float(ops.LOGISTIC_LOG_SIGMA), _stream(dev))
         return g_table, None, None, None, None, None, None, None, None
 
 

@@ -623,9 +623,6 @@ def prior_nll(z, ldj, length=None, channel_padding_mask=None, sums=None,
     return neglog, nll
 
 
-ENCODER_BWD_LDS_ENTRIES = 2048      # cnf_encoder_forward_bwd keeps the [C, 2D] gradient table in LDS up to this size
-
-
 def encoder_fused_supported(C, D):
     """Whether the LDS-resident mixture-model encoder kernels (cnf_encoder_forward / cnf_encoder_decode / the backward)
     take this vocabulary: the derived class table [C, 6D+3] and the row partials must fit 64 KiB of LDS, D <= 16

@@ -591,13 +591,8 @@ int cnf_mixture_params_bwd(const float* nn_out, const float* scaling_factor, con
                            int B, int N, int D, int K, cnf_stream_t stream);
 
 /* d(LinearCategoricalEncoding.forward, num_flows == 0) w.r.t. the class table [C,2D] (linear_encoding.py:59-106,
- * 153-174): g_table [C,2D]; workspace = cnf_bwd_workspace_floats(C*2D).  eps / categories / prior are constants. */
-int cnf_encoder_forward_bwd(const int64_t* categ, const float* eps, const float* table,
-                            const float* category_prior, const float* pad, float beta,
-                            const float* g_zout, const float* g_ldj, float* g_table, float* workspace,
-                            int B, int N, int D, int C, float sigma, float log_sigma, cnf_stream_t stream);
-/* The same gradient for tables of any size (required when C * 2D > 2048, e.g. word-level vocabularies): a token-lane
- * pass (log-denominator and d loss / d z per token in one sweep over the class chunks) and a class-lane pass (every
+ * 153-174): g_table [C,2D]; eps / categories / prior are constants.  Tables of any size (word-level vocabularies included):
+ * a token-lane pass (log-denominator and d loss / d z per token in one sweep over the class chunks) and a class-lane pass (every
  * lane owns one class and accumulates its table row over the token records), partial tables summed in a fixed order;
  * no [T*C] tensor, no floating-point atomics, bit-reproducible.  On small batches (up to 16 384 tokens, 16 ... 192 classes,
  * D in {1,2,3,4,6,8}) it repeats the forward's density sum and runs the pair kernel of cnf_encoder_forward_bwd_cpl instead.

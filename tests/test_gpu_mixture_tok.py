@@ -434,3 +434,35 @@ def test_fp32_backward_is_deterministic_and_handles_tails():
         assert torch.equal(fin, torch.isfinite(x)), name
         scale = y[fin].abs().max().item() + 1e-6
         assert (x[fin] - y[fin]).abs().max().item() <= 3e-4 * scale + 2e-5, name
+
+
+@pytest.mark.parametrize("B,N,D,K", [(48, 16, 4, 8), (256, 64, 6, 8), (16, 288, 3, 51)])
+def test_fp64_backward_is_deterministic_too(B, N, D, K):
+    """The reference-precision mixture backward (cnf_mixture_coupling_bwd, kernel 1 / math mode 0) meets its workgroup's
+    parameter-gradient sums in 64-bit fixed-point LDS words (integer atomics: order-independent), so it is bit-reproducible
+    like the fp32 kernels — rounds 1-4 added fp32 with atomicAdd there.  Three runs, torch.equal on every gradient; the
+    split (static API) form through MixtureParamsFn / MixtureTransformFn likewise."""
+    from categoricalnf_amd import functional as Fn
+    z, nn_out, sf, msf, mask, ln, pad = _case(B, N, D, K, "channel", 99 + B)
+    gen = torch.Generator().manual_seed(4)
+    gz, gl = torch.randn(B, N, D, generator=gen), torch.randn(B, generator=gen)
+    ref = _bwd(1, z, nn_out, sf, msf, mask, pad, K, gz, gl, (3.5, 2.0))
+    for _ in range(2):
+        for x, y in zip(ref, _bwd(1, z, nn_out, sf, msf, mask, pad, K, gz, gl, (3.5, 2.0))):
+            assert torch.equal(x, y)
+    # the fixed-point sums cost no accuracy against the fp32 token-pass kernel's fp64 row sums
+    new = _bwd(0, z, nn_out, sf, msf, mask, pad, K, gz, gl, (3.5, 2.0))
+    for name, x, y in zip(("g_sf", "g_msf"), ref[2:], new[2:]):
+        scale = y.abs().max().item() + 1e-6
+        assert (x - y).abs().max().item() <= 3e-4 * scale + 2e-5, name
+
+    def split_grads():
+        nn_ = g(nn_out).requires_grad_(True)
+        sf_, msf_ = g(sf).requires_grad_(True), g(msf).requires_grad_(True)
+        t, log_s, log_pi, mu, ls = Fn.MixtureParamsFn.apply(nn_, sf_, msf_, g(mask), K)
+        torch.autograd.backward([t, log_s, log_pi, mu, ls], [torch.ones_like(t), 0.5 * torch.ones_like(log_s), torch.ones_like(log_pi),
+                                                             0.25 * torch.ones_like(mu), torch.ones_like(ls)])
+        return [x.grad.detach().cpu() for x in (nn_, sf_, msf_)]
+    a = split_grads()
+    for x, y in zip(a, split_grads()):
+        assert torch.equal(x, y)

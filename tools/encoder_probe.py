@@ -62,10 +62,7 @@ for T_B, T_N, C in ((16384, 64, 16), (16384, 64, 51), (4096, 64, 32), (4096, 64,
     for tiled in ((False, None, True) if ops.encoder_fused_supported(C, D) else (True,)):
         f = steady(lambda: ops.encoder_forward(categ, eps, table, prior, tiled=tiled), reps=10)
         d = steady(lambda: ops.encoder_decode(z, table, prior, tiled=tiled), reps=10)
-        if tiled is False and C * 2 * D > ops.ENCODER_BWD_LDS_ENTRIES:
-            fb = float("nan")
-        else:
-            fb = bwd_time(categ, eps, table, prior, tiled)
+        fb = bwd_time(categ, eps, table, prior, tiled)
         row.append("%8.1f /%8.1f /%9.1f" % (f, d, fb))
     evals = T_B * T_N * C * D
     print("T=%8d C=%6d  %s   (%.2f G class-channel evaluations per pass)" % (T_B * T_N, C, "  |  ".join(row), evals / 1e9), flush=True)

@@ -39,7 +39,6 @@ rm -f "$OUT"/prof_layers/*kernel_trace.csv
 timeout 300 python tools/bench_flow_graph.py > "$OUT/flow_graph.txt" 2>&1; tail -6 "$OUT/flow_graph.txt"
 timeout 400 python tools/encoder_probe.py > "$OUT/encoder_probe.txt" 2>&1; tail -7 "$OUT/encoder_probe.txt"
 timeout 300 python tools/encoder_ab.py 2>/dev/null > "$OUT/encoder_ab.txt"; tail -9 "$OUT/encoder_ab.txt" | cut -c1-160
-timeout 200 python tools/encoder_lds_vs_tiled.py 2>/dev/null > "$OUT/encoder_lds_vs_tiled.txt"; tail -3 "$OUT/encoder_lds_vs_tiled.txt"
 timeout 200 python tools/encoder_fused_sampler.py 2>/dev/null > "$OUT/encoder_fused_sampler.txt"; tail -5 "$OUT/encoder_fused_sampler.txt"
 timeout 200 python tools/sustained_probe.py > "$OUT/sustained_probe.txt" 2>&1; tail -6 "$OUT/sustained_probe.txt"
 bash tools/pmc_ceilings.sh ceilings > "$OUT/ceilings.log" 2>&1; tail -10 "$OUT/ceilings.log"
