@@ -11,7 +11,8 @@ a sort of the doubled pair list, compaction of the valid pairs to a flat list an
   * pair features live in the pair list [B, E, C] (E = V (V - 1) / 2, pair p = (i < j)); a [V, V] table of pair indices
     (built once per call from `x_indices`) turns a per-pair quantity into a symmetric [B, V, V, C] view with one gather;
   * "node i attends over its neighbours j" is a masked [V, V] attention per head: `softmax(Q K^T / sqrt(d) + A)` and
-    `P @ V` are batched GEMMs (hipBLASLt / MFMA), the per-pair terms `sum_j P_ij E_ij` one fused multiply-reduce;
+    `P @ V` are batched GEMMs (hipBLASLt / MFMA), the per-pair terms `sum_j P_ij E_ij` a scaling of the pair values in pair
+    space followed by two batched GEMMs with the pair list's constant incidence matrices (all heads at once);
   * invalid pairs / padded nodes are masked, never compacted: no data-dependent shapes, no host syncs, capturable in a
     HIP graph.
 
@@ -62,7 +63,9 @@ def neighbour_mask(mask_valid, table, binary_adjacency=None):
 
 
 class _GraphContext:
-    """What every layer of one EdgeGNN call shares: the pair table, the neighbour mask, the valid-pair mask."""
+    """What every layer of one EdgeGNN call shares: the pair table, the neighbour mask, the valid-pair mask, and the pair
+    list's incidence matrices (which node is a pair's first / second end) with the positions of (i, j) and (j, i) in a
+    flattened [V, V] matrix."""
 
     def __init__(self, x_indices, mask_valid, num_nodes, binary_adjacency=None):
         self.x1, self.x2 = x_indices
@@ -70,6 +73,13 @@ class _GraphContext:
         self.neigh = neighbour_mask(mask_valid, self.table, binary_adjacency)          # [B, V, V]
         self.has_neigh = self.neigh.any(dim=-1)                                         # [B, V]
         self.valid = mask_valid > 0                                                     # [B, E]
+        nodes = torch.arange(num_nodes, device=self.x1.device).unsqueeze(1)
+        dtype = mask_valid.dtype if mask_valid.is_floating_point() else torch.float32
+        self.inc1 = (nodes == self.x1.unsqueeze(0)).to(dtype)                           # [V, E]: inc1[i, p] = 1 iff x1[p] == i
+        self.inc2 = (nodes == self.x2.unsqueeze(0)).to(dtype)
+        self.inc12 = torch.cat([self.inc1, self.inc2], dim=1)                           # [V, 2E]
+        self.flat12 = self.x1 * num_nodes + self.x2                                     # [E]: position of (x1, x2) in [V * V]
+        self.flat21 = self.x2 * num_nodes + self.x1
 
 
 def _context(kwargs, x_indices, mask_valid, num_nodes):
@@ -104,15 +114,20 @@ class _Edge2NodeBase(nn.Module):
     def _heads(self, t, B, n):
         return t.reshape(B, n, self.num_heads, self.hidden_size_per_head)
 
-    def _pair_terms(self, probs, pair_vals, table):
-        """sum_j P[b,h,i,j] * m[b, pair(i,j), h, :] -> [B, V, H, d]: the pair values are gathered head by head so that the
-        dense [B, V, V, d] view exists for one head at a time."""
+    def _pair_terms(self, probs, pair_vals, ctx):
+        """sum_j P[b,h,i,j] * m[b, pair(i,j), h, :] -> [B, V, H, d], in PAIR space: pair p = (i, j) hands P[i,j] m_p to node i
+        and P[j,i] m_p to node j, and "hand to the end node" is a product with the constant incidence matrix — one batched
+        [V, 2E] x [2E, H d] GEMM (MFMA) for all heads and both ends at once.  (Round 4 gathered a dense [B, V, V, d] copy of the pair values
+        per head in a Python loop and contracted it with one-row matrix products: 16x16 / 32x32 GEMM tiles at 2-5 % of the
+        MFMA peak, profiles/r04_mfma_util_molecule.txt.)  The incidence products add exact zeros for every other pair."""
         B, H, V, _ = probs.shape
-        out = []
-        for h in range(H):
-            dense = pairs_to_dense(pair_vals[:, :, h], table)                           # [B, V, V, d]
-            out.append(torch.einsum("bij,bijc->bic", probs[:, h], dense))
-        return torch.stack(out, dim=2)
+        E = pair_vals.size(1)
+        flat = probs.reshape(B, H, V * V)
+        w12 = flat.index_select(2, ctx.flat12).transpose(1, 2).unsqueeze(-1)           # [B, E, H, 1]: P[x1, x2]
+        w21 = flat.index_select(2, ctx.flat21).transpose(1, 2).unsqueeze(-1)           #               P[x2, x1]
+        both = torch.stack([w12, w21], dim=1) * pair_vals.unsqueeze(1)                  # [B, 2, E, H, d]: one pass over the pair values
+        out = torch.matmul(ctx.inc12.to(pair_vals.dtype), both.reshape(B, 2 * E, -1))   # [V, 2E] x [B, 2E, H d]: one GEMM, K = 2E
+        return out.reshape(B, V, H, -1)
 
 
 class Edge2NodeQKVAttnLayer(_Edge2NodeBase):
@@ -146,7 +161,7 @@ class Edge2NodeQKVAttnLayer(_Edge2NodeBase):
         logits = torch.matmul(q, k.transpose(-1, -2)) * self.dot_prod_scaling + pair_bias
         logits = logits.masked_fill(~ctx.neigh.unsqueeze(1), _NEG)
         probs = torch.softmax(logits, dim=-1) * ctx.has_neigh[:, None, :, None].to(logits.dtype)
-        attn = torch.matmul(probs, v).permute(0, 2, 1, 3) + self._pair_terms(probs, pair_val, ctx.table)     # [B, V, H, d]
+        attn = torch.matmul(probs, v).permute(0, 2, 1, 3) + self._pair_terms(probs, pair_val, ctx)     # [B, V, H, d]
         comb = self.act_fn(self.dropout(self.output_projection(torch.cat([h_in, attn.reshape(B, V, -1)], dim=-1))))
         return self.skip_layer(orig=node_feat, feat=comb)
 
@@ -179,7 +194,7 @@ class Edge2NodeAttnLayer(_Edge2NodeBase):
         gate = gate * ctx.neigh.unsqueeze(1).to(gate.dtype)
         probs = gate / gate.sum(dim=-1, keepdim=True).clamp(min=1e-5)
         context = self._heads(context, B, V).permute(0, 2, 1, 3)                          # [B, H, V, d]
-        attn = torch.matmul(probs, context).permute(0, 2, 1, 3) + self._pair_terms(probs, pair_val, ctx.table)
+        attn = torch.matmul(probs, context).permute(0, 2, 1, 3) + self._pair_terms(probs, pair_val, ctx)
         comb = self.act_fn(self.dropout(own + attn.reshape(B, V, self.hidden_size_output)))
         return self.skip_layer(orig=node_feat, feat=comb)
 
@@ -195,7 +210,11 @@ class EdgeGNNLayer(nn.Module):
     def forward(self, node_feat, edge_feat, x_indices, mask_valid, **kwargs):
         node_feat = self.edge2node_layer(node_feat=node_feat, edge_feat=edge_feat, x_indices=x_indices, mask_valid=mask_valid, **kwargs)
         edge_feat = self.node2edge_layer(node_feat=node_feat, edge_feat=edge_feat, x_indices=x_indices, mask_valid=mask_valid, **kwargs)
-        return node_feat, edge_feat * mask_valid.unsqueeze(dim=-1)
+        # (graph_layers.py:262 multiplies by mask_valid here; Node2EdgePlainLayer has just zeroed the invalid pairs — a 0/1
+        # mask applied twice — so only a foreign node2edge layer still needs it)
+        if not isinstance(self.node2edge_layer, Node2EdgePlainLayer):
+            edge_feat = edge_feat * mask_valid.unsqueeze(dim=-1)
+        return node_feat, edge_feat
 
 
 class EdgeGNN(nn.Module):
