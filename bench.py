@@ -209,15 +209,30 @@ def mixture_measure(ops, dev, R=4, reps=50):
             "needed_bytes_per_launch": bytes_needed, "fwd_needed_GBps": bytes_needed / (tf * 1e-3) / 1e9,
             "fwd_needed_hbm_frac": bytes_needed / (tf * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "inv_needed_hbm_frac": bytes_needed / (ti * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "line_floor_bytes_per_launch": line_floor_bytes(B, N, D, K),
             "note_on_pricing": "fwd_hbm_frac uses SURVEY 8d's 16 + 12 K bytes per element (all of nn_out); *_needed_* uses the bytes "
                                "the kernel has to touch (transformed channels' blocks only). The PMC traffic of the forward is "
-                               "~1.45 x the needed bytes: spans of 208 bytes at a 416-byte stride share their first and last "
-                               "64-byte sectors with the skipped blocks (profiles/traffic.json)",
+                               "1.57 x the needed bytes and 1.07 x line_floor_bytes: the memory side fetches whole 128-byte lines "
+                               "whatever part of them is asked for (tools/microbench/fetch_granularity.hip), and spans of 208 bytes "
+                               "at a 416-byte stride touch 320 bytes of lines per token (profiles/r05_mixture_fwd_traffic.txt)",
             "fwd_ms": tf, "inv_ms": ti, "fwd_elems_per_s": elems / (tf * 1e-3), "inv_elems_per_s": elems / (ti * 1e-3),
             "fwd_inv_elems_per_s": elems / ((tf + ti) * 1e-3),
             "fwd_algorithmic_GBps": bytes_alg / (tf * 1e-3) / 1e9, "fwd_hbm_frac": bytes_alg / (tf * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "fwd_bound": "hbm", "inv_bound": "valu (fp32 Newton iterations over the staged rows) on top of the same HBM stream",
             "inv_hbm_frac": bytes_alg / (ti * 1e-3) / 1e9 / HBM_PEAK_GBS}
+
+
+def line_floor_bytes(B, N, D, K, line=128):
+    """HBM bytes the mixture forward cannot avoid at 128-byte line granularity: the lines touched by the transformed channels'
+    parameter spans (DA x (2 + 3K) floats at the end of every token's D x (2 + 3K) floats) + latents in and out + log-det."""
+    P4, DA = (2 + 3 * K) * 4, D - D // 2
+    rec, span, off = D * P4, DA * P4, (D - DA) * P4
+    period = line // np.gcd(rec, line)                    # the line pattern repeats after this many tokens
+    lines = set()
+    for t in range(int(period)):
+        a = rec * t + off
+        lines.update(range(a // line, (a + span - 1) // line + 1))
+    return B * N * (len(lines) * line / float(period) + 8 * D) + 4 * B
 
 
 def kernel_table(lib, ops, dev, budget_ms=6.0):
@@ -411,12 +426,21 @@ def kernel_table(lib, ops, dev, budget_ms=6.0):
         for c in fwd:
             c()
         inv = [ops.mixture_coupling_launch(zf[r], nns[r], mask, K, zs[r], lf, reverse=True) for r in range(R)]
+        needed = B * N * ((D - D // 2) * (2 + 3 * K) * 4 + 8 * D) + 4 * B      # the transformed channels' parameter blocks only
+        floor_b = line_floor_bytes(B, N, D, K)
+
+        def priced(ms):
+            # `frac` prices all of nn_out (16 + 12 K bytes per element) although the kernel skips the blocks of the
+            # channels that pass through: it is NOT a bandwidth (S* forward: 0.83-0.87 "of 8 TB/s" = 6.7-7 TB/s, above what the
+            # chip streams).  needed_frac = the bytes the kernel has to touch, line_floor_frac = the 128-byte lines they sit in.
+            rows[-1].update(needed_bytes=float(needed), needed_frac=needed / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            line_floor_bytes=float(floor_b), line_floor_frac=floor_b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
         for mode, what in ((1, "fp32 (default)"), (0, "fp64 (the reference's precision)")):
             lib.cnf_set_math_mode(mode)
-            row("mixture_coupling forward, %s" % what, S, alg, fwd, math_mode=mode)
+            priced(row("mixture_coupling forward, %s" % what, S, alg, fwd, math_mode=mode))
             for c in fwd:
                 c()
-            row("mixture_coupling inverse (Newton), %s" % what, S, alg, inv, math_mode=mode)
+            priced(row("mixture_coupling inverse (Newton), %s" % what, S, alg, inv, math_mode=mode))
         lib.cnf_set_math_mode(1)
         for c in fwd:
             c()
