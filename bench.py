@@ -435,12 +435,34 @@ def kernel_table(lib, ops, dev, budget_ms=6.0):
             # chip streams).  needed_frac = the bytes the kernel has to touch, line_floor_frac = the 128-byte lines they sit in.
             rows[-1].update(needed_bytes=float(needed), needed_frac=needed / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                             line_floor_bytes=float(floor_b), line_floor_frac=floor_b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
+        def fp64_ceiling(ms, reverse):
+            # the reference-precision rows against the fp64 vector ceiling: instruction counts per launch from the
+            # committed counter run (profiles/r05_fp64_ceilings.json, same shapes and K) x measured issue costs (v_fma / v_mul /
+            # v_add_f64 4 cycles per wave-instruction and SIMD = the 78.6 TFLOP/s peak, v_rcp_f64 16, fp32 transcendentals 8,
+            # other VALU 2 ... 4: profiles/r05_op_rates.txt) over this run's time at 2.4 GHz on 1024 SIMDs
+            try:
+                ks = json.load(open(os.path.join(ROOT, "profiles", "r05_fp64_ceilings.json")))["kernels"]
+                mine = sorted((x for x in ks if (", true, 8, true>" in x["kernel"]) == reverse), key=lambda x: x["grid"])
+                k = mine[0] if tag == "configs[1]" else mine[-1]            # two shapes in the counter run: configs[1] (the smaller grid), S*
+            except Exception:
+                return
+            core = (k["fma_f64"] + k["mul_f64"] + k["add_f64"]) * 4 + k["trans_f64"] * 16 + k["trans_f32"] * 8
+            simd_cycles = 1024 * 2.4e9 * ms * 1e-3
+            lo, hi = (core + k["other_valu"] * 2) / simd_cycles, (core + k["other_valu"] * 4) / simd_cycles
+            rows[-1].update(fp64_issue_frac=[lo, hi], fp64_flops_frac=2 * (k["fma_f64"] * 2 + k["mul_f64"] + k["add_f64"]) * 64 / 2 / (ms * 1e-3) / 78.6e12,
+                            bound=("fp64 valu" if lo >= 0.6 else "latency (2 waves per SIMD; neither the fp64 unit nor HBM)"))
         for mode, what in ((1, "fp32 (default)"), (0, "fp64 (the reference's precision)")):
             lib.cnf_set_math_mode(mode)
-            priced(row("mixture_coupling forward, %s" % what, S, alg, fwd, math_mode=mode))
+            ms = row("mixture_coupling forward, %s" % what, S, alg, fwd, math_mode=mode)
+            priced(ms)
+            if mode == 0 and K == 8:
+                fp64_ceiling(ms, False)
             for c in fwd:
                 c()
-            priced(row("mixture_coupling inverse (Newton), %s" % what, S, alg, inv, math_mode=mode))
+            ms = row("mixture_coupling inverse (Newton), %s" % what, S, alg, inv, math_mode=mode)
+            priced(ms)
+            if mode == 0 and K == 8:
+                fp64_ceiling(ms, True)
         lib.cnf_set_math_mode(1)
         for c in fwd:
             c()

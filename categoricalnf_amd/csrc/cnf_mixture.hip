@@ -202,8 +202,13 @@ __device__ __forceinline__ void forward_elem_f64(const MixArgs& a, const ElemPar
 }
 // SPLIT selects the parameter source and the I/O precision (fp64 tensors for the static API);
 // KT = compile-time number of mixtures (0 = run-time K); NEWTON = safeguarded Newton inverse.
+#ifdef CNF_MIX64_WAVES
+#define CNF_MIX64_ATTR __attribute__((amdgpu_waves_per_eu(CNF_MIX64_WAVES, 8)))
+#else
+#define CNF_MIX64_ATTR
+#endif
 template <bool SPLIT, bool REVERSE, int KT, bool NEWTON>
-__global__ __launch_bounds__(kBlock) void mixture_kernel(MixArgs a, RowTiling tl) {
+__global__ __launch_bounds__(kBlock) CNF_MIX64_ATTR void mixture_kernel(MixArgs a, RowTiling tl) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int W = blockDim.x >> 6;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;

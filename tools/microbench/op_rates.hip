@@ -82,6 +82,62 @@ __global__ __launch_bounds__(256) void op_kernel(float* out, int iters) {
     out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+#define RD8(OP)                                                                                                      \
+    asm volatile(OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7)                                                     \
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])    \
+                 : "v"(b), "v"(c))
+#define DP0(i) "v_fma_f64 %" #i ", %" #i ", %8, %9\n"
+#define DP1(i) "v_mul_f64 %" #i ", %" #i ", %8\n"
+#define DP2(i) "v_add_f64 %" #i ", %" #i ", %8\n"
+#define DP3(i) "v_rcp_f64 %" #i ", %" #i "\n"
+#define DP4(i) "v_ldexp_f64 %" #i ", %" #i ", 1\n"
+#define DP5(i) "v_max_f64 %" #i ", %" #i ", %8\n"
+#define DP6(i) "v_rsq_f64 %" #i ", %" #i "\n"
+#define DP7(i) "v_fract_f64 %" #i ", %" #i "\n"
+#define DP8(i) "v_add_f64 %" #i ", %" #i ", |%8|\n"
+static const char* kNames64[] = {"v_fma_f64", "v_mul_f64", "v_add_f64", "v_rcp_f64", "v_ldexp_f64", "v_max_f64", "v_rsq_f64", "v_fract_f64", "v_add_f64 |src|"};
+constexpr int kModes64 = 9;
+template <int MODE>
+__global__ __launch_bounds__(256) void op64_kernel(double* out, int iters) {
+    double a[8];
+    for (int k = 0; k < 8; ++k) a[k] = 1.0 + 1e-3 * (double)((threadIdx.x + k) & 7);
+    double b = 0.999, c = 1e-3;
+    asm volatile("" : "+v"(b), "+v"(c));
+    for (int it = 0; it < iters; ++it) {
+#define RUN64(M, OP) if (MODE == M) { RD8(OP); RD8(OP); RD8(OP); RD8(OP); }
+        RUN64(0, DP0) RUN64(1, DP1) RUN64(2, DP2) RUN64(3, DP3) RUN64(4, DP4) RUN64(5, DP5) RUN64(6, DP6) RUN64(7, DP7) RUN64(8, DP8)
+    }
+    double s = 0.0;
+    for (int k = 0; k < 8; ++k) s += a[k];
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+template <int MODE>
+static double run64(int wps, double* d_out, int iters) {
+    const int blocks = 256 * wps;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    op64_kernel<MODE><<<blocks, 256>>>(d_out, iters);
+    CK(hipDeviceSynchronize());
+    float best = 1e30f;
+    for (int r = 0; r < 3; ++r) {
+        CK(hipEventRecord(e0));
+        op64_kernel<MODE><<<blocks, 256>>>(d_out, iters);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        best = ms < best ? ms : best;
+    }
+    return (double)best * 1e6 / ((double)wps * iters * 32.0);
+}
+template <int MODE>
+static void row64(double* d_out, int iters) {
+    printf("%-28s", kNames64[MODE]);
+    for (int wps : {1, 2, 4, 8}) printf("  %6.3f", run64<MODE>(wps, d_out, iters));
+    printf("\n");
+    if constexpr (MODE + 1 < kModes64) row64<MODE + 1>(d_out, iters);
+}
+
 template <int MODE>
 static double run(int wps, float* d_out, int iters) {
     const int blocks = 256 * wps;
@@ -117,5 +173,9 @@ int main() {
     printf("ns per wave-instruction per SIMD (8 independent chains per wave; v_fma_f32 = 2 cycles at the clock the chip holds)\n");
     printf("%-28s  %6s  %6s  %6s  %6s   (waves per SIMD)\n", "opcode", "1", "2", "4", "8");
     row<0>(d_out, 2000);
+    double* d_out64;
+    CK(hipMalloc(&d_out64, (size_t)256 * 8 * 256 * sizeof(double)));
+    printf("fp64 (v_fma_f64 at the 78.6 TFLOP/s vector peak = 4 cycles per wave-instruction)\n");
+    row64<0>(d_out64, 1000);
     return 0;
 }
