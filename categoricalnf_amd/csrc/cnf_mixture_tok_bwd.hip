@@ -340,7 +340,13 @@ __device__ __forceinline__ void mixture_tok_bwd_body(const MixArgs& a, const Tok
             }
 
             float g_x = gzo;                       // an element that is not transformed passes its gradient through
+#ifdef CNF_MIXBWD_ABLATE
+            // A/B build: the data movement alone (rows staged, the latents' gradient passed through, rows and zero blocks written
+            // back) with the arithmetic compiled out: the floor of this kernel's access pattern (profiles/r05_mixture_bwd_floor.txt)
+            if (false) {
+#else
             if (active) {
+#endif
                 const float t = my[0];
                 const float raw_ls = my[1];
                 const float log_s = a.sf ? apply_bound(raw_ls, sf_tab[d]) : raw_ls;
@@ -688,7 +694,7 @@ bool launch_mixture_tok_bwd(MixArgs& a, const float* g_zout, const float* g_ldj,
     // kernel (round 4) the ROLLED run-time-K kernel — ~100 VGPRs, 5 waves per SIMD, lane-private LDS sums — beats the unrolled
     // register-slot kernels (K = 8: 160 VGPRs) at every measured shape: S* 357 -> 331-340 us, configs[1] 59.4 -> 55, Zinc edges
     // 79 -> 54, Zinc nodes 35 -> 26, graph colouring (K = 16) 32 -> 23, a 1024-set training batch 23 -> 17-18.  Lanes per item G
-    // by the amount of work: one lane per item from ~2 M transformed elements on, two from ~400 k, four below (more waves for
+    // by the amount of work: one lane per item from ~2 M transformed elements on (two with 8 or more mixtures), two from ~400 k, four below (more waves for
     // small launches); K > 32 needs four for its stage to fit.  Modes 0 / 1 keep the unrolled kernels (natural registers / held
     // to 4 waves per SIMD) for A/B runs, 2-4 force G = 1 / 2 / 4.
     int kt = 0;
@@ -705,7 +711,10 @@ bool launch_mixture_tok_bwd(MixArgs& a, const float* g_zout, const float* g_ldj,
         if (a.K == 16 && items >= 2000000L &&
             launch_mixture_tok_bwd_with(a, g_zout, g_ldj, g_z, g_nn, g_sf, g_msf, workspace, st, 16, 0))
             return true;
-        int g = items >= 2000000L ? 1 : (items >= 400000L ? 2 : 4);
+        // (round 5, profiles/r05_mixture_bwd_floor.txt: at S* with K = 8 two lanes per item beat one — 320-334 against 347-371 us on two
+        // boxes: passes of 10 tokens instead of 21 move the same bytes faster, and the kernel is 90 % data movement; at K = 4 one lane
+        // per item stays ahead, 207 against 229 us, profiles/r04_mixture_bwd_variants.txt)
+        int g = items >= 2000000L ? (a.K >= 8 ? 2 : 1) : (items >= 400000L ? 2 : 4);
         if (a.K > 32) g = 4;
         while (g > 1 && g > a.K) g >>= 1;
         // the rule's G, or the next one whose stage fits LDS
