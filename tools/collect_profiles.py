@@ -4,7 +4,7 @@ import csv, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 
 
 def last_json_line(path):
@@ -31,7 +31,7 @@ for src, dst in (("sweep_affine.log", "_sweep_affine.txt"), ("sweep_nll.log", "_
                  ("ceilings_bwd/ceilings.txt", "_ceilings_backward.txt"), ("ceilings_bwd/ceilings.json", "_ceilings_backward.json"),
                  ("ceilings_mixbwd/ceilings.txt", "_ceilings_mixture_backward.txt"),
                  ("bwd_probe.txt", "_bwd_probe.txt"), ("bwd_kernel_stats.csv", "_bwd_kernel_stats.csv"),
-                 ("encoder_bwd_kernel_stats.csv", "_encoder_bwd_kernel_stats.csv"), ("encoder_bwd_breakdown.txt", "_encoder_bwd_breakdown.txt"),
+                 ("encoder_bwd_kernel_stats.csv", "_encoder_bwd_kernel_stats.csv"), ("encoder_bwd_variants.txt", "_encoder_bwd_variants.txt"),
                  ("autograd_overhead.txt", "_autograd_overhead.txt"),
                  ("pmc_small/table.txt", "_pmc_small_mixture.txt"), ("ab_mixture_inverse.txt", "_ab_mixture_inverse.txt"), ("flow_traffic.txt", "_flow_traffic.txt"),
                  ("flow_traffic.json", "_flow_traffic.json"), ("mfma_set/mfma_util.txt", "_mfma_util_set_modelling.txt"),

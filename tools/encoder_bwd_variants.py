@@ -1,6 +1,8 @@
-"""A/B of cnf_encoder_forward_bwd_tiled's launch variants (cnf_set_encoder_bwd_kernel) at the benchmark shape: us per call
-(all launches of the call, CUDA events over REP calls, interleaved rounds) and the largest difference to variant 1 (the two
-passes).  python tools/encoder_bwd_variants.py [B,N,D,C ...]"""
+"""A/B of the encoder backward's routes (cnf_set_encoder_bwd_kernel) at the benchmark shape: us per call (all launches of the
+call, CUDA events over REP calls, interleaved rounds) and the largest difference to variant 1.  Variants: 1 = the two passes;
+2 = the pair kernel behind the library's own pre-pass (cnf_encoder_forward_bwd_tiled); 12 = the pair kernel with the forward's
+class_prob_log (cnf_encoder_forward_bwd_cpl, knob 2); 10 = cnf_encoder_forward_bwd_cpl with the library's choice by shape (knob 0).
+python tools/encoder_bwd_variants.py [B,N,D,C ...]   (ENC_BWD_VARIANTS=1,12 selects)"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,7 +13,7 @@ lib = _lib.load()
 SHAPES = ((16384, 64, 6, 16), (16384, 64, 6, 51), (16384, 64, 6, 3), (4096, 64, 4, 27), (256, 64, 6, 16), (16384, 64, 8, 42), (2048, 64, 6, 200))
 if len(sys.argv) > 1:
     SHAPES = tuple(tuple(int(v) for v in a.split(",")) for a in sys.argv[1:])
-VARIANTS = tuple(int(v) for v in os.environ.get('ENC_BWD_VARIANTS', '1,16,17,18,19').split(','))      # 16 / 17 = 6 / 7 through cnf_encoder_forward_bwd_cpl with the forward's class_prob_log
+VARIANTS = tuple(int(v) for v in os.environ.get('ENC_BWD_VARIANTS', '1,2,12,10').split(','))      # 16 / 17 = 6 / 7 through cnf_encoder_forward_bwd_cpl with the forward's class_prob_log
 REP, ROUNDS = 20, 5
 for B, N, D, C in SHAPES:
     g = torch.Generator(device=dev).manual_seed(1)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Re-measure everything profiles/ holds, on the GPU box.  Run from the repo root:
 #   gpurun --timeout 2400 -- 'bash tools/refresh_profiles.sh'        (CNF_REFRESH_QUICK=1: the kernel measurements only)
-# then, back in the build container:  python tools/collect_profiles.py r04
+# then, back in the build container:  python tools/collect_profiles.py r05
 # The --pmc passes are separate rocprofv3 runs with --kernel-trace only (never combined with sys/hip traces).
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -50,11 +50,13 @@ rm -rf "$OUT/prof_bwd"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_bwd" -o bwd -- python tools/bwd_probe.py --reps 30 > /dev/null 2>&1
 python tools/summarize_kernel_stats.py "$OUT/prof_bwd/bwd_kernel_stats.csv" "$OUT/bwd_kernel_stats.csv" "tools/bwd_probe.py --reps 30 (every streaming backward kernel at B=16384, N=64, D=6 on four rotating buffer sets; kernel durations by themselves: the start-to-start table of r04_bwd_probe.txt includes the reduction launch behind a kernel)" 40 | head -3
 rm -f "$OUT"/prof_bwd/*kernel_trace.csv
-# the encoder backward per kernel (token-lane, class-lane and split-sum launches) at the benchmark token count, C = 16 and 51
+# the encoder backward per kernel at the benchmark token count, C = 16 and 51: the two passes (variant 1) and what
+# cnf_encoder_forward_bwd_cpl picks by shape (variant 10: the pair kernel at 16 classes, the two passes at 51)
 rm -rf "$OUT/prof_encbwd"
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_encbwd" -o encbwd -- python tools/encoder_bwd_breakdown.py 16384,64,16 16384,64,51 > "$OUT/encoder_bwd_breakdown.txt" 2>&1
-python tools/summarize_kernel_stats.py "$OUT/prof_encbwd/encbwd_kernel_stats.csv" "$OUT/encoder_bwd_kernel_stats.csv" "tools/encoder_bwd_breakdown.py 16384,64,16 16384,64,51 (encoder forward + cnf_encoder_forward_bwd_tiled at 1 048 576 tokens, D = 6, C = 16 and 51, 20 steps each: its launches one by one)" 12 | head -3
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_encbwd" -o encbwd -- python tools/pmc_encoder_bwd_workload.py 16,51 1,10 > /dev/null 2>&1
+python tools/summarize_kernel_stats.py "$OUT/prof_encbwd/encbwd_kernel_stats.csv" "$OUT/encoder_bwd_kernel_stats.csv" "tools/pmc_encoder_bwd_workload.py 16,51 1,10 (encoder forward once + 10 calls each of cnf_encoder_forward_bwd_tiled forced onto the two passes and of cnf_encoder_forward_bwd_cpl with the library's own choice, at 1 048 576 tokens, D = 6, C = 16 and 51: their launches one by one)" 12 | head -3
 rm -f "$OUT"/prof_encbwd/*kernel_trace.csv
+timeout 200 python tools/encoder_bwd_variants.py 16384,64,6,16 16384,64,6,51 1024,64,6,16 64,64,6,27 2>/dev/null > "$OUT/encoder_bwd_variants.txt"; tail -12 "$OUT/encoder_bwd_variants.txt"
 ( timeout 200 python tools/autograd_overhead.py 2>&1 | grep -v amdgpu.ids; echo; echo "== --single_thread (torch.autograd.set_multithreading_enabled(False): backward() on the calling thread, what the three drivers set)"; timeout 200 python tools/autograd_overhead.py --single_thread 2>&1 | grep "wall" ) > "$OUT/autograd_overhead.txt"; tail -3 "$OUT/autograd_overhead.txt"
 bash tools/pmc_passes.sh pmc_small python tools/pmc_small_mixture.py > "$OUT/pmc_small.log" 2>&1
 bash tools/pmc_passes.sh flow_fused python tools/flow_traffic_workload.py fused > /dev/null 2>&1
