@@ -68,6 +68,9 @@ def parse(argv=None):
     p.add_argument("--graph_step", action="store_true",
                    help="capture the training step (forward, HIP backward kernels, clipping, RAdam) in a HIP graph and replay it; "
                         "single process; batches keep the data set's full width, beta and the learning rate live in device scalars")
+    p.add_argument("--graph_step_unverified", action="store_true",
+                   help="with --graph_step: accept a captured step whose hipGraph could not be inspected for memset nodes "
+                        "(a torch without CUDAGraph(keep_graph=True)); without it such a step is refused")
     p.add_argument("--backend", default=None, help="torch.distributed backend when started with WORLD_SIZE > 1 (nccl = RCCL)")
     p.add_argument("--share_device", action="store_true", help="TEST ONLY: every rank on cuda:0 (1-GPU box, --backend gloo)")
     return p.parse_args(argv)
@@ -143,6 +146,16 @@ def evaluate(model, prior, dataset, device, batch_size, max_graphs=None, rank=0,
 
 
 def main(argv=None):
+    """Runs the driver; the process-wide switches it sets (autograd threading, cudnn / MIOpen) are restored when it returns."""
+    threading, cudnn = torch.autograd.is_multithreading_enabled(), torch.backends.cudnn.enabled
+    try:
+        return _main(argv)
+    finally:
+        torch.autograd.set_multithreading_enabled(threading)
+        torch.backends.cudnn.enabled = cudnn
+
+
+def _main(argv=None):
     args = parse(argv)
     # one process per GPU: backward() runs on the calling thread instead of being handed to the autograd engine's device
     # thread and waited for (two thread wake-ups per call; tools/autograd_overhead.py --single_thread)
@@ -224,7 +237,7 @@ def main(argv=None):
         beta_t = torch.tensor(beta_at(args, state["iteration"]), dtype=torch.float32, device=device)      # the beta schedule lives in a device scalar
         graphed = GraphedTraining(model, lambda: model(s_nodes, s_adj, reverse=False, beta=beta_t, length=s_len, noise=s_noise,
                                                        _nll=model.nll_request(length=s_len, prior=prior))[2].mean(),
-                                  device, args.max_gradient_norm, lr=lr_of(state["iteration"]), eager_optimizer=optimizer)
+                                  device, args.max_gradient_norm, lr=lr_of(state["iteration"]), eager_optimizer=optimizer, allow_unverified=args.graph_step_unverified)
         optimizer = graphed.optimizer
         say("[#] --graph_step: captured training step, hipGraph nodes %s" % (graphed.nodes,))
     ddp.train()

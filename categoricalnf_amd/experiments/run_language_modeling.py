@@ -114,6 +114,9 @@ def parse(argv=None):
                    help="capture the training step (forward, HIP backward kernels, clipping, RAdam) in a HIP graph and replay it; "
                         "single process; beta and the learning rate live in device scalars; the LSTM runs on PyTorch's native "
                         "path (MIOpen's RNN calls are refused inside a stream capture)")
+    p.add_argument("--graph_step_unverified", action="store_true",
+                   help="with --graph_step: accept a captured step whose hipGraph could not be inspected for memset nodes "
+                        "(a torch without CUDAGraph(keep_graph=True)); without it such a step is refused")
     p.add_argument("--backend", default=None, help="torch.distributed backend when started with WORLD_SIZE > 1 (nccl = RCCL)")
     p.add_argument("--share_device", action="store_true", help="TEST ONLY: every rank on cuda:0 (1-GPU box, --backend gloo)")
     return p.parse_args(argv)
@@ -173,6 +176,16 @@ def evaluate(model, prior, val, batch_size, rank=0, world=1):
 
 
 def main(argv=None):
+    """Runs the driver; the process-wide switches it sets (autograd threading, cudnn / MIOpen) are restored when it returns."""
+    threading, cudnn = torch.autograd.is_multithreading_enabled(), torch.backends.cudnn.enabled
+    try:
+        return _main(argv)
+    finally:
+        torch.autograd.set_multithreading_enabled(threading)
+        torch.backends.cudnn.enabled = cudnn
+
+
+def _main(argv=None):
     args = parse(argv)
     # one process per GPU: backward() runs on the calling thread instead of being handed to the autograd engine's device
     # thread and waited for (two thread wake-ups per call; tools/autograd_overhead.py --single_thread)
@@ -217,13 +230,14 @@ def main(argv=None):
         say("validation %.4f bits per character (source %.4f)" % (bpc, corpus.entropy_rate()))
         return {"val_bpc": bpc, "entropy_rate": corpus.entropy_rate()}
 
-    graphed = None
+    graphed, eval_cudnn = None, torch.backends.cudnn.enabled
     if args.graph_step and world > 1:
         say("[#] --graph_step ignored: it is a single-process mode")
     elif args.graph_step:
         from ..graphs import GraphedTraining
         # MIOpen's RNN (hipBLASLt inside it) aborts under a stream capture; nn.LSTM's native per-time-step path is captured
         # instead — a few thousand small kernels, which is exactly what a graph replay is good at
+        eval_cudnn = torch.backends.cudnn.enabled        # evaluation keeps the RNN path it would have without --graph_step
         torch.backends.cudnn.enabled = False
         lr_of = lambda step: args.learning_rate * args.lr_decay_factor ** step
         model.train()
@@ -232,7 +246,7 @@ def main(argv=None):
         beta_t = torch.tensor(beta_at(args, state["iteration"]), dtype=torch.float32, device=device)      # the beta schedule lives in a device scalar
         graphed = GraphedTraining(model, lambda: model(s_x, reverse=False, beta=beta_t, length=s_len, noise=s_noise,
                                                        _nll=model.nll_request(length=s_len, prior=prior))[2].mean(),
-                                  device, args.max_gradient_norm, lr=lr_of(state["iteration"]), eager_optimizer=optimizer)
+                                  device, args.max_gradient_norm, lr=lr_of(state["iteration"]), eager_optimizer=optimizer, allow_unverified=args.graph_step_unverified)
         optimizer = graphed.optimizer
         say("[#] --graph_step: captured training step, hipGraph nodes %s" % (graphed.nodes,))
     ddp.train()
@@ -264,7 +278,8 @@ def main(argv=None):
         if step % args.eval_freq == 0 or step == args.max_iterations:
             if graphed is not None:
                 graphed.drop_weight_caches()
-            bpc = evaluate(ddp, prior, val, args.batch_size, rank, world)
+            with torch.backends.cudnn.flags(enabled=eval_cudnn):
+                bpc = evaluate(ddp, prior, val, args.batch_size, rank, world)
             state["evaluation_dict"][step] = bpc
             say("iteration %7d | validation %.4f bits per character (source %.4f, context-free %.4f)"
                 % (step, bpc, corpus.entropy_rate(), corpus.unigram_entropy()))
@@ -277,7 +292,8 @@ def main(argv=None):
                                     evaluation_dict=state["evaluation_dict"])
     if graphed is not None:
         graphed.drop_weight_caches()
-    bpc = evaluate(ddp, prior, val, args.batch_size, rank, world)
+    with torch.backends.cudnn.flags(enabled=eval_cudnn):
+        bpc = evaluate(ddp, prior, val, args.batch_size, rank, world)
     say("final: validation %.4f bits per character; source entropy rate %.4f, context-free optimum %.4f"
         % (bpc, corpus.entropy_rate(), corpus.unigram_entropy()))
     if world > 1:

@@ -22,6 +22,7 @@ import argparse
 import contextlib
 import glob
 import io
+import json
 import os
 import pickle
 import time
@@ -68,6 +69,9 @@ def parse(argv=None):
                    help="single process only: the whole training step (forward, HIP backward kernels, clipping, RAdam) is captured "
                         "once in a HIP graph and replayed (categoricalnf_amd.graphs.GraphedTrainStep); between replays only the "
                         "batch, the encoder noise and the learning rate are written into static device buffers")
+    p.add_argument("--graph_step_unverified", action="store_true",
+                   help="with --graph_step: accept a captured step whose hipGraph could not be inspected for memset nodes "
+                        "(a torch without CUDAGraph(keep_graph=True)); without it such a step is refused")
     p.add_argument("--flat_optimizer", action="store_true",
                    help="single process only: optimiser, clipping and zero_grad on ONE flat parameter buffer "
                         "(host_utils.FlatParameters: 23.0 -> 21.8 ms per step at batch 64); checkpoints "
@@ -191,6 +195,16 @@ MODEL_ARGS = ("dataset", "set_size", "encoding_dim", "coupling_hidden_size", "co
 
 
 def main(argv=None):
+    """Runs the driver; the process-wide switches it sets (autograd threading, cudnn / MIOpen) are restored when it returns."""
+    threading, cudnn = torch.autograd.is_multithreading_enabled(), torch.backends.cudnn.enabled
+    try:
+        return _main(argv)
+    finally:
+        torch.autograd.set_multithreading_enabled(threading)
+        torch.backends.cudnn.enabled = cudnn
+
+
+def _main(argv=None):
     args = parse(argv)
     # one process per GPU: backward() runs on the calling thread instead of being handed to the autograd engine's device
     # thread and waited for (two thread wake-ups per call; tools/autograd_overhead.py --single_thread)
@@ -272,22 +286,27 @@ def main(argv=None):
         # the NLL assembly rides in the last coupling layer's kernel
         graphed = GraphedTraining(model, lambda: model(static_x, reverse=False, length=static_ln, beta=1, noise=static_noise,
                                                        _nll=model.nll_request(length=static_ln))[2].mean(),
-                                  device, args.max_gradient_norm, lr=lr_of(state["iteration"]), eager_optimizer=optimizer)
+                                  device, args.max_gradient_norm, lr=lr_of(state["iteration"]), eager_optimizer=optimizer, allow_unverified=args.graph_step_unverified)
         optimizer = graphed.optimizer
         say("[#] --graph_step: captured training step, hipGraph nodes %s" % (graphed.nodes,))
     ddp.train()
     best = state["best_save_dict"]
     periodic = set()          # full-state checkpoints written at save_freq steps (kept when a better validation file appears)
+    periodic_list = os.path.join(args.checkpoint_path, "periodic_checkpoints.json") if args.checkpoint_path else None
     if args.checkpoint_path and rank == 0 and os.path.isdir(args.checkpoint_path):
         # resumed: the full-state files already in the directory stay protected (a pre-resume periodic file that is also the best
-        # one must not be removed when a better validation file appears)
+        # one must not be removed when a better validation file appears).  Their names are kept in a sidecar file; only a
+        # directory written before the sidecar existed is scanned by unpickling every checkpoint once
         import glob
-        for f in glob.glob(os.path.join(args.checkpoint_path, "checkpoint_*.tar")):
-            try:
-                if "optimizer_state_dict" in torch.load(f, map_location="cpu", weights_only=False):
-                    periodic.add(f)
-            except Exception:
-                pass
+        if os.path.isfile(periodic_list):
+            periodic.update(f for f in (os.path.join(args.checkpoint_path, n) for n in json.load(open(periodic_list))) if os.path.isfile(f))
+        else:
+            for f in glob.glob(os.path.join(args.checkpoint_path, "checkpoint_*.tar")):
+                try:
+                    if "optimizer_state_dict" in torch.load(f, map_location="cpu", weights_only=False):
+                        periodic.add(f)
+                except Exception:
+                    pass
     t0, run_loss, seen = time.time(), torch.zeros((), device=device), 0       # the loss stays on the device between prints
     for it in range(state["iteration"], args.max_iterations):
         x, ln = batch()
@@ -336,6 +355,7 @@ def main(argv=None):
                 save_checkpoint(args.checkpoint_path, step, ddp, optimizer if flat is None else None, scheduler,
                                 best_save_dict=best, evaluation_dict=state["evaluation_dict"])
             periodic.add(checkpoint_file(args.checkpoint_path, step))
+            json.dump(sorted(os.path.basename(f) for f in periodic), open(periodic_list, "w"))
     if graphed is not None:
         graphed.drop_weight_caches()
     _, val_bpd = evaluate(ddp, val_sets, device, rank, world, args.eval_batch_size)

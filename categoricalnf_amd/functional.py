@@ -261,7 +261,11 @@ class MixtureActConvFn(torch.autograd.Function):
     """Mixture-CDF coupling of one flow step + ActNorm + 1x1 convolution of the next: ONE forward kernel
     (cnf_mixture_coupling_actconv: the coupling's output stays in registers).  The backward recomputes what that output
     was from the saved result (cnf_actnorm_invconv_bwd, saved_is_output = 1), then runs the coupling's own backward kernel
-    on the saved input.  (z, nn_out, sf, msf, bias, scales, weight, sldj, ldj) -> (z', ldj')."""
+    on the saved input.  (z, nn_out, sf, msf, bias, scales, weight, sldj, ldj) -> (z', ldj').
+    Tolerance of the from-output form: the pair's input is rebuilt from fp32 outputs through W^-1 (inverted in fp64), so the error
+    of g_weight / g_scales grows with cond(W) x fp32 epsilon — within 2e-3 of each tensor's largest entry up to cond(W) ~ 3000
+    (log_s of the LU parametrisation spread over +-4: tests/test_gpu_backward.py); CNF_FUSE_TRAINING=0 runs the layers one by one,
+    each from its own saved input, where a flow's convolutions are trained into worse conditioning than that."""
 
     @staticmethod
     def forward(ctx, z, nn_out, sf, msf, bias, scales, weight, sldj, ldj, mask, pad, length, K, reg_max, reg_factor, is_training):

@@ -207,8 +207,8 @@ class GraphedTrainStep:
                 raise RuntimeError(
                     "the captured step's hipGraph could not be inspected (torch.cuda.CUDAGraph(keep_graph=True) / hipGraphGetNodes "
                     "unavailable), so it cannot be shown to be free of memset nodes, which this HIP runtime replays wrongly from the "
-                    "second launch on (profiles/r03_graph_train_root_cause.txt).  Pass allow_memset_nodes=True to accept the step "
-                    "unverified (nodes == 'unverified').")
+                    "second launch on (profiles/r03_graph_train_root_cause.txt).  Pass allow_memset_nodes=True (GraphedTraining: "
+                    "allow_unverified=True; the drivers: --graph_step_unverified) to accept the step unverified (nodes == 'unverified').")
             import warnings
             warnings.warn("GraphedTrainStep: captured graph accepted WITHOUT a node census (allow_memset_nodes=True)")
         elif self.nodes.get("memset", 0) and not allow_memset_nodes:
@@ -248,7 +248,10 @@ class GraphedTraining:
     eager run stores and back); `drop_weight_caches()` must be called before the model runs in eval mode (replays do not run
     the modules' Python, so the eval-mode caches of the 1x1 convolutions are not dropped by a training forward any more)."""
 
-    def __init__(self, model, loss_fn, device, max_grad_norm, lr=7.5e-4, eager_optimizer=None, optimizer_cls=torch.optim.RAdam):
+    def __init__(self, model, loss_fn, device, max_grad_norm, lr=7.5e-4, eager_optimizer=None, optimizer_cls=torch.optim.RAdam,
+                 allow_unverified=False):
+        # allow_unverified: accept a captured step whose hipGraph could not be inspected for memset nodes (GraphedTrainStep's
+        # allow_memset_nodes; the drivers' --graph_step_unverified) — without it such a step is refused
         self.model, self.device = model, torch.device(device)
         self.lr = torch.tensor(float(lr), dtype=torch.float32, device=self.device)       # the schedule lives in a device scalar
         eager_state = eager_optimizer.state_dict()["state"] if eager_optimizer is not None else {}
@@ -275,7 +278,7 @@ class GraphedTraining:
             p.grad = None
         snapshot = [p.detach().clone() for p in plist], {k: {n: v.clone() for n, v in st.items() if torch.is_tensor(v)}
                                                          for k, st in optimizer.state.items()}
-        self.step = GraphedTrainStep(train_step, self.device)
+        self.step = GraphedTrainStep(train_step, self.device, allow_memset_nodes=allow_unverified)
         self.nodes = self.step.nodes
         # the warm-up steps before the capture trained on one batch: undo them (parameters and moments)
         with torch.no_grad():
@@ -305,8 +308,17 @@ class GraphedTraining:
         flag (an eager resume must not inherit the device-side step counters' mode)."""
         for group in self.optimizer.param_groups:
             group["lr"], group["capturable"] = float(lr), False
+        # ... and the step counters as an eager (non-capturable) optimiser keeps them: CPU scalars.  Left on the device, an eager
+        # resume would call step.item() — a host sync — for every parameter on every step.
+        device_steps = {}
+        for p_, st in self.optimizer.state.items():
+            if torch.is_tensor(st.get("step")) and st["step"].is_cuda:
+                device_steps[p_] = st["step"]
+                st["step"] = st["step"].detach().to("cpu")
         try:
             yield self.optimizer
         finally:
+            for p_, t in device_steps.items():
+                self.optimizer.state[p_]["step"] = t
             for group in self.optimizer.param_groups:
                 group["lr"], group["capturable"] = self.lr, True

@@ -115,8 +115,11 @@ class FlowModel(nn.Module):
                                                  channel_padding_mask=kwargs.get("channel_padding_mask", None), ldj=ldj)
                     skip.add(order[pos + 1][0])
                     continue
+            # the differentiable NLL Functions are built for the unit logistic prior (their backward kernels hard-code it): a
+            # request with another sigma — e.g. one made under no_grad and used with grad on — must not take them
+            unit_prior = nll_request is not None and float(nll_request["sigma"]) == ops.LOGISTIC_SIGMA
             last_with_nll = (nll_request is not None and pos == len(order) - 1 and not reverse and z.is_cuda and z.dtype == torch.float32
-                             and (not torch.is_grad_enabled() or trainable))
+                             and (not torch.is_grad_enabled() or (trainable and unit_prior)))
             if last_with_nll and type(layer).__name__ == "CouplingLayer":
                 # last layer = affine coupling: transform + prior log-prob + NLL in one kernel
                 pad = kwargs.get("channel_padding_mask", None)
@@ -171,6 +174,10 @@ class FlowModel(nn.Module):
                 per_layer.append(detail)
         if nll_request is not None and "nll" not in nll_request:
             if torch.is_grad_enabled() and (z.requires_grad or ldj.requires_grad):
+                if not z.is_cuda or float(nll_request["sigma"]) != ops.LOGISTIC_SIGMA:
+                    raise NotImplementedError("FlowModel: the differentiable NLL (PriorNllFn) runs on the device under the unit logistic "
+                                              "prior only (sigma %s, device %s): assemble the NLL from z and ldj instead"
+                                              % (nll_request["sigma"], z.device))
                 nll_request["nll"] = Fn.PriorNllFn.apply(z, ldj, nll_request["length"], kwargs.get("channel_padding_mask", None))
                 if nll_request["sums"] is not None:
                     ops.nll_sum(nll_request["nll"].detach(), nll_request["sums"])

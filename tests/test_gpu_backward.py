@@ -752,3 +752,36 @@ def test_lu_weight_assembly_hands_out_the_inverse_the_fused_backward_needs(D):
     torch.cuda.synchronize()
     for a, b in zip(*outs):
         assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
+@pytest.mark.parametrize("spread", [1.0, 4.0])
+def test_fused_pair_backward_from_the_output_with_an_ill_conditioned_weight(spread):
+    """the fused training groups keep only the pair's OUTPUT and rebuild its input through W^-1 (fp64 inverse, fp32
+    latents), so the error of g_weight / g_scales grows with cond(W).  log_s of the LU parametrisation spread over +-`spread`
+    (cond(W) up to e^8 ~ 3000 at 4): the from-output gradients stay within 2e-3 of the from-input ones relative to each
+    tensor's largest entry — the documented tolerance of CNF_FUSE_TRAINING (functional.MixtureActConvFn / EncoderActConvFn)."""
+    from categoricalnf_amd import functional as Fn, ops
+    from categoricalnf_amd.layers.flows.permutation_layers import InvertibleConv
+    dev = torch.device("cuda:0")
+    D, B, N = 6, 256, 32
+    torch.manual_seed(3)
+    np.random.seed(3)
+    conv = InvertibleConv(D).cuda().train()
+    with torch.no_grad():
+        conv.log_s.copy_(torch.linspace(-spread, spread, D, device=dev))
+        conv.l.add_(0.3 * torch.randn_like(conv.l))
+        conv.u.add_(0.3 * torch.randn_like(conv.u))
+    w, sldj = conv._build_weight()
+    w = w.detach()
+    cond = float(torch.linalg.cond(w.double()))
+    bias, scales = torch.randn(D, device=dev), 0.3 * torch.randn(D, device=dev)
+    z = torch.randn(B, N, D, device=dev)
+    z_out, _ = ops.actnorm_invconv(z, bias, scales, w, sldj.detach())
+    gz, gl = torch.randn(B, N, D, device=dev), torch.randn(B, device=dev)
+    from_in = Fn._actconv_bwd(z, False, bias, scales, w, None, None, gz, gl, Fn._Hold())
+    from_out = Fn._actconv_bwd(z_out, True, bias, scales, w, None, None, gz, gl, Fn._Hold(), weight_inv=Fn._known_inverse(conv._build_weight()[0]))
+    torch.cuda.synchronize()
+    for name, a, b in zip(("g_z", "g_bias", "g_scales", "g_weight", "g_sldj"), from_out, from_in):
+        scale = float(b.abs().max()) + 1e-12
+        err = float((a - b).abs().max()) / scale
+        assert err <= 2e-3, (name, err, cond)

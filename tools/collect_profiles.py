@@ -40,10 +40,11 @@ for src, dst in (("sweep_affine.log", "_sweep_affine.txt"), ("sweep_nll.log", "_
                  ("enc/table.txt", "_pmc_encoder.txt"), ("train_lm.txt", "_train_language_modelling.txt"),
                  ("train_lm_ptb.txt", "_train_language_modelling_ptb_shape.txt"),
                  ("lm_kernel_stats.csv", "_train_language_modelling_kernel_stats.csv")):
-    if os.path.exists(os.path.join(G, src)):
+    # only what THIS refresh produced: gpurun_out/ keeps the files of earlier rounds (a lean refresh re-measures a subset)
+    if os.path.exists(os.path.join(G, src)) and os.path.getmtime(os.path.join(G, src)) > os.path.getmtime(os.path.join(G, "bench.log")) - 7200:
         shutil.copy(os.path.join(G, src), os.path.join(P, tag + dst))
 tr = os.path.join(G, "prof_train", "train_kernel_stats.csv")
-if os.path.exists(tr):
+if os.path.exists(tr) and os.path.getmtime(tr) > os.path.getmtime(os.path.join(G, "bench.log")) - 7200:
     rows = list(csv.reader(open(tr)))
     tot = sum(float(r[2]) for r in rows[1:])
     ours = sum(float(r[2]) for r in rows[1:] if "cnf::" in r[0])
