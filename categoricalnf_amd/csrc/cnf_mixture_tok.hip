@@ -474,7 +474,7 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
     // one stage per wave: DMA (the compiler waits for it before the first LDS read), compute, next pass; the other waves of
     // the CU cover the latency.  (A second stage per wave with the next pass's DMA in flight during the compute — inline
     // assembly DMA, explicit vmcnt waits — was built and measured: slower at equal LDS, 16.7 vs 15.3 us at K = 4, because the
-    // doubled stages halve the resident waves)
+    // doubled stages halve the resident waves; profiles/HISTORY.md section 4.)
     for (int tp = 0; tp < ntok; tp += gm.TPP) {                               // wave-uniform
         const int npt = min(gm.TPP, ntok - tp);
         wave_lds_sync();

@@ -1,4 +1,4 @@
-"""Diagnostic for the captured TRAINING step: with the parameters held fixed, the loss and
+"""Diagnostic for the captured TRAINING step (profiles/HISTORY.md section 8 item 1): with the parameters held fixed, the loss and
 every parameter gradient of one step replayed from a HIP graph against the same step run eagerly, on several fresh
 inputs.  Any difference is the capture's (no optimiser in the loop, so nothing can drift).  Prints the parameters whose
 gradients differ, largest first, and the first flow layer whose OUTPUT differs between the two paths.

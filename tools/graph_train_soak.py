@@ -1,4 +1,4 @@
-"""Soak test for a HIP-graph-captured TRAINING step: NOT part of the package or of the test
+"""Soak test for a HIP-graph-captured TRAINING step (profiles/HISTORY.md section 8, item 1): NOT part of the package or of the test
 suite — the acceptance experiment a graph-captured step has to pass before it returns to the package.
 
 Two identical copies of the set-modelling flow are trained on the same data and the same encoder noise: copy A eagerly,

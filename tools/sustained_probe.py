@@ -5,7 +5,7 @@ no arithmetic), each in three streams:
   (b) sustained: thousands of launches back to back,
   (c) the bench step: forward (or the probe in its place) alternating with the inverse,
 measured twice: per-launch dispatch timestamps (cnf_prof_arm; every 8th launch, or the last 8 of a burst) and
-start-to-start times from one event pair around a block of launches.  Findings: consecutive
+start-to-start times from one event pair around a block of launches.  Findings (profiles/HISTORY.md section 4): consecutive
 launches overlap, so timestamps in a continuous stream exceed the stream's advance per launch; there is no burst-versus-
 sustained clock effect; in the bench step the inverse runs faster and the forward slower than in streams of their own."""
 import ctypes, os, sys
