@@ -406,9 +406,9 @@ def kernel_table(lib, ops, dev, budget_ms=6.0):
                  SC, T * (12 + 8 * D),
                  [call("cnf_encoder_forward_bwd_cpl", P(cats[r]), P(zs[r]), P(table), P(prior), None, 1.0, P(cpls[r]), P(gz[r]), P(gl), P(g_table), P(wsb),
                        B, N, D, C, float(ops.LOGISTIC_SIGMA), float(ops.LOGISTIC_LOG_SIGMA), st) for r in range(R)], bound="valu")
-        pair = 9 <= C <= 64 and ((192 // C) * C * 100 >= 192 * 84 or T <= 131072)      # pair_kernel_preferred, cnf_encoder_bwd_tiled.hip
+        pair = 9 <= C <= 64                         # pair_kernel_choice (cnf_encoder_bwd_tiled.hip) at this token count
         rows[-1]["valu_frac"] = slots * (120e-9 if pair else 262e-9) / (ms * 1e-3)
-        rows[-1]["route"] = "pair kernel" if pair else "two passes"
+        rows[-1]["route"] = ("pair kernel, %d-lane workgroup" % (256 if C <= 27 else 512)) if pair else "two passes"
         del cpls
     del zs, nn2, gz, o1, o2, us_
 

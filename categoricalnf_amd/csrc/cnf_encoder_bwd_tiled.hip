@@ -854,23 +854,30 @@ static int bwd_tiled_splits(long ntok, int C) {
 // ---- the pair kernel's geometry --------------------------------------------------------------------------------------
 static std::atomic<int> g_enc_bwd_kernel{0};
 constexpr int kPairWaves = 3, kPairTokens = 4;          // 3 pair waves + the token wave = a 256-lane workgroup; 4 tokens per pair lane
-constexpr int kPairMaxC = kPairWaves * 64;
+constexpr int kPairWavesWide = 7;                        // the wide workgroup: 7 pair waves + the token wave = 512 lanes
+constexpr int kPairMaxC = kPairWaves * 64, kPairMaxCWide = kPairWavesWide * 64;
 constexpr int kPairMaxWgs = 2048;
-static bool pair_shape_ok(long ntok, int D, int C) {
-    return C <= kPairMaxC && ntok < (1l << 31) && (D <= 4 || D == 6 || D == 8);
+static bool pair_shape_ok(long ntok, int D, int C, int max_c = kPairMaxCWide) {
+    return C <= max_c && ntok < (1l << 31) && (D <= 4 || D == 6 || D == 8);
 }
-// Where the pair kernel wins (profiles/r05_encoder_bwd_sweep.txt, one MI355X): with the forward's class_prob_log at 9 ... 64
-// classes (16 classes: 94 vs 117 us at 10^6 tokens, 14 vs 21 at 4096; 42: 239 vs 299) and at every class count up to
-// 16 384 tokens (the two passes cost 17 ... 110 us there whatever the size, the pair kernel 14 ... 42); without it (the pre-pass
-// repeats the forward's density sum) only on small batches of 16 classes or more.  Elsewhere the two passes: beyond 64 classes
-// the pair lanes' workgroup holds too few tokens per stage, below 9 the class sums in the token lanes' registers are cheaper.
-static bool pair_kernel_preferred(long ntok, int C, bool have_cpl) {
-    if (ntok <= 16384) return have_cpl || C >= 16;
-    if (!have_cpl || C < 9 || C > 64) return false;
-    // large batches: only where the class count fills the 192 pair lanes (51 classes: 3 x 51 = 153 lanes, 328 vs 320 us at
-    // 10^6 tokens, but 40 vs 44 at 65 536)
-    const int lanes = (kPairMaxC / C) * C;
-    return lanes * 100 >= kPairMaxC * 84 || ntok <= 131072;
+// Which route (profiles/r05_encoder_bwd_sweep.txt, r05_encoder_bwd_sweep_wide.txt, one MI355X): 0 = the two passes, kPairWaves = the
+// 256-lane pair workgroup, kPairWavesWide = the 512-lane one.  With the forward's class_prob_log: the narrow workgroup at 9 ... 27
+// classes (16 classes: 94 vs 117 us at 10^6 tokens), the wide one from 28 classes on, where a stage of 448 / C x 4 tokens still fits
+// the token wave's 64 lanes and the class count fills more of 448 lanes than of 192 (51 classes: 265 vs 316 us for the two passes and
+// 328 for the narrow workgroup; 42: 214 vs 296; 64: 314 vs 343) — up to 64 classes at any size, up to 200 on batches of at most
+// 131 072 tokens (96 classes: 53 vs 68 us at 65 536 tokens); on small batches (<= 16 384 tokens) at every class count the workgroups
+// can hold (4 096 tokens: 14-17 us up to 64 classes, 31-58 us at 200-448, against 28-168 us).  Below 9 classes the class sums in the
+// token lanes' registers are cheaper; beyond these limits a stage holds too few tokens for the workgroup.  Without class_prob_log (the
+// pre-pass repeats the forward's density sum): small batches of 16 classes or more only.
+static int pair_kernel_choice(long ntok, int C, bool have_cpl) {
+    const int small = C <= 48 ? kPairWaves : kPairWavesWide;
+    if (ntok <= 16384) return (have_cpl || C >= 16) ? small : 0;
+    if (!have_cpl || C < 9) return 0;
+    if (C <= 27) return kPairWaves;
+    if (C <= 64) return kPairWavesWide;
+    if (ntok <= 131072 && C <= 200) return kPairWavesWide;
+    if (C <= 96) return kPairWaves;
+    return 0;
 }
 static size_t make_pairs_geom(long ntok, int D, int C, int U, int pair_lanes, PairsGeom& g, int resident_per_cu = 0) {
     int rs = (C + 1) & ~1;
@@ -900,11 +907,13 @@ static size_t make_pairs_geom(long ntok, int D, int C, int U, int pair_lanes, Pa
 
 }  // extern "C"
 
+// false = the stage does not fit 64 KB of LDS at this class count (the caller takes the two passes)
 template <int DT, int U, int PW>
-static void launch_pairs(EncBwdTiledArgs& b, const float* cpl, int D, int C, hipStream_t st) {
+static bool launch_pairs(EncBwdTiledArgs& b, const float* cpl, int D, int C, hipStream_t st) {
     constexpr int kPairsNT = PW * 64 + 64;
     PairsGeom g;
     size_t lds = make_pairs_geom(b.ntok, D, C, U, PW * 64, g);
+    if (lds > 64 * 1024) return false;
     // resident workgroups per CU for this instantiation and LDS size (registers and wave slots included), cached
     static std::mutex mu;
     static std::map<size_t, int> cache;
@@ -925,6 +934,7 @@ static void launch_pairs(EncBwdTiledArgs& b, const float* cpl, int D, int C, hip
     const int wgs = (int)((g.nstages + g.per_wg - 1) / g.per_wg);
     b.S = wgs;
     CNF_LAUNCH((encoder_bwd_pairs_kernel<DT, U, PW>), dim3(wgs), dim3(kPairsNT), lds, st, b, cpl, g);
+    return true;
 }
 
 extern "C" {
@@ -977,7 +987,12 @@ static int encoder_bwd_dispatch(const char* what, const int64_t* categ, const fl
     hipStream_t st = (hipStream_t)stream;
     const int which = g_enc_bwd_kernel.load(std::memory_order_relaxed);
     const long P = (long)C * 2 * D;
-    if (pair_shape_ok(b.ntok, D, C) && (which == 2 || (which == 0 && pair_kernel_preferred(b.ntok, C, class_prob_log != nullptr)))) {
+    // which: 0 = by shape, 1 = the two passes, 2 / 3 = the narrow / wide pair workgroup wherever its lanes hold the classes
+    int pw = 0;
+    if (which == 2 && pair_shape_ok(b.ntok, D, C, kPairMaxC)) pw = kPairWaves;
+    else if (which == 3 && pair_shape_ok(b.ntok, D, C)) pw = kPairWavesWide;
+    else if (which == 0 && pair_shape_ok(b.ntok, D, C)) pw = pair_kernel_choice(b.ntok, C, class_prob_log != nullptr);
+    if (pw) {
         // the pairs walked once with the token denominators known: the forward's class_prob_log, or a pre-pass that repeats
         // the forward's density sum
         b.partials = workspace;
@@ -989,9 +1004,13 @@ static int encoder_bwd_dispatch(const char* what, const int64_t* categ, const fl
             DISPATCH_D(D, CNF_LAUNCH((encoder_bwd_cpl_kernel<(DT > 0 ? DT : 1)>), dim3(grid_c), dim3(kBlock), lds_c, st, b, own_cpl));
             cpl = own_cpl;
         }
-        DISPATCH_D(D, (launch_pairs<(DT > 0 ? DT : 1), kPairTokens, kPairWaves>(b, cpl, D, C, st)));
-        CNF_LAUNCH(encoder_bwd_splits64_kernel, dim3((unsigned)((P + 3) / 4)), dim3(kBlock), 0, st, (const float*)b.partials, b.S, P, g_table);
-        return launch_status(what);
+        bool done = false;
+        if (pw == kPairWavesWide) { DISPATCH_D(D, done = (launch_pairs<(DT > 0 ? DT : 1), kPairTokens, kPairWavesWide>(b, cpl, D, C, st))); }
+        else { DISPATCH_D(D, done = (launch_pairs<(DT > 0 ? DT : 1), kPairTokens, kPairWaves>(b, cpl, D, C, st))); }
+        if (done) {
+            CNF_LAUNCH(encoder_bwd_splits64_kernel, dim3((unsigned)((P + 3) / 4)), dim3(kBlock), 0, st, (const float*)b.partials, b.S, P, g_table);
+            return launch_status(what);
+        }
     }
     b.S = bwd_tiled_splits(b.ntok, C);
     b.rec = workspace;

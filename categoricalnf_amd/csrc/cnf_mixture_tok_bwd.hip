@@ -57,6 +57,32 @@ __device__ __forceinline__ void bound_grads_f(float raw, const BoundTab& b, floa
     d_sf = b.f >= 1.f ? b.f * (th - uu * sech2) : b.f * th;
 }
 
+// Stores of the gradient rows and zero blocks (g_nn is written once and not read again by this kernel): -DCNF_MIXBWD_NT = nontemporal
+// (A/B build, profiles/r05_mixture_bwd_floor.txt)
+typedef float mb_f4 __attribute__((ext_vector_type(4)));
+typedef float mb_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void wb_store(float4* p, float4 v) {
+#ifdef CNF_MIXBWD_NT
+    __builtin_nontemporal_store(mb_f4{v.x, v.y, v.z, v.w}, reinterpret_cast<mb_f4*>(p));
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void wb_store(float2* p, float2 v) {
+#ifdef CNF_MIXBWD_NT
+    __builtin_nontemporal_store(mb_f2{v.x, v.y}, reinterpret_cast<mb_f2*>(p));
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void wb_store(float* p, float v) {
+#ifdef CNF_MIXBWD_NT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
 // g_z of an element the streaming kernel left to the fix-up launch: a quiet NaN with this payload
 constexpr uint32_t kTailSentinel = 0x7fc0a11eu;
 
@@ -501,7 +527,7 @@ __device__ __forceinline__ void mixture_tok_bwd_body(const MixArgs& a, const Tok
                         const int lpos = gm.contig ? (int)(src0 & 15) + s * gm.tokstride + r
                                                    : s * gm.slot + (int)((src0 + (uintptr_t)s * gm.tokstride) & 15) + r;
                         const float4 v = *reinterpret_cast<const float4*>(stage_b + lpos);
-                        *reinterpret_cast<float4*>(reinterpret_cast<char*>(gspan0) + (size_t)s * gm.tokstride + r) = v;
+                        wb_store(reinterpret_cast<float4*>(reinterpret_cast<char*>(gspan0) + (size_t)s * gm.tokstride + r), v);
                     }
                 } else if (w.wb_align == 8) {
                     for (int b = lane * 8; b < total_b; b += kWave * 8) {
@@ -510,7 +536,7 @@ __device__ __forceinline__ void mixture_tok_bwd_body(const MixArgs& a, const Tok
                         const int lpos = gm.contig ? (int)(src0 & 15) + s * gm.tokstride + r
                                                    : s * gm.slot + (int)((src0 + (uintptr_t)s * gm.tokstride) & 15) + r;
                         const float2 v = *reinterpret_cast<const float2*>(stage_b + lpos);
-                        *reinterpret_cast<float2*>(reinterpret_cast<char*>(gspan0) + (size_t)s * gm.tokstride + r) = v;
+                        wb_store(reinterpret_cast<float2*>(reinterpret_cast<char*>(gspan0) + (size_t)s * gm.tokstride + r), v);
                     }
                 } else {
                     for (int b = lane * 4; b < total_b; b += kWave * 4) {
@@ -519,7 +545,7 @@ __device__ __forceinline__ void mixture_tok_bwd_body(const MixArgs& a, const Tok
                         const int lpos = gm.contig ? (int)(src0 & 15) + s * gm.tokstride + r
                                                    : s * gm.slot + (int)((src0 + (uintptr_t)s * gm.tokstride) & 15) + r;
                         const float v = *reinterpret_cast<const float*>(stage_b + lpos);
-                        *reinterpret_cast<float*>(reinterpret_cast<char*>(gspan0) + (size_t)s * gm.tokstride + r) = v;
+                        wb_store(reinterpret_cast<float*>(reinterpret_cast<char*>(gspan0) + (size_t)s * gm.tokstride + r), v);
                     }
                 }
             }
@@ -545,7 +571,7 @@ __device__ __forceinline__ void mixture_tok_bwd_body(const MixArgs& a, const Tok
                         const int tk = (int)fdiv((uint32_t)e, w.div_ncp);
                         const int rb = (e - tk * upt) * width;
                         const int col = rb < head_b ? rb : rb + span_b2;
-                        *reinterpret_cast<decltype(zero)*>(gtok0 + (size_t)tk * gm.tokstride + col) = zero;
+                        wb_store(reinterpret_cast<decltype(zero)*>(gtok0 + (size_t)tk * gm.tokstride + col), zero);
                     }
                 };
                 if (w.wb_align == 16) zero_fill(make_float4(0.f, 0.f, 0.f, 0.f), 16);

@@ -594,7 +594,7 @@ int cnf_mixture_params_bwd(const float* nn_out, const float* scaling_factor, con
  * 153-174): g_table [C,2D]; eps / categories / prior are constants.  Tables of any size (word-level vocabularies included):
  * a token-lane pass (log-denominator and d loss / d z per token in one sweep over the class chunks) and a class-lane pass (every
  * lane owns one class and accumulates its table row over the token records), partial tables summed in a fixed order;
- * no [T*C] tensor, no floating-point atomics, bit-reproducible.  On small batches (up to 16 384 tokens, 16 ... 192 classes,
+ * no [T*C] tensor, no floating-point atomics, bit-reproducible.  On small batches (up to 16 384 tokens, 16 ... 448 classes,
  * D in {1,2,3,4,6,8}) it repeats the forward's density sum and runs the pair kernel of cnf_encoder_forward_bwd_cpl instead.
  * workspace = cnf_encoder_bwd_tiled_workspace_floats(B, N, D, C) floats. */
 int64_t cnf_encoder_bwd_tiled_workspace_floats(int B, int N, int D, int C);
@@ -604,17 +604,20 @@ int cnf_encoder_forward_bwd_tiled(const int64_t* categ, const float* eps, const 
                                   int B, int N, int D, int C, float sigma, float log_sigma, cnf_stream_t stream);
 /* cnf_encoder_forward_bwd_tiled for a caller that kept the forward's class_prob_log [B*N] (log q_c of every token: an output
  * of cnf_encoder_forward* on the same inputs; linear_encoding.py:163-171).  Every token's denominator is then known up
- * front, and up to 192 classes (D in {1,2,3,4,6,8}) ONE kernel can walk the (token, class) pairs once: a lane owns a class
+ * front, and up to 448 classes (D in {1,2,3,4,6,8}) ONE kernel can walk the (token, class) pairs once: a lane owns a class
  * and a few tokens of a stage, the pair terms it computes feed both reductions (over the tokens in its registers for the
- * class row, over the classes through LDS for the token's own-class gradient).  Taken at 9 ... 64 classes and on small
- * batches (where it is faster: 94 vs 117 us at 10^6 tokens x 16 classes, 14 vs 21 us at 4096 tokens); the two passes
- * otherwise.  class_prob_log == NULL = cnf_encoder_forward_bwd_tiled.  Same workspace, same reproducibility. */
+ * class row, over the classes through LDS for the token's own-class gradient).  Two workgroup shapes (3 or 7 waves of pair
+ * lanes + one token wave); taken where it is faster than the two passes — 9 ... 64 classes at any size (10^6 tokens: 94 vs
+ * 117 us at 16 classes, 265 vs 316 at 51), more classes on smaller batches, every class count it can hold up to 16 384 tokens
+ * (4 096 tokens x 27 classes: 14 vs 27 us) — the two passes otherwise.  class_prob_log == NULL =
+ * cnf_encoder_forward_bwd_tiled.  Same workspace, same reproducibility. */
 int cnf_encoder_forward_bwd_cpl(const int64_t* categ, const float* eps, const float* table,
                                 const float* category_prior, const float* pad, float beta, const float* class_prob_log,
                                 const float* g_zout, const float* g_ldj, float* g_table, float* workspace,
                                 int B, int N, int D, int C, float sigma, float log_sigma, cnf_stream_t stream);
-/* A-B knob of the two entry points above: 0 (default) = by shape as described, 1 = always the two passes, 2 = the pair
- * kernel wherever its shape limits allow (with the pre-pass when no class_prob_log is given). */
+/* A-B knob of the two entry points above: 0 (default) = by shape as described, 1 = always the two passes, 2 / 3 = the pair
+ * kernel on its 256-lane / 512-lane workgroup wherever the pair lanes (192 / 448) hold the classes (with the pre-pass when no
+ * class_prob_log is given). */
 void cnf_set_encoder_bwd_kernel(int which);
 
 /* d(SigmoidFlow.forward) w.r.t. its input (sigmoid_layer.py:31-37). */

@@ -444,7 +444,8 @@ def _within(got, ref, rtol=2e-3, atol_rel=2e-4):
 # (B, N, D, C): one stage and many stages per workgroup, ragged last stage, every templated D, class counts at the limits of the
 # pair lanes (192 = 3 waves), a vocabulary of one class, more tokens per stage than the token wave's 64 lanes (C = 2, 3)
 PAIR_SHAPES = [(64, 16, 6, 16), (33, 8, 8, 51), (6, 30, 4, 64), (5, 7, 3, 5), (4, 5, 1, 2), (2, 300, 2, 120), (7, 33, 6, 192),
-               (300, 64, 6, 16), (129, 17, 6, 9), (3, 11, 4, 1), (40, 50, 6, 3), (512, 64, 6, 27)]
+               (300, 64, 6, 16), (129, 17, 6, 9), (3, 11, 4, 1), (40, 50, 6, 3), (512, 64, 6, 27), (5, 9, 6, 300), (3, 7, 4, 448),
+               (700, 64, 6, 51)]
 
 
 @pytest.mark.parametrize("B,N,D,C", PAIR_SHAPES)
@@ -461,16 +462,19 @@ def test_backward_pair_kernel_against_the_oracle(B, N, D, C, pad_mode):
     g = torch.Generator(device=dev).manual_seed(B + N)
     gz, gl = torch.randn(B, N, D, generator=g, device=dev), torch.randn(B, generator=g, device=dev)
     ref = _oracle_table_grad(categ, eps, table, prior, pad, 1.3, gz, gl)
-    for use_cpl in (True, False):
-        got = _bwd_call(lib, ops, 2, use_cpl, categ, eps, table, prior, pad, 1.3, gz, gl)
-        assert torch.isfinite(got).all()
-        assert _within(got, ref) <= 1.0, (use_cpl, _within(got, ref))
-        assert torch.equal(got, _bwd_call(lib, ops, 2, use_cpl, categ, eps, table, prior, pad, 1.3, gz, gl))      # fixed summation order
+    forced = {}
+    for knob in (2, 3):                                   # the 256-lane and the 512-lane pair workgroup
+        for use_cpl in (True, False):
+            got = _bwd_call(lib, ops, knob, use_cpl, categ, eps, table, prior, pad, 1.3, gz, gl)
+            assert torch.isfinite(got).all()
+            assert _within(got, ref) <= 1.0, (knob, use_cpl, _within(got, ref))
+            assert torch.equal(got, _bwd_call(lib, ops, knob, use_cpl, categ, eps, table, prior, pad, 1.3, gz, gl))      # fixed summation order
+            forced[(knob, use_cpl)] = got
     two = _bwd_call(lib, ops, 1, False, categ, eps, table, prior, pad, 1.3, gz, gl)
     assert _within(two, ref) <= 1.0
-    # the default route (by shape) is one of the two
+    # the default route (by shape) is one of the three
     dflt = _bwd_call(lib, ops, 0, True, categ, eps, table, prior, pad, 1.3, gz, gl)
-    assert torch.equal(dflt, _bwd_call(lib, ops, 2, True, categ, eps, table, prior, pad, 1.3, gz, gl)) or torch.equal(dflt, two)
+    assert torch.equal(dflt, forced[(2, True)]) or torch.equal(dflt, forced[(3, True)]) or torch.equal(dflt, two)
     # one upstream gradient only
     for a, b_ in ((gz, None), (None, gl)):
         r1 = _oracle_table_grad(categ, eps, table, prior, pad, 0.7, a, b_)
@@ -478,13 +482,14 @@ def test_backward_pair_kernel_against_the_oracle(B, N, D, C, pad_mode):
 
 
 def test_backward_pair_kernel_shape_limits_fall_back_to_the_two_passes():
-    """Beyond 192 classes or at a D without an instantiation the forced pair kernel is the two passes (same bits)."""
+    """Beyond the pair lanes' class count (192 / 448), where the stage does not fit 64 KB of LDS (448 classes at D = 8) or at a
+    D without an instantiation the forced pair kernel is the two passes (same bits)."""
     lib, ops = _setup()
     dev = torch.device("cuda:0")
-    for B, N, D, C in ((3, 9, 6, 193), (4, 6, 5, 7)):
+    for knob, B, N, D, C in ((2, 3, 9, 6, 193), (2, 4, 6, 5, 7), (3, 3, 9, 6, 449), (3, 2, 5, 8, 448)):
         categ, eps, table, prior, pad, _ = _inputs(B, N, D, C, 5, 1, dev)
         gz, gl = torch.randn(B, N, D, device=dev), torch.randn(B, device=dev)
-        a = _bwd_call(lib, ops, 2, True, categ, eps.contiguous(), table, prior, pad, 1.0, gz, gl)
+        a = _bwd_call(lib, ops, knob, True, categ, eps.contiguous(), table, prior, pad, 1.0, gz, gl)
         b_ = _bwd_call(lib, ops, 1, False, categ, eps.contiguous(), table, prior, pad, 1.0, gz, gl)
         assert torch.equal(a, b_)
 
@@ -512,10 +517,11 @@ def test_backward_pair_kernel_log_domain_tokens(B, N, D, C):
     cases.append((t2, -83.0 + 0.7 * torch.randn(C, generator=g, device=dev)))        # every own density ~2^-120 ... 2^-135
     for tb, pr in cases:
         ref = _oracle_table_grad(categ, eps, tb, pr, pad, 1.3, gz, gl)
-        for use_cpl in (True, False):
-            got = _bwd_call(lib, ops, 2, use_cpl, categ, eps, tb, pr, pad, 1.3, gz, gl)
-            assert torch.isfinite(got).all()
-            assert _within(got, ref) <= 1.0, (use_cpl, _within(got, ref))
+        for knob in (2, 3):
+            for use_cpl in (True, False):
+                got = _bwd_call(lib, ops, knob, use_cpl, categ, eps, tb, pr, pad, 1.3, gz, gl)
+                assert torch.isfinite(got).all()
+                assert _within(got, ref) <= 1.0, (knob, use_cpl, _within(got, ref))
 
 
 def test_backward_pair_kernel_at_the_benchmark_size():
@@ -539,6 +545,14 @@ def test_backward_pair_kernel_at_the_benchmark_size():
     z, ldj, _ = Fn.EncoderForwardFn.apply(tg, categ, eps, prior, None, 1.0, False, None)
     ((z * gz).sum() + (ldj * gl).sum()).backward()
     assert torch.equal(tg.grad, pair)
+    # 51 classes: the 512-lane workgroup is the library's choice there
+    C = 51
+    categ, eps, table, prior, _, _ = _inputs(B, N, D, C, 4, 0, dev)
+    eps = eps.contiguous()
+    wide = _bwd_call(lib, ops, 3, True, categ, eps, table, prior, None, 1.0, gz, gl)
+    assert torch.equal(wide, _bwd_call(lib, ops, 0, True, categ, eps, table, prior, None, 1.0, gz, gl))
+    two = _bwd_call(lib, ops, 1, False, categ, eps, table, prior, None, 1.0, gz, gl)
+    assert float((wide - two).abs().max()) <= 2e-4 * float(two.abs().max())
 
 
 def test_actconv_forward_hands_out_the_class_posterior():
