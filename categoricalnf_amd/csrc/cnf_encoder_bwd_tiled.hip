@@ -992,6 +992,10 @@ static int encoder_bwd_dispatch(const char* what, const int64_t* categ, const fl
     if (which == 2 && pair_shape_ok(b.ntok, D, C, kPairMaxC)) pw = kPairWaves;
     else if (which == 3 && pair_shape_ok(b.ntok, D, C)) pw = kPairWavesWide;
     else if (which == 0 && pair_shape_ok(b.ntok, D, C)) pw = pair_kernel_choice(b.ntok, C, class_prob_log != nullptr);
+    if (pw) {                                           // ... if its stage fits 64 KB of LDS at this class count
+        PairsGeom fit;
+        if (make_pairs_geom(b.ntok, D, C, kPairTokens, pw * 64, fit) > 64 * 1024) pw = 0;
+    }
     if (pw) {
         // the pairs walked once with the token denominators known: the forward's class_prob_log, or a pre-pass that repeats
         // the forward's density sum
