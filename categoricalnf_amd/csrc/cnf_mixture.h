@@ -59,7 +59,7 @@ struct MixArgs {
 };
 
 // cnf_mixture_tok.hip
-bool launch_mixture_tok(MixArgs& a, hipStream_t st, int force_g);
+bool launch_mixture_tok(MixArgs& a, hipStream_t st, int force_g, bool x64 = false);
 void set_mixture_split_waves(int w);
 void set_mixture_whole_tokens(int on);
 // cnf_mixture_tok_bwd.hip
@@ -88,6 +88,8 @@ __device__ __forceinline__ BoundTab make_bound(float raw_sf) {
 __device__ __forceinline__ float apply_bound(float v, const BoundTab& b) {
     return fmaf(__builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(v * b.x3) + 1.f), b.m2f, b.f);
 }
+// the same bound with the library tanh, as the fp64 kernels apply it (get_mixt_params :156-162: fp32, then widened)
+__device__ __forceinline__ float apply_bound_exact(float v, const BoundTab& b) { return tanhf(v / fmaxf(b.f, 1.f)) * b.f; }
 
 // G = lanes per item: 1, or 4 for a run-time K too large to stage 64 rows per wave (the language model's K = 51
 // rows are 620 bytes): a pass then covers 16 items, lane g of an item takes the mixtures k = g (mod 4) and the four
@@ -126,6 +128,19 @@ __device__ __forceinline__ float qsum(float v) {
     static_assert(G == 1 || G == 2 || G == 4, "quad-permute reductions cover groups of 1, 2 or 4 lanes");
     if (G >= 2) v += quad_dpp<kQuadXor1>(v);
     if (G >= 4) v += quad_dpp<kQuadXor2>(v);
+    return v;
+}
+template <int CTRL>
+__device__ __forceinline__ double quad_dpp64(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+template <int G>
+__device__ __forceinline__ double qsum64(double v) {
+    if (G >= 2) v += quad_dpp64<kQuadXor1>(v);
+    if (G >= 4) v += quad_dpp64<kQuadXor2>(v);
     return v;
 }
 template <int G>

@@ -956,6 +956,11 @@ static int launch_mixture(MixArgs& a, bool split, const int* act_host, int n_act
     if (!split && math_mode() == 1 && (!a.reverse || inverse_mode() == 1) && g_mix_kernel != 1) {
         if (launch_mixture_tok(a, st, g_mix_lanes)) return launch_status(who);
     }
+    // math mode 0 (fp64 like the reference) on the same token passes; the kernel below stays for the fp64-tensor API,
+    // bisection, K > 64 and shapes the token-pass geometry declines
+    if (!split && math_mode() == 0 && (!a.reverse || inverse_mode() == 1) && g_mix_kernel != 1 && !a.e_w && !a.nll_out) {
+        if (launch_mixture_tok(a, st, 0, /*x64=*/true)) return launch_status(who);
+    }
     if (a.e_w) {
         // the token-pass kernel declined: the plain coupling, then the fused ActNorm + 1x1 convolution kernel in place
         MixArgs b = a;

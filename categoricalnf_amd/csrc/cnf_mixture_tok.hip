@@ -46,11 +46,19 @@ namespace cnf {
 // evaluation, one serial chain per wave (PTB shape, K = 51: inverse 45 us against a 25 us forward).
 // Register budget: the K = 8 inverse (configs[1]) needs 97 VGPRs as compiled freely, one more than five waves per SIMD
 // allow; asking for five costs nothing in the loop (no spills) and buys the fifth wave.
-constexpr int tok_min_waves(int kt, bool reverse, int g, bool pr) { return (kt == 8 && reverse && g == 1 && !pr) ? 5 : 1; }
+constexpr int tok_min_waves(int kt, bool reverse, int g, bool pr, bool x64 = false) {
+    return (kt == 8 && reverse && g == 1 && !pr && !x64) ? 5 : 1;
+}
 
-template <int KT, bool REVERSE, int G, bool NLL, int ED = 0, bool PR = false>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(tok_min_waves(KT, REVERSE, G, PR))))
+//
+// X64 (math mode 0, the reference's precision: mixture_cdf_layer.py:62,173-178 compute in fp64): the same passes with
+// the arithmetic of the fp64 kernel of cnf_mixture.hip — every element takes what is the rare branch of the fp32
+// forward; the inverse polishes the fp32 Newton root with safeguarded Newton steps in fp64 (quadratic convergence: two
+// evaluations from a 1e-7 start) inside the widened component-quantile bracket.  KT > 0 only.
+template <int KT, bool REVERSE, int G, bool NLL, int ED = 0, bool PR = false, bool X64 = false>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(tok_min_waves(KT, REVERSE, G, PR, X64))))
 void mixture_tok_kernel(MixArgs a, TokGeom gm) {
+    static_assert(!X64 || (KT > 0 && !NLL && ED == 0), "fp64 arithmetic: register slots, plain coupling");
     static_assert(G == 1 || KT == 0 || PR, "several lanes per item: run-time K (rolled loop) or predicated slots");
     static_assert(!(NLL && REVERSE), "the NLL epilogue belongs to the forward pass");
     static_assert(ED == 0 || (!REVERSE && !NLL), "the ActNorm + convolution epilogue belongs to a forward pass inside a flow");
@@ -137,6 +145,7 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
     // slot i of this lane -> mixture index, and whether the slot holds a mixture of its own
     auto kidx = [&](int i) { return PR ? min(sub + G * i, K - 1) : i; };
     auto kown = [&](int i) { return !PR || sub + G * i < K; };
+    auto bound_of = [&](float v, const BoundTab& b) { return X64 ? apply_bound_exact(v, b) : apply_bound(v, b); };
     bool bad = false, range = false, badl = false;
     double acc_ldj = 0.0, acc_nlp = 0.0;          // split mode: this lane's running sums
 
@@ -160,6 +169,26 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
         float contrib = 0.f;
         double contrib64 = 0.0;
         bool use64 = false;
+        // log-space mixture log-pdf on the staged row, for a direct sum that underflows
+        auto logspace_pdf = [&](double xd, float mx, double sed) {
+            // log-space form (:217-223)
+            const double lse_pi = (double)mx + log(sed);
+            double m = -INFINITY;
+#pragma clang loop unroll(disable)
+            for (int k = 0; k < K; ++k) {
+                const float lsf = a.msf ? bound_of(my[2 + 2 * K + k], mt[k]) : my[2 + 2 * K + k];
+                const double zd = (xd - (double)my[2 + K + k]) * exp(-(double)lsf);
+                m = fmax(m, (double)my[2 + k] - lse_pi + zd - (double)lsf - 2.0 * softplus64(zd));
+            }
+            double ssum = 0.0;
+#pragma clang loop unroll(disable)
+            for (int k = 0; k < K; ++k) {
+                const float lsf = a.msf ? bound_of(my[2 + 2 * K + k], mt[k]) : my[2 + 2 * K + k];
+                const double zd = (xd - (double)my[2 + K + k]) * exp(-(double)lsf);
+                ssum += exp((double)my[2 + k] - lse_pi + zd - (double)lsf - 2.0 * softplus64(zd) - m);
+            }
+            return m + log(ssum);
+        };
         if (active && REVERSE) {
             // ---- inverse (:125-134, :235-264) in fp32: safeguarded Newton on the two-sided CDF.  u = sigmoid(v)
             // is clamped to [1e-5, 1 - 1e-5] by the reference, so the root lies where fp32 sums of positive
@@ -194,6 +223,7 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
                 mx = qmax<G>(mx);
             }
             float se = 0.f, spread = 0.f, lb = INFINITY, ub = -INFINITY, qws = 0.f;
+            float smin = INFINITY;                  // X64: smallest component scale (the polish's tolerance)
             auto setup = [&](int k, int slot, bool own) {
                 const float lsk = my[2 + 2 * K + k];
                 const float ls = a.msf ? apply_bound(lsk, mt[k]) : lsk;
@@ -206,6 +236,7 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
                 const float qk = fmaf(sk, logit_u, mk);
                 se += w;
                 spread += (PR && !own) ? 0.f : sk;
+                if (X64) smin = fminf(smin, sk);
                 lb = fminf(lb, qk);
                 ub = fmaxf(ub, qk);
                 qws = fmaf(w, qk, qws);
@@ -225,7 +256,9 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
             if (G > 1) {
                 se = qsum<G>(se); spread = qsum<G>(spread); qws = qsum<G>(qws);
                 lb = qmin<G>(lb); ub = qmax<G>(ub);
+                if (X64) smin = qmin<G>(smin);
             }
+            const float lb0 = lb, ub0 = ub;         // every component's own u-quantile lies in here, and so does the root
             const float target = (upper ? uc : u) * se;
             const float tol_scale = 1e-7f * spread;
             float xb = fminf(fmaxf(qws * __builtin_amdgcn_rcpf(se), lb), ub);
@@ -277,10 +310,83 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
                 float f;
                 eval(xb, f, dens);
             }
+            if constexpr (X64) {
+                // ---- the reference's precision: u, the weights and the scales in fp64 (:125-134), then safeguarded Newton
+                // in fp64 from the fp32 root.  Its error ~1e-7 (|x| + sum s_k) squares with every accepted step, so the
+                // second evaluation usually ends the loop; the bracket is the fp32 quantile bracket, widened past
+                // anything fp32 rounding of q_k can move it, and the bisection fallback of rtsafe stays in place.
+                float ls_raw = my[1];
+                if (a.sf) ls_raw = apply_bound_exact(ls_raw, sf_tab[d]);
+                const double lsd = (double)ls_raw;
+                const double vd = (double)x * exp(-lsd) - (double)t;
+                double ud = 1.0 / (1.0 + exp(-vd));
+                const double mldj = softplus64(vd) + softplus64(-vd);
+                ud = fmin(fmax(ud, 1e-5), 1.0 - 1e-5);
+                if (!(ud > 0.0 && ud < 1.0)) range = true;
+                double wd[KK], isd[KK];
+                double sed = 0.0;
+#pragma unroll
+                for (int i = 0; i < KK; ++i) {
+                    const int k = kidx(i);
+                    const float lsk = my[2 + 2 * K + k];
+                    const float lsf = a.msf ? apply_bound_exact(lsk, mt[k]) : lsk;
+                    double w = exp((double)my[2 + k] - (double)mx);
+                    if (PR && !kown(i)) w = 0.0;
+                    wd[i] = w;
+                    isd[i] = exp(-(double)lsf);
+                    sed += w;
+                }
+                sed = qsum64<G>(sed);
+                const double tgt = ud * sed;
+                const double widen = 1e-4 * (12.0 * (double)spread + fabs((double)lb0) + fabs((double)ub0));
+                double lbd = (double)lb0 - widen, ubd = (double)ub0 + widen;
+                double xq = fmin(fmax((double)xb, lbd), ubd);
+                double dxp = ubd - lbd, dn = 0.0;
+                const double tol_s = 1e-11 * (double)smin;
+                for (int iter = 0; iter < 100; ++iter) {
+                    double c = 0.0;
+                    dn = 0.0;
+#pragma unroll
+                    for (int i = 0; i < KK; ++i) {
+                        const double zk = (xq - (double)mur[i]) * isd[i];
+                        const double e = exp(-fabs(zk));
+                        const double rr = 1.0 / (1.0 + e);
+                        c += wd[i] * (zk >= 0.0 ? rr : e * rr);
+                        dn += wd[i] * isd[i] * (e * rr * rr);
+                    }
+                    if (G > 1) {
+                        c = qsum64<G>(c); dn = qsum64<G>(dn);
+                    }
+                    const double f = c - tgt;
+                    double nx;
+                    if (f > 0.0) {
+                        nx = 0.5 * (xq + lbd);
+                        ubd = xq;
+                    } else {
+                        nx = 0.5 * (xq + ubd);
+                        lbd = xq;
+                    }
+                    if (dn > 0.0 && fabs(2.0 * f) <= fabs(dxp * dn)) {
+                        const double xn = xq - f / dn;
+                        if (xn >= lbd && xn <= ubd) nx = xn;
+                    }
+                    const double dd = fabs(nx - xq);
+                    dxp = dd;
+                    xq = nx;
+                    // the density of the last evaluation stands in for the one at the root: relative error <= dd / s_min
+                    if (!(dd > fmax(tol_s, 4e-16 * fabs(xq)))) break;
+                }
+                const double lpdfd = dn > 1e-290 ? log(dn / sed) : logspace_pdf(xq, mx, sed);
+                of = (float)xq;
+                if (a.pad_output) of = of * pv;
+                contrib64 = lsd + mldj + lpdfd;
+                use64 = true;
+            } else {
             const float lpdf = (__builtin_amdgcn_logf(dens) - __builtin_amdgcn_logf(se)) * kLn2F;
             of = xb;
             if (a.pad_output) of = of * pv;
             contrib = log_s + mixt_ldj + lpdf;
+            }
         }
         if (active && !REVERSE) {
             const float t = my[0];
@@ -305,6 +411,53 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
                 mx = qmax<G>(mx);
             }
             float se = 0.f, cdf = 0.f, ccdf = 0.f, pdf = 0.f;
+            double reg = 0.0;
+            // the reference's u -> (z, log-det, regulariser) in fp64 from the three fp64 sums (:100-123, :217-233)
+            auto wide_tail = [&](double sed, double cdfd, double pdfd) {
+                const double xd = (double)x;
+                const double ud = cdfd / sed;
+                double lpdfd;
+                if (pdfd > 1e-290) {
+                    lpdfd = log(pdfd / sed);
+                } else {
+                    lpdfd = logspace_pdf(xd, mx, sed);
+                }
+                const double lud = safe_log(ud), l1ud = safe_log(1.0 - ud);
+                if (a.use_reg) {
+                    const double r1 = lud / kLn10, r2 = l1ud / kLn10;
+                    reg = (fmin(r1, -a.reg_max) + a.reg_max) + (fmin(r2, -a.reg_max) + a.reg_max);
+                }
+                const double yd = ud >= 1e-22 ? lud - l1ud : -safe_log(1.0 / ud - 1.0);
+                of = (float)((yd + (double)t) * exp((double)log_s));
+                contrib64 = (double)log_s + (-lud - l1ud) + lpdfd + reg * a.reg_factor;
+                use64 = true;
+            };
+            if constexpr (X64) {
+                double sed = 0.0, cdfd = 0.0, pdfd = 0.0;
+                // the reference's arithmetic on this lane's slots; log_s / log-scale bounds by the library tanh
+                if (a.sf) log_s = apply_bound_exact(my[1], sf_tab[d]);
+                const double xd = (double)x;
+                // a rolled loop over the LDS row (register arrays under a run-time index become select chains)
+#pragma unroll 2
+                for (int i = 0; i < KK; ++i) {
+                    const int k = kidx(i);
+                    const float lsk = my[2 + 2 * K + k];
+                    const float lsf = a.msf ? apply_bound_exact(lsk, mt[k]) : lsk;
+                    double wd = exp((double)my[2 + k] - (double)mx);
+                    if (PR && !kown(i)) wd = 0.0;
+                    const double isd = exp(-(double)lsf);
+                    const double zd = (xd - (double)my[2 + K + k]) * isd;
+                    const double ed = exp(-fabs(zd));
+                    const double rd = 1.0 / (1.0 + ed);
+                    sed += wd;
+                    cdfd += wd * (zd >= 0.0 ? rd : ed * rd);
+                    pdfd += wd * isd * (ed * rd * rd);
+                }
+                if (G > 1) {
+                    sed = qsum64<G>(sed); cdfd = qsum64<G>(cdfd); pdfd = qsum64<G>(pdfd);
+                }
+                wide_tail(sed, cdfd, pdfd);
+            } else {
             auto one = [&](float lpk, float muk, float lsk, int k, bool own) {
                 const float ls = a.msf ? apply_bound(lsk, mt[k]) : lsk;
                 const float inv_s = __builtin_amdgcn_exp2f(-ls * kLog2eF);
@@ -329,7 +482,6 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
             if (G > 1) {
                 se = qsum<G>(se); cdf = qsum<G>(cdf); ccdf = qsum<G>(ccdf); pdf = qsum<G>(pdf);
             }
-            double reg = 0.0;
             const float inv_se = __builtin_amdgcn_rcpf(se);
             const float u = cdf * inv_se, uc = ccdf * inv_se;
             if (u > 1e-9f && uc > 1e-9f && pdf > 1e-30f) {
@@ -364,38 +516,8 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
                     cdfd += wd * (zd >= 0.0 ? rd : ed * rd);
                     pdfd += wd * isd * (ed * rd * rd);
                 }
-                const double ud = cdfd / sed;
-                double lpdfd;
-                if (pdfd > 1e-290) {
-                    lpdfd = log(pdfd / sed);
-                } else {
-                    // log-space form (:217-223)
-                    const double lse_pi = (double)mx + log(sed);
-                    double m = -INFINITY;
-#pragma clang loop unroll(disable)
-                    for (int k = 0; k < K; ++k) {
-                        const float lsf = a.msf ? apply_bound(my[2 + 2 * K + k], mt[k]) : my[2 + 2 * K + k];
-                        const double zd = (xd - (double)my[2 + K + k]) * exp(-(double)lsf);
-                        m = fmax(m, (double)my[2 + k] - lse_pi + zd - (double)lsf - 2.0 * softplus64(zd));
-                    }
-                    double ssum = 0.0;
-#pragma clang loop unroll(disable)
-                    for (int k = 0; k < K; ++k) {
-                        const float lsf = a.msf ? apply_bound(my[2 + 2 * K + k], mt[k]) : my[2 + 2 * K + k];
-                        const double zd = (xd - (double)my[2 + K + k]) * exp(-(double)lsf);
-                        ssum += exp((double)my[2 + k] - lse_pi + zd - (double)lsf - 2.0 * softplus64(zd) - m);
-                    }
-                    lpdfd = m + log(ssum);
-                }
-                const double lud = safe_log(ud), l1ud = safe_log(1.0 - ud);
-                if (a.use_reg) {
-                    const double r1 = lud / kLn10, r2 = l1ud / kLn10;
-                    reg = (fmin(r1, -a.reg_max) + a.reg_max) + (fmin(r2, -a.reg_max) + a.reg_max);
-                }
-                const double yd = ud >= 1e-22 ? lud - l1ud : -safe_log(1.0 / ud - 1.0);
-                of = (float)((yd + (double)t) * exp((double)log_s));
-                contrib64 = (double)log_s + (-lud - l1ud) + lpdfd + reg * a.reg_factor;
-                use64 = true;
+                wide_tail(sed, cdfd, pdfd);
+            }
             }
             if (a.pad_output) of = of * pv;
             if (sub == 0 && a.use_reg && a.reg_out && reg != 0.0) atomicAdd(&a.reg_out[row0 + rl], (float)reg);
@@ -713,6 +835,12 @@ static void slots_for(int K, int& kt, int& g) {
 using TokKernel = void (*)(MixArgs, TokGeom);
 
 template <int KT, int G, bool PR>
+static TokKernel tok_variant64(const MixArgs& a) {
+    if (a.reverse) return mixture_tok_kernel<KT, true, G, false, 0, PR, true>;
+    return mixture_tok_kernel<KT, false, G, false, 0, PR, true>;
+}
+
+template <int KT, int G, bool PR>
 static TokKernel tok_variant(const MixArgs& a, bool nll) {
     if (a.reverse) return mixture_tok_kernel<KT, true, G, false, 0, PR>;
     if (nll) return mixture_tok_kernel<KT, false, G, true, 0, PR>;
@@ -731,7 +859,26 @@ static TokKernel tok_variant(const MixArgs& a, bool nll) {
     return mixture_tok_kernel<KT, false, G, false, 0, PR>;
 }
 
-static TokKernel tok_kernel_for(const MixArgs& a, int kt, int slot_g, int G, bool nll) {
+static TokKernel tok_kernel_for(const MixArgs& a, int kt, int slot_g, int G, bool nll, bool x64) {
+    if (x64) {
+        if (nll || a.e_w) return nullptr;
+        if (slot_g > 0) {
+            switch (kt * 8 + slot_g) {
+                case 7 * 8 + 1: return tok_variant64<7, 1, true>(a);
+                case 16 * 8 + 1: return tok_variant64<16, 1, true>(a);
+                case 7 * 8 + 2: return tok_variant64<7, 2, true>(a);
+                case 16 * 8 + 2: return tok_variant64<16, 2, true>(a);
+                case 7 * 8 + 4: return tok_variant64<7, 4, true>(a);
+                case 13 * 8 + 4: return tok_variant64<13, 4, true>(a);
+                case 16 * 8 + 4: return tok_variant64<16, 4, true>(a);
+                default: return nullptr;
+            }
+        }
+        if (kt == 4) return tok_variant64<4, 1, false>(a);
+        if (kt == 8) return tok_variant64<8, 1, false>(a);
+        if (kt == 16) return tok_variant64<16, 1, false>(a);
+        return nullptr;
+    }
     if (slot_g > 0) {
         switch (kt * 8 + slot_g) {
             case 7 * 8 + 1: return tok_variant<7, 1, true>(a, nll);
@@ -779,7 +926,8 @@ static long resident_workgroups(TokKernel kern, size_t lds) {
 }
 
 // forward (optionally with the NLL epilogue) or Newton inverse on the token-pass kernel; false = not handled
-bool launch_mixture_tok(MixArgs& a, hipStream_t st, int force_g) {
+bool launch_mixture_tok(MixArgs& a, hipStream_t st, int force_g, bool x64) {
+    if (x64 && (force_g != 0 || a.e_w || a.nll_out)) return false;      // fp64 arithmetic: register slots, plain coupling
     int kt = (a.K == 4 || a.K == 8 || a.K == 16) ? a.K : 0;
     // every other K: predicated register slots (force_g > 0, the sweep / test knob, keeps the rolled-loop kernel and
     // its lanes per item; the epilogue kernels exist for one lane per item only)
@@ -792,7 +940,7 @@ bool launch_mixture_tok(MixArgs& a, hipStream_t st, int force_g) {
     // (a whole token may not fit the stage where its transformed span does), then the rolled loop likewise
     bool whole = true;
     if (!make_tok_geom(a, kt, force_g, gm, G, lds, slot_g, true, 0) && (whole = false, !make_tok_geom(a, kt, force_g, gm, G, lds, slot_g, false, 0))) {
-        if (slot_g == 0) return false;
+        if (slot_g == 0 || x64) return false;
         kt = 0; slot_g = 0;
         whole = true;
         if (!make_tok_geom(a, kt, force_g, gm, G, lds, 0, true, 0) && (whole = false, !make_tok_geom(a, kt, force_g, gm, G, lds, 0, false, 0)))
@@ -800,7 +948,7 @@ bool launch_mixture_tok(MixArgs& a, hipStream_t st, int force_g) {
     }
     const bool nll = a.nll_out != nullptr;
     if (a.e_w && (G != 1 || !(a.D == 2 || a.D == 3 || a.D == 4 || a.D == 6))) return false;
-    const TokKernel kern = tok_kernel_for(a, kt, slot_g, G, nll);
+    const TokKernel kern = tok_kernel_for(a, kt, slot_g, G, nll, x64);
     if (!kern) return false;
     if (gm.split && gm.S > 1) {
         const long cap = resident_workgroups(kern, lds);

@@ -39,6 +39,11 @@ for (k, gs), c in sorted(rows.items()):
     wait = 100.0 * m.get("SQ_WAIT_ANY", 0.0) / wc if wc else float("nan")
     name = k.replace("void cnf::", "").split("(")[0]
     print("%-64s %9s %9.3g %9.3g %9.3g %9.3g %9.3g %11.2f %11.2f %8.0f" % (("%s (%d)" % (name, gs))[:64], "%.1f" % us if us else "-", fma, mul, add, t64, other, lo, hi, wait))
+    extra = {n: m[n] for n in ("SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_SCA",
+                               "SQ_ACTIVE_INST_LDS", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY", "SQ_INSTS_VALU", "SQ_INSTS_VALU_CVT",
+                               "SQ_INSTS_VALU_INT32", "GRBM_GUI_ACTIVE", "SQ_WAVES") if n in m}
+    if extra:
+        print("      " + "  ".join("%s %.3g" % (n.replace("SQ_", ""), v) for n, v in extra.items()))
     out.append({"kernel": name, "grid": gs, "us": us, "fma_f64": fma, "mul_f64": mul, "add_f64": add, "trans_f64": t64, "trans_f32": t32, "other_valu": other,
                 "fp64_issue_share_low": lo, "fp64_issue_share_high": hi, "wait_pct": wait})
 json.dump({"manifest": man, "kernels": out}, open(os.path.join(d, "fp64_ceilings.json"), "w"), indent=1)
