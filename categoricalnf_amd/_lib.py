@@ -87,6 +87,7 @@ SIGNATURES = {
     "cnf_stream_probe": [_p, _p, _p, ctypes.c_long, _i, _p],
     "cnf_stream_probe_bwd": [_p, _p, _p, _p, _p, ctypes.c_long, _i, _i, _p],
     "cnf_probe_affine_fwd_tile": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "cnf_probe_f64_math": [_i, _p, _p, ctypes.c_long, _i, _p],
 }
 _PLAIN = {"cnf_abi_version": ([], _i), "cnf_last_error": ([], ctypes.c_char_p),
           "cnf_set_tile_chunks": ([_i], None), "cnf_set_unroll": ([_i], None),

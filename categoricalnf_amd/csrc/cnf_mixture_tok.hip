@@ -23,6 +23,7 @@
 // sums of positive terms; elements with u or 1 - u below 1e-9, or an underflowing PDF sum, take the fp64 branch that
 // reproduces the reference's clamps.
 #include "cnf_mixture_tok.h"
+#include "cnf_f64_math.h"
 
 #include <algorithm>
 #include <atomic>
@@ -46,8 +47,16 @@ namespace cnf {
 // evaluation, one serial chain per wave (PTB shape, K = 51: inverse 45 us against a 25 us forward).
 // Register budget: the K = 8 inverse (configs[1]) needs 97 VGPRs as compiled freely, one more than five waves per SIMD
 // allow; asking for five costs nothing in the loop (no spills) and buys the fifth wave.
+#ifndef CNF_X64_FWD_WAVES
+#define CNF_X64_FWD_WAVES 1
+#endif
+#ifndef CNF_X64_INV_WAVES
+#define CNF_X64_INV_WAVES 3
+#endif
 constexpr int tok_min_waves(int kt, bool reverse, int g, bool pr, bool x64 = false) {
-    return (kt == 8 && reverse && g == 1 && !pr && !x64) ? 5 : 1;
+    // fp64 inverse with up to 8 slots: 184 VGPRs as compiled freely; three waves per SIMD (168) cost 2 spilled registers
+    if (x64) return reverse ? (kt <= 8 ? CNF_X64_INV_WAVES : 2) : CNF_X64_FWD_WAVES;
+    return (kt == 8 && reverse && g == 1 && !pr) ? 5 : 1;
 }
 
 //
@@ -319,8 +328,16 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
                 if (a.sf) ls_raw = apply_bound_exact(ls_raw, sf_tab[d]);
                 const double lsd = (double)ls_raw;
                 const double vd = (double)x * exp(-lsd) - (double)t;
-                double ud = 1.0 / (1.0 + exp(-vd));
-                const double mldj = softplus64(vd) + softplus64(-vd);
+                // sigmoid(v) and softplus(v) + softplus(-v) (:127-129) from ONE exponential E = e^{-|v|}: u = 1 / (1 + E) or
+                // E / (1 + E); softplus(|v|) = |v| + log1p(E) — F.softplus returns its argument above the threshold 20 —
+                // and softplus(-|v|) = log1p(E)
+                const double av = fabs(vd);
+                const double Ev = exp(-av);
+                const double rv1 = rcp64(1.0 + Ev);
+                double ud = vd >= 0.0 ? rv1 : Ev * rv1;
+                const double l1pE = log1p64_unit(Ev);
+                double mldj = av > 20.0 ? av + l1pE : av + (l1pE + l1pE);
+                if (!(av == av)) { ud = vd; mldj = vd; }       // NaN in: NaN out
                 ud = fmin(fmax(ud, 1e-5), 1.0 - 1e-5);
                 if (!(ud > 0.0 && ud < 1.0)) range = true;
                 double wd[KK], isd[KK];
@@ -343,14 +360,16 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
                 double xq = fmin(fmax((double)xb, lbd), ubd);
                 double dxp = ubd - lbd, dn = 0.0;
                 const double tol_s = 1e-11 * (double)smin;
+                int n_eval = 0;
                 for (int iter = 0; iter < 100; ++iter) {
                     double c = 0.0;
                     dn = 0.0;
+                    ++n_eval;
 #pragma unroll
                     for (int i = 0; i < KK; ++i) {
                         const double zk = (xq - (double)mur[i]) * isd[i];
                         const double e = exp(-fabs(zk));
-                        const double rr = 1.0 / (1.0 + e);
+                        const double rr = rcp64(1.0 + e);
                         c += wd[i] * (zk >= 0.0 ? rr : e * rr);
                         dn += wd[i] * isd[i] * (e * rr * rr);
                     }
@@ -376,8 +395,11 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
                     // the density of the last evaluation stands in for the one at the root: relative error <= dd / s_min
                     if (!(dd > fmax(tol_s, 4e-16 * fabs(xq)))) break;
                 }
-                const double lpdfd = dn > 1e-290 ? log(dn / sed) : logspace_pdf(xq, mx, sed);
+                const double lpdfd = dn > 1e-290 ? log64_pos(dn / sed) : logspace_pdf(xq, mx, sed);
                 of = (float)xq;
+#ifdef CNF_MIX64_COUNT_ITERS
+                of = (float)n_eval;             // diagnostic build (tools/mix64_iters.py): evaluations of the fp64 loop
+#endif
                 if (a.pad_output) of = of * pv;
                 contrib64 = lsd + mldj + lpdfd;
                 use64 = true;
@@ -395,7 +417,11 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
             constexpr int KK = KT > 0 ? KT : 1;
             float lp[KK], mu[KK], lsr[KK];
             float mx = -INFINITY;
-            if (KT > 0) {
+            if (X64) {
+                // the fp64 loop below reads the row where it lies: no register copies of it
+                for (int i = 0; i < KK; ++i) mx = fmaxf(mx, my[2 + kidx(i)]);
+                mx = qmax<G>(mx);
+            } else if (KT > 0) {
 #pragma unroll
                 for (int i = 0; i < KK; ++i) {
                     const int k = kidx(i);
@@ -418,16 +444,18 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
                 const double ud = cdfd / sed;
                 double lpdfd;
                 if (pdfd > 1e-290) {
-                    lpdfd = log(pdfd / sed);
+                    lpdfd = log64_pos(pdfd / sed);
                 } else {
                     lpdfd = logspace_pdf(xd, mx, sed);
                 }
-                const double lud = safe_log(ud), l1ud = safe_log(1.0 - ud);
+                // safe_log (:266-268) on arguments that are positive normals after its clamp
+                const double lud = log64_pos(fmax(ud, 1e-22)), l1ud = log64_pos(fmax(1.0 - ud, 1e-22));
                 if (a.use_reg) {
                     const double r1 = lud / kLn10, r2 = l1ud / kLn10;
                     reg = (fmin(r1, -a.reg_max) + a.reg_max) + (fmin(r2, -a.reg_max) + a.reg_max);
                 }
-                const double yd = ud >= 1e-22 ? lud - l1ud : -safe_log(1.0 / ud - 1.0);
+                double yd = lud - l1ud;
+                if (ud < 1e-22) yd = -safe_log(1.0 / ud - 1.0);
                 of = (float)((yd + (double)t) * exp((double)log_s));
                 contrib64 = (double)log_s + (-lud - l1ud) + lpdfd + reg * a.reg_factor;
                 use64 = true;
@@ -448,7 +476,7 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
                     const double isd = exp(-(double)lsf);
                     const double zd = (xd - (double)my[2 + K + k]) * isd;
                     const double ed = exp(-fabs(zd));
-                    const double rd = 1.0 / (1.0 + ed);
+                    const double rd = rcp64(1.0 + ed);          // 1 + e in [1, 2]: no scaling, correctly rounded on test
                     sed += wd;
                     cdfd += wd * (zd >= 0.0 ? rd : ed * rd);
                     pdfd += wd * isd * (ed * rd * rd);

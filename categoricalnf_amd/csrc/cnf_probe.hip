@@ -4,6 +4,7 @@
 // the 8 TB/s data-sheet figure ("also report a measured stream-copy ceiling from the same run").
 // Not part of the reference's interface; nothing in the layers calls it.
 #include "cnf_common.h"
+#include "cnf_f64_math.h"
 
 namespace cnf {
 namespace {
@@ -154,8 +155,54 @@ __global__ __launch_bounds__(256) void affine_fwd_tile_probe_kernel(const float*
         probe_lds_order();
     }
 }
+
+// which: 0 log64_pos, 1 rcp64, 2 log1p64_unit; 3 library exp, 4 library log, 5 library 1 / x, 6 library log1p.
+// reps > 1 (timing): the function is applied reps times to values derived from the input, results folded together
+template <int WHICH>
+__device__ __forceinline__ double f64_math_apply(double x) {
+    if (WHICH == 0) return log64_pos(x);
+    if (WHICH == 1) return rcp64(x);
+    if (WHICH == 2) return log1p64_unit(x);
+    if (WHICH == 3) return exp(x);
+    if (WHICH == 4) return log(x);
+    if (WHICH == 5) return 1.0 / x;
+    return log1p(x);
+}
+template <int WHICH>
+__global__ __launch_bounds__(256) void f64_math_kernel(const double* in, double* out, long n, int reps) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double x = in[i];
+    if (reps <= 1) {
+        out[i] = f64_math_apply<WHICH>(x);
+        return;
+    }
+    double acc = 0.0, v = x;
+    for (int r = 0; r < reps; ++r) {
+        acc += f64_math_apply<WHICH>(v);
+        v = x + acc * 1e-300;           // a dependence the compiler cannot remove, numerically void
+    }
+    out[i] = acc;
+}
 }  // namespace
 }  // namespace cnf
+
+extern "C" int cnf_probe_f64_math(int which, const double* in, double* out, long n, int reps, void* stream) {
+    using namespace cnf;
+    CNF_REQUIRE(in && out && n > 0 && which >= 0 && which <= 6, "cnf_probe_f64_math: which in 0..6");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    switch (which) {
+        case 0: CNF_LAUNCH((f64_math_kernel<0>), grid, block, 0, st, in, out, n, reps); break;
+        case 1: CNF_LAUNCH((f64_math_kernel<1>), grid, block, 0, st, in, out, n, reps); break;
+        case 2: CNF_LAUNCH((f64_math_kernel<2>), grid, block, 0, st, in, out, n, reps); break;
+        case 3: CNF_LAUNCH((f64_math_kernel<3>), grid, block, 0, st, in, out, n, reps); break;
+        case 4: CNF_LAUNCH((f64_math_kernel<4>), grid, block, 0, st, in, out, n, reps); break;
+        case 5: CNF_LAUNCH((f64_math_kernel<5>), grid, block, 0, st, in, out, n, reps); break;
+        default: CNF_LAUNCH((f64_math_kernel<6>), grid, block, 0, st, in, out, n, reps); break;
+    }
+    return launch_status("cnf_probe_f64_math");
+}
 
 extern "C" int cnf_stream_probe(const float* a, const float* b, float* out, long n, int chunks_per_lane, void* stream) {
     using namespace cnf;

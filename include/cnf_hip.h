@@ -120,6 +120,12 @@ int cnf_probe_affine_fwd_tile(const float* z, const float* nn_out, const float* 
                               float* z_out, float* ldj_out, int B, int N, int tiles_per_wave, int nontemporal_nn_loads,
                               cnf_stream_t stream);
 
+/* Test / timing hook of the fp64 log / log1p / reciprocal the reference-precision mixture kernels use
+ * (csrc/cnf_f64_math.h): out[i] = f(in[i]), which = 0 log of a positive normal, 1 reciprocal, 2 log1p on [0, 1]; 3 / 4 / 5 / 6 the
+ * library's exp / log / division / log1p; reps > 1 applies f reps times per element (tools/f64_math_rates.py).  fp64 device
+ * pointers.  No reference counterpart (numpy's / mpmath's log are what tests/test_gpu_f64_math.py compares with). */
+int cnf_probe_f64_math(int which, const double* in, double* out, long n, int reps, cnf_stream_t stream);
+
 /* ---- affine coupling -------------------------------------------------------------------- */
 
 /* coupling_layer.py:42-65 (CouplingLayer.forward after the subnet), :76-98.
