@@ -442,7 +442,9 @@ def kernel_table(lib, ops, dev, budget_ms=6.0):
             # other VALU 2 ... 4: profiles/r05_op_rates.txt) over this run's time at 2.4 GHz on 1024 SIMDs
             try:
                 ks = json.load(open(os.path.join(ROOT, "profiles", "r05_fp64_ceilings.json")))["kernels"]
-                mine = sorted((x for x in ks if (", true, 8, true>" in x["kernel"]) == reverse), key=lambda x: x["grid"])
+                # the token-pass kernel at the reference's precision: mixture_tok_kernel<KT = 8, REVERSE, ..., X64 = true>
+                mine = sorted((x for x in ks if x["kernel"].startswith("mixture_tok_kernel<8, ") and x["kernel"].endswith(", true>")
+                               and x["kernel"].startswith("mixture_tok_kernel<8, true") == reverse), key=lambda x: x["grid"])
                 k = mine[0] if tag == "configs[1]" else mine[-1]            # two shapes in the counter run: configs[1] (the smaller grid), S*
             except Exception:
                 return
@@ -450,7 +452,7 @@ def kernel_table(lib, ops, dev, budget_ms=6.0):
             simd_cycles = 1024 * 2.4e9 * ms * 1e-3
             lo, hi = (core + k["other_valu"] * 2) / simd_cycles, (core + k["other_valu"] * 4) / simd_cycles
             rows[-1].update(fp64_issue_frac=[lo, hi], fp64_flops_frac=2 * (k["fma_f64"] * 2 + k["mul_f64"] + k["add_f64"]) * 64 / 2 / (ms * 1e-3) / 78.6e12,
-                            bound=("fp64 valu" if lo >= 0.6 else "latency (2 waves per SIMD; neither the fp64 unit nor HBM)"))
+                            bound=("fp64 valu" if lo >= 0.6 else "latency (neither the fp64 unit nor HBM)"))
         for mode, what in ((1, "fp32 (default)"), (0, "fp64 (the reference's precision)")):
             lib.cnf_set_math_mode(mode)
             ms = row("mixture_coupling forward, %s" % what, S, alg, fwd, math_mode=mode)

@@ -3,8 +3,10 @@
 // + a full division, ~90 instructions), a division is 16 instructions with its scaling.  Every fp64 instruction costs 4
 // issue cycles per wave (profiles/r05_op_rates.txt) and the kernels run at 0.6-0.8 of that issue ceiling, so the
 // instruction count IS the run time.  Measured per call and SIMD (tools/f64_math_rates.py, profiles/r05_f64_math.txt):
-// log 85 ns against the library's 185, reciprocal 34 against 42; an exp written the same way (argument <= 0, one clamp
-// instead of the library's two range checks) gained 6 % over the library's 58 ns and was dropped — the library exp stays.
+// log 85 ns against the library's 185, reciprocal 34 against 42; the library's exp (58 ns) stays: two replacements were built and
+// measured — the library's structure (degree-11 polynomial) with one clamp instead of its two range checks: 55 ns; a 64-entry
+// 2^(j/64) table in LDS with a degree-5 polynomial: 49 ns by itself, 2 % on the forward kernel and a loss on the inverse (the
+// table reads and index arithmetic raise its register pressure past three waves per SIMD).
 // Polynomial: Chebyshev interpolant of (log((1+s)/(1-s)) - 2s) / s^3 in z = s^2, computed with mpmath at 200 bits
 // (tools/f64_math_coeffs.py), truncation error 5e-18 relative.  Accuracy on the GPU against mpmath / numpy
 // (tests/test_gpu_f64_math.py): reciprocal on [1, 2] correctly rounded on every sample, log and log1p <= 1 ulp.

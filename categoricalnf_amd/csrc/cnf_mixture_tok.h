@@ -34,6 +34,7 @@ struct TokGeom {
     int rw;             // rows per wave tile (split == 0)
     int S;              // workgroups per row (split == 1)
     int ppr;            // passes per row = ceil(N / TPP)
+    int pre;            // fp64 kernels: the DMA source offsets of a pass are kept in LDS (behind epi_off)
     long ntiles;        // wave tiles (split == 0)
     FastDiv div_slot, div_n, div_lpt, div_nc;
 };

@@ -48,11 +48,15 @@ namespace cnf {
 // Register budget: the K = 8 inverse (configs[1]) needs 97 VGPRs as compiled freely, one more than five waves per SIMD
 // allow; asking for five costs nothing in the loop (no spills) and buys the fifth wave.
 #ifndef CNF_X64_FWD_WAVES
-#define CNF_X64_FWD_WAVES 1
+#define CNF_X64_FWD_WAVES 4
+#endif
+#ifndef CNF_X64_FWD_UNROLL
+#define CNF_X64_FWD_UNROLL 2
 #endif
 #ifndef CNF_X64_INV_WAVES
 #define CNF_X64_INV_WAVES 3
 #endif
+constexpr int kTokPre = 8;      // DMA instructions per pass whose source offsets the fp64 kernels keep (8 KiB stages)
 constexpr int tok_min_waves(int kt, bool reverse, int g, bool pr, bool x64 = false) {
     // fp64 inverse with up to 8 slots: 184 VGPRs as compiled freely; three waves per SIMD (168) cost 2 spilled registers
     if (x64) return reverse ? (kt <= 8 ? CNF_X64_INV_WAVES : 2) : CNF_X64_FWD_WAVES;
@@ -127,8 +131,44 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
     // wave that first waited for them and the barrier started its DMA one memory round trip late (split rows: every
     // workgroup, on the critical path of launches that are a single round of workgroups)
     int my_pos = 0;
-    if (ntok > 0)
-        my_pos = stage_pass(gm, stage_b, span0, nn_last, min(gm.TPP, ntok), lane, tli, j + (gm.d0 - gm.sd0), P);
+    // X64: the per-lane source offsets of a pass's DMA instructions do not change from pass to pass when every span
+    // starts at the same 16-byte phase (token stride a multiple of 16 bytes); stage_pass recomputes them with a
+    // division per instruction — ~35 VALU instructions each, 250 per pass at S*, which an issue-bound kernel pays for
+    // They are kept in LDS ([instruction][lane] behind the accumulators; registers are what the fp64 kernels are short of).
+    uint32_t* goff = reinterpret_cast<uint32_t*>(smem + gm.epi_off) + (size_t)wave * (kTokPre * kWave) + lane;
+    bool pre = false;
+    int phase = 0;
+    if constexpr (X64) {
+        pre = gm.pre != 0;
+        phase = (int)(reinterpret_cast<uintptr_t>(span0) & 15);
+        if (pre) {
+            for (int i = 0; i < kTokPre; ++i) {
+                const uint32_t cb = (uint32_t)(i * kWave + lane) << 4;
+                const uint32_t sl = fdiv(cb, gm.div_slot);
+                goff[i * kWave] = sl * (uint32_t)gm.tokstride + (cb - sl * (uint32_t)gm.slot);
+            }
+        }
+    }
+    auto stage = [&](const char* pass_addr, int npt) {
+        if constexpr (!X64) {
+            return stage_pass(gm, stage_b, pass_addr, nn_last, npt, lane, tli, j + (gm.d0 - gm.sd0), P);
+        } else if (pre) {
+            const int ni = (npt * gm.slot + 1023) >> 10;
+            const char* base = pass_addr - phase;                                   // wave-uniform, 16-byte aligned
+            const uint32_t last = (uint32_t)min((ptrdiff_t)(nn_last - base), (ptrdiff_t)0x7fffffff);
+#pragma unroll
+            for (int i = 0; i < kTokPre; ++i) {
+                if (i < ni) {
+                    const uint32_t off = min(goff[i * kWave], last);
+                    __builtin_amdgcn_global_load_lds((glb_void_t*)(base + off), (lds_void_t*)(stage_b + (i << 10)), 16, 0, CNF_MIX_DMA_AUX);
+                }
+            }
+            return tli * gm.slot + phase + (j + (gm.d0 - gm.sd0)) * P * 4;
+        } else {
+            return stage_pass(gm, stage_b, pass_addr, nn_last, npt, lane, tli, j + (gm.d0 - gm.sd0), P);
+        }
+    };
+    if (ntok > 0) my_pos = stage(span0, min(gm.TPP, ntok));
     if (ED > 0) {
         for (int i = threadIdx.x; i < ED; i += blockDim.x) {
             etab[i] = a.e_bias[i];
@@ -444,12 +484,14 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
                 const double ud = cdfd / sed;
                 double lpdfd;
                 if (pdfd > 1e-290) {
-                    lpdfd = log64_pos(pdfd / sed);
+                    lpdfd = X64 ? log64_pos(pdfd / sed) : log(pdfd / sed);
                 } else {
                     lpdfd = logspace_pdf(xd, mx, sed);
                 }
                 // safe_log (:266-268) on arguments that are positive normals after its clamp
-                const double lud = log64_pos(fmax(ud, 1e-22)), l1ud = log64_pos(fmax(1.0 - ud, 1e-22));
+                // (the fp32 kernels' rare branch keeps the library's log: 9 VGPRs fewer in kernels that sit at an occupancy step)
+                const double lud = X64 ? log64_pos(fmax(ud, 1e-22)) : safe_log(ud);
+                const double l1ud = X64 ? log64_pos(fmax(1.0 - ud, 1e-22)) : safe_log(1.0 - ud);
                 if (a.use_reg) {
                     const double r1 = lud / kLn10, r2 = l1ud / kLn10;
                     reg = (fmin(r1, -a.reg_max) + a.reg_max) + (fmin(r2, -a.reg_max) + a.reg_max);
@@ -466,7 +508,7 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
                 if (a.sf) log_s = apply_bound_exact(my[1], sf_tab[d]);
                 const double xd = (double)x;
                 // a rolled loop over the LDS row (register arrays under a run-time index become select chains)
-#pragma unroll 2
+#pragma unroll CNF_X64_FWD_UNROLL
                 for (int i = 0; i < KK; ++i) {
                     const int k = kidx(i);
                     const float lsk = my[2 + 2 * K + k];
@@ -631,8 +673,7 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
         pass_body(tp, npt, stage_b, my_pos, [&](size_t i) { return z_tile[i]; }, [&](int t) { return pad_tile[t]; });
         wave_lds_sync();      // the stage is overwritten by the next pass
         if (tp + gm.TPP < ntok)
-            my_pos = stage_pass(gm, stage_b, span0 + (size_t)(tp + gm.TPP) * gm.tokstride, nn_last, min(gm.TPP, ntok - tp - gm.TPP),
-                                lane, tli, j + (gm.d0 - gm.sd0), P);
+            my_pos = stage(span0 + (size_t)(tp + gm.TPP) * gm.tokstride, min(gm.TPP, ntok - tp - gm.TPP));
     }
 
     // ---- per-sample results
@@ -803,6 +844,7 @@ bool make_tok_geom(const MixArgs& a, int kt, int force_g, TokGeom& gm, int& G, s
     const long tiles0 = ((long)a.B + rw - 1) / rw;
     gm.split = 0; gm.rw = rw; gm.S = 1; gm.ntiles = tiles0;
     gm.ppr = ppr;
+    gm.pre = 0;
     if (tiles0 < 2048 && ppr >= 2 && (long)ppr * kWavesPerBlock * 64 < 0x7fffffffL) {
         // few long rows: S workgroups x 4 waves per row, each wave a run of whole passes
         int s_hi = (int)std::max<long>(1, (g_split_waves + 4L * a.B - 1) / (4L * a.B));
@@ -978,13 +1020,20 @@ bool launch_mixture_tok(MixArgs& a, hipStream_t st, int force_g, bool x64) {
     if (a.e_w && (G != 1 || !(a.D == 2 || a.D == 3 || a.D == 4 || a.D == 6))) return false;
     const TokKernel kern = tok_kernel_for(a, kt, slot_g, G, nll, x64);
     if (!kern) return false;
+    // fp64 kernels keep the per-lane DMA source offsets of a pass when they repeat from pass to pass (spans, every one at
+    // the same 16-byte phase) and a pass is at most kTokPre instructions
+    gm.pre = (x64 && !gm.contig && (gm.tokstride & 15) == 0 && gm.stage_bytes <= kTokPre * 1024) ? 1 : 0;
+    size_t extra = gm.pre ? (size_t)kWavesPerBlock * kTokPre * kWave * sizeof(uint32_t) : 0;
+    if (lds + extra > 65536) { gm.pre = 0; extra = 0; }
     if (gm.split && gm.S > 1) {
-        const long cap = resident_workgroups(kern, lds);
+        const long cap = resident_workgroups(kern, lds + extra);
+        const int keep = gm.pre;
         if (cap > 0 && (long)a.B * gm.S > cap && !make_tok_geom(a, kt, force_g, gm, G, lds, slot_g, whole, cap)) return false;
+        gm.pre = keep;          // (make_tok_geom clears it) the re-split changes S only: stage and strides stay
     }
     const dim3 block(kBlock);
     const dim3 grid(gm.split ? (unsigned)((long)a.B * gm.S) : (unsigned)((gm.ntiles + kWavesPerBlock - 1) / kWavesPerBlock));
-    CNF_LAUNCH(kern, grid, block, lds, st, a, gm);
+    CNF_LAUNCH(kern, grid, block, lds + extra, st, a, gm);
     return true;
 }
 

@@ -68,3 +68,4 @@ def test_reciprocal_is_correctly_rounded_on_its_range():
     x = np.concatenate([rng.uniform(1.0, 2.0, 1 << 19), rng.uniform(1.7, 2.5, 1 << 17), [1.0, 2.0, 1.0 + 2.0 ** -52, 2.0 - 2.0 ** -52]])
     got = _run(1, x)
     assert np.array_equal(got, 1.0 / x)
+

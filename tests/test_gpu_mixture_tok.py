@@ -466,3 +466,94 @@ def test_fp64_backward_is_deterministic_too(B, N, D, K):
     a = split_grads()
     for x, y in zip(a, split_grads()):
         assert torch.equal(x, y)
+
+
+# ---- math mode 0 (fp64 like mixture_cdf_layer.py:62,173-178) on the same token passes ---------------------------------------
+
+def _mode0(fn):
+    lib = _lib.load()
+    lib.cnf_set_math_mode(0)
+    try:
+        return fn()
+    finally:
+        lib.cnf_set_math_mode(1)
+        lib.cnf_set_mixture_kernel(0)
+
+
+@pytest.mark.parametrize("B,N,D,K,kind", SHAPES)
+def test_fp64_token_pass_against_the_oracle_and_the_round1_fp64_kernel(B, N, D, K, kind):
+    """Reference precision on the token-pass kernel: the oracle's fp64 results at fp32 output rounding, and the bits of the
+    round-1 fp64 kernel for z (same fp64 expressions per element; the inverse is a Newton polish of the fp32 root that
+    converges to the same double before it is rounded to fp32) — per-sample sums differ by their order only."""
+    z, nn_out, sf, msf, mask, ln, pad = _case(B, N, D, K, kind, 3 * B + 5 * N + 7 * D + K)
+    kw = dict(num_mixtures=K, reg_max=3.5, reg_factor=2.0, is_training=True)
+    gk = dict(scaling_factor=g(sf), mixture_scaling_factor=g(msf), channel_padding_mask=g(pad), **kw)
+    zo, lo, ro = O.mixture_coupling(z, nn_out, mask, scaling_factor=sf, mixture_scaling_factor=msf, channel_padding_mask=pad, **kw)
+    lib = _lib.load()
+
+    def run(which):
+        lib.cnf_set_mixture_kernel(which)
+        f = ops().mixture_coupling(g(z), g(nn_out), g(mask), **gk)
+        r = ops().mixture_coupling(g(zo), g(nn_out), g(mask), reverse=True, **gk)
+        return f, r
+    (zf, lf, rf), (zr, lr, _) = _mode0(lambda: run(0))
+    (z1, l1, r1), (zr1, lr1, _) = _mode0(lambda: run(1))
+    # the bound parameters come from fp32 tanh (library versions differ by an ulp between host and device): 2e-6
+    close(zf, zo, rtol=2e-6, atol=2e-6); loglik_close(lf, lo, rel=2e-6); loglik_close(rf, ro, rel=2e-6)
+    assert torch.equal(zf, z1) and torch.equal(zr, zr1)
+    close(lf, l1, rtol=2e-6, atol=2e-6); close(lr, lr1, rtol=2e-6, atol=2e-6); close(rf, r1, rtol=2e-6, atol=2e-6)
+    zo2, lo2, _ = O.mixture_coupling(zo, nn_out, mask, scaling_factor=sf, mixture_scaling_factor=msf,
+                                     channel_padding_mask=pad, reverse=True, **kw)
+    close(zr, zo2, rtol=1e-5, atol=1e-5); loglik_close(lr, lo2, rel=1e-5)
+    ops().check_flags(torch.device("cuda"), "fp64 tok kernel")
+
+
+def test_fp64_token_pass_tails_and_flat_regions():
+    """Latents out to 12 sigma and narrow, far-apart components: the forward's clamps (safe_log, the log-space pdf) and the
+    inverse's bisection fallback inside the widened quantile bracket give the round-1 fp64 kernel's z."""
+    B, N, D, K = 64, 32, 4, 8
+    gen = torch.Generator().manual_seed(77)
+    z = 12.0 * torch.randn(B, N, D, generator=gen)
+    nn_out = torch.randn(B, N, D * (2 + 3 * K), generator=gen)
+    nn_out.view(B, N, D, 2 + 3 * K)[..., 2 + K:2 + 2 * K] *= 6.0          # means far apart
+    nn_out.view(B, N, D, 2 + 3 * K)[..., 2 + 2 * K:] -= 2.5                # narrow components
+    mask = O.channel_mask(D)
+    lib = _lib.load()
+
+    def run(which):
+        lib.cnf_set_mixture_kernel(which)
+        f = ops().mixture_coupling(g(z), g(nn_out), g(mask), K)
+        r = ops().mixture_coupling(f[0], g(nn_out), g(mask), K, reverse=True)
+        return f, r
+    (zf, lf, _), (zr, lr, _) = _mode0(lambda: run(0))
+    (z1, l1, _), (zr1, lr1, _) = _mode0(lambda: run(1))
+    assert torch.equal(zf, z1)
+    close(zr, zr1, rtol=1e-6, atol=1e-6)
+    close(lf, l1, rtol=2e-6, atol=1e-5); close(lr, lr1, rtol=2e-6, atol=1e-5)
+    # (no oracle here: with components this narrow and far apart the reference's own `1 - u` is rounding noise of its
+    # log-space evaluation on the plateaus between them — tests/test_gpu_parity.py::test_mixture_fast_vs_exact has the
+    # oracle comparison out to 12 sigma with ordinary parameters, and in math mode 0 it runs this kernel)
+
+
+def test_fp64_token_pass_keeps_nans_where_the_round1_kernel_has_them():
+    B, N, D, K = 8, 24, 4, 8
+    z, nn_out, sf, msf, mask, ln, pad = _case(B, N, D, K, "channel", 5)
+    z[1, 3, 3] = float("nan"); z[2, 5, 2] = float("inf")
+    nn_out.view(B, N, D, 2 + 3 * K)[3, 7, 3, 2 + K + 1] = float("nan")       # a mean
+    nn_out.view(B, N, D, 2 + 3 * K)[4, 9, 2, 2 + 2] = float("nan")           # a mixture weight
+    lib = _lib.load()
+
+    def run(which):
+        lib.cnf_set_mixture_kernel(which)
+        out = ops().mixture_coupling(g(z), g(nn_out), g(mask), K, scaling_factor=g(sf), mixture_scaling_factor=g(msf))
+        inv = ops().mixture_coupling(g(z), g(nn_out), g(mask), K, scaling_factor=g(sf), mixture_scaling_factor=g(msf), reverse=True)
+        word = ops().flag_word(torch.device("cuda", torch.cuda.current_device()))
+        assert int(word.item()) & (_lib.FLAG_NAN_Z | _lib.FLAG_NAN_LDJ)
+        word.zero_()
+        return out, inv
+    (zf, lf, _), (zr, lr, _) = _mode0(lambda: run(0))
+    (z1, l1, _), (zr1, lr1, _) = _mode0(lambda: run(1))
+    assert torch.equal(torch.isnan(zf), torch.isnan(z1)) and torch.equal(torch.isnan(lf), torch.isnan(l1))
+    assert torch.equal(torch.isnan(lr), torch.isnan(lr1))
+    ok = ~torch.isnan(z1)
+    assert torch.equal(zf[ok], z1[ok])

@@ -32,7 +32,10 @@ for src, dst in (("sweep_affine.log", "_sweep_affine.txt"), ("sweep_nll.log", "_
                  ("ceilings_mixbwd/ceilings.txt", "_ceilings_mixture_backward.txt"),
                  ("bwd_probe.txt", "_bwd_probe.txt"), ("bwd_kernel_stats.csv", "_bwd_kernel_stats.csv"),
                  ("encoder_bwd_kernel_stats.csv", "_encoder_bwd_kernel_stats.csv"), ("encoder_bwd_variants.txt", "_encoder_bwd_variants.txt"),
-                 ("autograd_overhead.txt", "_autograd_overhead.txt"),
+                 ("autograd_overhead.txt", "_autograd_overhead.txt"), ("flow_autograd_overhead.txt", "_flow_autograd_overhead.txt"),
+                 ("fp64_ceilings/fp64_ceilings.txt", "_fp64_ceilings.txt"), ("fp64_ceilings/fp64_ceilings.json", "_fp64_ceilings.json"),
+                 ("mix64_ab.txt", "_mixture_fp64_token_pass_ab.txt"), ("f64_math_rates.txt", "_f64_math.txt"),
+                 ("dep_latency.txt", "_dep_latency.txt"), ("mix64_iters.txt", "_mixture_fp64_newton_evaluations.txt"),
                  ("pmc_small/table.txt", "_pmc_small_mixture.txt"), ("ab_mixture_inverse.txt", "_ab_mixture_inverse.txt"), ("flow_traffic.txt", "_flow_traffic.txt"),
                  ("flow_traffic.json", "_flow_traffic.json"), ("mfma_set/mfma_util.txt", "_mfma_util_set_modelling.txt"),
                  ("mfma_set/mfma_util.json", "_mfma_util_set_modelling.json"),

@@ -16,6 +16,12 @@ timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$O
 python tools/pmc_summarize.py "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/traffic.json" "$OUT/traffic.txt" | tail -8
 rm -f "$OUT"/pmc_fetch/*kernel_trace.csv "$OUT"/pmc_write/*kernel_trace.csv "$OUT"/prof_bench/*kernel_trace.csv
 cp "$OUT/traffic.json" "$ROOT/profiles/traffic.json"
+# the reference-precision (fp64) mixture kernels: instruction counts for the bench rows' fp64 issue fractions, the A/B against the
+# round-1 fp64 kernel, the cost of the fp64 functions
+bash tools/pmc_fp64.sh fp64_ceilings > "$OUT/fp64_ceilings.log" 2>&1; tail -12 "$OUT/fp64_ceilings.log" | cut -c1-200
+cp "$OUT/fp64_ceilings/fp64_ceilings.json" "$ROOT/profiles/r05_fp64_ceilings.json"
+timeout 300 python tools/mix64_tok_ab.py > "$OUT/mix64_ab.txt" 2>&1; NOSF=1 SHAPES="configs[1],S*" timeout 300 python tools/mix64_tok_ab.py >> "$OUT/mix64_ab.txt" 2>&1; tail -4 "$OUT/mix64_ab.txt" | cut -c1-200
+timeout 300 python tools/f64_math_rates.py > "$OUT/f64_math_rates.txt" 2>&1; head -6 "$OUT/f64_math_rates.txt"
 timeout 500 python bench.py > "$OUT/bench.log" 2>&1; tail -1 "$OUT/bench.log" | cut -c1-400
 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-mixture > "$OUT/bench_steps20.log" 2>&1; tail -1 "$OUT/bench_steps20.log" | cut -c1-200
 timeout 300 python tools/sweep_mixture_bwd.py > "$OUT/sweep_mixture_bwd.log" 2>&1; tail -7 "$OUT/sweep_mixture_bwd.log" | cut -c1-200
