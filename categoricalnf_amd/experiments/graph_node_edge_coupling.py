@@ -32,12 +32,25 @@ class NodeEdgeCoupling(FlowLayer):
         self.mixture_scaling_factor_nodes = nn.Parameter(torch.zeros(self.c_in_nodes, self.num_mixtures_nodes))
         self.mixture_scaling_factor_edges = nn.Parameter(torch.zeros(self.c_in_edges, self.num_mixtures_edges))
 
+    def _mask_view(self, name, n):
+        """The mask cut to n rows, as ONE tensor object per (buffer, n): ops caches a mask's transformed-channel list per tensor
+        object (reading it is a device-to-host copy), and a fresh slice on every call would read it again — under a stream
+        capture (graphs.GraphedTraining) that copy is not permitted at all."""
+        buf = getattr(self, name)
+        key = (name, min(buf.size(0), int(n)))
+        views = self.__dict__.setdefault("_mask_views", {})
+        hit = views.get(key)
+        if hit is None or hit[0] is not buf or hit[1] != buf._version:
+            hit = (buf, buf._version, buf[None, :key[1], :])
+            views[key] = hit
+        return hit[2]
+
     def forward(self, z_nodes, z_edges, ldj=None, reverse=False, length=None, channel_padding_mask=None,
                 mask_valid=None, x_indices=None, binary_adjacency=None, **kwargs):
         if ldj is None:
             ldj = z_nodes.new_zeros(z_nodes.size(0),)
-        mask_nodes = self.mask_nodes[None, :min(self.mask_nodes.size(0), z_nodes.size(1)), :]
-        mask_edges = self.mask_edges[None, :min(self.mask_edges.size(0), z_edges.size(1)), :]
+        mask_nodes = self._mask_view("mask_nodes", z_nodes.size(1))
+        mask_edges = self._mask_view("mask_edges", z_edges.size(1))
         nn_nodes, nn_edges = self.nn(z_nodes=mask_nodes * z_nodes, z_edges=mask_edges * z_edges, length=length,
                                      channel_padding_mask=channel_padding_mask, x_indices=x_indices,
                                      mask_valid=mask_valid, binary_adjacency=binary_adjacency)

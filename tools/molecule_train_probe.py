@@ -23,6 +23,7 @@ ap.add_argument("--hidden_nodes", type=int, default=256)
 ap.add_argument("--hidden_edges", type=int, default=128)
 ap.add_argument("--layers", type=int, default=4)
 ap.add_argument("--graphs", type=int, default=4096)
+ap.add_argument("--graph_step", action="store_true", help="capture the training step in a hipGraph (categoricalnf_amd.graphs.GraphedTraining)")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 torch.manual_seed(0); np.random.seed(0)
@@ -75,6 +76,16 @@ with contextlib.redirect_stdout(io.StringIO()):
     model.initialize_data_dependent(init)
 model.train()
 opt = torch.optim.Adam(model.parameters(), lr=5e-4)
+graphed = None
+if args.graph_step:
+    # shapes are static (every batch is padded to MAX_NODES): the whole step — ~10 000 kernel launches of the Edge-GNN stages,
+    # their backward, clipping, Adam — becomes one hipGraph replay
+    from categoricalnf_amd.graphs import GraphedTraining
+    sx, sadj, sln = (t.clone() for t in batch(rng.randint(0, args.graphs, size=args.batch)))
+    t_cap = time.time()
+    graphed = GraphedTraining(model, lambda: nll_per_node(sx, sadj, sln).mean(), dev, 0.25, lr=5e-4, eager_optimizer=None,
+                              optimizer_cls=torch.optim.Adam, allow_unverified=True)
+    print("captured training step: hipGraph nodes %s, %.1f s" % (graphed.nodes, time.time() - t_cap), flush=True)
 print("GraphCNF at configs[4]'s sizes: flows %s, %d layers, %.1f M parameters, batch %d x %d nodes / %d pairs" % (
     args.flows, len(model.step1_flows) + len(model.step2_flows) + len(model.step3_flows), n_par / 1e6, args.batch, MAX_NODES, MAX_NODES * (MAX_NODES - 1) // 2), flush=True)
 hist, t0 = [], None
@@ -82,11 +93,15 @@ for step in range(1, args.steps + 1):
     if step == 6:
         torch.cuda.synchronize(); t0 = time.time()
     x, adj, ln = batch(rng.randint(0, args.graphs, size=args.batch))
-    loss = nll_per_node(x, adj, ln).mean()
-    opt.zero_grad(set_to_none=True)
-    loss.backward()
-    torch.nn.utils.clip_grad_norm_(model.parameters(), 0.25)
-    opt.step()
+    if graphed is not None:
+        sx.copy_(x); sadj.copy_(adj); sln.copy_(ln)
+        loss = graphed()
+    else:
+        loss = nll_per_node(x, adj, ln).mean()
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 0.25)
+        opt.step()
     hist.append(float(loss))
     if step % 10 == 0 or step == 1:
         print("step %4d | NLL per node %.4f (%.3f bits)" % (step, hist[-1], hist[-1] * np.log2(np.e)), flush=True)
@@ -95,6 +110,8 @@ rate = (args.steps - 5) / (time.time() - t0) if t0 else float("nan")
 first, last = float(np.mean(hist[:5])), float(np.mean(hist[-5:]))
 print("training: NLL per node %.4f -> %.4f over %d steps, %.2f steps/s" % (first, last, args.steps, rate), flush=True)
 assert np.isfinite(hist).all() and last < first, "the loss did not fall"
+if graphed is not None:
+    graphed.drop_weight_caches()
 model.eval()
 with torch.no_grad():
     x, adj, ln = batch(np.arange(32))
