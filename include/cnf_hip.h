@@ -58,7 +58,11 @@ void cnf_set_unroll(int u);
  * sampling kernels (absolute error ~1e-7), and the module-form mixture-CDF coupling (cnf_mixture_coupling,
  * forward and Newton inverse) in fp32 on LDS-staged parameter rows with two-sided tail sums and an in-kernel
  * fp64 branch for |logit| > 20.7 (<= 1e-5 from the fp64 kernel).
- * 0 ("exact"): ocml expf / tanhf, fp64 logit in the sampler, fp64 mixture kernels throughout.
+ * 0 ("exact"): ocml expf / tanhf, fp64 logit in the sampler, the mixture-CDF coupling in fp64 throughout like the
+ * reference (mixture_cdf_layer.py:62,173-178): the reference's expressions on the same DMA-staged rows as mode 1, library
+ * exp, log / log1p / 1/(1+e) to <= 1 ulp (csrc/cnf_f64_math.h); with inverse mode 1 the inverse is the fp32 Newton root
+ * polished by the same safeguarded iteration in fp64 (step <= 1e-11 of the smallest scale), with inverse mode 0 the
+ * reference's bisection on the round-1 fp64 kernel.
  * The static fp64 API (cnf_mixture_transform) is fp64 in both modes. */
 void cnf_set_math_mode(int mode);
 /* Mixture-CDF inverse: 0 = the reference's bisection (mixture_cdf_layer.py:235-264, per-element stop at
