@@ -53,6 +53,9 @@ namespace cnf {
 #ifndef CNF_X64_FWD_UNROLL
 #define CNF_X64_FWD_UNROLL 2
 #endif
+#ifndef CNF_X64_ONE_EVAL
+#define CNF_X64_ONE_EVAL 0
+#endif
 #ifndef CNF_X64_INV_WAVES
 #define CNF_X64_INV_WAVES 3
 #endif
@@ -402,7 +405,7 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
                 const double tol_s = 1e-11 * (double)smin;
                 int n_eval = 0;
                 for (int iter = 0; iter < 100; ++iter) {
-                    double c = 0.0;
+                    double c = 0.0, ddn = 0.0;
                     dn = 0.0;
                     ++n_eval;
 #pragma unroll
@@ -410,11 +413,19 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
                         const double zk = (xq - (double)mur[i]) * isd[i];
                         const double e = exp(-fabs(zk));
                         const double rr = rcp64(1.0 + e);
-                        c += wd[i] * (zk >= 0.0 ? rr : e * rr);
-                        dn += wd[i] * isd[i] * (e * rr * rr);
+                        const double sg = zk >= 0.0 ? rr : e * rr;
+                        const double pk = wd[i] * isd[i] * (e * rr * rr);
+                        c += wd[i] * sg;
+                        dn += pk;
+#if CNF_X64_ONE_EVAL
+                        ddn += pk * (isd[i] * fma(-2.0, sg, 1.0));      // d/dx of the component's density: w s^-2 sigma''(z)
+#endif
                     }
                     if (G > 1) {
                         c = qsum64<G>(c); dn = qsum64<G>(dn);
+#if CNF_X64_ONE_EVAL
+                        ddn = qsum64<G>(ddn);
+#endif
                     }
                     const double f = c - tgt;
                     double nx;
@@ -425,11 +436,26 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
                         nx = 0.5 * (xq + ubd);
                         lbd = xq;
                     }
+                    bool newton = false;
                     if (dn > 0.0 && fabs(2.0 * f) <= fabs(dxp * dn)) {
                         const double xn = xq - f / dn;
-                        if (xn >= lbd && xn <= ubd) nx = xn;
+                        if (xn >= lbd && xn <= ubd) {
+                            nx = xn;
+                            newton = true;
+                        }
                     }
                     const double dd = fabs(nx - xq);
+#if CNF_X64_ONE_EVAL
+                    // A Newton step of length dd leaves an error <= dd^2 max|pdf'/pdf| / 2 <= dd^2 / (2 s_min) (every logistic
+                    // component has |p'/p| <= 1/s): below 4.47e-6 s_min that is under the 1e-11 s_min the loop asks for, and the
+                    // density at the new point follows to first order from its derivative (relative error <= 2e-11).  From the
+                    // fp32 root (error ~1e-7 (|x| + sum s)) this is the usual case: one fp64 evaluation per element.
+                    if (newton && dd <= 4.47e-6 * (double)smin) {
+                        dn = fma(ddn, nx - xq, dn);
+                        xq = nx;
+                        break;
+                    }
+#endif
                     dxp = dd;
                     xq = nx;
                     // the density of the last evaluation stands in for the one at the root: relative error <= dd / s_min
