@@ -195,7 +195,8 @@ __device__ __forceinline__ void forward_elem_f64(const MixArgs& a, const ElemPar
     }
     // y = -safe_log(1/u - 1) (:273) = log u - log(1-u) wherever safe_log(u) is not clamped; below u = 1e-22
     // the reference's form keeps falling (down to -inf at u == 0) while lu stays at log(1e-22)
-    const double y = u >= 1e-22 ? lu - l1u : -safe_log(1.0 / u - 1.0);
+    // (a NaN u stays a NaN: torch.clamp keeps it, the fmax of safe_log does not)
+    const double y = u >= 1e-22 ? lu - l1u : (u != u ? u : -safe_log(1.0 / u - 1.0));
     const double mixt_ldj = -lu - l1u;
     out = (y + p.t_) * exp(p.log_s_);
     contrib = p.log_s_ + mixt_ldj + ev.log_pdf + reg * a.reg_factor;

@@ -54,14 +54,14 @@ namespace cnf {
 #define CNF_X64_FWD_UNROLL 2
 #endif
 #ifndef CNF_X64_ONE_EVAL
-#define CNF_X64_ONE_EVAL 0
+#define CNF_X64_ONE_EVAL 1
 #endif
 #ifndef CNF_X64_INV_WAVES
-#define CNF_X64_INV_WAVES 3
+#define CNF_X64_INV_WAVES 2
 #endif
 constexpr int kTokPre = 8;      // DMA instructions per pass whose source offsets the fp64 kernels keep (8 KiB stages)
 constexpr int tok_min_waves(int kt, bool reverse, int g, bool pr, bool x64 = false) {
-    // fp64 inverse with up to 8 slots: 184 VGPRs as compiled freely; three waves per SIMD (168) cost 2 spilled registers
+    // fp64 inverse: two waves per SIMD (up to 8 slots: 226 VGPRs as compiled freely; a cap at three waves spills 48)
     if (x64) return reverse ? (kt <= 8 ? CNF_X64_INV_WAVES : 2) : CNF_X64_FWD_WAVES;
     return (kt == 8 && reverse && g == 1 && !pr) ? 5 : 1;
 }
@@ -383,6 +383,8 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
                 if (!(av == av)) { ud = vd; mldj = vd; }       // NaN in: NaN out
                 ud = fmin(fmax(ud, 1e-5), 1.0 - 1e-5);
                 if (!(ud > 0.0 && ud < 1.0)) range = true;
+                // (16 slots: the derivative's accumulator and products push the kernel past its 256 registers: 38 spilled, slower)
+                constexpr bool kOneEval = CNF_X64_ONE_EVAL && KT <= 13;
                 double wd[KK], isd[KK];
                 double sed = 0.0;
 #pragma unroll
@@ -410,22 +412,19 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
                     ++n_eval;
 #pragma unroll
                     for (int i = 0; i < KK; ++i) {
-                        const double zk = (xq - (double)mur[i]) * isd[i];
+                        const double w_ = wd[i], is_ = isd[i];
+                        const double zk = (xq - (double)mur[i]) * is_;
                         const double e = exp(-fabs(zk));
                         const double rr = rcp64(1.0 + e);
                         const double sg = zk >= 0.0 ? rr : e * rr;
-                        const double pk = wd[i] * isd[i] * (e * rr * rr);
-                        c += wd[i] * sg;
+                        const double pk = w_ * is_ * (e * rr * rr);
+                        c += w_ * sg;
                         dn += pk;
-#if CNF_X64_ONE_EVAL
-                        ddn += pk * (isd[i] * fma(-2.0, sg, 1.0));      // d/dx of the component's density: w s^-2 sigma''(z)
-#endif
+                        if (kOneEval) ddn += pk * (is_ * fma(-2.0, sg, 1.0));       // d/dx of the component's density: w s^-2 sigma''(z)
                     }
                     if (G > 1) {
                         c = qsum64<G>(c); dn = qsum64<G>(dn);
-#if CNF_X64_ONE_EVAL
-                        ddn = qsum64<G>(ddn);
-#endif
+                        if (kOneEval) ddn = qsum64<G>(ddn);
                     }
                     const double f = c - tgt;
                     double nx;
@@ -445,17 +444,16 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
                         }
                     }
                     const double dd = fabs(nx - xq);
-#if CNF_X64_ONE_EVAL
                     // A Newton step of length dd leaves an error <= dd^2 max|pdf'/pdf| / 2 <= dd^2 / (2 s_min) (every logistic
                     // component has |p'/p| <= 1/s): below 4.47e-6 s_min that is under the 1e-11 s_min the loop asks for, and the
                     // density at the new point follows to first order from its derivative (relative error <= 2e-11).  From the
-                    // fp32 root (error ~1e-7 (|x| + sum s)) this is the usual case: one fp64 evaluation per element.
-                    if (newton && dd <= 4.47e-6 * (double)smin) {
+                    // fp32 root (error ~1e-7 (|x| + sum s)) this is the usual case: one fp64 evaluation per element
+                    // (profiles/r05_mixture_fp64_newton_evaluations.txt: 1.00 on average, 1.05 with latents out to 8 sigma).
+                    if (kOneEval && newton && dd <= 4.47e-6 * (double)smin) {
                         dn = fma(ddn, nx - xq, dn);
                         xq = nx;
                         break;
                     }
-#endif
                     dxp = dd;
                     xq = nx;
                     // the density of the last evaluation stands in for the one at the root: relative error <= dd / s_min
@@ -523,7 +521,8 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
                     reg = (fmin(r1, -a.reg_max) + a.reg_max) + (fmin(r2, -a.reg_max) + a.reg_max);
                 }
                 double yd = lud - l1ud;
-                if (ud < 1e-22) yd = -safe_log(1.0 / ud - 1.0);
+                // below the clamp the reference's own form (:273); a NaN u stays a NaN (torch.clamp keeps it, fmax does not)
+                if (!(ud >= 1e-22)) yd = ud != ud ? ud : -safe_log(1.0 / ud - 1.0);
                 of = (float)((yd + (double)t) * exp((double)log_s));
                 contrib64 = (double)log_s + (-lud - l1ud) + lpdfd + reg * a.reg_factor;
                 use64 = true;
