@@ -31,7 +31,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .graph_layers import GNNSkipConnection
+from .graph_layers import GNNSkipConnection, SplitKLinear as _Linear
 
 _NEG = -9e15        # the reference's masking constant (its softmax rows without a neighbour are zeroed afterwards)
 
@@ -95,8 +95,8 @@ class Node2EdgePlainLayer(nn.Module):
     def __init__(self, hidden_size_nodes, hidden_size_edges, skip_config=0, dp_rate=0.0, act_fn=nn.GELU):
         super().__init__()
         self.hidden_size_nodes, self.hidden_size_edges = hidden_size_nodes, hidden_size_edges
-        self.node_feat_layer = nn.Sequential(nn.LayerNorm(hidden_size_nodes), nn.Linear(hidden_size_nodes, hidden_size_edges))
-        self.edge_feat_layer = nn.Sequential(nn.LayerNorm(hidden_size_edges), nn.Linear(hidden_size_edges, hidden_size_edges))
+        self.node_feat_layer = nn.Sequential(nn.LayerNorm(hidden_size_nodes), _Linear(hidden_size_nodes, hidden_size_edges))
+        self.edge_feat_layer = nn.Sequential(nn.LayerNorm(hidden_size_edges), _Linear(hidden_size_edges, hidden_size_edges))
         self.skip_layer = GNNSkipConnection(hidden_size_edges, config=skip_config, dp_rate=dp_rate)
         self.dropout = nn.Dropout(dp_rate)
         self.act_fn = act_fn()
@@ -140,10 +140,10 @@ class Edge2NodeQKVAttnLayer(_Edge2NodeBase):
         self.hidden_size_per_head = hidden_size_nodes // num_heads
         self.dot_prod_scaling = float(self.hidden_size_per_head) ** -0.5
         inner = num_heads * self.hidden_size_per_head
-        self.node_query_key_val_layer = nn.Linear(hidden_size_nodes, inner * 3)
-        self.edge_val_layer = nn.Linear(hidden_size_edges, inner)
-        self.edge_adj_layer = nn.Linear(hidden_size_edges, num_heads)
-        self.output_projection = nn.Linear(inner + hidden_size_nodes, hidden_size_nodes)
+        self.node_query_key_val_layer = _Linear(hidden_size_nodes, inner * 3)
+        self.edge_val_layer = _Linear(hidden_size_edges, inner)
+        self.edge_adj_layer = _Linear(hidden_size_edges, num_heads)
+        self.output_projection = _Linear(inner + hidden_size_nodes, hidden_size_nodes)
         self.skip_layer = GNNSkipConnection(hidden_size_nodes, config=skip_config, input_size=hidden_size_nodes, dp_rate=dp_rate)
         self.dropout = nn.Dropout(dp_rate)
         self.act_fn = act_fn()
@@ -175,9 +175,9 @@ class Edge2NodeAttnLayer(_Edge2NodeBase):
         self.hidden_size_nodes, self.hidden_size_edges, self.num_heads = hidden_size_nodes, hidden_size_edges, num_heads
         self.hidden_size_per_head = int(hidden_size_nodes // num_heads)
         self.hidden_size_output = self.hidden_size_per_head * num_heads
-        self.node_feat_layer = nn.Linear(hidden_size_nodes, self.hidden_size_output * 2)
-        self.edge_feat_layer = nn.Linear(hidden_size_edges, self.hidden_size_output)
-        self.edge_logits_layer = nn.Linear(hidden_size_edges, num_heads)
+        self.node_feat_layer = _Linear(hidden_size_nodes, self.hidden_size_output * 2)
+        self.edge_feat_layer = _Linear(hidden_size_edges, self.hidden_size_output)
+        self.edge_logits_layer = _Linear(hidden_size_edges, num_heads)
         self.skip_layer = GNNSkipConnection(hidden_size_nodes, config=skip_config, input_size=self.hidden_size_output)
         self.dropout = nn.Dropout(dp_rate)
         self.act_fn = act_fn()
@@ -229,16 +229,16 @@ class EdgeGNN(nn.Module):
         hidden_nodes = self.layers[0].node2edge_layer.hidden_size_nodes
 
         def mlp_in(c_in, hidden):
-            return nn.Sequential(nn.Linear(c_in, hidden), nn.GELU(), nn.Linear(hidden, hidden))
+            return nn.Sequential(_Linear(c_in, hidden), nn.GELU(), _Linear(hidden, hidden))
 
         def mlp_out(hidden, c_out):
-            return nn.Sequential(nn.LayerNorm(hidden), nn.Linear(hidden, hidden), nn.GELU(), nn.Linear(hidden, c_out))
+            return nn.Sequential(nn.LayerNorm(hidden), _Linear(hidden, hidden), nn.GELU(), _Linear(hidden, c_out))
 
         self.input_layer_edges, self.input_layer_nodes = mlp_in(c_in_edges, hidden_edges), mlp_in(c_in_nodes, hidden_nodes)
         self.out_layer_edges, self.out_layer_nodes = mlp_out(hidden_edges, c_out_edges), mlp_out(hidden_nodes, c_out_nodes)
         if max_neighbours > 0:
             self.max_neighbours = max_neighbours
-            self.node_neighbour_embed = nn.Linear(max_neighbours + 1, hidden_nodes)
+            self.node_neighbour_embed = _Linear(max_neighbours + 1, hidden_nodes)
 
     def forward(self, z_nodes, z_edges, length, x_indices, mask_valid, channel_padding_mask=None, binary_adjacency=None, **kwargs):
         nodes, edges = self.input_layer_nodes(z_nodes), self.input_layer_edges(z_edges)

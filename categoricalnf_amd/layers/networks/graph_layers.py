@@ -10,9 +10,51 @@ gather into a padded neighbour list (index_select / masked_select with a host sy
 the result is the same softmax over each node's neighbours."""
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from ...host_utils import one_hot
 
+
+
+class _LinearSplitK(torch.autograd.Function):
+    """y = x W^T + b with the weight gradient as a split-K batched GEMM.  The pair list of a batch is 45 000 rows of 128
+    features (64 graphs x 703 pairs): `grad_out^T @ x` is then a [128 x 45 000] x [45 000 x 128] product — one output tile
+    per 32 x 32 block and a serial K loop, 120-265 us on hipBLASLt (5-8 TFLOP/s; 16 % of a training step in
+    profiles/r05_mfma_util_molecule.txt).  Cut into S = 16 slabs of rows it is a batched GEMM of 16 x more workgroups and
+    a 16-term sum: 25-53 us for the same shapes (tools/molecule_train_probe.py: 5.55 -> 6.1 steps/s eager).  Same
+    mathematics; the fp32 sum over rows is associated per slab."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, slabs):
+        ctx.save_for_backward(x, weight)
+        ctx.slabs = slabs
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        g2, x2 = g.reshape(-1, g.size(-1)), x.reshape(-1, x.size(-1))
+        gx = g.matmul(weight) if ctx.needs_input_grad[0] else None
+        gw = gb = None
+        if ctx.needs_input_grad[1]:
+            S = ctx.slabs
+            gw = torch.bmm(g2.view(S, -1, g2.size(1)).transpose(1, 2), x2.view(S, -1, x2.size(1))).sum(dim=0)
+        if ctx.needs_input_grad[2]:
+            gb = g2.sum(dim=0)
+        return gx, gw, gb, None
+
+
+class SplitKLinear(nn.Linear):
+    """nn.Linear (same parameters, same state_dict) whose backward takes the split-K weight gradient on long inputs."""
+    _MIN_ROWS = 8192
+
+    def forward(self, x):
+        rows = x.numel() // max(x.size(-1), 1)
+        if x.is_cuda and rows >= self._MIN_ROWS and torch.is_grad_enabled() and self.weight.requires_grad:
+            for slabs in (16, 8, 4):
+                if rows % slabs == 0:
+                    return _LinearSplitK.apply(x, self.weight, self.bias, slabs)
+        return F.linear(x, self.weight, self.bias)
 
 class RelationGraphConv(nn.Module):
     """h_i = W_s x_i + (1/|N_i|) sum_{j in N_i} W_{r(i,j)} x_j on layer-normed features."""
@@ -87,7 +129,7 @@ class GNNSkipConnection(nn.Module):
         self.config = config
         self.dp_rate = dp_rate
         assert config in (0, 1, 2), "[!] ERROR: Unknown skip connection config \"%s\"" % str(config)
-        self.skip_layer = nn.Linear(self.input_size, self.hidden_size * (1 if config == 0 else 2))
+        self.skip_layer = SplitKLinear(self.input_size, self.hidden_size * (1 if config == 0 else 2))     # also runs on pair lists
         if self.dp_rate > 0.0:
             self.skip_layer = nn.Sequential(nn.Dropout(self.dp_rate), self.skip_layer)
 

@@ -75,7 +75,7 @@ with contextlib.redirect_stdout(io.StringIO()):
         init.append((x, {"adjacency": adj, "length": ln}))
     model.initialize_data_dependent(init)
 model.train()
-opt = torch.optim.Adam(model.parameters(), lr=5e-4)
+opt = torch.optim.Adam(model.parameters(), lr=5e-4, fused=True)
 graphed = None
 if args.graph_step:
     # shapes are static (every batch is padded to MAX_NODES): the whole step — ~10 000 kernel launches of the Edge-GNN stages,
