@@ -26,6 +26,7 @@ namespace cnf {
 
 constexpr int kTokBwdGrid = 1024;       // rows of the partials buffer (cnf_bwd_workspace_floats)
 static std::atomic<int> g_tok_bwd_w4{-1}, g_tok_bwd_pf{-1};
+static std::atomic<int> g_tok_bwd_wb24{1};        // A/B switch of the 16-byte-grid write-back (cnf_set_mixture_bwd_prefetch(2 / 3): off / on)
 static inline int tok_bwd_w4() { return g_tok_bwd_w4.load(std::memory_order_relaxed); }
 
 struct TokBwdArgs {
@@ -34,7 +35,11 @@ struct TokBwdArgs {
     float* g_z;               // [B,N,D]
     float* g_nn;              // [B,N,D*P]
     float* partials;          // [gridDim.x, D + D*K]
-    int wb_align;             // 16, 8 or 4: bytes per lane of the write-back
+    int wb_align;             // 16, 8 or 4: bytes per lane of the write-back; 24: 16-byte stores on the tokens' 16-byte grid although
+                              // the span starts or ends on an odd multiple of 8 bytes (u_lo .. hi_half below)
+    int u_lo, nu, ntu;        // mode 24: first 16-byte unit of a token the span touches, units it touches, units per token
+    int lo_half, hi_half;     // mode 24: the span's first / last unit is half zeros (an untransformed block's bytes)
+    FastDiv div_nu, div_nz;   // mode 24: by nu; by ntu - nu
     int nacc;                 // run-time K: lane-private accumulator slots = 1 + ceil(K / G)
     int lacc_off;             // byte offset of the lane-private accumulators / the reduction scratch in dynamic LDS
     int wrow_off;             // byte offset of the per-wave parameter-gradient rows [4][PP]
@@ -520,7 +525,21 @@ __device__ __forceinline__ void mixture_tok_bwd_body(const MixArgs& a, const Tok
                 const int total_b = npt * span_b;
                 float* gspan0 = gnn_tile + ((size_t)tp * a.D + gm.d0) * P;       // first token's span in g_nn
                 const uintptr_t src0 = reinterpret_cast<uintptr_t>(span0 + (size_t)tp * gm.tokstride);
-                if (w.wb_align == 16) {
+                if (w.wb_align == 24) {
+                    // S* (D = 6: the span is bytes 312..623 of a 624-byte token): 8-byte stores were twice the instructions at half
+                    // the width.  A token's base is 16-byte aligned, so the span is written as the 16-byte units it touches — the unit
+                    // it shares with an untransformed block takes that block's zeros along — and the zero loop writes the other units.
+                    const int total_u = npt * w.nu;
+                    char* gtok = reinterpret_cast<char*>(gnn_tile + (size_t)tp * a.D * P);
+                    for (int e = lane; e < total_u; e += kWave) {
+                        const int s = (int)fdiv((uint32_t)e, w.div_nu);
+                        const int ui = e - s * w.nu;
+                        float4 v = *reinterpret_cast<const float4*>(stage_b + s * gm.slot + 16 * ui);
+                        if (ui == 0 && w.lo_half) v.x = v.y = 0.f;
+                        if (ui == w.nu - 1 && w.hi_half) v.z = v.w = 0.f;
+                        wb_store(reinterpret_cast<float4*>(gtok + (size_t)s * gm.tokstride + 16 * (w.u_lo + ui)), v);
+                    }
+                } else if (w.wb_align == 16) {
                     for (int b = lane * 16; b < total_b; b += kWave * 16) {
                         const int s = (int)fdiv((uint32_t)b, w.div_span);
                         const int r = b - s * span_b;
@@ -574,7 +593,15 @@ __device__ __forceinline__ void mixture_tok_bwd_body(const MixArgs& a, const Tok
                         wb_store(reinterpret_cast<decltype(zero)*>(gtok0 + (size_t)tk * gm.tokstride + col), zero);
                     }
                 };
-                if (w.wb_align == 16) zero_fill(make_float4(0.f, 0.f, 0.f, 0.f), 16);
+                if (w.wb_align == 24) {
+                    const int nzu = w.ntu - w.nu, nz = npt * nzu;
+                    for (int e = lane; e < nz; e += kWave) {
+                        const int tk = (int)fdiv((uint32_t)e, w.div_nz);
+                        const int zi = e - tk * nzu;
+                        const int u = zi < w.u_lo ? zi : zi + w.nu;
+                        wb_store(reinterpret_cast<float4*>(gtok0 + (size_t)tk * gm.tokstride + 16 * u), make_float4(0.f, 0.f, 0.f, 0.f));
+                    }
+                } else if (w.wb_align == 16) zero_fill(make_float4(0.f, 0.f, 0.f, 0.f), 16);
                 else if (w.wb_align == 8) zero_fill(make_float2(0.f, 0.f), 8);
                 else zero_fill(0.f, 4);
             }
@@ -636,6 +663,7 @@ using namespace cnf;
 
 extern "C" void cnf_set_mixture_bwd_prefetch(int mode) {
     if (mode >= -1 && mode <= 1) cnf::g_tok_bwd_pf.store(mode, std::memory_order_relaxed);
+    if (mode == 2 || mode == 3) cnf::g_tok_bwd_wb24.store(mode - 2, std::memory_order_relaxed);     // 16-byte-grid write-back off / on
 }
 
 extern "C" void cnf_set_mixture_bwd_waves(int mode) {
@@ -678,10 +706,22 @@ static bool launch_mixture_tok_bwd_with(MixArgs& a, const float* g_zout, const f
     const int first_b = gm.d0 * P * 4;
     const bool base16 = (reinterpret_cast<uintptr_t>(g_nn) & 15) == 0;
     if (base16 && span_b % 16 == 0 && gm.tokstride % 16 == 0 && first_b % 16 == 0 && (gm.contig || gm.slot % 16 == 0)) w.wb_align = 16;
+    else if (base16 && !gm.contig && gm.ncopy > 0 && gm.tokstride % 16 == 0 && gm.slot % 16 == 0 && span_b % 8 == 0 && first_b % 8 == 0 &&
+             g_tok_bwd_wb24.load(std::memory_order_relaxed) != 0) {
+        w.wb_align = 24;
+        w.u_lo = first_b / 16;
+        w.nu = (first_b + span_b + 15) / 16 - w.u_lo;
+        w.ntu = gm.tokstride / 16;
+        w.lo_half = first_b % 16 != 0;
+        w.hi_half = (first_b + span_b) % 16 != 0;
+        w.div_nu = make_fastdiv((uint32_t)w.nu);
+        w.div_nz = make_fastdiv((uint32_t)std::max(w.ntu - w.nu, 1));
+        if (w.nu * 16 > gm.slot || gm.TPP * w.ntu >= 65536) w.wb_align = 8;      // the stage slot must hold the units that are read
+    }
     else if ((reinterpret_cast<uintptr_t>(g_nn) & 7) == 0 && span_b % 8 == 0 && gm.tokstride % 8 == 0 && first_b % 8 == 0) w.wb_align = 8;
     else w.wb_align = 4;
     w.nunits = gm.split ? (long)a.B * gm.S * kWavesPerBlock : gm.ntiles;
-    w.div_ncp = make_fastdiv((uint32_t)std::max(gm.ncopy * P * 4 / w.wb_align, 1));        // zero-fill units per token
+    w.div_ncp = make_fastdiv((uint32_t)std::max(gm.ncopy * P * 4 / (w.wb_align == 24 ? 8 : w.wb_align), 1));        // zero-fill units per token
     w.div_span = make_fastdiv((uint32_t)span_b);
     if (span_b >= 65536 || gm.TPP * span_b >= 65536 || gm.ncopy * P * gm.TPP >= 65536) return false;
     const int grid = (int)std::min<long>((w.nunits + kWavesPerBlock - 1) / kWavesPerBlock, kTokBwdGrid);

@@ -96,7 +96,10 @@ void cnf_set_affine_bwd_tiles(int mode);
 void cnf_set_mixture_bwd_waves(int mode);
 /* the same entry point's run-time-K kernels: a second LDS stage per wave, so that the next pass's parameter rows are DMA-staged
  * while the current pass computes: 1 = wherever 64 KB of LDS allow, -1 (default) / 0 = never (measured: no gain, profiles/
- * r04_sweep_mixture_bwd.txt).  A/B knob; bit-identical gradients either way. */
+ * r04_sweep_mixture_bwd.txt).  A/B knob; bit-identical gradients either way.
+ * 2 / 3: the write-back of g_nn where a token's transformed span starts or ends on an odd multiple of 8 bytes (D = 6: bytes 312..623
+ * of 624) with 8-byte stores / (default) with 16-byte stores on the token's 16-byte grid, the unit shared with an untransformed block
+ * carrying that block's zeros (S* 330 -> 314 us, profiles/r05_mixture_bwd_writeback_ab.txt); bit-identical. */
 void cnf_set_mixture_bwd_prefetch(int mode);
 
 /* Kernel timing bound to the dispatch (bench.py's `roofline`; a timed launch costs ~4 us of queue time; the reference has no counterpart — its
