@@ -97,7 +97,7 @@ _PLAIN = {"cnf_abi_version": ([], _i), "cnf_last_error": ([], ctypes.c_char_p),
           "cnf_mixture_workspace_bytes": ([_i], _i64), "cnf_encoder_workspace_floats": ([_i, _i, _i, _i], _i64),
           "cnf_encoder_bwd_tiled_workspace_floats": ([_i, _i, _i, _i], _i64), "cnf_set_mixture_kernel": ([_i], None), "cnf_set_encoder_kernel": ([_i], None), "cnf_set_encoder_bwd_kernel": ([_i], None), "cnf_encoder_pair_launches": ([], _i64),
           "cnf_set_mixture_lanes": ([_i], None), "cnf_set_mixture_split": ([_i], None),
-          "cnf_set_mixture_whole_tokens": ([_i], None),
+          "cnf_set_mixture_whole_tokens": ([_i], None), "cnf_set_mixture_nt_mb": ([_i], None),
           "cnf_prof_arm": ([_i], _i), "cnf_prof_collect": ([ctypes.POINTER(ctypes.c_float), _i], _i)}
 
 _lib = None

@@ -1084,6 +1084,7 @@ void cnf_set_mixture_lanes(int lanes_per_item) {
 }
 
 void cnf_set_mixture_whole_tokens(int on) { set_mixture_whole_tokens(on); }
+void cnf_set_mixture_nt_mb(int megabytes) { set_mixture_nt_mb(megabytes); }
 
 void cnf_set_mixture_split(int waves) {
     if (waves >= 256 && waves <= 65536) set_mixture_split_waves(waves);

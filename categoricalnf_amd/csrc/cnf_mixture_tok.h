@@ -35,11 +35,19 @@ struct TokGeom {
     int S;              // workgroups per row (split == 1)
     int ppr;            // passes per row = ceil(N / TPP)
     int pre;            // fp64 kernels: the DMA source offsets of a pass are kept in LDS (behind epi_off)
+    int nt;             // forward / inverse: nontemporal DMA loads (launches that stage more than cnf_set_mixture_nt_mb megabytes)
     long ntiles;        // wave tiles (split == 0)
     FastDiv div_slot, div_n, div_lpt, div_nc;
 };
 
 __device__ __forceinline__ long long to_fix(double v) { return __double2ll_rn(v * kFix32); }
+
+// one 1 KiB DMA instruction; nt (wave-uniform): the parameters are read once — with the nontemporal hint the fp32 forward gains 2-8 %
+// from 78 MB of staged spans up (S*: 312 MB, 103.6 -> 95-100 us) and loses 4 % at configs[1]'s 52 MB (profiles/r05_mixture_nt_sweep.txt)
+__device__ __forceinline__ void dma_1k(const char* gp, char* lds, int nt) {
+    if (nt) __builtin_amdgcn_global_load_lds((glb_void_t*)gp, (lds_void_t*)lds, 16, 0, 2);
+    else __builtin_amdgcn_global_load_lds((glb_void_t*)gp, (lds_void_t*)lds, 16, 0, CNF_MIX_DMA_AUX);
+}
 
 
 // Stage the parameter spans of one pass (tokens [tp, tp + npt) of the wave's tile, first span at `pass_addr`) into the
@@ -55,7 +63,7 @@ __device__ __forceinline__ int stage_pass(const TokGeom& gm, char* stage_b, cons
         for (int i = 0; i < ni; ++i) {
             const char* gp = abase + ((size_t)(i * kWave + lane) << 4);
             gp = gp > nn_last ? nn_last : gp;
-            __builtin_amdgcn_global_load_lds((glb_void_t*)gp, (lds_void_t*)(stage_b + (i << 10)), 16, 0, CNF_MIX_DMA_AUX);
+            dma_1k(gp, stage_b + (i << 10), gm.nt);
         }
         return off0 + tli * gm.tokstride + j * P * 4;
     }
@@ -67,7 +75,7 @@ __device__ __forceinline__ int stage_pass(const TokGeom& gm, char* stage_b, cons
         const char* ta = pass_addr + (size_t)s * gm.tokstride;
         const char* gp = ta - (reinterpret_cast<uintptr_t>(ta) & 15) + o;
         gp = gp > nn_last ? nn_last : gp;
-        __builtin_amdgcn_global_load_lds((glb_void_t*)gp, (lds_void_t*)(stage_b + (i << 10)), 16, 0, CNF_MIX_DMA_AUX);
+        dma_1k(gp, stage_b + (i << 10), gm.nt);
     }
     const char* ta = pass_addr + (size_t)tli * gm.tokstride;
     return tli * gm.slot + (int)(reinterpret_cast<uintptr_t>(ta) & 15) + j * P * 4;

@@ -163,7 +163,7 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
             for (int i = 0; i < kTokPre; ++i) {
                 if (i < ni) {
                     const uint32_t off = min(goff[i * kWave], last);
-                    __builtin_amdgcn_global_load_lds((glb_void_t*)(base + off), (lds_void_t*)(stage_b + (i << 10)), 16, 0, CNF_MIX_DMA_AUX);
+                    dma_1k(base + off, stage_b + (i << 10), gm.nt);
                 }
             }
             return tli * gm.slot + phase + (j + (gm.d0 - gm.sd0)) * P * 4;
@@ -780,6 +780,8 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
 // ---- host side: geometry ------------------------------------------------------------------------------------
 static std::atomic<int> g_split_waves{4096};      // waves a split launch aims at (cnf_set_mixture_split)
 void set_mixture_split_waves(int w) { g_split_waves = w; }
+static std::atomic<int> g_mix_nt{64};            // MB of staged parameters above which the DMA loads are nontemporal (0 = never)
+void set_mixture_nt_mb(int mb) { g_mix_nt = mb < 0 ? 64 : mb; }
 static std::atomic<int> g_whole_tokens{1};        // cnf_set_mixture_whole_tokens: A/B switch of the whole-token staging
 void set_mixture_whole_tokens(int on) { g_whole_tokens = on ? 1 : 0; }
 static bool whole_tokens_enabled() { return g_whole_tokens != 0; }
@@ -870,6 +872,7 @@ bool make_tok_geom(const MixArgs& a, int kt, int force_g, TokGeom& gm, int& G, s
     gm.split = 0; gm.rw = rw; gm.S = 1; gm.ntiles = tiles0;
     gm.ppr = ppr;
     gm.pre = 0;
+    gm.nt = 0;
     if (tiles0 < 2048 && ppr >= 2 && (long)ppr * kWavesPerBlock * 64 < 0x7fffffffL) {
         // few long rows: S workgroups x 4 waves per row, each wave a run of whole passes
         int s_hi = (int)std::max<long>(1, (g_split_waves + 4L * a.B - 1) / (4L * a.B));
@@ -1041,6 +1044,9 @@ bool launch_mixture_tok(MixArgs& a, hipStream_t st, int force_g, bool x64) {
         if (!make_tok_geom(a, kt, force_g, gm, G, lds, 0, true, 0) && (whole = false, !make_tok_geom(a, kt, force_g, gm, G, lds, 0, false, 0)))
             return false;
     }
+    // nontemporal DMA loads for launches that stage more than 64 MB (profiles/r05_mixture_nt_sweep.txt: 2-8 % from 78 MB up, -4 % at 52)
+    const size_t staged = (size_t)a.B * a.N * (gm.contig ? gm.tokstride : gm.DA * a.P * 4);
+    gm.nt = (g_mix_nt.load() != 0 && staged > ((size_t)g_mix_nt.load() << 20)) ? 1 : 0;
     const bool nll = a.nll_out != nullptr;
     if (a.e_w && (G != 1 || !(a.D == 2 || a.D == 3 || a.D == 4 || a.D == 6))) return false;
     const TokKernel kern = tok_kernel_for(a, kt, slot_g, G, nll, x64);
@@ -1052,8 +1058,9 @@ bool launch_mixture_tok(MixArgs& a, hipStream_t st, int force_g, bool x64) {
     if (lds + extra > 65536) { gm.pre = 0; extra = 0; }
     if (gm.split && gm.S > 1) {
         const long cap = resident_workgroups(kern, lds + extra);
-        const int keep = gm.pre;
+        const int keep = gm.pre, keep_nt = gm.nt;
         if (cap > 0 && (long)a.B * gm.S > cap && !make_tok_geom(a, kt, force_g, gm, G, lds, slot_g, whole, cap)) return false;
+        gm.nt = keep_nt;
         gm.pre = keep;          // (make_tok_geom clears it) the re-split changes S only: stage and strides stay
     }
     const dim3 block(kBlock);

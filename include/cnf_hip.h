@@ -304,6 +304,10 @@ void cnf_set_mixture_kernel(int which);
 void cnf_set_mixture_lanes(int lanes_per_item);
 void cnf_set_mixture_split(int waves);
 void cnf_set_mixture_whole_tokens(int on);
+/* Staged parameter bytes of one forward / inverse launch (MB) above which its DMA loads carry the nontemporal hint: the rows are
+ * read once.  Measured (profiles/r05_mixture_nt_sweep.txt): 2-8 % from 78 MB up (S*: 312 MB, fp32 forward 103.6 -> 95-100 us), -4 %
+ * at configs[1]'s 52 MB.  Default 64; 0 = never; negative = default. */
+void cnf_set_mixture_nt_mb(int megabytes);
 
 /* MixtureCDFCoupling.get_mixt_params (mixture_cdf_layer.py:145-180): split + bound + mask in
  * fp32, results cast to fp64: t, log_s [B,N,D]; log_pi, mixt_t, mixt_log_s [B,N,D,K]. */
