@@ -57,12 +57,11 @@ namespace cnf {
 #define CNF_X64_ONE_EVAL 1
 #endif
 #ifndef CNF_X64_INV_WAVES
-#define CNF_X64_INV_WAVES 2
+#define CNF_X64_INV_WAVES 1
 #endif
 constexpr int kTokPre = 8;      // DMA instructions per pass whose source offsets the fp64 kernels keep (8 KiB stages)
 constexpr int tok_min_waves(int kt, bool reverse, int g, bool pr, bool x64 = false) {
-    // fp64 inverse: two waves per SIMD (up to 8 slots: 226 VGPRs as compiled freely; a cap at three waves spills 48)
-    if (x64) return reverse ? (kt <= 8 ? CNF_X64_INV_WAVES : 2) : CNF_X64_FWD_WAVES;
+    if (x64) return reverse ? CNF_X64_INV_WAVES : CNF_X64_FWD_WAVES;
     return (kt == 8 && reverse && g == 1 && !pr) ? 5 : 1;
 }
 
@@ -383,23 +382,11 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
                 if (!(av == av)) { ud = vd; mldj = vd; }       // NaN in: NaN out
                 ud = fmin(fmax(ud, 1e-5), 1.0 - 1e-5);
                 if (!(ud > 0.0 && ud < 1.0)) range = true;
-                // (16 slots: the derivative's accumulator and products push the kernel past its 256 registers: 38 spilled, slower)
-                constexpr bool kOneEval = CNF_X64_ONE_EVAL && KT <= 13;
-                double wd[KK], isd[KK];
+                // With ONE evaluation per element in the usual case nothing is reused between evaluations, so the weights e^{lp - max}
+                // and the inverse scales e^{-ls} are not kept: every evaluation is one rolled pass over the staged row like the
+                // forward's (no register arrays: 2K doubles per lane cost the unrolled form its third and fourth wave per SIMD — 226
+                // VGPRs at K = 8, spills at K = 16); the rare further evaluations pay two exponentials per mixture more.
                 double sed = 0.0;
-#pragma unroll
-                for (int i = 0; i < KK; ++i) {
-                    const int k = kidx(i);
-                    const float lsk = my[2 + 2 * K + k];
-                    const float lsf = a.msf ? apply_bound_exact(lsk, mt[k]) : lsk;
-                    double w = exp((double)my[2 + k] - (double)mx);
-                    if (PR && !kown(i)) w = 0.0;
-                    wd[i] = w;
-                    isd[i] = exp(-(double)lsf);
-                    sed += w;
-                }
-                sed = qsum64<G>(sed);
-                const double tgt = ud * sed;
                 const double widen = 1e-4 * (12.0 * (double)spread + fabs((double)lb0) + fabs((double)ub0));
                 double lbd = (double)lb0 - widen, ubd = (double)ub0 + widen;
                 double xq = fmin(fmax((double)xb, lbd), ubd);
@@ -407,25 +394,32 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
                 const double tol_s = 1e-11 * (double)smin;
                 int n_eval = 0;
                 for (int iter = 0; iter < 100; ++iter) {
-                    double c = 0.0, ddn = 0.0;
+                    double c = 0.0, ddn = 0.0, se = 0.0;
                     dn = 0.0;
                     ++n_eval;
-#pragma unroll
+#pragma unroll CNF_X64_FWD_UNROLL
                     for (int i = 0; i < KK; ++i) {
-                        const double w_ = wd[i], is_ = isd[i];
-                        const double zk = (xq - (double)mur[i]) * is_;
+                        const int k = kidx(i);
+                        const float lsk = my[2 + 2 * K + k];
+                        const float lsf = a.msf ? apply_bound_exact(lsk, mt[k]) : lsk;
+                        double w_ = exp((double)my[2 + k] - (double)mx);
+                        if (PR && !kown(i)) w_ = 0.0;
+                        const double is_ = exp(-(double)lsf);
+                        const double zk = (xq - (double)my[2 + K + k]) * is_;
                         const double e = exp(-fabs(zk));
                         const double rr = rcp64(1.0 + e);
                         const double sg = zk >= 0.0 ? rr : e * rr;
                         const double pk = w_ * is_ * (e * rr * rr);
+                        se += w_;
                         c += w_ * sg;
                         dn += pk;
-                        if (kOneEval) ddn += pk * (is_ * fma(-2.0, sg, 1.0));       // d/dx of the component's density: w s^-2 sigma''(z)
+                        ddn += pk * (is_ * fma(-2.0, sg, 1.0));       // d/dx of the component's density: w s^-2 sigma''(z)
                     }
                     if (G > 1) {
-                        c = qsum64<G>(c); dn = qsum64<G>(dn);
-                        if (kOneEval) ddn = qsum64<G>(ddn);
+                        se = qsum64<G>(se); c = qsum64<G>(c); dn = qsum64<G>(dn); ddn = qsum64<G>(ddn);
                     }
+                    sed = se;
+                    const double tgt = ud * sed;
                     const double f = c - tgt;
                     double nx;
                     if (f > 0.0) {
@@ -449,7 +443,7 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
                     // density at the new point follows to first order from its derivative (relative error <= 2e-11).  From the
                     // fp32 root (error ~1e-7 (|x| + sum s)) this is the usual case: one fp64 evaluation per element
                     // (profiles/r05_mixture_fp64_newton_evaluations.txt: 1.00 on average, 1.05 with latents out to 8 sigma).
-                    if (kOneEval && newton && dd <= 4.47e-6 * (double)smin) {
+                    if (CNF_X64_ONE_EVAL && newton && dd <= 4.47e-6 * (double)smin) {
                         dn = fma(ddn, nx - xq, dn);
                         xq = nx;
                         break;
