@@ -1824,6 +1824,31 @@ def test_edge_gnn_golden_on_the_device():
         assert (oe.cpu() - c.out_edges).abs().max().item() <= 5e-5 * max(scale_e, 1.0), c.meta
 
 
+def test_split_k_linear_has_the_gradients_of_nn_linear():
+    """graph_layers.SplitKLinear (the Linear layers of the Edge-GNN that run on the pair list, 45 000 rows a batch): same
+    output bits as nn.Linear, gradients of input / weight / bias to fp32 re-association of the sum over rows, same
+    state_dict; short inputs and no-grad calls take F.linear itself."""
+    from categoricalnf_amd.layers.networks.graph_layers import SplitKLinear
+    torch.manual_seed(3)
+    for rows, i_f, o_f in ((64 * 703, 128, 128), (16 * 703, 128, 4), (8192, 96, 52)):
+        ref = torch.nn.Linear(i_f, o_f).cuda()
+        lin = SplitKLinear(i_f, o_f).cuda()
+        lin.load_state_dict(ref.state_dict())
+        x = torch.randn(rows // 703 if rows % 703 == 0 else 1, 703 if rows % 703 == 0 else rows, i_f, device="cuda")
+        xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        ya, yb = ref(xa), lin(xb)
+        assert torch.equal(ya, yb)
+        go = torch.randn_like(ya)
+        ya.backward(go); yb.backward(go)
+        assert torch.equal(xa.grad, xb.grad)
+        for pa, pb in zip(ref.parameters(), lin.parameters()):
+            scale = pa.grad.abs().max().item()
+            assert (pa.grad - pb.grad).abs().max().item() <= 2e-5 * scale
+        assert list(lin.state_dict()) == list(ref.state_dict())
+    with torch.no_grad():
+        assert torch.equal(lin(x), ref(x))
+
+
 @pytest.mark.parametrize("c", load_cases("encoder"))
 def test_fused_encoder_entry_points_against_the_oracle_on_the_golden_cases(c):
     """The three fused entry points of round 3 directly against the oracle on the reference's golden encoder cases (they are
