@@ -675,7 +675,10 @@ __global__ __launch_bounds__(PW * 64 + 64) void encoder_bwd_pairs_kernel(EncBwdT
         PROBE(1);
         // ---- Y: the stage's terms summed over the classes, class order -------------------------------------------------------
         {
-            // 8-byte reads: rows an odd multiple of 8 bytes apart are conflict-free and need 2 (not 4) floats of padding
+            // 8-byte reads: rows an odd multiple of 8 bytes apart are conflict-free and need 2 (not 4) floats of padding.
+            // (Measured and dropped: a cell's classes dealt to 2 or 4 adjacent lanes with quad-permute sums, so that 288 cells fill
+            // 256 lanes evenly / 192 cells use all 512 — 97 -> 106 / 116 us at 16 classes, 266 -> 273 / 282 at 51: the cells
+            // are not what the barrier behind this phase waits for.)
             const int c2 = (b.C + 1) >> 1;
             for (int cell = L; cell < nt * D; cell += NT) {
                 const float2* p = reinterpret_cast<const float2*>(ctr + (size_t)cell * rs);
