@@ -564,3 +564,29 @@ def test_fp64_token_pass_keeps_nans_where_the_round1_kernel_has_them():
     assert torch.equal(zf[ok], z1[ok])
     clean = torch.tensor([0, 5, 6, 7])
     close(lf[clean], l1[clean], rtol=1e-5, atol=1e-5); close(lr[clean], lr1[clean], rtol=1e-5, atol=1e-5)
+
+
+def test_nontemporal_dma_loads_change_no_bit_at_the_north_star_size():
+    """S* (B = 16384, N = 64, D = 6, K = 8: 312 MB of staged parameter spans) takes the nontemporal DMA loads by the 64 MB rule
+    (cnf_set_mixture_nt_mb); forward and Newton inverse give the bits of the plain loads, and the round trip closes."""
+    B, N, D, K = 16384, 64, 6, 8
+    dev = torch.device("cuda")
+    gen = torch.Generator(device=dev).manual_seed(11)
+    z = torch.randn(B, N, D, generator=gen, device=dev)
+    nn_out = 0.5 * torch.randn(B, N, D * (2 + 3 * K), generator=gen, device=dev)
+    mask = g(O.channel_mask(D))
+    lib = _lib.load()
+    outs = []
+    try:
+        for mb in (0, -1):
+            lib.cnf_set_mixture_nt_mb(mb)
+            zf, lf, _ = ops().mixture_coupling(z, nn_out, mask, K)
+            zr, lr, _ = ops().mixture_coupling(zf, nn_out, mask, K, reverse=True)
+            outs.append((zf, lf, zr, lr))
+    finally:
+        lib.cnf_set_mixture_nt_mb(-1)
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert (outs[1][2] - z).abs().max().item() < 5e-4
+    assert (outs[1][1] + outs[1][3]).abs().max().item() < 2e-2          # log-dets of forward and inverse cancel (sums of 192 terms)
+    ops().check_flags(dev, "north-star size")
