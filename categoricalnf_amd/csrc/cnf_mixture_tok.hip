@@ -47,6 +47,11 @@ namespace cnf {
 // evaluation, one serial chain per wave (PTB shape, K = 51: inverse 45 us against a 25 us forward).
 // Register budget: the K = 8 inverse (configs[1]) needs 97 VGPRs as compiled freely, one more than five waves per SIMD
 // allow; asking for five costs nothing in the loop (no spills) and buys the fifth wave.
+#ifndef CNF_TOK_PRE_F32
+#define CNF_TOK_PRE_F32 0      // 1: the fp32 kernels keep their DMA source offsets too.  Measured (+4 VGPRs everywhere, four
+                               // instantiations lose a wave per SIMD): S* forward 102 -> 101 us, inverse 109.4 -> 113.3; configs[1]
+                               // 18.8 -> 18.9 / 23.3 -> 22.5: they are not short of VALU issue slots the way the fp64 kernels are
+#endif
 #ifndef CNF_X64_FWD_WAVES
 #define CNF_X64_FWD_WAVES 4
 #endif
@@ -140,7 +145,8 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
     uint32_t* goff = reinterpret_cast<uint32_t*>(smem + gm.epi_off) + (size_t)wave * (kTokPre * kWave) + lane;
     bool pre = false;
     int phase = 0;
-    if constexpr (X64) {
+    constexpr bool kPreOk = X64 || (CNF_TOK_PRE_F32 && ED == 0);
+    if constexpr (kPreOk) {
         pre = gm.pre != 0;
         phase = (int)(reinterpret_cast<uintptr_t>(span0) & 15);
         if (pre) {
@@ -152,7 +158,7 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
         }
     }
     auto stage = [&](const char* pass_addr, int npt) {
-        if constexpr (!X64) {
+        if constexpr (!kPreOk) {
             return stage_pass(gm, stage_b, pass_addr, nn_last, npt, lane, tli, j + (gm.d0 - gm.sd0), P);
         } else if (pre) {
             const int ni = (npt * gm.slot + 1023) >> 10;
@@ -1047,7 +1053,7 @@ bool launch_mixture_tok(MixArgs& a, hipStream_t st, int force_g, bool x64) {
     if (!kern) return false;
     // fp64 kernels keep the per-lane DMA source offsets of a pass when they repeat from pass to pass (spans, every one at
     // the same 16-byte phase) and a pass is at most kTokPre instructions
-    gm.pre = (x64 && !gm.contig && (gm.tokstride & 15) == 0 && gm.stage_bytes <= kTokPre * 1024) ? 1 : 0;
+    gm.pre = ((x64 || (CNF_TOK_PRE_F32 && !a.e_w)) && !gm.contig && (gm.tokstride & 15) == 0 && gm.stage_bytes <= kTokPre * 1024) ? 1 : 0;
     size_t extra = gm.pre ? (size_t)kWavesPerBlock * kTokPre * kWave * sizeof(uint32_t) : 0;
     if (lds + extra > 65536) { gm.pre = 0; extra = 0; }
     if (gm.split && gm.S > 1) {
