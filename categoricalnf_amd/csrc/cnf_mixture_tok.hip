@@ -92,6 +92,9 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
     // accumulators: split == 0: [wave][rw][2] fixed-point row sums; split == 1: [wave][2] fp64 wave partials
     long long* rowacc = reinterpret_cast<long long*>(smem + gm.acc_off) + (size_t)wave * gm.rw * 2;
     double* wpart = reinterpret_cast<double*>(smem + gm.acc_off);
+    // rows of this wave's tile that met a term the fixed-point words cannot hold (NaN, +-inf): their results are NaN, as a
+    // floating-point sum's would be (bit i = row i of the tile; split == 0 only — the other mode sums in fp64 inside a workgroup)
+    unsigned long long* rowbad = reinterpret_cast<unsigned long long*>(smem + gm.acc_off) + (size_t)kWavesPerBlock * gm.rw * 2 + wave;
     // epilogue: constants [bias D | e^scales D | W D*D | sum scales] and this wave's strip of one pass of tokens
     float* etab = reinterpret_cast<float*>(smem + gm.epi_off);
     float* ep = etab + (2 * ED + ED * ED + 4) + (size_t)wave * gm.TPP * ED;
@@ -194,7 +197,10 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
     for (int i = threadIdx.x; i < a.D * K; i += blockDim.x)
         if (a.msf) msf_tab[i] = make_bound(a.msf[i]);
     if (!gm.split)
+    {
         for (int i = lane; i < gm.rw * 2; i += kWave) rowacc[i] = 0;
+        if (lane == 0) *rowbad = 0ull;
+    }
     __syncthreads();
     if (!gm.split && nrows <= 0) return;            // no barrier follows in this mode
     const BoundTab* mt = msf_tab + d * K;
@@ -635,6 +641,7 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
         } else if (owner) {
             if (active) atomicAdd(reinterpret_cast<unsigned long long*>(rowacc + rl * 2), (unsigned long long)to_fix(cd));
             if (NLL) atomicAdd(reinterpret_cast<unsigned long long*>(rowacc + rl * 2 + 1), (unsigned long long)to_fix(nlp));
+            if (!(fabs(cd) < 1e300) || (NLL && !(fabs(nlp) < 1e300))) atomicOr(rowbad, 1ull << rl);
         }
         // ---- the pass's channels that are not transformed: copied through (times the padding mask)
         if (gm.ncopy > 0) {
@@ -656,6 +663,7 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
                     } else {
                         const int rl2 = (int)fdiv((uint32_t)tl2, gm.div_n);
                         atomicAdd(reinterpret_cast<unsigned long long*>(rowacc + rl2 * 2 + 1), (unsigned long long)to_fix(lp2));
+                        if (!(fabs(lp2) < 1e300)) atomicOr(rowbad, 1ull << rl2);
                     }
                 }
             }
@@ -735,9 +743,11 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
     };
     if (!gm.split) {
         wave_lds_sync();
-        if (own_row)
-            finish(row0 + lane, (double)rowacc[lane * 2] * (1.0 / kFix32), (double)rowacc[lane * 2 + 1] * (1.0 / kFix32),
+        if (own_row) {
+            const double poison = ((*rowbad >> lane) & 1ull) ? (double)NAN : 0.0;
+            finish(row0 + lane, (double)rowacc[lane * 2] * (1.0 / kFix32) + poison, (double)rowacc[lane * 2 + 1] * (1.0 / kFix32) + poison,
                    my_ldj, my_len);
+        }
     } else {
         acc_ldj = wave_sum(acc_ldj);
         if (NLL) acc_nlp = wave_sum(acc_nlp);
@@ -760,13 +770,15 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
                 unsigned long long* wa = reinterpret_cast<unsigned long long*>(a.ws_acc) + (size_t)row0 * 2;
                 unsigned long long o0 = atomicAdd(wa, (unsigned long long)to_fix(t0));
                 unsigned long long o1 = NLL ? atomicAdd(wa + 1, (unsigned long long)to_fix(t1)) : 0ull;
+                // a partial the fixed-point word cannot hold marks the row in bit 30 of its ticket counter (before the ticket)
+                if (!(fabs(t0) < 1e300) || (NLL && !(fabs(t1) < 1e300))) o0 += (unsigned long long)atomicOr(a.ws_cnt + row0, 1 << 30);
                 asm volatile("s_waitcnt vmcnt(0)" : "+v"(o0), "+v"(o1) : : "memory");
-                const int ticket = atomicAdd(a.ws_cnt + row0, 1);
+                const int ticket = atomicAdd(a.ws_cnt + row0, 1) & ((1 << 30) - 1);
                 if (ticket == gm.S - 1) {
                     const long long s0 = (long long)atomicExch(wa, 0ull);
                     const long long s1 = NLL ? (long long)atomicExch(wa + 1, 0ull) : 0ll;
-                    atomicExch(a.ws_cnt + row0, 0);
-                    finish(row0, (double)s0 * (1.0 / kFix32), (double)s1 * (1.0 / kFix32),
+                    const double poison = ((atomicExch(a.ws_cnt + row0, 0) >> 30) & 1) ? (double)NAN : 0.0;
+                    finish(row0, (double)s0 * (1.0 / kFix32) + poison, (double)s1 * (1.0 / kFix32) + poison,
                            a.ldj_in ? a.ldj_in[row0] : 0.f, (NLL && a.length) ? a.length[row0] : (float)a.N);
                 }
             }
@@ -898,7 +910,7 @@ bool make_tok_geom(const MixArgs& a, int kt, int force_g, TokGeom& gm, int& G, s
     gm.tab_off = kWavesPerBlock * stage;
     gm.acc_off = (int)((size_t)gm.tab_off + tabs);
     const size_t accb = gm.split ? (size_t)kWavesPerBlock * 2 * sizeof(double)
-                                 : (size_t)kWavesPerBlock * gm.rw * 2 * sizeof(long long);
+                                 : (size_t)kWavesPerBlock * (gm.rw * 2 + 1) * sizeof(long long);       // + one word of row marks per wave
     gm.epi_off = (int)(((size_t)gm.acc_off + accb + 15) & ~(size_t)15);
     lds = (size_t)gm.epi_off;
     if (a.e_w) {

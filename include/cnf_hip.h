@@ -40,8 +40,8 @@ extern "C" {
 
 #define CNF_FLAG_NAN_Z 1       /* a latent output is NaN          (flow_model.py:42) */
 #define CNF_FLAG_NAN_LDJ 2     /* a log-det output is NaN         (activation_normalization.py:46); the token-pass mixture kernels
-                                * sum a row's terms in 31.32 fixed point (order-independent bits): a non-finite TERM raises this
-                                * flag and leaves that row's log-det meaningless — read the flag word, not isnan(ldj) */
+                                * sum a row's terms in 31.32 fixed point (order-independent bits): a row that met a NaN or infinite
+                                * term is marked, comes out NaN and raises this flag */
 #define CNF_FLAG_RANGE 4       /* inverse-CDF input outside (0,1) (mixture_cdf_layer.py:238-239) */
 #define CNF_FLAG_CATEGORY 8    /* a category index outside [0, C)     (general/mutils.py:264, the one_hot assert) */
 

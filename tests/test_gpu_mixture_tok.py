@@ -556,14 +556,30 @@ def test_fp64_token_pass_keeps_nans_where_the_round1_kernel_has_them():
         return out, inv
     (zf, lf, _), (zr, lr, _) = _mode0(lambda: run(0))
     (z1, l1, _), (zr1, lr1, _) = _mode0(lambda: run(1))
-    # z carries the NaNs element by element like the round-1 kernel; a row's log-det is a fixed-point sum in the token-pass
-    # kernels (both math modes): a non-finite term raises CNF_FLAG_NAN_LDJ (asserted in run) and leaves the row's value
-    # meaningless — include/cnf_hip.h, the flag word is the error channel (ops.check_flags raises the reference's assertion)
+    # z carries the NaNs element by element like the round-1 kernel, and so do the rows' log-dets: the fixed-point row sums of
+    # the token-pass kernels cannot hold a NaN or an infinity, a row that met one is marked and comes out NaN
     assert torch.equal(torch.isnan(zf), torch.isnan(z1))
     ok = ~torch.isnan(z1)
     assert torch.equal(zf[ok], z1[ok])
+    assert torch.isnan(lf[[1, 3, 4]]).all() and torch.isnan(lr[[1, 3, 4]]).all() and torch.isnan(l1[[1, 3, 4]]).all()
+    assert not torch.isfinite(lf[2]) and not torch.isfinite(lr[2])                  # the row with an infinite latent
     clean = torch.tensor([0, 5, 6, 7])
     close(lf[clean], l1[clean], rtol=1e-5, atol=1e-5); close(lr[clean], lr1[clean], rtol=1e-5, atol=1e-5)
+    # the same in the default fp32 mode, whole rows per wave and rows shared by several workgroups (long rows)
+    for Bx, Nx in ((8, 24), (2, 1500)):
+        zx, nnx, sfx, msfx, maskx, _, _ = _case(Bx, Nx, D, K, "channel", 9)
+        zx[1, 3, 3] = float("nan")
+        nnx.view(Bx, Nx, D, 2 + 3 * K)[0, 7, 3, 2 + K + 1] = float("nan")
+        for rev in (False, True):
+            _, lx, _ = ops().mixture_coupling(g(zx), g(nnx), g(maskx), K, scaling_factor=g(sfx), mixture_scaling_factor=g(msfx), reverse=rev)
+            word = ops().flag_word(torch.device("cuda", torch.cuda.current_device()))
+            assert int(word.item()) & _lib.FLAG_NAN_LDJ
+            word.zero_()
+            assert torch.isnan(lx[:2]).all() and torch.isfinite(lx[2:]).all()
+    # ... and the workspace of the shared rows is handed back clean (ticket counters included)
+    torch.cuda.synchronize()
+    for w in ops()._mix_ws.values():
+        assert int(w.count_nonzero().item()) == 0
 
 
 def test_nontemporal_dma_loads_change_no_bit_at_the_north_star_size():
