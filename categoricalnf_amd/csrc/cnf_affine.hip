@@ -275,10 +275,13 @@ __global__ __launch_bounds__(kBlock) void affine_coupling_kernel(AffineArgs a, R
             // result does not depend on the order the rows arrive in) into one of 64 words that sit in 64 different
             // cache lines: 256 atomics per line for B = 16384, hidden behind the streaming (64 ADJACENT words, i.e.
             // four lines, serialised them: 55 us per launch)
+            // A per-sample NLL the fixed-point word cannot take (|nll| >= 4096, +-inf, NaN) goes to the slot's fp64 escape
+            // word with one floating-point atomic (cnf_common.h: fix_pair_add) — the sum then follows the reference's
+            // floating-point mean instead of wrapping.
             if (a.acc) {
-                const unsigned long long fix = (unsigned long long)__double2ll_rn((double)nll * 4294967296.0);
-                if (wg_acc) __hip_atomic_fetch_add(&wg_sum, fix, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // LDS
-                else atomicAdd(reinterpret_cast<unsigned long long*>(a.acc) + (size_t)(row & 63) * kAccStride, fix);
+                if (wg_acc && fabsf(nll) < (float)kAccTermMax)
+                    __hip_atomic_fetch_add(&wg_sum, (unsigned long long)to_fix((double)nll), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // LDS
+                else nll_acc_add(a.acc, row & 63, nll);
             }
         } else {
             ldj_of(row, sum, base);
@@ -818,7 +821,9 @@ __global__ __launch_bounds__(1024) void nll_acc_read_kernel(const long long* acc
     // (one wave walking 16k words paid the memory latency 256 times over: ~0.2 ms)
     __shared__ double sh[16];
     double t = 0.0;
-    for (long i = threadIdx.x; i < n; i += 1024) t += (double)acc[i] * (1.0 / 4294967296.0);
+    // word 16 k + 1 of every 128-byte line is the slot's fp64 escape word (cnf_common.h: nll_acc_add), the others fixed point
+    for (long i = threadIdx.x; i < n; i += 1024)
+        t += (i & (cnf::kAccStride - 1)) == 1 ? __longlong_as_double(acc[i]) : (double)acc[i] * (1.0 / 4294967296.0);
     t = cnf::wave_sum(t);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = t;
     __syncthreads();

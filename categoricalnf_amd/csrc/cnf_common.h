@@ -293,6 +293,31 @@ __device__ __forceinline__ void walk_row_tile(const RowTiling& tl, T* part, Chun
 
 constexpr int kAccStride = 16;  // int64 words between two of the 64 batch-sum accumulators (128 B: one cache line each)
 
+// ---- order-free sums: 64-bit fixed point with an fp64 escape word ------------------------------
+// Sums whose terms arrive in no fixed order (per-row log-det sums of the token-pass mixture kernels, the batch NLL
+// accumulator, the fp64 mixture backward's parameter-gradient words) are integer sums of v * 2^32: integer addition is
+// associative, so the result is bit-reproducible.  The word holds |sum| < 2^31 only.  A term at or above the caller's limit
+// (chosen so that the largest possible number of smaller terms stays below 2^31), and every +-inf / NaN term, goes to an
+// fp64 word BESIDE the integer word with a floating-point atomic instead; the value of the pair is fix / 2^32 + big.  The
+// reference sums these quantities in floating point (mixture_cdf_layer.py:95-123 `.sum(dim=[1,2])`, task.py:96-118), so a
+// finite term of 1e10 gives a finite sum there, +-inf gives +-inf, NaN gives NaN — and the same here.  Reproducibility to
+// the last bit is kept wherever no such term exists (the big word stays +0.0).
+constexpr double kFix32 = 4294967296.0;
+__device__ __forceinline__ long long to_fix(double v) { return __double2ll_rn(v * kFix32); }
+__device__ __forceinline__ double fix_pair_value(long long fix, double big) { return (double)fix * (1.0 / kFix32) + big; }
+__device__ __forceinline__ void fix_pair_add(unsigned long long* fix, double* big, double v, double lim) {
+    if (fabs(v) < lim) atomicAdd(fix, (unsigned long long)to_fix(v));
+    else unsafeAtomicAdd(big, v);           // ds_add_f64 / global_atomic_add_f64 (rare)
+}
+// The batch NLL accumulator (cnf_affine_coupling_nll_acc, cnf_mixture_coupling_nll): word 16 k is the fixed-point sum of
+// slot k, word 16 k + 1 of the same 128-byte line its fp64 escape word.  Per-sample NLLs below 4096 (bits per dimension are
+// O(1)) leave room for 2^19 samples per slot, 3.3e7 per accumulator, before the integer word could wrap.
+constexpr double kAccTermMax = 4096.0;
+__device__ __forceinline__ void nll_acc_add(long long* acc, int slot, float nll) {
+    unsigned long long* w = reinterpret_cast<unsigned long long*>(acc) + (size_t)slot * kAccStride;
+    fix_pair_add(w, reinterpret_cast<double*>(w + 1), (double)nll, kAccTermMax);
+}
+
 // logistic prior log-prob (distributions.py:129-136,154-163) for mu = 0:
 // softplus(v) + softplus(-v) = |v| + 2 log(1 + e^{-|v|}), one exp and one log instead of two each,
 // with the constants folded on the host: a = 1/sigma, a2 = log2(e)/sigma; the hardware

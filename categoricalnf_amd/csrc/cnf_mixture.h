@@ -32,6 +32,11 @@ struct MixArgs {
     double* reg_elem64;
     int* flags;
     int B, N, D, K, P, L;
+    // layout of nn (and of g_nn in the backward): nn_D parameter blocks per token, the first one belonging to channel nn_c0.
+    // Reference layout: nn_D = D, nn_c0 = 0 (blocks for ALL channels, half of them multiplied by the zero mask).  Compact layout
+    // (cnf_mixture_coupling_compact*): nn_D = DA, nn_c0 = first transformed channel — blocks of the transformed channels only.
+    int nn_D, nn_c0;
+    int compact;            // entry point asked for the compact layout (launch_mixture derives nn_D / nn_c0 from the channel list)
     int mr, mc;
     int DA;                 // transformed channels per token (channel mask) or D (per-item test)
     unsigned long long act_bits;   // bit d set = channel d is transformed (a list cannot be indexed per lane)
@@ -47,6 +52,7 @@ struct MixArgs {
     float* nll_out;         // [B]; non-null selects the NLL epilogue
     long long* nll_acc;     // optional: 64 fixed-point batch-sum words (as cnf_affine_coupling_nll_acc)
     long long* ws_acc;      // [2B] fixed-point row sums, zero before and after every launch (or null)
+    double* ws_big;         // [2B] fp64 escape words of the row sums (terms the fixed-point words cannot take), zero likewise
     int* ws_cnt;            // [B] arrival tickets, zero before and after every launch (or null)
     PriorConst prior;
     // optional epilogue of the forward kernel: ActNorm and 1x1 convolution of the NEXT flow step applied to z' before

@@ -76,8 +76,10 @@ __device__ __noinline__ double log_pdf_logspace(const ParamRow<SPLIT> p, int K, 
     for (int k = 0; k < K; ++k) {
         const double ls = p.ls(k);
         const double zk = (x - p.mu(k)) * exp(-ls);
-        m = fmax(m, p.log_pi(k) - lse_pi + zk - ls - 2.0 * softplus64(zk));
+        const double tk = p.log_pi(k) - lse_pi + zk - ls - 2.0 * softplus64(zk);
+        m = (tk != tk || m != m) ? (double)NAN : fmax(m, tk);       // torch.max keeps a NaN
     }
+    if (isinf(m)) return m;       // torch.logsumexp: every term -inf (a latent of -inf) gives -inf, not exp(-inf + inf)
     double s = 0.0;
     for (int k = 0; k < K; ++k) {
         const double ls = p.ls(k);
@@ -773,7 +775,8 @@ __global__ __launch_bounds__(kBlock) void mixture_f32_kernel(MixArgs a, RowTilin
                     for (int k = 0; k < K; ++k) {
                         const float lsf = a.msf ? apply_bound(my[2 + 2 * K + k], mt[k]) : my[2 + 2 * K + k];
                         const double zd = (xd - (double)my[2 + K + k]) * exp(-(double)lsf);
-                        m = fmax(m, (double)my[2 + k] - lse_pi + zd - (double)lsf - 2.0 * softplus64(zd));
+                        const double tk = (double)my[2 + k] - lse_pi + zd - (double)lsf - 2.0 * softplus64(zd);
+                        m = (tk != tk || m != m) ? (double)NAN : fmax(m, tk);
                     }
                     double ssum = 0.0;
 #pragma clang loop unroll(disable)
@@ -782,7 +785,7 @@ __global__ __launch_bounds__(kBlock) void mixture_f32_kernel(MixArgs a, RowTilin
                         const double zd = (xd - (double)my[2 + K + k]) * exp(-(double)lsf);
                         ssum += exp((double)my[2 + k] - lse_pi + zd - (double)lsf - 2.0 * softplus64(zd) - m);
                     }
-                    lpdfd = m + log(ssum);
+                    lpdfd = isinf(m) ? m : m + log(ssum);
                 }
                 const double lud = safe_log(ud), l1ud = safe_log(1.0 - ud);
                 if (a.use_reg) {
@@ -884,9 +887,7 @@ __global__ __launch_bounds__(kBlock) void mixture_params_kernel(const float* nn,
 // fallback of cnf_mixture_coupling_nll: per-sample NLL -> the 64 fixed-point batch-sum words
 __global__ void nll_to_acc_kernel(const float* nll, long long* acc, int B) {
     const int row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row < B)
-        atomicAdd(reinterpret_cast<unsigned long long*>(acc) + (size_t)(row & 63) * kAccStride,
-                  (unsigned long long)__double2ll_rn((double)nll[row] * 4294967296.0));
+    if (row < B) nll_acc_add(acc, row & 63, nll[row]);
 }
 
 static std::atomic<int> g_mix_kernel{0};     // 0: token-pass kernel first; 1: round-1 fp32 kernel (A/B and tests)
@@ -932,6 +933,13 @@ static int launch_mixture(MixArgs& a, bool split, const int* act_host, int n_act
     a.div_d = make_fastdiv((uint32_t)a.D);
     fill_act(a, act_host, n_act);
     a.div_da = make_fastdiv((uint32_t)a.DA);
+    a.nn_D = a.D; a.nn_c0 = 0;
+    if (a.compact) {
+        // nn_out = [B, N, DA * P]: the blocks of the transformed channels only (a channel mask whose transformed channels are one range)
+        CNF_REQUIRE(!split && a.mask && !a.per_item_mask && a.act_bits != 0, "%s: the compact layout needs a channel mask and its host channel list", who);
+        a.nn_D = a.DA;
+        a.nn_c0 = __builtin_ctzll(a.act_bits);
+    }
     const RowTiling tl = make_row_tiling(a.B, a.N * a.DA, /*force_vec=*/1);
     // block size: with a run-time K the inverse keeps 3K fp64 constants per thread in LDS (<= 64 KiB/block)
     const int kt = (a.K == 4 || a.K == 8 || a.K == 16) ? a.K : 0;
@@ -961,6 +969,11 @@ static int launch_mixture(MixArgs& a, bool split, const int* act_host, int n_act
     // bisection, K > 64 and shapes the token-pass geometry declines
     if (!split && math_mode() == 0 && (!a.reverse || inverse_mode() == 1) && g_mix_kernel != 1 && !a.e_w && !a.nll_out) {
         if (launch_mixture_tok(a, st, 0, /*x64=*/true)) return launch_status(who);
+    }
+    if (a.compact && !a.e_w && !a.nll_out) {
+        // only the token-pass kernels read the compact layout: the caller expands nn_out to the reference layout and calls again
+        set_error("%s: shape / mode outside the compact-layout kernels (B=%d N=%d D=%d K=%d)", who, a.B, a.N, a.D, a.K);
+        return CNF_ERR_UNSUPPORTED;
     }
     if (a.e_w) {
         // the token-pass kernel declined: the plain coupling, then the fused ActNorm + 1x1 convolution kernel in place
@@ -1066,14 +1079,15 @@ int cnf_mixture_coupling(const float* z, const float* nn_out,
 }
 
 static void split_workspace(MixArgs& a, void* workspace, int64_t workspace_bytes) {
-    // [2B] int64 row sums | [B] int32 tickets
-    if (workspace && workspace_bytes >= (int64_t)a.B * 20 && (reinterpret_cast<uintptr_t>(workspace) & 7) == 0) {
+    // [2B] int64 fixed-point row sums | [2B] fp64 escape words | [B] int32 tickets
+    if (workspace && workspace_bytes >= (int64_t)a.B * 36 && (reinterpret_cast<uintptr_t>(workspace) & 7) == 0) {
         a.ws_acc = reinterpret_cast<long long*>(workspace);
-        a.ws_cnt = reinterpret_cast<int*>(a.ws_acc + (size_t)2 * a.B);
+        a.ws_big = reinterpret_cast<double*>(a.ws_acc + (size_t)2 * a.B);
+        a.ws_cnt = reinterpret_cast<int*>(a.ws_acc + (size_t)4 * a.B);
     }
 }
 
-int64_t cnf_mixture_workspace_bytes(int B) { return B > 0 ? (int64_t)B * 20 : 0; }
+int64_t cnf_mixture_workspace_bytes(int B) { return B > 0 ? (int64_t)B * 36 : 0; }
 
 void cnf_set_mixture_kernel(int which) {
     if (which == 0 || which == 1) g_mix_kernel = which;
@@ -1090,7 +1104,7 @@ void cnf_set_mixture_split(int waves) {
     if (waves >= 256 && waves <= 65536) set_mixture_split_waves(waves);
 }
 
-int cnf_mixture_coupling_ws(const float* z, const float* nn_out,
+static int mixture_coupling_ws_impl(const char* who, int compact, const float* z, const float* nn_out,
                             const float* scaling_factor, const float* mixture_scaling_factor,
                             const float* mask, int mask_rows, int mask_cols,
                             const int* act_host, int n_act,
@@ -1100,8 +1114,9 @@ int cnf_mixture_coupling_ws(const float* z, const float* nn_out,
                             double reg_max, double reg_factor, int is_training,
                             void* workspace, int64_t workspace_bytes,
                             int* flags, cnf_stream_t stream) {
-    CNF_REQUIRE(z && nn_out && z_out && ldj_out, "cnf_mixture_coupling_ws: null tensor");
+    CNF_REQUIRE(z && nn_out && z_out && ldj_out, "%s: null tensor", who);
     MixArgs a = {};
+    a.compact = compact;
     a.z = z; a.nn = nn_out; a.sf = scaling_factor; a.msf = mixture_scaling_factor;
     a.mask = mask; a.pad = pad; a.ldj_in = ldj_in; a.z_out = z_out; a.ldj_out = ldj_out;
     a.reg_out = reg_out; a.flags = flags;
@@ -1112,7 +1127,68 @@ int cnf_mixture_coupling_ws(const float* z, const float* nn_out,
     a.use_reg = (!reverse && reg_max > 0 && is_training) ? 1 : 0;
     a.reg_max = reg_max; a.reg_factor = reg_factor;
     split_workspace(a, workspace, workspace_bytes);
-    return launch_mixture(a, false, act_host, n_act, (hipStream_t)stream, "cnf_mixture_coupling_ws");
+    return launch_mixture(a, false, act_host, n_act, (hipStream_t)stream, who);
+}
+
+int cnf_mixture_coupling_ws(const float* z, const float* nn_out,
+                            const float* scaling_factor, const float* mixture_scaling_factor,
+                            const float* mask, int mask_rows, int mask_cols,
+                            const int* act_host, int n_act,
+                            const float* pad, int pad_in_transform, int pad_output,
+                            const float* ldj_in, float* z_out, float* ldj_out, float* reg_out,
+                            int B, int N, int D, int K, int reverse,
+                            double reg_max, double reg_factor, int is_training,
+                            void* workspace, int64_t workspace_bytes,
+                            int* flags, cnf_stream_t stream) {
+    return mixture_coupling_ws_impl("cnf_mixture_coupling_ws", 0, z, nn_out, scaling_factor, mixture_scaling_factor, mask, mask_rows, mask_cols,
+                                    act_host, n_act, pad, pad_in_transform, pad_output, ldj_in, z_out, ldj_out, reg_out, B, N, D, K, reverse,
+                                    reg_max, reg_factor, is_training, workspace, workspace_bytes, flags, stream);
+}
+
+int cnf_mixture_coupling_compact(const float* z, const float* nn_compact,
+                                 const float* scaling_factor, const float* mixture_scaling_factor,
+                                 const float* mask, int mask_rows, int mask_cols,
+                                 const int* act_host, int n_act,
+                                 const float* pad, int pad_in_transform, int pad_output,
+                                 const float* ldj_in, float* z_out, float* ldj_out, float* reg_out,
+                                 int B, int N, int D, int K, int reverse,
+                                 double reg_max, double reg_factor, int is_training,
+                                 void* workspace, int64_t workspace_bytes,
+                                 int* flags, cnf_stream_t stream) {
+    return mixture_coupling_ws_impl("cnf_mixture_coupling_compact", 1, z, nn_compact, scaling_factor, mixture_scaling_factor, mask, mask_rows,
+                                    mask_cols, act_host, n_act, pad, pad_in_transform, pad_output, ldj_in, z_out, ldj_out, reg_out, B, N, D, K,
+                                    reverse, reg_max, reg_factor, is_training, workspace, workspace_bytes, flags, stream);
+}
+
+static int mixture_coupling_nll_impl(const char* who, int compact, const float* z, const float* nn_out,
+                             const float* scaling_factor, const float* mixture_scaling_factor,
+                             const float* mask, int mask_rows, int mask_cols,
+                             const int* act_host, int n_act,
+                             const float* pad, int pad_in_transform, int pad_output,
+                             const float* ldj_in, float* z_out, float* ldj_out, float* reg_out,
+                             const float* length, float* neglog_out, float* nll_out, int64_t* nll_acc,
+                             int B, int N, int D, int K,
+                             double reg_max, double reg_factor, int is_training,
+                             float sigma, float log_sigma,
+                             void* workspace, int64_t workspace_bytes,
+                             int* flags, cnf_stream_t stream) {
+    CNF_REQUIRE(z && nn_out && z_out && ldj_out && nll_out, "%s: null tensor", who);
+    MixArgs a = {};
+    a.compact = compact;
+    a.z = z; a.nn = nn_out; a.sf = scaling_factor; a.msf = mixture_scaling_factor;
+    a.mask = mask; a.pad = pad; a.ldj_in = ldj_in; a.z_out = z_out; a.ldj_out = ldj_out;
+    a.reg_out = reg_out; a.flags = flags;
+    a.B = B; a.N = N; a.D = D; a.K = K; a.mr = mask_rows; a.mc = mask_cols;
+    a.reverse = 0;
+    a.pad_in_transform = pad ? pad_in_transform : 0;
+    a.pad_output = pad ? pad_output : 0;
+    a.use_reg = (reg_max > 0 && is_training) ? 1 : 0;
+    a.reg_max = reg_max; a.reg_factor = reg_factor;
+    a.length = length; a.neglog_out = neglog_out; a.nll_out = nll_out;
+    a.nll_acc = reinterpret_cast<long long*>(nll_acc);
+    a.prior = make_prior_const(sigma, log_sigma);
+    split_workspace(a, workspace, workspace_bytes);
+    return launch_mixture(a, false, act_host, n_act, (hipStream_t)stream, who);
 }
 
 int cnf_mixture_coupling_nll(const float* z, const float* nn_out,
@@ -1127,22 +1203,59 @@ int cnf_mixture_coupling_nll(const float* z, const float* nn_out,
                              float sigma, float log_sigma,
                              void* workspace, int64_t workspace_bytes,
                              int* flags, cnf_stream_t stream) {
-    CNF_REQUIRE(z && nn_out && z_out && ldj_out && nll_out, "cnf_mixture_coupling_nll: null tensor");
+    return mixture_coupling_nll_impl("cnf_mixture_coupling_nll", 0, z, nn_out, scaling_factor, mixture_scaling_factor, mask, mask_rows, mask_cols,
+                                     act_host, n_act, pad, pad_in_transform, pad_output, ldj_in, z_out, ldj_out, reg_out, length, neglog_out,
+                                     nll_out, nll_acc, B, N, D, K, reg_max, reg_factor, is_training, sigma, log_sigma, workspace,
+                                     workspace_bytes, flags, stream);
+}
+
+int cnf_mixture_coupling_compact_nll(const float* z, const float* nn_compact,
+                                     const float* scaling_factor, const float* mixture_scaling_factor,
+                                     const float* mask, int mask_rows, int mask_cols,
+                                     const int* act_host, int n_act,
+                                     const float* pad, int pad_in_transform, int pad_output,
+                                     const float* ldj_in, float* z_out, float* ldj_out, float* reg_out,
+                                     const float* length, float* neglog_out, float* nll_out, int64_t* nll_acc,
+                                     int B, int N, int D, int K,
+                                     double reg_max, double reg_factor, int is_training,
+                                     float sigma, float log_sigma,
+                                     void* workspace, int64_t workspace_bytes,
+                                     int* flags, cnf_stream_t stream) {
+    return mixture_coupling_nll_impl("cnf_mixture_coupling_compact_nll", 1, z, nn_compact, scaling_factor, mixture_scaling_factor, mask, mask_rows,
+                                     mask_cols, act_host, n_act, pad, pad_in_transform, pad_output, ldj_in, z_out, ldj_out, reg_out, length,
+                                     neglog_out, nll_out, nll_acc, B, N, D, K, reg_max, reg_factor, is_training, sigma, log_sigma, workspace,
+                                     workspace_bytes, flags, stream);
+}
+
+static int mixture_coupling_actconv_impl(const char* who, int compact, const float* z, const float* nn_out,
+                                 const float* scaling_factor, const float* mixture_scaling_factor,
+                                 const float* mask, int mask_rows, int mask_cols,
+                                 const int* act_host, int n_act,
+                                 const float* pad,
+                                 const float* ldj_in, float* z_out, float* ldj_out, float* reg_out,
+                                 const float* an_bias, const float* an_scales, const float* conv_weight, const float* conv_sldj,
+                                 const float* length,
+                                 int B, int N, int D, int K,
+                                 double reg_max, double reg_factor, int is_training,
+                                 void* workspace, int64_t workspace_bytes,
+                                 int* flags, cnf_stream_t stream) {
+    CNF_REQUIRE(z && nn_out && z_out && ldj_out && an_bias && an_scales && conv_weight && conv_sldj, "%s: null tensor", who);
+    CNF_REQUIRE(D == 1 || D == 2 || D == 3 || D == 4 || D == 5 || D == 6 || D == 8,
+                "%s: D=%d is outside the fused ActNorm + convolution kernels", who, D);
     MixArgs a = {};
+    a.compact = compact;
     a.z = z; a.nn = nn_out; a.sf = scaling_factor; a.msf = mixture_scaling_factor;
     a.mask = mask; a.pad = pad; a.ldj_in = ldj_in; a.z_out = z_out; a.ldj_out = ldj_out;
     a.reg_out = reg_out; a.flags = flags;
     a.B = B; a.N = N; a.D = D; a.K = K; a.mr = mask_rows; a.mc = mask_cols;
     a.reverse = 0;
-    a.pad_in_transform = pad ? pad_in_transform : 0;
-    a.pad_output = pad ? pad_output : 0;
+    a.pad_in_transform = pad ? 1 : 0;
+    a.pad_output = pad ? 1 : 0;
     a.use_reg = (reg_max > 0 && is_training) ? 1 : 0;
     a.reg_max = reg_max; a.reg_factor = reg_factor;
-    a.length = length; a.neglog_out = neglog_out; a.nll_out = nll_out;
-    a.nll_acc = reinterpret_cast<long long*>(nll_acc);
-    a.prior = make_prior_const(sigma, log_sigma);
+    a.e_bias = an_bias; a.e_scales = an_scales; a.e_w = conv_weight; a.e_sldj = conv_sldj; a.e_length = length;
     split_workspace(a, workspace, workspace_bytes);
-    return launch_mixture(a, false, act_host, n_act, (hipStream_t)stream, "cnf_mixture_coupling_nll");
+    return launch_mixture(a, false, act_host, n_act, (hipStream_t)stream, who);
 }
 
 int cnf_mixture_coupling_actconv(const float* z, const float* nn_out,
@@ -1157,26 +1270,31 @@ int cnf_mixture_coupling_actconv(const float* z, const float* nn_out,
                                  double reg_max, double reg_factor, int is_training,
                                  void* workspace, int64_t workspace_bytes,
                                  int* flags, cnf_stream_t stream) {
-    CNF_REQUIRE(z && nn_out && z_out && ldj_out && an_bias && an_scales && conv_weight && conv_sldj,
-                "cnf_mixture_coupling_actconv: null tensor");
-    CNF_REQUIRE(D == 1 || D == 2 || D == 3 || D == 4 || D == 5 || D == 6 || D == 8,
-                "cnf_mixture_coupling_actconv: D=%d is outside the fused ActNorm + convolution kernels", D);
-    MixArgs a = {};
-    a.z = z; a.nn = nn_out; a.sf = scaling_factor; a.msf = mixture_scaling_factor;
-    a.mask = mask; a.pad = pad; a.ldj_in = ldj_in; a.z_out = z_out; a.ldj_out = ldj_out;
-    a.reg_out = reg_out; a.flags = flags;
-    a.B = B; a.N = N; a.D = D; a.K = K; a.mr = mask_rows; a.mc = mask_cols;
-    a.reverse = 0;
-    a.pad_in_transform = pad ? 1 : 0;
-    a.pad_output = pad ? 1 : 0;
-    a.use_reg = (reg_max > 0 && is_training) ? 1 : 0;
-    a.reg_max = reg_max; a.reg_factor = reg_factor;
-    a.e_bias = an_bias; a.e_scales = an_scales; a.e_w = conv_weight; a.e_sldj = conv_sldj; a.e_length = length;
-    split_workspace(a, workspace, workspace_bytes);
-    return launch_mixture(a, false, act_host, n_act, (hipStream_t)stream, "cnf_mixture_coupling_actconv");
+    return mixture_coupling_actconv_impl("cnf_mixture_coupling_actconv", 0, z, nn_out, scaling_factor, mixture_scaling_factor, mask, mask_rows,
+                                         mask_cols, act_host, n_act, pad, ldj_in, z_out, ldj_out, reg_out, an_bias, an_scales, conv_weight,
+                                         conv_sldj, length, B, N, D, K, reg_max, reg_factor, is_training, workspace, workspace_bytes, flags,
+                                         stream);
 }
 
-int cnf_mixture_coupling_bwd_f32(const float* z, const float* nn_out,
+int cnf_mixture_coupling_compact_actconv(const float* z, const float* nn_compact,
+                                         const float* scaling_factor, const float* mixture_scaling_factor,
+                                         const float* mask, int mask_rows, int mask_cols,
+                                         const int* act_host, int n_act,
+                                         const float* pad,
+                                         const float* ldj_in, float* z_out, float* ldj_out, float* reg_out,
+                                         const float* an_bias, const float* an_scales, const float* conv_weight, const float* conv_sldj,
+                                         const float* length,
+                                         int B, int N, int D, int K,
+                                         double reg_max, double reg_factor, int is_training,
+                                         void* workspace, int64_t workspace_bytes,
+                                         int* flags, cnf_stream_t stream) {
+    return mixture_coupling_actconv_impl("cnf_mixture_coupling_compact_actconv", 1, z, nn_compact, scaling_factor, mixture_scaling_factor, mask,
+                                         mask_rows, mask_cols, act_host, n_act, pad, ldj_in, z_out, ldj_out, reg_out, an_bias, an_scales,
+                                         conv_weight, conv_sldj, length, B, N, D, K, reg_max, reg_factor, is_training, workspace,
+                                         workspace_bytes, flags, stream);
+}
+
+static int mixture_coupling_bwd_f32_impl(const char* who, int compact, const float* z, const float* nn_out,
                                  const float* scaling_factor, const float* mixture_scaling_factor,
                                  const float* mask, int mask_rows, int mask_cols,
                                  const int* act_host, int n_act,
@@ -1186,10 +1304,10 @@ int cnf_mixture_coupling_bwd_f32(const float* z, const float* nn_out,
                                  float* workspace,
                                  int B, int N, int D, int K, double reg_max, double reg_factor, int is_training,
                                  cnf_stream_t stream) {
-    CNF_REQUIRE(z && nn_out && g_z && g_nn && workspace, "cnf_mixture_coupling_bwd_f32: null tensor");
-    CNF_REQUIRE(B > 0 && N > 0 && D > 0 && K > 0, "cnf_mixture_coupling_bwd_f32: bad shape");
-    CNF_REQUIRE(!scaling_factor || g_scaling_factor, "cnf_mixture_coupling_bwd_f32: g_scaling_factor missing");
-    CNF_REQUIRE(!mixture_scaling_factor || g_mixture_scaling_factor, "cnf_mixture_coupling_bwd_f32: g_mixture_scaling_factor missing");
+    CNF_REQUIRE(z && nn_out && g_z && g_nn && workspace, "%s: null tensor", who);
+    CNF_REQUIRE(B > 0 && N > 0 && D > 0 && K > 0, "%s: bad shape", who);
+    CNF_REQUIRE(!scaling_factor || g_scaling_factor, "%s: g_scaling_factor missing", who);
+    CNF_REQUIRE(!mixture_scaling_factor || g_mixture_scaling_factor, "%s: g_mixture_scaling_factor missing", who);
     if (math_mode() == 1 && g_mix_kernel != 1 && D <= kMaxAct && (long)N * D < 65536) {
         MixArgs a = {};
         a.z = z; a.nn = nn_out; a.sf = scaling_factor; a.msf = mixture_scaling_factor; a.mask = mask; a.pad = pad;
@@ -1204,14 +1322,59 @@ int cnf_mixture_coupling_bwd_f32(const float* z, const float* nn_out,
         if (a.mr >= 1 && (a.mc == D || a.mc == 1)) {
             fill_act(a, act_host, n_act);
             a.div_da = make_fastdiv((uint32_t)a.DA);
-            if (launch_mixture_tok_bwd(a, g_zout, g_ldj, g_z, g_nn, g_scaling_factor, g_mixture_scaling_factor, workspace,
+            a.nn_D = D; a.nn_c0 = 0;
+            a.compact = compact;
+            const bool compact_ok = compact && mask && !a.per_item_mask && a.act_bits != 0;
+            if (compact_ok) {
+                a.nn_D = a.DA;
+                a.nn_c0 = __builtin_ctzll(a.act_bits);
+            }
+            if ((!compact || compact_ok) &&
+                launch_mixture_tok_bwd(a, g_zout, g_ldj, g_z, g_nn, g_scaling_factor, g_mixture_scaling_factor, workspace,
                                        (hipStream_t)stream, g_mix_lanes))
-                return launch_status("cnf_mixture_coupling_bwd_f32");
+                return launch_status(who);
         }
+    }
+    if (compact) {
+        // only the token-pass backward writes the compact layout: the caller expands nn_out / g_nn to the reference layout
+        set_error("%s: shape / mode outside the compact-layout backward (B=%d N=%d D=%d K=%d)", who, B, N, D, K);
+        return CNF_ERR_UNSUPPORTED;
     }
     return cnf_mixture_coupling_bwd(z, nn_out, scaling_factor, mixture_scaling_factor, mask, mask_rows, mask_cols, pad,
                                     pad_in_transform, pad_output, g_zout, g_ldj, g_z, g_nn, g_scaling_factor,
                                     g_mixture_scaling_factor, workspace, B, N, D, K, reg_max, reg_factor, is_training, stream);
+}
+
+int cnf_mixture_coupling_bwd_f32(const float* z, const float* nn_out,
+                                 const float* scaling_factor, const float* mixture_scaling_factor,
+                                 const float* mask, int mask_rows, int mask_cols,
+                                 const int* act_host, int n_act,
+                                 const float* pad, int pad_in_transform, int pad_output,
+                                 const float* g_zout, const float* g_ldj,
+                                 float* g_z, float* g_nn, float* g_scaling_factor, float* g_mixture_scaling_factor,
+                                 float* workspace,
+                                 int B, int N, int D, int K, double reg_max, double reg_factor, int is_training,
+                                 cnf_stream_t stream) {
+    return mixture_coupling_bwd_f32_impl("cnf_mixture_coupling_bwd_f32", 0, z, nn_out, scaling_factor, mixture_scaling_factor, mask, mask_rows,
+                                         mask_cols, act_host, n_act, pad, pad_in_transform, pad_output, g_zout, g_ldj, g_z, g_nn,
+                                         g_scaling_factor, g_mixture_scaling_factor, workspace, B, N, D, K, reg_max, reg_factor, is_training,
+                                         stream);
+}
+
+int cnf_mixture_coupling_compact_bwd_f32(const float* z, const float* nn_compact,
+                                         const float* scaling_factor, const float* mixture_scaling_factor,
+                                         const float* mask, int mask_rows, int mask_cols,
+                                         const int* act_host, int n_act,
+                                         const float* pad, int pad_in_transform, int pad_output,
+                                         const float* g_zout, const float* g_ldj,
+                                         float* g_z, float* g_nn_compact, float* g_scaling_factor, float* g_mixture_scaling_factor,
+                                         float* workspace,
+                                         int B, int N, int D, int K, double reg_max, double reg_factor, int is_training,
+                                         cnf_stream_t stream) {
+    return mixture_coupling_bwd_f32_impl("cnf_mixture_coupling_compact_bwd_f32", 1, z, nn_compact, scaling_factor, mixture_scaling_factor, mask,
+                                         mask_rows, mask_cols, act_host, n_act, pad, pad_in_transform, pad_output, g_zout, g_ldj, g_z,
+                                         g_nn_compact, g_scaling_factor, g_mixture_scaling_factor, workspace, B, N, D, K, reg_max,
+                                         reg_factor, is_training, stream);
 }
 
 int cnf_mixture_transform(const double* z, const double* t, const double* log_s,

@@ -20,12 +20,15 @@ constexpr double kLn10b = 2.302585092994045684;
 // A workgroup's parameter-gradient sums: the lanes meet in LDS words, many lanes per word and in no fixed order — so the words
 // are 64-bit FIXED-POINT sums (2^-32 units, integer atomics): integer addition is associative, the sum does not depend on the
 // order, and the gradients of this file are bit-reproducible like the rest of the library's (rounds 1-4 added fp32 here with
-// atomicAdd: run-to-run differences in the last bits).  Range +-2^31 per workgroup and parameter, resolution 2.3e-10.
-constexpr double kFixScale = 4294967296.0;
-__device__ __forceinline__ void fix_add(long long* word, double v) {
-    atomicAdd(reinterpret_cast<unsigned long long*>(word), (unsigned long long)__double2ll_rn(v * kFixScale));
+// atomicAdd: run-to-run differences in the last bits).  Range +-2^31 per workgroup and parameter, resolution 2.3e-10: a
+// workgroup sees fewer than 2^21 elements (B N D < 2^31 over 1024 workgroups), so terms below 2^10 cannot wrap its word; a
+// larger term, +-inf and NaN (a diverged element) go to the word's fp64 escape twin (cnf_common.h: fix_pair_add) and the
+// gradient comes out as the reference's floating-point sum would — NaN for a NaN term, not a finite wrong number.
+constexpr double kGradTermMax = 1024.0;
+__device__ __forceinline__ void fix_add(long long* word, double* big, double v) {
+    fix_pair_add(reinterpret_cast<unsigned long long*>(word), big, v, kGradTermMax);
 }
-__device__ __forceinline__ float fix_value(long long word) { return (float)((double)word / kFixScale); }
+__device__ __forceinline__ float fix_value(long long word, double big) { return (float)fix_pair_value(word, big); }
 
 struct MixBwdArgs {
     const float* z;
@@ -80,8 +83,12 @@ __device__ __forceinline__ void bound_grads(float raw, const float* fac_ptr, dou
 template <bool SPLIT>
 __global__ __launch_bounds__(kBlock) void mixture_fwd_bwd_kernel(MixBwdArgs a) {
     __shared__ long long acc[kMixBwdMaxP];
+    __shared__ double accbig[kMixBwdMaxP];
     const int PP = a.D + a.D * a.K;
-    for (int i = threadIdx.x; i < PP; i += kBlock) acc[i] = 0;
+    for (int i = threadIdx.x; i < PP; i += kBlock) {
+        acc[i] = 0;
+        accbig[i] = 0.0;
+    }
     __syncthreads();
     const int K = a.K;
     for (long e = (long)blockIdx.x * kBlock + threadIdx.x; e < a.total; e += (long)gridDim.x * kBlock) {
@@ -134,10 +141,11 @@ __global__ __launch_bounds__(kBlock) void mixture_fwd_bwd_kernel(MixBwdArgs a) {
         const double u = cdf / se;
         const double pdf_n = pdf / se;
         const double a_s = exp(log_s);
-        const double uc = fmax(u, 1e-22), u1c = fmax(1.0 - u, 1e-22);
+        // torch.clamp keeps a NaN (fmax returns its other operand): a diverged element gives NaN gradients, as autograd does
+        const double uc = u != u ? u : fmax(u, 1e-22), u1c = u != u ? u : fmax(1.0 - u, 1e-22);
         const double lu = log(uc), l1u = log(u1c);
-        const double dlu = u > 1e-22 ? 1.0 / u : 0.0;               // d safe_log(u) / du
-        const double dl1u = (1.0 - u) > 1e-22 ? -1.0 / (1.0 - u) : 0.0;   // d safe_log(1-u) / du
+        const double dlu = u > 1e-22 ? 1.0 / u : (u != u ? u : 0.0);               // d safe_log(u) / du
+        const double dl1u = (1.0 - u) > 1e-22 ? -1.0 / (1.0 - u) : (u != u ? u : 0.0);   // d safe_log(1-u) / du
         const double zt = ((lu - l1u) + t) * a_s;
         double g_u = gzo * a_s * (dlu - dl1u) + gl * (-dlu - dl1u);
         if (a.use_reg) {
@@ -160,7 +168,7 @@ __global__ __launch_bounds__(kBlock) void mixture_fwd_bwd_kernel(MixBwdArgs a) {
             double d_raw, d_sf;
             bound_grads(row[1], sf_d, d_raw, d_sf);
             grow[1] = (float)(g_logs * d_raw);
-            if (sf_d) fix_add(&acc[d], g_logs * d_sf);
+            if (sf_d) fix_add(&acc[d], &accbig[d], g_logs * d_sf);
         }
         // pass 2: per-mixture parameter gradients
         for (int k = 0; k < K; ++k) {
@@ -188,13 +196,13 @@ __global__ __launch_bounds__(kBlock) void mixture_fwd_bwd_kernel(MixBwdArgs a) {
                 double d_raw, d_sf;                                  // through the tanh bound
                 bound_grads(row[2 + 2 * K + k], msf_k, d_raw, d_sf);
                 grow[2 + 2 * K + k] = (float)(g_ls * d_raw);
-                if (msf_k) fix_add(&acc[a.D + d * K + k], g_ls * d_sf);
+                if (msf_k) fix_add(&acc[a.D + d * K + k], &accbig[a.D + d * K + k], g_ls * d_sf);
             }
         }
     }
     __syncthreads();
     if (!SPLIT)
-        for (int i = threadIdx.x; i < PP; i += kBlock) a.partials[(size_t)blockIdx.x * PP + i] = fix_value(acc[i]);
+        for (int i = threadIdx.x; i < PP; i += kBlock) a.partials[(size_t)blockIdx.x * PP + i] = fix_value(acc[i], accbig[i]);
 }
 
 // d(get_mixt_params) (:145-180): five fp64 upstream gradients -> g_nn (fp32) through mask and tanh bounds
@@ -215,8 +223,12 @@ struct MixParamsBwdArgs {
 };
 __global__ __launch_bounds__(kBlock) void mixture_params_bwd_kernel(MixParamsBwdArgs a) {
     __shared__ long long acc[kMixBwdMaxP];
+    __shared__ double accbig[kMixBwdMaxP];
     const int K = a.K, P = 2 + 3 * K, PP = a.D + a.D * K;
-    for (int i = threadIdx.x; i < PP; i += kBlock) acc[i] = 0;
+    for (int i = threadIdx.x; i < PP; i += kBlock) {
+        acc[i] = 0;
+        accbig[i] = 0.0;
+    }
     __syncthreads();
     const long total = a.nelem * P;
     for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long)gridDim.x * kBlock) {
@@ -242,10 +254,10 @@ __global__ __launch_bounds__(kBlock) void mixture_params_bwd_kernel(MixParamsBwd
         }
         g *= keep;
         a.g_nn[i] = (float)(g * d_raw);
-        if (slot >= 0 && g != 0.0) fix_add(&acc[slot], g * d_sf);
+        if (slot >= 0 && g != 0.0) fix_add(&acc[slot], &accbig[slot], g * d_sf);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < PP; i += kBlock) a.partials[(size_t)blockIdx.x * PP + i] = fix_value(acc[i]);
+    for (int i = threadIdx.x; i < PP; i += kBlock) a.partials[(size_t)blockIdx.x * PP + i] = fix_value(acc[i], accbig[i]);
 }
 
 // partials [nrows, P] -> column sums in fp64, fixed order; columns [0, split) go to out_a, the rest to out_b (either may

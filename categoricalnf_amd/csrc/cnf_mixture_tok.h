@@ -12,7 +12,6 @@ namespace cnf {
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void glb_void_t;
 
-constexpr double kFix32 = 4294967296.0;
 constexpr int kMaxRowSlots = 64;       // rows one wave tile may hold
 constexpr int kMaxDmaInstr = 24;       // 1 KiB DMA instructions per pass
 
@@ -40,7 +39,10 @@ struct TokGeom {
     FastDiv div_slot, div_n, div_lpt, div_nc;
 };
 
-__device__ __forceinline__ long long to_fix(double v) { return __double2ll_rn(v * kFix32); }
+// Limits of the fixed-point row sums (cnf_common.h: fix_pair_add).  A row has fewer than 65 536 terms (N * D < 65536), so terms
+// below 2^14 keep its integer word below 2^30; a split row adds at most 2^14 workgroup partials, each below 2^16.
+constexpr double kRowTermMax = 16384.0;
+constexpr double kRowPartMax = 65536.0;
 
 // one 1 KiB DMA instruction; nt (wave-uniform): the parameters are read once — with the nontemporal hint the fp32 forward gains 2-8 %
 // from 78 MB of staged spans up (S*: 312 MB, 103.6 -> 95-100 us) and loses 4 % at configs[1]'s 52 MB (profiles/r05_mixture_nt_sweep.txt)

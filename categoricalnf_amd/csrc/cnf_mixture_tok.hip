@@ -65,8 +65,9 @@ namespace cnf {
 #define CNF_X64_INV_WAVES 1
 #endif
 constexpr int kTokPre = 8;      // DMA instructions per pass whose source offsets the fp64 kernels keep (8 KiB stages)
-constexpr int tok_min_waves(int kt, bool reverse, int g, bool pr, bool x64 = false) {
+constexpr int tok_min_waves(int kt, bool reverse, int g, bool pr, bool x64 = false, bool nll = false) {
     if (x64) return reverse ? CNF_X64_INV_WAVES : CNF_X64_FWD_WAVES;
+    if (kt == 16 && nll && g == 1 && !pr) return 4;        // 129 VGPRs as compiled freely (round 6: the escape words of the row sums)
     return (kt == 8 && reverse && g == 1 && !pr) ? 5 : 1;
 }
 
@@ -76,7 +77,7 @@ constexpr int tok_min_waves(int kt, bool reverse, int g, bool pr, bool x64 = fal
 // forward; the inverse polishes the fp32 Newton root with safeguarded Newton steps in fp64 (quadratic convergence: two
 // evaluations from a 1e-7 start) inside the widened component-quantile bracket.  KT > 0 only.
 template <int KT, bool REVERSE, int G, bool NLL, int ED = 0, bool PR = false, bool X64 = false>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(tok_min_waves(KT, REVERSE, G, PR, X64))))
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(tok_min_waves(KT, REVERSE, G, PR, X64, NLL))))
 void mixture_tok_kernel(MixArgs a, TokGeom gm) {
     static_assert(!X64 || (KT > 0 && !NLL && ED == 0), "fp64 arithmetic: register slots, plain coupling");
     static_assert(G == 1 || KT == 0 || PR, "several lanes per item: run-time K (rolled loop) or predicated slots");
@@ -89,12 +90,11 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
     char* stage_b = smem + (size_t)wave * gm.stage_bytes;
     BoundTab* sf_tab = reinterpret_cast<BoundTab*>(smem + gm.tab_off);
     BoundTab* msf_tab = sf_tab + a.D;
-    // accumulators: split == 0: [wave][rw][2] fixed-point row sums; split == 1: [wave][2] fp64 wave partials
+    // accumulators: split == 0: [wave][rw][2] fixed-point row sums, then [wave][rw][2] fp64 escape words for the terms the
+    // fixed-point words cannot take (|term| >= 2^14, +-inf, NaN: cnf_common.h fix_pair_add); split == 1: [wave][2] fp64 wave partials
     long long* rowacc = reinterpret_cast<long long*>(smem + gm.acc_off) + (size_t)wave * gm.rw * 2;
+    double* rowbig = reinterpret_cast<double*>(smem + gm.acc_off) + (size_t)(kWavesPerBlock + wave) * gm.rw * 2;
     double* wpart = reinterpret_cast<double*>(smem + gm.acc_off);
-    // rows of this wave's tile that met a term the fixed-point words cannot hold (NaN, +-inf): their results are NaN, as a
-    // floating-point sum's would be (bit i = row i of the tile; split == 0 only — the other mode sums in fp64 inside a workgroup)
-    unsigned long long* rowbad = reinterpret_cast<unsigned long long*>(smem + gm.acc_off) + (size_t)kWavesPerBlock * gm.rw * 2 + wave;
     // epilogue: constants [bias D | e^scales D | W D*D | sum scales] and this wave's strip of one pass of tokens
     float* etab = reinterpret_cast<float*>(smem + gm.epi_off);
     float* ep = etab + (2 * ED + ED * ED + 4) + (size_t)wave * gm.TPP * ED;
@@ -129,8 +129,8 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
     float* zo_tile = a.z_out + tok_g0 * a.D;
     const float* pad_tile = a.pad ? a.pad + tok_g0 : nullptr;
     const char* nn_lo = reinterpret_cast<const char*>(a.nn);
-    const char* nn_last = nn_lo + ((size_t)a.B * a.N * a.D * P - 4) * sizeof(float);      // last aligned 16-byte chunk
-    const char* span0 = nn_lo + (tok_g0 * a.D + gm.sd0) * (size_t)P * sizeof(float);       // first token's staged span
+    const char* nn_last = nn_lo + ((size_t)a.B * a.N * a.nn_D * P - 4) * sizeof(float);      // last aligned 16-byte chunk
+    const char* span0 = nn_lo + (tok_g0 * a.nn_D + (gm.sd0 - a.nn_c0)) * (size_t)P * sizeof(float);       // first token's staged span
 
     // lane -> (token in pass, channel, share of the mixtures)
     const int tli = (int)fdiv((uint32_t)lane, gm.div_lpt);
@@ -198,8 +198,10 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
         if (a.msf) msf_tab[i] = make_bound(a.msf[i]);
     if (!gm.split)
     {
-        for (int i = lane; i < gm.rw * 2; i += kWave) rowacc[i] = 0;
-        if (lane == 0) *rowbad = 0ull;
+        for (int i = lane; i < gm.rw * 2; i += kWave) {
+            rowacc[i] = 0;
+            rowbig[i] = 0.0;
+        }
     }
     __syncthreads();
     if (!gm.split && nrows <= 0) return;            // no barrier follows in this mode
@@ -241,7 +243,8 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
             for (int k = 0; k < K; ++k) {
                 const float lsf = a.msf ? bound_of(my[2 + 2 * K + k], mt[k]) : my[2 + 2 * K + k];
                 const double zd = (xd - (double)my[2 + K + k]) * exp(-(double)lsf);
-                m = fmax(m, (double)my[2 + k] - lse_pi + zd - (double)lsf - 2.0 * softplus64(zd));
+                const double tk = (double)my[2 + k] - lse_pi + zd - (double)lsf - 2.0 * softplus64(zd);
+                m = (tk != tk || m != m) ? (double)NAN : fmax(m, tk);       // torch.max keeps a NaN
             }
             double ssum = 0.0;
 #pragma clang loop unroll(disable)
@@ -250,7 +253,7 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
                 const double zd = (xd - (double)my[2 + K + k]) * exp(-(double)lsf);
                 ssum += exp((double)my[2 + k] - lse_pi + zd - (double)lsf - 2.0 * softplus64(zd) - m);
             }
-            return m + log(ssum);
+            return isinf(m) ? m : m + log(ssum);      // torch.logsumexp: every term -inf (a latent of -inf) gives -inf
         };
         if (active && REVERSE) {
             // ---- inverse (:125-134, :235-264) in fp32: safeguarded Newton on the two-sided CDF.  u = sigmoid(v)
@@ -391,8 +394,9 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
                 double ud = vd >= 0.0 ? rv1 : Ev * rv1;
                 const double l1pE = log1p64_unit(Ev);
                 double mldj = av > 20.0 ? av + l1pE : av + (l1pE + l1pE);
-                if (!(av == av)) { ud = vd; mldj = vd; }       // NaN in: NaN out
                 ud = fmin(fmax(ud, 1e-5), 1.0 - 1e-5);
+                // NaN in: NaN out (torch.clamp keeps a NaN, fmin / fmax return their other operand: set after the clamp)
+                if (!(av == av)) { ud = vd; mldj = vd; }
                 if (!(ud > 0.0 && ud < 1.0)) range = true;
                 // With ONE evaluation per element in the usual case nothing is reused between evaluations, so the weights e^{lp - max}
                 // and the inverse scales e^{-ls} are not kept: every evaluation is one rolled pass over the staged row like the
@@ -639,9 +643,8 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
             acc_ldj += cd;
             if (NLL) acc_nlp += nlp;
         } else if (owner) {
-            if (active) atomicAdd(reinterpret_cast<unsigned long long*>(rowacc + rl * 2), (unsigned long long)to_fix(cd));
-            if (NLL) atomicAdd(reinterpret_cast<unsigned long long*>(rowacc + rl * 2 + 1), (unsigned long long)to_fix(nlp));
-            if (!(fabs(cd) < 1e300) || (NLL && !(fabs(nlp) < 1e300))) atomicOr(rowbad, 1ull << rl);
+            if (active) fix_pair_add(reinterpret_cast<unsigned long long*>(rowacc + rl * 2), rowbig + rl * 2, cd, kRowTermMax);
+            if (NLL) fix_pair_add(reinterpret_cast<unsigned long long*>(rowacc + rl * 2 + 1), rowbig + rl * 2 + 1, nlp, kRowTermMax);
         }
         // ---- the pass's channels that are not transformed: copied through (times the padding mask)
         if (gm.ncopy > 0) {
@@ -662,8 +665,7 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
                         acc_nlp += lp2;
                     } else {
                         const int rl2 = (int)fdiv((uint32_t)tl2, gm.div_n);
-                        atomicAdd(reinterpret_cast<unsigned long long*>(rowacc + rl2 * 2 + 1), (unsigned long long)to_fix(lp2));
-                        if (!(fabs(lp2) < 1e300)) atomicOr(rowbad, 1ull << rl2);
+                        fix_pair_add(reinterpret_cast<unsigned long long*>(rowacc + rl2 * 2 + 1), rowbig + rl2 * 2 + 1, lp2, kRowTermMax);
                     }
                 }
             }
@@ -736,18 +738,14 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
             if (a.neglog_out) a.neglog_out[row] = neglog;
             const float nll = (-v) / len + neglog / len;
             a.nll_out[row] = nll;
-            if (a.nll_acc)
-                atomicAdd(reinterpret_cast<unsigned long long*>(a.nll_acc) + (size_t)(row & 63) * kAccStride,
-                          (unsigned long long)__double2ll_rn((double)nll * kFix32));
+            if (a.nll_acc) nll_acc_add(a.nll_acc, row & 63, nll);
         }
     };
     if (!gm.split) {
         wave_lds_sync();
-        if (own_row) {
-            const double poison = ((*rowbad >> lane) & 1ull) ? (double)NAN : 0.0;
-            finish(row0 + lane, (double)rowacc[lane * 2] * (1.0 / kFix32) + poison, (double)rowacc[lane * 2 + 1] * (1.0 / kFix32) + poison,
+        if (own_row)
+            finish(row0 + lane, fix_pair_value(rowacc[lane * 2], rowbig[lane * 2]), fix_pair_value(rowacc[lane * 2 + 1], rowbig[lane * 2 + 1]),
                    my_ldj, my_len);
-        }
     } else {
         acc_ldj = wave_sum(acc_ldj);
         if (NLL) acc_nlp = wave_sum(acc_nlp);
@@ -766,19 +764,27 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
                 finish(row0, t0, t1, a.ldj_in ? a.ldj_in[row0] : 0.f, (NLL && a.length) ? a.length[row0] : (float)a.N);
             } else {
                 // fixed-point row words in the workspace: device-scope integer atomics on both sides.  The adds
-                // return (and are waited for) before the ticket is drawn, so the last arriver sees every term.
+                // return (and are waited for) before the ticket is drawn, so the last arriver sees every term.  A partial
+                // the fixed-point word cannot take (|partial| >= 2^16, +-inf, NaN) goes to the row's fp64 escape word
+                // (returning atomic, waited for like the others).
                 unsigned long long* wa = reinterpret_cast<unsigned long long*>(a.ws_acc) + (size_t)row0 * 2;
-                unsigned long long o0 = atomicAdd(wa, (unsigned long long)to_fix(t0));
-                unsigned long long o1 = NLL ? atomicAdd(wa + 1, (unsigned long long)to_fix(t1)) : 0ull;
-                // a partial the fixed-point word cannot hold marks the row in bit 30 of its ticket counter (before the ticket)
-                if (!(fabs(t0) < 1e300) || (NLL && !(fabs(t1) < 1e300))) o0 += (unsigned long long)atomicOr(a.ws_cnt + row0, 1 << 30);
+                double* wb = reinterpret_cast<double*>(a.ws_big) + (size_t)row0 * 2;
+                unsigned long long o0 = 0ull, o1 = 0ull;
+                if (fabs(t0) < kRowPartMax) o0 = atomicAdd(wa, (unsigned long long)to_fix(t0));
+                else o0 = (unsigned long long)__double_as_longlong(unsafeAtomicAdd(wb, t0));
+                if (NLL) {
+                    if (fabs(t1) < kRowPartMax) o1 = atomicAdd(wa + 1, (unsigned long long)to_fix(t1));
+                    else o1 = (unsigned long long)__double_as_longlong(unsafeAtomicAdd(wb + 1, t1));
+                }
                 asm volatile("s_waitcnt vmcnt(0)" : "+v"(o0), "+v"(o1) : : "memory");
-                const int ticket = atomicAdd(a.ws_cnt + row0, 1) & ((1 << 30) - 1);
+                const int ticket = atomicAdd(a.ws_cnt + row0, 1);
                 if (ticket == gm.S - 1) {
                     const long long s0 = (long long)atomicExch(wa, 0ull);
                     const long long s1 = NLL ? (long long)atomicExch(wa + 1, 0ull) : 0ll;
-                    const double poison = ((atomicExch(a.ws_cnt + row0, 0) >> 30) & 1) ? (double)NAN : 0.0;
-                    finish(row0, (double)s0 * (1.0 / kFix32) + poison, (double)s1 * (1.0 / kFix32) + poison,
+                    const double b0 = __longlong_as_double((long long)atomicExch(reinterpret_cast<unsigned long long*>(wb), 0ull));
+                    const double b1 = NLL ? __longlong_as_double((long long)atomicExch(reinterpret_cast<unsigned long long*>(wb + 1), 0ull)) : 0.0;
+                    atomicExch(a.ws_cnt + row0, 0);
+                    finish(row0, fix_pair_value(s0, b0), fix_pair_value(s1, b1),
                            a.ldj_in ? a.ldj_in[row0] : 0.f, (NLL && a.length) ? a.length[row0] : (float)a.N);
                 }
             }
@@ -824,11 +830,14 @@ bool make_tok_geom(const MixArgs& a, int kt, int force_g, TokGeom& gm, int& G, s
         if (run != a.act_bits) return false;
     }
     if ((reinterpret_cast<uintptr_t>(a.nn) & 15) != 0) return false;
-    if (((size_t)a.B * a.N * a.D * P) % 4 != 0) return false;
+    // compact layout: nn holds the DA transformed channels' blocks only — every pass is one contiguous span
+    const bool compact = a.nn_D != a.D;
+    if (compact && (a.per_item_mask || a.nn_D != DA || a.nn_c0 != d0)) return false;
+    if (((size_t)a.B * a.N * a.nn_D * P) % 4 != 0) return false;
     const int span = DA * P * 4;
-    const int tokstride = a.D * P * 4;
-    const bool whole = whole_tokens && DA < a.D && (span + 128) * 20 >= tokstride * 19 && whole_tokens_enabled();
-    const bool contig = DA == a.D || whole;
+    const int tokstride = a.nn_D * P * 4;
+    const bool whole = !compact && whole_tokens && DA < a.D && (span + 128) * 20 >= tokstride * 19 && whole_tokens_enabled();
+    const bool contig = DA == a.nn_D || whole;
     const bool phase0 = tokstride % 16 == 0 && (d0 * P * 4) % 16 == 0;       // every span starts on a 16-byte boundary
     const int slot = contig ? tokstride : ((span + (phase0 ? 0 : 12) + 15) & ~15);
     if (slot >= 32768) return false;
@@ -910,7 +919,7 @@ bool make_tok_geom(const MixArgs& a, int kt, int force_g, TokGeom& gm, int& G, s
     gm.tab_off = kWavesPerBlock * stage;
     gm.acc_off = (int)((size_t)gm.tab_off + tabs);
     const size_t accb = gm.split ? (size_t)kWavesPerBlock * 2 * sizeof(double)
-                                 : (size_t)kWavesPerBlock * (gm.rw * 2 + 1) * sizeof(long long);       // + one word of row marks per wave
+                                 : (size_t)kWavesPerBlock * gm.rw * 4 * sizeof(long long);       // fixed-point words + their fp64 escape words
     gm.epi_off = (int)(((size_t)gm.acc_off + accb + 15) & ~(size_t)15);
     lds = (size_t)gm.epi_off;
     if (a.e_w) {

@@ -98,8 +98,9 @@ constexpr uint32_t kTailSentinel = 0x7fc0a11eu;
 __device__ __forceinline__ void tail_fixup(const MixArgs& a, const TokBwdArgs& w, const BoundTab* mt, const BoundTab* sf_tab,
                                            size_t tok, int d, int K, int P, int lane, float* prow) {
     const size_t e = tok * a.D + d;
-    const float* prm = a.nn + e * (size_t)P;
-    float* gprm = w.g_nn + e * (size_t)P;
+    const size_t pe = tok * a.nn_D + (d - a.nn_c0);          // the element's parameter block (reference / compact layout)
+    const float* prm = a.nn + pe * (size_t)P;
+    float* gprm = w.g_nn + pe * (size_t)P;
     const float pv = a.pad ? a.pad[tok] : 1.f;
     const float outscale = a.pad_output ? pv : 1.f;
     const double xd = (double)a.z[e];
@@ -140,10 +141,11 @@ __device__ __forceinline__ void tail_fixup(const MixArgs& a, const TokBwdArgs& w
     }
     const double ud = cdfd / sed, pdf_n = pdfd / sed;
     const double a_s = exp((double)log_s);
-    const double ucl = fmax(ud, 1e-22), u1cl = fmax(1.0 - ud, 1e-22);
+    // torch.clamp keeps a NaN (fmax returns its other operand): a diverged element gives NaN gradients, as autograd does
+    const double ucl = ud != ud ? ud : fmax(ud, 1e-22), u1cl = ud != ud ? ud : fmax(1.0 - ud, 1e-22);
     const double lud = log(ucl), l1ud = log(u1cl);
-    const double dlu = ud > 1e-22 ? 1.0 / ud : 0.0;
-    const double dl1u = (1.0 - ud) > 1e-22 ? -1.0 / (1.0 - ud) : 0.0;
+    const double dlu = ud > 1e-22 ? 1.0 / ud : (ud != ud ? ud : 0.0);
+    const double dl1u = (1.0 - ud) > 1e-22 ? -1.0 / (1.0 - ud) : (ud != ud ? ud : 0.0);
     const double zt = ((lud - l1ud) + (double)t) * a_s;
     double g_ud = gzd * a_s * (dlu - dl1u) + gld * (-dlu - dl1u);
     if (a.use_reg) {
@@ -305,7 +307,7 @@ __device__ __forceinline__ void mixture_tok_bwd_body(const MixArgs& a, const Tok
     const int d = gm.d0 + j;
     const BoundTab* mt = msf_tab + d * K;
     const char* nn_lo = reinterpret_cast<const char*>(a.nn);
-    const char* nn_last = nn_lo + ((size_t)a.B * a.N * a.D * P - 4) * sizeof(float);
+    const char* nn_last = nn_lo + ((size_t)a.B * a.N * a.nn_D * P - 4) * sizeof(float);
     constexpr int KK = KT > 0 ? KT : 1;
     float acc_sf = 0.f, acc_m[KK];
 #pragma unroll
@@ -332,8 +334,8 @@ __device__ __forceinline__ void mixture_tok_bwd_body(const MixArgs& a, const Tok
         const float* gzo_tile = w.g_zout ? w.g_zout + tok_g0 * a.D : nullptr;
         float* gz_tile = w.g_z + tok_g0 * a.D;
         const float* pad_tile = a.pad ? a.pad + tok_g0 : nullptr;
-        const char* span0 = nn_lo + (tok_g0 * a.D + gm.d0) * (size_t)P * sizeof(float);
-        float* gnn_tile = w.g_nn + tok_g0 * a.D * (size_t)P;          // first token's first block
+        const char* span0 = nn_lo + (tok_g0 * a.nn_D + (gm.d0 - a.nn_c0)) * (size_t)P * sizeof(float);
+        float* gnn_tile = w.g_nn + tok_g0 * a.nn_D * (size_t)P;          // first token's first block
 
         // two stages per wave (run-time K kernels): the NEXT pass's rows are DMA-staged into the other stage as soon as this pass's
         // have landed, so their latency runs behind this pass's arithmetic and write-back instead of in front of the next pass
@@ -523,14 +525,28 @@ __device__ __forceinline__ void mixture_tok_bwd_body(const MixArgs& a, const Tok
             {
                 const int span_b = gm.DA * P * 4;
                 const int total_b = npt * span_b;
-                float* gspan0 = gnn_tile + ((size_t)tp * a.D + gm.d0) * P;       // first token's span in g_nn
+                float* gspan0 = gnn_tile + ((size_t)tp * a.nn_D + (gm.d0 - a.nn_c0)) * P;       // first token's span in g_nn
                 const uintptr_t src0 = reinterpret_cast<uintptr_t>(span0 + (size_t)tp * gm.tokstride);
-                if (w.wb_align == 24) {
+                if (w.wb_align == 32) {
+                    // the pass is ONE contiguous span (compact layout, or no mask) whose token size is not a multiple of 16 bytes
+                    // (S* compact: 312-byte tokens; the language model's 1860): 16-byte stores on the span's own 16-byte grid — nn and
+                    // g_nn share the phase, the stage was filled at it — with up to three 4-byte stores at either end
+                    const int ph = (int)(src0 & 15);
+                    const int head = (16 - ph) & 15;
+                    const int hb = min(head, total_b);
+                    char* gdst = reinterpret_cast<char*>(gspan0);
+                    if (lane * 4 < hb) wb_store(reinterpret_cast<float*>(gdst + lane * 4), *reinterpret_cast<const float*>(stage_b + ph + lane * 4));
+                    const int body = (total_b - hb) & ~15;
+                    for (int b = hb + lane * 16; b < hb + body; b += kWave * 16)
+                        wb_store(reinterpret_cast<float4*>(gdst + b), *reinterpret_cast<const float4*>(stage_b + ph + b));
+                    const int tb = hb + body + lane * 4;
+                    if (tb < total_b) wb_store(reinterpret_cast<float*>(gdst + tb), *reinterpret_cast<const float*>(stage_b + ph + tb));
+                } else if (w.wb_align == 24) {
                     // S* (D = 6: the span is bytes 312..623 of a 624-byte token): 8-byte stores were twice the instructions at half
                     // the width.  A token's base is 16-byte aligned, so the span is written as the 16-byte units it touches — the unit
                     // it shares with an untransformed block takes that block's zeros along — and the zero loop writes the other units.
                     const int total_u = npt * w.nu;
-                    char* gtok = reinterpret_cast<char*>(gnn_tile + (size_t)tp * a.D * P);
+                    char* gtok = reinterpret_cast<char*>(gnn_tile + (size_t)tp * a.nn_D * P);
                     for (int e = lane; e < total_u; e += kWave) {
                         const int s = (int)fdiv((uint32_t)e, w.div_nu);
                         const int ui = e - s * w.nu;
@@ -569,6 +585,7 @@ __device__ __forceinline__ void mixture_tok_bwd_body(const MixArgs& a, const Tok
                 }
             }
             // ---- channels that are not transformed: their latents pass the gradient through, their parameter blocks get zeros
+            // (the compact layout has no such blocks)
             if (gm.ncopy > 0) {
                 const int ne = npt * gm.ncopy;
                 for (int e = lane; e < ne; e += kWave) {
@@ -579,10 +596,12 @@ __device__ __forceinline__ void mixture_tok_bwd_body(const MixArgs& a, const Tok
                     const float pv2 = (pad_tile && a.pad_output) ? pad_tile[tl2] : 1.f;
                     gz_tile[(size_t)tl2 * a.D + c] = gzo_tile ? gzo_tile[(size_t)tl2 * a.D + c] * pv2 : 0.f;
                 }
+            }
+            if (gm.ncopy > 0 && a.nn_D == a.D) {
                 // zeros for the parameter blocks of the untransformed channels, as wide as the write-back
                 const int ncp_b = gm.ncopy * P * 4;            // bytes of untransformed parameter blocks per token
                 const int head_b = gm.d0 * P * 4, span_b2 = gm.DA * P * 4;
-                char* gtok0 = reinterpret_cast<char*>(gnn_tile + (size_t)tp * a.D * P);
+                char* gtok0 = reinterpret_cast<char*>(gnn_tile + (size_t)tp * a.nn_D * P);
                 auto zero_fill = [&](auto zero, int width) {
                     const int upt = ncp_b / width;             // units per token
                     const int nz = npt * upt;
@@ -703,9 +722,10 @@ static bool launch_mixture_tok_bwd_with(MixArgs& a, const float* g_zout, const f
     const size_t lds = (size_t)w.wrow_off + (size_t)kWavesPerBlock * PP * sizeof(float);
     if (lds > 65536) return false;
     const int span_b = gm.DA * P * 4;
-    const int first_b = gm.d0 * P * 4;
+    const int first_b = (gm.d0 - a.nn_c0) * P * 4;
     const bool base16 = (reinterpret_cast<uintptr_t>(g_nn) & 15) == 0;
     if (base16 && span_b % 16 == 0 && gm.tokstride % 16 == 0 && first_b % 16 == 0 && (gm.contig || gm.slot % 16 == 0)) w.wb_align = 16;
+    else if (base16 && gm.contig && span_b == gm.tokstride && g_tok_bwd_wb24.load(std::memory_order_relaxed) != 0) w.wb_align = 32;
     else if (base16 && !gm.contig && gm.ncopy > 0 && gm.tokstride % 16 == 0 && gm.slot % 16 == 0 && span_b % 8 == 0 && first_b % 8 == 0 &&
              g_tok_bwd_wb24.load(std::memory_order_relaxed) != 0) {
         w.wb_align = 24;

@@ -39,9 +39,10 @@ extern "C" {
 #define CNF_ERR_UNSUPPORTED 3  /* shape outside what the kernels are built for */
 
 #define CNF_FLAG_NAN_Z 1       /* a latent output is NaN          (flow_model.py:42) */
-#define CNF_FLAG_NAN_LDJ 2     /* a log-det output is NaN         (activation_normalization.py:46); the token-pass mixture kernels
-                                * sum a row's terms in 31.32 fixed point (order-independent bits): a row that met a NaN or infinite
-                                * term is marked, comes out NaN and raises this flag */
+#define CNF_FLAG_NAN_LDJ 2     /* a log-det output is NaN         (activation_normalization.py:46).  The token-pass mixture kernels
+                                * sum a row's terms in 31.32 fixed point (order-independent bits); terms that format cannot take
+                                * (|term| >= 2^14, +-inf, NaN) meet in an fp64 word beside it, so a row follows the reference's
+                                * floating-point sum: finite for large finite terms, +-inf for infinite ones, NaN (and this flag) for NaN */
 #define CNF_FLAG_RANGE 4       /* inverse-CDF input outside (0,1) (mixture_cdf_layer.py:238-239) */
 #define CNF_FLAG_CATEGORY 8    /* a category index outside [0, C)     (general/mutils.py:264, the one_hot assert) */
 
@@ -294,6 +295,53 @@ int cnf_mixture_coupling_actconv(const float* z, const float* nn_out,
                                  void* workspace, int64_t workspace_bytes,
                                  int* flags, cnf_stream_t stream);
 
+/* ---- compact parameter layout --------------------------------------------------------------------
+ * The reference's coupling sub-network emits parameter blocks for ALL D channels and get_mixt_params multiplies the blocks of
+ * the untransformed channels by the zero mask (mixture_cdf_layer.py:65-78, 163-171): with a channel mask half of nn_out is
+ * computed, written, fetched (whole 128-byte lines) and — in the backward — written again as zeros, for nothing.  The three
+ * entry points below take `nn_compact` = fp32 [B, N, n_act * (2 + 3K)]: the blocks of the transformed channels only, in
+ * channel order (what the sub-network's last Linear produces when only its rows d0 P .. (d0 + n_act) P are applied:
+ * layers.flows.MixtureCDFCoupling(compact_params=True) slices those rows at call time, parameters and checkpoints
+ * unchanged).  Everything else as cnf_mixture_coupling_ws / _nll / _actconv; results are identical to theirs on the expanded
+ * tensor (same kernels, same arithmetic: only the address of a token's span changes).  Needs a channel mask ([1,D]) with its
+ * host channel list (act_host, one contiguous range).  Served by the token-pass kernels only (math mode 1, or math mode 0 with
+ * inverse mode 1): a shape or mode they decline returns CNF_ERR_UNSUPPORTED with nothing launched — the caller expands
+ * nn_compact to the reference layout and calls the plain entry point. */
+int cnf_mixture_coupling_compact(const float* z, const float* nn_compact,
+                                 const float* scaling_factor, const float* mixture_scaling_factor,
+                                 const float* mask, int mask_rows, int mask_cols,
+                                 const int* act_host, int n_act,
+                                 const float* pad, int pad_in_transform, int pad_output,
+                                 const float* ldj_in, float* z_out, float* ldj_out, float* reg_out,
+                                 int B, int N, int D, int K, int reverse,
+                                 double reg_max, double reg_factor, int is_training,
+                                 void* workspace, int64_t workspace_bytes,
+                                 int* flags, cnf_stream_t stream);
+int cnf_mixture_coupling_compact_nll(const float* z, const float* nn_compact,
+                                     const float* scaling_factor, const float* mixture_scaling_factor,
+                                     const float* mask, int mask_rows, int mask_cols,
+                                     const int* act_host, int n_act,
+                                     const float* pad, int pad_in_transform, int pad_output,
+                                     const float* ldj_in, float* z_out, float* ldj_out, float* reg_out,
+                                     const float* length, float* neglog_out, float* nll_out, int64_t* nll_acc,
+                                     int B, int N, int D, int K,
+                                     double reg_max, double reg_factor, int is_training,
+                                     float sigma, float log_sigma,
+                                     void* workspace, int64_t workspace_bytes,
+                                     int* flags, cnf_stream_t stream);
+int cnf_mixture_coupling_compact_actconv(const float* z, const float* nn_compact,
+                                         const float* scaling_factor, const float* mixture_scaling_factor,
+                                         const float* mask, int mask_rows, int mask_cols,
+                                         const int* act_host, int n_act,
+                                         const float* pad,
+                                         const float* ldj_in, float* z_out, float* ldj_out, float* reg_out,
+                                         const float* an_bias, const float* an_scales, const float* conv_weight, const float* conv_sldj,
+                                         const float* length,
+                                         int B, int N, int D, int K,
+                                         double reg_max, double reg_factor, int is_training,
+                                         void* workspace, int64_t workspace_bytes,
+                                         int* flags, cnf_stream_t stream);
+
 /* Tuning / A-B knobs of the fp32 mixture kernels: which kernel serves math mode 1 (0 = token-pass kernel on
  * DMA-staged rows, default; 1 = the round-1 kernel); lanes per item for a run-time K (0 = automatic: K = 4 / 8 / 16
  * exactly, every other K <= 64 on predicated register slots, larger K on the rolled LDS loop; 1, 2, 4 = the rolled
@@ -371,8 +419,11 @@ int cnf_affine_coupling_nll(const float* z, const float* nn_out, const float* sc
  * atomic to one of 64 global words — integer adds are associative, so the sum is deterministic; the 64 words sit 128
  * bytes apart (one cache line each).  (One global atomic per ROW, rounds 1-2, kept every wave slot occupied until its
  * atomic was acknowledged: 18.3 -> 17.9 us per launch at B = 16384, N = 64, D = 6.)  `acc` =
- * CNF_NLL_ACC_WORDS int64 (only every 16th is used), zeroed by the caller; it may be accumulated over several calls
- * (|sum| < 2^31).  cnf_nll_acc_read turns n such words into sums = {sum / 2^32, count}. */
+ * CNF_NLL_ACC_WORDS int64, zeroed by the caller; it may be accumulated over several calls.  Word 16 k is the fixed-point sum
+ * of slot k; word 16 k + 1 is the slot's fp64 escape word: a per-sample value the fixed-point word cannot take safely
+ * (|nll| >= 4096, +-inf, NaN) is added there with a floating-point atomic, so the batch sum follows the reference's
+ * floating-point mean (task.py:96-118) instead of wrapping; with per-sample values below 4096 the integer words hold 3.3e7
+ * samples.  cnf_nll_acc_read turns n such words into sums = {sum of (fixed / 2^32 + escape), count}. */
 #define CNF_NLL_ACC_WORDS 1024
 int cnf_affine_coupling_nll_acc(const float* z, const float* nn_out, const float* scaling_factor,
                                 const float* mask, int mask_rows, int mask_cols,
@@ -588,6 +639,22 @@ int cnf_mixture_coupling_bwd_f32(const float* z, const float* nn_out,
                                  float* workspace,
                                  int B, int N, int D, int K, double reg_max, double reg_factor, int is_training,
                                  cnf_stream_t stream);
+
+/* The same on the compact parameter layout (cnf_mixture_coupling_compact): nn_compact and g_nn_compact are fp32
+ * [B, N, n_act * (2 + 3K)]; there are no untransformed blocks, so nothing is zero-filled — at a half channel mask the kernel
+ * reads and writes half of what cnf_mixture_coupling_bwd_f32 does.  d loss / d (last Linear) follows from g_nn_compact through
+ * the row slice (autograd: zero rows for the untransformed channels, as the zero blocks give the reference).  Math mode 1 and
+ * shapes of the token-pass backward only; otherwise CNF_ERR_UNSUPPORTED (expand, call cnf_mixture_coupling_bwd_f32, slice). */
+int cnf_mixture_coupling_compact_bwd_f32(const float* z, const float* nn_compact,
+                                         const float* scaling_factor, const float* mixture_scaling_factor,
+                                         const float* mask, int mask_rows, int mask_cols,
+                                         const int* act_host, int n_act,
+                                         const float* pad, int pad_in_transform, int pad_output,
+                                         const float* g_zout, const float* g_ldj,
+                                         float* g_z, float* g_nn_compact, float* g_scaling_factor, float* g_mixture_scaling_factor,
+                                         float* workspace,
+                                         int B, int N, int D, int K, double reg_max, double reg_factor, int is_training,
+                                         cnf_stream_t stream);
 
 /* d(MixtureCDFCoupling.run_with_params, reverse=False) on fp64 split parameters (static API, :95-123):
  * fp64 gradients for z and the five parameter tensors (zero where nothing is transformed). */
