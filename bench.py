@@ -485,7 +485,41 @@ def kernel_table(lib, ops, dev, budget_ms=6.0):
         row("mixture_coupling_bwd_f32 (+ fix-up and reduction launches)", S, e * (16 + 24 * K) + 8 * e,
             [call("cnf_mixture_coupling_bwd_f32", P(zs[r]), P(nns[r]), P(sf0), P(msf0), P(m), mr, mc, act, n_act, None, 0, 0, P(gzu), P(gl), P(g_z), P(g_nn),
                   P(g_sf), P(g_msf), P(wsb), B, N, D, K, -1.0, 1.0, 1, st) for r in range(R)])
-        del zs, nns, zf, g_nn
+        # ---- the same four on the compact parameter layout (cnf_mixture_coupling_compact*: nn_out = the transformed channels' blocks
+        # only, [B, N, DA * (2 + 3K)] — what the sub-network's last Linear emits with MixtureCDFCoupling(compact_params=True)).  `frac`
+        # prices the bytes these kernels really move (contiguous spans: a bandwidth); contract_frac prices SURVEY 8d's contract bytes
+        # of the reference layout over the same time, for comparison with the rows above (not a bandwidth).
+        del g_nn
+        DA = D - D // 2
+        nnc = [rn(B, N, DA * (2 + 3 * K), k=0.5) for _ in range(R)]
+        cfwd = [ops.mixture_coupling_launch(zs[r], nnc[r], mask, K, zf[r], lf) for r in range(R)]
+        assert all(c.name == "cnf_mixture_coupling_compact" for c in cfwd)
+        for c in cfwd:
+            c()
+        cinv = [ops.mixture_coupling_launch(zf[r], nnc[r], mask, K, zs[r], lf, reverse=True) for r in range(R)]
+
+        def contract(ms, nbytes):
+            rows[-1].update(layout="compact", contract_bytes=float(nbytes), contract_frac=nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
+        for mode, what in ((1, "fp32 (default)"), (0, "fp64 (the reference's precision)")):
+            lib.cnf_set_math_mode(mode)
+            contract(row("mixture_coupling forward, compact parameter layout, %s" % what, S, needed, cfwd, math_mode=mode), alg)
+            for c in cfwd:
+                c()
+            contract(row("mixture_coupling inverse (Newton), compact parameter layout, %s" % what, S, needed, cinv, math_mode=mode), alg)
+        lib.cnf_set_math_mode(1)
+        for c in cfwd:
+            c()
+        contract(row("mixture_coupling + ActNorm + 1x1 conv of the next step, compact parameter layout", S, needed,
+                     [call("cnf_mixture_coupling_compact_actconv", P(zs[r]), P(nnc[r]), None, None, P(m), mr, mc, act, n_act, None, None, P(zf[r]), P(lf),
+                           None, P(bias), P(scales), P(w), P(sldj), None, B, N, D, K, -1.0, 1.0, 1, P(wsm), int(wsm.numel()), flags, st)
+                      for r in range(R)]), alg)
+        g_nnc = torch.empty_like(nnc[0])
+        bwd_needed = B * N * (2 * DA * (2 + 3 * K) * 4 + 12 * D) + 4 * B          # rows in, gradient rows out, z + g_zout in, g_z out
+        contract(row("mixture_coupling_bwd_f32, compact parameter layout (+ fix-up and reduction launches)", S, bwd_needed,
+                     [call("cnf_mixture_coupling_compact_bwd_f32", P(zs[r]), P(nnc[r]), P(sf0), P(msf0), P(m), mr, mc, act, n_act, None, 0, 0, P(gzu),
+                           P(gl), P(g_z), P(g_nnc), P(g_sf), P(g_msf), P(wsb), B, N, D, K, -1.0, 1.0, 1, st) for r in range(R)]),
+                 e * (16 + 24 * K) + 8 * e)
+        del zs, nns, zf, nnc, g_nnc
     ops.check_flags(dev, "bench kernel table")
     return rows
 

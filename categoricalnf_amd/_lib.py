@@ -41,6 +41,12 @@ SIGNATURES = {
                                  _p, _p, _p, _p, _i, _i, _i, _i, _d, _d, _i, _f, _f, _p, _i64, _p, _p],
     "cnf_mixture_coupling_actconv": [_p, _p, _p, _p, _p, _i, _i, _p, _i, _p, _p, _p, _p, _p,
                                      _p, _p, _p, _p, _p, _i, _i, _i, _i, _d, _d, _i, _p, _i64, _p, _p],
+    "cnf_mixture_coupling_compact": [_p, _p, _p, _p, _p, _i, _i, _p, _i, _p, _i, _i, _p, _p, _p, _p,
+                                     _i, _i, _i, _i, _i, _d, _d, _i, _p, _i64, _p, _p],
+    "cnf_mixture_coupling_compact_nll": [_p, _p, _p, _p, _p, _i, _i, _p, _i, _p, _i, _i, _p, _p, _p, _p,
+                                         _p, _p, _p, _p, _i, _i, _i, _i, _d, _d, _i, _f, _f, _p, _i64, _p, _p],
+    "cnf_mixture_coupling_compact_actconv": [_p, _p, _p, _p, _p, _i, _i, _p, _i, _p, _p, _p, _p, _p,
+                                             _p, _p, _p, _p, _p, _i, _i, _i, _i, _d, _d, _i, _p, _i64, _p, _p],
     "cnf_mixture_params": [_p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "cnf_mixture_transform": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _i, _p, _p, _p, _p,
                               _i, _i, _i, _i, _i, _d, _d, _i, _p, _p],
@@ -76,6 +82,8 @@ SIGNATURES = {
                                  _i, _i, _i, _i, _d, _d, _i, _p],
     "cnf_mixture_coupling_bwd_f32": [_p, _p, _p, _p, _p, _i, _i, _p, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p,
                                      _i, _i, _i, _i, _d, _d, _i, _p],
+    "cnf_mixture_coupling_compact_bwd_f32": [_p, _p, _p, _p, _p, _i, _i, _p, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p,
+                                             _i, _i, _i, _i, _d, _d, _i, _p],
     "cnf_bwd_defer_flush": [_p],
     "cnf_encoder_forward_bwd_tiled": [_p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
     "cnf_encoder_forward_bwd_cpl": [_p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],

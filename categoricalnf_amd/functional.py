@@ -451,10 +451,21 @@ def _mixture_bwd(z, nn_out, sf, msf, mask, pad, g_zout, g_ldj, K, reg_max, reg_f
     g_msf = torch.empty(D, K, dtype=torch.float32, device=dev) if msf is not None else None
     ws = _ws(D + D * K, dev)
     act, n_act = ops._act_list(mask, m, mr, mc, D)
-    _launch(dev, "cnf_mixture_coupling_bwd_f32", _ptr(zc), _ptr(nn_c), _ptr(sfc), _ptr(msfc), _ptr(m), mr, mc, act, n_act,
-                                                _ptr(p2), int(pit), int(pout),
-                                                hold(g_zout), hold(g_ldj), _ptr(g_z), _ptr(g_nn), _ptr(g_sf), _ptr(g_msf), _ptr(ws),
-                                                B, N, D, K, reg_max, reg_factor, int(is_training), _stream(dev))
+    compact = ops.mixture_layout(nn_c, zc, K, act, n_act)
+    args = lambda nn_t, g_nn_t: (_ptr(zc), _ptr(nn_t), _ptr(sfc), _ptr(msfc), _ptr(m), mr, mc, act, n_act, _ptr(p2), int(pit), int(pout),
+                                 hold(g_zout), hold(g_ldj), _ptr(g_z), _ptr(g_nn_t), _ptr(g_sf), _ptr(g_msf), _ptr(ws),
+                                 B, N, D, K, reg_max, reg_factor, int(is_training), _stream(dev))
+    if compact:
+        # the compact layout (cnf_mixture_coupling_compact_bwd_f32): no zero blocks are written; a shape / mode its kernel declines
+        # goes through the reference layout and is sliced back
+        if _launch(dev, "cnf_mixture_coupling_compact_bwd_f32", *args(nn_c, g_nn), allow_unsupported=True) != _lib.CNF_OK:
+            full = ops.expand_compact(nn_c, zc.shape, K, act, n_act)
+            g_full = torch.empty_like(full)
+            _launch(dev, "cnf_mixture_coupling_bwd_f32", *args(full, g_full))
+            d0 = int(act[0])
+            g_nn = g_full.view(B, N, D, 2 + 3 * K)[:, :, d0:d0 + n_act].reshape(nn_c.shape)
+    else:
+        _launch(dev, "cnf_mixture_coupling_bwd_f32", *args(nn_c, g_nn))
     return (g_z, g_nn.view_as(nn_out), (g_sf.view_as(sf) if sf is not None else None),
             (g_msf.view_as(msf) if msf is not None else None))
 

@@ -431,6 +431,30 @@ def _mixture_workspace(dev, B):
     return w
 
 
+def mixture_layout(nn_out, z, K, act, n_act):
+    """Which layout `nn_out` has for latents z [B,N,D]: False = the reference's [B,N,D*P] (blocks for all channels), True = the
+    compact [B,N,n_act*P] (blocks of the transformed channels of a channel mask only: cnf_mixture_coupling_compact*)."""
+    P = 2 + 3 * int(K)
+    if nn_out.numel() == z.numel() * P:
+        return False
+    B, N, D = z.shape
+    if act is not None and 0 < n_act < D and nn_out.numel() == B * N * n_act * P:
+        return True
+    raise ValueError("nn_out must be [B,N,D*(2+3K)] (or, with a channel mask, the compact [B,N,n_act*(2+3K)]); got %s for z %s, K=%d"
+                     % (tuple(nn_out.shape), tuple(z.shape), K))
+
+
+def expand_compact(nn_compact, z_shape, K, act, n_act):
+    """The compact parameter tensor scattered into the reference layout (zero blocks for the untransformed channels): the route of
+    shapes / modes the compact-layout kernels decline (CNF_ERR_UNSUPPORTED)."""
+    B, N, D = z_shape
+    P = 2 + 3 * int(K)
+    full = torch.zeros(B, N, D, P, dtype=nn_compact.dtype, device=nn_compact.device)
+    d0 = int(act[0])
+    full[:, :, d0:d0 + n_act] = nn_compact.reshape(B, N, n_act, P)
+    return full.view(B, N, D * P)
+
+
 def mixture_coupling(z, nn_out, mask, num_mixtures, scaling_factor=None, mixture_scaling_factor=None,
                      reverse=False, channel_padding_mask=None, reg_max=-1, reg_factor=1, is_training=True,
                      pad_in_transform=True, pad_output=True, ldj=None, want_reg=True):
@@ -440,24 +464,27 @@ def mixture_coupling(z, nn_out, mask, num_mixtures, scaling_factor=None, mixture
     B, N, D = z.shape
     K = int(num_mixtures)
     nn_out = _f32(nn_out, "nn_out")
-    if nn_out.numel() != z.numel() * (2 + 3 * K):
-        raise ValueError("nn_out must be [B,N,D*(2+3K)]; got %s for z %s, K=%d" % (tuple(nn_out.shape), tuple(z.shape), K))
     sf = _opt_f32(scaling_factor, "scaling_factor", dev)
     msf = _opt_f32(mixture_scaling_factor, "mixture_scaling_factor", dev)
     m, mr, mc = _mask_desc(mask, D, dev)
     act, n_act = _act_list(mask, m, mr, mc, D)
+    compact = mixture_layout(nn_out, z, K, act, n_act)
     pad = _pad2d(channel_padding_mask, B, N, dev)
     ldj_in, ldj_out = _ldj_io(ldj, B, dev, inplace=False)
     z_out = torch.empty_like(z)
     use_reg = (not reverse) and reg_max > 0 and is_training
     reg = torch.zeros(B, dtype=torch.float32, device=dev) if want_reg else None
     ws = _mixture_workspace(dev, B)
-    _launch(dev, "cnf_mixture_coupling_ws", _ptr(z), _ptr(nn_out), _ptr(sf), _ptr(msf), _ptr(m), mr, mc,
-                                           act, n_act, _ptr(pad), int(bool(pad_in_transform)), int(bool(pad_output)),
-                                           _ptr(ldj_in), _ptr(z_out), _ptr(ldj_out), _ptr(reg if use_reg else None),
-                                           B, N, D, K, int(bool(reverse)), float(reg_max), float(reg_factor),
-                                           int(bool(is_training)), _ptr(ws), int(ws.numel()),
-                                           _ptr(flag_word(dev)), _stream(dev))
+    for name in (("cnf_mixture_coupling_compact", "cnf_mixture_coupling_ws") if compact else ("cnf_mixture_coupling_ws",)):
+        status = _launch(dev, name, _ptr(z), _ptr(nn_out), _ptr(sf), _ptr(msf), _ptr(m), mr, mc,
+                         act, n_act, _ptr(pad), int(bool(pad_in_transform)), int(bool(pad_output)),
+                         _ptr(ldj_in), _ptr(z_out), _ptr(ldj_out), _ptr(reg if use_reg else None),
+                         B, N, D, K, int(bool(reverse)), float(reg_max), float(reg_factor),
+                         int(bool(is_training)), _ptr(ws), int(ws.numel()),
+                         _ptr(flag_word(dev)), _stream(dev), allow_unsupported=compact and name.endswith("compact"))
+        if status == _lib.CNF_OK:
+            break
+        nn_out = expand_compact(nn_out, z.shape, K, act, n_act)       # declined: the reference layout through the plain entry point
     _after(dev, "mixture-CDF coupling")
     return z_out, ldj_out, reg
 
@@ -473,12 +500,11 @@ def mixture_coupling_nll(z, nn_out, mask, num_mixtures, scaling_factor=None, mix
     B, N, D = z.shape
     K = int(num_mixtures)
     nn_out = _f32(nn_out, "nn_out")
-    if nn_out.numel() != z.numel() * (2 + 3 * K):
-        raise ValueError("nn_out must be [B,N,D*(2+3K)]; got %s for z %s, K=%d" % (tuple(nn_out.shape), tuple(z.shape), K))
     sf = _opt_f32(scaling_factor, "scaling_factor", dev)
     msf = _opt_f32(mixture_scaling_factor, "mixture_scaling_factor", dev)
     m, mr, mc = _mask_desc(mask, D, dev)
     act, n_act = _act_list(mask, m, mr, mc, D)
+    compact = mixture_layout(nn_out, z, K, act, n_act)
     pad = _pad2d(channel_padding_mask, B, N, dev)
     ln = _length(length, B, dev)
     ldj_in, ldj_out = _ldj_io(ldj, B, dev, inplace=False)
@@ -490,13 +516,17 @@ def mixture_coupling_nll(z, nn_out, mask, num_mixtures, scaling_factor=None, mix
     if acc is not None and (acc.dtype != torch.int64 or acc.numel() < NLL_ACC_SLOTS or not acc.is_contiguous()):
         raise ValueError("acc must be a contiguous int64 tensor with at least %d elements" % NLL_ACC_SLOTS)
     ws = _mixture_workspace(dev, B)
-    _launch(dev, "cnf_mixture_coupling_nll", _ptr(z), _ptr(nn_out), _ptr(sf), _ptr(msf), _ptr(m), mr, mc,
-                                            act, n_act, _ptr(pad), int(bool(pad_in_transform)), int(bool(pad_output)),
-                                            _ptr(ldj_in), _ptr(z_out), _ptr(ldj_out), _ptr(reg if use_reg else None),
-                                            _ptr(ln), _ptr(neglog), _ptr(nll), _ptr(acc),
-                                            B, N, D, K, float(reg_max), float(reg_factor), int(bool(is_training)),
-                                            float(sigma), float(log_sigma), _ptr(ws), int(ws.numel()),
-                                            _ptr(flag_word(dev)), _stream(dev))
+    for name in (("cnf_mixture_coupling_compact_nll", "cnf_mixture_coupling_nll") if compact else ("cnf_mixture_coupling_nll",)):
+        status = _launch(dev, name, _ptr(z), _ptr(nn_out), _ptr(sf), _ptr(msf), _ptr(m), mr, mc,
+                         act, n_act, _ptr(pad), int(bool(pad_in_transform)), int(bool(pad_output)),
+                         _ptr(ldj_in), _ptr(z_out), _ptr(ldj_out), _ptr(reg if use_reg else None),
+                         _ptr(ln), _ptr(neglog), _ptr(nll), _ptr(acc),
+                         B, N, D, K, float(reg_max), float(reg_factor), int(bool(is_training)),
+                         float(sigma), float(log_sigma), _ptr(ws), int(ws.numel()),
+                         _ptr(flag_word(dev)), _stream(dev), allow_unsupported=compact and name.endswith("compact_nll"))
+        if status == _lib.CNF_OK:
+            break
+        nn_out = expand_compact(nn_out, z.shape, K, act, n_act)
     _after(dev, "mixture-CDF coupling + NLL")
     return z_out, ldj_out, reg, neglog, nll
 
@@ -511,12 +541,11 @@ def mixture_coupling_actconv(z, nn_out, mask, num_mixtures, an_bias, an_scales, 
     B, N, D = z.shape
     K = int(num_mixtures)
     nn_out = _f32(nn_out, "nn_out")
-    if nn_out.numel() != z.numel() * (2 + 3 * K):
-        raise ValueError("nn_out must be [B,N,D*(2+3K)]; got %s for z %s, K=%d" % (tuple(nn_out.shape), tuple(z.shape), K))
     sf = _opt_f32(scaling_factor, "scaling_factor", dev)
     msf = _opt_f32(mixture_scaling_factor, "mixture_scaling_factor", dev)
     m, mr, mc = _mask_desc(mask, D, dev)
     act, n_act = _act_list(mask, m, mr, mc, D)
+    compact = mixture_layout(nn_out, z, K, act, n_act)
     pad = _pad2d(channel_padding_mask, B, N, dev)
     ln = _length(length, B, dev) if isinstance(length, torch.Tensor) else None
     b, sc = _f32(an_bias.reshape(-1), "bias"), _f32(an_scales.reshape(-1), "scales")
@@ -526,11 +555,16 @@ def mixture_coupling_actconv(z, nn_out, mask, num_mixtures, an_bias, an_scales, 
     use_reg = reg_max > 0 and is_training
     reg = torch.zeros(B, dtype=torch.float32, device=dev) if want_reg else None
     ws = _mixture_workspace(dev, B)
-    _launch(dev, "cnf_mixture_coupling_actconv", _ptr(z), _ptr(nn_out), _ptr(sf), _ptr(msf), _ptr(m), mr, mc, act, n_act,
-                                                _ptr(pad), _ptr(ldj_in), _ptr(z_out), _ptr(ldj_out), _ptr(reg if use_reg else None),
-                                                _ptr(b), _ptr(sc), _ptr(w), _ptr(sl), _ptr(ln),
-                                                B, N, D, K, float(reg_max), float(reg_factor), int(bool(is_training)),
-                                                _ptr(ws), int(ws.numel()), _ptr(flag_word(dev)), _stream(dev))
+    for name in (("cnf_mixture_coupling_compact_actconv", "cnf_mixture_coupling_actconv") if compact else ("cnf_mixture_coupling_actconv",)):
+        status = _launch(dev, name, _ptr(z), _ptr(nn_out), _ptr(sf), _ptr(msf), _ptr(m), mr, mc, act, n_act,
+                         _ptr(pad), _ptr(ldj_in), _ptr(z_out), _ptr(ldj_out), _ptr(reg if use_reg else None),
+                         _ptr(b), _ptr(sc), _ptr(w), _ptr(sl), _ptr(ln),
+                         B, N, D, K, float(reg_max), float(reg_factor), int(bool(is_training)),
+                         _ptr(ws), int(ws.numel()), _ptr(flag_word(dev)), _stream(dev),
+                         allow_unsupported=compact and name.endswith("compact_actconv"))
+        if status == _lib.CNF_OK:
+            break
+        nn_out = expand_compact(nn_out, z.shape, K, act, n_act)
     _after(dev, "mixture-CDF coupling + ActNorm + InvertibleConv")
     return z_out, ldj_out, reg
 
@@ -932,8 +966,8 @@ def mixture_coupling_launch(z, nn_out, mask, num_mixtures, z_out, ldj_out, scali
     args = [_ptr(z), _ptr(nn_out), _ptr(sf), _ptr(msf), _ptr(m), mr, mc, act, n_act, _ptr(pad), 1, 1, None,
             _ptr(z_out), _ptr(ldj_out), None, B, N, D, int(num_mixtures), int(bool(reverse)), -1.0, 1.0, 0,
             _ptr(ws), int(ws.numel()), _ptr(flag_word(dev)), None]
-    return Launch("cnf_mixture_coupling_ws", lib.cnf_mixture_coupling_ws, args, dev,
-                  (z, nn_out, sf, msf, m, act, pad, z_out, ldj_out, ws))
+    name = "cnf_mixture_coupling_compact" if mixture_layout(nn_out, z, num_mixtures, act, n_act) else "cnf_mixture_coupling_ws"
+    return Launch(name, getattr(lib, name), args, dev, (z, nn_out, sf, msf, m, act, pad, z_out, ldj_out, ws))
 
 
 def mixture_coupling_nll_launch(z, nn_out, mask, num_mixtures, z_out, ldj_out, length, neglog, nll, acc=None,
@@ -954,5 +988,5 @@ def mixture_coupling_nll_launch(z, nn_out, mask, num_mixtures, z_out, ldj_out, l
             _ptr(z_out), _ptr(ldj_out), None, _ptr(ln), _ptr(neglog), _ptr(nll), _ptr(acc),
             B, N, D, int(num_mixtures), -1.0, 1.0, 0, float(sigma), float(log_sigma),
             _ptr(ws), int(ws.numel()), _ptr(flag_word(dev)), None]
-    return Launch("cnf_mixture_coupling_nll", lib.cnf_mixture_coupling_nll, args, dev,
-                  (z, nn_out, sf, msf, m, act, pad, ln, z_out, ldj_out, neglog, nll, acc, ws))
+    name = "cnf_mixture_coupling_compact_nll" if mixture_layout(nn_out, z, num_mixtures, act, n_act) else "cnf_mixture_coupling_nll"
+    return Launch(name, getattr(lib, name), args, dev, (z, nn_out, sf, msf, m, act, pad, ln, z_out, ldj_out, neglog, nll, acc, ws))
