@@ -225,10 +225,20 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
             n = tokl - rl * a.N;
         }
         const float pv = pad_tile ? padload(tokl) : 1.f;
+#if defined(CNF_MIXFWD_ABLATE) && CNF_MIXFWD_ABLATE >= 3
+        const float x = 0.f;            // A/B build: no loads of z either
+#else
         const float x = valid ? zload((size_t)tokl * a.D + d) : 0.f;
+#endif
         bool active = valid;
         if (a.per_item_mask) active = active && mask_at(a.mask, a.mr, a.mc, n, d) == 0.f;
         if (a.pad_in_transform && pv == 0.f) active = false;
+#ifdef CNF_MIXFWD_ABLATE
+        // A/B builds (tools/mixture_fwd_floor.py, profiles/r06_mixture_fwd_floor.txt): 1 = the data movement alone — rows staged,
+        // latents in and out, row sums — with the arithmetic compiled out: the floor of this kernel's access pattern and launch
+        // geometry; 2 = without the stores of z' as well; 3 = without the loads of z either (the DMA stream and the launch alone)
+        active = false;
+#endif
         float* my = reinterpret_cast<float*>(stg + (valid ? my_pos_in : 0));
         float of = a.pad_output ? x * pv : x;       // a lane that transforms nothing copies its element through
         float contrib = 0.f;
@@ -629,6 +639,9 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
         }
         // ---- outputs of the item lanes
         const bool owner = valid && sub == 0;       // one lane per element stores and accounts
+#if defined(CNF_MIXFWD_ABLATE) && CNF_MIXFWD_ABLATE >= 2
+        if (of == 12345.678f)
+#endif
         if (owner) {
             if (ED > 0) ep[tli * ED + d] = of;
             else zo_tile[(size_t)tokl * a.D + d] = of;
@@ -647,6 +660,9 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
             if (NLL) fix_pair_add(reinterpret_cast<unsigned long long*>(rowacc + rl * 2 + 1), rowbig + rl * 2 + 1, nlp, kRowTermMax);
         }
         // ---- the pass's channels that are not transformed: copied through (times the padding mask)
+#if defined(CNF_MIXFWD_ABLATE) && CNF_MIXFWD_ABLATE >= 2
+        if (of == 12345.678f)
+#endif
         if (gm.ncopy > 0) {
             const int ne = npt * gm.ncopy;
             for (int e = lane; e < ne; e += kWave) {

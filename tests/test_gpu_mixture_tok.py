@@ -354,9 +354,9 @@ def test_flow_model_uses_the_fused_kernels_and_matches_the_layer_by_layer_pass()
     o = ops()
     real = o._launch
 
-    def spy(dev, name, *a):
+    def spy(dev, name, *a, **kw):
         calls.append(name)
-        return real(dev, name, *a)
+        return real(dev, name, *a, **kw)
     o._launch = spy
     try:
         with torch.no_grad():
