@@ -353,13 +353,43 @@ __device__ __forceinline__ void mixture_tok_bwd_body(const MixArgs& a, const Tok
                 n = tokl - rl * a.N;
             }
             const float pv = pad_tile ? pad_tile[tokl] : 1.f;
+#if defined(CNF_MIXBWD_ABLATE) && CNF_MIXBWD_ABLATE + 0 >= 4
+            const float x = 0.f;             // A/B build: none of the small loads either (the DMA stream alone)
+#else
             const float x = valid ? z_tile[(size_t)tokl * a.D + d] : 0.f;
+#endif
             const float outscale = a.pad_output ? pv : 1.f;
+#if defined(CNF_MIXBWD_ABLATE) && CNF_MIXBWD_ABLATE + 0 >= 4
+            const float gzo = outscale, gl = 0.f;
+#else
             const float gzo = (valid && gzo_tile) ? gzo_tile[(size_t)tokl * a.D + d] * outscale : 0.f;
             const float gl = (valid && w.g_ldj) ? w.g_ldj[row0 + rl] : 0.f;
+#endif
             bool active = valid;
             if (a.per_item_mask) active = active && mask_at(a.mask, a.mr, a.mc, n, d) == 0.f;
             if (a.pad_in_transform && pv == 0.f) active = false;
+            // the upstream gradients of the channels that are copied through (this lane's element `lane` of the pass's
+            // npt * ncopy), loaded HERE with the pass's other inputs: loaded where they are stored — behind the write-back — their
+            // wait drained the write-back's stores as well (one more serial round trip per pass, under the write stream's
+            // back-pressure: profiles/r06_mixture_bwd_floor.txt)
+            constexpr int CTB = 1;
+            float ctg[CTB];
+#pragma unroll
+            for (int i = 0; i < CTB; ++i) {
+                ctg[i] = 0.f;
+                const int e = lane + i * kWave;
+#if defined(CNF_MIXBWD_ABLATE) && CNF_MIXBWD_ABLATE + 0 >= 4
+                if (false)
+#endif
+                if (gm.ncopy > 0 && gzo_tile && e < npt * gm.ncopy) {
+                    const int tk = (int)fdiv((uint32_t)e, gm.div_nc);
+                    const int jj = e - tk * gm.ncopy;
+                    const int c = jj < gm.d0 ? jj : jj + gm.DA;
+                    const int tl2 = tp + tk;
+                    const float pv2 = (pad_tile && a.pad_output) ? pad_tile[tl2] : 1.f;
+                    ctg[i] = gzo_tile[(size_t)tl2 * a.D + c] * pv2;
+                }
+            }
 
             const char* pass_addr = span0 + (size_t)tp * gm.tokstride;
             int my_pos = pf ? pos_cur : stage_pass(gm, stage_b, pass_addr, nn_last, npt, lane, tli, j, P);
@@ -511,6 +541,9 @@ __device__ __forceinline__ void mixture_tok_bwd_body(const MixArgs& a, const Tok
                 // padded token / masked item: its parameters get no gradient
                 for (int i = sub; i < P; i += G) my[i] = 0.f;
             }
+#if defined(CNF_MIXBWD_ABLATE) && CNF_MIXBWD_ABLATE + 0 >= 3
+            if (g_x == 12345.678f)           // A/B build: no stores of g_z either
+#endif
             if (valid && sub == 0) gz_tile[(size_t)tokl * a.D + d] = g_x;
             if (pf) {
                 // LDS ordering only (the lanes' gradient rows are read back by other lanes): the fence of wave_lds_sync() would also
@@ -522,6 +555,9 @@ __device__ __forceinline__ void mixture_tok_bwd_body(const MixArgs& a, const Tok
             }
 
             // ---- the staged gradient rows go back to g_nn: the transformed spans of the pass's tokens
+#if defined(CNF_MIXBWD_ABLATE) && CNF_MIXBWD_ABLATE + 0 >= 2
+            if (g_x == 12345.678f)           // A/B build: no write-back of g_nn either
+#endif
             {
                 const int span_b = gm.DA * P * 4;
                 const int total_b = npt * span_b;
@@ -586,15 +622,24 @@ __device__ __forceinline__ void mixture_tok_bwd_body(const MixArgs& a, const Tok
             }
             // ---- channels that are not transformed: their latents pass the gradient through, their parameter blocks get zeros
             // (the compact layout has no such blocks)
+#if defined(CNF_MIXBWD_ABLATE) && CNF_MIXBWD_ABLATE + 0 >= 3
+            if (g_x == 12345.678f)
+#endif
             if (gm.ncopy > 0) {
                 const int ne = npt * gm.ncopy;
-                for (int e = lane; e < ne; e += kWave) {
+                int it = 0;
+                for (int e = lane; e < ne; e += kWave, ++it) {
                     const int tk = (int)fdiv((uint32_t)e, gm.div_nc);
                     const int jj = e - tk * gm.ncopy;
                     const int c = jj < gm.d0 ? jj : jj + gm.DA;
                     const int tl2 = tp + tk;
-                    const float pv2 = (pad_tile && a.pad_output) ? pad_tile[tl2] : 1.f;
-                    gz_tile[(size_t)tl2 * a.D + c] = gzo_tile ? gzo_tile[(size_t)tl2 * a.D + c] * pv2 : 0.f;
+                    float v;
+                    if (it < CTB) v = ctg[it < CTB ? it : 0];
+                    else {
+                        const float pv2 = (pad_tile && a.pad_output) ? pad_tile[tl2] : 1.f;
+                        v = gzo_tile ? gzo_tile[(size_t)tl2 * a.D + c] * pv2 : 0.f;
+                    }
+                    gz_tile[(size_t)tl2 * a.D + c] = v;
                 }
             }
             if (gm.ncopy > 0 && a.nn_D == a.D) {
@@ -701,6 +746,30 @@ static bool launch_mixture_tok_bwd_with(MixArgs& a, const float* g_zout, const f
     probe.ws_acc = reinterpret_cast<long long*>(8);      // rows may be split freely: the backward has no per-row sums
     probe.ws_cnt = reinterpret_cast<int*>(8);
     if (!make_tok_geom(probe, kt, force_g, gm, G, lds_fwd)) return false;
+#ifndef CNF_MIXBWD_ROWS
+#define CNF_MIXBWD_ROWS 1
+#endif
+    if (CNF_MIXBWD_ROWS && !gm.split) {
+        // Rows per wave tile.  The forward's choice (~128 items per wave: one 64-token row at S*) leaves a last pass of ONE token
+        // behind three of 21 — a full DMA round trip for 312 bytes, a quarter of all passes.  The backward has no per-row sums,
+        // so its tiles can be any number of whole rows: the count with the fewest wasted pass slots that still leaves one unit
+        // for every wave of the persistent grid (S*: 4 rows = 256 tokens = 13 passes, 94 % full, 4096 units).
+        const long want_units = (long)kTokBwdGrid * kWavesPerBlock;
+        int best_r = gm.rw;
+        double best = (double)(gm.rw * a.N) / (double)((((long)gm.rw * a.N + gm.TPP - 1) / gm.TPP) * gm.TPP);
+        const int rcap = (int)std::min<long>(std::min<long>(a.B, 65535 / std::max(a.N, 1)), 64);
+        for (int r = 1; r <= rcap; ++r) {
+            if (((long)a.B + r - 1) / r < want_units && r > gm.rw) break;
+            const long tk = (long)r * a.N;
+            const double eff = (double)tk / (double)(((tk + gm.TPP - 1) / gm.TPP) * gm.TPP);
+            if (eff > best + 1e-9) {
+                best = eff;
+                best_r = r;
+            }
+        }
+        gm.rw = best_r;
+        gm.ntiles = ((long)a.B + best_r - 1) / best_r;
+    }
     const int K = a.K, P = a.P, PP = a.D + a.D * K;
     TokBwdArgs w = {};
     w.g_zout = g_zout; w.g_ldj = g_ldj; w.g_z = g_z; w.g_nn = g_nn; w.partials = workspace;
@@ -754,7 +823,9 @@ static bool launch_mixture_tok_bwd_with(MixArgs& a, const float* g_zout, const f
     // (modes 1 and 5-7: the builds held to 4 waves per SIMD — K = 8 unrolled: 160 -> 128 VGPRs, 34 of them spilled; no difference for
     // the rolled kernels, which fit anyway)
     const int w4_knob = tok_bwd_w4();
-    const bool w4 = w4_knob == 1 || w4_knob >= 5;
+    // (round 6: with the copied-through gradients prefetched the rolled kernels with 2 / 4 lanes per item need 136 VGPRs as compiled
+    // freely — three waves per SIMD; their builds held to 128, 5 registers spilled, keep the fourth wave and are the default)
+    const bool w4 = w4_knob == 1 || w4_knob >= 5 || (w4_knob < 0 && kt == 0 && G > 1);
 #define TOK_BWD(KT_, G_)                                                                        \
     do {                                                                                        \
         if (w4) CNF_LAUNCH((mixture_tok_bwd_kernel_w4<KT_, G_>), g, b, lds, st, a, gm, w);      \
@@ -800,7 +871,11 @@ bool launch_mixture_tok_bwd(MixArgs& a, const float* g_zout, const float* g_ldj,
         // (round 5, profiles/r05_mixture_bwd_floor.txt: at S* with K = 8 two lanes per item beat one — 320-334 against 347-371 us on two
         // boxes: passes of 10 tokens instead of 21 move the same bytes faster, and the kernel is 90 % data movement; at K = 4 one lane
         // per item stays ahead, 207 against 229 us, profiles/r04_mixture_bwd_variants.txt)
-        int g = items >= 2000000L ? (a.K >= 8 ? 2 : 1) : (items >= 400000L ? 2 : 4);
+        // (round 6, profiles/r06_mixture_bwd_floor.txt, with the copied-through gradients loaded ahead of the write-back: one lane per
+        // item from ~400 k transformed elements on — configs[1] 60.5 against 63 us — except the reference layout at S* size with 8
+        // or more mixtures, 316-320 us with two lanes against 338-345; the compact layout takes one lane there: 231-235 against 250)
+        const bool compact = a.nn_D != a.D;
+        int g = items >= 2000000L ? ((a.K >= 8 && !compact) ? 2 : 1) : (items >= 400000L ? 1 : 4);
         if (a.K > 32) g = 4;
         while (g > 1 && g > a.K) g >>= 1;
         // the rule's G, or the next one whose stage fits LDS

@@ -15,7 +15,7 @@ typedef __attribute__((address_space(1))) const void glb_void_t;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
 
 template <int MODE, int INSTR, int NT>
-__global__ __launch_bounds__(256) void reader(const char* buf, long bytes, int passes, float* out, int pad_lds) {
+__global__ __launch_bounds__(256) void reader(const char* buf, long bytes, int passes, float* out, int pad_lds, char* dst = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long chunk = (long)passes * INSTR * 1024;
@@ -40,6 +40,27 @@ __global__ __launch_bounds__(256) void reader(const char* buf, long bytes, int p
             }
 #pragma unroll
             for (int i = 0; i < INSTR; ++i) acc += v[i].x + v[i].w;
+        } else if (MODE == 3) {
+            // write-only: INSTR float4 stores per lane and pass
+#pragma unroll
+            for (int i = 0; i < INSTR; ++i) {
+                f4* d = reinterpret_cast<f4*>(dst + off + i * 1024 + lane * 16);
+                const f4 v = {acc, 1.f, 2.f, (float)p};
+                if (NT) __builtin_nontemporal_store(v, d); else *d = v;
+            }
+        } else if (MODE == 4) {
+            // copy: DMA into the stage, wait, LDS -> registers -> float4 stores (the backward's write-back), next pass
+            dma(stage, off);
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < INSTR; ++i) {
+                const f4 v = *reinterpret_cast<const f4*>(stage + i * 1024 + lane * 16);
+                f4* d = reinterpret_cast<f4*>(dst + off + i * 1024 + lane * 16);
+                if (NT) __builtin_nontemporal_store(v, d); else *d = v;
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_wave_barrier();
         } else if (MODE == 1) {
             dma(stage, off);
             __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -61,17 +82,17 @@ __global__ __launch_bounds__(256) void reader(const char* buf, long bytes, int p
 }
 
 template <int MODE, int INSTR, int NT>
-static void run(const char* bufs[3], long bytes, int passes, float* out, int extra_lds, const char* what) {
+static void run(const char* bufs[3], long bytes, int passes, float* out, int extra_lds, const char* what, char* dsts[3] = nullptr) {
     const long chunk = (long)passes * INSTR * 1024;
     const unsigned grid = (unsigned)((bytes / chunk + 3) / 4);
-    const size_t lds = (MODE == 0 ? 0 : (size_t)4 * (MODE == 2 ? 2 : 1) * INSTR * 1024) + extra_lds;
+    const size_t lds = ((MODE == 0 || MODE == 3) ? 0 : (size_t)4 * (MODE == 2 ? 2 : 1) * INSTR * 1024) + extra_lds;
     hipEvent_t a, b;
     CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-    for (int r = 0; r < 3; ++r) hipLaunchKernelGGL((reader<MODE, INSTR, NT>), dim3(grid), dim3(256), lds, 0, bufs[r], bytes, passes, out, 0);
+    for (int r = 0; r < 3; ++r) hipLaunchKernelGGL((reader<MODE, INSTR, NT>), dim3(grid), dim3(256), lds, 0, bufs[r], bytes, passes, out, 0, dsts ? dsts[r] : nullptr);
     CK(hipDeviceSynchronize());
     const int reps = 9;
     CK(hipEventRecord(a));
-    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((reader<MODE, INSTR, NT>), dim3(grid), dim3(256), lds, 0, bufs[r % 3], bytes, passes, out, 0);
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((reader<MODE, INSTR, NT>), dim3(grid), dim3(256), lds, 0, bufs[r % 3], bytes, passes, out, 0, dsts ? dsts[r % 3] : nullptr);
     CK(hipEventRecord(b));
     CK(hipEventSynchronize(b));
     float ms;
@@ -87,6 +108,15 @@ int main() {
     float* out;
     for (int r = 0; r < 3; ++r) { char* p; CK(hipMalloc(&p, bytes + 65536)); CK(hipMemset(p, 0, bytes + 65536)); bufs[r] = p; }
     CK(hipMalloc(&out, 64));
+    if (getenv("DMA_PROFILE")) {
+        // the three reference streams only (counter runs: tools/pmc_stream_ref.sh)
+        char* d3[3];
+        for (int r = 0; r < 3; ++r) { CK(hipMalloc(&d3[r], bytes + 65536)); CK(hipMemset(d3[r], 0, bytes + 65536)); }
+        run<1, 7, 1>(bufs, bytes, 16, out, 0, "LDS DMA, nt");
+        run<3, 7, 0>(bufs, bytes, 16, out, 0, "write only", d3);
+        run<4, 7, 1>(bufs, bytes, 16, out, 0, "copy, nt loads and stores", d3);
+        return 0;
+    }
     for (int passes : {1, 3, 4, 16}) {
         run<0, 7, 0>(bufs, bytes, passes, out, 0, "VGPR loads");
         run<0, 7, 1>(bufs, bytes, passes, out, 0, "VGPR loads, nt");
@@ -94,6 +124,15 @@ int main() {
         run<1, 7, 1>(bufs, bytes, passes, out, 0, "LDS DMA, nt");
         run<1, 7, 1>(bufs, bytes, passes, out, 4096, "LDS DMA, nt, 32 KiB LDS");
         run<2, 7, 1>(bufs, bytes, passes, out, 0, "LDS DMA, nt, 2 stages");
+    }
+    char* dsts[3];
+    for (int r = 0; r < 3; ++r) { CK(hipMalloc(&dsts[r], bytes + 65536)); CK(hipMemset(dsts[r], 0, bytes + 65536)); }
+    for (int passes : {1, 4, 16}) {
+        run<3, 7, 0>(bufs, bytes, passes, out, 0, "write only", dsts);
+        run<3, 7, 1>(bufs, bytes, passes, out, 0, "write only, nt", dsts);
+        run<4, 7, 0>(bufs, bytes, passes, out, 0, "copy (DMA, LDS, stores)", dsts);
+        run<4, 7, 1>(bufs, bytes, passes, out, 0, "copy, nt loads and stores", dsts);
+        run<4, 3, 1>(bufs, bytes, passes * 2, out, 0, "copy, nt loads and stores", dsts);
     }
     for (int passes : {2, 8}) {
         run<0, 14, 1>(bufs, bytes, passes, out, 0, "VGPR loads, nt");

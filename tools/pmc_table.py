@@ -9,7 +9,7 @@ meta = {}
 for path in glob.glob(os.path.join(d, "pass*", "**", "*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(path)):
         k = row["Kernel_Name"]
-        if "cnf::" not in k and "copyBuffer" not in k:
+        if "cnf::" not in k and "copyBuffer" not in k and "reader<" not in k:
             continue
         vals[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
         meta[k] = (row.get("VGPR_Count") or row.get("Arch_VGPR_Count"), row.get("SGPR_Count"), row.get("LDS_Block_Size"),
