@@ -100,7 +100,7 @@ SIGNATURES = {
 _PLAIN = {"cnf_abi_version": ([], _i), "cnf_last_error": ([], ctypes.c_char_p),
           "cnf_set_tile_chunks": ([_i], None), "cnf_set_unroll": ([_i], None),
           "cnf_set_math_mode": ([_i], None), "cnf_set_inverse_mode": ([_i], None), "cnf_set_mixture_tile": ([_i], None),
-          "cnf_set_bwd_tile": ([_i, _i], None), "cnf_set_actnorm_bwd_tiles": ([_i], None), "cnf_set_linear_tiles": ([_i], None), "cnf_set_affine_bwd_tiles": ([_i], None), "cnf_set_mixture_bwd_waves": ([_i], None), "cnf_set_mixture_bwd_prefetch": ([_i], None),
+          "cnf_set_bwd_tile": ([_i, _i], None), "cnf_set_actnorm_bwd_tiles": ([_i], None), "cnf_set_affine_bwd_tiles": ([_i], None), "cnf_set_mixture_bwd_waves": ([_i], None),
           "cnf_bwd_workspace_floats": ([_i], _i64), "cnf_bwd_defer_begin": ([], None),
           "cnf_mixture_workspace_bytes": ([_i], _i64), "cnf_encoder_workspace_floats": ([_i, _i, _i, _i], _i64),
           "cnf_encoder_bwd_tiled_workspace_floats": ([_i, _i, _i, _i], _i64), "cnf_set_mixture_kernel": ([_i], None), "cnf_set_encoder_kernel": ([_i], None), "cnf_set_encoder_bwd_kernel": ([_i], None), "cnf_encoder_pair_launches": ([], _i64),
@@ -148,7 +148,7 @@ def load():
 
 
 def exported_symbols():
-    """Names declared in include/cnf_hip.h (used by the CPU-side ABI test)."""
+    """Names declared in include/cnf_hip.h and include/cnf_tuning.h (used by the CPU-side ABI test)."""
     return sorted(list(SIGNATURES) + list(_PLAIN))
 
 

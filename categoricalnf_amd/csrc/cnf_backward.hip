@@ -110,14 +110,15 @@ __global__ __launch_bounds__(kReduceBlock) void bwd_reduce_jobs_kernel(ReduceJob
 }
 struct DeferState {
     bool on = false;
+    hipStream_t stream = nullptr;       // the stream the queued jobs' kernels were launched on: their reduction goes there and nowhere else
     ReduceJobs jobs;
 };
 static thread_local DeferState g_defer;
-static void flush_reduce_jobs(hipStream_t st) {
+static void flush_reduce_jobs() {
     ReduceJobs& q = g_defer.jobs;
     if (q.n > 0) {
         const int total = q.j[q.n - 1].col0 + q.j[q.n - 1].cols;
-        CNF_LAUNCH(bwd_reduce_jobs_kernel, dim3(total), dim3(kReduceBlock), 0, st, q);
+        CNF_LAUNCH(bwd_reduce_jobs_kernel, dim3(total), dim3(kReduceBlock), 0, g_defer.stream, q);
         q.n = 0;
     }
 }
@@ -129,7 +130,9 @@ static void enqueue_reduce(int cols, const float* partials, int nrows, int P, fl
         return;
     }
     ReduceJobs& q = g_defer.jobs;
-    if (q.n == kMaxReduceJobs) flush_reduce_jobs(st);
+    // a full table, or a call on ANOTHER stream than the queued ones: what is queued is reduced first, on its own stream
+    if (q.n == kMaxReduceJobs || (q.n > 0 && st != g_defer.stream)) flush_reduce_jobs();
+    g_defer.stream = st;
     ReduceJob& jb = q.j[q.n];
     jb.partials = partials; jb.out_a = out_a; jb.out_b = out_b;
     jb.nrows = nrows; jb.split = split; jb.extra = extra; jb.extra_from = extra_from;
@@ -1837,12 +1840,20 @@ extern "C" {
  * kBwdMaxRowP wide), one per workgroup (at most 1024, twice for the mixture kernel and its fix-up launch) for the
  * mixture / encoder kernels — + one reduced row + the fix-up launch's flag words */
 void cnf_bwd_defer_begin(void) {
+    // jobs left over from a batch that was never flushed (a host that failed between begin and flush) are reduced now rather
+    // than dropped: their outputs would stay uninitialised
+    flush_reduce_jobs();
     g_defer.on = true;
-    g_defer.jobs.n = 0;
 }
 int cnf_bwd_defer_flush(cnf_stream_t stream) {
-    flush_reduce_jobs((hipStream_t)stream);
+    // the queued reductions run on the stream their kernels ran on (`stream` is checked against it, not trusted over it)
+    const bool mismatch = g_defer.jobs.n > 0 && (hipStream_t)stream != g_defer.stream;
+    flush_reduce_jobs();
     g_defer.on = false;
+    if (mismatch) {
+        set_error("cnf_bwd_defer_flush: the queued calls ran on another stream than the one given; their reductions were launched on their own stream");
+        return CNF_ERR_ARG;
+    }
     return launch_status("cnf_bwd_defer_flush");
 }
 

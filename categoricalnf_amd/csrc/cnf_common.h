@@ -8,6 +8,7 @@
 #include <stdarg.h>
 
 #include "../../include/cnf_hip.h"
+#include "../../include/cnf_tuning.h"
 
 namespace cnf {
 

@@ -136,63 +136,6 @@ struct ConvArgs {
     long ntok;
 };
 
-// permutation_layers.py:106-136.  One lane per token, the D-vector in registers, W broadcast
-// through scalar loads (uniform addresses).  The dot product runs i = 0..D-1 in order.
-template <int D>
-__global__ __launch_bounds__(kBlock) void invconv_kernel(ConvArgs a) {
-    bool bad = false;
-    for (long t = (long)blockIdx.x * kBlock + threadIdx.x; t < a.ntok; t += (long)gridDim.x * kBlock) {
-        float xv[D], ov[D];
-        const float* src = a.x + t * D;
-        if (D % 4 == 0) {
-#pragma unroll
-            for (int i = 0; i < D; i += 4) {
-                const float4 q = *reinterpret_cast<const float4*>(src + i);
-                xv[i] = q.x; xv[i + 1] = q.y; xv[i + 2] = q.z; xv[i + 3] = q.w;
-            }
-        } else if (D % 2 == 0) {
-#pragma unroll
-            for (int i = 0; i < D; i += 2) {
-                const float2 q = *reinterpret_cast<const float2*>(src + i);
-                xv[i] = q.x; xv[i + 1] = q.y;
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < D; ++i) xv[i] = src[i];
-        }
-        const float p = a.pad ? a.pad[t] : 1.f;
-#pragma unroll
-        for (int j = 0; j < D; ++j) {
-            float acc = 0.f;
-#pragma unroll
-            for (int i = 0; i < D; ++i) acc = fmaf(xv[i], a.w[i * D + j], acc);
-            if (a.pad) acc = acc * p;
-            bad |= isnan(acc);
-            ov[j] = acc;
-        }
-        float* dst = a.z_out + t * D;
-        if (D % 4 == 0) {
-#pragma unroll
-            for (int i = 0; i < D; i += 4) *reinterpret_cast<float4*>(dst + i) = make_float4(ov[i], ov[i + 1], ov[i + 2], ov[i + 3]);
-        } else if (D % 2 == 0) {
-#pragma unroll
-            for (int i = 0; i < D; i += 2) *reinterpret_cast<float2*>(dst + i) = make_float2(ov[i], ov[i + 1]);
-        } else {
-#pragma unroll
-            for (int i = 0; i < D; ++i) dst[i] = ov[i];
-        }
-    }
-    if (bad) raise_flag(a.flags, CNF_FLAG_NAN_Z);
-    const float sl = a.sldj[0];
-    for (long b = (long)blockIdx.x * kBlock + threadIdx.x; b < a.B; b += (long)gridDim.x * kBlock) {
-        const float s = sl * (a.length ? a.length[b] : (float)a.N);
-        const float base = a.ldj_in ? a.ldj_in[b] : 0.f;
-        const float v = a.reverse ? base - s : base + s;
-        a.ldj_out[b] = v;
-        if (isnan(v)) raise_flag(a.flags, CNF_FLAG_NAN_LDJ);
-    }
-}
-
 // ActNorm followed by the 1x1 convolution (the first two layers of every flow step of the reference's models),
 // one pass instead of two: forward  z' = (((z + b) e^{sc}) pad) @ W pad ; reverse  z' = (((z @ W^-1) pad) e^{-sc} - b) pad.
 // The arithmetic is the two kernels' arithmetic in the same order, so results are identical to running them
@@ -473,7 +416,6 @@ static inline int stream_grid(long n) {
 using namespace cnf;
 
 // 1 (default): cnf_actnorm / cnf_invconv take the fused pair's token-owner kernel for D in {1..6, 8}; 0 = their own older kernels (A/B, tests)
-static std::atomic<int> g_standalone_tiles{1};
 
 // launches actnorm_invconv_kernel<D, ACT, CONV> for D in {1..6, 8}; false = another D (the callers keep their generic kernels)
 template <bool ACT, bool CONV>
@@ -498,8 +440,6 @@ static bool launch_act_conv(const ActConvArgs& a, hipStream_t st) {
 
 extern "C" {
 
-void cnf_set_linear_tiles(int on) { g_standalone_tiles.store(on ? 1 : 0, std::memory_order_relaxed); }
-
 
 int cnf_actnorm(const float* z, const float* bias, const float* scales,
                 const float* pad, const float* length,
@@ -510,7 +450,7 @@ int cnf_actnorm(const float* z, const float* bias, const float* scales,
     if (B == 0) return CNF_OK;
     {   // D in {1..6, 8}: the token-owner kernel of the fused pair with the convolution compiled out
         ActConvArgs f{z, bias, scales, nullptr, nullptr, pad, length, ldj_in, z_out, ldj_out, flags, B, N, D, reverse, (long)B * N};
-        if (g_standalone_tiles.load(std::memory_order_relaxed) && launch_act_conv<true, false>(f, (hipStream_t)stream)) return launch_status("cnf_actnorm");
+        if (launch_act_conv<true, false>(f, (hipStream_t)stream)) return launch_status("cnf_actnorm");
     }
     ActNormArgs a{z, bias, scales, pad, length, ldj_in, z_out, ldj_out, flags, B, N, D, reverse, (long)B * N * D};
     const long work = std::max<long>(a.total / 4, B);
@@ -543,21 +483,11 @@ int cnf_invconv(const float* x, const float* weight, const float* sldj,
     hipStream_t st = (hipStream_t)stream;
     {   // D in {1..6, 8}: the token-owner kernel of the fused pair with ActNorm compiled out
         ActConvArgs f{x, nullptr, nullptr, weight, sldj, pad, length, ldj_in, z_out, ldj_out, flags, B, N, D, reverse, (long)B * N};
-        if (g_standalone_tiles.load(std::memory_order_relaxed) && launch_act_conv<false, true>(f, st)) return launch_status("cnf_invconv");
+        if (launch_act_conv<false, true>(f, st)) return launch_status("cnf_invconv");
     }
     ConvArgs a{x, weight, sldj, pad, length, ldj_in, z_out, ldj_out, flags, B, N, D, reverse, (long)B * N};
-    const dim3 grid(stream_grid(std::max<long>(a.ntok, B))), block(kBlock);
-    switch (D) {
-        case 1: CNF_LAUNCH((invconv_kernel<1>), grid, block, 0, st, a); break;
-        case 2: CNF_LAUNCH((invconv_kernel<2>), grid, block, 0, st, a); break;
-        case 3: CNF_LAUNCH((invconv_kernel<3>), grid, block, 0, st, a); break;
-        case 4: CNF_LAUNCH((invconv_kernel<4>), grid, block, 0, st, a); break;
-        case 5: CNF_LAUNCH((invconv_kernel<5>), grid, block, 0, st, a); break;
-        case 6: CNF_LAUNCH((invconv_kernel<6>), grid, block, 0, st, a); break;
-        case 8: CNF_LAUNCH((invconv_kernel<8>), grid, block, 0, st, a); break;
-        default:
-            CNF_LAUNCH(invconv_generic_kernel, dim3(stream_grid(a.ntok * D)), block, 0, st, a);
-    }
+    // every other D: the generic kernel (one lane per output element)
+    CNF_LAUNCH(invconv_generic_kernel, dim3(stream_grid(a.ntok * D)), dim3(kBlock), 0, st, a);
     return launch_status("cnf_invconv");
 }
 

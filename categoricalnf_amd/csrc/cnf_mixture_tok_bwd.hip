@@ -25,8 +25,7 @@
 namespace cnf {
 
 constexpr int kTokBwdGrid = 1024;       // rows of the partials buffer (cnf_bwd_workspace_floats)
-static std::atomic<int> g_tok_bwd_w4{-1}, g_tok_bwd_pf{-1};
-static std::atomic<int> g_tok_bwd_wb24{1};        // A/B switch of the 16-byte-grid write-back (cnf_set_mixture_bwd_prefetch(2 / 3): off / on)
+static std::atomic<int> g_tok_bwd_w4{-1};
 static inline int tok_bwd_w4() { return g_tok_bwd_w4.load(std::memory_order_relaxed); }
 
 struct TokBwdArgs {
@@ -43,7 +42,6 @@ struct TokBwdArgs {
     int nacc;                 // run-time K: lane-private accumulator slots = 1 + ceil(K / G)
     int lacc_off;             // byte offset of the lane-private accumulators / the reduction scratch in dynamic LDS
     int wrow_off;             // byte offset of the per-wave parameter-gradient rows [4][PP]
-    int nbuf;                 // stages per wave: 2 = the next pass's rows are DMA-staged while this pass computes (run-time K kernels)
     float* fix_partials;      // [gridDim.x, D + D*K] rows of the fix-up launch (read for flagged workgroups only)
     int* wave_flags;          // [gridDim.x * 4] 1 = the wave met a tail element
     int* block_flags;         // [gridDim.x]
@@ -282,10 +280,10 @@ __device__ __forceinline__ void mixture_tok_bwd_body(const MixArgs& a, const Tok
     const int K = KT > 0 ? KT : a.K;
     const int P = a.P;
     const int PP = a.D + a.D * K;
-    const int nbuf = KT == 0 ? w.nbuf : 1;
-    char* const stage0 = smem + (size_t)wave * nbuf * gm.stage_bytes;
-    char* stage_b = stage0;
-    BoundTab* sf_tab = reinterpret_cast<BoundTab*>(smem + (size_t)kWavesPerBlock * nbuf * gm.stage_bytes);
+    // one stage per wave.  (A second stage with the next pass's DMA issued behind this pass's arithmetic was built in round 4 —
+    // bit-identical, S* 322 -> 326 us, Zinc nodes 26.6 -> 31.6: profiles/r04_sweep_mixture_bwd.txt — and removed in round 6.)
+    char* const stage_b = smem + (size_t)wave * gm.stage_bytes;
+    BoundTab* sf_tab = reinterpret_cast<BoundTab*>(smem + (size_t)kWavesPerBlock * gm.stage_bytes);
     BoundTab* msf_tab = sf_tab + a.D;
     // lane-private partial sums [64][nacc] per wave: a region of their own for a run-time K (they live there during the
     // passes); with a compile-time K they live in registers and only visit LDS for the final reduction, in the stage
@@ -337,14 +335,8 @@ __device__ __forceinline__ void mixture_tok_bwd_body(const MixArgs& a, const Tok
         const char* span0 = nn_lo + (tok_g0 * a.nn_D + (gm.d0 - a.nn_c0)) * (size_t)P * sizeof(float);
         float* gnn_tile = w.g_nn + tok_g0 * a.nn_D * (size_t)P;          // first token's first block
 
-        // two stages per wave (run-time K kernels): the NEXT pass's rows are DMA-staged into the other stage as soon as this pass's
-        // have landed, so their latency runs behind this pass's arithmetic and write-back instead of in front of the next pass
-        const bool pf = nbuf == 2;
-        int cur = 0, pos_cur = 0;
-        if (pf && ntok > 0) pos_cur = stage_pass(gm, stage0, span0, nn_last, min(gm.TPP, ntok), lane, tli, j, P);
         for (int tp = 0; tp < ntok; tp += gm.TPP) {
             const int npt = min(gm.TPP, ntok - tp);
-            stage_b = stage0 + (size_t)cur * gm.stage_bytes;
             const bool valid = tli < npt;
             const int tokl = tp + (valid ? tli : 0);
             int rl = 0, n = n_first + tokl;
@@ -392,15 +384,10 @@ __device__ __forceinline__ void mixture_tok_bwd_body(const MixArgs& a, const Tok
             }
 
             const char* pass_addr = span0 + (size_t)tp * gm.tokstride;
-            int my_pos = pf ? pos_cur : stage_pass(gm, stage_b, pass_addr, nn_last, npt, lane, tli, j, P);
+            int my_pos = stage_pass(gm, stage_b, pass_addr, nn_last, npt, lane, tli, j, P);
             if (!valid) my_pos = 0;
             float* my = reinterpret_cast<float*>(stage_b + my_pos);
             wave_lds_sync();
-            if (pf && tp + gm.TPP < ntok) {
-                pos_cur = stage_pass(gm, stage0 + (size_t)(cur ^ 1) * gm.stage_bytes, pass_addr + (size_t)gm.TPP * gm.tokstride, nn_last,
-                                     min(gm.TPP, ntok - tp - gm.TPP), lane, tli, j, P);
-                cur ^= 1;
-            }
 
             float g_x = gzo;                       // an element that is not transformed passes its gradient through
 #ifdef CNF_MIXBWD_ABLATE
@@ -545,14 +532,7 @@ __device__ __forceinline__ void mixture_tok_bwd_body(const MixArgs& a, const Tok
             if (g_x == 12345.678f)           // A/B build: no stores of g_z either
 #endif
             if (valid && sub == 0) gz_tile[(size_t)tokl * a.D + d] = g_x;
-            if (pf) {
-                // LDS ordering only (the lanes' gradient rows are read back by other lanes): the fence of wave_lds_sync() would also
-                // wait for the next pass's DMA, which is meant to stay in flight across the write-back
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_wave_barrier();
-            } else {
-                wave_lds_sync();
-            }
+            wave_lds_sync();
 
             // ---- the staged gradient rows go back to g_nn: the transformed spans of the pass's tokens
 #if defined(CNF_MIXBWD_ABLATE) && CNF_MIXBWD_ABLATE + 0 >= 2
@@ -669,9 +649,8 @@ __device__ __forceinline__ void mixture_tok_bwd_body(const MixArgs& a, const Tok
                 else if (w.wb_align == 8) zero_fill(make_float2(0.f, 0.f), 8);
                 else zero_fill(0.f, 4);
             }
-            // the stage is overwritten by the next pass (one stage per wave); with two, the next pass reads the other one and this
-            // one is refilled only behind the next pass's own sync
-            if (!pf) wave_lds_sync();
+            // the stage is overwritten by the next pass
+            wave_lds_sync();
         }
     }
 
@@ -725,11 +704,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
 
 using namespace cnf;
 
-extern "C" void cnf_set_mixture_bwd_prefetch(int mode) {
-    if (mode >= -1 && mode <= 1) cnf::g_tok_bwd_pf.store(mode, std::memory_order_relaxed);
-    if (mode == 2 || mode == 3) cnf::g_tok_bwd_wb24.store(mode - 2, std::memory_order_relaxed);     // 16-byte-grid write-back off / on
-}
-
 extern "C" void cnf_set_mixture_bwd_waves(int mode) {
     if (mode >= -1 && mode <= 7) cnf::g_tok_bwd_w4.store(mode, std::memory_order_relaxed);
 }
@@ -775,17 +749,7 @@ static bool launch_mixture_tok_bwd_with(MixArgs& a, const float* g_zout, const f
     w.g_zout = g_zout; w.g_ldj = g_ldj; w.g_z = g_z; w.g_nn = g_nn; w.partials = workspace;
     w.nacc = kt > 0 ? 1 + kt : 1 + (K + G - 1) / G;
     const size_t tabs = (((size_t)(a.D + a.D * K) * sizeof(BoundTab)) + 15) & ~(size_t)15;
-    // a second stage per wave (the next pass's DMA behind this pass's arithmetic) for the run-time K kernels: built, bit-identical, and
-    // NOT faster — S* 322 -> 326 us, Zinc nodes 26.6 -> 31.6, everything else within 1 % (profiles/r04_sweep_mixture_bwd.txt): with
-    // four waves per SIMD the other waves already cover a wave's DMA latency.  Off unless cnf_set_mixture_bwd_prefetch(1) asks for it
-    w.nbuf = 1;
-    if (kt == 0) {
-        const int pfk = g_tok_bwd_pf.load(std::memory_order_relaxed);
-        const size_t rest = tabs + (size_t)kWavesPerBlock * kWave * (1 + (K + G - 1) / G) * sizeof(float) + (size_t)kWavesPerBlock * PP * sizeof(float);
-        const size_t lds2 = (size_t)kWavesPerBlock * 2 * gm.stage_bytes + rest;
-        if (pfk == 1 && lds2 <= (size_t)65536) w.nbuf = 2;
-    }
-    w.lacc_off = (int)((size_t)kWavesPerBlock * w.nbuf * gm.stage_bytes + tabs);
+    w.lacc_off = (int)((size_t)kWavesPerBlock * gm.stage_bytes + tabs);
     w.wrow_off = w.lacc_off + (kt > 0 ? 0 : (int)((size_t)kWavesPerBlock * kWave * w.nacc * sizeof(float)));
     if (kt > 0 && (size_t)gm.stage_bytes < (size_t)kWave * w.nacc * sizeof(float)) return false;
     const size_t lds = (size_t)w.wrow_off + (size_t)kWavesPerBlock * PP * sizeof(float);
@@ -794,9 +758,8 @@ static bool launch_mixture_tok_bwd_with(MixArgs& a, const float* g_zout, const f
     const int first_b = (gm.d0 - a.nn_c0) * P * 4;
     const bool base16 = (reinterpret_cast<uintptr_t>(g_nn) & 15) == 0;
     if (base16 && span_b % 16 == 0 && gm.tokstride % 16 == 0 && first_b % 16 == 0 && (gm.contig || gm.slot % 16 == 0)) w.wb_align = 16;
-    else if (base16 && gm.contig && span_b == gm.tokstride && g_tok_bwd_wb24.load(std::memory_order_relaxed) != 0) w.wb_align = 32;
-    else if (base16 && !gm.contig && gm.ncopy > 0 && gm.tokstride % 16 == 0 && gm.slot % 16 == 0 && span_b % 8 == 0 && first_b % 8 == 0 &&
-             g_tok_bwd_wb24.load(std::memory_order_relaxed) != 0) {
+    else if (base16 && gm.contig && span_b == gm.tokstride) w.wb_align = 32;
+    else if (base16 && !gm.contig && gm.ncopy > 0 && gm.tokstride % 16 == 0 && gm.slot % 16 == 0 && span_b % 8 == 0 && first_b % 8 == 0) {
         w.wb_align = 24;
         w.u_lo = first_b / 16;
         w.nu = (first_b + span_b + 15) / 16 - w.u_lo;

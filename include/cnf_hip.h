@@ -51,12 +51,6 @@ typedef void* cnf_stream_t;
 int cnf_abi_version(void);
 const char* cnf_last_error(void);
 
-/* Tuning knob for the row-streaming kernels: float4 chunks one wave owns per tile (default 128). */
-void cnf_set_tile_chunks(int chunks);
-/* Load scheduling of the affine coupling kernel: 0 = one chunk at a time, software-pipelined (the next
- * chunk's loads are issued before the current one is computed); 1..4 = that many chunks per lane
- * loaded back to back.  Default 2. */
-void cnf_set_unroll(int u);
 /* Arithmetic mode.  1 (default, "fast"): hardware v_exp_f32 / v_log_f32 / v_rcp_f32 in the affine, prior and
  * sampling kernels (absolute error ~1e-7), and the module-form mixture-CDF coupling (cnf_mixture_coupling,
  * forward and Newton inverse) in fp32 on LDS-staged parameter rows with two-sided tail sums and an in-kernel
@@ -73,68 +67,6 @@ void cnf_set_math_mode(int mode);
  * component quantiles mu_k + s_k logit(u) and started at their weighted mean, same stop: same root to
  * ~1e-10, several times fewer CDF evaluations. */
 void cnf_set_inverse_mode(int mode);
-/* Items (transformed elements) one wave of the fp32 mixture forward kernel owns, 64..512 (default 128). */
-void cnf_set_mixture_tile(int items);
-/* Flat tiles of the streaming backward kernels (csrc/cnf_backward.hip): 16-byte chunks a lane keeps in flight (1..3) and
- * chunk groups one wave walks (1..64); 0 = every kernel's own default (2 chunks; 1 group for the flat-tile kernels, 2 for ExtActNorm, 4 for the token-owner ActNorm / 1x1 conv / fused-pair kernels).  A tuning knob like the ones above: the reference has no
- * counterpart (its backward is autograd, general/train.py:144-155).  All tuning knobs are process-wide atomics — set them
- * before use; they are not per device or per thread. */
-void cnf_set_bwd_tile(int chunks_in_flight, int groups_per_tile);
-/* cnf_actnorm_bwd: 1 (default) = the token-owner wave-tile kernel (register sums) for D in {1..6, 8}, 0 = always the flat-tile
- * kernel with lane-private LDS sums (A/B measurements and tests; same results up to the order of the additions). */
-void cnf_set_actnorm_bwd_tiles(int on);
-/* cnf_actnorm / cnf_invconv (forward kernels): 1 (default) = the fused pair's token-owner wave-tile kernel with the other layer compiled
- * out for D in {1..6, 8} (the same bits, 12.5 -> ~9.7 us at the benchmark shape), 0 = their own older kernels (A/B, tests). */
-void cnf_set_linear_tiles(int on);
-/* cnf_affine_coupling_bwd, channel masks at D in {2, 3, 4, 6, 8}: 1 (default) = the token-owner wave-tile kernel where it is the
- * faster one (no scaling factor, or the forward direction), 2 = always, 0 = always the flat-tile kernel (A/B measurements and
- * tests; same results up to the order of the additions). */
-void cnf_set_affine_bwd_tiles(int mode);
-/* fp32 mixture-coupling backward (cnf_mixture_coupling_bwd_f32), which streaming kernel: -1 (default) = the rolled run-time-K
- * kernel with 1 / 2 / 4 lanes per item by the amount of work; 2 / 3 / 4 force that kernel with 1 / 2 / 4 lanes (5-7: its build
- * held to 4 waves per SIMD); 0 / 1 = the unrolled register-slot kernels of K = 4 / 8 / 16 (natural registers / held to 4 waves
- * per SIMD), the defaults until round 4.  A/B knob; same gradients up to the order of the additions.  No reference counterpart. */
-void cnf_set_mixture_bwd_waves(int mode);
-/* the same entry point's run-time-K kernels: a second LDS stage per wave, so that the next pass's parameter rows are DMA-staged
- * while the current pass computes: 1 = wherever 64 KB of LDS allow, -1 (default) / 0 = never (measured: no gain, profiles/
- * r04_sweep_mixture_bwd.txt).  A/B knob; bit-identical gradients either way.
- * 2 / 3: the write-back of g_nn where a token's transformed span starts or ends on an odd multiple of 8 bytes (D = 6: bytes 312..623
- * of 624) with 8-byte stores / (default) with 16-byte stores on the token's 16-byte grid, the unit shared with an untransformed block
- * carrying that block's zeros (S* 330 -> 314 us, profiles/r05_mixture_bwd_writeback_ab.txt); bit-identical. */
-void cnf_set_mixture_bwd_prefetch(int mode);
-
-/* Kernel timing bound to the dispatch (bench.py's `roofline`; a timed launch costs ~4 us of queue time; the reference has no counterpart — its
- * only clock is the host-side time_per_step tracker, general/train.py:147-157).  cnf_prof_arm(n): the next n
- * kernel launches made by this host thread through this library carry their dispatch's own start / stop
- * timestamps (hipExtLaunchKernelGGL event pair; at most 8192 pairs between two collects).
- * cnf_prof_collect: waits for the timed launches, writes their durations in milliseconds in launch order
- * (HOST pointer), returns how many were written, and disarms. */
-int cnf_prof_arm(int launches);
-int cnf_prof_collect(float* ms_out_host, int capacity);
-/* Diagnostic: a streaming kernel with the affine coupling's traffic mix and no real arithmetic — a [n] fp32 read,
- * b [2n] fp32 read, out [n] fp32 written (out = a + b_even * b_odd), 16-byte accesses, `chunks_per_lane` in {1,2,4}.
- * bench.py times it in the same run as the coupling kernel: the measured ceiling for 12 B read + 4 B written per
- * element on this device ("a measured stream-copy ceiling from the same run").  No reference
- * counterpart. */
-int cnf_stream_probe(const float* a, const float* b, float* out, long n, int chunks_per_lane, cnf_stream_t stream);
-/* The same for the affine coupling's BACKWARD mix (tools/bwd_probe.py, bench.py's extra.kernels): a [n], b [2n], c [n]
- * read, o1 [n], o2 [2n] written — 16 B read + 12 B written per element; chunks_per_lane in {1,2}; hint bit 0 / 1 / 2 =
- * nontemporal loads of (a, b) / of c / nontemporal stores.  No reference counterpart. */
-int cnf_stream_probe_bwd(const float* a, const float* b, const float* c, float* o1, float* o2, long n,
-                         int chunks_per_lane, int hint, cnf_stream_t stream);
-/* Experiment kept for the record (tools/affine_fwd_tile_probe.py, profiles/r04_affine_fwd_tile_experiment.txt): the affine
- * coupling FORWARD (coupling_layer.py:53-63) in the token-owner wave-tile form that won in the backward kernels, D = 6,
- * channel mask, scaling factor, rows of 16..128 tokens, B*N a multiple of 128.  Same z bits as cnf_affine_coupling; SLOWER
- * (17.6-18.7 vs 16.7 us at the benchmark shape), so the flat row-tile kernel stays.  No reference counterpart. */
-int cnf_probe_affine_fwd_tile(const float* z, const float* nn_out, const float* scaling_factor, const float* mask, const float* ldj_in,
-                              float* z_out, float* ldj_out, int B, int N, int tiles_per_wave, int nontemporal_nn_loads,
-                              cnf_stream_t stream);
-
-/* Test / timing hook of the fp64 log / log1p / reciprocal the reference-precision mixture kernels use
- * (csrc/cnf_f64_math.h): out[i] = f(in[i]), which = 0 log of a positive normal, 1 reciprocal, 2 log1p on [0, 1]; 3 / 4 / 5 / 6 the
- * library's exp / log / division / log1p; reps > 1 applies f reps times per element (tools/f64_math_rates.py).  fp64 device
- * pointers.  No reference counterpart (numpy's / mpmath's log are what tests/test_gpu_f64_math.py compares with). */
-int cnf_probe_f64_math(int which, const double* in, double* out, long n, int reps, cnf_stream_t stream);
 
 /* ---- affine coupling -------------------------------------------------------------------- */
 
@@ -305,7 +237,8 @@ int cnf_mixture_coupling_actconv(const float* z, const float* nn_out,
  * unchanged).  Everything else as cnf_mixture_coupling_ws / _nll / _actconv; results are identical to theirs on the expanded
  * tensor (same kernels, same arithmetic: only the address of a token's span changes).  Needs a channel mask ([1,D]) with its
  * host channel list (act_host, one contiguous range).  Served by the token-pass kernels only (math mode 1, or math mode 0 with
- * inverse mode 1): a shape or mode they decline returns CNF_ERR_UNSUPPORTED with nothing launched — the caller expands
+ * inverse mode 1) and for tensors of a multiple of 4 floats (B N n_act (2+3K) % 4 == 0: the staging DMA's last 16-byte chunk):
+ * a shape or mode they decline returns CNF_ERR_UNSUPPORTED with nothing launched — the caller expands
  * nn_compact to the reference layout and calls the plain entry point. */
 int cnf_mixture_coupling_compact(const float* z, const float* nn_compact,
                                  const float* scaling_factor, const float* mixture_scaling_factor,
@@ -341,21 +274,6 @@ int cnf_mixture_coupling_compact_actconv(const float* z, const float* nn_compact
                                          double reg_max, double reg_factor, int is_training,
                                          void* workspace, int64_t workspace_bytes,
                                          int* flags, cnf_stream_t stream);
-
-/* Tuning / A-B knobs of the fp32 mixture kernels: which kernel serves math mode 1 (0 = token-pass kernel on
- * DMA-staged rows, default; 1 = the round-1 kernel); lanes per item for a run-time K (0 = automatic: K = 4 / 8 / 16
- * exactly, every other K <= 64 on predicated register slots, larger K on the rolled LDS loop; 1, 2, 4 = the rolled
- * loop with that many lanes per item, the A/B partner of the register slots); the number of waves a split-row launch
- * aims at (default 4096; never more workgroups than the device holds at once); and whether forward / inverse may stage whole tokens when skipping the untransformed
- * parameter blocks would skip no 128-byte lines anyway (default 1).  No counterpart in the reference (pure tuning). */
-void cnf_set_mixture_kernel(int which);
-void cnf_set_mixture_lanes(int lanes_per_item);
-void cnf_set_mixture_split(int waves);
-void cnf_set_mixture_whole_tokens(int on);
-/* Staged parameter bytes of one forward / inverse launch (MB) above which its DMA loads carry the nontemporal hint: the rows are
- * read once.  Measured (profiles/r05_mixture_nt_sweep.txt): 2-8 % from 78 MB up (S*: 312 MB, fp32 forward 103.6 -> 95-100 us), -4 %
- * at configs[1]'s 52 MB.  Default 64; 0 = never; negative = default. */
-void cnf_set_mixture_nt_mb(int megabytes);
 
 /* MixtureCDFCoupling.get_mixt_params (mixture_cdf_layer.py:145-180): split + bound + mask in
  * fp32, results cast to fp64: t, log_s [B,N,D]; log_pi, mixt_t, mixt_log_s [B,N,D,K]. */
@@ -447,8 +365,6 @@ int cnf_encoder_forward(const int64_t* categ, const float* eps, const float* tab
                         int B, int N, int D, int C, float sigma, float log_sigma,
                         int* flags, cnf_stream_t stream);
 
-/* LinearCategoricalEncoding reverse / _posterior_sample (linear_encoding.py:108-118,184-196):
- * argmax_c of (reverse-flow log-prob + category prior) -> int64 [B,N]; first max wins. */
 /* cnf_encoder_forward with LogisticDistribution.sample fused in (distributions.py:139-145,117-127 + linear_encoding.py:59-106):
  * `u` fp32 [B*N,D] is the UNIFORM draw; the kernel squeezes it (u (1 - squeeze_eps) + squeeze_eps / 2), takes the logit and
  * scales by sigma — the arithmetic of cnf_logistic_from_uniform in math mode 1, mu = 0 — and goes on as cnf_encoder_forward:
@@ -483,6 +399,8 @@ int cnf_encoder_forward_actconv_cpl(const int64_t* categ, const float* u, float 
                                     int B, int N, int D, int C, float sigma, float log_sigma,
                                     int* flags, cnf_stream_t stream);
 
+/* LinearCategoricalEncoding reverse / _posterior_sample (linear_encoding.py:108-118,184-196):
+ * argmax_c of (reverse-flow log-prob + category prior) -> int64 [B,N]; first max wins. */
 int cnf_encoder_decode(const float* z, const float* table, const float* category_prior,
                        int64_t* categ_out, int B, int N, int D, int C, float sigma, float log_sigma,
                        cnf_stream_t stream);
@@ -497,16 +415,6 @@ int cnf_encoder_decode_actconv(const float* z, const float* act_bias, const floa
                                const float* table, const float* category_prior,
                                const float* ldj_in, int64_t* categ_out, float* ldj_out,
                                int B, int N, int D, int C, float sigma, float log_sigma, int* flags, cnf_stream_t stream);
-
-/* A-B knob of the LDS-resident encoder kernels: 2 = two tokens per lane with 16-byte LDS constants wherever the shape
- * allows it (whole-row wave tiles of an even number of tokens, 16-byte aligned views, D in {1,2,3,4,6,8}), 1 = the
- * one-token-per-lane kernels (the fallback for every other shape), both on 256-token wave tiles; 0 (default) = by
- * measurement: since the forward sums class densities instead of streaming a log-sum-exp that is the one-token kernels
- * at every size, on 64- / 128-token tiles.  Same arithmetic per token: 1 and 2 give bit-identical latents, log-det and
- * decoded indices (linear_encoding.py:59-133,153-196); 0 differs from them only in the order of the per-row sums. */
-void cnf_set_encoder_kernel(int which);
-/* number of cnf_encoder_forward / cnf_encoder_decode calls this process served with the two-token kernels (tests) */
-int64_t cnf_encoder_pair_launches(void);
 
 /* The same two for vocabularies whose class table does not fit LDS (wikitext: 10^4 classes): the classes are walked
  * in chunks whose score constants a workgroup rebuilds in LDS, the sum of class densities (forward) / the arg-max
@@ -549,15 +457,6 @@ int cnf_sigmoid_flow(const float* z, const float* ldj_in, float* z_out, float* l
  * `workspace` with cnf_bwd_workspace_floats(P) floats (P = number of parameter entries of that call); the
  * sum is formed in fp64 in a fixed order (deterministic). */
 int64_t cnf_bwd_workspace_floats(int param_count);
-/* Deferred reductions, for a host that owns a whole backward pass (general/train.py:144-155 `loss.backward()` as one unit).
- * Between cnf_bwd_defer_begin() and cnf_bwd_defer_flush(stream) — host-thread local — cnf_affine_coupling_bwd,
- * cnf_affine_params_bwd, cnf_actnorm_bwd, cnf_invconv_bwd and cnf_actnorm_invconv_bwd only write their partial rows and queue
- * their closing reduction; the flush runs all of them as ONE launch on `stream` (the stream of the calls).  Every call in
- * between needs its OWN workspace, alive until the flush, and its parameter-gradient outputs hold nothing before it.  The
- * gradients are the bits of the immediate reductions.  (PyTorch's autograd consumes a node's parameter gradients before the
- * next node runs — the LU weight assembly reads d loss / d W at once — so the Python host of this repo does not defer.) */
-void cnf_bwd_defer_begin(void);
-int cnf_bwd_defer_flush(cnf_stream_t stream);
 
 /* d(CouplingLayer.forward) (coupling_layer.py:53-63,88-98).  z_out = the forward OUTPUT of the same
  * direction.  g_scaling_factor [D] only when scaling_factor != NULL (P = D). */
@@ -701,10 +600,6 @@ int cnf_encoder_forward_bwd_cpl(const int64_t* categ, const float* eps, const fl
                                 const float* category_prior, const float* pad, float beta, const float* class_prob_log,
                                 const float* g_zout, const float* g_ldj, float* g_table, float* workspace,
                                 int B, int N, int D, int C, float sigma, float log_sigma, cnf_stream_t stream);
-/* A-B knob of the two entry points above: 0 (default) = by shape as described, 1 = always the two passes, 2 / 3 = the pair
- * kernel on its 256-lane / 512-lane workgroup wherever the pair lanes (192 / 448) hold the classes (with the pre-pass when no
- * class_prob_log is given). */
-void cnf_set_encoder_bwd_kernel(int which);
 
 /* d(SigmoidFlow.forward) w.r.t. its input (sigmoid_layer.py:31-37). */
 int cnf_sigmoid_flow_bwd(const float* z_in, const float* g_zout, const float* g_ldj, float* g_z,

@@ -24,9 +24,13 @@ def built_lib():
 
 def test_abi_exports_every_declared_symbol(built_lib):
     from categoricalnf_amd import _lib
-    header = open(os.path.join(ROOT, "include", "cnf_hip.h")).read()
-    declared = set(re.findall(r"^(?:int64_t|int|void|const char\*)\s+(cnf_\w+)\s*\(", header, flags=re.M))
-    assert declared, "no prototypes found in include/cnf_hip.h"
+    proto = r"^(?:int64_t|int|void|const char\*)\s+(cnf_\w+)\s*\("
+    product = set(re.findall(proto, open(os.path.join(ROOT, "include", "cnf_hip.h")).read(), flags=re.M))
+    tuning = set(re.findall(proto, open(os.path.join(ROOT, "include", "cnf_tuning.h")).read(), flags=re.M))
+    assert product and tuning and not (product & tuning), "no prototypes found / a name declared twice"
+    # the product header holds what a maintainer of the reference binds: no A/B knob, probe or experimental entry point in it
+    assert not [n for n in product if re.match(r"cnf_(set_(?!math_mode|inverse_mode)|probe_|stream_probe|prof_|bwd_defer)", n)], sorted(product)
+    declared = product | tuning
     assert declared == set(_lib.exported_symbols())
     nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], stdout=subprocess.PIPE, text=True).stdout
     exported = set(re.findall(r" T (cnf_\w+)", nm))
@@ -379,7 +383,8 @@ def test_best_model_and_argument_pickle_round_trip(tmp_path):
 def test_every_c_entry_point_is_documented_for_integrators():
     """include/cnf_hip.h and INTEGRATION.md stay in step: every exported function appears in the binding table."""
     import re
-    names = set(re.findall(r"\b(cnf_[a-z0-9_]+)\s*\(", open(os.path.join(ROOT, "include", "cnf_hip.h")).read()))
+    names = set(re.findall(r"\b(cnf_[a-z0-9_]+)\s*\(", open(os.path.join(ROOT, "include", "cnf_hip.h")).read()
+                           + open(os.path.join(ROOT, "include", "cnf_tuning.h")).read()))
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     missing = sorted(n for n in names if n not in doc)
     assert not missing, missing

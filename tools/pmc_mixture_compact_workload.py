@@ -1,5 +1,7 @@
 """Workload for counter runs: fp32 mixture forward and backward on the compact parameter layout at S* (and the reference layout's
-backward), a few launches each.  tools/pmc_memory_path.sh wraps it."""
+backward), a few launches each:  bash tools/pmc_passes.sh <out> python tools/pmc_mixture_compact_workload.py
+(SQ / FETCH_SIZE / WRITE_SIZE passes.  The L1 -> L2 / L2 -> fabric request counters — TCP_TCC_*_sum, TCC_EA0_*_sum — hung rocprofv3 until its
+timeout on this pool in round 6, 25 GPU-minutes: do not add them to a pass.)"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -67,15 +67,6 @@ for name, B, N, D, K, masked in shapes:
             except Exception as e:
                 extra.append("n/a")
         print("   rolled kernel, lanes per item 1 / 2 / 4: natural %s / %s / %s us, 4 waves per SIMD %s / %s / %s us" % tuple(extra), flush=True)
-        if hasattr(lib, "cnf_set_mixture_bwd_prefetch"):
-            pf = []
-            for pmode in (0, 1):             # one stage per wave / two (the next pass's DMA behind this pass's arithmetic) wherever LDS allows
-                lib.cnf_set_mixture_bwd_prefetch(pmode)
-                for mode in (2, 3, 4):
-                    lib.cnf_set_mixture_bwd_waves(mode)
-                    pf.append("%.1f" % timeit(f32)[0])
-            lib.cnf_set_mixture_bwd_prefetch(-1)
-            print("   ... the same three with one stage per wave %s / %s / %s us, with two stages (DMA prefetch) %s / %s / %s us" % tuple(pf), flush=True)
     lib.cnf_set_mixture_bwd_waves(-1)
     (t32, k32), (t64, k64) = timeit(f32), timeit(f64, reps=3)
     e = B * N * D
