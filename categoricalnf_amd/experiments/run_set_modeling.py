@@ -298,8 +298,14 @@ def _main(argv=None):
         # one must not be removed when a better validation file appears).  Their names are kept in a sidecar file; only a
         # directory written before the sidecar existed is scanned by unpickling every checkpoint once
         import glob
+        listed = None
         if os.path.isfile(periodic_list):
-            periodic.update(f for f in (os.path.join(args.checkpoint_path, n) for n in json.load(open(periodic_list))) if os.path.isfile(f))
+            try:
+                listed = [os.path.join(args.checkpoint_path, n) for n in json.load(open(periodic_list))]
+            except (ValueError, OSError):
+                listed = None          # a truncated sidecar (a crash during its write): fall back to the scan
+        if listed is not None:
+            periodic.update(f for f in listed if os.path.isfile(f))
         else:
             for f in glob.glob(os.path.join(args.checkpoint_path, "checkpoint_*.tar")):
                 try:
@@ -355,7 +361,10 @@ def _main(argv=None):
                 save_checkpoint(args.checkpoint_path, step, ddp, optimizer if flat is None else None, scheduler,
                                 best_save_dict=best, evaluation_dict=state["evaluation_dict"])
             periodic.add(checkpoint_file(args.checkpoint_path, step))
-            json.dump(sorted(os.path.basename(f) for f in periodic), open(periodic_list, "w"))
+            # written to a temporary file and renamed into place: a crash leaves the old list or the new one, never half of one
+            with open(periodic_list + ".tmp", "w") as fh:
+                json.dump(sorted(os.path.basename(f) for f in periodic), fh)
+            os.replace(periodic_list + ".tmp", periodic_list)
     if graphed is not None:
         graphed.drop_weight_caches()
     _, val_bpd = evaluate(ddp, val_sets, device, rank, world, args.eval_batch_size)

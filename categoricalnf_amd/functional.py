@@ -308,10 +308,14 @@ class EncoderActConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, table, bias, scales, weight, sldj, ldj, categ, uniform, prior, pad, length, beta, squeeze):
         # class_prob_log rides along for the backward's pair kernel (cnf_encoder_forward_bwd_cpl)
-        z_out, ldj_out, cpl = ops.encoder_forward_actconv(categ, uniform, table, prior, bias, scales, weight, sldj, beta=beta,
-                                                          channel_padding_mask=pad, length=length, ldj=ldj, uniform_squeeze=squeeze,
-                                                          want_class_prob=True)
+        # (only when a gradient for the table can follow: ctx.needs_input_grad is False under torch.no_grad())
+        keep_cpl = bool(ctx.needs_input_grad[0])
+        res = ops.encoder_forward_actconv(categ, uniform, table, prior, bias, scales, weight, sldj, beta=beta,
+                                          channel_padding_mask=pad, length=length, ldj=ldj, uniform_squeeze=squeeze,
+                                          want_class_prob=keep_cpl)
+        z_out, ldj_out = res[0], res[1]
         empty = z_out.new_empty(0)
+        cpl = res[2] if len(res) > 2 and res[2] is not None else empty
         inv = _known_inverse(weight)
         ctx.save_for_backward(table, categ, uniform, prior, pad if isinstance(pad, torch.Tensor) else empty,
                               length if isinstance(length, torch.Tensor) else empty, z_out, bias, scales, weight, cpl,
@@ -335,7 +339,7 @@ class EncoderActConvFn(torch.autograd.Function):
         g_table = torch.empty_like(tc)
         ws = torch.empty(int(_lib.load().cnf_encoder_bwd_tiled_workspace_floats(B, N, D, C)), dtype=torch.float32, device=dev)
         _launch(dev, "cnf_encoder_forward_bwd_cpl", _ptr(categ.contiguous()), _ptr(_f32(eps, "eps")), _ptr(tc), _ptr(pc), _ptr(p2), ctx.beta,
-                _ptr(cpl.contiguous()), _ptr(g_ze), hold(g_ldj), _ptr(g_table), _ptr(ws), B, N, D, C,
+                (_ptr(cpl.contiguous()) if cpl.numel() else None), _ptr(g_ze), hold(g_ldj), _ptr(g_table), _ptr(ws), B, N, D, C,
                 float(ops.LOGISTIC_SIGMA), float(ops.LOGISTIC_LOG_SIGMA), _stream(dev))
         return (g_table, g_b, g_s, g_w, g_sl.view(ctx.sldj_shape), (g_ldj if ctx.has_ldj else None),
                 None, None, None, None, None, None, None)
@@ -553,7 +557,9 @@ class EncoderForwardFn(torch.autograd.Function):
         # the backward kernels), see ops.encoder_forward
         # the backward's pair kernel takes every token's denominator from the forward's class_prob_log (4 bytes per token
         # more to write here, a whole sweep over the classes less there): ask for it whenever a gradient can follow
-        keep_cpl = table.requires_grad
+        # (ctx.needs_input_grad, not table.requires_grad: a Parameter still "requires grad" under torch.no_grad(), where no backward
+        # can follow — evaluation and sampling passes must not write and keep 4 bytes per token for nothing)
+        keep_cpl = bool(ctx.needs_input_grad[0])
         if uniform_squeeze is not None:
             z, ldj, cpl, eps = ops.encoder_forward(categ, eps, table, prior, beta=beta, channel_padding_mask=pad,
                                                    want_class_prob=want_class_prob or keep_cpl, tiled=tiled,
