@@ -309,6 +309,15 @@ def kernel_table(lib, ops, dev, budget_ms=6.0):
     S = "B=%d N=%d D=%d" % (B, N, D)
     row("actnorm_invconv (fused pair, forward)", S, 8 * e,
         [call("cnf_actnorm_invconv", P(zs[r]), P(bias), P(scales), P(w), P(sldj), None, None, P(ldj), P(o1[r]), P(lo), B, N, D, 0, flags, st) for r in range(R)])
+    # affine coupling of one flow step + ActNorm + 1x1 conv of the next (forward) / + the inverted pair of its own step (reverse) in one
+    # kernel: 16 B/elem (SURVEY 8d "Fused [coupling_i + ActNorm_{i+1} + InvConv_{i+1}]") against 16 + 8 as coupling + fused pair
+    w_inv0 = torch.inverse(w.double()).float().contiguous()
+    for rev, wt, what in ((0, w, "forward"), (1, w_inv0, "inverse")):
+        row("affine_coupling + ActNorm + 1x1 conv (three-way fusion, %s)" % what, S, 16 * e,
+            [call("cnf_affine_coupling_actconv", P(zs[r]), P(nn2[r]), P(sf), P(mask), 1, D, P(ldj), P(o1[r]), P(lo), P(bias), P(scales), P(wt), P(sldj),
+                  None, None, B, N, D, rev, flags, st) for r in range(R)])
+        row("affine_coupling (plain, %s)" % what, S, 16 * e,
+            [call("cnf_affine_coupling", P(zs[r]), P(nn2[r]), P(sf), P(mask), 1, D, P(ldj), P(o1[r]), P(lo), B, N, D, rev, flags, st) for r in range(R)])
     neglog, nll = torch.empty(B, device=dev), torch.empty(B, device=dev)
     row("prior_nll", S, 4 * e,
         [call("cnf_prior_nll", P(zs[r]), None, P(ldj), P(ln), P(neglog), P(nll), None, B, N, D, float(ops.LOGISTIC_SIGMA), float(ops.LOGISTIC_LOG_SIGMA), st) for r in range(R)])

@@ -27,6 +27,7 @@ _i64 = ctypes.c_int64
 SIGNATURES = {
     "cnf_affine_coupling": [_p, _p, _p, _p, _i, _i, _p, _p, _p, _i, _i, _i, _i, _p, _p],
     "cnf_affine_params": [_p, _p, _p, _i, _i, _p, _p, _i, _i, _i, _p],
+    "cnf_affine_coupling_actconv": [_p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p],
     "cnf_affine_transform": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p],
     "cnf_actnorm": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p],
     "cnf_ext_actnorm": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p],

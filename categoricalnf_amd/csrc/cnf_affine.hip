@@ -57,8 +57,17 @@ struct AffineArgs {
     float* nll_out;
     long long* acc;        // optional: 64 fixed-point partial sums of nll (see cnf_affine_coupling_nll_acc)
     PriorConst prior;
+    // ActNorm + 1x1 convolution epilogue (affine_coupling_kernel<..., ED > 0>, cnf_affine_coupling_actconv): the pair of the NEXT
+    // flow step (forward) / of the same step, inverted (reverse) applied to the coupling's output while the tile is in LDS
+    const float* e_bias;   // [D]
+    const float* e_scales; // [D]
+    const float* e_w;      // [D,D]: the forward weight, or the inverse weight in the reverse direction
+    const float* e_sldj;   // [1]
+    const float* e_pad;    // [B,N] or null (the affine coupling itself ignores padding; the pair does not)
+    const float* e_length; // [B] or null
 };
 
+typedef float mb_vec4 __attribute__((ext_vector_type(4)));
 template <int VEC>
 struct VecIO;
 // Cache hints of the 16-byte row-streaming I/O.  bit 0: nontemporal loads of the conditioning values (s, t); bit 1:
@@ -148,14 +157,35 @@ struct AffineChunk {
 };
 
 // NLLM: 0 = coupling only, 1 = + NLL epilogue, 2 = + NLL epilogue with a padding mask on the prior term
-template <int VEC, int U, bool HAS_SF, bool REVERSE, bool FAST, int NLLM = 0>
+// ED > 0 (= D; whole rows per wave tile, VEC = 4): the coupling's output is not stored but kept in the wave's LDS strip; when the
+// tile is through, its tokens go through ActNorm and the 1x1 convolution there (activation_normalization.py:24-48,
+// permutation_layers.py:106-136: the arithmetic of actnorm_invconv_kernel, in its order) and leave as one contiguous, coalesced
+// store.  The coupling itself — arithmetic, tile walk, order of the row sums — is this kernel's own: z and the log-det are the
+// bits of cnf_affine_coupling followed by cnf_actnorm_invconv, and the [B,N,D] round trip between them (8 B/elem) is gone.
+template <int VEC, int U, bool HAS_SF, bool REVERSE, bool FAST, int NLLM = 0, int ED = 0>
 __global__ __launch_bounds__(kBlock) void affine_coupling_kernel(AffineArgs a, RowTiling tl) {
     constexpr bool NLL = NLLM != 0;
+    static_assert(ED == 0 || (VEC == 4 && NLLM == 0), "the ActNorm + convolution epilogue: float4 chunks, no NLL assembly");
     using Acc = typename std::conditional<NLL, Sum2, float>::type;
 
     // per-wave strip of row partials, sized by the host to the tile (rw * cpr entries; unused when rw == 1)
     extern __shared__ __attribute__((aligned(16))) char part_raw[];
     Acc* part = reinterpret_cast<Acc*>(part_raw) + (size_t)(threadIdx.x >> 6) * (tl.rw * tl.cpr);
+    // ED: behind the partials of the four waves, [bias | e^{+-scales} | W] and one strip of rw * L outputs per wave
+    const size_t part_bytes = ((tl.rw == 1 ? 0 : (size_t)kWavesPerBlock * tl.rw * tl.cpr * sizeof(Acc)) + 15) & ~(size_t)15;
+    float* etab = reinterpret_cast<float*>(part_raw + part_bytes);
+    float* zs = etab + ((2 * ED + ED * ED + 3) & ~3) + (size_t)(threadIdx.x >> 6) * ((size_t)tl.rw * tl.L);
+    const int e_row0 = (int)(((long)walker_block() * kWavesPerBlock + (threadIdx.x >> 6)) * tl.rw);
+    // (the pair's constants through LDS: read as uniform loads into scalar registers at the start of the kernel, the way
+    // actnorm_invconv_kernel keeps them, the fused forward took 23.1 instead of 20.6 us at S*)
+    if (ED > 0) {
+        for (int i = threadIdx.x; i < ED; i += kBlock) {
+            etab[i] = a.e_bias[i];
+            etab[ED + i] = expf(REVERSE ? -a.e_scales[i] : a.e_scales[i]);
+        }
+        for (int i = threadIdx.x; i < ED * ED; i += kBlock) etab[2 * ED + i] = a.e_w[i];
+        __syncthreads();
+    }
     __shared__ ChanTab tab_all[kWavesPerBlock][kMaxTab];
     ChanTab* tab = tab_all[threadIdx.x >> 6];
     // per-wave constant table: its two tiny loads are issued FIRST, the table itself is finished
@@ -247,7 +277,11 @@ __global__ __launch_bounds__(kBlock) void affine_coupling_kernel(AffineArgs a, R
                 lp_prod *= 1.f + __builtin_amdgcn_exp2f(-ax * a.prior.inv_sigma_log2e);
             }
         }
-        VecIO<VEC>::store(a.z_out + off, out);
+        if constexpr (ED > 0) {
+            *reinterpret_cast<float4*>(zs + (size_t)(row - e_row0) * a.L + e0) = make_float4(out[0], out[1], out[2], out[3]);
+        } else {
+            VecIO<VEC>::store(a.z_out + off, out);
+        }
         if constexpr (NLL) {
             // un-padded rows: the log term and the constant log(sigma) of the chunk's elements are added once
             if (NLLM == 1)
@@ -258,7 +292,27 @@ __global__ __launch_bounds__(kBlock) void affine_coupling_kernel(AffineArgs a, R
         }
     };
     auto ldj_of = [&](int row, float sum, float base) {
-        const float v = REVERSE ? base - sum : base + sum;
+        float v = REVERSE ? base - sum : base + sum;
+        if constexpr (ED > 0) {
+            // the pair's log-det on top, same association as the two kernels run in sequence: ActNorm uses length | sum(pad) | N,
+            // the convolution length | N
+            float len_a, len_c;
+            if (a.e_length) {
+                len_a = len_c = a.e_length[row];
+            } else {
+                len_c = (float)a.N;
+                len_a = (float)a.N;
+                if (a.e_pad) {
+                    len_a = 0.f;
+                    for (int n = 0; n < a.N; ++n) len_a += a.e_pad[(size_t)row * a.N + n];
+                }
+            }
+            float ssum = 0.f;
+#pragma unroll
+            for (int i = 0; i < ED; ++i) ssum += a.e_scales[i];
+            const float sl = a.e_sldj[0];
+            v = REVERSE ? (v - sl * len_c) + (-ssum) * len_a : (v + ssum * len_a) + sl * len_c;
+        }
         a.ldj_out[row] = v;
         if (isnan(v)) raise_flag(a.flags, CNF_FLAG_NAN_LDJ);
         return v;
@@ -293,6 +347,53 @@ __global__ __launch_bounds__(kBlock) void affine_coupling_kernel(AffineArgs a, R
         else emit(row, sum, a.ldj_in ? a.ldj_in[row] : 0.f, (NLL && a.length) ? a.length[row] : (float)a.N);
     };
     walk_row_tile_split<(U == 0 ? 1 : U), Acc, AffineChunk<VEC>, U == 0>(tl, part, load, proc, finish, pre);
+    if constexpr (ED > 0) {
+        // ---- the tile's tokens through ActNorm and the 1x1 convolution, one token per lane and trip, in place in the strip
+        const int nrows = min(tl.rw, tl.B - e_row0);
+        if (nrows > 0) {
+            wave_lds_sync();
+            const int lane = threadIdx.x & 63;
+            const int ntok = nrows * a.N;
+            for (int t = lane; t < ntok; t += kWave) {
+                const float p = a.e_pad ? a.e_pad[(size_t)e_row0 * a.N + t] : 1.f;
+                float xv[ED > 0 ? ED : 1], ov[ED > 0 ? ED : 1];
+                float* tok = zs + (size_t)t * ED;
+#pragma unroll
+                for (int i = 0; i < ED; ++i) xv[i] = tok[i];
+                if (!REVERSE) {
+#pragma unroll
+                    for (int i = 0; i < ED; ++i) {
+                        float y = (xv[i] + etab[i]) * etab[ED + i];
+                        if (a.e_pad) y = y * p;
+                        xv[i] = y;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < ED; ++j) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int i = 0; i < ED; ++i) acc = fmaf(xv[i], etab[2 * ED + i * ED + j], acc);
+                    if (a.e_pad) acc = acc * p;
+                    if (REVERSE) {
+                        acc = acc * etab[ED + j] - etab[j];
+                        if (a.e_pad) acc = acc * p;
+                    }
+                    bad |= isnan(acc);
+                    ov[j] = acc;
+                }
+#pragma unroll
+                for (int i = 0; i < ED; ++i) tok[i] = ov[i];
+            }
+            wave_lds_sync();
+            float4* dst = reinterpret_cast<float4*>(a.z_out + (size_t)e_row0 * a.L);
+            const float4* src = reinterpret_cast<const float4*>(zs);
+            const int nv = nrows * a.L / 4;
+            for (int i = lane; i < nv; i += kWave) {
+                const float4 q = src[i];
+                __builtin_nontemporal_store(mb_vec4{q.x, q.y, q.z, q.w}, reinterpret_cast<mb_vec4*>(dst + i));
+            }
+        }
+    }
     if (wg_acc) {
         // every wave comes through here, with or without a tile; its rows' LDS adds precede its ticket in program order
         wave_lds_sync();
@@ -320,6 +421,33 @@ static void launch_affine_u(const AffineArgs& a, const RowTiling& tl, bool has_s
         } else {
             if (has_sf) CNF_LAUNCH((affine_coupling_kernel<VEC, UN, true, false, FAST, 1>), grid, block, lds, st, a, tl);
             else CNF_LAUNCH((affine_coupling_kernel<VEC, UN, false, false, FAST, 1>), grid, block, lds, st, a, tl);
+        }
+        return;
+    }
+    if (a.e_w) {
+        // ActNorm + 1x1 convolution epilogue (cnf_affine_coupling_actconv): float4 chunks, fast math, 2 chunks in flight (the host has
+        // checked the rest); the order of the row sums does not depend on the chunks in flight
+        if constexpr (VEC == 4 && FAST && U == 2) {
+            const size_t part_b = ((kWavesPerBlock * strip * sizeof(float)) + 15) & ~(size_t)15;
+            const size_t lds_e = part_b + (((size_t)(2 * a.D + a.D * a.D + 3) & ~(size_t)3) + (size_t)kWavesPerBlock * tl.rw * tl.L) * sizeof(float);
+#define CNF_AFF_ED(ED_)                                                                                                   \
+    do {                                                                                                                  \
+        if (has_sf) {                                                                                                     \
+            if (reverse) CNF_LAUNCH((affine_coupling_kernel<4, 2, true, true, true, 0, ED_>), grid, block, lds_e, st, a, tl);   \
+            else CNF_LAUNCH((affine_coupling_kernel<4, 2, true, false, true, 0, ED_>), grid, block, lds_e, st, a, tl);          \
+        } else {                                                                                                          \
+            if (reverse) CNF_LAUNCH((affine_coupling_kernel<4, 2, false, true, true, 0, ED_>), grid, block, lds_e, st, a, tl);  \
+            else CNF_LAUNCH((affine_coupling_kernel<4, 2, false, false, true, 0, ED_>), grid, block, lds_e, st, a, tl);         \
+        }                                                                                                                 \
+    } while (0)
+            switch (a.D) {
+                case 2: CNF_AFF_ED(2); break;
+                case 3: CNF_AFF_ED(3); break;
+                case 4: CNF_AFF_ED(4); break;
+                case 6: CNF_AFF_ED(6); break;
+                default: CNF_AFF_ED(8); break;
+            }
+#undef CNF_AFF_ED
         }
         return;
     }
@@ -753,7 +881,7 @@ static int affine_coupling_impl(const char* who, const float* z, const float* nn
                                 int B, int N, int D, int reverse,
                                 const float* pad, const float* length, float* neglog_out, float* nll_out,
                                 double* sums, float sigma, float log_sigma, int* flags, cnf_stream_t stream,
-                                long long* acc = nullptr) {
+                                long long* acc = nullptr, const float* const* epi = nullptr) {
     CNF_REQUIRE(z && nn_out && z_out && ldj_out, "%s: null tensor", who);
     CNF_REQUIRE(B >= 0 && N > 0 && D > 0, "%s: bad shape B=%d N=%d D=%d", who, B, N, D);
     if (B == 0) return CNF_OK;
@@ -772,10 +900,27 @@ static int affine_coupling_impl(const char* who, const float* z, const float* nn
     a.div_p = make_fastdiv((uint32_t)a.P);
     a.pad = pad; a.length = length; a.neglog_out = neglog_out; a.nll_out = nll_out; a.acc = acc;
     a.prior = make_prior_const(sigma, log_sigma);
+    a.e_bias = a.e_scales = a.e_w = a.e_sldj = a.e_pad = a.e_length = nullptr;
+    if (epi) {
+        a.e_bias = epi[0]; a.e_scales = epi[1]; a.e_w = epi[2]; a.e_sldj = epi[3]; a.e_pad = epi[4]; a.e_length = epi[5];
+    }
     // one tiling for the plain and the NLL variant: the per-row summation order depends on it, and the fused kernel's
     // log-det must stay bit-equal to the plain forward's (and exactly minus the inverse's).  A larger tile (384 chunks)
     // would save the NLL variant 0.5 us at the benchmark shape (tools/sweep_nll.py) at the price of that equality.
     const RowTiling tl = make_row_tiling(B, a.L, 0, tile_chunks_target());
+    if (epi) {
+        // the epilogue kernels: whole rows per wave tile in float4 chunks, fast math, D in {2, 3, 4, 6, 8}, the tile's outputs in LDS
+        const size_t strip = tl.rw == 1 ? 0 : (size_t)tl.rw * tl.cpr;
+        const size_t lds_e = (((size_t)kWavesPerBlock * strip * sizeof(float) + 15) & ~(size_t)15) +
+                             (((size_t)(2 * D + D * D + 3) & ~(size_t)3) + (size_t)kWavesPerBlock * tl.rw * tl.L) * sizeof(float);
+        if (!(D == 2 || D == 3 || D == 4 || D == 6 || D == 8) || tl.vec != 4 || tl.bpr || math_mode() != 1 || lds_e > 65536 ||
+            (reinterpret_cast<uintptr_t>(z_out) & 15) != 0) {
+            set_error("%s: shape / mode outside the fused kernel (B=%d N=%d D=%d): run cnf_affine_coupling and cnf_actnorm_invconv", who, B, N, D);
+            return CNF_ERR_UNSUPPORTED;
+        }
+        launch_affine_u<4, 2, true>(a, tl, scaling_factor != nullptr, reverse != 0, (hipStream_t)stream);
+        return launch_status(who);
+    }
     DISPATCH_VEC(tl, launch_affine<V>(a, tl, scaling_factor != nullptr, reverse != 0, (hipStream_t)stream));
     if (sums) CNF_LAUNCH(nll_sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, nll_out, B, sums);
     return launch_status(who);
@@ -788,6 +933,19 @@ int cnf_affine_coupling(const float* z, const float* nn_out, const float* scalin
     return affine_coupling_impl("cnf_affine_coupling", z, nn_out, scaling_factor, mask, mask_rows, mask_cols,
                                 ldj_in, z_out, ldj_out, B, N, D, reverse, nullptr, nullptr, nullptr, nullptr,
                                 nullptr, 1.f, 0.f, flags, stream);
+}
+
+int cnf_affine_coupling_actconv(const float* z, const float* nn_out, const float* scaling_factor,
+                                const float* mask, int mask_rows, int mask_cols,
+                                const float* ldj_in, float* z_out, float* ldj_out,
+                                const float* an_bias, const float* an_scales, const float* conv_weight, const float* conv_sldj,
+                                const float* pad, const float* length,
+                                int B, int N, int D, int reverse, int* flags, cnf_stream_t stream) {
+    CNF_REQUIRE(an_bias && an_scales && conv_weight && conv_sldj, "cnf_affine_coupling_actconv: null tensor");
+    const float* epi[6] = {an_bias, an_scales, conv_weight, conv_sldj, pad, length};
+    return affine_coupling_impl("cnf_affine_coupling_actconv", z, nn_out, scaling_factor, mask, mask_rows, mask_cols,
+                                ldj_in, z_out, ldj_out, B, N, D, reverse, nullptr, nullptr, nullptr, nullptr,
+                                nullptr, 1.f, 0.f, flags, stream, nullptr, epi);
 }
 
 int cnf_affine_coupling_nll(const float* z, const float* nn_out, const float* scaling_factor,

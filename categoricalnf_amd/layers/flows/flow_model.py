@@ -73,6 +73,21 @@ class FlowModel(nn.Module):
                     reg_factor=layer.regularizer_factor, is_training=layer.training, ldj=ldj, want_reg=False)
                 skip.update((order[pos + 1][0], order[pos + 2][0]))
                 continue
+            if (fuse and pos + 2 < len(order) and type(layer).__name__ == "CouplingLayer" and layer.c_in in ops.FUSED_ACTCONV_DIMS
+                    and type(order[pos + 1][1]) is (InvertibleConv if reverse else ActNormFlow)
+                    and type(order[pos + 2][1]) is (ActNormFlow if reverse else InvertibleConv)):
+                # affine coupling of this flow step + ActNorm + 1x1 conv of the next one (forward), or the coupling's inverse + the
+                # inverted conv + ActNorm of its own step (reverse: the order the layers are walked in) in ONE kernel, the bits of
+                # the three layers (cnf_affine_coupling_actconv; shapes outside that kernel run as coupling + fused pair)
+                act, conv = (order[pos + 2][1], order[pos + 1][1]) if reverse else (order[pos + 1][1], order[pos + 2][1])
+                pad = kwargs.get("channel_padding_mask", None)
+                net_kwargs = {k: v for k, v in kwargs.items() if k != "channel_padding_mask"}
+                nn_out = layer.run_network(x=z * layer._prepare_mask(layer.mask, z), **net_kwargs)
+                weight, sldj = conv._get_weight(device_name=str(z.device), inverse=reverse)
+                z, ldj = ops.affine_coupling_actconv(z, nn_out, layer.scaling_factor, layer.mask, act.bias, act.scales, weight, sldj,
+                                                     reverse=reverse, length=kwargs.get("length", None), channel_padding_mask=pad, ldj=ldj)
+                skip.update((order[pos + 1][0], order[pos + 2][0]))
+                continue
             if ((fusable or trainable) and not reverse and pos + 2 < len(order) and type(layer).__name__ == "LinearCategoricalEncoding"
                     and not z.is_floating_point()
                     and type(order[pos + 1][1]) is ActNormFlow and type(order[pos + 2][1]) is InvertibleConv

@@ -227,6 +227,44 @@ def affine_coupling(z, nn_out, scaling_factor, mask, reverse=False, ldj=None):
     return z_out, ldj_out
 
 
+def affine_coupling_actconv(z, nn_out, scaling_factor, mask, an_bias, an_scales, conv_weight, conv_sldj, reverse=False,
+                            length=None, channel_padding_mask=None, ldj=None):
+    """Affine coupling of one flow step + ActNorm + 1x1 convolution of the next step (forward), or the coupling's inverse + the
+    inverted convolution and ActNorm of its own step (reverse; conv_weight = the inverse weight), in one kernel
+    (cnf_affine_coupling_actconv); where that kernel does not apply the two kernels run one after the other — the same bits
+    either way.  Returns (z_out, ldj_out)."""
+    z = _f32(z, "z")
+    dev = z.device
+    B, N, D = z.shape
+    nn_out = _f32(nn_out, "nn_out")
+    if nn_out.numel() != z.numel() * 2:
+        raise ValueError("nn_out must be [B,N,2D]; got %s for z %s" % (tuple(nn_out.shape), tuple(z.shape)))
+    sf = _opt_f32(scaling_factor, "scaling_factor", dev)
+    m, mr, mc = _mask_desc(mask, D, dev)
+    pad = _pad2d(channel_padding_mask, B, N, dev)
+    ln = _length(length, B, dev) if isinstance(length, torch.Tensor) else None
+    b, sc = _f32(an_bias.reshape(-1), "bias"), _f32(an_scales.reshape(-1), "scales")
+    w, sl = _f32(conv_weight, "weight"), _f32(conv_sldj.reshape(1), "sldj")
+    ldj_in, ldj_out = _ldj_io(ldj, B, dev, inplace=False)
+    z_out = torch.empty_like(z)
+    status = _launch(dev, "cnf_affine_coupling_actconv", _ptr(z), _ptr(nn_out), _ptr(sf), _ptr(m), mr, mc, _ptr(ldj_in), _ptr(z_out),
+                     _ptr(ldj_out), _ptr(b), _ptr(sc), _ptr(w), _ptr(sl), _ptr(pad), _ptr(ln), B, N, D, int(bool(reverse)),
+                     _ptr(flag_word(dev)), _stream(dev), allow_unsupported=True)
+    if status != _lib.CNF_OK:
+        zc, lc = affine_coupling(z, nn_out, scaling_factor, mask, reverse=reverse, ldj=ldj)
+        if D in FUSED_ACTCONV_DIMS:
+            return actnorm_invconv(zc, an_bias, an_scales, conv_weight, conv_sldj, reverse=reverse, length=length,
+                                   channel_padding_mask=channel_padding_mask, ldj=lc)
+        kw = dict(reverse=reverse, length=length, channel_padding_mask=channel_padding_mask)
+        if reverse:
+            zc, lc = invconv(zc, conv_weight, conv_sldj, ldj=lc, **kw)
+            return actnorm(zc, an_bias, an_scales, ldj=lc, **kw)
+        zc, lc = actnorm(zc, an_bias, an_scales, ldj=lc, **kw)
+        return invconv(zc, conv_weight, conv_sldj, ldj=lc, **kw)
+    _after(dev, "affine coupling + ActNorm + InvertibleConv")
+    return z_out, ldj_out
+
+
 def affine_coupling_nll(z, nn_out, scaling_factor, mask, ldj=None, length=None, channel_padding_mask=None, sums=None,
                         sigma=LOGISTIC_SIGMA, log_sigma=LOGISTIC_LOG_SIGMA, acc=None):
     """Last coupling layer + NLL assembly in one kernel: == affine_coupling(reverse=False) then prior_nll on its

@@ -79,6 +79,21 @@ int cnf_affine_coupling(const float* z, const float* nn_out, const float* scalin
                         const float* ldj_in, float* z_out, float* ldj_out,
                         int B, int N, int D, int reverse, int* flags, cnf_stream_t stream);
 
+/* CouplingLayer.forward of one flow step (coupling_layer.py:42-65) followed by the ActNormFlow and InvertibleConv of the NEXT step
+ * (activation_normalization.py:24-48, permutation_layers.py:106-136) in ONE pass — or, reverse != 0, the coupling's inverse followed
+ * by the inverted convolution and ActNorm of its own step (conv_weight = the inverse weight, as InvertibleConv._get_weight(inverse =
+ * True) hands it out): the order FlowModel walks the layers in either direction.  The coupling's output stays in LDS; z and the
+ * log-det are the bits of cnf_affine_coupling followed by cnf_actnorm_invconv, the [B,N,D] round trip between them is gone
+ * (S*: 17.2 + 9.7 us as two kernels).  pad / length are the pair's (the affine coupling ignores padding like the reference).
+ * D in {2, 3, 4, 6, 8}, N * D a multiple of 4, rows short enough for a wave tile, math mode 1; otherwise CNF_ERR_UNSUPPORTED with
+ * nothing launched (run the two entry points). */
+int cnf_affine_coupling_actconv(const float* z, const float* nn_out, const float* scaling_factor,
+                                const float* mask, int mask_rows, int mask_cols,
+                                const float* ldj_in, float* z_out, float* ldj_out,
+                                const float* an_bias, const float* an_scales, const float* conv_weight, const float* conv_sldj,
+                                const float* pad, const float* length,
+                                int B, int N, int D, int reverse, int* flags, cnf_stream_t stream);
+
 /* CouplingLayer.get_coup_params (coupling_layer.py:76-86): materialise s, t [B,N,D]. */
 int cnf_affine_params(const float* nn_out, const float* scaling_factor,
                       const float* mask, int mask_rows, int mask_cols,

@@ -1966,3 +1966,81 @@ def test_deferred_reductions_give_the_bits_of_the_immediate_ones():
     # after the flush the library is back to immediate reductions
     again = run(False)
     assert all(torch.equal(now[k], again[k]) for k in now)
+
+
+@pytest.mark.parametrize("B,N,D", [(256, 64, 6), (64, 16, 4), (40, 16, 2), (33, 20, 3), (16, 38, 6), (7, 5, 8), (130, 64, 6), (9, 11, 5), (4, 703, 2)])
+@pytest.mark.parametrize("with_sf", [True, False])
+def test_affine_coupling_actnorm_conv_fusion_is_bit_identical_to_the_chain(B, N, D, with_sf):
+    """cnf_affine_coupling_actconv: affine coupling + ActNorm + 1x1 convolution of the next flow step in one kernel (forward), the
+    coupling's inverse + the inverted convolution and ActNorm of its own step (reverse) — z and log-det torch.equal to
+    cnf_affine_coupling followed by cnf_actnorm_invconv, with padding and lengths, and against the oracle's three layers.
+    Shapes outside the fused kernel (D = 5; N * D odd; rows too long for a wave tile) take the two kernels: same results."""
+    gen = torch.Generator().manual_seed(B * 11 + N + D)
+    z = torch.randn(B, N, D, generator=gen)
+    nn_out = 0.5 * torch.randn(B, N, 2 * D, generator=gen)
+    sf = 0.1 * torch.randn(D, generator=gen) if with_sf else None
+    mask = O.channel_mask(D)
+    bias, scales = torch.randn(1, 1, D, generator=gen), 0.3 * torch.randn(1, 1, D, generator=gen)
+    w = torch.linalg.qr(torch.randn(D, D, generator=gen))[0].contiguous() + 0.05 * torch.randn(D, D, generator=gen)
+    sldj = torch.slogdet(w)[1]
+    w_inv = torch.inverse(w.double()).float().contiguous()
+    ln = torch.randint(1, N + 1, (B,), generator=gen); ln[0] = N
+    pad = O.length_mask(ln, N)
+    ldj0 = torch.randn(B, generator=gen)
+    for kw in ({}, {"channel_padding_mask": g(pad)}, {"length": g(ln.float())}, {"channel_padding_mask": g(pad), "length": g(ln.float())}):
+        for reverse, weight in ((False, w), (True, w_inv)):
+            zc, lc = ops().affine_coupling(g(z), g(nn_out), g(sf), g(mask), reverse=reverse, ldj=g(ldj0))
+            zp, lp = ops().actnorm_invconv(zc, g(bias), g(scales), g(weight), g(sldj), reverse=reverse, ldj=lc, **kw)
+            zf, lf = ops().affine_coupling_actconv(g(z), g(nn_out), g(sf), g(mask), g(bias), g(scales), g(weight), g(sldj), reverse=reverse,
+                                                   ldj=g(ldj0), **kw)
+            assert torch.equal(zf, zp) and torch.equal(lf, lp), (kw.keys(), reverse)
+    zo, lo = O.affine_coupling(z, nn_out, mask, sf, ldj=ldj0)
+    zo, lo = O.actnorm(zo, bias, scales, channel_padding_mask=pad, ldj=lo)
+    zo, lo = O.invconv(zo, w, sldj, channel_padding_mask=pad, ldj=lo)
+    zf, lf = ops().affine_coupling_actconv(g(z), g(nn_out), g(sf), g(mask), g(bias), g(scales), g(w), g(sldj), channel_padding_mask=g(pad), ldj=g(ldj0))
+    close(zf, zo, **ELEM); loglik_close(lf, lo)
+    ops().check_flags(torch.device("cuda"), "affine actconv fusion")
+
+
+def test_flow_model_fuses_affine_couplings_with_the_next_steps_pair():
+    """FlowModel (no grad): [ActNorm, conv, affine coupling] x 4 — every coupling but the last runs fused with the next step's
+    ActNorm + convolution (forward), every coupling with its own step's inverted pair (reverse); same bits as the layer-by-layer
+    pass, and the sampling direction closes the round trip."""
+    from categoricalnf_amd.layers.flows.activation_normalization import ActNormFlow
+    from categoricalnf_amd.layers.flows.coupling_layer import CouplingLayer
+    from categoricalnf_amd.layers.flows.flow_model import FlowModel
+    from categoricalnf_amd.layers.flows.permutation_layers import InvertibleConv
+    D, B, N = 6, 128, 16
+    torch.manual_seed(3)
+    mask = CouplingLayer.create_channel_mask(D)
+    mf = lambda c_out: nn.Sequential(nn.Linear(D, 32), nn.GELU(), nn.Linear(32, c_out))
+    layers = []
+    for _ in range(4):
+        layers += [ActNormFlow(D), InvertibleConv(D), CouplingLayer(D, mask, mf)]
+    flow = FlowModel(layers).cuda()
+    with torch.no_grad():
+        for p in flow.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    z = torch.randn(B, N, D, device="cuda")
+    calls = []
+    o = ops()
+    real = o._launch
+
+    def spy(dev, name, *a, **kw):
+        calls.append(name)
+        return real(dev, name, *a, **kw)
+    o._launch = spy
+    try:
+        with torch.no_grad():
+            zf, lf = flow(z)
+            zr, lr = flow(zf, reverse=True)
+            fused = list(calls)
+            o.FUSE_LAYERS = False
+            z1, l1 = flow(z)
+            zr1, lr1 = flow(z1, reverse=True)
+    finally:
+        o._launch = real
+        o.FUSE_LAYERS = True
+    assert fused.count("cnf_affine_coupling_actconv") == 3 + 4, fused
+    assert torch.equal(zf, z1) and torch.equal(lf, l1) and torch.equal(zr, zr1) and torch.equal(lr, lr1)
+    close(zr, z, rtol=1e-3, atol=1e-3)
