@@ -438,6 +438,19 @@ def kernel_table(lib, ops, dev, budget_ms=6.0):
         needed = B * N * ((D - D // 2) * (2 + 3 * K) * 4 + 8 * D) + 4 * B      # the transformed channels' parameter blocks only
         floor_b = line_floor_bytes(B, N, D, K)
 
+        # HBM bytes of the forward from the counters (profiles/traffic.json: FETCH_SIZE / WRITE_SIZE passes of tools/pmc_workload.py,
+        # calibrated on a known copy; tools/refresh_r06.sh), per launch, for this shape and layout — read from the committed file
+        try:
+            _tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        except Exception:
+            _tr = {}
+        pmc_key = {"configs[1]": "mixture_fwd", "S*": "mixture_fwd_Sstar"}[tag]
+
+        def pmc(compact_layout):
+            v = _tr.get(pmc_key + ("_compact" if compact_layout else "") + "_bytes_per_launch")
+            if v:
+                rows[-1].update(pmc_bytes=float(v), pmc_source="profiles/traffic.json (forward, fp32; FETCH_SIZE x2 + WRITE_SIZE)")
+
         def priced(ms):
             # `frac` prices all of nn_out (16 + 12 K bytes per element) although the kernel skips the blocks of the
             # channels that pass through: it is NOT a bandwidth (S* forward: 0.83-0.87 "of 8 TB/s" = 6.7-7 TB/s, above what the
@@ -466,6 +479,8 @@ def kernel_table(lib, ops, dev, budget_ms=6.0):
             lib.cnf_set_math_mode(mode)
             ms = row("mixture_coupling forward, %s" % what, S, alg, fwd, math_mode=mode)
             priced(ms)
+            if mode == 1:
+                pmc(False)
             if mode == 0 and K == 8:
                 fp64_ceiling(ms, False)
             for c in fwd:
@@ -512,6 +527,8 @@ def kernel_table(lib, ops, dev, budget_ms=6.0):
         for mode, what in ((1, "fp32 (default)"), (0, "fp64 (the reference's precision)")):
             lib.cnf_set_math_mode(mode)
             contract(row("mixture_coupling forward, compact parameter layout, %s" % what, S, needed, cfwd, math_mode=mode), alg)
+            if mode == 1:
+                pmc(True)
             for c in cfwd:
                 c()
             contract(row("mixture_coupling inverse (Newton), compact parameter layout, %s" % what, S, needed, cinv, math_mode=mode), alg)

@@ -31,14 +31,21 @@ srcs = [torch.randn(B * N * D * 4, generator=g, device=dev) for _ in range(R)]
 dsts = [torch.empty_like(srcs[0]) for _ in range(R)]
 for i in range(REP):
     dsts[i % R].copy_(srcs[i % R])
+# the fp32 mixture forward: configs[1] and S*, reference layout then compact layout — FOUR groups of REP launches of the same
+# kernel, in this order (tools/pmc_summarize.py tells them apart by dispatch order)
 K = 8
-Bm, Nm, Dm = 16384, 16, 4
-zm = [torch.randn(Bm, Nm, Dm, generator=g, device=dev) for _ in range(R)]
-nm = [0.5 * torch.randn(Bm, Nm, Dm * (2 + 3 * K), generator=g, device=dev) for _ in range(R)]
-mm = torch.tensor([[1., 1., 0., 0.]], device=dev)
-zmo, lmo = torch.empty_like(zm[0]), torch.empty(Bm, device=dev)
-mf = [ops.mixture_coupling_launch(zm[r], nm[r], mm, K, zmo, lmo) for r in range(R)]
-for i in range(REP):
-    mf[i % R]()
+del zs, nns, zo, srcs, dsts
+for (Bm, Nm, Dm) in ((16384, 16, 4), (16384, 64, 6)):
+    DAm = Dm - Dm // 2
+    mm = torch.tensor([[1.] * (Dm // 2) + [0.] * DAm], device=dev)
+    zm = [torch.randn(Bm, Nm, Dm, generator=g, device=dev) for _ in range(R)]
+    zmo, lmo = torch.empty_like(zm[0]), torch.empty(Bm, device=dev)
+    for width in (Dm * (2 + 3 * K), DAm * (2 + 3 * K)):
+        nm = [0.5 * torch.randn(Bm, Nm, width, generator=g, device=dev) for _ in range(R)]
+        mf = [ops.mixture_coupling_launch(zm[r], nm[r], mm, K, zmo, lmo) for r in range(R)]
+        for i in range(REP):
+            mf[i % R]()
+        torch.cuda.synchronize()
+        del nm, mf
 torch.cuda.synchronize()
 print("done")
