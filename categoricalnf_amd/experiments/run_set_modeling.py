@@ -64,6 +64,9 @@ def parse(argv=None):
     p.add_argument("--coupling_num_flows", type=int, default=8)
     p.add_argument("--coupling_mask_ratio", type=float, default=0.5)
     p.add_argument("--coupling_num_mixtures", type=int, default=8)
+    p.add_argument("--compact_params", action="store_true",
+                   help="the mixture couplings' sub-networks emit the transformed channels' parameter blocks only (the last Linear applies "
+                        "just those rows; same parameters and checkpoints): half the parameter traffic, no zero blocks in the backward")
     p.add_argument("--backend", default=None, help="torch.distributed backend (default: nccl = RCCL)")
     p.add_argument("--graph_step", action="store_true",
                    help="single process only: the whole training step (forward, HIP backward kernels, clipping, RAdam) is captured "
@@ -230,6 +233,9 @@ def _main(argv=None):
     optimum = (SetShufflingDataset.optimum_bpd(args.set_size) if args.dataset == "shuffling" else train_set.optimum_bpd())
     with (contextlib.nullcontext() if rank == 0 else contextlib.redirect_stdout(io.StringIO())):
         model = FlowSetModeling(model_params(args), data_cls).to(device)
+        if getattr(args, "compact_params", False):
+            n = sum(bool(layer.enable_compact_params()) for layer in model.flow_layers if hasattr(layer, "enable_compact_params"))
+            say("[#] --compact_params: %d mixture couplings on the compact parameter layout" % n)
     rng = np.random.RandomState(args.seed + 1000 * rank)           # every rank draws different training sets
     per_rank = max(1, args.batch_size // world)
 

@@ -606,8 +606,9 @@ def _set_model(meta):
     return FlowSetModeling(params, SetShufflingDataset), SetShufflingDataset
 
 
+@pytest.mark.parametrize("compact", [False, True])
 @pytest.mark.parametrize("golden", ["set_shuffling_model.npz", "set_shuffling_trained.npz"])
-def test_set_shuffling_trained_model_bits_per_dim(golden):
+def test_set_shuffling_trained_model_bits_per_dim(golden, compact):
     """A FlowSetModeling trained WITH THE REFERENCE for 6000 CPU iterations (CNF_TRAIN_ITERS=6000, 3.59 bpd; oracle/gen_set_shuffling_golden.py)
     and one trained by this package's driver on an MI355X for 50000 iterations (2.94 bpd, sharp mixtures) and evaluated
     by the REFERENCE on the CPU (oracle/gen_set_shuffling_trained_golden.py): same weights on the HIP path must give
@@ -621,6 +622,11 @@ def test_set_shuffling_trained_model_bits_per_dim(golden):
     model, dataset = _set_model(meta)
     model.load_state_dict({k[3:]: torch.from_numpy(np.array(data[k])) for k in data.files if k.startswith("sd_")})
     model.cuda().eval()
+    if compact:
+        # the same reference-trained weights with every mixture coupling on the compact parameter layout (the last Linear of its
+        # Transformer sub-network applies the transformed channels' rows only): the reference's numbers all the same
+        on = [layer.enable_compact_params() for layer in model.flow_layers if hasattr(layer, "enable_compact_params")]
+        assert on and all(on)
     S = meta["set_size"]
     x = torch.from_numpy(data["x256"]).cuda()
     ln = torch.full((x.size(0),), S, dtype=torch.long, device="cuda")
