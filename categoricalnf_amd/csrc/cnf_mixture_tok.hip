@@ -905,6 +905,21 @@ bool make_tok_geom(const MixArgs& a, int kt, int force_g, TokGeom& gm, int& G, s
             }
         }
     }
+    {
+        // (round 6) more rows per tile where that fills the passes better and still leaves two rounds of waves: S* (64-token rows,
+        // 21 tokens per pass) 1 row = 21 + 21 + 21 + 1 tokens -> 2 rows = 7 passes, 87 % full, 8192 tiles — fp32 forward / inverse
+        // 108 / 124 -> 104 / 119 us, at the reference's precision 175 / 254 -> 156 / 231 (3 rows: 5462 tiles, 1.33 rounds, slower;
+        // 4 rows: one round, the same as 2; profiles/r06_mixture_tile_rows.txt)
+        const auto eff_of = [&](int r) { const int tk = r * a.N; return (double)tk / (double)(((tk + tpp - 1) / tpp) * tpp); };
+        double best = eff_of(rw) + 0.05;
+        const int rcap = std::min(std::min(kMaxRowSlots, a.B), std::max(1, 65535 / std::max(a.N, 1)));
+        for (int r = rw + 1; r <= rcap && ((long)a.B + r - 1) / r >= 8192; ++r) {
+            if (eff_of(r) > best) {
+                best = eff_of(r);
+                rw = r;
+            }
+        }
+    }
     const long tiles0 = ((long)a.B + rw - 1) / rw;
     gm.split = 0; gm.rw = rw; gm.S = 1; gm.ntiles = tiles0;
     gm.ppr = ppr;
