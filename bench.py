@@ -533,6 +533,13 @@ def kernel_table(lib, ops, dev, budget_ms=6.0):
                 c()
             contract(row("mixture_coupling inverse (Newton), compact parameter layout, %s" % what, S, needed, cinv, math_mode=mode), alg)
         lib.cnf_set_math_mode(1)
+        # as the module calls it: with its scaling_factor / mixture_scaling_factor parameters (a tanh bound per log-scale: two more
+        # transcendentals per mixture; every row above passes none, like rounds 1-5)
+        sfm, msfm = rn(D, k=0.1), rn(D, K, k=0.1)
+        for lay, nn_l, nb in (("reference", nns, needed), ("compact", nnc, needed)):
+            bounded = [ops.mixture_coupling_launch(zs[r], nn_l[r], mask, K, zf[r], lf, scaling_factor=sfm, mixture_scaling_factor=msfm) for r in range(R)]
+            contract(row("mixture_coupling forward with the scaling-factor bounds, %s layout, fp32" % lay, S, nb, bounded), alg)
+            rows[-1]["layout"] = lay
         for c in cfwd:
             c()
         contract(row("mixture_coupling + ActNorm + 1x1 conv of the next step, compact parameter layout", S, needed,
