@@ -602,14 +602,15 @@ def read_traffic(path=None):
 
 
 def rocprof_cross_check(kern_ms):
-    """The committed rocprofv3 summary of this command (profiles/r05_bench_kernel_stats.csv — the newest round's file that exists, `rocprofv3 --kernel-trace --stats
+    """The committed rocprofv3 summary of this command (profiles/r06_bench_kernel_stats.csv — the newest round's file that exists, `rocprofv3 --kernel-trace --stats
     -- python bench.py --no-cpu-baseline` on these kernel sources' round): its AverageNs for the dominant kernel next to this
     run's `kernel_ms`.  A static file, reported for the reader's convenience — None when it is absent."""
     import csv
-    path = next((f for f in (os.path.join(ROOT, "profiles", "r%02d_bench_kernel_stats.csv" % r) for r in (5, 4, 3)) if os.path.exists(f)), "")
+    path = next((f for f in (os.path.join(ROOT, "profiles", "r%02d_bench_kernel_stats.csv" % r) for r in (6, 5, 4, 3)) if os.path.exists(f)), "")
     try:
         for row in csv.DictReader(open(path)):
-            if "affine_coupling_kernel<4, 2, true, false, true, 1>" in row["Name"]:
+            # (<VEC, U, HAS_SF, REVERSE, FAST, NLL[, ED]>: the epilogue parameter ED exists since round 6)
+            if "affine_coupling_kernel<4, 2, true, false, true, 1>" in row["Name"] or "affine_coupling_kernel<4, 2, true, false, true, 1, 0>" in row["Name"]:
                 avg_ms = float(row["AverageNs"]) * 1e-6
                 return {"file": os.path.relpath(path, ROOT), "rocprofv3_average_kernel_ms": avg_ms, "calls": int(row["Calls"]),
                         "this_run_over_rocprofv3": kern_ms / avg_ms}
