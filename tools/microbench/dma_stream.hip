@@ -61,6 +61,26 @@ __global__ __launch_bounds__(256) void reader(const char* buf, long bytes, int p
             }
             __builtin_amdgcn_s_waitcnt(0xC07F);
             __builtin_amdgcn_wave_barrier();
+        } else if (MODE == 5) {
+            // copy with the stores issued BEHIND the next pass's DMA: the wait for that DMA (in-order counter) then leaves this
+            // pass's INSTR stores outstanding instead of draining them — does a wave that both loads and stores lose time waiting for
+            // its stores' acknowledgements?
+            if (p == 0) dma(stage, off);
+            constexpr int kLeave = INSTR;                                  // stores of the previous pass still in flight
+            if (p == 0) __builtin_amdgcn_s_waitcnt(0x0F70);
+            else __builtin_amdgcn_s_waitcnt((kLeave & 15) | ((kLeave >> 4) << 14) | (7 << 4) | (15 << 8));
+            __builtin_amdgcn_wave_barrier();
+            f4 v[INSTR];
+#pragma unroll
+            for (int i = 0; i < INSTR; ++i) v[i] = *reinterpret_cast<const f4*>(stage + i * 1024 + lane * 16);
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_wave_barrier();
+            if (p + 1 < passes) dma(stage, off + INSTR * 1024);
+#pragma unroll
+            for (int i = 0; i < INSTR; ++i) {
+                f4* d = reinterpret_cast<f4*>(dst + off + i * 1024 + lane * 16);
+                if (NT) __builtin_nontemporal_store(v[i], d); else *d = v[i];
+            }
         } else if (MODE == 1) {
             dma(stage, off);
             __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -85,7 +105,7 @@ template <int MODE, int INSTR, int NT>
 static void run(const char* bufs[3], long bytes, int passes, float* out, int extra_lds, const char* what, char* dsts[3] = nullptr) {
     const long chunk = (long)passes * INSTR * 1024;
     const unsigned grid = (unsigned)((bytes / chunk + 3) / 4);
-    const size_t lds = ((MODE == 0 || MODE == 3) ? 0 : (size_t)4 * (MODE == 2 ? 2 : 1) * INSTR * 1024) + extra_lds;
+    const size_t lds = ((MODE == 0 || MODE == 3) ? 0 : (size_t)4 * (MODE == 2 ? 2 : 1) * INSTR * 1024) + extra_lds;      // (modes 4, 5: one stage)
     hipEvent_t a, b;
     CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     for (int r = 0; r < 3; ++r) hipLaunchKernelGGL((reader<MODE, INSTR, NT>), dim3(grid), dim3(256), lds, 0, bufs[r], bytes, passes, out, 0, dsts ? dsts[r] : nullptr);
@@ -133,6 +153,9 @@ int main() {
         run<4, 7, 0>(bufs, bytes, passes, out, 0, "copy (DMA, LDS, stores)", dsts);
         run<4, 7, 1>(bufs, bytes, passes, out, 0, "copy, nt loads and stores", dsts);
         run<4, 3, 1>(bufs, bytes, passes * 2, out, 0, "copy, nt loads and stores", dsts);
+        run<5, 7, 0>(bufs, bytes, passes, out, 0, "copy, stores behind next DMA", dsts);
+        run<5, 7, 1>(bufs, bytes, passes, out, 0, "copy, stores behind next DMA, nt", dsts);
+        run<5, 3, 1>(bufs, bytes, passes * 2, out, 0, "copy, stores behind next DMA, nt", dsts);
     }
     for (int passes : {2, 8}) {
         run<0, 14, 1>(bufs, bytes, passes, out, 0, "VGPR loads, nt");
