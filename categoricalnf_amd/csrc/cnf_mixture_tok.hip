@@ -617,6 +617,9 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
                 // rare: a tail or an underflow.  The reference's fp64 arithmetic (u, then 1 - u by subtraction,
                 // safe_log clamps; :100-123, :217-233) on the staged row, one mixture at a time — rolled loops
                 // keep this branch's registers below the fast path's.
+#ifdef CNF_MIXFWD_NOTAIL
+                of = 0.f;       // A/B build: what the fast path alone needs in registers (66 VGPRs at K = 8 against 112)
+#else
                 const double xd = (double)x;
                 double sed = 0.0, cdfd = 0.0, pdfd = 0.0;
 #pragma clang loop unroll(disable)
@@ -632,6 +635,7 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
                     pdfd += wd * isd * (ed * rd * rd);
                 }
                 wide_tail(sed, cdfd, pdfd);
+#endif
             }
             }
             if (a.pad_output) of = of * pv;
