@@ -101,7 +101,7 @@ SIGNATURES = {
 _PLAIN = {"cnf_abi_version": ([], _i), "cnf_last_error": ([], ctypes.c_char_p),
           "cnf_set_tile_chunks": ([_i], None), "cnf_set_unroll": ([_i], None),
           "cnf_set_math_mode": ([_i], None), "cnf_set_inverse_mode": ([_i], None), "cnf_set_mixture_tile": ([_i], None),
-          "cnf_set_bwd_tile": ([_i, _i], None), "cnf_set_actnorm_bwd_tiles": ([_i], None), "cnf_set_affine_bwd_tiles": ([_i], None), "cnf_set_mixture_bwd_waves": ([_i], None),
+          "cnf_set_bwd_tile": ([_i, _i], None), "cnf_set_actnorm_bwd_tiles": ([_i], None), "cnf_set_affine_bwd_tiles": ([_i], None), "cnf_set_mixture_bwd_waves": ([_i], None), "cnf_set_mixture_bwd_big_mb": ([_i], None),
           "cnf_bwd_workspace_floats": ([_i], _i64), "cnf_bwd_defer_begin": ([], None),
           "cnf_mixture_workspace_bytes": ([_i], _i64), "cnf_encoder_workspace_floats": ([_i, _i, _i, _i], _i64),
           "cnf_encoder_bwd_tiled_workspace_floats": ([_i, _i, _i, _i], _i64), "cnf_set_mixture_kernel": ([_i], None), "cnf_set_encoder_kernel": ([_i], None), "cnf_set_encoder_bwd_kernel": ([_i], None), "cnf_encoder_pair_launches": ([], _i64),
@@ -137,7 +137,12 @@ def load():
         fn.argtypes = argtypes
         fn.restype = _i
     for name, (argtypes, restype) in _PLAIN.items():
-        fn = getattr(lib, name)
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            if os.environ.get("CNF_LIB_OVERRIDE"):      # an A/B build of older sources may lack a newer tuning knob
+                continue
+            raise CnfLibraryError("%s does not export %s (stale build?)" % (LIB_PATH, name))
         fn.argtypes = argtypes
         fn.restype = restype
     runtimes = set(re.findall(r"\S*libamdhip64\S*", open("/proc/self/maps").read()))

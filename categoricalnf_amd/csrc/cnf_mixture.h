@@ -69,6 +69,7 @@ bool launch_mixture_tok(MixArgs& a, hipStream_t st, int force_g, bool x64 = fals
 void set_mixture_split_waves(int w);
 void set_mixture_whole_tokens(int on);
 void set_mixture_nt_mb(int mb);
+int mixture_nt_mb();
 // cnf_mixture_tok_bwd.hip
 bool launch_mixture_tok_bwd(MixArgs& a, const float* g_zout, const float* g_ldj, float* g_z, float* g_nn,
                             float* g_sf, float* g_msf, float* workspace, hipStream_t st, int force_g);

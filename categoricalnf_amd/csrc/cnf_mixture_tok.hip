@@ -820,6 +820,7 @@ static std::atomic<int> g_split_waves{4096};      // waves a split launch aims a
 void set_mixture_split_waves(int w) { g_split_waves = w; }
 static std::atomic<int> g_mix_nt{64};            // MB of staged parameters above which the DMA loads are nontemporal (0 = never)
 void set_mixture_nt_mb(int mb) { g_mix_nt = mb < 0 ? 64 : mb; }
+int mixture_nt_mb() { return g_mix_nt.load(); }
 static std::atomic<int> g_whole_tokens{1};        // cnf_set_mixture_whole_tokens: A/B switch of the whole-token staging
 void set_mixture_whole_tokens(int on) { g_whole_tokens = on ? 1 : 0; }
 static bool whole_tokens_enabled() { return g_whole_tokens != 0; }

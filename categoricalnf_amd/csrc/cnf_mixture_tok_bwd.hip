@@ -25,6 +25,17 @@
 namespace cnf {
 
 constexpr int kTokBwdGrid = 1024;       // rows of the partials buffer (cnf_bwd_workspace_floats)
+#ifndef CNF_MIXBWD_MERGED
+#define CNF_MIXBWD_MERGED 1
+#endif
+#ifndef CNF_MIXBWD_DMA_NT_SPANS
+#define CNF_MIXBWD_DMA_NT_SPANS 1
+#endif
+#ifndef CNF_MIXBWD_NT_MB
+#define CNF_MIXBWD_NT_MB 128
+#endif
+constexpr int kTokBwdNtMB = CNF_MIXBWD_NT_MB;      // MB of gradient rows above which the write-back is nontemporal
+static std::atomic<int> g_tok_bwd_big_mb{kTokBwdNtMB};
 static std::atomic<int> g_tok_bwd_w4{-1};
 static inline int tok_bwd_w4() { return g_tok_bwd_w4.load(std::memory_order_relaxed); }
 
@@ -38,6 +49,10 @@ struct TokBwdArgs {
                               // the span starts or ends on an odd multiple of 8 bytes (u_lo .. hi_half below)
     int u_lo, nu, ntu;        // mode 24: first 16-byte unit of a token the span touches, units it touches, units per token
     int lo_half, hi_half;     // mode 24: the span's first / last unit is half zeros (an untransformed block's bytes)
+    int wb_nt;                // nontemporal write-back (large launches whose write-back instructions cover whole contiguous kilobytes)
+    int merged;               // reference layout, modes 16 / 24: ONE loop writes the pass's tokens in address order, zero blocks included
+    int src_stride;           // merged: bytes between the staged spans of consecutive tokens
+    FastDiv div_ntu;          // merged: by ntu
     FastDiv div_nu, div_nz;   // mode 24: by nu; by ntu - nu
     int nacc;                 // run-time K: lane-private accumulator slots = 1 + ceil(K / G)
     int lacc_off;             // byte offset of the lane-private accumulators / the reduction scratch in dynamic LDS
@@ -60,30 +75,24 @@ __device__ __forceinline__ void bound_grads_f(float raw, const BoundTab& b, floa
     d_sf = b.f >= 1.f ? b.f * (th - uu * sech2) : b.f * th;
 }
 
-// Stores of the gradient rows and zero blocks (g_nn is written once and not read again by this kernel): -DCNF_MIXBWD_NT = nontemporal
-// (A/B build, profiles/r05_mixture_bwd_floor.txt)
+// Stores of the gradient rows and zero blocks (g_nn is written once and not read again by this kernel).  `nt` = nontemporal: set by
+// the host for launches whose every write-back instruction covers whole contiguous kilobytes (round 6, profiles/
+// r06_mixture_bwd_floor.txt section 4: S* compact 239 -> 188 us; on write-backs whose cache lines are completed by a SECOND
+// instruction — the reference layout's zero blocks written by a loop of their own — the same hint costs 10-30 %, which is why the
+// reference layout writes its tokens in address order, zeros included, in one loop)
 typedef float mb_f4 __attribute__((ext_vector_type(4)));
 typedef float mb_f2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void wb_store(float4* p, float4 v) {
-#ifdef CNF_MIXBWD_NT
-    __builtin_nontemporal_store(mb_f4{v.x, v.y, v.z, v.w}, reinterpret_cast<mb_f4*>(p));
-#else
-    *p = v;
-#endif
+__device__ __forceinline__ void wb_store(float4* p, float4 v, bool nt = false) {       // (nt: constant false outside the BIG builds)
+    if (nt) __builtin_nontemporal_store(mb_f4{v.x, v.y, v.z, v.w}, reinterpret_cast<mb_f4*>(p));
+    else *p = v;
 }
-__device__ __forceinline__ void wb_store(float2* p, float2 v) {
-#ifdef CNF_MIXBWD_NT
-    __builtin_nontemporal_store(mb_f2{v.x, v.y}, reinterpret_cast<mb_f2*>(p));
-#else
-    *p = v;
-#endif
+__device__ __forceinline__ void wb_store(float2* p, float2 v, bool nt = false) {
+    if (nt) __builtin_nontemporal_store(mb_f2{v.x, v.y}, reinterpret_cast<mb_f2*>(p));
+    else *p = v;
 }
-__device__ __forceinline__ void wb_store(float* p, float v) {
-#ifdef CNF_MIXBWD_NT
-    __builtin_nontemporal_store(v, p);
-#else
-    *p = v;
-#endif
+__device__ __forceinline__ void wb_store(float* p, float v, bool nt = false) {
+    if (nt) __builtin_nontemporal_store(v, p);
+    else *p = v;
 }
 
 // g_z of an element the streaming kernel left to the fix-up launch: a quiet NaN with this payload
@@ -272,7 +281,7 @@ __global__ __launch_bounds__(kBlock) void mix_reduce_partials_fix_kernel(const f
     }
 }
 
-template <int KT, int G>
+template <int KT, int G, bool BIG>
 __device__ __forceinline__ void mixture_tok_bwd_body(const MixArgs& a, const TokGeom& gm, const TokBwdArgs& w) {
     static_assert(G == 1 || KT == 0, "several lanes per item only with a run-time K");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -526,7 +535,9 @@ __device__ __forceinline__ void mixture_tok_bwd_body(const MixArgs& a, const Tok
                 }
             } else if (valid) {
                 // padded token / masked item: its parameters get no gradient
+#ifndef CNF_MIXBWD_NOZERO          // (A/B build with CNF_MIXBWD_ABLATE: the staged rows go back as they came — no LDS row writes)
                 for (int i = sub; i < P; i += G) my[i] = 0.f;
+#endif
             }
 #if defined(CNF_MIXBWD_ABLATE) && CNF_MIXBWD_ABLATE + 0 >= 3
             if (g_x == 12345.678f)           // A/B build: no stores of g_z either
@@ -543,6 +554,9 @@ __device__ __forceinline__ void mixture_tok_bwd_body(const MixArgs& a, const Tok
                 const int total_b = npt * span_b;
                 float* gspan0 = gnn_tile + ((size_t)tp * a.nn_D + (gm.d0 - a.nn_c0)) * P;       // first token's span in g_nn
                 const uintptr_t src0 = reinterpret_cast<uintptr_t>(span0 + (size_t)tp * gm.tokstride);
+                // BIG (large launches, one lane per item): nontemporal stores, the reference layout in address order — a build of its
+                // own, so that the ordinary write-back's loops stay as they were (a run-time flag in them cost configs[1] 11 %)
+                const bool nt = BIG && w.wb_nt != 0;
                 if (w.wb_align == 32) {
                     // the pass is ONE contiguous span (compact layout, or no mask) whose token size is not a multiple of 16 bytes
                     // (S* compact: 312-byte tokens; the language model's 1860): 16-byte stores on the span's own 16-byte grid — nn and
@@ -554,9 +568,27 @@ __device__ __forceinline__ void mixture_tok_bwd_body(const MixArgs& a, const Tok
                     if (lane * 4 < hb) wb_store(reinterpret_cast<float*>(gdst + lane * 4), *reinterpret_cast<const float*>(stage_b + ph + lane * 4));
                     const int body = (total_b - hb) & ~15;
                     for (int b = hb + lane * 16; b < hb + body; b += kWave * 16)
-                        wb_store(reinterpret_cast<float4*>(gdst + b), *reinterpret_cast<const float4*>(stage_b + ph + b));
+                        wb_store(reinterpret_cast<float4*>(gdst + b), *reinterpret_cast<const float4*>(stage_b + ph + b), nt);
                     const int tb = hb + body + lane * 4;
                     if (tb < total_b) wb_store(reinterpret_cast<float*>(gdst + tb), *reinterpret_cast<const float*>(stage_b + ph + tb));
+                } else if (BIG && w.merged) {
+                    // reference layout, everything on the tokens' 16-byte grid: the pass's tokens are written in address order — a
+                    // unit inside the transformed span comes from the stage (a unit it shares with an untransformed block takes that
+                    // block's zeros along), every other unit is zeros — so that each store instruction covers 1 KiB of whole lines
+                    const int total_u = npt * w.ntu;
+                    char* gtok = reinterpret_cast<char*>(gnn_tile + (size_t)tp * a.nn_D * P);
+                    for (int e = lane; e < total_u; e += kWave) {
+                        const int s = (int)fdiv((uint32_t)e, w.div_ntu);
+                        const int ui = e - s * w.ntu;
+                        const int k = ui - w.u_lo;
+                        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (k >= 0 && k < w.nu) {
+                            v = *reinterpret_cast<const float4*>(stage_b + s * w.src_stride + 16 * k);
+                            if (k == 0 && w.lo_half) v.x = v.y = 0.f;
+                            if (k == w.nu - 1 && w.hi_half) v.z = v.w = 0.f;
+                        }
+                        wb_store(reinterpret_cast<float4*>(gtok + (size_t)s * gm.tokstride + 16 * ui), v, nt);
+                    }
                 } else if (w.wb_align == 24) {
                     // S* (D = 6: the span is bytes 312..623 of a 624-byte token): 8-byte stores were twice the instructions at half
                     // the width.  A token's base is 16-byte aligned, so the span is written as the 16-byte units it touches — the unit
@@ -578,7 +610,7 @@ __device__ __forceinline__ void mixture_tok_bwd_body(const MixArgs& a, const Tok
                         const int lpos = gm.contig ? (int)(src0 & 15) + s * gm.tokstride + r
                                                    : s * gm.slot + (int)((src0 + (uintptr_t)s * gm.tokstride) & 15) + r;
                         const float4 v = *reinterpret_cast<const float4*>(stage_b + lpos);
-                        wb_store(reinterpret_cast<float4*>(reinterpret_cast<char*>(gspan0) + (size_t)s * gm.tokstride + r), v);
+                        wb_store(reinterpret_cast<float4*>(reinterpret_cast<char*>(gspan0) + (size_t)s * gm.tokstride + r), v, nt);
                     }
                 } else if (w.wb_align == 8) {
                     for (int b = lane * 8; b < total_b; b += kWave * 8) {
@@ -622,7 +654,7 @@ __device__ __forceinline__ void mixture_tok_bwd_body(const MixArgs& a, const Tok
                     gz_tile[(size_t)tl2 * a.D + c] = v;
                 }
             }
-            if (gm.ncopy > 0 && a.nn_D == a.D) {
+            if (gm.ncopy > 0 && a.nn_D == a.D && !(BIG && w.merged)) {
                 // zeros for the parameter blocks of the untransformed channels, as wide as the write-back
                 const int ncp_b = gm.ncopy * P * 4;            // bytes of untransformed parameter blocks per token
                 const int head_b = gm.d0 * P * 4, span_b2 = gm.DA * P * 4;
@@ -689,20 +721,24 @@ __device__ __forceinline__ void mixture_tok_bwd_body(const MixArgs& a, const Tok
     }
 }
 
-template <int KT, int G>
+template <int KT, int G, bool BIG = false>
 __global__ __launch_bounds__(kBlock) void mixture_tok_bwd_kernel(MixArgs a, TokGeom gm, TokBwdArgs w) {
-    mixture_tok_bwd_body<KT, G>(a, gm, w);
+    mixture_tok_bwd_body<KT, G, BIG>(a, gm, w);
 }
 // the same kernel held to 128 VGPRs (4 waves per SIMD): a few registers of scratch buy twice the resident waves, which is
 // what large launches are short of (selected by size in launch_mixture_tok_bwd; measured in profiles/r04_sweep_mixture_bwd.txt)
 template <int KT, int G>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void mixture_tok_bwd_kernel_w4(MixArgs a, TokGeom gm, TokBwdArgs w) {
-    mixture_tok_bwd_body<KT, G>(a, gm, w);
+    mixture_tok_bwd_body<KT, G, false>(a, gm, w);
 }
 
 }  // namespace cnf
 
 using namespace cnf;
+
+extern "C" void cnf_set_mixture_bwd_big_mb(int megabytes) {
+    cnf::g_tok_bwd_big_mb.store(megabytes < 0 ? cnf::kTokBwdNtMB : megabytes, std::memory_order_relaxed);
+}
 
 extern "C" void cnf_set_mixture_bwd_waves(int mode) {
     if (mode >= -1 && mode <= 7) cnf::g_tok_bwd_w4.store(mode, std::memory_order_relaxed);
@@ -772,6 +808,36 @@ static bool launch_mixture_tok_bwd_with(MixArgs& a, const float* g_zout, const f
     }
     else if ((reinterpret_cast<uintptr_t>(g_nn) & 7) == 0 && span_b % 8 == 0 && gm.tokstride % 8 == 0 && first_b % 8 == 0) w.wb_align = 8;
     else w.wb_align = 4;
+    // (modes 1 and 5-7: the builds held to 4 waves per SIMD — K = 8 unrolled: 160 -> 128 VGPRs, 34 of them spilled; no difference for
+    // the rolled kernels, which fit anyway)
+    const int w4_knob = tok_bwd_w4();
+    // (round 6: with the copied-through gradients prefetched the rolled kernels with 2 / 4 lanes per item need 136 VGPRs as compiled
+    // freely — three waves per SIMD; their builds held to 128, 5 registers spilled, keep the fourth wave and are the default)
+    const bool w4 = w4_knob == 1 || w4_knob >= 5 || (w4_knob < 0 && kt == 0 && G > 1);
+    // Large launches (one lane per item, more than kTokBwdNtMB of gradient rows — past what the memory-side cache absorbs; sweep in
+    // profiles/r06_mixture_bwd_floor.txt section 4): nontemporal DMA loads and a nontemporal write-back whose every instruction
+    // covers whole contiguous kilobytes — passes that are one contiguous span (compact layout, no mask) as they are; the reference
+    // layout on the tokens' 16-byte grid by ONE address-ordered loop over gradient spans and zero blocks.  cnf_set_mixture_nt_mb(0)
+    // switches all of it off.
+    bool big = false;
+    {
+        const size_t gnn_bytes = (size_t)a.B * a.N * a.nn_D * P * sizeof(float);
+        // (its kernels: the rolled one and the unrolled K = 16 one — the two that large launches take by default)
+        big = G == 1 && (kt == 0 || kt == 16) && !w4 && mixture_nt_mb() != 0 && gnn_bytes > ((size_t)g_tok_bwd_big_mb.load(std::memory_order_relaxed) << 20);
+        if (big && CNF_MIXBWD_MERGED && gm.ncopy > 0 && a.nn_D == a.D && (w.wb_align == 16 || w.wb_align == 24) &&
+            gm.TPP * (gm.tokstride / 16) < 65536) {
+            w.merged = 1;
+            if (w.wb_align == 16) {
+                w.u_lo = first_b / 16; w.nu = span_b / 16; w.ntu = gm.tokstride / 16;
+                w.lo_half = w.hi_half = 0;
+            }
+            w.src_stride = gm.contig ? gm.tokstride : gm.slot;
+            w.div_ntu = make_fastdiv((uint32_t)w.ntu);
+        }
+        const bool whole_passes = w.merged || w.wb_align == 32 || (w.wb_align == 16 && gm.contig && span_b == gm.tokstride);
+        w.wb_nt = (big && whole_passes) ? 1 : 0;
+        gm.nt = (big && (w.wb_nt || CNF_MIXBWD_DMA_NT_SPANS)) ? 1 : 0;
+    }
     w.nunits = gm.split ? (long)a.B * gm.S * kWavesPerBlock : gm.ntiles;
     w.div_ncp = make_fastdiv((uint32_t)std::max(gm.ncopy * P * 4 / (w.wb_align == 24 ? 8 : w.wb_align), 1));        // zero-fill units per token
     w.div_span = make_fastdiv((uint32_t)span_b);
@@ -783,18 +849,14 @@ static bool launch_mixture_tok_bwd_with(MixArgs& a, const float* g_zout, const f
     w.wave_flags = reinterpret_cast<int*>(workspace + (size_t)2 * kTokBwdGrid * PP);
     w.block_flags = w.wave_flags + kWavesPerBlock * kTokBwdGrid;
     const dim3 g(grid), b(kBlock);
-    // (modes 1 and 5-7: the builds held to 4 waves per SIMD — K = 8 unrolled: 160 -> 128 VGPRs, 34 of them spilled; no difference for
-    // the rolled kernels, which fit anyway)
-    const int w4_knob = tok_bwd_w4();
-    // (round 6: with the copied-through gradients prefetched the rolled kernels with 2 / 4 lanes per item need 136 VGPRs as compiled
-    // freely — three waves per SIMD; their builds held to 128, 5 registers spilled, keep the fourth wave and are the default)
-    const bool w4 = w4_knob == 1 || w4_knob >= 5 || (w4_knob < 0 && kt == 0 && G > 1);
 #define TOK_BWD(KT_, G_)                                                                        \
     do {                                                                                        \
         if (w4) CNF_LAUNCH((mixture_tok_bwd_kernel_w4<KT_, G_>), g, b, lds, st, a, gm, w);      \
         else CNF_LAUNCH((mixture_tok_bwd_kernel<KT_, G_>), g, b, lds, st, a, gm, w);            \
     } while (0)
-    if (kt == 4) TOK_BWD(4, 1);
+    if (big && kt == 16) CNF_LAUNCH((mixture_tok_bwd_kernel<16, 1, true>), g, b, lds, st, a, gm, w);
+    else if (big) CNF_LAUNCH((mixture_tok_bwd_kernel<0, 1, true>), g, b, lds, st, a, gm, w);
+    else if (kt == 4) TOK_BWD(4, 1);
     else if (kt == 8) TOK_BWD(8, 1);
     else if (kt == 16) TOK_BWD(16, 1);
     else if (G == 1) TOK_BWD(0, 1);
@@ -814,7 +876,7 @@ bool launch_mixture_tok_bwd(MixArgs& a, const float* g_zout, const float* g_ldj,
     // kernel (round 4) the ROLLED run-time-K kernel — ~100 VGPRs, 5 waves per SIMD, lane-private LDS sums — beats the unrolled
     // register-slot kernels (K = 8: 160 VGPRs) at every measured shape: S* 357 -> 331-340 us, configs[1] 59.4 -> 55, Zinc edges
     // 79 -> 54, Zinc nodes 35 -> 26, graph colouring (K = 16) 32 -> 23, a 1024-set training batch 23 -> 17-18.  Lanes per item G
-    // by the amount of work: one lane per item from ~2 M transformed elements on (two with 8 or more mixtures), two from ~400 k, four below (more waves for
+    // by the amount of work: one lane per item from ~400 k transformed elements on, four below (more waves for
     // small launches); K > 32 needs four for its stage to fit.  Modes 0 / 1 keep the unrolled kernels (natural registers / held
     // to 4 waves per SIMD) for A/B runs, 2-4 force G = 1 / 2 / 4.
     int kt = 0;
@@ -838,7 +900,14 @@ bool launch_mixture_tok_bwd(MixArgs& a, const float* g_zout, const float* g_ldj,
         // item from ~400 k transformed elements on — configs[1] 60.5 against 63 us — except the reference layout at S* size with 8
         // or more mixtures, 316-320 us with two lanes against 338-345; the compact layout takes one lane there: 231-235 against 250)
         const bool compact = a.nn_D != a.D;
+        // (later in round 6, section 4 of the same file: with the reference layout's tokens written in address order by nontemporal
+        // stores one lane per item wins there too — S* 280 us against 334-343 with two lanes, 316-327 before)
+#ifdef CNF_MIXBWD_OLD_RULE          // A/B build (with -DCNF_MIXBWD_NT_MB=100000000: the backward as it was before the streaming write-back)
         int g = items >= 2000000L ? ((a.K >= 8 && !compact) ? 2 : 1) : (items >= 400000L ? 1 : 4);
+#else
+        (void)compact;
+        int g = items >= 400000L ? 1 : 4;
+#endif
         if (a.K > 32) g = 4;
         while (g > 1 && g > a.K) g >>= 1;
         // the rule's G, or the next one whose stage fits LDS

@@ -50,6 +50,12 @@ void cnf_set_affine_bwd_tiles(int mode);
  * per SIMD), the defaults until round 4.  A/B knob; same gradients up to the order of the additions.  No reference counterpart. */
 void cnf_set_mixture_bwd_waves(int mode);
 
+/* fp32 mixture-coupling backward: megabytes of parameter-gradient rows above which a one-lane-per-item launch streams — nontemporal DMA
+ * loads, nontemporal write-back, the reference layout's tokens written in address order with their zero blocks (default 128, the size
+ * past which the memory-side cache no longer absorbs the rows; < 0 restores it; cnf_set_mixture_nt_mb(0) switches streaming off
+ * altogether).  Same gradients bit for bit either way; the tests set 0 to run the streaming write-back on small shapes. */
+void cnf_set_mixture_bwd_big_mb(int megabytes);
+
 /* Kernel timing bound to the dispatch (bench.py's `roofline`; a timed launch costs ~4 us of queue time; the reference has no counterpart — its
  * only clock is the host-side time_per_step tracker, general/train.py:147-157).  cnf_prof_arm(n): the next n
  * kernel launches made by this host thread through this library carry their dispatch's own start / stop

@@ -705,6 +705,60 @@ def test_mixture_backward_kernel_variants_agree(B, N, D, K):
         lib.cnf_set_mixture_bwd_waves(-1)
 
 
+@pytest.mark.parametrize("compact", [False, True])
+@pytest.mark.parametrize("B,N,D,K,pad_last", [(64, 16, 4, 8, False), (33, 17, 6, 4, True), (40, 64, 6, 8, True), (20, 38, 6, 16, False),
+                                              (24, 30, 3, 5, True), (16, 21, 2, 8, False), (12, 40, 8, 4, True)])
+def test_mixture_backward_streaming_write_back_is_bit_identical(B, N, D, K, pad_last, compact):
+    """Large launches of the fp32 mixture backward (one lane per item, > 128 MB of gradient rows) write g_nn with nontemporal stores
+    — the reference layout's tokens in address order, zero blocks included, by one loop (cnf_mixture_tok_bwd.hip) — and stage with
+    nontemporal loads.  cnf_set_mixture_bwd_big_mb(0) runs that path on small shapes: every gradient, the zero blocks of the
+    untransformed channels included, has the bits of the ordinary write-back (same kernel, lanes per item forced to one)."""
+    from categoricalnf_amd import _lib, ops
+    from categoricalnf_amd.ops import _ptr as P_
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(B * 7 + K)
+    Pn = 2 + 3 * K
+    z = g(torch.randn(B, N, D, generator=gen))
+    mask = g(_mask("channel", D))
+    m, mr, mc = ops._mask_desc(mask, D, dev)
+    act, n_act = ops._act_list(mask, m, mr, mc, D)
+    DA = D - D // 2
+    width = (DA if compact else D) * Pn
+    if compact and (B * N * width) % 4 != 0:
+        pytest.skip("compact layout needs B N DA P to be a multiple of 4")
+    nn_out = g(0.5 * torch.randn(B, N, width, generator=gen))
+    sf, msf = g(0.2 * torch.randn(D, generator=gen)), g(0.2 * torch.randn(D, K, generator=gen))
+    ln = torch.randint(1, N + 1, (B,), generator=gen); ln[0] = N
+    pad = g(O.length_mask(ln, N)) if pad_last else None
+    gz, gl = g(torch.randn(B, N, D, generator=gen)), g(torch.randn(B, generator=gen))
+    ws = torch.empty(int(lib.cnf_bwd_workspace_floats(D + D * K)), device=dev)
+    fn = lib.cnf_mixture_coupling_compact_bwd_f32 if compact else lib.cnf_mixture_coupling_bwd_f32
+
+    def run():
+        g_z = torch.full_like(z, float("nan"))
+        g_nn = torch.full_like(nn_out, float("nan"))
+        g_sf, g_msf = torch.empty_like(sf), torch.empty_like(msf)
+        rc = fn(P_(z), P_(nn_out), P_(sf), P_(msf), P_(m), mr, mc, act, n_act, P_(pad) if pad is not None else None, 1, 1, P_(gz), P_(gl),
+                P_(g_z), P_(g_nn), P_(g_sf), P_(g_msf), P_(ws), B, N, D, K, -1.0, 1.0, 1, ops._stream(dev))
+        if compact and rc == _lib.CNF_ERR_UNSUPPORTED:
+            pytest.skip("the compact-layout backward declines this shape (its stage does not fit with one lane per item)")
+        assert rc == 0, lib.cnf_last_error()
+        torch.cuda.synchronize()
+        return g_z, g_nn, g_sf, g_msf
+    try:
+        lib.cnf_set_mixture_bwd_waves(2)          # one lane per item, the rolled kernel
+        plain = run()
+        lib.cnf_set_mixture_bwd_big_mb(0)
+        streamed = run()
+    finally:
+        lib.cnf_set_mixture_bwd_big_mb(-1)
+        lib.cnf_set_mixture_bwd_waves(-1)
+    assert not torch.isnan(plain[1]).any()
+    for name, x, y in zip(("g_z", "g_nn", "g_sf", "g_msf"), streamed, plain):
+        assert torch.equal(x, y), name
+
+
 @pytest.mark.parametrize("D", [1, 2, 3, 4, 6, 8])
 def test_lu_weight_assembly_hands_out_the_inverse_the_fused_backward_needs(D):
     """cnf_invconv_lu_weight_inv: W and sum log_s of cnf_invconv_lu_weight bit for bit, and W^-1 = the bits of the inverse launch

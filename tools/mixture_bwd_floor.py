@@ -10,7 +10,10 @@ dev = torch.device("cuda:0")
 lib = _lib.load()
 P_ = ops._ptr
 modes = [int(m) for m in sys.argv[1:]] or [-1, 2, 3, 4, 0]
-for name, B, N, D, K in [("cfg1", 16384, 16, 4, 8), ("S*", 16384, 64, 6, 8)]:
+shapes = [("cfg1", 16384, 16, 4, 8), ("S*", 16384, 64, 6, 8)]
+if os.environ.get("SHAPES"):           # SHAPES="name:B:N:D:K,..."
+    shapes = [(f[0],) + tuple(int(v) for v in f[1:]) for f in (t.split(":") for t in os.environ["SHAPES"].split(","))]
+for name, B, N, D, K in shapes:
     g = torch.Generator(device=dev).manual_seed(1)
     R = 2
     DA, P = D - D // 2, 2 + 3 * K
