@@ -64,6 +64,14 @@ namespace cnf {
 #ifndef CNF_X64_INV_WAVES
 #define CNF_X64_INV_WAVES 1
 #endif
+// stores of z' (A/B build -DCNF_MIXFWD_NT_STORES: nontemporal)
+__device__ __forceinline__ void zstore(float* p, float v) {
+#ifdef CNF_MIXFWD_NT_STORES
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
 constexpr int kTokPre = 8;      // DMA instructions per pass whose source offsets the fp64 kernels keep (8 KiB stages)
 constexpr int tok_min_waves(int kt, bool reverse, int g, bool pr, bool x64 = false, bool nll = false) {
     if (x64) return reverse ? CNF_X64_INV_WAVES : CNF_X64_FWD_WAVES;
@@ -648,7 +656,7 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
 #endif
         if (owner) {
             if (ED > 0) ep[tli * ED + d] = of;
-            else zo_tile[(size_t)tokl * a.D + d] = of;
+            else zstore(&zo_tile[(size_t)tokl * a.D + d], of);
             bad |= isnan(of);
         }
         double cd = use64 ? contrib64 : (double)contrib;
@@ -678,7 +686,7 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
                 const float pv2 = pad_tile ? padload(tl2) : 1.f;
                 const float o = a.pad_output ? zv * pv2 : zv;
                 if (ED > 0) ep[tk * ED + c] = o;
-                else zo_tile[(size_t)tl2 * a.D + c] = o;
+                else zstore(&zo_tile[(size_t)tl2 * a.D + c], o);
                 if (NLL) {
                     const double lp2 = (double)(-prior_logp(o, prior) * (pad_tile ? pv2 : 1.f));
                     if (gm.split) {

@@ -759,6 +759,62 @@ def test_mixture_backward_streaming_write_back_is_bit_identical(B, N, D, K, pad_
         assert torch.equal(x, y), name
 
 
+@pytest.mark.parametrize("compact,K", [(True, 16), (False, 16), (True, 8), (False, 8)])
+def test_mixture_backward_large_launch_streams_by_default(compact, K):
+    """At a size the streaming write-back takes by itself (B = 16384, N = 64, D = 4: 2.1 M transformed elements, 200-840 MB of gradient
+    rows; K = 16 takes the unrolled kernel's streaming build, K = 8 the rolled one's) the default launch gives the gradients of the
+    ordinary kernel (rolled, one / two lanes per item at K = 8 / 16, streaming switched off) — g_z and g_nn to fp32 rounding of the same formulas, the two
+    parameter gradients to the rounding of their summation order."""
+    from categoricalnf_amd import _lib, ops
+    from categoricalnf_amd.ops import _ptr as P_
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    B, N, D = 16384, 64, 4
+    gen = torch.Generator(device=dev).manual_seed(K)
+    Pn = 2 + 3 * K
+    DA = D - D // 2
+    z = torch.randn(B, N, D, generator=gen, device=dev)
+    mask = g(_mask("channel", D))
+    m, mr, mc = ops._mask_desc(mask, D, dev)
+    act, n_act = ops._act_list(mask, m, mr, mc, D)
+    nn_out = 0.5 * torch.randn(B, N, (DA if compact else D) * Pn, generator=gen, device=dev)
+    sf, msf = 0.2 * torch.randn(D, generator=gen, device=dev), 0.2 * torch.randn(D, K, generator=gen, device=dev)
+    gz, gl = torch.randn(B, N, D, generator=gen, device=dev), torch.randn(B, generator=gen, device=dev)
+    ws = torch.empty(int(lib.cnf_bwd_workspace_floats(D + D * K)), device=dev)
+    fn = lib.cnf_mixture_coupling_compact_bwd_f32 if compact else lib.cnf_mixture_coupling_bwd_f32
+
+    def run():
+        g_z = torch.full_like(z, float("nan"))
+        g_nn = torch.full_like(nn_out, float("nan"))
+        g_sf, g_msf = torch.empty_like(sf), torch.empty_like(msf)
+        rc = fn(P_(z), P_(nn_out), P_(sf), P_(msf), P_(m), mr, mc, act, n_act, None, 1, 1, P_(gz), P_(gl),
+                P_(g_z), P_(g_nn), P_(g_sf), P_(g_msf), P_(ws), B, N, D, K, -1.0, 1.0, 1, ops._stream(dev))
+        assert rc == 0, lib.cnf_last_error()
+        torch.cuda.synchronize()
+        return g_z, g_nn, g_sf, g_msf
+    streamed = run()
+    try:
+        lib.cnf_set_mixture_bwd_waves(2 if K == 8 else 3)      # (K = 16: one lane per item does not fit LDS with the rolled kernel's sums)
+        lib.cnf_set_mixture_bwd_big_mb(1 << 30)
+        plain = run()
+    finally:
+        lib.cnf_set_mixture_bwd_big_mb(-1)
+        lib.cnf_set_mixture_bwd_waves(-1)
+    assert not torch.isnan(streamed[1]).any() and not torch.isnan(streamed[0]).any()
+    if not compact:
+        # the untransformed channels' blocks: exact zeros, written by the address-ordered loop
+        blocks = streamed[1].view(B, N, D, Pn)
+        assert int(torch.count_nonzero(blocks[:, :, : D // 2])) == 0
+    if K == 8:
+        assert torch.equal(streamed[0], plain[0]) and torch.equal(streamed[1], plain[1])         # the same kernel, another write-back
+    else:
+        for name, x, y in zip(("g_z", "g_nn"), streamed[:2], plain[:2]):
+            err = (x - y).abs().max().item()
+            assert err <= 2e-5 * max(1.0, y.abs().max().item()), (name, err)
+    for name, x, y in zip(("g_sf", "g_msf"), streamed[2:], plain[2:]):
+        grad_close(x, y, name, rel=2e-4)
+
+
 @pytest.mark.parametrize("D", [1, 2, 3, 4, 6, 8])
 def test_lu_weight_assembly_hands_out_the_inverse_the_fused_backward_needs(D):
     """cnf_invconv_lu_weight_inv: W and sum log_s of cnf_invconv_lu_weight bit for bit, and W^-1 = the bits of the inverse launch

@@ -20,11 +20,12 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void glb_void_t;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
 
-constexpr int kTok = 312, kTPP = 21, kD = 6, kDA = 3, kN = 64, kRows = 4;
+constexpr int kTok = 312, kTPP = 21, kD = 6, kDA = 3, kN = 64;
+static int g_grid = 1024, g_rows = 4, g_extra_lds = 2048;      // argv: grid, rows per unit, extra LDS bytes per workgroup (occupancy)
 
 template <int FLAGS>
 __global__ __launch_bounds__(256) void stream(const char* nn, char* gnn, const float* z, const float* gzo, const float* gl, float* gz,
-                                              long units, float* sink) {
+                                              long units, float* sink, int kRows) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     char* stage = smem + (size_t)wave * 7 * 1024;
@@ -46,7 +47,8 @@ __global__ __launch_bounds__(256) void stream(const char* nn, char* gnn, const f
                 ct = gzo[(tok0 + tp + tk) * kD + c];
             }
             // ---- DMA of the pass
-            const char* src = (FLAGS & 1) ? nn + (tok0 + tp) * kTok : nn + (unit * 13 + tp / kTPP) * 7168;
+            const int ppu = (ntok + kTPP - 1) / kTPP;
+            const char* src = (FLAGS & 1) ? nn + (tok0 + tp) * kTok : nn + (unit * ppu + tp / kTPP) * 7168;
             const int bytes = (FLAGS & 1) ? npt * kTok : 7168;
             const int off0 = __builtin_amdgcn_readfirstlane((int)(reinterpret_cast<uintptr_t>(src) & 15));
             const char* abase = src - off0;
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(256) void stream(const char* nn, char* gnn, const f
             if ((FLAGS & 4) && valid) gz[tok * kD + d] = g + x * 1e-30f;
             // ---- write-back on the span's 16-byte grid
             if (!(FLAGS & 32)) {
-                char* gdst = (FLAGS & 1) ? gnn + (tok0 + tp) * kTok : gnn + (unit * 13 + tp / kTPP) * 7168;
+                char* gdst = (FLAGS & 1) ? gnn + (tok0 + tp) * kTok : gnn + (unit * ppu + tp / kTPP) * 7168;
                 const int head = (16 - off0) & 15;
                 const int hb = min(head, bytes);
                 if (lane * 4 < hb) *reinterpret_cast<float*>(gdst + lane * 4) = *reinterpret_cast<const float*>(stage + off0 + lane * 4);
@@ -91,14 +93,14 @@ template <int FLAGS>
 static void run(const Bufs& b, long units, const char* what) {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    const size_t lds = 4 * 7 * 1024 + 2048;
-    for (int r = 0; r < 2; ++r) hipLaunchKernelGGL((stream<FLAGS>), dim3(1024), dim3(256), lds, 0, b.nn[r], b.gnn[r], b.z[r], b.gzo[r], b.gl, b.gz, units, b.sink);
+    const size_t lds = 4 * 7 * 1024 + g_extra_lds;
+    for (int r = 0; r < 2; ++r) hipLaunchKernelGGL((stream<FLAGS>), dim3(g_grid), dim3(256), lds, 0, b.nn[r], b.gnn[r], b.z[r], b.gzo[r], b.gl, b.gz, units, b.sink, g_rows);
     CK(hipDeviceSynchronize());
     const int reps = 8;
     float best = 1e9f, sum = 0.f;
     for (int t = 0; t < 5; ++t) {
         CK(hipEventRecord(e0));
-        for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((stream<FLAGS>), dim3(1024), dim3(256), lds, 0, b.nn[r & 1], b.gnn[r & 1], b.z[r & 1], b.gzo[r & 1], b.gl, b.gz, units, b.sink);
+        for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((stream<FLAGS>), dim3(g_grid), dim3(256), lds, 0, b.nn[r & 1], b.gnn[r & 1], b.z[r & 1], b.gzo[r & 1], b.gl, b.gz, units, b.sink, g_rows);
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));
         float ms;
@@ -109,9 +111,14 @@ static void run(const Bufs& b, long units, const char* what) {
     printf("flags %2d  %-72s %7.1f us (best %7.1f)\n", FLAGS, what, sum / 5 * 1e3, best * 1e3);
 }
 
-int main() {
+int main(int argc, char** argv) {
+    if (argc > 1) g_grid = atoi(argv[1]);
+    if (argc > 2) g_rows = atoi(argv[2]);
+    if (argc > 3) g_extra_lds = atoi(argv[3]);
+    const int kRows = g_rows;
     const long B = 16384, tokens = B * kN, units = B / kRows;
-    const size_t nnb = (size_t)units * 13 * 7168 + 65536;            // >= tokens * 312
+    const size_t nnb = (size_t)units * ((kRows * kN + kTPP - 1) / kTPP) * 7168 + 65536;            // >= tokens * 312
+    printf("grid %d, %d rows per unit (%ld units), LDS %d B per workgroup\n", g_grid, kRows, units, 4 * 7 * 1024 + g_extra_lds);
     Bufs b;
     for (int r = 0; r < 2; ++r) {
         CK(hipMalloc(&b.nn[r], nnb)); CK(hipMemset(b.nn[r], 0, nnb));
@@ -121,6 +128,12 @@ int main() {
     }
     CK(hipMalloc(&b.gz, tokens * kD * 4)); CK(hipMalloc(&b.gl, B * 4)); CK(hipMemset(b.gl, 0, B * 4));
     CK(hipMalloc(&b.sink, 64));
+    if (argc > 1) {
+        run<17>(b, units, "copy, rows' grid, nontemporal stores");
+        run<31>(b, units, "  the kernel's movement, nontemporal write-back");
+        run<47>(b, units, "  the kernel's movement without the write-back");
+        return 0;
+    }
     for (int rep = 0; rep < 2; ++rep) {
         run<32>(b, units, "read side alone, 7 KiB aligned passes");
         run<33>(b, units, "read side alone, 6552-byte passes on the rows' grid");
