@@ -369,9 +369,15 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
                 f_out = sgn * (side - target);                      // increasing in x either way
                 dens_out = dn * kLn2F;
             };
+#ifdef CNF_MIX32_COUNT_ITERS
+            int n_eval32 = 0;               // diagnostic build (tools/mix32_iters.py): evaluations of the fp32 Newton loop
+#endif
             for (int iter = 0; iter < 64; ++iter) {
                 float f;
                 eval(xb, f, dens);
+#ifdef CNF_MIX32_COUNT_ITERS
+                ++n_eval32;
+#endif
                 float nx;
                 if (f > 0.f) {
                     nx = 0.5f * (xb + lb);
@@ -498,6 +504,9 @@ void mixture_tok_kernel(MixArgs a, TokGeom gm) {
             } else {
             const float lpdf = (__builtin_amdgcn_logf(dens) - __builtin_amdgcn_logf(se)) * kLn2F;
             of = xb;
+#ifdef CNF_MIX32_COUNT_ITERS
+            of = (float)n_eval32;
+#endif
             if (a.pad_output) of = of * pv;
             contrib = log_s + mixt_ldj + lpdf;
             }
