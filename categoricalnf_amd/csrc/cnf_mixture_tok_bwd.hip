@@ -28,9 +28,6 @@ constexpr int kTokBwdGrid = 1024;       // rows of the partials buffer (cnf_bwd_
 #ifndef CNF_MIXBWD_MERGED
 #define CNF_MIXBWD_MERGED 1
 #endif
-#ifndef CNF_MIXBWD_DMA_NT_SPANS
-#define CNF_MIXBWD_DMA_NT_SPANS 1
-#endif
 #ifndef CNF_MIXBWD_NT_MB
 #define CNF_MIXBWD_NT_MB 128
 #endif
@@ -535,9 +532,7 @@ __device__ __forceinline__ void mixture_tok_bwd_body(const MixArgs& a, const Tok
                 }
             } else if (valid) {
                 // padded token / masked item: its parameters get no gradient
-#ifndef CNF_MIXBWD_NOZERO          // (A/B build with CNF_MIXBWD_ABLATE: the staged rows go back as they came — no LDS row writes)
                 for (int i = sub; i < P; i += G) my[i] = 0.f;
-#endif
             }
 #if defined(CNF_MIXBWD_ABLATE) && CNF_MIXBWD_ABLATE + 0 >= 3
             if (g_x == 12345.678f)           // A/B build: no stores of g_z either
@@ -836,7 +831,7 @@ static bool launch_mixture_tok_bwd_with(MixArgs& a, const float* g_zout, const f
         }
         const bool whole_passes = w.merged || w.wb_align == 32 || (w.wb_align == 16 && gm.contig && span_b == gm.tokstride);
         w.wb_nt = (big && whole_passes) ? 1 : 0;
-        gm.nt = (big && (w.wb_nt || CNF_MIXBWD_DMA_NT_SPANS)) ? 1 : 0;
+        gm.nt = big ? 1 : 0;          // (spans of the reference layout too: 280 against 288 us at S*)
     }
     w.nunits = gm.split ? (long)a.B * gm.S * kWavesPerBlock : gm.ntiles;
     w.div_ncp = make_fastdiv((uint32_t)std::max(gm.ncopy * P * 4 / (w.wb_align == 24 ? 8 : w.wb_align), 1));        // zero-fill units per token
@@ -899,15 +894,9 @@ bool launch_mixture_tok_bwd(MixArgs& a, const float* g_zout, const float* g_ldj,
         // (round 6, profiles/r06_mixture_bwd_floor.txt, with the copied-through gradients loaded ahead of the write-back: one lane per
         // item from ~400 k transformed elements on — configs[1] 60.5 against 63 us — except the reference layout at S* size with 8
         // or more mixtures, 316-320 us with two lanes against 338-345; the compact layout takes one lane there: 231-235 against 250)
-        const bool compact = a.nn_D != a.D;
         // (later in round 6, section 4 of the same file: with the reference layout's tokens written in address order by nontemporal
         // stores one lane per item wins there too — S* 280 us against 334-343 with two lanes, 316-327 before)
-#ifdef CNF_MIXBWD_OLD_RULE          // A/B build (with -DCNF_MIXBWD_NT_MB=100000000: the backward as it was before the streaming write-back)
-        int g = items >= 2000000L ? ((a.K >= 8 && !compact) ? 2 : 1) : (items >= 400000L ? 1 : 4);
-#else
-        (void)compact;
         int g = items >= 400000L ? 1 : 4;
-#endif
         if (a.K > 32) g = 4;
         while (g > 1 && g > a.K) g >>= 1;
         // the rule's G, or the next one whose stage fits LDS
