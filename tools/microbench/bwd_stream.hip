@@ -10,6 +10,7 @@
 //   flag 8   the copied-through channels: one g_zout load and one g_z store per lane (the other 12 bytes)
 //   flag 16  nontemporal write-back
 //   flag 32  no write-back at all (read side alone)
+//   flag 64 / 128  s_sleep 4 / 1 behind every store instruction of the write-back (do paced stores help the mixed stream?)
 //   hipcc --offload-arch=gfx950 -O3 -o /tmp/bwd_stream tools/microbench/bwd_stream.hip && /tmp/bwd_stream
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -70,6 +71,8 @@ __global__ __launch_bounds__(256) void stream(const char* nn, char* gnn, const f
                     const f4 v = *reinterpret_cast<const f4*>(stage + off0 + b);
                     if (FLAGS & 16) __builtin_nontemporal_store(v, reinterpret_cast<f4*>(gdst + b));
                     else *reinterpret_cast<f4*>(gdst + b) = v;
+                    if (FLAGS & 64) __builtin_amdgcn_s_sleep(4);          // paced stores: ~256 cycles between the write-back's instructions
+                    if (FLAGS & 128) __builtin_amdgcn_s_sleep(1);
                 }
                 const int tb = hb + body + lane * 4;
                 if (tb < bytes) *reinterpret_cast<float*>(gdst + tb) = *reinterpret_cast<const float*>(stage + off0 + tb);
@@ -132,6 +135,9 @@ int main(int argc, char** argv) {
         run<17>(b, units, "copy, rows' grid, nontemporal stores");
         run<31>(b, units, "  the kernel's movement, nontemporal write-back");
         run<47>(b, units, "  the kernel's movement without the write-back");
+        run<31 + 64>(b, units, "  the kernel's movement, nontemporal, stores paced (s_sleep 4)");
+        run<31 + 128>(b, units, "  the kernel's movement, nontemporal, stores paced (s_sleep 1)");
+        run<15 + 64>(b, units, "  the kernel's movement, plain stores, paced (s_sleep 4)");
         return 0;
     }
     for (int rep = 0; rep < 2; ++rep) {
