@@ -720,7 +720,10 @@ def test_mixture_backward_streaming_write_back_is_bit_identical(B, N, D, K, pad_
     gen = torch.Generator().manual_seed(B * 7 + K)
     Pn = 2 + 3 * K
     z = g(torch.randn(B, N, D, generator=gen))
-    mask = g(_mask("channel", D))
+    chess = D == 3                      # (one shape with a chess mask: every channel transformed somewhere, passes are whole tokens)
+    if chess and compact:
+        pytest.skip("the compact layout is for channel masks")
+    mask = g(_mask("chess" if chess else "channel", D))
     m, mr, mc = ops._mask_desc(mask, D, dev)
     act, n_act = ops._act_list(mask, m, mr, mc, D)
     DA = D - D // 2
