@@ -141,6 +141,63 @@ int main() {
         printf("ABI_C mixture max errors: z %.2e ldj (rel) %.2e round-trip z %.2e ldj %.2e | compact layout bit-identical: %d flags %d\n",
                wz, wl, wrt, wlr, (int)same, flags);
         ok = ok && wz < 5e-5 && wl < 1e-4 && wrt < 2e-4 && wlr < 1e-4 && same && flags == 0;
+
+        // backward (fp32 streaming kernel) on both layouts with g_zout = 1, g_ldj = 1: the compact rows are the reference layout's
+        // transformed blocks bit for bit, its untransformed blocks are exact zeros, the copied-through channels pass g_zout, and
+        // g_z of one element agrees with a central difference of (sum z' + ldj) through the forward entry point
+        {
+            const size_t nref = (size_t)B2 * N * D * P, ncmp = (size_t)B2 * N * DA * P, ne = (size_t)B2 * N * D;
+            std::vector<float> ones(ne, 1.f), gz(ne), gzc(ne), gnn(nref), gnc(ncmp), gsf(D), gmsf((size_t)D * K), gsfc(D), gmsfc((size_t)D * K);
+            float *done, *dgz, *dgzc, *dgnn, *dgnc, *dgsf, *dgmsf, *dgsfc, *dgmsfc, *dws;
+            const int64_t wsf = cnf_bwd_workspace_floats(D + D * K);
+            CHECK(hipMalloc(&done, ne * 4)); CHECK(hipMalloc(&dgz, ne * 4)); CHECK(hipMalloc(&dgzc, ne * 4)); CHECK(hipMalloc(&dgnn, nref * 4));
+            CHECK(hipMalloc(&dgnc, ncmp * 4)); CHECK(hipMalloc(&dgsf, D * 4)); CHECK(hipMalloc(&dgmsf, D * K * 4)); CHECK(hipMalloc(&dgsfc, D * 4));
+            CHECK(hipMalloc(&dgmsfc, D * K * 4)); CHECK(hipMalloc(&dws, (size_t)wsf * 4));
+            CHECK(hipMemcpy(done, ones.data(), ne * 4, hipMemcpyHostToDevice));
+            CHECK(hipMemset(dgnn, 0xff, nref * 4)); CHECK(hipMemset(dgnc, 0xff, ncmp * 4));
+            rc = cnf_mixture_coupling_bwd_f32(dz, dmnn, dmsf, dmmsf, dmask, 1, D, act, 3, nullptr, 0, 0, done, done, dgz, dgnn, dgsf, dgmsf, dws,
+                                              B2, N, D, K, -1.0, 1.0, 0, st);
+            if (rc != CNF_OK) { printf("mixture backward failed: %s\n", cnf_last_error()); return 1; }
+            rc = cnf_mixture_coupling_compact_bwd_f32(dz, dmcomp, dmsf, dmmsf, dmask, 1, D, act, 3, nullptr, 0, 0, done, done, dgzc, dgnc, dgsfc, dgmsfc, dws,
+                                                      B2, N, D, K, -1.0, 1.0, 0, st);
+            if (rc != CNF_OK) { printf("mixture backward (compact layout) failed: %s\n", cnf_last_error()); return 1; }
+            CHECK(hipStreamSynchronize(st));
+            CHECK(hipMemcpy(gz.data(), dgz, ne * 4, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(gzc.data(), dgzc, ne * 4, hipMemcpyDeviceToHost));
+            CHECK(hipMemcpy(gnn.data(), dgnn, nref * 4, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(gnc.data(), dgnc, ncmp * 4, hipMemcpyDeviceToHost));
+            CHECK(hipMemcpy(gsf.data(), dgsf, D * 4, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(gsfc.data(), dgsfc, D * 4, hipMemcpyDeviceToHost));
+            CHECK(hipMemcpy(gmsf.data(), dgmsf, D * K * 4, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(gmsfc.data(), dgmsfc, D * K * 4, hipMemcpyDeviceToHost));
+            bool bsame = true, zeros = true, pass = true;
+            for (size_t t = 0; t < (size_t)B2 * N; ++t) {
+                for (int j = 0; j < d0 * P; ++j) zeros = zeros && gnn[t * D * P + j] == 0.f;
+                for (int j = 0; j < DA * P; ++j) bsame = bsame && gnn[(t * D + d0) * P + j] == gnc[t * DA * P + j];
+                for (int d = 0; d < D; ++d) {
+                    bsame = bsame && gz[t * D + d] == gzc[t * D + d];
+                    if (d < d0) pass = pass && gz[t * D + d] == 1.f;
+                }
+            }
+            for (int d = 0; d < D; ++d) bsame = bsame && gsf[d] == gsfc[d];
+            for (int i = 0; i < D * K; ++i) bsame = bsame && gmsf[i] == gmsfc[i];
+            // central difference in z[0, 0, d0]: only row 0's outputs move
+            const size_t ie = (size_t)d0;
+            double fd[2];
+            std::vector<float> zrow((size_t)N * D), lrow(1);
+            for (int sgn = 0; sgn < 2; ++sgn) {
+                const float h = 1e-2f, zv = z[ie] + (sgn ? h : -h);
+                CHECK(hipMemcpy(dz + ie, &zv, 4, hipMemcpyHostToDevice));
+                rc = cnf_mixture_coupling(dz, dmnn, dmsf, dmmsf, dmask, 1, D, act, 3, nullptr, 0, 0, nullptr, dmzo, dml, nullptr, 1, N, D, K, 0, -1.0, 1.0, 0, dflags, st);
+                if (rc != CNF_OK) { printf("mixture forward (difference) failed: %s\n", cnf_last_error()); return 1; }
+                CHECK(hipStreamSynchronize(st));
+                CHECK(hipMemcpy(zrow.data(), dmzo, (size_t)N * D * 4, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(lrow.data(), dml, 4, hipMemcpyDeviceToHost));
+                double tot = lrow[0];
+                for (float v : zrow) tot += v;
+                fd[sgn] = tot;
+            }
+            CHECK(hipMemcpy(dz + ie, &z[ie], 4, hipMemcpyHostToDevice));
+            const double num = (fd[1] - fd[0]) / 2e-2, ana = gz[ie];
+            printf("ABI_C mixture backward: compact rows bit-identical %d, untransformed blocks zero %d, copied-through channels pass g_zout %d, "
+                   "g_z[0,0,%d] %.5f vs central difference %.5f\n", (int)bsame, (int)zeros, (int)pass, d0, ana, num);
+            ok = ok && bsame && zeros && pass && fabs(num - ana) < 2e-2 * fmax(1.0, fabs(ana));
+        }
     }
 
     // ---- (3) mixture-model encoder: C = 7 classes, forward from given logistic noise, then the arg-max decode --------------------

@@ -1384,7 +1384,9 @@ def test_backward_with_non_contiguous_upstream_gradients():
 def test_c_abi_without_torch(tmp_path):
     """The boundary is a plain C ABI: tests/abi/abi_roundtrip.cpp (hipMalloc'ed buffers, no torch, no Python) is
     compiled against include/cnf_hip.h, linked to libcnf_hip.so and run in its own process; it checks the fused
-    coupling + NLL kernel, the batch sum and the inverse against a scalar fp64 loop."""
+    coupling + NLL kernel, the batch sum and the inverse against a scalar fp64 loop, the mixture coupling (both parameter layouts,
+    forward, inverse and the fp32 backward: compact rows bit for bit, zero blocks, a central difference) and the encoder
+    forward + decode."""
     import shutil, subprocess
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
