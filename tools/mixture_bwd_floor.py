@@ -27,7 +27,10 @@ for name, B, N, D, K in shapes:
     g_sf, g_msf = torch.empty_like(sf), torch.empty_like(msf)
     g_z = torch.empty_like(zs[0])
     ws = torch.empty(int(lib.cnf_bwd_workspace_floats(D + D * K)), device=dev)
-    for layout, width, entry in (("ref", D * P, "cnf_mixture_coupling_bwd_f32"), ("compact", DA * P, "cnf_mixture_coupling_compact_bwd_f32")):
+    layouts = (("ref", D * P, "cnf_mixture_coupling_bwd_f32"), ("compact", DA * P, "cnf_mixture_coupling_compact_bwd_f32"))
+    if os.environ.get("LAYOUT"):            # LAYOUT=ref|compact: one layout only (rocprofv3 runs: the kernel name is the same for both)
+        layouts = tuple(l for l in layouts if l[0] == os.environ["LAYOUT"])
+    for layout, width, entry in layouts:
         nns = [0.5 * torch.randn(B, N, width, generator=g, device=dev) for _ in range(R)]
         g_nn = torch.empty_like(nns[0])
         fn = getattr(lib, entry)
